@@ -1,0 +1,77 @@
+"""ctypes binding of libmi355q.so (include/mi355q.h).
+
+The shared object is built in-tree by `__graft_entry__.build()` into
+ai-edge-quantizer_amd/lib/. There is deliberately NO CPU fallback: if the
+library or a GPU is missing, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+# torch first: its bundled libamdhip64.so (SONAME libamdhip64.so.7) must be the
+# HIP runtime in the process so that torch device pointers / streams and our
+# kernels share one runtime.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmi355q.so")
+
+c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mi355q.h one to one.
+PROTOTYPES = {
+    "mi355q_version": (c_i32, []),
+    "mi355q_last_error": (ctypes.c_char_p, []),
+    "mi355q_device_info": (c_i32, [c_ptr, c_ptr, c_ptr, c_i32]),
+    "mi355q_minmax_workspace_bytes": (c_size, [c_i64, c_i64, c_i64]),
+    "mi355q_minmax_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_requant_sym_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr,
+                                       c_ptr, c_ptr, c_ptr]),
+    "mi355q_requant_sym_f32_batched": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i32, c_i32, c_ptr,
+                                               c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mi355q_quantize_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i32, c_ptr, c_i32, c_i32,
+                                    c_i32, c_i32, c_ptr, c_ptr]),
+    "mi355q_dequantize_f32": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i32,
+                                      c_i32, c_ptr, c_ptr]),
+    "mi355q_pack_bits": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr]),
+    "mi355q_act_minmax_workspace_bytes": (c_size, [c_i32]),
+    "mi355q_act_minmax_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_f32, c_f32, c_i32, c_ptr, c_ptr,
+                                      c_size, c_ptr]),
+}
+
+STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "BAD_SHAPE", -3: "UNSUPPORTED", -4: "HIP_ERROR"}
+
+
+class Mi355qError(RuntimeError):
+  """A libmi355q call returned a negative status."""
+
+  def __init__(self, status: int, message: str):
+    super().__init__(f"libmi355q {STATUS_NAMES.get(status, status)}: {message}")
+    self.status = status
+    self.message = message
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+  """Loads libmi355q.so once; raises if it has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise RuntimeError(
+          f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+          " (hipcc --offload-arch=gfx950). mi355q has no CPU fallback.")
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+      fn = getattr(handle, name)  # AttributeError = header/library drift
+      fn.restype, fn.argtypes = res, args
+    _lib = handle
+  return _lib
+
+
+def check(status: int) -> None:
+  if status != 0:
+    raise Mi355qError(status, lib().mi355q_last_error().decode("utf-8", "replace"))

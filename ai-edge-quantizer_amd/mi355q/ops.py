@@ -1,0 +1,208 @@
+"""Device-level operators: one function per libmi355q entry point.
+
+Inputs and outputs are torch tensors resident in HBM (torch is only the
+allocator / stream owner). Every function enqueues on the current HIP stream and
+returns without synchronizing. Shapes follow the [outer, channels, inner] view of
+include/mi355q.h.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _ffi
+from . import runtime as rt
+
+
+def _f32(x: torch.Tensor) -> torch.Tensor:
+  if x.dtype != torch.float32 or not x.is_cuda:
+    raise TypeError(f"expected a float32 device tensor, got {x.dtype} on {x.device}")
+  return x.contiguous()
+
+
+def device_info() -> dict:
+  import ctypes
+  rt.require_gpu()
+  cu, wave = ctypes.c_int32(0), ctypes.c_int32(0)
+  name = ctypes.create_string_buffer(64)
+  _ffi.check(_ffi.lib().mi355q_device_info(ctypes.byref(cu), ctypes.byref(wave), name, 64))
+  return {"cu_count": cu.value, "wavefront": wave.value, "arch": name.value.decode()}
+
+
+def minmax(x: torch.Tensor, outer: int, channels: int, inner: int):
+  """K1. Returns (min, max) float32[channels]. ref: common_quantize.py:1311-1359."""
+  rt.require_gpu()
+  x = _f32(x)
+  if x.numel() != outer * channels * inner:
+    raise ValueError("shape view does not match numel")
+  if channels and (outer == 0 or inner == 0):
+    raise ValueError("zero-size array to reduction operation minimum which has no identity")
+  mn = rt.empty((channels,), torch.float32)
+  mx = rt.empty((channels,), torch.float32)
+  L = _ffi.lib()
+  nbytes = L.mi355q_minmax_workspace_bytes(outer, channels, inner)
+  ws = rt.empty((max(nbytes, 1),), torch.uint8)
+  _ffi.check(L.mi355q_minmax_f32(rt.ptr(x), outer, channels, inner, rt.ptr(mn), rt.ptr(mx),
+                                 rt.ptr(ws), nbytes, rt.stream_ptr()))
+  return mn, mx
+
+
+def requant_sym(x: torch.Tensor, block: int, bits: int, clip: torch.Tensor | None = None,
+                want_q: bool = True, want_packed: bool = False, want_scale_f16: bool = False):
+  """Fused K1+K2+K3(+K4) for a [rows, cols] float32 weight buffer.
+
+  Returns dict(q=int8[rows,cols]|None, packed=uint8[...]|None,
+               scale=float32[rows] or [rows, cols/block], scale_f16=float16|None).
+  ref: naive_min_max_quantize.py:34-110; transformation_utils.py:293-353.
+  """
+  rt.require_gpu()
+  x = _f32(x)
+  if x.dim() != 2:
+    raise ValueError("requant_sym expects a 2-D [rows, cols] tensor")
+  rows, cols = x.shape
+  if block and cols % block != 0:
+    raise ValueError(f"Quantized dimension {cols} in tensor shape {tuple(x.shape)} is not"
+                     f" divisible by block size {block}.")
+  nscale_shape = (rows, cols // block) if block else (rows,)
+  scale = rt.empty(nscale_shape, torch.float32)
+  q = rt.empty((rows, cols), torch.int8) if want_q else None
+  packed = None
+  if want_packed:
+    per = 8 // bits
+    if (rows * cols) % per:
+      raise ValueError("packed output needs numel divisible by values-per-byte")
+    packed = rt.empty((rows * cols // per,), torch.uint8)
+  s16 = rt.empty(nscale_shape, torch.float16) if (want_scale_f16 and block) else None
+  if clip is not None:
+    clip = _f32(clip)
+    if clip.numel() != scale.numel():
+      raise ValueError("clip must have one entry per scale")
+  _ffi.check(_ffi.lib().mi355q_requant_sym_f32(
+      rt.ptr(x), rows, cols, block, bits, rt.ptr(clip), rt.ptr(q), rt.ptr(packed),
+      rt.ptr(scale), rt.ptr(s16), rt.stream_ptr()))
+  return {"q": q, "packed": packed, "scale": scale, "scale_f16": s16}
+
+
+class RequantBatch:
+  """Pre-staged pointer tables for mi355q_requant_sym_f32_batched.
+
+  Holds `count` equally shaped weight buffers and their outputs in HBM so one
+  launch requantizes all of them (used by bench.py and the model-level driver).
+  """
+
+  def __init__(self, xs, block: int, bits: int, want_q=True, want_packed=False,
+               want_scale_f16=False):
+    rt.require_gpu()
+    self.xs = [_f32(x) for x in xs]
+    self.rows, self.cols = self.xs[0].shape
+    if any(x.shape != self.xs[0].shape for x in self.xs):
+      raise ValueError("all tensors of a batch must share one shape")
+    self.block, self.bits = block, bits
+    n = len(self.xs)
+    sshape = (self.rows, self.cols // block) if block else (self.rows,)
+    per = 8 // bits
+    self.q = [rt.empty((self.rows, self.cols), torch.int8) for _ in range(n)] if want_q else None
+    self.packed = ([rt.empty((self.rows * self.cols // per,), torch.uint8) for _ in range(n)]
+                   if want_packed else None)
+    self.scale = [rt.empty(sshape, torch.float32) for _ in range(n)]
+    self.scale_f16 = ([rt.empty(sshape, torch.float16) for _ in range(n)]
+                      if (want_scale_f16 and block) else None)
+    self._tx = rt.ptr_table(self.xs)
+    self._tq = rt.ptr_table(self.q) if self.q else None
+    self._tp = rt.ptr_table(self.packed) if self.packed else None
+    self._ts = rt.ptr_table(self.scale)
+    self._t16 = rt.ptr_table(self.scale_f16) if self.scale_f16 else None
+
+  def run(self) -> None:
+    _ffi.check(_ffi.lib().mi355q_requant_sym_f32_batched(
+        rt.ptr(self._tx), len(self.xs), self.rows, self.cols, self.block, self.bits,
+        rt.ptr(self._tq), rt.ptr(self._tp), rt.ptr(self._ts), rt.ptr(self._t16),
+        rt.stream_ptr()))
+
+
+_OUT_DTYPE = {8: torch.int8, 16: torch.int16, 32: torch.int32}
+
+
+def quantize(x: torch.Tensor, outer: int, channels: int, inner: int, scale: torch.Tensor,
+             zero_point: torch.Tensor | None, bits: int, narrow: bool,
+             zp_via_f64: bool = False) -> torch.Tensor:
+  """K3 with given parameters. scale is float32 or float64 [channels]; zero_point
+  int32 [channels] or None. ref: uniform_quantize_tensor.py:273-362."""
+  rt.require_gpu()
+  x = _f32(x)
+  if x.numel() != outer * channels * inner:
+    raise ValueError("shape view does not match numel")
+  if scale.numel() != channels:
+    raise ValueError("scale must have one entry per channel")
+  if scale.dtype not in (torch.float32, torch.float64):
+    raise TypeError("scale must be float32 or float64")
+  out_bits = 8 if bits <= 8 else 16 if bits <= 16 else 32
+  q = rt.empty(tuple(x.shape), _OUT_DTYPE[out_bits])
+  if zero_point is not None:
+    zero_point = zero_point.to(torch.int32).contiguous()
+  _ffi.check(_ffi.lib().mi355q_quantize_f32(
+      rt.ptr(x), outer, channels, inner, rt.ptr(scale.contiguous()),
+      1 if scale.dtype == torch.float64 else 0, rt.ptr(zero_point), 1 if zp_via_f64 else 0,
+      bits, 1 if narrow else 0, out_bits, rt.ptr(q), rt.stream_ptr()))
+  return q
+
+
+def dequantize(q: torch.Tensor, outer: int, channels: int, inner: int, scale: torch.Tensor,
+               zero_point: torch.Tensor | None, diff_bits: int) -> torch.Tensor:
+  """(q - zp) * scale. ref: uniform_quantize_tensor.py:365-409."""
+  rt.require_gpu()
+  in_bits = {torch.int8: 8, torch.int16: 16, torch.int32: 32}[q.dtype]
+  out_f64 = in_bits == 32 or diff_bits == 32
+  out = rt.empty(tuple(q.shape), torch.float64 if out_f64 else torch.float32)
+  if zero_point is not None:
+    zero_point = zero_point.to(torch.int32).contiguous()
+  _ffi.check(_ffi.lib().mi355q_dequantize_f32(
+      rt.ptr(q.contiguous()), in_bits, outer, channels, inner, rt.ptr(_f32(scale)),
+      rt.ptr(zero_point), diff_bits, 1 if out_f64 else 0, rt.ptr(out), rt.stream_ptr()))
+  return out
+
+
+def pack_bits(q: torch.Tensor, bits: int) -> torch.Tensor:
+  """K4. int8 values -> packed bytes. ref: transformation_utils.py:293-353."""
+  rt.require_gpu()
+  if q.dtype not in (torch.int8, torch.uint8) or not q.is_cuda:
+    raise TypeError("pack_bits expects an int8/uint8 device tensor")
+  q = q.contiguous().view(-1)
+  n = q.numel()
+  n_out = n if bits not in (2, 4) else -(-n * bits // 8)
+  out = rt.empty((n_out,), torch.uint8)
+  if bits not in (2, 4):
+    out.copy_(q.view(torch.uint8))
+    return out
+  _ffi.check(_ffi.lib().mi355q_pack_bits(rt.ptr(q), n, bits, rt.ptr(out), rt.stream_ptr()))
+  return out
+
+
+def act_minmax(tensors, lo: float | None = -3e38, hi: float | None = 3e38) -> torch.Tensor:
+  """K7 over a list of float32 device tensors -> float32[count, 2] (min, max).
+
+  ref: common_quantize.py:1362-1413. lo/hi None disables the range masks.
+  """
+  rt.require_gpu()
+  ts = [_f32(t) for t in tensors]
+  if any(t.numel() == 0 for t in ts):
+    raise ValueError("zero-size array to reduction operation minimum which has no identity")
+  n = len(ts)
+  out = rt.empty((n, 2), torch.float32)
+  if n == 0:
+    return out
+  use = lo is not None and hi is not None
+  if (lo is None) != (hi is None):
+    raise ValueError("lo and hi must both be given or both be None")
+  L = _ffi.lib()
+  for start in range(0, n, 65535):
+    part = ts[start:start + 65535]
+    tab = rt.ptr_table(part)
+    numel = torch.tensor([t.numel() for t in part], dtype=torch.int64).to(rt.device())
+    nbytes = L.mi355q_act_minmax_workspace_bytes(len(part))
+    ws = rt.empty((nbytes,), torch.uint8)
+    _ffi.check(L.mi355q_act_minmax_f32(
+        rt.ptr(tab), rt.ptr(numel), len(part), np.float32(lo if use else 0.0),
+        np.float32(hi if use else 0.0), 1 if use else 0, rt.ptr(out[start:]), rt.ptr(ws), nbytes,
+        rt.stream_ptr()))
+  return out

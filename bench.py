@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: weight-bytes quantized / second and
+% of the HBM roofline for per-channel int8 symmetric requantization of
+4096x4096 FP32 weight buffers (BASELINE config 2).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one pass of the hot path over one batch: ONE launch of
+mi355q_requant_sym_f32_batched over POOL distinct, HBM-resident 4096x4096 FP32
+buffers (POOL x 64 MiB = 1 GiB > the 256 MiB Infinity Cache, so no step can be
+served from cache). Multi-GPU shards whole tensor-buffers: every rank owns its
+own pool (weak scaling, no collective on the data path).
+
+One JSON line is printed by rank 0 (contract in the task statement) with
+`roofline` (dominant kernel, HIP-event timed) and `cpu_baseline` (the NumPy
+oracle timed on the host, baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ai-edge-quantizer_amd"))
+sys.path.insert(0, ROOT)
+
+ROWS = COLS = 4096
+POOL = 16
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+# Algorithmic bytes per 4096x4096 buffer: one FP32 read, int8 write,
+# f32 scale write, int8 zero-point write (zero points are implicit here but the
+# byte count follows the survey's definition).
+ALG_BYTES = ROWS * COLS * 4 + ROWS * COLS + ROWS * 4 + ROWS
+
+
+def parse():
+  p = argparse.ArgumentParser()
+  p.add_argument("--gpus", type=int, default=1)
+  p.add_argument("--steps", type=int, default=200)
+  p.add_argument("--warmup", type=int, default=20)
+  p.add_argument("--cpu-seconds", type=float, default=10.0,
+                 help="target CPU time for the cpu_baseline sample (0 disables)")
+  p.add_argument("--extras", type=int, default=1, help="also time configs 3 / int4 (untimed region)")
+  return p.parse_args()
+
+
+def cpu_baseline(seconds: float):
+  """Oracle (NumPy restatement, kind='port') on the host: same workload, bounded sample."""
+  if seconds <= 0:
+    return None
+  import numpy as np
+  from oracle import aeq_oracle as O
+  w = np.random.default_rng(1234).standard_normal((ROWS, COLS), dtype=np.float32)
+  O.min_max_quant_params(w[:256], 8, True, "CHANNELWISE")  # warm caches / imports
+  reps, t0 = 0, time.perf_counter()
+  while True:
+    O.min_max_quant_params(w, 8, True, "CHANNELWISE")
+    reps += 1
+    dt = time.perf_counter() - t0
+    if dt >= seconds or reps >= 200:
+      break
+  return {"value": round(reps * ROWS * COLS * 4 / dt / 1e9, 4), "unit": "GB/s", "cores": 1,
+          "kind": "port",
+          "sample": f"{reps} x get_tensor_quant_params(4096x4096 f32, int8 sym CHANNELWISE) via"
+                    f" oracle/aeq_oracle.py (NumPy {np.__version__}, single thread,"
+                    f" host has {os.cpu_count()} cpus) in {dt:.2f}s"}
+
+
+def event_time_ms(fn, iters: int) -> float:
+  """Average duration of fn() measured with HIP events on the launch stream."""
+  import torch
+  start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  start.record()
+  for _ in range(iters):
+    fn()
+  end.record()
+  end.synchronize()
+  return start.elapsed_time(end) / iters
+
+
+def main():
+  args = parse()
+  import torch
+  import torch.distributed as dist
+
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local = int(os.environ.get("LOCAL_RANK", "0"))
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a GPU (no CPU fallback on the product path)")
+  torch.cuda.set_device(local)
+  if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+  import __graft_entry__ as g
+  g.build()
+  from mi355q import ops
+
+  gen = torch.Generator(device="cuda")
+  gen.manual_seed(1234 + rank)
+  xs = [torch.randn((ROWS, COLS), generator=gen, device="cuda", dtype=torch.float32)
+        for _ in range(POOL)]
+  batch = ops.RequantBatch(xs, block=0, bits=8, want_q=True)
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    batch.run()
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    batch.run()
+  barrier()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  # --- per-launch duration of the dominant kernel, HIP events on the launch stream
+  kern_ms = event_time_ms(batch.run, max(20, min(args.steps, 200)))
+  achieved = POOL * ALG_BYTES / (kern_ms * 1e-3) / 1e9
+
+  extras = {}
+  if args.extras and rank == 0:
+    # one 4096x4096 buffer per launch, rotating over the pool (launch-gap inclusive)
+    outs = [ops.requant_sym(x, 0, 8) for x in xs[:2]]  # warm
+    del outs
+    single = [ops.RequantBatch([x], 0, 8) for x in xs]
+    state = {"i": 0}
+
+    def one():
+      single[state["i"] % POOL].run()
+      state["i"] += 1
+    for _ in range(POOL):
+      one()
+    ms = event_time_ms(one, 320)
+    extras["single_buffer_launch"] = {"ms": round(ms, 5),
+                                      "weight_GBps": round(ROWS * COLS * 4 / ms / 1e6, 1),
+                                      "hbm_frac": round(ALG_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del single
+    # config 3 shape: blockwise-128 int4 with fused packing, 4096x11008, pool of 6 (1 GiB)
+    r3, c3 = 4096, 11008
+    x3 = [torch.randn((r3, c3), generator=gen, device="cuda", dtype=torch.float32) * 0.02
+          for _ in range(6)]
+    b3 = ops.RequantBatch(x3, block=128, bits=4, want_q=False, want_packed=True, want_scale_f16=True)
+    for _ in range(5):
+      b3.run()
+    ms3 = event_time_ms(b3.run, 50)
+    alg3 = r3 * c3 * 4 + r3 * c3 // 2 + (r3 * c3 // 128) * 2
+    extras["c3_blockwise128_int4_packed"] = {
+        "ms_per_layer": round(ms3 / 6, 5),
+        "weight_GBps": round(6 * r3 * c3 * 4 / ms3 / 1e6, 1),
+        "hbm_frac": round(6 * alg3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "alg_bytes_per_layer": alg3}
+    del b3, x3
+    # int4 channelwise with fused packing on the C2 shape
+    b4 = ops.RequantBatch(xs, block=0, bits=4, want_q=False, want_packed=True)
+    for _ in range(5):
+      b4.run()
+    ms4 = event_time_ms(b4.run, 50)
+    extras["c2_int4_packed"] = {"ms": round(ms4 / POOL, 5),
+                                "weight_GBps": round(POOL * ROWS * COLS * 4 / ms4 / 1e6, 1)}
+    del b4
+
+  if rank == 0:
+    total_bytes = world * args.steps * POOL * ROWS * COLS * 4
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc):
+      try:
+        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+      except Exception:  # noqa: BLE001
+        traffic = None
+    line = {
+        "metric": "weight-bytes quantized/sec (GB/s), 4096x4096 per-channel int8",
+        "value": round(total_bytes / elapsed / 1e9, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "per-channel int8 symmetric requant of 4096x4096 FP32 weight"
+                               " buffers (BASELINE config 2)",
+                   "buffers_per_step": POOL, "bytes_in_per_step": POOL * ROWS * COLS * 4,
+                   "sharding": f"tensor-buffers x{world} (no collective)"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "kernel": "requant_rows_kernel<8,256,4,batched>",
+                     "alg_bytes_per_launch": POOL * ALG_BYTES,
+                     "launch_ms": round(kern_ms, 5)},
+        "cpu_baseline": cpu_baseline(args.cpu_seconds),
+        "extras": extras,
+    }
+    print(json.dumps(line), flush=True)
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,174 @@
+/*
+ * mi355q.h -- C ABI of libmi355q.so: MI355X (gfx950) kernels for the AI Edge
+ * Quantizer calibration + requantization hot path.
+ *
+ * This is the drop-in boundary. The reference has no native
+ * code; each entry point below replaces a NumPy/SciPy routine of the reference
+ * (cited as `ref:` relative to /root/reference/ai_edge_quantizer/). The Python
+ * mirror of the reference's plugin interface (ai-edge-quantizer_amd/mi355q) binds
+ * these symbols with ctypes; INTEGRATION.md shows the stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host;
+ *   - the caller owns every buffer; the library never allocates, frees or retains
+ *     caller memory and keeps no state besides a thread-local error string;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls
+ *     only enqueue work, they never synchronize;
+ *   - functions return 0 on success or a negative mi355q_status; a message is
+ *     available from mi355q_last_error();
+ *   - weights are row-major FP32, `rows x cols` with `cols` contiguous (LiteRT
+ *     FULLY_CONNECTED / EMBEDDING_LOOKUP layout [out, in]);
+ *   - integer outputs are bit-exact with the reference (IEEE division, round half
+ *     to even, NaN -> 0); see DESIGN.md for the parity contract.
+ */
+#ifndef MI355Q_H_
+#define MI355Q_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355Q_VERSION 100 /* 0.1.0 */
+
+typedef enum mi355q_status {
+  MI355Q_OK = 0,
+  MI355Q_BAD_ARG = -1,     /* null pointer, negative size, bad enum value */
+  MI355Q_BAD_SHAPE = -2,   /* e.g. cols not divisible by block size */
+  MI355Q_UNSUPPORTED = -3, /* valid request this build has no kernel for */
+  MI355Q_HIP_ERROR = -4    /* launch / runtime failure; see mi355q_last_error() */
+} mi355q_status;
+
+int32_t mi355q_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* mi355q_last_error(void);
+/* Device facts the host side uses for launch geometry and bench reporting. */
+int32_t mi355q_device_info(int32_t* cu_count_host, int32_t* wavefront_size_host,
+                           char* arch_name_host, int32_t arch_name_len);
+
+/* ------------------------------------------------------------------------
+ * K1 -- weight min / max.
+ * ref: algorithms/uniform_quantize/common_quantize.py:1311-1359 (init_tensor_min_max)
+ *
+ * x is viewed as [outer, channels, inner] (row-major); min/max are reduced over
+ * `outer` and `inner` for every channel:
+ *   TENSORWISE            outer=1, channels=1,            inner=numel
+ *   CHANNELWISE dim 0     outer=1, channels=shape[0],     inner=numel/shape[0]
+ *   CHANNELWISE last dim  outer=numel/shape[-1], channels=shape[-1], inner=1
+ *   BLOCKWISE_b (dim 1)   outer=1, channels=rows*cols/b,  inner=b
+ * NaN propagates (np.min / np.max semantics).
+ * workspace: mi355q_minmax_workspace_bytes(...) bytes of scratch (may be NULL
+ * when that returns 0).
+ * ------------------------------------------------------------------------ */
+size_t mi355q_minmax_workspace_bytes(int64_t outer, int64_t channels, int64_t inner);
+int32_t mi355q_minmax_f32(const float* x, int64_t outer, int64_t channels, int64_t inner,
+                          float* min_out, float* max_out, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K1+K2+K3(+K4) fused -- symmetric min/max requantization of a weight buffer.
+ * ref: naive_min_max_quantize.py:34-110 (get_tensor_quant_params) =
+ *      common_quantize.py:1311-1359 (min/max)
+ *    + uniform_quantize_tensor.py:492-586 (scale; zero point is 0)
+ *    + uniform_quantize_tensor.py:273-362 (divide, rint, clip, cast)
+ *    + transformations/transformation_utils.py:293-353 (pack_data, optional)
+ *
+ *   block == 0 : CHANNELWISE on dim 0 -- one scale per row: scale[rows]
+ *   block  > 0 : BLOCKWISE along cols -- scale[rows, cols/block], rounded
+ *                f32 -> bf16 (RNE) -> f16 -> f32 as the reference does; block must
+ *                be a multiple of 4 and divide cols
+ *   bits       : 8, 4 or 2 (signed; narrow range [-127,127] only for 8 bits)
+ *   clip       : NULL, or per-scale absolute clipping constants (OCTAV) applied as
+ *                bound = clip(max|x|, -c, c) (+ the f16 range cap when blockwise)
+ *   q_out      : NULL, or int8[rows*cols] unpacked values (UniformQuantParams.quantized_data)
+ *   packed_out : NULL, or the bytes quantize_tensor stores in the flatbuffer:
+ *                bits=8 -> same as q_out; bits=4 -> rows*cols/2 bytes, element 0 in
+ *                the low nibble; bits=2 -> rows*cols/4 bytes. Requires
+ *                rows*cols % (8/bits) == 0 (use mi355q_pack_bits for ragged tails).
+ *   scale_out  : float[n_scales] (required)
+ *   scale_f16_out : NULL, or uint16[n_scales] IEEE half bit patterns of
+ *                f16(bf16(scale)) -- what transformations/quantize_tensor.py:129-137
+ *                stores in the `<name>_scales` tensor
+ * One HBM read of x; scales, q and packed bytes are written once.
+ * ------------------------------------------------------------------------ */
+int32_t mi355q_requant_sym_f32(const float* x, int64_t rows, int64_t cols, int32_t block,
+                               int32_t bits, const float* clip, int8_t* q_out,
+                               uint8_t* packed_out, float* scale_out,
+                               uint16_t* scale_f16_out, void* stream);
+
+/* Same, over `count` equally shaped weight buffers in ONE launch (model-level
+ * batching of ParamsGenerator's per-op loop, ref: params_generator.py:110-183).
+ * The pointer tables themselves live in device memory. Any output table may be
+ * NULL (that output is skipped for all tensors); clip is not supported here. */
+int32_t mi355q_requant_sym_f32_batched(const float* const* x_ptrs, int32_t count,
+                                       int64_t rows, int64_t cols, int32_t block,
+                                       int32_t bits, int8_t* const* q_ptrs,
+                                       uint8_t* const* packed_ptrs,
+                                       float* const* scale_ptrs,
+                                       uint16_t* const* scale_f16_ptrs, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K3 -- uniform quantize with given parameters ("T1" path; also asymmetric,
+ * tensorwise and channel-last layouts).
+ * ref: uniform_quantize_tensor.py:273-362
+ *
+ * x is viewed as [outer, channels, inner]; scale/zero_point have `channels`
+ * entries (1 for TENSORWISE; rows*cols/b with inner=b for BLOCKWISE).
+ *   q = cast(clip(rint(x / scale[c] + zp[c]), lo, hi)),  lo = qmin + (narrow ? 1 : 0)
+ *   scale_is_f64 : scale points at double[channels]; the division and the zero-point
+ *                  add are then done in FP64 as NumPy does for a float64 scale
+ *   zero_point   : NULL (all zero) or int32[channels]
+ *   zp_via_f64   : the reference adds an int32/int64 zero point in FP64 and rounds
+ *                  back to FP32 (np.add(f32, int32, out=f32)); int8/int16 zero points
+ *                  are added in FP32. Pass 1 for the former.
+ *   out_bits     : container of q_out: 8 -> int8, 16 -> int16, 32 -> int32
+ * ------------------------------------------------------------------------ */
+int32_t mi355q_quantize_f32(const float* x, int64_t outer, int64_t channels, int64_t inner,
+                            const void* scale, int32_t scale_is_f64,
+                            const int32_t* zero_point, int32_t zp_via_f64, int32_t bits,
+                            int32_t narrow, int32_t out_bits, void* q_out, void* stream);
+
+/* (q - zp) * scale. ref: uniform_quantize_tensor.py:365-409.
+ * q is int8/int16/int32 per in_bits; same [outer, channels, inner] view.
+ *   diff_bits  : width NumPy subtracts in = promoted type of (q, zero_point):
+ *                8 when both are int8 (the difference wraps, as in the reference),
+ *                16 / 32 otherwise
+ *   out_is_f64 : 0 -> float32 out (int8/int16 times float32 scale);
+ *                1 -> double out (NumPy promotes int32 * float32 to float64) */
+int32_t mi355q_dequantize_f32(const void* q, int32_t in_bits, int64_t outer,
+                              int64_t channels, int64_t inner, const float* scale,
+                              const int32_t* zero_point, int32_t diff_bits,
+                              int32_t out_is_f64, void* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K4 -- bit packing of int4 / int2 values held in int8 containers.
+ * ref: transformations/transformation_utils.py:293-353 (pack_data)
+ * out has ceil(n * bits / 8) bytes; element 0 sits in the lowest bits; the ragged
+ * tail is zero padded. bits=8 copies.
+ * ------------------------------------------------------------------------ */
+int32_t mi355q_pack_bits(const int8_t* q, int64_t n, int32_t bits, uint8_t* out,
+                         void* stream);
+
+/* ------------------------------------------------------------------------
+ * K7 -- activation statistics: scalar min over x > lo, max over x < hi, with the
+ * all-masked fallback to the plain min / max.
+ * ref: common_quantize.py:1362-1413 (get_activation_min_max)
+ *
+ * Processes `count` tensors (one calibration sample each, or any mix) in one
+ * launch. `x_ptrs`, `numel` are device tables. minmax_out is float[count][2].
+ * use_range == 0 disables the masks (integer-like / no valid range).
+ * workspace: mi355q_act_minmax_workspace_bytes(count) bytes.
+ * ------------------------------------------------------------------------ */
+size_t mi355q_act_minmax_workspace_bytes(int32_t count);
+int32_t mi355q_act_minmax_f32(const float* const* x_ptrs, const int64_t* numel,
+                              int32_t count, float lo, float hi, int32_t use_range,
+                              float* minmax_out, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* MI355Q_H_ */

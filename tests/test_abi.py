@@ -1,0 +1,66 @@
+"""CPU-only checks of the C-ABI boundary: libmi355q.so builds, loads and exports
+every symbol include/mi355q.h declares; argument validation that needs no GPU."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+  sys.path.insert(0, ROOT)
+  import __graft_entry__ as g
+  g.build()
+  from mi355q import _ffi
+  return _ffi.lib()
+
+
+def _header_symbols():
+  text = open(os.path.join(ROOT, "include", "mi355q.h")).read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return sorted(set(re.findall(r"\b(mi355q_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+  syms = _header_symbols()
+  assert len(syms) >= 10
+  for s in syms:
+    assert hasattr(lib, s), f"{s} declared in include/mi355q.h but not exported"
+
+
+def test_ffi_table_matches_header(lib):
+  from mi355q import _ffi
+  assert sorted(_ffi.PROTOTYPES) == _header_symbols()
+
+
+def test_version_and_error_string(lib):
+  assert lib.mi355q_version() == 100
+  assert lib.mi355q_last_error() == b""
+
+
+def test_argument_validation_without_gpu(lib):
+  # These paths return before touching the device.
+  from mi355q import _ffi
+  st = lib.mi355q_requant_sym_f32(None, 4, 130, 128, 4, None, None, None, None, None, None)
+  assert st == -2 and b"is not divisible by block size 128" in lib.mi355q_last_error()
+  st = lib.mi355q_requant_sym_f32(None, 4, 128, 0, 8, None, None, None, None, None, None)
+  assert st == -1  # null x
+  st = lib.mi355q_requant_sym_f32(None, 0, 128, 0, 8, None, None, None, None, None, None)
+  assert st == 0   # empty tensor is a no-op
+  with pytest.raises(_ffi.Mi355qError, match="BAD_ARG"):
+    _ffi.check(lib.mi355q_pack_bits(None, -1, 4, None, None))
+  assert lib.mi355q_minmax_workspace_bytes(1, 1, 1 << 24) > 0
+  assert lib.mi355q_minmax_workspace_bytes(1, 4096, 4096) == 0
+  assert lib.mi355q_act_minmax_workspace_bytes(3) == 3 * 32 * 5 * 4
+
+
+def test_product_path_refuses_to_run_without_gpu(lib):
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip("GPU present")
+  from mi355q import runtime
+  with pytest.raises(RuntimeError, match="no CPU fallback"):
+    runtime.require_gpu()
