@@ -1,0 +1,346 @@
+// Order-exact reductions: OCTAV clipping search (K5) and MSE scale (a14).
+//
+//   ref: algorithms/uniform_quantize/octav.py:30-112  (_guess_clipping_with_octav)
+//   ref: algorithms/uniform_quantize/mse.py:100-109   (k * sqrt(mean(x^2)))
+//
+// Both reductions are float32 sums whose value depends on the order NumPy adds
+// in. That order is deterministic (verified against NumPy 2.2 in
+// tests/test_numpy_sum_model.py) and is reproduced here so the clipping
+// constants / scales are BIT-IDENTICAL to the reference, not merely close:
+//   * a reduction unit (row, block, or the whole tensor) is consumed in chunks
+//     of 8192 elements (the nditer buffer);
+//   * inside a chunk every maximal run of consecutive selected elements is summed
+//     with NumPy's pairwise routine (n < 8: left to right; n <= 128: eight strided
+//     accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) then the tail;
+//     larger: split at n/2 rounded down to a multiple of 8) and the run sum is
+//     added to the running total:  acc = acc + pairwise(run).
+//
+// One wave owns one unit. The unit is staged once into LDS (one HBM read for all
+// 10 Newton iterations); selections are wave ballots, runs are found with scalar
+// bit scans, and short runs are summed from registers with v_readlane.
+#include "common.h"
+
+namespace mi355q {
+namespace {
+
+constexpr int kChunk = 8192;  // NumPy nditer buffer size (elements)
+
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+template <bool SQUARE>
+__device__ __forceinline__ float tr(float v) {
+  if constexpr (SQUARE) return v * v;
+  return v;
+}
+
+// NumPy pairwise leaf, 8 <= m <= 128: lanes 0..7 are the eight accumulators.
+template <bool SQUARE>
+__device__ __forceinline__ float leaf_sum(const float* a, int m, int lane) {
+  const int full = m & ~7;
+  float r = 0.f;
+  if (lane < 8) {
+    r = tr<SQUARE>(a[lane]);
+    for (int i = 8; i < full; i += 8) r = r + tr<SQUARE>(a[i + lane]);
+  }
+  const float r0 = lane_bcast(r, 0), r1 = lane_bcast(r, 1), r2 = lane_bcast(r, 2),
+              r3 = lane_bcast(r, 3), r4 = lane_bcast(r, 4), r5 = lane_bcast(r, 5),
+              r6 = lane_bcast(r, 6), r7 = lane_bcast(r, 7);
+  float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (int i = full; i < m; ++i) res = res + tr<SQUARE>(a[i]);
+  return res;
+}
+
+// pairwise(a[0:n]) for n <= 8192; recursion depth is bounded by DEPTH.
+template <bool SQUARE, int DEPTH>
+__device__ __noinline__ float pairwise_sum(const float* a, int n, int lane) {
+  if (n < 8) {
+    float res = 0.f;
+    for (int i = 0; i < n; ++i) res = res + tr<SQUARE>(a[i]);
+    return res;
+  }
+  if (n <= 128) return leaf_sum<SQUARE>(a, n, lane);
+  if constexpr (DEPTH > 0) {
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const float left = pairwise_sum<SQUARE, DEPTH - 1>(a, n2, lane);
+    const float right = pairwise_sum<SQUARE, DEPTH - 1>(a + n2, n - n2, lane);
+    return left + right;
+  } else {
+    return leaf_sum<SQUARE>(a, n, lane);  // unreachable for n <= 8192
+  }
+}
+
+// Running masked sum in NumPy order. All members are wave-uniform.
+struct RunSum {
+  float acc = 0.f;
+  unsigned count = 0;
+  int pend_start = 0;
+  int pend_len = 0;
+
+  __device__ __forceinline__ void flush(const float* a, int lane) {
+    if (pend_len > 0) {
+      acc = acc + pairwise_sum<false, 8>(a + pend_start, pend_len, lane);
+      pend_len = 0;
+    }
+  }
+
+  // m: ballot of the selected lanes of the batch starting at element `base`;
+  // v: this lane's element (lane l <-> element base + l); a: the unit.
+  __device__ __forceinline__ void feed(unsigned long long m, int base, float v, const float* a,
+                                       int lane) {
+    if ((base % kChunk) == 0 || (m & 1ull) == 0) flush(a, lane);
+    count += static_cast<unsigned>(__builtin_popcountll(m));
+    int pos = 0;
+    while (m != 0) {
+      const int s = __builtin_ctzll(m);
+      const unsigned long long t = m >> s;
+      const int len = (~t == 0) ? 64 - s : __builtin_ctzll(~t);
+      pos = s + len;
+      if (pos == 64) {  // touches the batch end: may continue in the next batch
+        if (pend_len > 0) {  // (only when s == 0)
+          pend_len += len;
+        } else {
+          pend_start = base + s;
+          pend_len = len;
+        }
+        return;
+      }
+      if (pend_len > 0) {  // run that started in an earlier batch ends here
+        pend_len += len;
+        flush(a, lane);
+      } else if (len < 8) {  // the common case: sum straight from registers
+        float rs = 0.f;
+        for (int i = 0; i < len; ++i) rs = rs + lane_bcast(v, s + i);
+        acc = acc + rs;
+      } else {
+        acc = acc + pairwise_sum<false, 8>(a + base + s, len, lane);
+      }
+      m &= ~(((1ull << len) - 1ull) << s);  // len < 64 here
+    }
+  }
+};
+
+// Copy a unit into this wave's LDS slice (or return the global pointer).
+template <bool USE_LDS>
+__device__ __forceinline__ const float* stage_unit(const float* g, int len, float* lds, int lane) {
+  if constexpr (!USE_LDS) return g;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    const int n4 = len / 4;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* l4 = reinterpret_cast<float4*>(lds);
+    for (int i = lane; i < n4; i += kWave) l4[i] = g4[i];
+    for (int i = n4 * 4 + lane; i < len; i += kWave) lds[i] = g[i];
+  } else {
+    for (int i = lane; i < len; i += kWave) lds[i] = g[i];
+  }
+  return lds;
+}
+
+struct OctavArgs {
+  const float* x;
+  long long units;
+  int len;          // elements per unit
+  int lds_stride;   // floats per wave slice (multiple of 4)
+  int max_iter;
+  int count_is_f64; // axis given: s * N is evaluated in float64 (N is np.int64)
+  float s;          // float32(4^-bits / divisor)
+  float* hist;      // [max_iter][units] guesses
+  int* not_close;   // [max_iter] units whose guess still moved
+};
+
+template <bool USE_LDS>
+__global__ void octav_kernel(OctavArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const long long unit = static_cast<long long>(blockIdx.x) * (blockDim.x / kWave) + wave;
+  const bool live = unit < a.units;
+  const float* u = nullptr;
+  if (live)
+    u = stage_unit<USE_LDS>(a.x + unit * a.len, a.len, smem + static_cast<size_t>(wave) * a.lds_stride, lane);
+  if constexpr (USE_LDS) __syncthreads();
+  if (!live) return;
+
+  const int len = a.len;
+  const float one_minus_s = 1.0f - a.s;
+  const float qnan = __builtin_nanf("");
+  float guess = 1.0f;
+  for (int it = 0; it < a.max_iter; ++it) {
+    RunSum pos, neg;
+    const float hi = guess, lo = -guess;
+    for (int base = 0; base < len; base += kWave) {
+      const int i = base + lane;
+      const float v = i < len ? u[i] : qnan;
+      pos.feed(__ballot(v >= hi), base, v, u, lane);
+      neg.feed(__ballot(v <= lo), base, v, u, lane);
+    }
+    pos.flush(u, lane);
+    neg.flush(u, lane);
+    // ref octav.py:76-108, with NumPy's promotions spelled out
+    const float num = pos.acc - neg.acc;
+    float den = static_cast<float>(pos.count);
+    den = static_cast<float>(static_cast<double>(den) + static_cast<double>(neg.count));
+    den = den * one_minus_s;
+    if (a.count_is_f64)
+      den = static_cast<float>(static_cast<double>(den) +
+                               static_cast<double>(a.s) * static_cast<double>(len));
+    else
+      den = den + a.s * static_cast<float>(len);
+    const float next = num / den;
+    // np.allclose(old, new): |old - new| <= atol + rtol * |new|, all float32
+    const float tol = 1e-8f + 1e-5f * fabsf(next);
+    const bool close = (fabsf(guess - next) <= tol && __builtin_isfinite(next)) || guess == next;
+    if (lane == 0) {
+      a.hist[static_cast<long long>(it) * a.units + unit] = next;
+      if (!close) atomicAdd(&a.not_close[it], 1);
+    }
+    guess = next;
+  }
+}
+
+// The reference stops at the first iteration where *every* unit is close
+// (octav.py:109); every unit ran all iterations, so just pick that iterate.
+__global__ __launch_bounds__(256) void octav_pick_kernel(const float* __restrict__ hist,
+                                                        const int* __restrict__ not_close,
+                                                        long long units, int max_iter, int early_stop,
+                                                        float* __restrict__ clip, int* iters_out) {
+  int k = max_iter - 1;
+  if (early_stop)
+    for (int it = 0; it < max_iter; ++it)
+      if (not_close[it] == 0) { k = it; break; }
+  const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < units) clip[i] = hist[static_cast<long long>(k) * units + i];
+  if (i == 0 && iters_out != nullptr) *iters_out = k + 1;
+}
+
+struct MseArgs {
+  const float* x;
+  long long units;
+  int len;
+  int lds_stride;
+  float multiplier;
+  float* scale;
+};
+
+template <bool USE_LDS>
+__global__ void mse_scale_kernel(MseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const long long unit = static_cast<long long>(blockIdx.x) * (blockDim.x / kWave) + wave;
+  const bool live = unit < a.units;
+  const float* u = nullptr;
+  if (live)
+    u = stage_unit<USE_LDS>(a.x + unit * a.len, a.len, smem + static_cast<size_t>(wave) * a.lds_stride, lane);
+  if constexpr (USE_LDS) __syncthreads();
+  if (!live) return;
+  float acc = 0.f;
+  for (int c = 0; c < a.len; c += kChunk) {
+    const int n = a.len - c < kChunk ? a.len - c : kChunk;
+    const float part = pairwise_sum<true, 8>(u + c, n, lane);
+    acc = c == 0 ? part : acc + part;
+  }
+  const float mean = acc / static_cast<float>(a.len);
+  if (lane == 0) a.scale[unit] = a.multiplier * __builtin_sqrtf(mean);
+}
+
+struct UnitPlan {
+  bool use_lds;
+  int waves;       // waves (units) per block
+  int lds_stride;  // floats
+  size_t smem;
+};
+
+UnitPlan plan_units(int len) {
+  UnitPlan p{};
+  const int stride = (len + 3) / 4 * 4;
+  const size_t per_wave = static_cast<size_t>(stride) * sizeof(float);
+  constexpr size_t kBudget = 64 * 1024;  // per block: keeps >= 2 blocks per CU
+  int waves = static_cast<int>(kBudget / (per_wave ? per_wave : 1));
+  if (waves > 4) waves = 4;
+  if (waves >= 1) {
+    p.use_lds = true;
+    p.waves = waves;
+    p.lds_stride = stride;
+    p.smem = per_wave * waves;
+  } else {
+    p.use_lds = false;
+    p.waves = 4;
+    p.lds_stride = 0;
+    p.smem = 0;
+  }
+  return p;
+}
+
+}  // namespace
+}  // namespace mi355q
+
+using namespace mi355q;
+
+extern "C" size_t mi355q_octav_workspace_bytes(int64_t units, int32_t max_iter) {
+  if (units <= 0 || max_iter <= 0) return 0;
+  return static_cast<size_t>(units) * max_iter * sizeof(float) + 64 * sizeof(int);
+}
+
+extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t unit_len,
+                                         int32_t bits, int32_t max_iter, float exponent_divisor,
+                                         int32_t early_stop, int32_t count_is_f64, float* clip_out,
+                                         int32_t* iters_out, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (units < 0 || unit_len < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (max_iter < 1 || max_iter > 64) return fail(MI355Q_BAD_ARG, "max_iter must be in [1, 64]");
+  if (bits < 1 || bits > 16) return fail(MI355Q_BAD_ARG, "bits must be in [1, 16]");
+  if (units == 0) return MI355Q_OK;
+  if (unit_len == 0) return fail(MI355Q_BAD_SHAPE, "empty reduction unit");
+  if (unit_len > 0x7FFFFFFFLL - 64) return fail(MI355Q_UNSUPPORTED, "unit_len too large");
+  if (!x || !clip_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  const size_t need = mi355q_octav_workspace_bytes(units, max_iter);
+  if (!workspace || workspace_bytes < need)
+    return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  hipStream_t st = as_stream(stream);
+  float* hist = static_cast<float*>(workspace);
+  int* not_close = reinterpret_cast<int*>(hist + units * max_iter);
+  if (hipMemsetAsync(not_close, 0, 64 * sizeof(int), st) != hipSuccess)
+    return fail(MI355Q_HIP_ERROR, "hipMemsetAsync failed");
+  // scale = np.asarray(4.0 ** (-bits) / exponent_divisor, dtype=np.float32)  (octav.py:64)
+  double p4 = 1.0;
+  for (int i = 0; i < bits; ++i) p4 *= 0.25;
+  const float s = static_cast<float>(p4 / static_cast<double>(exponent_divisor));
+  const UnitPlan p = plan_units(static_cast<int>(unit_len));
+  OctavArgs a{x, units, static_cast<int>(unit_len), p.lds_stride, max_iter, count_is_f64, s, hist, not_close};
+  const dim3 blk(p.waves * kWave);
+  const dim3 grid(static_cast<unsigned>((units + p.waves - 1) / p.waves));
+  if (p.use_lds)
+    hipLaunchKernelGGL(octav_kernel<true>, grid, blk, p.smem, st, a);
+  else
+    hipLaunchKernelGGL(octav_kernel<false>, grid, blk, 0, st, a);
+  MI355Q_CHECK_LAUNCH("octav launch");
+  hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
+                     hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
+  MI355Q_CHECK_LAUNCH("octav pick launch");
+  return MI355Q_OK;
+}
+
+extern "C" int32_t mi355q_mse_scale_f32(const float* x, int64_t units, int64_t unit_len,
+                                        float multiplier, float* scale_out, void* stream) {
+  clear_error();
+  if (units < 0 || unit_len < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (units == 0) return MI355Q_OK;
+  if (unit_len == 0) return fail(MI355Q_BAD_SHAPE, "empty reduction unit");
+  if (unit_len > 0x7FFFFFFFLL - 64) return fail(MI355Q_UNSUPPORTED, "unit_len too large");
+  if (!x || !scale_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  const UnitPlan p = plan_units(static_cast<int>(unit_len));
+  MseArgs a{x, units, static_cast<int>(unit_len), p.lds_stride, multiplier, scale_out};
+  const dim3 blk(p.waves * kWave);
+  const dim3 grid(static_cast<unsigned>((units + p.waves - 1) / p.waves));
+  hipStream_t st = as_stream(stream);
+  if (p.use_lds)
+    hipLaunchKernelGGL(mse_scale_kernel<true>, grid, blk, p.smem, st, a);
+  else
+    hipLaunchKernelGGL(mse_scale_kernel<false>, grid, blk, 0, st, a);
+  MI355Q_CHECK_LAUNCH("mse_scale launch");
+  return MI355Q_OK;
+}

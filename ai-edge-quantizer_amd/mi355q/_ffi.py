@@ -39,6 +39,11 @@ PROTOTYPES = {
     "mi355q_act_minmax_workspace_bytes": (c_size, [c_i32]),
     "mi355q_act_minmax_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_f32, c_f32, c_i32, c_ptr, c_ptr,
                                       c_size, c_ptr]),
+    "mi355q_octav_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "mi355q_octav_clip_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_f32, c_i32, c_i32,
+                                      c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_mse_scale_f32": (c_i32, [c_ptr, c_i64, c_i64, c_f32, c_ptr, c_ptr]),
+    "mi355q_hadamard_rotate_f32": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr]),
 }
 
 STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "BAD_SHAPE", -3: "UNSUPPORTED", -4: "HIP_ERROR"}

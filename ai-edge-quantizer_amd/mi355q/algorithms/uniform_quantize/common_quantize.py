@@ -1,0 +1,220 @@
+"""Statistics collection and FC / conv / embedding materializers, GPU backed.
+
+Mirror of the hot-path tail of the reference's common_quantize.py
+(ref: algorithms/uniform_quantize/common_quantize.py:1311-1495) plus the three
+materializers the registry binds for weight-bearing ops (ref :251-266, :306-396,
+:519-576). Min / max reductions run in libmi355q (K1, K7).
+"""
+from __future__ import annotations
+
+from collections.abc import MutableMapping, Sequence
+from typing import Any, Optional
+
+import numpy as np
+
+from ... import ops
+from ... import qtyping
+from ... import runtime as rt
+from ...utils import tfl_flatbuffer_utils
+from ..utils import common_utils
+from . import uniform_quantize_tensor
+
+_Op = qtyping.TFLOperationName
+_ComputePrecision = qtyping.ComputePrecision
+
+
+def check_if_quantized(tensor: Any) -> bool:
+  return tensor.quantization is not None and tensor.quantization.scale is not None
+
+
+def check_op_quantization_config(op_name, op_quant_config: qtyping.OpQuantizationConfig,
+                                 config_check_policy=None) -> None:
+  """ref :49-89 without the JSON policy table (recipe policy is out of the hot path)."""
+  w = op_quant_config.weight_tensor_config
+  if w is None:
+    raise ValueError("Weight tensor quantization is required for min/max uniform quantization.")
+  if w.dtype != qtyping.TensorDataType.INT:
+    raise ValueError(
+        "Weights need to have integer type for min/max uniform quantization. If you wish to"
+        " perform float casting quantization (e.g., fp16 weight only), please set algorithm"
+        " key as 'float_casting'.")
+  if op_quant_config.min_weight_elements < 0:
+    raise ValueError(f"min_weight_elements must be non-negative for op: {op_name} with"
+                     f" config: {op_quant_config}.")
+  common_utils.check_subchannel_config(op_name, op_quant_config)
+
+
+# ------------------------------------------------------------------ K1 ----
+def _minmax_view(tensor_data: np.ndarray, quantized_dim: Optional[int]):
+  shape = tensor_data.shape
+  if quantized_dim is None:
+    return 1, 1, int(tensor_data.size)
+  return (int(np.prod(shape[:quantized_dim], dtype=np.int64)), int(shape[quantized_dim]),
+          int(np.prod(shape[quantized_dim + 1:], dtype=np.int64)))
+
+
+def init_tensor_min_max(tensor_data: Optional[np.ndarray], op_info: qtyping.OpInfo) -> qtyping.QSV:
+  """Per-tensor / per-channel / per-block min & max of a weight (ref :1311-1359)."""
+  cfg = op_info.op_quant_config.weight_tensor_config
+  if tensor_data is None or cfg is None:
+    return {}
+  g = cfg.granularity
+  if g == qtyping.QuantGranularity.TENSORWISE:
+    view, out_shape = (1, 1, int(tensor_data.size)), (1,) * tensor_data.ndim
+  elif g == qtyping.QuantGranularity.CHANNELWISE:
+    qd = common_utils.get_weight_quantized_dim(op_info, tensor_data, g)
+    view = _minmax_view(tensor_data, qd)
+    out_shape = tuple(d if i == qd else 1 for i, d in enumerate(tensor_data.shape)) \
+        if qd is not None else (1,) * tensor_data.ndim
+  elif uniform_quantize_tensor.is_blockwise(g):
+    reshaped, red = uniform_quantize_tensor.reshape_data_for_blockwise(
+        tensor_data, op_info.op_name, g)
+    if any(d != 1 for d in reshaped.shape[red + 1:]):
+      raise NotImplementedError("blockwise min/max along a non-innermost dimension")
+    block = reshaped.shape[red]
+    view = (1, int(tensor_data.size // block), int(block))
+    out_shape = tuple(d for i, d in enumerate(reshaped.shape) if i != red)
+  else:
+    raise ValueError(f"Unsupported granularity: {g}")
+  if tensor_data.size == 0:
+    raise ValueError("zero-size array to reduction operation minimum which has no identity")
+  x = uniform_quantize_tensor._as_f32_exact(tensor_data)  # pylint: disable=protected-access
+  rt.require_gpu()
+  mn, mx = ops.minmax(rt.to_device(x), *view)
+  dt = tensor_data.dtype if np.issubdtype(tensor_data.dtype, np.floating) else np.float32
+  return {"min": rt.to_numpy(mn).reshape(out_shape).astype(dt, copy=False),
+          "max": rt.to_numpy(mx).reshape(out_shape).astype(dt, copy=False)}
+
+
+# ------------------------------------------------------------------ K7 ----
+def get_activation_min_max(tensor_content: np.ndarray,
+                           valid_float_range_min: float | None = None,
+                           valid_float_range_max: float | None = None) -> dict[str, np.ndarray]:
+  """Scalar min over x > lo / max over x < hi with the all-masked fallback (ref :1362-1413)."""
+  shape = (1,) * tensor_content.ndim
+  if tensor_content.size == 0:
+    raise ValueError("zero-size array to reduction operation minimum which has no identity")
+  if np.issubdtype(tensor_content.dtype, np.integer) or tensor_content.dtype != np.float32:
+    # integer activations (indices etc.) carry no float range; tiny host reduction
+    return {"min": np.reshape(np.min(tensor_content), shape),
+            "max": np.reshape(np.max(tensor_content), shape)}
+  rt.require_gpu()
+  flat = rt.to_device(np.ascontiguousarray(tensor_content).reshape(-1))
+  if valid_float_range_min is not None and valid_float_range_max is not None:
+    mm = ops.act_minmax([flat], valid_float_range_min, valid_float_range_max)
+  elif valid_float_range_min is None and valid_float_range_max is None:
+    mm = ops.act_minmax([flat], None, None)
+  else:  # one-sided range: widen the missing side so that its mask is always true
+    lo = -np.inf if valid_float_range_min is None else valid_float_range_min
+    hi = np.inf if valid_float_range_max is None else valid_float_range_max
+    mm = ops.act_minmax([flat], lo, hi)
+  host = rt.to_numpy(mm)
+  return {"min": np.reshape(host[0, 0], shape), "max": np.reshape(host[0, 1], shape)}
+
+
+def collect_activation_tensor_statistics(tensor_idx: int, graph_info: qtyping.GraphInfo,
+                                         tensor_content_map: MutableMapping[str, np.ndarray],
+                                         valid_float_range_min: float | None = None,
+                                         valid_float_range_max: float | None = None):
+  """(name, content, qsv{min,max,num_samples}) or None for constants (ref :1416-1456)."""
+  tensor = graph_info.subgraph_tensors[tensor_idx]
+  if tfl_flatbuffer_utils.get_tensor_data(tensor, graph_info.buffers) is not None:
+    return None
+  name = tfl_flatbuffer_utils.get_tensor_name(tensor)
+  content = tensor_content_map[name]
+  qsv = get_activation_min_max(content, valid_float_range_min, valid_float_range_max)
+  qsv["num_samples"] = np.array(content.shape[0] if content.ndim > 0 else 1)
+  return name, content, qsv
+
+
+def get_tensor_indices_requiring_calibration(tfl_op, graph_info: qtyping.GraphInfo,
+                                             inputs_to_ignore: Sequence[int] | None = None,
+                                             outputs_to_ignore: Sequence[int] | None = None):
+  """ref :1459-1495."""
+  skip_in = set(inputs_to_ignore or [])
+  skip_in.update(k for k, tid in enumerate(tfl_op.inputs)
+                 if tid != -1 and check_if_quantized(graph_info.subgraph_tensors[tid]))
+  skip_out = set(outputs_to_ignore or [])
+  return ([tid for k, tid in enumerate(tfl_op.inputs) if k not in skip_in and tid != -1]
+          + [tid for k, tid in enumerate(tfl_op.outputs) if k not in skip_out and tid != -1])
+
+
+# -------------------------------------------------------- materializers ----
+def _are_weights_too_small(op_info, graph_info, weight_index: int) -> bool:
+  tensor = graph_info.subgraph_tensors[op_info.op.inputs[weight_index]]
+  data = tfl_flatbuffer_utils.get_tensor_data(tensor, graph_info.buffers)
+  return data is not None and np.size(data) < op_info.op_quant_config.min_weight_elements
+
+
+def _is_srq(op_info: qtyping.OpInfo) -> bool:
+  c = op_info.op_quant_config
+  return c.compute_precision == _ComputePrecision.INTEGER and c.activation_tensor_config is not None
+
+
+def _materialize_bias_for_fc_conv_ops(op_info, graph_info, op_tensor_params, op_input_index=0,
+                                      op_weight_index=1, op_bias_index=2) -> None:
+  """Fused bias: int32 with scale = s_in * s_w under SRQ, untouched otherwise (ref :306-396)."""
+  _, weight_tensor, bias_tensor, _ = tfl_flatbuffer_utils.parse_fc_bmm_conv_tensors(
+      op_info.op, graph_info.subgraph_tensors, op_input_index, op_weight_index, op_bias_index)
+  if bias_tensor is None or check_if_quantized(bias_tensor):
+    return
+  # position of the bias entry in op_tensor_params (-1 inputs are skipped there)
+  pos = sum(1 for t in op_info.op.inputs[:op_bias_index] if t != -1)
+  in_pos = sum(1 for t in op_info.op.inputs[:op_input_index] if t != -1)
+  w_pos = sum(1 for t in op_info.op.inputs[:op_weight_index] if t != -1)
+  bias_params = None
+  if _is_srq(op_info):
+    bias = tfl_flatbuffer_utils.get_tensor_data(bias_tensor, graph_info.buffers)
+    in_params = op_tensor_params[in_pos].consumers[0].parameters
+    w_params = op_tensor_params[w_pos].consumers[0].parameters
+    if w_params is None and check_if_quantized(weight_tensor):
+      wq = weight_tensor.quantization
+      if op_info.op_quant_config.weight_tensor_config is None:
+        raise ValueError("weight_tensor_config cannot be None when weight tensor is quantized.")
+      w_params = qtyping.UniformQuantParams(
+          num_bits=op_info.op_quant_config.weight_tensor_config.num_bits, scale=wq.scale,
+          zero_point=wq.zeroPoint, quantized_dimension=wq.quantizedDimension)
+    try:
+      bias_params = uniform_quantize_tensor.symmetric_quantize_bias_tensor(
+          bias, in_params, w_params)
+    except ValueError as e:
+      raise ValueError(f"Failed to quantize bias tensor for op {op_info.op_name} with op id"
+                       f" {op_info.subgraph_op_index}.") from e
+  op_tensor_params[pos] = common_utils.get_tensor_transformation_params(
+      tfl_flatbuffer_utils.get_tensor_name(bias_tensor), op_info, is_inbounding_tensor=True,
+      quant_params=bias_params, is_constant=_is_srq(op_info))
+
+
+def materialize_fc_conv(get_tensor_quant_params_fn, op_info: qtyping.OpInfo,
+                        graph_info: qtyping.GraphInfo, tensor_name_to_qsv: dict[str, Any],
+                        tensor_quant_params_cache: common_utils.TensorQuantParamsCache,
+                        input_index: int = 0, weight_index: int = 1, bias_index: int = 2):
+  """FULLY_CONNECTED / CONV_2D / DEPTHWISE_CONV_2D (ref :519-576)."""
+  ignored = [bias_index]
+  w_tensor = graph_info.subgraph_tensors[op_info.op.inputs[weight_index]]
+  if check_if_quantized(w_tensor) or _are_weights_too_small(op_info, graph_info, weight_index):
+    ignored.append(weight_index)
+  params = common_utils.materialize_standard_op(
+      op_info, graph_info, tensor_name_to_qsv, get_tensor_quant_params_fn,
+      tensor_quant_params_cache=tensor_quant_params_cache, inputs_to_ignore=ignored)
+  _materialize_bias_for_fc_conv_ops(op_info, graph_info, params, input_index, weight_index,
+                                    bias_index)
+  return params
+
+
+def materialize_embedding_lookup(get_tensor_quant_params_fn, op_info, graph_info,
+                                 tensor_name_to_qsv, tensor_quant_params_cache):
+  """EMBEDDING_LOOKUP: the index input is never quantized (ref :251-266)."""
+  return common_utils.materialize_standard_op(
+      op_info, graph_info, tensor_name_to_qsv, get_tensor_quant_params_fn,
+      tensor_quant_params_cache=tensor_quant_params_cache, inputs_to_ignore=[0])
+
+
+def materialize_input(get_tensor_quant_params_fn, op_info, graph_info, tensor_name_to_qsv,
+                      tensor_quant_params_cache):
+  return common_utils.materialize_standard_op(
+      op_info, graph_info, tensor_name_to_qsv, get_tensor_quant_params_fn,
+      tensor_quant_params_cache=tensor_quant_params_cache)
+
+
+materialize_output = materialize_input

@@ -206,3 +206,51 @@ def act_minmax(tensors, lo: float | None = -3e38, hi: float | None = 3e38) -> to
         np.float32(hi if use else 0.0), 1 if use else 0, rt.ptr(out[start:]), rt.ptr(ws), nbytes,
         rt.stream_ptr()))
   return out
+
+
+def octav_clip(x: torch.Tensor, units: int, unit_len: int, bits: int, max_iter: int = 10,
+               exponent_divisor: float = 3.0, early_stop: bool = True, axis_given: bool = True):
+  """K5. Returns (clip float32[units], iterations int). ref: octav.py:30-112.
+
+  `axis_given=False` is the TENSORWISE form (axis=None in the reference).
+  """
+  rt.require_gpu()
+  x = _f32(x)
+  if x.numel() != units * unit_len:
+    raise ValueError("shape view does not match numel")
+  clip = rt.empty((units,), torch.float32)
+  iters = rt.empty((1,), torch.int32)
+  L = _ffi.lib()
+  nbytes = L.mi355q_octav_workspace_bytes(units, max_iter)
+  ws = rt.empty((max(nbytes, 1),), torch.uint8)
+  _ffi.check(L.mi355q_octav_clip_f32(
+      rt.ptr(x), units, unit_len, bits, max_iter, np.float32(exponent_divisor),
+      1 if early_stop else 0, 1 if axis_given else 0, rt.ptr(clip), rt.ptr(iters), rt.ptr(ws),
+      nbytes, rt.stream_ptr()))
+  return clip, iters
+
+
+def mse_scale(x: torch.Tensor, units: int, unit_len: int, multiplier: float) -> torch.Tensor:
+  """a14. scale[u] = multiplier * sqrt(mean(x_u**2)). ref: mse.py:100-109."""
+  rt.require_gpu()
+  x = _f32(x)
+  if x.numel() != units * unit_len:
+    raise ValueError("shape view does not match numel")
+  scale = rt.empty((units,), torch.float32)
+  _ffi.check(_ffi.lib().mi355q_mse_scale_f32(rt.ptr(x), units, unit_len, np.float32(multiplier),
+                                             rt.ptr(scale), rt.stream_ptr()))
+  return scale
+
+
+def hadamard_rotate(x: torch.Tensor, h: int) -> torch.Tensor:
+  """K6. reshape(x, (-1, h)) @ (H_h / sqrt(h)), same shape as x. ref: hadamard_rotation.py:93-134."""
+  rt.require_gpu()
+  x = _f32(x)
+  if h <= 0 or h & (h - 1):
+    raise ValueError("Hadamard matrix size must be a power of 2. ")
+  if x.numel() % h:
+    raise ValueError("tensor size is not a multiple of the Hadamard size")
+  out = torch.empty_like(x)
+  _ffi.check(_ffi.lib().mi355q_hadamard_rotate_f32(rt.ptr(x), x.numel() // h, h, rt.ptr(out),
+                                                   rt.stream_ptr()))
+  return out

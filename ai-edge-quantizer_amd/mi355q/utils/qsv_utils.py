@@ -1,0 +1,47 @@
+"""QSV (quantization statistics) merge rules -- host scalars, plus the GPTQ
+Hessian running mean. ref: utils/qsv_utils.py:25-122.
+
+These define what any multi-GPU exchange must reproduce:
+`moving_average_update` is order dependent, so ranks all-gather per-sample
+(min, max) and replay it in dataset order (mi355q.distributed).
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+
+from .. import qtyping
+
+
+def moving_average_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV,
+                          smoothing_factor: float = 0.95) -> qtyping.QSV:
+  """q <- f*q + (1-f)*new for min and max; first sample is taken as is."""
+  if not qsv:
+    return new_qsv
+  f = smoothing_factor
+  return {key: f * qsv[key] + (1.0 - f) * new_qsv[key] for key in ("min", "max")}
+
+
+def min_max_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qtyping.QSV:
+  if not qsv:
+    return new_qsv
+  return {"min": np.minimum(qsv["min"], new_qsv["min"]),
+          "max": np.maximum(qsv["max"], new_qsv["max"])}
+
+
+def _gptq_merge_hessian(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> tuple[Any, int]:
+  n0, n1 = qsv["num_samples"], new_qsv["num_samples"]
+  total = n0 + n1
+  if total == 0:
+    return new_qsv["hessian"], 0
+  return (qsv["hessian"] * n0 + new_qsv["hessian"] * n1) / total, total
+
+
+def gptq_and_moving_average_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qtyping.QSV:
+  """EMA for min/max + sample-weighted mean for the Hessian (ref :71-102)."""
+  if not qsv:
+    return new_qsv
+  out = moving_average_update(qsv, new_qsv)
+  out["hessian"], out["num_samples"] = _gptq_merge_hessian(qsv, new_qsv)
+  return out

@@ -168,6 +168,44 @@ int32_t mi355q_act_minmax_f32(const float* const* x_ptrs, const int64_t* numel,
                               float* minmax_out, void* workspace, size_t workspace_bytes,
                               void* stream);
 
+/* ------------------------------------------------------------------------
+ * K5 -- OCTAV clipping constants, NumPy-order exact.
+ * ref: algorithms/uniform_quantize/octav.py:30-112 (_guess_clipping_with_octav)
+ *
+ * x holds `units` contiguous reduction units of `unit_len` floats (rows for
+ * CHANNELWISE on dim 0, blocks for BLOCKWISE_*, the whole tensor for TENSORWISE).
+ *   c <- (sum_{x>=c} x - sum_{x<=-c} x) / (n_{|x|>=c} (1-s) + s N),  s = f32(4^-bits / divisor)
+ * starting from c = 1 for at most max_iter steps; with early_stop the result is
+ * the iterate at which np.allclose(old, new) first holds for ALL units.
+ *   count_is_f64 : 1 when the reference reduces over an axis (N is np.int64 and
+ *                  s*N is evaluated in float64), 0 for TENSORWISE (axis=None).
+ * The float32 sums are accumulated in the order NumPy uses (8192-element chunks,
+ * pairwise over runs of selected elements), so clip_out is bit-identical.
+ *   clip_out  : float[units];  iters_out: NULL or int32[1] (iterations used)
+ *   workspace : mi355q_octav_workspace_bytes(units, max_iter) bytes
+ * ------------------------------------------------------------------------ */
+size_t mi355q_octav_workspace_bytes(int64_t units, int32_t max_iter);
+int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t unit_len, int32_t bits,
+                              int32_t max_iter, float exponent_divisor, int32_t early_stop,
+                              int32_t count_is_f64, float* clip_out, int32_t* iters_out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * a14 -- MSE scale: scale[u] = multiplier * sqrt(mean(x_u^2)), NumPy-order exact.
+ * ref: algorithms/uniform_quantize/mse.py:100-109
+ * ------------------------------------------------------------------------ */
+int32_t mi355q_mse_scale_f32(const float* x, int64_t units, int64_t unit_len, float multiplier,
+                             float* scale_out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K6 -- block-diagonal Hadamard rotation: out = reshape(x, (n_vec, h)) @ (H_h / sqrt(h)),
+ * H_h the Sylvester matrix, h a power of two <= 16384. In-LDS fast Walsh-Hadamard
+ * transform; FP32; out may alias x.
+ * ref: algorithms/uniform_quantize/hadamard_rotation.py:48-134
+ * ------------------------------------------------------------------------ */
+int32_t mi355q_hadamard_rotate_f32(const float* x, int64_t n_vec, int32_t h, float* out,
+                                   void* stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -1,0 +1,236 @@
+"""GPU parity of the drop-in layer: get_tensor_quant_params of every algorithm,
+called exactly as the reference's ParamsGenerator calls it, against the fixtures
+recorded from the real reference and against the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+
+from golden_util import case_names, sha
+from oracle import aeq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def m():
+  import torch
+  assert torch.cuda.is_available()
+  import __graft_entry__ as g
+  g.build()
+  import types
+  from mi355q import qtyping
+  from mi355q.algorithms.uniform_quantize import (hadamard_rotation, mse,
+                                                 naive_min_max_quantize, octav,
+                                                 uniform_quantize_tensor)
+  return types.SimpleNamespace(qtyping=qtyping, mm=naive_min_max_quantize, octav=octav, mse=mse,
+                               had=hadamard_rotation, uqt=uniform_quantize_tensor)
+
+
+def op_info(m, op, cfg):
+  q = m.qtyping
+  return q.OpInfo(op=q.OperatorT(), op_name=q.TFLOperationName[op], subgraph_op_index=0,
+                  op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg))
+
+
+def cfg_of(m, c, **algo):
+  q = m.qtyping
+  return q.TensorQuantizationConfig(num_bits=c["num_bits"], symmetric=c["symmetric"],
+                                    granularity=q.QuantGranularity[c["granularity"]],
+                                    algorithm_params=algo)
+
+
+def check(arrays, name, p, c, exact_q=True):
+  assert p.quantized_dimension == c["quantized_dimension"]
+  assert p.block_size == c["block_size"]
+  assert p.num_bits == c["num_bits"] and p.symmetric == c["symmetric"]
+  s, z = arrays[f"{name}/scale"], arrays[f"{name}/zero_point"]
+  assert p.scale.shape == s.shape and p.scale.dtype == s.dtype
+  assert np.array_equal(p.scale, s, equal_nan=True)
+  assert p.zero_point.shape == z.shape and np.array_equal(p.zero_point, z)
+  if f"{name}/q" in arrays and exact_q:
+    q = arrays[f"{name}/q"]
+    assert p.quantized_data.dtype == q.dtype and p.quantized_data.shape == q.shape
+    assert np.array_equal(p.quantized_data, q)
+
+
+@pytest.mark.parametrize("name", case_names("min_max"))
+def test_min_max_get_tensor_quant_params(m, ref_cases, name):
+  arrays, cases = ref_cases
+  c = cases[name]
+  cfg = cfg_of(m, c)
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    p = m.mm.get_tensor_quant_params(op_info(m, c["op"], cfg), cfg, arrays[f"{name}/w"])
+  check(arrays, name, p, c)
+  assert p.zero_point.dtype == arrays[f"{name}/zero_point"].dtype
+
+
+@pytest.mark.parametrize("name", case_names("min_max_qsv"))
+def test_min_max_params_from_qsv(m, ref_cases, name):
+  arrays, cases = ref_cases
+  c = cases[name]
+  cfg = cfg_of(m, c)
+  p = m.mm.get_tensor_quant_params(op_info(m, c["op"], cfg), cfg, None,
+                                   {"min": arrays[f"{name}/min"], "max": arrays[f"{name}/max"]})
+  assert p.quantized_data is None
+  check(arrays, name, p, c)
+
+
+def test_min_max_missing_stats_errors(m):
+  q = m.qtyping
+  cfg = q.TensorQuantizationConfig(num_bits=8)
+  with pytest.raises(ValueError, match="not found in tensor_name_to_qsv"):
+    m.mm.get_tensor_quant_params(op_info(m, "FULLY_CONNECTED", cfg), cfg, None, None)
+  info = q.OpInfo(op=q.OperatorT(), op_name=q.TFLOperationName.FULLY_CONNECTED,
+                  subgraph_op_index=0, op_quant_config=q.OpQuantizationConfig())
+  with pytest.raises(ValueError, match="min and max must be provided"):
+    m.mm.get_tensor_quant_params(info, cfg, np.ones((4, 4), np.float32), None)
+  cfgb = q.TensorQuantizationConfig(num_bits=4, granularity=q.QuantGranularity.BLOCKWISE_32)
+  with pytest.raises(ValueError, match="is not divisible by block size"):
+    m.mm.get_tensor_quant_params(op_info(m, "FULLY_CONNECTED", cfgb), cfgb,
+                                 np.ones((4, 33), np.float32))
+
+
+@pytest.mark.parametrize("name", case_names("octav"))
+def test_octav_get_tensor_quant_params_bit_exact(m, ref_cases, name):
+  arrays, cases = ref_cases
+  c = cases[name]
+  cfg = cfg_of(m, c)
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    p = m.octav.get_tensor_quant_params(op_info(m, c["op"], cfg), cfg, arrays[f"{name}/w"])
+  check(arrays, name, p, c)
+
+
+@pytest.mark.parametrize("name", case_names("octav"))
+def test_octav_clipping_constants_bit_exact(m, ref_cases, name):
+  arrays, cases = ref_cases
+  c = cases[name]
+  w = arrays[f"{name}/w"]
+  gran = c["granularity"]
+  if "BLOCKWISE" in gran:
+    b = c["block_size"]
+    data, axis = w.reshape(w.shape[0], w.shape[1] // b, b), 2
+  elif gran == "CHANNELWISE":
+    data, axis = w, (1,)
+  else:
+    data, axis = w, None
+  for early, key in ((True, "clip"), (False, "clip_no_early_stop")):
+    got = m.octav._guess_clipping_with_octav(data, c["num_bits"], axis, 10, 3.0, early_stop=early)
+    ref = arrays[f"{name}/{key}"]
+    assert got.shape == ref.shape and np.array_equal(got, ref), key
+
+
+def test_octav_dense_and_degenerate_rows_bit_exact(m):
+  """Long runs (all-positive rows, constant rows, c -> 0) exercise the pairwise paths."""
+  rng = np.random.default_rng(3)
+  rows = [np.abs(rng.standard_normal(4096)).astype(np.float32) + 1.5,   # every element selected
+          np.full(4096, 0.75, np.float32), rng.standard_normal(4096).astype(np.float32) * 1e-3,
+          -np.abs(rng.standard_normal(4096)).astype(np.float32) * 3,
+          rng.standard_normal(4096).astype(np.float32)]
+  w = np.stack(rows)
+  for bits in (4, 8):
+    ref = O.octav_clip(w, bits, (1,), 10, 3.0)
+    got = m.octav._guess_clipping_with_octav(w, bits, (1,), 10, 3.0)
+    assert np.array_equal(got, ref)
+  for n in (9000, 20000):  # rows longer than NumPy's 8192-element buffer
+    w = np.abs(rng.standard_normal((3, n))).astype(np.float32)
+    assert np.array_equal(m.octav._guess_clipping_with_octav(w, 4, (1,), 10, 3.0),
+                          O.octav_clip(w, 4, (1,), 10, 3.0))
+
+
+def test_octav_anchor_digest(m, ref_digests):
+  d = ref_digests["octav_anchor"]
+  w = np.random.default_rng(d["seed"]).standard_normal(tuple(d["shape"]), dtype=np.float32)
+  q = m.qtyping
+  cfg = q.TensorQuantizationConfig(num_bits=4, granularity=q.QuantGranularity.CHANNELWISE)
+  p = m.octav.get_tensor_quant_params(op_info(m, "FULLY_CONNECTED", cfg), cfg, w)
+  assert sha(p.quantized_data) == d["q"] and sha(p.scale) == d["scale"]
+
+
+def test_octav_errors(m):
+  q = m.qtyping
+  cfg = q.TensorQuantizationConfig(num_bits=4, symmetric=False,
+                                   granularity=q.QuantGranularity.CHANNELWISE)
+  with pytest.raises(ValueError, match="Unsupported symmetry"):
+    m.octav.get_tensor_quant_params(op_info(m, "FULLY_CONNECTED", cfg), cfg,
+                                    np.ones((4, 4), np.float32))
+
+
+@pytest.mark.parametrize("name", case_names("mse"))
+def test_mse_get_tensor_quant_params_bit_exact(m, ref_cases, name):
+  arrays, cases = ref_cases
+  c = cases[name]
+  cfg = cfg_of(m, c)
+  p = m.mse.get_tensor_quant_params(op_info(m, c["op"], cfg), cfg, arrays[f"{name}/w"])
+  check(arrays, name, p, c)
+
+
+def test_mse_errors(m):
+  q = m.qtyping
+  cfg = q.TensorQuantizationConfig(num_bits=4, granularity=q.QuantGranularity.BLOCKWISE_32)
+  with pytest.raises(ValueError, match="Blockwise quantization is not supported for MSE"):
+    m.mse.get_tensor_quant_params(op_info(m, "FULLY_CONNECTED", cfg), cfg,
+                                  np.ones((4, 32), np.float32))
+
+
+@pytest.mark.parametrize("name", case_names("hadamard"))
+def test_hadamard_get_tensor_quant_params(m, ref_cases, name):
+  """Rotation is T2 (sgemm vs butterfly add order): rotated values within 2e-6 of
+  max|row|; given identical rotated values everything downstream is exact, so the
+  integers may differ by at most 1 on <= 1e-3 of the entries at these tiny sizes."""
+  arrays, cases = ref_cases
+  c = cases[name]
+  w = arrays[f"{name}/w"]
+  algo = {} if c["max_hadamard_size"] is None else {"max_hadamard_size": c["max_hadamard_size"]}
+  cfg = cfg_of(m, c, **algo)
+  rot, h, vec = m.had._rotate_with_diagonal_hadamard(w, w.ndim - 1, c["max_hadamard_size"])
+  assert h == c["hadamard_size"] and np.array_equal(vec, arrays[f"{name}/random_binary_vector"])
+  ref_rot = arrays[f"{name}/rotated"]
+  assert np.max(np.abs(rot - ref_rot)) <= 2e-6 * np.max(np.abs(ref_rot))
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    p = m.had.get_tensor_quant_params(op_info(m, c["op"], cfg), cfg, w)
+  assert p.hadamard.hadamard_size == c["hadamard_size"]
+  np.testing.assert_allclose(p.scale, arrays[f"{name}/scale"], rtol=1e-6)
+  diff = np.abs(p.quantized_data.astype(np.int32) - arrays[f"{name}/q"].astype(np.int32))
+  assert diff.max() <= 1 and (diff != 0).mean() <= 2e-3
+
+
+def test_hadamard_known_answers(m, known_answers):
+  q = m.qtyping
+  cfg = q.TensorQuantizationConfig(num_bits=8, symmetric=True,
+                                   granularity=q.QuantGranularity.CHANNELWISE)
+  for c in known_answers["hadamard_goldens"]["cases"]:
+    x = np.tile(np.array(c["input_tile"], dtype=c["input_dtype"]), c["input_reps"])
+    exp = np.tile(np.array(c["expected_tile"]), c["expected_reps"])
+    if c["reshape"]:
+      x, exp = x.reshape(c["reshape"]), exp.reshape(c["reshape"])
+    p = m.had.get_tensor_quant_params(op_info(m, "FULLY_CONNECTED", cfg), cfg, x, None)
+    np.testing.assert_array_equal(p.quantized_data, exp)
+
+
+def test_hadamard_errors(m):
+  q = m.qtyping
+  cfg = q.TensorQuantizationConfig(num_bits=8, granularity=q.QuantGranularity.CHANNELWISE)
+  info = op_info(m, "FULLY_CONNECTED", cfg)
+  with pytest.raises(ValueError, match="only supported for weight tensors"):
+    m.had.get_tensor_quant_params(info, cfg, None, None)
+  with pytest.raises(ValueError, match="static quantization"):
+    m.had.get_tensor_quant_params(info, cfg, np.ones((4, 4), np.float32), {})
+  with pytest.raises(ValueError, match="rank >= 2"):
+    m.had.get_tensor_quant_params(info, cfg, np.ones(4, np.float32), None)
+
+
+def test_hadamard_rotation_is_orthogonal_at_full_size(m):
+  """Size-independent property at BASELINE sizes: H/sqrt(h) is an involution."""
+  rng = np.random.default_rng(0)
+  for shape, mx in (((64, 4096), None), ((8, 16384), None), ((16, 11008), None)):
+    w = rng.standard_normal(shape).astype(np.float32)
+    rot, h, _ = m.had._rotate_with_diagonal_hadamard(w, 1, mx)
+    assert h == (shape[1] & -shape[1])
+    back, _, _ = m.had._rotate_with_diagonal_hadamard(rot, 1, mx)
+    assert np.max(np.abs(back - w)) < 2e-5
+    ref = (w.reshape(-1, h)[:2] @ O.hadamard_matrix(h)).reshape(-1)
+    assert np.max(np.abs(rot.reshape(-1)[: ref.size] - ref)) < 1e-5 * np.max(np.abs(ref))
