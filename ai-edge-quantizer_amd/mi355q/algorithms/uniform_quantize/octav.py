@@ -43,7 +43,9 @@ def _guess_clipping_with_octav(x: np.ndarray, bits: int, axis, max_iterations: i
     ax = (axis,) if isinstance(axis, int) else tuple(axis)
     reduced = tuple(1 if k in ax else d for k, d in enumerate(x.shape))
   else:
-    reduced = (1,)
+    # the reference starts from shape (1,) but np.sum(..., axis=None, keepdims=True)
+    # turns the guess into (1,)*ndim on the first iteration
+    reduced = (1,) * x.ndim if max_iterations > 0 and x.ndim > 0 else (1,)
   view = _unit_view(x, axis)
   if view is None:
     raise NotImplementedError("OCTAV over non-contiguous reduction units")

@@ -1,0 +1,179 @@
+"""world_size=2 gloo tests of the multi-GPU layer's exchange + replay logic (CPU).
+
+Per-sample statistics are produced with the oracle here (the product path needs
+a GPU); what is under test is that sharding + all-gather + host replay reproduce
+the single-process reference sequence bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def _setup(rank, world, port):
+  for p in (os.path.join(ROOT, "ai-edge-quantizer_amd"), ROOT):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                    WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+  import torch.distributed as dist
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  return dist
+
+
+def _make_samples(n_samples=11, n_tensors=3):
+  rng = np.random.default_rng(42)
+  samples = []
+  for s in range(n_samples):
+    d = {}
+    for t in range(n_tensors):
+      x = rng.standard_normal((1, 8, 16), dtype=np.float32) * (1 + t)
+      if (s + t) % 4 == 0:
+        x.reshape(-1)[:3] = [np.inf, -np.inf, 3.39e38]
+      d[f"act{t}"] = x
+    samples.append(d)
+  return samples
+
+
+def _worker_calibration(rank, world, port, out):
+  dist = _setup(rank, world, port)
+  from mi355q import distributed as D
+  from mi355q.utils import qsv_utils
+  from oracle import aeq_oracle as O
+  samples = _make_samples()
+  names = sorted(samples[0])
+  shard = D.sample_shard(len(samples), rank, world)
+  local = np.empty((len(shard), len(names), 2), np.float32)
+  for i, s in enumerate(shard):
+    for t, n in enumerate(names):
+      q = O.activation_min_max(samples[s][n], -3e38, 3e38)
+      local[i, t] = (q["min"].item(), q["max"].item())
+  stats = D.gather_sample_stats(local)
+  shapes = [samples[0][n].shape for n in names]
+  qsvs = D.replay_qsv_updates(stats, names, shapes)
+  fast = D.allreduce_min_max(local)
+  mm = D.replay_qsv_updates(stats, names, shapes, update_fn=qsv_utils.min_max_update)
+  out.put((rank, stats, {n: (qsvs[n]["min"], qsvs[n]["max"]) for n in names}, fast,
+           {n: (mm[n]["min"], mm[n]["max"]) for n in names}))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def _worker_hessian(rank, world, port, out):
+  dist = _setup(rank, world, port)
+  from mi355q import distributed as D
+  rng = np.random.default_rng(5)
+  xs = [rng.standard_normal((2 + i % 3, 6, 16)).astype(np.float32) for i in range(7)]
+  shard = D.sample_shard(len(xs), rank, world)
+  acc, n = np.zeros((16, 16), np.float64), 0
+  for s in shard:
+    x2 = xs[s].reshape(-1, 16)
+    ns = xs[s].shape[0]
+    acc += ns * ((2.0 / np.array(ns)) * x2.T.dot(x2))
+    n += ns
+  h, total = D.allreduce_hessian(acc, n)
+  out.put((rank, h, total))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def _worker_shard_quantize(rank, world, port, out):
+  dist = _setup(rank, world, port)
+  from mi355q import distributed as D
+  from oracle import aeq_oracle as O
+  rng = np.random.default_rng(9)
+  tensors = {f"w{i}": rng.standard_normal((8 + 4 * i, 32)).astype(np.float32) for i in range(5)}
+  seen = []
+
+  def fn(name, arr):
+    seen.append(name)
+    return O.min_max_quant_params(arr, 8, True, "CHANNELWISE")["quantized_data"]
+  res = D.quantize_sharded(tensors, fn)
+  out.put((rank, sorted(seen), None if res is None else {k: v for k, v in res.items()}))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def _run(worker, world=2):
+  ctx = mp.get_context("spawn")
+  q = ctx.SimpleQueue()
+  port = _free_port()
+  procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  results = [q.get() for _ in range(world)]
+  for p in procs:
+    p.join(120)
+    assert p.exitcode == 0
+  return sorted(results, key=lambda r: r[0])
+
+
+def test_sample_shard_and_plan():
+  from mi355q import distributed as D
+  assert [list(D.sample_shard(11, r, 2)) for r in range(2)] == [list(range(6)), list(range(6, 11))]
+  assert sum(len(D.sample_shard(512, r, 8)) for r in range(8)) == 512
+  owner = D.plan_tensor_shards([10, 9, 8, 7, 1, 1], 2)
+  loads = [sum(b for b, o in zip([10, 9, 8, 7, 1, 1], owner) if o == r) for r in range(2)]
+  assert abs(loads[0] - loads[1]) <= 2 and owner == D.plan_tensor_shards([10, 9, 8, 7, 1, 1], 2)
+  # C3: 32 equal layers over 8 ranks -> 4 each
+  owner = D.plan_tensor_shards([180355072] * 32, 8)
+  assert sorted(owner.count(r) for r in range(8)) == [4] * 8
+
+
+def test_gathered_ema_replay_matches_sequential_reference():
+  from oracle import aeq_oracle as O
+  results = _run(_worker_calibration)
+  samples = _make_samples()
+  names = sorted(samples[0])
+  # single-process reference sequence: moving_average_update per sample, in order
+  ref, ref_mm = {}, {}
+  for s in samples:
+    for n in names:
+      q = O.activation_min_max(s[n], -3e38, 3e38)
+      ref[n] = O.moving_average_update(ref.get(n), {"min": q["min"], "max": q["max"]})
+      ref_mm[n] = O.min_max_update(ref_mm.get(n), {"min": q["min"], "max": q["max"]})
+  for rank, stats, qsvs, fast, mm in results:
+    assert stats.shape == (len(samples), len(names), 2)
+    for t, n in enumerate(names):
+      assert np.array_equal(qsvs[n][0], ref[n]["min"]) and np.array_equal(qsvs[n][1], ref[n]["max"])
+      assert qsvs[n][0].shape == (1, 1, 1)
+      assert np.array_equal(mm[n][0], ref_mm[n]["min"]) and np.array_equal(mm[n][1], ref_mm[n]["max"])
+      assert fast[t, 0] == ref_mm[n]["min"].item() and fast[t, 1] == ref_mm[n]["max"].item()
+  assert np.array_equal(results[0][1], results[1][1])
+
+
+def test_hessian_allreduce_matches_sequential_merge():
+  from oracle import aeq_oracle as O
+  results = _run(_worker_hessian)
+  rng = np.random.default_rng(5)
+  xs = [rng.standard_normal((2 + i % 3, 6, 16)).astype(np.float32) for i in range(7)]
+  q = None
+  for x in xs:
+    q = O.gptq_and_moving_average_update(
+        q, {"min": np.float32(0), "max": np.float32(1), "hessian": O.gptq_hessian(x),
+            "num_samples": x.shape[0]})
+  for rank, h, total in results:
+    assert total == q["num_samples"]
+    np.testing.assert_allclose(h, q["hessian"], rtol=1e-12, atol=1e-12)
+
+
+def test_tensor_sharded_quantize_gathers_everything_on_rank0():
+  from oracle import aeq_oracle as O
+  results = _run(_worker_shard_quantize)
+  rng = np.random.default_rng(9)
+  tensors = {f"w{i}": rng.standard_normal((8 + 4 * i, 32)).astype(np.float32) for i in range(5)}
+  (r0, seen0, res0), (r1, seen1, res1) = results
+  assert res1 is None and sorted(seen0 + seen1) == sorted(tensors)
+  assert seen0 and seen1  # both ranks did work
+  for n, w in tensors.items():
+    assert np.array_equal(res0[n], O.min_max_quant_params(w, 8, True, "CHANNELWISE")["quantized_data"])
