@@ -1,0 +1,423 @@
+// GPTQ on gfx950: Hessian (K8), damped inverse through a blocked FP64 Cholesky
+// (K9) and the column-serial OBS weight update (K10).
+//
+//   ref: algorithms/uniform_quantize/gptq.py:100-107  H = (2/num_samples) X^T X
+//   ref: algorithms/uniform_quantize/gptq.py:111-128  _prepare_hessian_inverse
+//   ref: algorithms/uniform_quantize/gptq.py:131-216  _apply_gptq
+//   ref: utils/qsv_utils.py:71-88                     _gptq_merge_hessian
+//
+// Dense contractions go through the MFMA GEMMs of gemm.hip; everything that is
+// O(d^2) or column-serial is plain VALU code. The reference computes X^T X with
+// sgemm (FP32), scales it into FLOAT64 (the `2.0 / np.array(n)` factor promotes),
+// factors in FLOAT64 and inverts through FP32 LAPACK; here the whole inverse is
+// done in FP64 and cast to FP32 at the end (tolerance class T2).
+#include "gemm.h"
+
+namespace mi355q {
+namespace {
+
+constexpr int NB = 64;  // Cholesky / TRTRI block size and the reference's GPTQ blocksize
+
+// ------------------------------------------------------------ Hessian ----
+__global__ __launch_bounds__(256) void scale_to_f64_kernel(const float* __restrict__ p, long long n,
+                                                          double alpha, double* __restrict__ h) {
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride)
+    h[i] = alpha * static_cast<double>(p[i]);
+}
+
+// (h0*n0 + h1*n1) / (n0+n1) in FP64, as NumPy evaluates it.
+__global__ __launch_bounds__(256) void hessian_merge_kernel(const double* __restrict__ h0, double n0,
+                                                           const double* __restrict__ h1, double n1,
+                                                           long long n, double* __restrict__ out) {
+  const double total = n0 + n1;
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride)
+    out[i] = (h0[i] * n0 + h1[i] * n1) / total;
+}
+
+// ---------------------------------------------------- damping + copy ----
+// sum of where(diag, diag, 1.0) -> out[0]
+__global__ __launch_bounds__(256) void diag_sum_kernel(const double* __restrict__ h, int d, double* out) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    const double v = h[static_cast<long long>(i) * d + i];
+    s += (v != 0.0) ? v : 1.0;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = part[0];
+}
+
+// a = lower(h) with the damped diagonal; strictly upper part zeroed.
+__global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __restrict__ h, int d,
+                                                               const double* __restrict__ diag_sum,
+                                                               double damp, double* __restrict__ a) {
+  const double add = damp * (diag_sum[0] / static_cast<double>(d));
+  const long long n = static_cast<long long>(d) * d;
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
+    const int i = static_cast<int>(e / d), j = static_cast<int>(e % d);
+    double v = 0.0;
+    if (j < i) v = h[e];
+    if (j == i) { v = h[e]; v = ((v != 0.0) ? v : 1.0) + add; }
+    a[e] = v;
+  }
+}
+
+// ---------------------------------------------------------- Cholesky ----
+// Unblocked lower Cholesky of the nb x nb diagonal block at (k,k); info != 0 if not PD.
+__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int d, int k, int nb, int* info) {
+  __shared__ double s[NB][NB + 1];
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    s[r][c] = (r < nb && c <= r) ? a[static_cast<long long>(k + r) * d + k + c] : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    if (threadIdx.x == 0) {
+      const double v = s[j][j];
+      if (!(v > 0.0)) atomicCAS(info, 0, k + j + 1);
+      s[j][j] = __builtin_sqrt(v);
+    }
+    __syncthreads();
+    if (threadIdx.x > j && threadIdx.x < nb) s[threadIdx.x][j] /= s[j][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+      const int r = e / NB, c = e % NB;
+      if (c > j && r >= c && r < nb) s[r][c] -= s[r][j] * s[c][j];
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    if (r < nb && c <= r) a[static_cast<long long>(k + r) * d + k + c] = s[r][c];
+  }
+}
+
+// Panel solve: rows below the diagonal block, X * Lkk^T = A[r, k:k+nb]; one thread per row.
+__global__ __launch_bounds__(256) void trsm_panel_kernel(double* __restrict__ a, int d, int k, int nb) {
+  __shared__ double l[NB][NB + 1];
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    l[r][c] = (r < nb && c <= r) ? a[static_cast<long long>(k + r) * d + k + c] : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  const int r = k + nb + blockIdx.x * 256 + threadIdx.x;
+  if (r >= d) return;
+  double* row = a + static_cast<long long>(r) * d + k;
+  double x[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) x[j] = j < nb ? row[j] : 0.0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double v = x[j];
+#pragma unroll
+    for (int m = 0; m < j; ++m) v -= x[m] * l[j][m];
+    x[j] = v / l[j][j];
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (j < nb) row[j] = x[j];
+}
+
+// ------------------------------------------------- triangular inverse ----
+// In-place inverse of the lower-triangular nb x nb block at (k,k); thread c solves column c.
+__global__ __launch_bounds__(64) void trti2_kernel(double* __restrict__ a, int d, int k, int nb,
+                                                  double* __restrict__ neg_inv /* NB*NB, row-major, may be null */) {
+  __shared__ double l[NB][NB + 1];
+  __shared__ double x[NB][NB + 1];
+  for (int e = threadIdx.x; e < NB * NB; e += 64) {
+    const int r = e / NB, c = e % NB;
+    l[r][c] = (r < nb && c <= r) ? a[static_cast<long long>(k + r) * d + k + c] : (r == c ? 1.0 : 0.0);
+    x[r][c] = 0.0;
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < nb) {
+    for (int r = c; r < nb; ++r) {  // forward substitution for L x = e_c
+      double v = (r == c) ? 1.0 : 0.0;
+      for (int m = c; m < r; ++m) v -= l[r][m] * x[m][c];
+      x[r][c] = v / l[r][r];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NB * NB; e += 64) {
+    const int r = e / NB, cc = e % NB;
+    if (r < nb && cc <= r) a[static_cast<long long>(k + r) * d + k + cc] = x[r][cc];
+    if (neg_inv != nullptr) neg_inv[e] = (r < nb && cc < nb) ? -x[r][cc] : 0.0;
+  }
+}
+
+// out32 = sym(lower(src)) cast to float32 (both triangles written).
+__global__ __launch_bounds__(256) void symmetrize_cast_kernel(const double* __restrict__ src, int d,
+                                                             float* __restrict__ dst) {
+  const long long n = static_cast<long long>(d) * d;
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
+    const long long i = e / d, j = e % d;
+    dst[e] = static_cast<float>(j <= i ? src[e] : src[j * d + i]);
+  }
+}
+
+// -------------------------------------------------------- OBS update ----
+struct ApplyArgs {
+  float* w;             // [rows, d] working copy (updated in place)
+  int rows, d, c0, nb;  // current column block [c0, c0+nb)
+  const float* hinv;    // [d, d]
+  const void* scale;    // float or double
+  const int32_t* zp;    // null = zeros
+  int scale_mode;       // 0: one scale; 1: per row; 2: per (row, col / block_size)
+  int block_size, nblk;
+  float lo, hi;
+  int zp_via_f64;       // int32/int64 zero points are added in FP64
+  int diff_bits;        // width of (q - zp) in dequantize (8: wraps like int8 - int8)
+  float* err;           // [rows, NB]
+  int8_t* q;            // [rows, d]
+};
+
+template <typename ST>
+__global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
+  __shared__ float h[NB][NB + 1];
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    h[r][c] = (r < a.nb && c < a.nb) ? a.hinv[static_cast<long long>(a.c0 + r) * a.d + a.c0 + c] : 0.f;
+  }
+  __syncthreads();
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.rows) return;
+  float* wrow = a.w + static_cast<long long>(r) * a.d + a.c0;
+  float w[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) w[j] = j < a.nb ? wrow[j] : 0.f;
+  const ST* sc = static_cast<const ST*>(a.scale);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    if (i < a.nb) {
+      const int col = a.c0 + i;
+      long long si = 0;
+      if (a.scale_mode == 1) si = r;
+      if (a.scale_mode == 2) si = static_cast<long long>(r) * a.nblk + col / a.block_size;
+      const ST s = sc[si];
+      const int z = a.zp ? a.zp[si] : 0;
+      // quantize (ref gptq.py:191-195 -> uniform_quantize)
+      int qi;
+      float e;
+      if constexpr (sizeof(ST) == 8) {
+        const double v = static_cast<double>(w[i]) / s + static_cast<double>(z);
+        double rr = __builtin_rint(v);
+        rr = fmin(fmax(rr, static_cast<double>(a.lo)), static_cast<double>(a.hi));
+        qi = (v != v) ? 0 : static_cast<int>(rr);
+        int dd = qi - z;
+        if (a.diff_bits == 8) dd = static_cast<int8_t>(dd);
+        const double dq = static_cast<double>(dd) * s;
+        e = static_cast<float>(static_cast<double>(w[i]) - dq);  // np.subtract(f32, f64, out=f32)
+      } else {
+        float v = w[i] / s;
+        v = a.zp_via_f64 ? static_cast<float>(static_cast<double>(v) + static_cast<double>(z))
+                         : v + static_cast<float>(z);
+        float rr = __builtin_rintf(v);
+        rr = fminf(fmaxf(rr, a.lo), a.hi);
+        qi = (v != v) ? 0 : static_cast<int>(rr);
+        int dd = qi - z;
+        if (a.diff_bits == 8) dd = static_cast<int8_t>(dd);
+        const float dq = static_cast<float>(dd) * s;
+        e = w[i] - dq;
+      }
+      a.q[static_cast<long long>(r) * a.d + col] = static_cast<int8_t>(qi);
+      e = e / h[i][i];
+      a.err[static_cast<long long>(r) * NB + i] = e;
+      // intra-block rank-1 update: w[:, j] -= outer(err, hinv[c, j]) (product rounded, then subtracted)
+#pragma unroll
+      for (int j = i + 1; j < NB; ++j) {
+        const float p = e * h[i][j];
+        w[j] = w[j] - p;
+      }
+    } else {
+      a.err[static_cast<long long>(r) * NB + i] = 0.f;
+    }
+  }
+}
+
+inline unsigned grid1d(long long n) {
+  long long b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 256 * 16) b = 256 * 16;
+  return static_cast<unsigned>(b);
+}
+
+}  // namespace
+}  // namespace mi355q
+
+using namespace mi355q;
+
+extern "C" size_t mi355q_gptq_xtx_workspace_bytes(int64_t d) {
+  return d > 0 ? static_cast<size_t>(d) * d * sizeof(float) : 0;
+}
+
+extern "C" int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, double alpha,
+                                       double* hessian_out, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  clear_error();
+  if (n < 0 || d < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (d == 0) return MI355Q_OK;
+  if (d > 0x7FFFFFFF || n > 0x7FFFFFFF) return fail(MI355Q_UNSUPPORTED, "dimension too large");
+  if (!x || !hessian_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  const size_t need = mi355q_gptq_xtx_workspace_bytes(d);
+  if (!workspace || workspace_bytes < need)
+    return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  hipStream_t st = as_stream(stream);
+  float* p = static_cast<float*>(workspace);
+  // P = X^T X : A(i,k) = X[k][i], B(k,j) = X[k][j]
+  GemmArgs<float> g{x, 1, d, x, d, 1, p, d, 1, static_cast<int>(d), static_cast<int>(d),
+                    static_cast<int>(n), 1.0f, 0.0f, 0, 0};
+  if (int32_t s = launch_gemm<float>(g, st)) return s;
+  hipLaunchKernelGGL(scale_to_f64_kernel, dim3(grid1d(d * d)), dim3(256), 0, st, p,
+                     static_cast<long long>(d) * d, alpha, hessian_out);
+  MI355Q_CHECK_LAUNCH("hessian scale launch");
+  return MI355Q_OK;
+}
+
+extern "C" int32_t mi355q_gptq_hessian_merge_f64(const double* h_cur, double n_cur, const double* h_new,
+                                                 double n_new, int64_t d, double* h_out, void* stream) {
+  clear_error();
+  if (d < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (d == 0) return MI355Q_OK;
+  if (!h_cur || !h_new || !h_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  if (n_cur + n_new == 0.0) return fail(MI355Q_BAD_ARG, "total sample count is zero");
+  hipLaunchKernelGGL(hessian_merge_kernel, dim3(grid1d(d * d)), dim3(256), 0, as_stream(stream), h_cur,
+                     n_cur, h_new, n_new, static_cast<long long>(d) * d, h_out);
+  MI355Q_CHECK_LAUNCH("hessian merge launch");
+  return MI355Q_OK;
+}
+
+extern "C" size_t mi355q_gptq_hinv_workspace_bytes(int64_t d) {
+  // two d x d FP64 matrices + a d x NB FP64 panel + small scalars
+  return d > 0 ? (static_cast<size_t>(d) * d * 2 + static_cast<size_t>(d) * NB + NB * NB + 8) * sizeof(double) : 0;
+}
+
+extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, double damp_factor,
+                                        float* hinv_out, int32_t* info_out, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (d64 < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (d64 == 0) return MI355Q_OK;
+  if (d64 > 46000) return fail(MI355Q_UNSUPPORTED, "d too large");
+  if (!hessian || !hinv_out || !info_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  const size_t need = mi355q_gptq_hinv_workspace_bytes(d64);
+  if (!workspace || workspace_bytes < need)
+    return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  const int d = static_cast<int>(d64);
+  hipStream_t st = as_stream(stream);
+  double* a = static_cast<double*>(workspace);           // L, then L^-1 (lower, zeros above)
+  double* out = a + static_cast<size_t>(d) * d;          // lower(H^-1) in FP64
+  double* panel = out + static_cast<size_t>(d) * d;      // d x NB temporary
+  double* neg_inv = panel + static_cast<size_t>(d) * NB; // NB x NB
+  double* scal = neg_inv + NB * NB;
+  if (hipMemsetAsync(info_out, 0, sizeof(int32_t), st) != hipSuccess)
+    return fail(MI355Q_HIP_ERROR, "hipMemsetAsync failed");
+  hipLaunchKernelGGL(diag_sum_kernel, dim3(1), dim3(256), 0, st, hessian, d, scal);
+  hipLaunchKernelGGL(copy_damped_lower_kernel, dim3(grid1d(static_cast<long long>(d) * d)), dim3(256), 0, st,
+                     hessian, d, scal, damp_factor, a);
+  MI355Q_CHECK_LAUNCH("gptq damp launch");
+  // ---- blocked right-looking Cholesky (lower), FP64
+  for (int k = 0; k < d; k += NB) {
+    const int nb = d - k < NB ? d - k : NB;
+    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, info_out);
+    const int m = d - k - nb;
+    if (m > 0) {
+      hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + 255) / 256), dim3(256), 0, st, a, d, k, nb);
+      double* l21 = a + static_cast<long long>(k + nb) * d + k;
+      double* a22 = a + static_cast<long long>(k + nb) * d + k + nb;
+      GemmArgs<double> g{l21, d, 1, l21, 1, d, a22, d, 1, m, m, nb, -1.0, 1.0, 1, 0};
+      if (int32_t s = launch_gemm<double>(g, st)) return s;
+    }
+  }
+  MI355Q_CHECK_LAUNCH("gptq cholesky launch");
+  // ---- blocked in-place inverse of the lower-triangular factor (LAPACK dtrtri order)
+  const int nblocks = (d + NB - 1) / NB;
+  for (int jb = nblocks - 1; jb >= 0; --jb) {
+    const int k = jb * NB;
+    const int nb = d - k < NB ? d - k : NB;
+    const int m = d - k - nb;
+    hipLaunchKernelGGL(trti2_kernel, dim3(1), dim3(64), 0, st, a, d, k, nb, neg_inv);
+    if (m > 0) {
+      double* a21 = a + static_cast<long long>(k + nb) * d + k;
+      double* a22 = a + static_cast<long long>(k + nb) * d + k + nb;  // already inverted
+      // panel = A22inv * A21        (A22inv lower triangular)
+      GemmArgs<double> g1{a22, d, 1, a21, d, 1, panel, NB, 1, m, nb, m, 1.0, 0.0, 0, 1};
+      if (int32_t s = launch_gemm<double>(g1, st)) return s;
+      // A21 = panel * (-inv(A11))
+      GemmArgs<double> g2{panel, NB, 1, neg_inv, NB, 1, a21, d, 1, m, nb, nb, 1.0, 0.0, 0, 0};
+      if (int32_t s = launch_gemm<double>(g2, st)) return s;
+    }
+  }
+  MI355Q_CHECK_LAUNCH("gptq trtri launch");
+  // ---- H^-1 = L^-T L^-1 : out(i,j) = sum_k Linv[k][i] * Linv[k][j], k >= max(i,j); lower half
+  GemmArgs<double> gp{a, 1, d, a, d, 1, out, d, 1, d, d, d, 1.0, 0.0, 1, 2};
+  if (int32_t s = launch_gemm<double>(gp, st)) return s;
+  hipLaunchKernelGGL(symmetrize_cast_kernel, dim3(grid1d(static_cast<long long>(d) * d)), dim3(256), 0, st,
+                     out, d, hinv_out);
+  MI355Q_CHECK_LAUNCH("gptq symmetrize launch");
+  return MI355Q_OK;
+}
+
+extern "C" size_t mi355q_gptq_apply_workspace_bytes(int64_t rows, int64_t d) {
+  if (rows <= 0 || d <= 0) return 0;
+  return (static_cast<size_t>(rows) * d + static_cast<size_t>(rows) * NB) * sizeof(float);
+}
+
+extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d, const float* hinv,
+                                         const void* scale, int32_t scale_is_f64, const int32_t* zero_point,
+                                         int32_t scale_mode, int32_t block_size, int32_t bits, int32_t narrow,
+                                         int32_t zp_via_f64, int32_t diff_bits, int8_t* q_out,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (rows < 0 || d < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (rows == 0 || d == 0) return MI355Q_OK;
+  if (rows > 0x7FFFFFFF || d > 0x7FFFFFFF) return fail(MI355Q_UNSUPPORTED, "dimension too large");
+  if (bits < 2 || bits > 8) return fail(MI355Q_UNSUPPORTED, "gptq apply supports 2..8 bits");
+  if (scale_mode < 0 || scale_mode > 2) return fail(MI355Q_BAD_ARG, "bad scale_mode");
+  if (scale_mode == 2 && (block_size <= 0 || d % block_size != 0))
+    return fail(MI355Q_BAD_SHAPE, "Quantized dimension %lld is not divisible by block size %d.",
+                static_cast<long long>(d), block_size);
+  if (!w || !hinv || !scale || !q_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  const size_t need = mi355q_gptq_apply_workspace_bytes(rows, d);
+  if (!workspace || workspace_bytes < need)
+    return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  hipStream_t st = as_stream(stream);
+  float* wc = static_cast<float*>(workspace);
+  float* err = wc + rows * d;
+  if (hipMemcpyAsync(wc, w, static_cast<size_t>(rows) * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail(MI355Q_HIP_ERROR, "hipMemcpyAsync failed");
+  const double qmax = static_cast<double>((1 << (bits - 1)) - 1), qmin = -static_cast<double>(1 << (bits - 1));
+  ApplyArgs a{};
+  a.w = wc; a.rows = static_cast<int>(rows); a.d = static_cast<int>(d); a.hinv = hinv; a.scale = scale;
+  a.zp = zero_point; a.scale_mode = scale_mode; a.block_size = block_size > 0 ? block_size : 1;
+  a.nblk = scale_mode == 2 ? static_cast<int>(d / block_size) : 1;
+  a.lo = static_cast<float>(narrow ? qmin + 1 : qmin); a.hi = static_cast<float>(qmax);
+  a.zp_via_f64 = zp_via_f64; a.diff_bits = diff_bits; a.err = err; a.q = q_out;
+  for (int c0 = 0; c0 < a.d; c0 += NB) {
+    a.c0 = c0;
+    a.nb = a.d - c0 < NB ? a.d - c0 : NB;
+    const dim3 grid(static_cast<unsigned>((rows + 255) / 256));
+    if (scale_is_f64)
+      hipLaunchKernelGGL((gptq_block_kernel<double>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((gptq_block_kernel<float>), grid, dim3(256), 0, st, a);
+    const int c1 = c0 + a.nb;
+    if (c1 < a.d) {
+      // W[:, c1:] -= err[:, :nb] @ Hinv[c0:c1, c1:]     (ref gptq.py:213-214)
+      GemmArgs<float> g{err, NB, 1, hinv + static_cast<long long>(c0) * d + c1, d, 1, wc + c1, d, 1,
+                        a.rows, a.d - c1, a.nb, -1.0f, 1.0f, 0, 0};
+      if (int32_t s = launch_gemm<float>(g, st)) return s;
+    }
+  }
+  MI355Q_CHECK_LAUNCH("gptq apply launch");
+  return MI355Q_OK;
+}

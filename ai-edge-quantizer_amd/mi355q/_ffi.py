@@ -17,7 +17,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmi355q.so")
 
-c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+c_i32, c_i64, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
 
 # name -> (restype, argtypes); mirrors include/mi355q.h one to one.
@@ -44,6 +44,18 @@ PROTOTYPES = {
                                       c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_mse_scale_f32": (c_i32, [c_ptr, c_i64, c_i64, c_f32, c_ptr, c_ptr]),
     "mi355q_hadamard_rotate_f32": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr]),
+    "mi355q_gemm_f32": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64,
+                                c_i64, c_i64, c_i64, c_f32, c_f32, c_i32, c_ptr]),
+    "mi355q_gemm_f64": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64,
+                                c_i64, c_i64, c_i64, c_f64, c_f64, c_i32, c_ptr]),
+    "mi355q_gptq_xtx_workspace_bytes": (c_size, [c_i64]),
+    "mi355q_gptq_xtx_f32": (c_i32, [c_ptr, c_i64, c_i64, c_f64, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_gptq_hessian_merge_f64": (c_i32, [c_ptr, c_f64, c_ptr, c_f64, c_i64, c_ptr, c_ptr]),
+    "mi355q_gptq_hinv_workspace_bytes": (c_size, [c_i64]),
+    "mi355q_gptq_hinv_f64": (c_i32, [c_ptr, c_i64, c_f64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_gptq_apply_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "mi355q_gptq_apply_f32": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32,
+                                      c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_size, c_ptr]),
 }
 
 STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "BAD_SHAPE", -3: "UNSUPPORTED", -4: "HIP_ERROR"}

@@ -254,3 +254,85 @@ def hadamard_rotate(x: torch.Tensor, h: int) -> torch.Tensor:
   _ffi.check(_ffi.lib().mi355q_hadamard_rotate_f32(rt.ptr(x), x.numel() // h, h, rt.ptr(out),
                                                    rt.stream_ptr()))
   return out
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
+         lower_only: bool = False) -> torch.Tensor:
+  """MFMA GEMM on 2-D float32 / float64 device tensors: op(a) @ op(b)."""
+  rt.require_gpu()
+  if a.dtype != b.dtype or a.dtype not in (torch.float32, torch.float64):
+    raise TypeError("gemm expects matching float32 or float64 tensors")
+  a, b = a.contiguous(), b.contiguous()
+  m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
+  k2, n = (b.shape[1], b.shape[0]) if trans_b else b.shape
+  if k != k2:
+    raise ValueError("inner dimensions do not match")
+  c = torch.zeros((m, n), dtype=a.dtype, device=a.device)
+  a_i, a_k = (1, a.shape[1]) if trans_a else (a.shape[1], 1)
+  b_k, b_j = (1, b.shape[1]) if trans_b else (b.shape[1], 1)
+  fn = _ffi.lib().mi355q_gemm_f32 if a.dtype == torch.float32 else _ffi.lib().mi355q_gemm_f64
+  _ffi.check(fn(rt.ptr(a), a_i, a_k, rt.ptr(b), b_k, b_j, rt.ptr(c), n, 1, m, n, k, 1.0, 0.0,
+                1 if lower_only else 0, rt.stream_ptr()))
+  return c
+
+
+def gptq_xtx(x: torch.Tensor, alpha: float) -> torch.Tensor:
+  """K8. float64 [d, d] = alpha * (x^T x) for float32 x [n, d]. ref: gptq.py:100-107."""
+  rt.require_gpu()
+  x = _f32(x)
+  n, d = x.shape
+  h = rt.empty((d, d), torch.float64)
+  L = _ffi.lib()
+  nbytes = L.mi355q_gptq_xtx_workspace_bytes(d)
+  ws = rt.empty((max(nbytes, 1),), torch.uint8)
+  _ffi.check(L.mi355q_gptq_xtx_f32(rt.ptr(x), n, d, float(alpha), rt.ptr(h), rt.ptr(ws), nbytes,
+                                   rt.stream_ptr()))
+  return h
+
+
+def gptq_hessian_merge(h_cur: torch.Tensor, n_cur: float, h_new: torch.Tensor, n_new: float):
+  """(h_cur*n_cur + h_new*n_new)/(n_cur+n_new), float64. ref: qsv_utils.py:71-88."""
+  rt.require_gpu()
+  out = torch.empty_like(h_cur)
+  _ffi.check(_ffi.lib().mi355q_gptq_hessian_merge_f64(
+      rt.ptr(h_cur.contiguous()), float(n_cur), rt.ptr(h_new.contiguous()), float(n_new),
+      h_cur.shape[0], rt.ptr(out), rt.stream_ptr()))
+  return out
+
+
+def gptq_hinv(hessian: torch.Tensor, damp_factor: float = 0.01):
+  """K9. Returns (hinv float32 [d,d], info int32[1]). ref: gptq.py:111-128."""
+  rt.require_gpu()
+  if hessian.dtype != torch.float64:
+    hessian = hessian.to(torch.float64)
+  hessian = hessian.contiguous()
+  d = hessian.shape[0]
+  hinv = rt.empty((d, d), torch.float32)
+  info = rt.empty((1,), torch.int32)
+  L = _ffi.lib()
+  nbytes = L.mi355q_gptq_hinv_workspace_bytes(d)
+  ws = rt.empty((max(nbytes, 1),), torch.uint8)
+  _ffi.check(L.mi355q_gptq_hinv_f64(rt.ptr(hessian), d, float(damp_factor), rt.ptr(hinv),
+                                    rt.ptr(info), rt.ptr(ws), nbytes, rt.stream_ptr()))
+  return hinv, info
+
+
+def gptq_apply(w: torch.Tensor, hinv: torch.Tensor, scale: torch.Tensor,
+               zero_point: torch.Tensor | None, scale_mode: int, block_size: int, bits: int,
+               narrow: bool, zp_via_f64: bool, diff_bits: int) -> torch.Tensor:
+  """K10. int8 [rows, d]. ref: gptq.py:131-216."""
+  rt.require_gpu()
+  w = _f32(w)
+  rows, d = w.shape
+  q = rt.empty((rows, d), torch.int8)
+  if zero_point is not None:
+    zero_point = zero_point.to(torch.int32).contiguous()
+  L = _ffi.lib()
+  nbytes = L.mi355q_gptq_apply_workspace_bytes(rows, d)
+  ws = rt.empty((max(nbytes, 1),), torch.uint8)
+  _ffi.check(L.mi355q_gptq_apply_f32(
+      rt.ptr(w), rows, d, rt.ptr(_f32(hinv)), rt.ptr(scale.contiguous()),
+      1 if scale.dtype == torch.float64 else 0, rt.ptr(zero_point), scale_mode, block_size, bits,
+      1 if narrow else 0, 1 if zp_via_f64 else 0, diff_bits, rt.ptr(q), rt.ptr(ws), nbytes,
+      rt.stream_ptr()))
+  return q

@@ -206,6 +206,75 @@ int32_t mi355q_mse_scale_f32(const float* x, int64_t units, int64_t unit_len, fl
 int32_t mi355q_hadamard_rotate_f32(const float* x, int64_t n_vec, int32_t h, float* out,
                                    void* stream);
 
+/* ------------------------------------------------------------------------
+ * Dense contraction building blocks (MFMA): C = beta*C + alpha * A.B with
+ * A(i,k) at A + i*a_i + k*a_k (element strides; likewise B(k,j), C(i,j)), so
+ * transposes and sub-matrices need no copies. float -> v_mfma_f32_32x32x2_f32
+ * (exact FP32 fmaf chains, sgemm-class numerics), double -> v_mfma_f64_16x16x4_f64.
+ * lower_only writes only j <= i. Used by the GPTQ entry points below; replaces
+ * the BLAS calls behind np.matmul / x.T.dot(x) on this path
+ * (ref: gptq.py:106, 214; hadamard_rotation.py:129 uses the FWHT instead).
+ * ------------------------------------------------------------------------ */
+int32_t mi355q_gemm_f32(const float* A, int64_t a_i, int64_t a_k, const float* B, int64_t b_k,
+                        int64_t b_j, float* C, int64_t c_i, int64_t c_j, int64_t M, int64_t N,
+                        int64_t K, float alpha, float beta, int32_t lower_only, void* stream);
+int32_t mi355q_gemm_f64(const double* A, int64_t a_i, int64_t a_k, const double* B, int64_t b_k,
+                        int64_t b_j, double* C, int64_t c_i, int64_t c_j, int64_t M, int64_t N,
+                        int64_t K, double alpha, double beta, int32_t lower_only, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K8 -- GPTQ Hessian of one calibration tensor: hessian_out (FLOAT64 [d,d]) =
+ * alpha * (X^T X), X = float32 [n, d] (tokens x channels), X^T X accumulated in
+ * FP32 on the MFMA units, alpha = 2 / num_samples applied in FLOAT64 exactly as
+ * `(2.0 / num_samples) * x.T.dot(x)` promotes in the reference.
+ * ref: algorithms/uniform_quantize/gptq.py:100-107
+ * workspace: mi355q_gptq_xtx_workspace_bytes(d) bytes.
+ * ------------------------------------------------------------------------ */
+size_t mi355q_gptq_xtx_workspace_bytes(int64_t d);
+int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, double alpha,
+                            double* hessian_out, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
+/* Sample-weighted running mean of two Hessians, FLOAT64:
+ * h_out = (h_cur*n_cur + h_new*n_new) / (n_cur + n_new); h_out may alias an input.
+ * ref: utils/qsv_utils.py:71-88 (_gptq_merge_hessian) */
+int32_t mi355q_gptq_hessian_merge_f64(const double* h_cur, double n_cur, const double* h_new,
+                                      double n_new, int64_t d, double* h_out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K9 -- damped Hessian inverse: diag zeros -> 1, diag += damp*mean(diag), blocked
+ * FP64 Cholesky (MFMA trailing updates), triangular inverse, H^-1 = L^-T L^-1;
+ * hinv_out is float32 [d,d] (both triangles). info_out (device int32): 0 on
+ * success, j+1 if the leading minor of order j+1 is not positive definite
+ * (np.linalg.cholesky would raise LinAlgError).
+ * ref: algorithms/uniform_quantize/gptq.py:111-128 (_prepare_hessian_inverse)
+ * workspace: mi355q_gptq_hinv_workspace_bytes(d) bytes.
+ * ------------------------------------------------------------------------ */
+size_t mi355q_gptq_hinv_workspace_bytes(int64_t d);
+int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d, double damp_factor, float* hinv_out,
+                             int32_t* info_out, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/* ------------------------------------------------------------------------
+ * K10 -- GPTQ weight update + quantization: for each 64-column block, quantize
+ * column by column with the up-front scales, propagate err/Hinv[c,c] to the rest
+ * of the block (rank-1, FP32, product rounded before the subtraction as NumPy's
+ * np.outer does) and then to all later columns with one MFMA GEMM.
+ * ref: algorithms/uniform_quantize/gptq.py:131-216 (_apply_gptq, blocksize 64)
+ *   w [rows, d] float32 (not modified); hinv float32 [d, d]
+ *   scale_mode 0: scale[1] (TENSORWISE); 1: scale[rows] (CHANNELWISE);
+ *              2: scale[rows, d/block_size] (BLOCKWISE)
+ *   scale_is_f64 / zp_via_f64 / diff_bits: NumPy promotion switches, see
+ *              mi355q_quantize_f32 / mi355q_dequantize_f32
+ *   q_out int8 [rows, d]; workspace: mi355q_gptq_apply_workspace_bytes(rows, d)
+ * ------------------------------------------------------------------------ */
+size_t mi355q_gptq_apply_workspace_bytes(int64_t rows, int64_t d);
+int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d, const float* hinv,
+                              const void* scale, int32_t scale_is_f64, const int32_t* zero_point,
+                              int32_t scale_mode, int32_t block_size, int32_t bits, int32_t narrow,
+                              int32_t zp_via_f64, int32_t diff_bits, int8_t* q_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

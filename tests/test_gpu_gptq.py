@@ -1,0 +1,239 @@
+"""GPU parity of the GPTQ path (MFMA GEMMs, Hessian, FP64 Cholesky inverse, OBS apply).
+
+Tolerance class T2: the reference runs sgemm / LAPACK whose add
+order is unspecified. What is exact and tested as such: the apply step given the
+reference's own Hinv when d <= 64 (no GEMM involved), and the reference's
+known-answer vectors."""
+import warnings
+
+import numpy as np
+import pytest
+
+from golden_util import case_names, num
+from oracle import aeq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def m():
+  import torch
+  assert torch.cuda.is_available()
+  import __graft_entry__ as g
+  g.build()
+  import types
+  from mi355q import ops, qtyping
+  from mi355q.algorithms.uniform_quantize import gptq
+  return types.SimpleNamespace(ops=ops, qtyping=qtyping, gptq=gptq, torch=torch)
+
+
+def dev(m, a):
+  return m.torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+  return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype,rtol", [(np.float32, 2e-6), (np.float64, 1e-14)])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (5, 7, 3), (64, 64, 64), (130, 70, 33), (200, 257, 129),
+                                   (300, 128, 1000)])
+def test_gemm_matches_numpy(m, dtype, rtol, shape):
+  mm, nn, kk = shape
+  rng = np.random.default_rng(sum(shape))
+  a = rng.standard_normal((mm, kk)).astype(dtype)
+  b = rng.standard_normal((kk, nn)).astype(dtype)
+  ref = a.astype(np.float64) @ b.astype(np.float64)
+  tol = rtol * np.sqrt(kk) * np.abs(a).max() * np.abs(b).max() * 4 + 1e-30
+  for ta, tb in ((False, False), (True, False), (False, True), (True, True)):
+    aa = np.ascontiguousarray(a.T) if ta else a
+    bb = np.ascontiguousarray(b.T) if tb else b
+    c = host(m.ops.gemm(dev(m, aa), dev(m, bb), ta, tb))
+    assert c.shape == (mm, nn) and c.dtype == dtype
+    assert np.max(np.abs(c - ref)) <= tol * np.sqrt(kk)
+
+
+def test_gemm_exact_on_small_integers_and_asymmetric_layout(m):
+  """Transpose-detecting check: integer operands make every product exact."""
+  rng = np.random.default_rng(0)
+  a = rng.integers(-8, 9, (150, 70)).astype(np.float32)
+  b = rng.integers(-8, 9, (70, 90)).astype(np.float32)
+  assert np.array_equal(host(m.ops.gemm(dev(m, a), dev(m, b))), a @ b)
+  ad, bd = a.astype(np.float64), b.astype(np.float64)
+  assert np.array_equal(host(m.ops.gemm(dev(m, ad), dev(m, bd))), ad @ bd)
+  s = rng.integers(-5, 6, (100, 100)).astype(np.float64)
+  low = host(m.ops.gemm(dev(m, s), dev(m, s), False, True, lower_only=True))
+  assert np.array_equal(np.tril(low), np.tril(s @ s.T)) and not np.triu(low, 1).any()
+
+
+@pytest.mark.parametrize("name", case_names("gptq"))
+def test_hessian_matches_reference(m, ref_cases, name):
+  arrays, _ = ref_cases
+  x = arrays[f"{name}/x"]
+  ref = arrays[f"{name}/hessian"]
+  h = m.gptq.hessian_of(x, np.array(x.shape[0]))
+  assert h.dtype == np.float64 and h.shape == ref.shape
+  assert np.array_equal(h, h.T)
+  assert np.max(np.abs(h - ref)) <= 2e-6 * np.max(np.abs(ref))
+
+
+def test_hessian_known_answer_with_float64_overflow_values(m, known_answers):
+  """ref gptq_test.py:50-114: 1e39 in float64 content (squares leave FP32)."""
+  k = known_answers["gptq_hessian"]
+  for key in ("input", "output"):
+    x = np.array([[[num(v, k["val"]) for v in row] for row in mat] for mat in k[key]])
+    h = m.gptq.hessian_of(x, np.array(1))
+    x2 = x.reshape(-1, 3)
+    np.testing.assert_allclose(h, 2.0 * x2.T @ x2)
+
+
+@pytest.mark.parametrize("name", case_names("gptq"))
+def test_hessian_inverse_matches_reference(m, ref_cases, name):
+  arrays, _ = ref_cases
+  hess, ref = arrays[f"{name}/hessian"], arrays[f"{name}/hinv"]
+  hinv = m.gptq._prepare_hessian_inverse(hess.copy())
+  assert hinv.dtype == np.float32 and np.array_equal(hinv, hinv.T)
+  # against the exact FP64 inverse of the damped matrix: FP32 rounding only
+  damped = hess.copy()
+  dg = np.where(np.diag(hess), np.diag(hess), 1.0)
+  np.fill_diagonal(damped, dg + 0.01 * dg.mean())
+  exact = np.linalg.inv(damped)
+  assert np.max(np.abs(hinv - exact)) <= 1e-6 * np.max(np.abs(exact))
+  # against the reference's float32 LAPACK result
+  assert np.max(np.abs(hinv - ref)) <= 2e-5 * np.max(np.abs(ref))
+
+
+def test_hessian_inverse_larger_and_not_positive_definite(m):
+  rng = np.random.default_rng(1)
+  for d in (200, 513):
+    x = rng.standard_normal((3 * d, d)).astype(np.float32)
+    x[:, 5] = 0  # dead channel -> zero diagonal entry replaced by 1
+    h = (2.0 / np.array(3)) * (x.T.dot(x))
+    hinv = m.gptq._prepare_hessian_inverse(h)
+    damped = h.copy()
+    dg = np.where(np.diag(h), np.diag(h), 1.0)
+    np.fill_diagonal(damped, dg + 0.01 * dg.mean())
+    exact = np.linalg.inv(damped)
+    assert np.max(np.abs(hinv - exact)) <= 2e-6 * np.max(np.abs(exact))
+  bad = -np.eye(8)
+  bad[0, 0] = 1.0
+  with pytest.raises(np.linalg.LinAlgError):
+    m.gptq._prepare_hessian_inverse(bad)
+
+
+def _apply_with_reference_hinv(m, arrays, name, c):
+  w, scale, zp = arrays[f"{name}/w"], arrays[f"{name}/scale"], arrays[f"{name}/zero_point"]
+  rows, d = w.shape
+  if c["block_size"]:
+    mode = 2
+  elif scale.size == 1:
+    mode = 0
+  else:
+    mode = 1
+  q = m.ops.gptq_apply(dev(m, w), dev(m, arrays[f"{name}/hinv"]), dev(m, scale.reshape(-1)),
+                       dev(m, zp.reshape(-1).astype(np.int32)), mode, c["block_size"], c["num_bits"],
+                       c["symmetric"] and c["num_bits"] >= 8, zp.dtype.itemsize >= 4, 8)
+  return host(q)
+
+
+@pytest.mark.parametrize("name", case_names("gptq"))
+def test_apply_given_reference_hinv(m, ref_cases, name):
+  """T1: with the reference's own Hinv the intra-block path is exact (d <= 64);
+  with several 64-column blocks only the GEMM add order can move a value."""
+  arrays, cases = ref_cases
+  c = cases[name]
+  q = _apply_with_reference_hinv(m, arrays, name, c)
+  ref = arrays[f"{name}/q"]
+  if ref.shape[1] <= 64:
+    assert np.array_equal(q, ref)
+  else:
+    diff = np.abs(q.astype(np.int32) - ref.astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() <= 2e-3
+
+
+@pytest.mark.parametrize("name", case_names("gptq"))
+def test_get_tensor_quant_params_end_to_end(m, ref_cases, name):
+  arrays, cases = ref_cases
+  c = cases[name]
+  q_ = m.qtyping
+  cfg = q_.TensorQuantizationConfig(num_bits=c["num_bits"], symmetric=c["symmetric"],
+                                    granularity=q_.QuantGranularity[c["granularity"]])
+  info = q_.OpInfo(op=q_.OperatorT(), op_name=q_.TFLOperationName.FULLY_CONNECTED,
+                   subgraph_op_index=0,
+                   op_quant_config=q_.OpQuantizationConfig(weight_tensor_config=cfg))
+  qsv = {"activation_tensor_qsv": {"hessian": arrays[f"{name}/hessian"], "num_samples": 1}}
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    p = m.gptq.get_tensor_quant_params(info, cfg, arrays[f"{name}/w"], qsv)
+  assert np.array_equal(p.scale, arrays[f"{name}/scale"])
+  assert np.array_equal(p.zero_point, arrays[f"{name}/zero_point"])
+  assert p.quantized_data.dtype == np.int8
+  diff = np.abs(p.quantized_data.astype(np.int32) - arrays[f"{name}/q"].astype(np.int32))
+  assert diff.max() <= 1 and (diff != 0).mean() <= 5e-3
+
+
+def test_known_answers(m, known_answers):
+  """ref gptq_test.py:214-299 (float64 QSV scale) and :326-398 (blockwise scale per column)."""
+  q_ = m.qtyping
+  k = known_answers["gptq_goldens"]
+  w = np.array(k["weights"], dtype=np.float32)
+  cfg = q_.TensorQuantizationConfig(num_bits=8, symmetric=True,
+                                    granularity=q_.QuantGranularity.TENSORWISE)
+  for c in k["cases"]:
+    wcfg = None if c["qsv_min"] is not None else cfg
+    info = q_.OpInfo(op=q_.OperatorT(), op_name=q_.TFLOperationName.FULLY_CONNECTED,
+                     subgraph_op_index=-1,
+                     op_quant_config=q_.OpQuantizationConfig(weight_tensor_config=wcfg))
+    qsv = {"activation_tensor_qsv": {"hessian": np.array(k["hessian"], np.float32), "num_samples": 1}}
+    if c["qsv_min"] is not None:
+      qsv["min"], qsv["max"] = np.array(c["qsv_min"]), np.array(c["qsv_max"])
+    p = m.gptq.get_tensor_quant_params(info, cfg, w, qsv)
+    np.testing.assert_allclose(p.scale, np.array([[c["expected_scale"]]]), rtol=1e-6)
+    np.testing.assert_array_equal(p.quantized_data, np.array(c["expected"], np.int8))
+  info = q_.OpInfo(op=q_.OperatorT(), op_name=q_.TFLOperationName.FULLY_CONNECTED,
+                   subgraph_op_index=-1, op_quant_config=q_.OpQuantizationConfig())
+  p = m.gptq.get_tensor_quant_params(info, cfg, None,
+                                     {"min": np.array([[-1.1]]), "max": np.array([[2.2]])})
+  assert p.quantized_data is None
+  np.testing.assert_allclose(p.scale, np.array([[2.2 / 127]]))
+
+
+def test_apply_blockwise_scale_per_column_known_answer(m, known_answers):
+  k = known_answers["gptq_blockwise"]
+  w = (np.array(k["weights_times_127"], np.float32) / 127).astype(np.float32)
+  a = np.array(k["qsv_abs"])
+  zp, scale = O.zp_scale_from_min_max(-a, a, 8, True, "BLOCKWISE_32")
+  hinv = m.gptq._prepare_hessian_inverse(np.eye(4))
+  q = m.ops.gptq_apply(dev(m, w), dev(m, hinv), dev(m, scale.reshape(-1).astype(np.float32)),
+                       dev(m, zp.reshape(-1).astype(np.int32)), 2, k["block"], 8, True, False, 8)
+  assert (host(q) == k["expected_all"]).all()
+
+
+def test_medium_size_against_oracle(m):
+  """rows x d = 96 x 320 (five 64-column blocks), Hessian from 1024 tokens."""
+  rng = np.random.default_rng(11)
+  d, rows = 320, 96
+  w = (rng.standard_normal((rows, d)) * 0.05).astype(np.float32)
+  x = rng.standard_normal((4, 256, d)).astype(np.float32)
+  x[..., 7] *= 5
+  h = O.gptq_hessian(x)
+  ref = O.gptq_quant_params(w, 4, True, "CHANNELWISE",
+                            {"activation_tensor_qsv": {"hessian": h, "num_samples": 4}})
+  q_ = m.qtyping
+  cfg = q_.TensorQuantizationConfig(num_bits=4, symmetric=True,
+                                    granularity=q_.QuantGranularity.CHANNELWISE)
+  info = q_.OpInfo(op=q_.OperatorT(), op_name=q_.TFLOperationName.FULLY_CONNECTED,
+                   subgraph_op_index=0,
+                   op_quant_config=q_.OpQuantizationConfig(weight_tensor_config=cfg))
+  hg = m.gptq.hessian_of(x, np.array(4))
+  p = m.gptq.get_tensor_quant_params(info, cfg, w,
+                                     {"activation_tensor_qsv": {"hessian": hg, "num_samples": 4}})
+  assert np.array_equal(p.scale, ref["scale"])
+  diff = np.abs(p.quantized_data.astype(np.int32) - ref["quantized_data"].astype(np.int32))
+  assert diff.max() <= 1 and (diff != 0).mean() <= 5e-3
+  # GPTQ must beat plain rounding on the Hessian-weighted error it minimises
+  plain = O.min_max_quant_params(w, 4, True, "CHANNELWISE")["quantized_data"]
+  def loss(q):
+    e = (w - q.astype(np.float32) * ref["scale"]).astype(np.float64)
+    return np.einsum("ri,ij,rj->", e, h, e)
+  assert loss(p.quantized_data) < loss(plain)
