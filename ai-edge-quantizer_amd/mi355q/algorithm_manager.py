@@ -1,0 +1,102 @@
+"""Module-level algorithm registry with the GPU-backed algorithms registered.
+
+Same surface as ref: algorithm_manager.py:43-75 (singleton + re-exported bound
+methods + AlgorithmName) and the same registration pattern
+(ref :150-164, 310-320, 365-383, 406-419, 437-451):
+`functools.partial(materialize_fn, <alg>.get_tensor_quant_params)`.
+Registered here: the weight-bearing ops of the hot path (FULLY_CONNECTED, CONV_2D,
+DEPTHWISE_CONV_2D, EMBEDDING_LOOKUP) plus the virtual INPUT / OUTPUT ops.
+"""
+from __future__ import annotations
+
+import enum
+import functools
+
+from . import algorithm_manager_api
+from . import qtyping
+from .algorithms.uniform_quantize import common_quantize
+from .algorithms.uniform_quantize import gptq
+from .algorithms.uniform_quantize import hadamard_rotation
+from .algorithms.uniform_quantize import mse
+from .algorithms.uniform_quantize import naive_min_max_quantize
+from .algorithms.uniform_quantize import octav
+from .utils import qsv_utils
+
+_Op = qtyping.TFLOperationName
+
+_alg_manager_instance = algorithm_manager_api.AlgorithmManagerApi()
+
+get_quantization_func = _alg_manager_instance.get_quantization_func
+get_supported_ops = _alg_manager_instance.get_supported_ops
+get_update_qsv_func = _alg_manager_instance.get_update_qsv_func
+get_init_qsv_func = _alg_manager_instance.get_init_qsv_func
+register_op_quant_config_validation_func = (
+    _alg_manager_instance.register_op_quant_config_validation_func)
+register_config_check_policy_func = _alg_manager_instance.register_config_check_policy
+register_quantized_op = _alg_manager_instance.register_quantized_op
+is_op_registered = _alg_manager_instance.is_op_registered
+is_algorithm_registered = _alg_manager_instance.is_algorithm_registered
+check_op_quantization_config = _alg_manager_instance.check_op_quantization_config
+
+
+class AlgorithmName(str, enum.Enum):
+  """ref :65-75 (keys of algorithms outside the hot path are kept for recipe compatibility)."""
+  NO_QUANTIZE = "no_quantize"
+  MIN_MAX_UNIFORM_QUANT = naive_min_max_quantize.ALGORITHM_KEY
+  FLOAT_CASTING = "float_casting"
+  DEQUANTIZED_WEIGHT_RECOVERY = "dequantized_weight_recovery"
+  OCTAV = octav.ALGORITHM_KEY
+  HADAMARD_ROTATION = hadamard_rotation.CUSTOM_OP_ALGORITHM_KEY
+  DECOMPOSED_HADAMARD_ROTATION = hadamard_rotation.DECOMPOSED_ALGORITHM_KEY
+  MSE = mse.ALGORITHM_KEY
+  GPTQ = gptq.ALGORITHM_KEY
+  OSCAR = "OSCAR"
+
+
+_MATERIALIZERS = {
+    _Op.INPUT: common_quantize.materialize_input,
+    _Op.OUTPUT: common_quantize.materialize_output,
+    _Op.FULLY_CONNECTED: common_quantize.materialize_fc_conv,
+    _Op.CONV_2D: common_quantize.materialize_fc_conv,
+    _Op.DEPTHWISE_CONV_2D: common_quantize.materialize_fc_conv,
+    _Op.EMBEDDING_LOOKUP: common_quantize.materialize_embedding_lookup,
+}
+
+
+def _register_weight_algorithm(name, module, ops, calibration_func, update_qsv_func):
+  register_op_quant_config_validation_func(name, common_quantize.check_op_quantization_config)
+  register_config_check_policy_func(name, None)
+  for op in ops:
+    register_quantized_op(
+        name, op, naive_min_max_quantize.init_qsvs, calibration_func=calibration_func,
+        materialize_func=functools.partial(_MATERIALIZERS[op], module.get_tensor_quant_params),
+        update_qsv_func=update_qsv_func)
+
+
+# min/max: every op above (ref :78-164)
+_register_weight_algorithm(AlgorithmName.MIN_MAX_UNIFORM_QUANT, naive_min_max_quantize,
+                           list(_MATERIALIZERS), naive_min_max_quantize.min_max_calibrate,
+                           qsv_utils.moving_average_update)
+# OCTAV (ref :237-320) and MSE (ref :385-419): same op tables, min/max calibration
+for _name, _mod in ((AlgorithmName.OCTAV, octav), (AlgorithmName.MSE, mse)):
+  _register_weight_algorithm(_name, _mod, list(_MATERIALIZERS),
+                             naive_min_max_quantize.min_max_calibrate,
+                             qsv_utils.moving_average_update)
+# GPTQ (ref :421-451): Hessian-collecting calibration + Hessian-merging QSV update
+_register_weight_algorithm(AlgorithmName.GPTQ, gptq,
+                           [_Op.INPUT, _Op.OUTPUT, _Op.FULLY_CONNECTED], gptq.calibrate,
+                           qsv_utils.gptq_and_moving_average_update)
+
+# Hadamard rotation (ref :322-383): whole-op materializers, no partial
+for _name, _fc, _emb in (
+    (AlgorithmName.HADAMARD_ROTATION, hadamard_rotation.materialize_fully_connected_custom_op,
+     hadamard_rotation.materialize_embedding_lookup_custom_op),
+    (AlgorithmName.DECOMPOSED_HADAMARD_ROTATION,
+     hadamard_rotation.materialize_fully_connected_decomposed,
+     hadamard_rotation.materialize_embedding_lookup_decomposed)):
+  register_op_quant_config_validation_func(_name, common_quantize.check_op_quantization_config)
+  register_config_check_policy_func(_name, None)
+  for _op, _fn in ((_Op.FULLY_CONNECTED, _fc), (_Op.EMBEDDING_LOOKUP, _emb)):
+    register_quantized_op(_name, _op, naive_min_max_quantize.init_qsvs,
+                          calibration_func=naive_min_max_quantize.min_max_calibrate,
+                          materialize_func=_fn)

@@ -75,3 +75,90 @@ def get_tensor_quant_params(
       block_size=p.block_size,
       hadamard=qtyping.UniformQuantParams.HadamardRotationParams(
           random_binary_vector=vec, hadamard_size=h))
+
+
+# ------------------------------------------------------------ materializers ---
+# ref :206-500. The weight gets QUANTIZE_TENSOR with the rotated + OCTAV params;
+# the tensor on the other side of the matmul gets an INSERT_(DECOMPOSED_)HADAMARD_
+# ROTATION instruction carrying the same params (the graph rewrite itself is
+# outside the hot path).
+from ..utils import common_utils as _cu  # noqa: E402
+from ...utils import tfl_flatbuffer_utils as _fb  # noqa: E402
+
+_T = qtyping.QuantTransformation
+
+
+def _link(op_info, transformations, params=None):
+  return qtyping.OpToTensorParams(subgraph_op_id=op_info.subgraph_op_index,
+                                  parameters=params, transformations=transformations)
+
+
+def _weight_params(op_info, graph_info, weight_tensor, cache):
+  cfg = op_info.op_quant_config.weight_tensor_config
+  params = cache.lookup(weight_tensor.buffer, cfg) if cache is not None else None
+  if not params:
+    params = get_tensor_quant_params(op_info, cfg,
+                                     _fb.get_tensor_data(weight_tensor, graph_info.buffers), None)
+    if cache is not None:
+      cache.insert(weight_tensor.buffer, cfg, params)
+  return params
+
+
+def _materialize_fully_connected(op_info, graph_info, tensor_quant_params_cache,
+                                 is_decomposed=False, tensor_name_to_qsv=None):
+  del tensor_name_to_qsv
+  if op_info.op_quant_config.weight_tensor_config is None:
+    raise ValueError("Weight tensor quantization config is not provided for Hadamard Rotation"
+                     " quantization.")
+  tensors = graph_info.subgraph_tensors
+  inp, w, bias = (tensors[op_info.op.inputs[k]] for k in range(3))
+  out = tensors[op_info.op.outputs[0]]
+  params = _weight_params(op_info, graph_info, w, tensor_quant_params_cache)
+  rot = _T.INSERT_DECOMPOSED_HADAMARD_ROTATION if is_decomposed else _T.INSERT_HADAMARD_ROTATION
+  P = qtyping.TensorTransformationParams
+  return [
+      P(tensor_name=_fb.get_tensor_name(inp), consumers=[_link(op_info, [rot], params)]),
+      P(tensor_name=_fb.get_tensor_name(w), consumers=[_link(op_info, [_T.QUANTIZE_TENSOR], params)]),
+      P(tensor_name=_fb.get_tensor_name(bias), consumers=[_link(op_info, [_T.NO_QUANTIZE])]),
+      P(tensor_name=_fb.get_tensor_name(out), producer=_link(op_info, [_T.NO_QUANTIZE])),
+  ]
+
+
+def materialize_fully_connected_custom_op(op_info, graph_info, tensor_quant_params_cache,
+                                          tensor_name_to_qsv=None):
+  return _materialize_fully_connected(op_info, graph_info, tensor_quant_params_cache, False,
+                                      tensor_name_to_qsv)
+
+
+def materialize_fully_connected_decomposed(op_info, graph_info, tensor_quant_params_cache,
+                                           tensor_name_to_qsv=None):
+  return _materialize_fully_connected(op_info, graph_info, tensor_quant_params_cache, True,
+                                      tensor_name_to_qsv)
+
+
+def _materialize_embedding_lookup(op_info, graph_info, tensor_quant_params_cache,
+                                  is_decomposed=False, tensor_name_to_qsv=None):
+  del tensor_name_to_qsv
+  tensors = graph_info.subgraph_tensors
+  lookup, emb = tensors[op_info.op.inputs[0]], tensors[op_info.op.inputs[1]]
+  out = tensors[op_info.op.outputs[0]]
+  params = _weight_params(op_info, graph_info, emb, tensor_quant_params_cache)
+  rot = _T.INSERT_DECOMPOSED_HADAMARD_ROTATION if is_decomposed else _T.INSERT_HADAMARD_ROTATION
+  P = qtyping.TensorTransformationParams
+  return [
+      P(tensor_name=_fb.get_tensor_name(lookup), consumers=[_link(op_info, [_T.NO_QUANTIZE])]),
+      P(tensor_name=_fb.get_tensor_name(emb), consumers=[_link(op_info, [_T.QUANTIZE_TENSOR], params)]),
+      P(tensor_name=_fb.get_tensor_name(out), producer=_link(op_info, [rot], params)),
+  ]
+
+
+def materialize_embedding_lookup_custom_op(op_info, graph_info, tensor_quant_params_cache,
+                                           tensor_name_to_qsv=None):
+  return _materialize_embedding_lookup(op_info, graph_info, tensor_quant_params_cache, False,
+                                       tensor_name_to_qsv)
+
+
+def materialize_embedding_lookup_decomposed(op_info, graph_info, tensor_quant_params_cache,
+                                            tensor_name_to_qsv=None):
+  return _materialize_embedding_lookup(op_info, graph_info, tensor_quant_params_cache, True,
+                                       tensor_name_to_qsv)

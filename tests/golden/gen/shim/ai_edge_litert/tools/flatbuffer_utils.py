@@ -147,5 +147,15 @@ def _no(*a, **k):
   raise NotImplementedError("not available in the oracle shim")
 
 
-get_options_as = read_model = read_model_from_bytearray = write_model = _no
+read_model = read_model_from_bytearray = write_model = _no
+
+
+def get_options_as(op, cls):
+  """Options object of `op` when it is an instance of `cls`, else None."""
+  for attr in ("builtinOptions2", "builtinOptions"):
+    o = getattr(op, attr, None)
+    if isinstance(o, cls):
+      return o
+  return None
+
 convert_object_to_bytearray = _no
