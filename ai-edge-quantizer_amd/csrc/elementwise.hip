@@ -266,7 +266,7 @@ __device__ __forceinline__ void act_add(ActAcc& a, float v, float lo, float hi, 
   a.nan |= (v != v);
 }
 
-constexpr int kActBlocks = 32;  // blocks per tensor
+constexpr int kActBlocks = 64;  // blocks per tensor (<= 64: one wave finalizes)
 
 // grid (kActBlocks, count). partial layout: [count][kActBlocks][5]
 __global__ __launch_bounds__(256) void act_minmax_kernel(
@@ -284,12 +284,15 @@ __global__ __launch_bounds__(256) void act_minmax_kernel(
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const int64_t n4 = n / 4;
     int64_t i = tid;
-    for (; i + nthreads < n4; i += 2 * nthreads) {  // two 16-byte loads in flight
-      const float4 v = x4[i], w = x4[i + nthreads];
-      act_add(a, v.x, lo, hi, r); act_add(a, v.y, lo, hi, r);
-      act_add(a, v.z, lo, hi, r); act_add(a, v.w, lo, hi, r);
-      act_add(a, w.x, lo, hi, r); act_add(a, w.y, lo, hi, r);
-      act_add(a, w.z, lo, hi, r); act_add(a, w.w, lo, hi, r);
+    for (; i + 3 * nthreads < n4; i += 4 * nthreads) {  // four 16-byte loads in flight per lane
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = x4[i + u * nthreads];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        act_add(a, v[u].x, lo, hi, r); act_add(a, v[u].y, lo, hi, r);
+        act_add(a, v[u].z, lo, hi, r); act_add(a, v[u].w, lo, hi, r);
+      }
     }
     for (; i < n4; i += nthreads) {
       const float4 v = x4[i];

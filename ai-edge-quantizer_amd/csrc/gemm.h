@@ -20,7 +20,15 @@ struct GemmArgs {
                        // 2: A(i,k) == 0 for k < i and B(k,j) == 0 for k < j: k >= max(i0, j0)
 };
 
+// Number of K slices launch_gemm would use for this shape (1 = no split) and the
+// workspace that needs; pass a workspace to launch_gemm to allow the split.
 template <typename T>
-int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st);
+int gemm_pick_splitk(int M, int N, int K);
+template <typename T>
+size_t gemm_splitk_workspace_bytes(int M, int N, int K);
+
+template <typename T>
+int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws = nullptr,
+                    size_t splitk_ws_bytes = 0);
 
 }  // namespace mi355q

@@ -12,9 +12,14 @@
 // sgemm-class numerics; see MI355X_MICROARCH.md.
 //
 // Structure: 256 threads = 4 waves in a 2x2 grid; each wave owns a 2x2 arrangement
-// of MFMA tiles; K is consumed BK = 16 at a time through LDS tiles stored k-major
-// ([k][i]) so that an MFMA operand fragment (lane -> (i = lane % T, k = lane / T))
-// is one conflict-free ds_read per lane.
+// of MFMA tiles (block tile 128x128 for float, 64x64 for double). K is consumed
+// BK = 16 at a time through LDS tiles stored k-major ([k][i]) so that an MFMA operand
+// fragment (lane -> (i = lane % T, k = lane / T)) is one conflict-free ds_read per
+// lane. The LDS tiles are double buffered: the 16-byte global loads of tile t+1 are
+// issued before the MFMAs of tile t and land in the other buffer afterwards, one
+// barrier per K step. Long-K / few-tile shapes (the Hessian at d = 2048: K = 65536,
+// 256 tiles) are split along K over gridDim.z into a workspace and summed in a fixed
+// order by a second kernel (deterministic, unlike atomics).
 #include "gemm.h"
 
 namespace mi355q {
@@ -26,17 +31,21 @@ template <typename T>
 struct Tile;
 template <>
 struct Tile<float> {
-  static constexpr int MF = 32;        // MFMA tile edge
-  static constexpr int KF = 2;         // k per MFMA
-  static constexpr int BM = 128;       // block tile edge (2 waves x 2 MFMA tiles x 32)
+  static constexpr int MF = 32;   // MFMA tile edge
+  static constexpr int KF = 2;    // k per MFMA
+  static constexpr int BM = 128;  // block tile edge (2 waves x 2 MFMA tiles x 32)
+  static constexpr int VEC = 4;   // elements per 16-byte load
   using Acc = __attribute__((ext_vector_type(16))) float;
+  using Vec = float4;
 };
 template <>
 struct Tile<double> {
   static constexpr int MF = 16;
   static constexpr int KF = 4;
-  static constexpr int BM = 64;        // 2 waves x 2 MFMA tiles x 16
+  static constexpr int BM = 64;  // 2 waves x 2 MFMA tiles x 16
+  static constexpr int VEC = 2;
   using Acc = __attribute__((ext_vector_type(4))) double;
+  using Vec = double2;
 };
 
 __device__ __forceinline__ Tile<float>::Acc mfma(float a, float b, Tile<float>::Acc c) {
@@ -52,14 +61,87 @@ __device__ __forceinline__ int acc_row(float, int reg, int lane) {
 }
 __device__ __forceinline__ int acc_row(double, int reg, int lane) { return (lane >> 4) + 4 * reg; }
 
+__device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+__device__ __forceinline__ double comp(const double2& v, int c) { return c == 0 ? v.x : v.y; }
+
+// How one operand tile (BM x BK, "m" = the non-k index) is fetched.
+enum LoadMode { kGeneric = 0, kMFast = 1, kKFast = 2 };
+
+// Per-thread staging registers of one operand tile: 2 x 16 bytes.
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g) {
+struct Stage {
+  typename Tile<T>::Vec v[2];
+};
+
+// Global -> registers. p(m, k) = base + m*s_m + k*s_k; the tile origin is (m0, k0).
+template <typename T>
+__device__ __forceinline__ void load_tile(Stage<T>& st, const T* __restrict__ base, long long s_m,
+                                          long long s_k, int m0, int k0, int M, int K, int mode, int tid) {
+  using TL = Tile<T>;
+  constexpr int BM = TL::BM, VEC = TL::VEC;
+  using Vec = typename TL::Vec;
+  const bool inside = m0 + BM <= M && k0 + BK <= K;
+  if (mode == kMFast && inside) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int e = tid + 256 * l, mv = e % (BM / VEC), k = e / (BM / VEC);
+      st.v[l] = *reinterpret_cast<const Vec*>(base + (m0 + mv * VEC) * s_m + static_cast<long long>(k0 + k) * s_k);
+    }
+  } else if (mode == kKFast && inside) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int e = tid + 256 * l, kv = e % (BK / VEC), m = e / (BK / VEC);
+      st.v[l] = *reinterpret_cast<const Vec*>(base + static_cast<long long>(m0 + m) * s_m + (k0 + kv * VEC) * s_k);
+    }
+  } else {  // generic strides, ragged edges: scalar loads in the kMFast register layout
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int e = tid + 256 * l, mv = e % (BM / VEC), k = e / (BM / VEC);
+      T tmp[VEC];
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        const long long m = m0 + mv * VEC + c, kk = k0 + k;
+        tmp[c] = (m < M && kk < K) ? base[m * s_m + kk * s_k] : T(0);
+      }
+      if constexpr (VEC == 4) st.v[l] = Vec{tmp[0], tmp[1], tmp[2], tmp[3]};
+      else st.v[l] = Vec{tmp[0], tmp[1]};
+    }
+  }
+}
+
+// Registers -> LDS tile [BK][BM + PAD] (k-major).
+template <typename T, int LD>
+__device__ __forceinline__ void store_tile(const Stage<T>& st, T (*lds)[LD], int m0, int k0, int M, int K,
+                                           int mode, int tid) {
+  using TL = Tile<T>;
+  constexpr int BM = TL::BM, VEC = TL::VEC;
+  using Vec = typename TL::Vec;
+  const bool inside = m0 + BM <= M && k0 + BK <= K;
+  if (mode == kKFast && inside) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int e = tid + 256 * l, kv = e % (BK / VEC), m = e / (BK / VEC);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) lds[kv * VEC + c][m] = comp(st.v[l], c);
+    }
+  } else {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int e = tid + 256 * l, mv = e % (BM / VEC), k = e / (BM / VEC);
+      *reinterpret_cast<Vec*>(&lds[k][mv * VEC]) = st.v[l];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g, int a_mode, int b_mode, int k_chunk,
+                                                   T* __restrict__ partial) {
   using TL = Tile<T>;
   constexpr int BM = TL::BM, MF = TL::MF, KF = TL::KF;
-  constexpr int PAD = 4;
+  constexpr int LD = BM + TL::VEC;  // keeps every row 16-byte aligned, breaks the power-of-2 stride
   constexpr int NREG = sizeof(typename TL::Acc) / sizeof(T);
-  __shared__ T As[BK][BM + PAD];
-  __shared__ T Bs[BK][BM + PAD];
+  __shared__ __attribute__((aligned(16))) T As[2][BK][LD];
+  __shared__ __attribute__((aligned(16))) T Bs[2][BK][LD];
 
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (g.lower_only && bj > bi) return;  // only tiles touching the lower triangle
@@ -76,41 +158,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g) {
 #pragma unroll
       for (int r = 0; r < NREG; ++r) acc[a][b][r] = T(0);
 
-  const bool a_k_fast = g.a_k == 1 && g.a_i != 1;  // which index is contiguous in memory
-  const bool b_k_fast = g.b_k == 1 && g.b_j != 1;
-
   int k_begin = 0, k_end = g.K;
   if (g.k_mode == 1) k_end = min(g.K, i0 + BM);
   if (g.k_mode == 2) k_begin = (max(i0, j0) / BK) * BK;
+  if (k_chunk > 0) {  // split-K slice of this z
+    k_begin = max(k_begin, static_cast<int>(blockIdx.z) * k_chunk);
+    k_end = min(k_end, (static_cast<int>(blockIdx.z) + 1) * k_chunk);
+  }
+
+  Stage<T> sa, sb;
+  if (k_begin < k_end) {
+    load_tile<T>(sa, g.A, g.a_i, g.a_k, i0, k_begin, g.M, g.K, a_mode, tid);
+    load_tile<T>(sb, g.B, g.b_j, g.b_k, j0, k_begin, g.N, g.K, b_mode, tid);
+    store_tile<T, LD>(sa, As[0], i0, k_begin, g.M, g.K, a_mode, tid);
+    store_tile<T, LD>(sb, Bs[0], j0, k_begin, g.N, g.K, b_mode, tid);
+  }
+  __syncthreads();
+  int buf = 0;
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-    // ---- stage A(i0:i0+BM, k0:k0+BK) and B(k0:k0+BK, j0:j0+BM) into LDS
-#pragma unroll
-    for (int e = tid; e < BM * BK; e += 256) {
-      int i, k;
-      if (a_k_fast) { k = e % BK; i = e / BK; } else { i = e % BM; k = e / BM; }
-      const long long gi = i0 + i, gk = k0 + k;
-      As[k][i] = (gi < g.M && gk < g.K) ? g.A[gi * g.a_i + gk * g.a_k] : T(0);
+    const int kn = k0 + BK;
+    const bool more = kn < k_end;
+    if (more) {  // next tile's global loads fly while this tile's MFMAs run
+      load_tile<T>(sa, g.A, g.a_i, g.a_k, i0, kn, g.M, g.K, a_mode, tid);
+      load_tile<T>(sb, g.B, g.b_j, g.b_k, j0, kn, g.N, g.K, b_mode, tid);
     }
-#pragma unroll
-    for (int e = tid; e < BM * BK; e += 256) {
-      int j, k;
-      if (b_k_fast) { k = e % BK; j = e / BK; } else { j = e % BM; k = e / BM; }
-      const long long gj = j0 + j, gk = k0 + k;
-      Bs[k][j] = (gj < g.N && gk < g.K) ? g.B[gk * g.b_k + gj * g.b_j] : T(0);
-    }
-    __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < BK; kk += KF) {
-      const T a0 = As[kk + fk][wi + fi], a1 = As[kk + fk][wi + MF + fi];
-      const T b0 = Bs[kk + fk][wj + fi], b1 = Bs[kk + fk][wj + MF + fi];
+      const T a0 = As[buf][kk + fk][wi + fi], a1 = As[buf][kk + fk][wi + MF + fi];
+      const T b0 = Bs[buf][kk + fk][wj + fi], b1 = Bs[buf][kk + fk][wj + MF + fi];
       acc[0][0] = mfma(a0, b0, acc[0][0]);
       acc[0][1] = mfma(a0, b1, acc[0][1]);
       acc[1][0] = mfma(a1, b0, acc[1][0]);
       acc[1][1] = mfma(a1, b1, acc[1][1]);
     }
+    if (more) {
+      store_tile<T, LD>(sa, As[buf ^ 1], i0, kn, g.M, g.K, a_mode, tid);
+      store_tile<T, LD>(sb, Bs[buf ^ 1], j0, kn, g.N, g.K, b_mode, tid);
+    }
     __syncthreads();
+    buf ^= 1;
   }
-  // ---- epilogue: C = beta*C + alpha*P  (P rounded first, as sgemm-then-update does)
+  // ---- epilogue
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -120,27 +208,100 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g) {
         const long long i = i0 + wi + a * MF + acc_row(T(0), r, lane);
         const long long j = j0 + wj + b * MF + fi;
         if (i < g.M && j < g.N && (!g.lower_only || j <= i)) {
-          T* c = g.C + i * g.c_i + j * g.c_j;
-          const T p = g.alpha * acc[a][b][r];
-          *c = (g.beta == T(0)) ? p : g.beta * (*c) + p;
+          if (partial != nullptr) {  // raw partial sums; alpha / beta applied by the reducer
+            partial[(static_cast<long long>(blockIdx.z) * g.M + i) * g.N + j] = acc[a][b][r];
+          } else {
+            T* c = g.C + i * g.c_i + j * g.c_j;
+            const T p = g.alpha * acc[a][b][r];  // P is rounded first, as sgemm-then-update does
+            *c = (g.beta == T(0)) ? p : g.beta * (*c) + p;
+          }
         }
       }
+}
+
+// C = beta*C + alpha * (partial[0] + partial[1] + ... ), slices added in order.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs<T> g, const T* __restrict__ partial,
+                                                            int slices) {
+  const long long n = static_cast<long long>(g.M) * g.N;
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
+    const long long i = e / g.N, j = e % g.N;
+    if (g.lower_only && j > i) continue;
+    T s = partial[e];
+    for (int z = 1; z < slices; ++z) s = s + partial[z * n + e];
+    T* c = g.C + i * g.c_i + j * g.c_j;
+    const T p = g.alpha * s;
+    *c = (g.beta == T(0)) ? p : g.beta * (*c) + p;
+  }
+}
+
+template <typename T>
+int pick_mode(const T* base, long long s_m, long long s_k) {
+  constexpr int VEC = Tile<T>::VEC;
+  const bool aligned = (reinterpret_cast<uintptr_t>(base) & 15u) == 0;
+  if (aligned && s_m == 1 && s_k % VEC == 0) return kMFast;
+  if (aligned && s_k == 1 && s_m % VEC == 0) return kKFast;
+  return kGeneric;
 }
 
 }  // namespace
 
 template <typename T>
-int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st) {
+size_t gemm_splitk_workspace_bytes(int M, int N, int K) {
+  const int s = gemm_pick_splitk<T>(M, N, K);
+  return s > 1 ? static_cast<size_t>(s) * M * N * sizeof(T) : 0;
+}
+
+template <typename T>
+int gemm_pick_splitk(int M, int N, int K) {
+  constexpr int BM = Tile<T>::BM;
+  const long long tiles = static_cast<long long>((M + BM - 1) / BM) * ((N + BM - 1) / BM);
+  if (tiles >= 1024 || K < 4096) return 1;
+  int s = static_cast<int>((1024 + tiles - 1) / tiles);
+  const int max_s = K / 1024;  // >= 1024 of K per slice
+  if (s > max_s) s = max_s;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+
+template <typename T>
+int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_t splitk_ws_bytes) {
   if (g.M <= 0 || g.N <= 0) return MI355Q_OK;
   constexpr int BM = Tile<T>::BM;
-  const dim3 grid(static_cast<unsigned>((g.N + BM - 1) / BM), static_cast<unsigned>((g.M + BM - 1) / BM));
-  hipLaunchKernelGGL((gemm_kernel<T>), grid, dim3(256), 0, st, g);
-  MI355Q_CHECK_LAUNCH("gemm launch");
+  const int a_mode = pick_mode<T>(g.A, g.a_i, g.a_k);
+  const int b_mode = pick_mode<T>(g.B, g.b_j, g.b_k);
+  int slices = 1;
+  if (splitk_ws != nullptr && g.k_mode == 0) {
+    slices = gemm_pick_splitk<T>(g.M, g.N, g.K);
+    if (static_cast<size_t>(slices) * g.M * g.N * sizeof(T) > splitk_ws_bytes) slices = 1;
+  }
+  const dim3 grid(static_cast<unsigned>((g.N + BM - 1) / BM), static_cast<unsigned>((g.M + BM - 1) / BM),
+                  static_cast<unsigned>(slices));
+  if (slices > 1) {
+    int chunk = (g.K + slices - 1) / slices;
+    chunk = (chunk + BK - 1) / BK * BK;
+    hipLaunchKernelGGL((gemm_kernel<T>), grid, dim3(256), 0, st, g, a_mode, b_mode, chunk,
+                       static_cast<T*>(splitk_ws));
+    MI355Q_CHECK_LAUNCH("gemm launch");
+    long long n = static_cast<long long>(g.M) * g.N;
+    unsigned blocks = static_cast<unsigned>((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, g,
+                       static_cast<const T*>(splitk_ws), slices);
+    MI355Q_CHECK_LAUNCH("gemm split-k reduce launch");
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<T>), grid, dim3(256), 0, st, g, a_mode, b_mode, 0, static_cast<T*>(nullptr));
+    MI355Q_CHECK_LAUNCH("gemm launch");
+  }
   return MI355Q_OK;
 }
 
-template int32_t launch_gemm<float>(const GemmArgs<float>&, hipStream_t);
-template int32_t launch_gemm<double>(const GemmArgs<double>&, hipStream_t);
+template int32_t launch_gemm<float>(const GemmArgs<float>&, hipStream_t, void*, size_t);
+template int32_t launch_gemm<double>(const GemmArgs<double>&, hipStream_t, void*, size_t);
+template int gemm_pick_splitk<float>(int, int, int);
+template int gemm_pick_splitk<double>(int, int, int);
+template size_t gemm_splitk_workspace_bytes<float>(int, int, int);
+template size_t gemm_splitk_workspace_bytes<double>(int, int, int);
 
 }  // namespace mi355q
 
@@ -159,7 +320,7 @@ int32_t gemm_entry(const void* A, int64_t a_i, int64_t a_k, const void* B, int64
   GemmArgs<T> g{static_cast<const T*>(A), a_i, a_k, static_cast<const T*>(B), b_k, b_j,
                 static_cast<T*>(C), c_i, c_j, static_cast<int>(M), static_cast<int>(N),
                 static_cast<int>(K), static_cast<T>(alpha), static_cast<T>(beta), lower_only, 0};
-  return launch_gemm<T>(g, as_stream(stream));
+  return launch_gemm<T>(g, as_stream(stream), nullptr, 0);
 }
 }  // namespace
 

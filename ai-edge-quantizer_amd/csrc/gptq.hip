@@ -71,12 +71,19 @@ __global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __
 }
 
 // ---------------------------------------------------------- Cholesky ----
-// Unblocked lower Cholesky of the nb x nb diagonal block at (k,k); info != 0 if not PD.
-__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int d, int k, int nb, int* info) {
+// Unblocked lower Cholesky of the nb x nb diagonal block at (k,k) followed by the
+// inverse of that triangular factor. L_kk goes back into `a`; inv(L_kk) (zeros above
+// the diagonal, identity padding past nb) goes to `dinv` (NB x NB, row-major): the
+// panel solve and the triangular-inverse sweep then are plain MFMA GEMMs.
+// info != 0 if a pivot is not positive.
+__global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ a, int d, int k, int nb,
+                                                       double* __restrict__ dinv, int* info) {
   __shared__ double s[NB][NB + 1];
+  __shared__ double x[NB][NB + 1];
   for (int e = threadIdx.x; e < NB * NB; e += 256) {
     const int r = e / NB, c = e % NB;
     s[r][c] = (r < nb && c <= r) ? a[static_cast<long long>(k + r) * d + k + c] : 0.0;
+    x[r][c] = 0.0;
   }
   __syncthreads();
   for (int j = 0; j < nb; ++j) {
@@ -94,63 +101,48 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int 
     }
     __syncthreads();
   }
-  for (int e = threadIdx.x; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    if (r < nb && c <= r) a[static_cast<long long>(k + r) * d + k + c] = s[r][c];
-  }
-}
-
-// Panel solve: rows below the diagonal block, X * Lkk^T = A[r, k:k+nb]; one thread per row.
-__global__ __launch_bounds__(256) void trsm_panel_kernel(double* __restrict__ a, int d, int k, int nb) {
-  __shared__ double l[NB][NB + 1];
-  for (int e = threadIdx.x; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    l[r][c] = (r < nb && c <= r) ? a[static_cast<long long>(k + r) * d + k + c] : (r == c ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  const int r = k + nb + blockIdx.x * 256 + threadIdx.x;
-  if (r >= d) return;
-  double* row = a + static_cast<long long>(r) * d + k;
-  double x[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) x[j] = j < nb ? row[j] : 0.0;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    double v = x[j];
-#pragma unroll
-    for (int m = 0; m < j; ++m) v -= x[m] * l[j][m];
-    x[j] = v / l[j][j];
-  }
-#pragma unroll
-  for (int j = 0; j < NB; ++j)
-    if (j < nb) row[j] = x[j];
-}
-
-// ------------------------------------------------- triangular inverse ----
-// In-place inverse of the lower-triangular nb x nb block at (k,k); thread c solves column c.
-__global__ __launch_bounds__(64) void trti2_kernel(double* __restrict__ a, int d, int k, int nb,
-                                                  double* __restrict__ neg_inv /* NB*NB, row-major, may be null */) {
-  __shared__ double l[NB][NB + 1];
-  __shared__ double x[NB][NB + 1];
-  for (int e = threadIdx.x; e < NB * NB; e += 64) {
-    const int r = e / NB, c = e % NB;
-    l[r][c] = (r < nb && c <= r) ? a[static_cast<long long>(k + r) * d + k + c] : (r == c ? 1.0 : 0.0);
-    x[r][c] = 0.0;
-  }
-  __syncthreads();
+  // inverse: thread c solves L x = e_c by forward substitution
   const int c = threadIdx.x;
-  if (c < nb) {
-    for (int r = c; r < nb; ++r) {  // forward substitution for L x = e_c
-      double v = (r == c) ? 1.0 : 0.0;
-      for (int m = c; m < r; ++m) v -= l[r][m] * x[m][c];
-      x[r][c] = v / l[r][r];
+  if (c < NB) {
+    if (c < nb) {
+      for (int r = c; r < nb; ++r) {
+        double v = (r == c) ? 1.0 : 0.0;
+        for (int m = c; m < r; ++m) v -= s[r][m] * x[m][c];
+        x[r][c] = v / s[r][r];
+      }
+    } else {
+      x[c][c] = 1.0;
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < NB * NB; e += 64) {
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
     const int r = e / NB, cc = e % NB;
-    if (r < nb && cc <= r) a[static_cast<long long>(k + r) * d + k + cc] = x[r][cc];
-    if (neg_inv != nullptr) neg_inv[e] = (r < nb && cc < nb) ? -x[r][cc] : 0.0;
+    if (r < nb && cc <= r) a[static_cast<long long>(k + r) * d + k + cc] = s[r][cc];
+    dinv[e] = x[r][cc];
+  }
+}
+
+// dst[i, 0:nb] (row stride ld_dst) = src[i, 0:nb] (row stride ld_src), i < m
+__global__ __launch_bounds__(256) void copy_panel_kernel(const double* __restrict__ src, long long ld_src,
+                                                        double* __restrict__ dst, long long ld_dst, int m,
+                                                        int nb) {
+  const long long n = static_cast<long long>(m) * nb;
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
+    const long long i = e / nb, j = e % nb;
+    dst[i * ld_dst + j] = src[i * ld_src + j];
+  }
+}
+
+// Every diagonal block of `a` := its inverse (lower part of dinv[block]).
+__global__ __launch_bounds__(256) void put_diag_inverses_kernel(double* __restrict__ a, int d,
+                                                               const double* __restrict__ dinv) {
+  const int kb = blockIdx.x, k = kb * NB;
+  const int nb = d - k < NB ? d - k : NB;
+  const double* x = dinv + static_cast<long long>(kb) * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    if (r < nb && c <= r) a[static_cast<long long>(k + r) * d + k + c] = x[e];
   }
 }
 
@@ -256,8 +248,10 @@ inline unsigned grid1d(long long n) {
 
 using namespace mi355q;
 
-extern "C" size_t mi355q_gptq_xtx_workspace_bytes(int64_t d) {
-  return d > 0 ? static_cast<size_t>(d) * d * sizeof(float) : 0;
+extern "C" size_t mi355q_gptq_xtx_workspace_bytes(int64_t n, int64_t d) {
+  if (d <= 0 || d > 0x7FFFFFFF || n > 0x7FFFFFFF) return 0;
+  return static_cast<size_t>(d) * d * sizeof(float) +
+         gemm_splitk_workspace_bytes<float>(static_cast<int>(d), static_cast<int>(d), static_cast<int>(n < 0 ? 0 : n));
 }
 
 extern "C" int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, double alpha,
@@ -268,15 +262,16 @@ extern "C" int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, dou
   if (d == 0) return MI355Q_OK;
   if (d > 0x7FFFFFFF || n > 0x7FFFFFFF) return fail(MI355Q_UNSUPPORTED, "dimension too large");
   if (!x || !hessian_out) return fail(MI355Q_BAD_ARG, "null pointer");
-  const size_t need = mi355q_gptq_xtx_workspace_bytes(d);
+  const size_t need = mi355q_gptq_xtx_workspace_bytes(n, d);
   if (!workspace || workspace_bytes < need)
     return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
   hipStream_t st = as_stream(stream);
   float* p = static_cast<float*>(workspace);
-  // P = X^T X : A(i,k) = X[k][i], B(k,j) = X[k][j]
+  float* split_ws = p + d * d;
+  // P = X^T X : A(i,k) = X[k][i], B(k,j) = X[k][j]; long K is split over gridDim.z
   GemmArgs<float> g{x, 1, d, x, d, 1, p, d, 1, static_cast<int>(d), static_cast<int>(d),
                     static_cast<int>(n), 1.0f, 0.0f, 0, 0};
-  if (int32_t s = launch_gemm<float>(g, st)) return s;
+  if (int32_t s = launch_gemm<float>(g, st, split_ws, need - static_cast<size_t>(d) * d * sizeof(float))) return s;
   hipLaunchKernelGGL(scale_to_f64_kernel, dim3(grid1d(d * d)), dim3(256), 0, st, p,
                      static_cast<long long>(d) * d, alpha, hessian_out);
   MI355Q_CHECK_LAUNCH("hessian scale launch");
@@ -297,8 +292,10 @@ extern "C" int32_t mi355q_gptq_hessian_merge_f64(const double* h_cur, double n_c
 }
 
 extern "C" size_t mi355q_gptq_hinv_workspace_bytes(int64_t d) {
-  // two d x d FP64 matrices + a d x NB FP64 panel + small scalars
-  return d > 0 ? (static_cast<size_t>(d) * d * 2 + static_cast<size_t>(d) * NB + NB * NB + 8) * sizeof(double) : 0;
+  // two d x d FP64 matrices + a d x NB panel + one NB x NB inverse per diagonal block + scalars
+  if (d <= 0) return 0;
+  const size_t nblocks = static_cast<size_t>((d + NB - 1) / NB);
+  return (static_cast<size_t>(d) * d * 2 + static_cast<size_t>(d) * NB + nblocks * NB * NB + 8) * sizeof(double);
 }
 
 extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, double damp_factor,
@@ -314,49 +311,58 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
     return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
   const int d = static_cast<int>(d64);
   hipStream_t st = as_stream(stream);
+  const int nblocks = (d + NB - 1) / NB;
   double* a = static_cast<double*>(workspace);           // L, then L^-1 (lower, zeros above)
   double* out = a + static_cast<size_t>(d) * d;          // lower(H^-1) in FP64
   double* panel = out + static_cast<size_t>(d) * d;      // d x NB temporary
-  double* neg_inv = panel + static_cast<size_t>(d) * NB; // NB x NB
-  double* scal = neg_inv + NB * NB;
+  double* dinv = panel + static_cast<size_t>(d) * NB;    // nblocks x (NB x NB): inv(L_kk)
+  double* scal = dinv + static_cast<size_t>(nblocks) * NB * NB;
   if (hipMemsetAsync(info_out, 0, sizeof(int32_t), st) != hipSuccess)
     return fail(MI355Q_HIP_ERROR, "hipMemsetAsync failed");
   hipLaunchKernelGGL(diag_sum_kernel, dim3(1), dim3(256), 0, st, hessian, d, scal);
   hipLaunchKernelGGL(copy_damped_lower_kernel, dim3(grid1d(static_cast<long long>(d) * d)), dim3(256), 0, st,
                      hessian, d, scal, damp_factor, a);
   MI355Q_CHECK_LAUNCH("gptq damp launch");
-  // ---- blocked right-looking Cholesky (lower), FP64
-  for (int k = 0; k < d; k += NB) {
+  // ---- blocked right-looking Cholesky (lower), FP64. Per 64-column step:
+  //   diagonal block: factor + invert (one workgroup)
+  //   panel:    L21 = A21 * inv(L11)^T                      (MFMA GEMM)
+  //   trailing: A22 -= L21 * L21^T, lower triangle only     (MFMA GEMM)
+  for (int kb = 0; kb < nblocks; ++kb) {
+    const int k = kb * NB;
     const int nb = d - k < NB ? d - k : NB;
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, info_out);
+    double* inv11 = dinv + static_cast<size_t>(kb) * NB * NB;
+    hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, inv11, info_out);
     const int m = d - k - nb;
     if (m > 0) {
-      hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + 255) / 256), dim3(256), 0, st, a, d, k, nb);
-      double* l21 = a + static_cast<long long>(k + nb) * d + k;
+      double* a21 = a + static_cast<long long>(k + nb) * d + k;
       double* a22 = a + static_cast<long long>(k + nb) * d + k + nb;
-      GemmArgs<double> g{l21, d, 1, l21, 1, d, a22, d, 1, m, m, nb, -1.0, 1.0, 1, 0};
-      if (int32_t s = launch_gemm<double>(g, st)) return s;
+      // panel(i,j) = sum_c A21[i][c] * inv11[j][c]
+      GemmArgs<double> gs{a21, d, 1, inv11, 1, NB, panel, NB, 1, m, nb, nb, 1.0, 0.0, 0, 0};
+      if (int32_t s = launch_gemm<double>(gs, st)) return s;
+      hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m) * nb)), dim3(256), 0, st,
+                         panel, static_cast<long long>(NB), a21, static_cast<long long>(d), m, nb);
+      GemmArgs<double> gt{panel, NB, 1, panel, 1, NB, a22, d, 1, m, m, nb, -1.0, 1.0, 1, 0};
+      if (int32_t s = launch_gemm<double>(gt, st)) return s;
     }
   }
   MI355Q_CHECK_LAUNCH("gptq cholesky launch");
-  // ---- blocked in-place inverse of the lower-triangular factor (LAPACK dtrtri order)
-  const int nblocks = (d + NB - 1) / NB;
+  // ---- in-place inverse of the lower-triangular factor, block columns right to left
+  // (LAPACK dtrtri order):  A21 <- -(A22^-1 * A21) * A11^-1 ;  A11 <- A11^-1
   for (int jb = nblocks - 1; jb >= 0; --jb) {
     const int k = jb * NB;
     const int nb = d - k < NB ? d - k : NB;
     const int m = d - k - nb;
-    hipLaunchKernelGGL(trti2_kernel, dim3(1), dim3(64), 0, st, a, d, k, nb, neg_inv);
     if (m > 0) {
       double* a21 = a + static_cast<long long>(k + nb) * d + k;
       double* a22 = a + static_cast<long long>(k + nb) * d + k + nb;  // already inverted
-      // panel = A22inv * A21        (A22inv lower triangular)
+      const double* inv11 = dinv + static_cast<size_t>(jb) * NB * NB;
       GemmArgs<double> g1{a22, d, 1, a21, d, 1, panel, NB, 1, m, nb, m, 1.0, 0.0, 0, 1};
       if (int32_t s = launch_gemm<double>(g1, st)) return s;
-      // A21 = panel * (-inv(A11))
-      GemmArgs<double> g2{panel, NB, 1, neg_inv, NB, 1, a21, d, 1, m, nb, nb, 1.0, 0.0, 0, 0};
+      GemmArgs<double> g2{panel, NB, 1, inv11, NB, 1, a21, d, 1, m, nb, nb, -1.0, 0.0, 0, 0};
       if (int32_t s = launch_gemm<double>(g2, st)) return s;
     }
   }
+  hipLaunchKernelGGL(put_diag_inverses_kernel, dim3(nblocks), dim3(256), 0, st, a, d, dinv);
   MI355Q_CHECK_LAUNCH("gptq trtri launch");
   // ---- H^-1 = L^-T L^-1 : out(i,j) = sum_k Linv[k][i] * Linv[k][j], k >= max(i,j); lower half
   GemmArgs<double> gp{a, 1, d, a, d, 1, out, d, 1, d, d, d, 1.0, 0.0, 1, 2};

@@ -48,7 +48,7 @@ PROTOTYPES = {
                                 c_i64, c_i64, c_i64, c_f32, c_f32, c_i32, c_ptr]),
     "mi355q_gemm_f64": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64,
                                 c_i64, c_i64, c_i64, c_f64, c_f64, c_i32, c_ptr]),
-    "mi355q_gptq_xtx_workspace_bytes": (c_size, [c_i64]),
+    "mi355q_gptq_xtx_workspace_bytes": (c_size, [c_i64, c_i64]),
     "mi355q_gptq_xtx_f32": (c_i32, [c_ptr, c_i64, c_i64, c_f64, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_gptq_hessian_merge_f64": (c_i32, [c_ptr, c_f64, c_ptr, c_f64, c_i64, c_ptr, c_ptr]),
     "mi355q_gptq_hinv_workspace_bytes": (c_size, [c_i64]),

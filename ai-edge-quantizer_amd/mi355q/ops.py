@@ -283,7 +283,7 @@ def gptq_xtx(x: torch.Tensor, alpha: float) -> torch.Tensor:
   n, d = x.shape
   h = rt.empty((d, d), torch.float64)
   L = _ffi.lib()
-  nbytes = L.mi355q_gptq_xtx_workspace_bytes(d)
+  nbytes = L.mi355q_gptq_xtx_workspace_bytes(n, d)
   ws = rt.empty((max(nbytes, 1),), torch.uint8)
   _ffi.check(L.mi355q_gptq_xtx_f32(rt.ptr(x), n, d, float(alpha), rt.ptr(h), rt.ptr(ws), nbytes,
                                    rt.stream_ptr()))

@@ -228,9 +228,10 @@ int32_t mi355q_gemm_f64(const double* A, int64_t a_i, int64_t a_k, const double*
  * FP32 on the MFMA units, alpha = 2 / num_samples applied in FLOAT64 exactly as
  * `(2.0 / num_samples) * x.T.dot(x)` promotes in the reference.
  * ref: algorithms/uniform_quantize/gptq.py:100-107
- * workspace: mi355q_gptq_xtx_workspace_bytes(d) bytes.
+ * workspace: mi355q_gptq_xtx_workspace_bytes(n, d) bytes (X^T X in FP32 plus the
+ * split-K partial sums used when d is small and n is long).
  * ------------------------------------------------------------------------ */
-size_t mi355q_gptq_xtx_workspace_bytes(int64_t d);
+size_t mi355q_gptq_xtx_workspace_bytes(int64_t n, int64_t d);
 int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, double alpha,
                             double* hessian_out, void* workspace, size_t workspace_bytes,
                             void* stream);

@@ -54,7 +54,7 @@ def test_argument_validation_without_gpu(lib):
     _ffi.check(lib.mi355q_pack_bits(None, -1, 4, None, None))
   assert lib.mi355q_minmax_workspace_bytes(1, 1, 1 << 24) > 0
   assert lib.mi355q_minmax_workspace_bytes(1, 4096, 4096) == 0
-  assert lib.mi355q_act_minmax_workspace_bytes(3) == 3 * 32 * 5 * 4
+  assert lib.mi355q_act_minmax_workspace_bytes(3) == 3 * 64 * 5 * 4
 
 
 def test_product_path_refuses_to_run_without_gpu(lib):
