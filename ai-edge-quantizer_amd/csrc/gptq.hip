@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void copy_panel_kernel(const double* __restric
 
 // Every diagonal block of `a` := its inverse (lower part of dinv[block]).
 __global__ __launch_bounds__(256) void put_diag_inverses_kernel(double* __restrict__ a, int d,
-                                                               const double* __restrict__ dinv) {
-  const int kb = blockIdx.x, k = kb * NB;
+                                                               const double* __restrict__ dinv, int first) {
+  const int kb = first + blockIdx.x, k = kb * NB;
   const int nb = d - k < NB ? d - k : NB;
   const double* x = dinv + static_cast<long long>(kb) * NB * NB;
   for (int e = threadIdx.x; e < NB * NB; e += 256) {
@@ -361,8 +361,9 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
       GemmArgs<double> g2{panel, NB, 1, inv11, NB, 1, a21, d, 1, m, nb, nb, -1.0, 0.0, 0, 0};
       if (int32_t s = launch_gemm<double>(g2, st)) return s;
     }
+    // A11 <- A11^-1 (the next, more leftward, step reads it as part of its A22^-1)
+    hipLaunchKernelGGL(put_diag_inverses_kernel, dim3(1), dim3(256), 0, st, a, d, dinv, jb);
   }
-  hipLaunchKernelGGL(put_diag_inverses_kernel, dim3(nblocks), dim3(256), 0, st, a, d, dinv);
   MI355Q_CHECK_LAUNCH("gptq trtri launch");
   // ---- H^-1 = L^-T L^-1 : out(i,j) = sum_k Linv[k][i] * Linv[k][j], k >= max(i,j); lower half
   GemmArgs<double> gp{a, 1, d, a, d, 1, out, d, 1, d, d, d, 1.0, 0.0, 1, 2};

@@ -178,34 +178,51 @@ def pack_bits(q: torch.Tensor, bits: int) -> torch.Tensor:
   return out
 
 
+class ActMinMaxBatch:
+  """Pre-staged K7 launch over a fixed list of float32 device tensors (<= 65535).
+
+  Pointer / length tables, workspace and the [count, 2] output live in HBM, so
+  `run()` is just the two kernel launches (used per calibration sample).
+  """
+
+  def __init__(self, tensors, lo: float | None = -3e38, hi: float | None = 3e38):
+    rt.require_gpu()
+    self.tensors = [_f32(t) for t in tensors]
+    if len(self.tensors) > 65535:
+      raise ValueError("at most 65535 tensors per batch")
+    if any(t.numel() == 0 for t in self.tensors):
+      raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    if (lo is None) != (hi is None):
+      raise ValueError("lo and hi must both be given or both be None")
+    self.use = lo is not None
+    self.lo = np.float32(lo if self.use else 0.0)
+    self.hi = np.float32(hi if self.use else 0.0)
+    n = len(self.tensors)
+    self.out = rt.empty((n, 2), torch.float32)
+    if n:
+      self._tab = rt.ptr_table(self.tensors)
+      self._numel = torch.tensor([t.numel() for t in self.tensors], dtype=torch.int64).to(rt.device())
+      self._nbytes = _ffi.lib().mi355q_act_minmax_workspace_bytes(n)
+      self._ws = rt.empty((self._nbytes,), torch.uint8)
+
+  def run(self) -> torch.Tensor:
+    n = len(self.tensors)
+    if n:
+      _ffi.check(_ffi.lib().mi355q_act_minmax_f32(
+          rt.ptr(self._tab), rt.ptr(self._numel), n, self.lo, self.hi, 1 if self.use else 0,
+          rt.ptr(self.out), rt.ptr(self._ws), self._nbytes, rt.stream_ptr()))
+    return self.out
+
+
 def act_minmax(tensors, lo: float | None = -3e38, hi: float | None = 3e38) -> torch.Tensor:
   """K7 over a list of float32 device tensors -> float32[count, 2] (min, max).
 
   ref: common_quantize.py:1362-1413. lo/hi None disables the range masks.
   """
-  rt.require_gpu()
-  ts = [_f32(t) for t in tensors]
-  if any(t.numel() == 0 for t in ts):
-    raise ValueError("zero-size array to reduction operation minimum which has no identity")
-  n = len(ts)
-  out = rt.empty((n, 2), torch.float32)
-  if n == 0:
-    return out
-  use = lo is not None and hi is not None
-  if (lo is None) != (hi is None):
-    raise ValueError("lo and hi must both be given or both be None")
-  L = _ffi.lib()
-  for start in range(0, n, 65535):
-    part = ts[start:start + 65535]
-    tab = rt.ptr_table(part)
-    numel = torch.tensor([t.numel() for t in part], dtype=torch.int64).to(rt.device())
-    nbytes = L.mi355q_act_minmax_workspace_bytes(len(part))
-    ws = rt.empty((nbytes,), torch.uint8)
-    _ffi.check(L.mi355q_act_minmax_f32(
-        rt.ptr(tab), rt.ptr(numel), len(part), np.float32(lo if use else 0.0),
-        np.float32(hi if use else 0.0), 1 if use else 0, rt.ptr(out[start:]), rt.ptr(ws), nbytes,
-        rt.stream_ptr()))
-  return out
+  ts = list(tensors)
+  if len(ts) <= 65535:
+    return ActMinMaxBatch(ts, lo, hi).run()
+  return torch.cat([ActMinMaxBatch(ts[i:i + 65535], lo, hi).run() for i in range(0, len(ts), 65535)])
 
 
 def octav_clip(x: torch.Tensor, units: int, unit_len: int, bits: int, max_iter: int = 10,

