@@ -94,21 +94,19 @@ def get_activation_min_max(tensor_content: np.ndarray,
   shape = (1,) * tensor_content.ndim
   if tensor_content.size == 0:
     raise ValueError("zero-size array to reduction operation minimum which has no identity")
-  if np.issubdtype(tensor_content.dtype, np.integer) or tensor_content.dtype != np.float32:
-    # integer activations (indices etc.) carry no float range; tiny host reduction
-    return {"min": np.reshape(np.min(tensor_content), shape),
-            "max": np.reshape(np.max(tensor_content), shape)}
+  is_int = np.issubdtype(tensor_content.dtype, np.integer)
+  # The kernel reads float32; other dtypes are accepted when the conversion is exact
+  # (integers below 2^24, float64 holding float32 values) so min / max are unchanged.
+  x = uniform_quantize_tensor._as_f32_exact(tensor_content)  # pylint: disable=protected-access
   rt.require_gpu()
-  flat = rt.to_device(np.ascontiguousarray(tensor_content).reshape(-1))
-  if valid_float_range_min is not None and valid_float_range_max is not None:
-    mm = ops.act_minmax([flat], valid_float_range_min, valid_float_range_max)
-  elif valid_float_range_min is None and valid_float_range_max is None:
-    mm = ops.act_minmax([flat], None, None)
-  else:  # one-sided range: widen the missing side so that its mask is always true
+  flat = rt.to_device(np.ascontiguousarray(x).reshape(-1))
+  if is_int or (valid_float_range_min is None and valid_float_range_max is None):
+    mm = ops.act_minmax([flat], None, None)  # integers: plain min / max (ref :1382-1384)
+  else:  # a missing side gets an always-true mask
     lo = -np.inf if valid_float_range_min is None else valid_float_range_min
     hi = np.inf if valid_float_range_max is None else valid_float_range_max
     mm = ops.act_minmax([flat], lo, hi)
-  host = rt.to_numpy(mm)
+  host = rt.to_numpy(mm).astype(tensor_content.dtype if is_int else np.float32)
   return {"min": np.reshape(host[0, 0], shape), "max": np.reshape(host[0, 1], shape)}
 
 

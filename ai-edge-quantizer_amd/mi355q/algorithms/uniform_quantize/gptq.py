@@ -46,15 +46,21 @@ def calibrate(tfl_op, graph_info: qtyping.GraphInfo,
 
 
 def hessian_of(tensor_content: np.ndarray, num_samples) -> np.ndarray:
-  """(2.0 / num_samples) * x.T.dot(x), x = content.reshape(-1, last) (ref :100-107)."""
-  x = tensor_content.reshape([-1, tensor_content.shape[-1]])
-  if x.dtype == np.float32 and x.size and np.isfinite(x).all():
-    rt.require_gpu()
-    alpha = 2.0 / np.asarray(num_samples)  # float64, as in the reference
+  """(2.0 / num_samples) * x.T.dot(x), x = content.reshape(-1, last) (ref :100-107).
+
+  float32 content: X^T X on the FP32 MFMA units, scaled into float64 (NumPy's
+  promotion of `2.0 / np.array(n)`). float64 content (the reference's own test
+  feeds 1e39): the FP64 MFMA GEMM.
+  """
+  x = np.ascontiguousarray(tensor_content.reshape([-1, tensor_content.shape[-1]]))
+  alpha = 2.0 / np.asarray(num_samples)
+  rt.require_gpu()
+  if x.dtype == np.float32:
     return rt.to_numpy(ops.gptq_xtx(rt.to_device(x), float(alpha)))
-  # Non-float32 content, or values whose squares leave FP32 (the reference's own
-  # test feeds 1e39 in float64): tiny host evaluation of the reference formula.
-  return (2.0 / num_samples) * x.T.dot(x)
+  if x.dtype == np.float64:
+    xd = rt.to_device(x)
+    return alpha * rt.to_numpy(ops.gemm(xd, xd, trans_a=True))
+  raise TypeError(f"GPTQ calibration expects float32 / float64 activations, got {x.dtype}")
 
 
 def _prepare_hessian_inverse(hessian: np.ndarray, damp_factor: float = 0.01) -> np.ndarray:

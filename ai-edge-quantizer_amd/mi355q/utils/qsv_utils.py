@@ -31,11 +31,24 @@ def min_max_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qtyping.QSV:
 
 
 def _gptq_merge_hessian(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> tuple[Any, int]:
+  """(H_cur*n_cur + H_new*n_new) / (n_cur + n_new), num_samples summed (ref :71-88).
+
+  float64 Hessians (what calibrate() produces) are merged by
+  mi355q_gptq_hessian_merge_f64 -- the same three IEEE operations per element.
+  """
   n0, n1 = qsv["num_samples"], new_qsv["num_samples"]
   total = n0 + n1
   if total == 0:
     return new_qsv["hessian"], 0
-  return (qsv["hessian"] * n0 + new_qsv["hessian"] * n1) / total, total
+  h0, h1 = np.asarray(qsv["hessian"]), np.asarray(new_qsv["hessian"])
+  if h0.dtype == np.float64 and h1.dtype == np.float64 and h0.ndim == 2 and h0.shape == h1.shape \
+      and h0.shape[0] == h0.shape[1]:
+    from .. import ops
+    from .. import runtime as rt
+    rt.require_gpu()
+    merged = ops.gptq_hessian_merge(rt.to_device(h0), float(n0), rt.to_device(h1), float(n1))
+    return rt.to_numpy(merged), total
+  return (h0 * n0 + h1 * n1) / total, total
 
 
 def gptq_and_moving_average_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qtyping.QSV:

@@ -67,3 +67,20 @@ def parse_fc_bmm_conv_tensors(op: Any, tensors: list[Any], input_index: int = 0,
   if len(op.inputs) > bias_index and op.inputs[bias_index] != -1:
     bias = tensors[op.inputs[bias_index]]
   return inp, w, bias, tensors[op.outputs[output_index]]
+
+
+def get_subgraph_input_output_operators(subgraph: Any) -> list[qtyping.IOOperator]:
+  """Virtual INPUT / OUTPUT ops of a subgraph (ref :318-340)."""
+  return [qtyping.IOOperator(inputs=[], outputs=list(subgraph.inputs), op_key=_Op.INPUT),
+          qtyping.IOOperator(inputs=list(subgraph.outputs), outputs=[], op_key=_Op.OUTPUT)]
+
+
+def get_op_scope(op: Any, subgraph_tensors: list[Any], max_length: int = 10000) -> str:
+  """Scope string recipes match their regex against: the op's output tensor names
+  (inputs when it has no outputs), each followed by ';' (ref :371-417)."""
+  def names(ids):
+    out = [get_tensor_name(subgraph_tensors[i]) for i in ids if i != -1]
+    return [n for n in out if n]
+  picked = names(op.outputs) or names(op.inputs)
+  scope = ";".join(picked) + (";" if picked else "")
+  return scope[:max_length]

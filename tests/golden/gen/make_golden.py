@@ -438,6 +438,87 @@ def digest_cases():
   DIGESTS.update(t)
 
 
+# ------------------------------------------ C1: full orchestration in memory ---
+def c1_cases():
+  """BASELINE config 1 through the reference's own ParamsGenerator ->
+  transformation instructions -> TransformationPerformer on an in-memory model
+  (flatbuffer serialization is third-party and not available)."""
+  from ai_edge_quantizer import params_generator, recipe, recipe_manager
+  from ai_edge_quantizer import transformation_instruction_generator as tig
+  from ai_edge_quantizer import transformation_performer as tp
+
+  def tensor(name, shape, buf):
+    t = qtyping.TensorT()
+    t.name, t.shape, t.buffer, t.type = name.encode(), list(shape), buf, 0
+    return t
+
+  def build():
+    w = np.random.default_rng(1234).standard_normal((256, 256), dtype=np.float32)
+    model = qtyping.ModelT()
+    bufs = [qtyping.BufferT() for _ in range(3)]
+    bufs[1].data = w.view(np.uint8).reshape(-1)
+    model.buffers = bufs
+    sg = qtyping.SubGraphT()
+    sg.tensors = [tensor("x", (1, 256), 0), tensor("w", (256, 256), 1), tensor("y", (1, 256), 2)]
+    op = qtyping.OperatorT()
+    op.inputs, op.outputs, op.opcodeIndex = [0, 1, -1], [2], 0
+    sg.operators, sg.inputs, sg.outputs = [op], [0], [2]
+    oc = qtyping.OperatorCodeT()
+    oc.builtinCode = qtyping.BuiltinOperator.FULLY_CONNECTED
+    oc.deprecatedBuiltinCode = 9
+    model.operatorCodes, model.subgraphs = [oc], [sg]
+    return model, sg, w
+
+  recipes = {
+      "c1_dynamic_wi8_afp32": recipe.dynamic_wi8_afp32(),
+      "c1_dynamic_wi4_afp32": recipe.dynamic_wi4_afp32(),
+      "c1_dynamic_wi4b32_afp32": recipe.dynamic_wi4b32_afp32(),
+      "c1_dynamic_wi8_octav": recipe.dynamic_wi8_afp32(algorithm_key="OCTAV"),
+  }
+  for name, rcp in recipes.items():
+    model, sg, w = build()
+    if "b32" in name:  # blockwise scales pass through `.astype(ml_dtypes.bfloat16)`
+      model.buffers[1].data = w.view(np.uint8).reshape(-1)
+    rm = recipe_manager.RecipeManager()
+    rm.load_quantization_recipe(rcp)
+    pg = params_generator.ParamsGenerator(model)
+    if "b32" in name:
+      # feed the weight as the bf16-aware subclass (see shim/ml_dtypes.py)
+      from ai_edge_quantizer.utils import tfl_flatbuffer_utils as fbu
+      orig = fbu.get_tensor_data
+      fbu.get_tensor_data = lambda t, b, _o=orig: (
+          None if _o(t, b) is None else _o(t, b).view(ml_dtypes.Bf16Aware))
+    try:
+      with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        params = pg.generate_quantization_parameters(rm)
+        insts = tig.TransformationInstructionsGenerator().quant_params_to_transformation_insts(
+            params, model)
+        tp.TransformationPerformer().transform_graph(insts, model)
+    finally:
+      if "b32" in name:
+        fbu.get_tensor_data = orig
+    wt = sg.tensors[1]
+    q = wt.quantization
+    rec = dict(name=name, algo="c1", recipe=rcp, tensor_type=int(wt.type),
+               quantized_dimension=int(q.quantizedDimension), n_tensors=len(sg.tensors),
+               transformations={k: [t.name for c in (v.consumers or []) for t in c.transformations]
+                                for k, v in params.items()})
+    ARR[f"{name}/buffer"] = np.asarray(model.buffers[1].data).view(np.uint8).copy()
+    if q.scale is not None:
+      ARR[f"{name}/scale"] = np.asarray(q.scale)
+      ARR[f"{name}/zero_point"] = np.asarray(q.zeroPoint)
+    if q.details is not None:
+      st = sg.tensors[q.details.scales]
+      rec.update(block_size=int(q.details.blockSize), zero_points=int(q.details.zeroPoints),
+                 scales_tensor_name=st.name.decode(), scales_tensor_type=int(st.type),
+                 scales_tensor_shape=list(st.shape))
+      ARR[f"{name}/scales_f16"] = np.frombuffer(
+          bytes(np.asarray(model.buffers[st.buffer].data)), dtype=np.float16).copy()
+    CASES.append(json.loads(json.dumps(rec, default=str)))
+    DIGESTS[name] = dict(buffer=sha(ARR[f"{name}/buffer"]))
+
+
 def main():
   # cross-check the bf16 stand-in against an independent implementation
   import torch
@@ -456,6 +537,7 @@ def main():
   pack_cases()
   direct_cases()
   digest_cases()
+  c1_cases()
 
   np.savez_compressed(os.path.join(GOLDEN, "ref_cases.npz"), **ARR)
   meta = dict(generator="tests/golden/gen/make_golden.py",
