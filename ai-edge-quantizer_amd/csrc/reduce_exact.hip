@@ -92,13 +92,11 @@ struct RunSum {
                                        int lane) {
     if ((base % kChunk) == 0 || (m & 1ull) == 0) flush(a, lane);
     count += static_cast<unsigned>(__builtin_popcountll(m));
-    int pos = 0;
     while (m != 0) {
       const int s = __builtin_ctzll(m);
       const unsigned long long t = m >> s;
       const int len = (~t == 0) ? 64 - s : __builtin_ctzll(~t);
-      pos = s + len;
-      if (pos == 64) {  // touches the batch end: may continue in the next batch
+      if (s + len == 64) {  // touches the batch end: may continue in the next batch
         if (pend_len > 0) {  // (only when s == 0)
           pend_len += len;
         } else {

@@ -115,16 +115,14 @@ template <int BITS, int CL, bool FAST>
 __device__ __forceinline__ void emit(const float4 (&v)[CL], float s, int64_t idx4, int8_t* q,
                                      uint8_t* packed) {
   const float r = FAST ? 1.0f / s : 0.f;  // one IEEE division per call
-  uint32_t w8[CL];
-  uint32_t sub = 0;  // CL * 4 * BITS bits (<= 32 for CL<=2@int4, CL<=4@int2)
-  uint32_t subw[CL];
+  uint32_t w8[CL];    // 4 values as int8 containers
+  uint32_t subw[CL];  // the same 4 values packed to 4*BITS bits
 #pragma unroll
   for (int c = 0; c < CL; ++c) {
     const Quant4<BITS> o = quant4<BITS, FAST>(v[c], s, r);
     w8[c] = pack_i8<BITS>(o);
     subw[c] = pack_sub<BITS>(o);
   }
-  (void)sub;
   const bool same = BITS == 8 && reinterpret_cast<int8_t*>(packed) == q;
   if (q != nullptr) {
     uint32_t* dst = reinterpret_cast<uint32_t*>(q) + idx4;
