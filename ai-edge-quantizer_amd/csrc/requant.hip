@@ -21,15 +21,19 @@ namespace {
 
 using namespace requant;
 
-// Tuning choices; tools/kbench/kbench.hip times the alternatives on MI355X
-// (profiles/r01_kbench_variants.txt). Sub-byte outputs want every lane to own 8
-// consecutive floats (CL = 2) so that the packed store is a full dword; int8 output
-// is best with one float4 per lane and 4 tiles in flight. The reciprocal-multiply
-// fast path (exact, see requant_kernels.h) is a wash against the IEEE division --
-// the kernels are HBM-bound -- so the simpler division stays.
-constexpr bool kFastDiv = false;
-template <int BITS> constexpr int kGroupsU = BITS == 8 ? 4 : 1;
-template <int BITS> constexpr int kGroupsCL = BITS == 8 ? 1 : 2;
+// Tuning choices; tools/kbench/kbench.hip times the alternatives on MI355X with
+// interleaved rounds (profiles/r01_kbench_variants.txt):
+//   * rows kernel: non-temporal loads/stores (x is read once, q never re-read):
+//     72.7 % -> 76.6 % of 8 TB/s on C2;
+//   * blockwise kernel: every lane owns 8 consecutive floats (CL = 2) so packed
+//     int4 leaves as full dwords (55 % -> 72 %); for sub-byte outputs the exact
+//     reciprocal path (requant_kernels.h, one IEEE division per block instead of
+//     one per element) adds another ~4 points; nt does not help there;
+//   * int8 blockwise output: CL = 2 with two tiles in flight.
+constexpr bool kRowsNT = true;
+template <int BITS> constexpr bool kGroupsFast = BITS < 8;
+template <int BITS> constexpr int kGroupsU = BITS == 8 ? 2 : 1;
+template <int BITS> constexpr int kGroupsCL = 2;
 
 template <int BITS, bool BATCHED>
 int32_t launch_bits(const RequantArgs& a, int count, bool aligned16, hipStream_t st) {
@@ -44,10 +48,10 @@ int32_t launch_bits(const RequantArgs& a, int count, bool aligned16, hipStream_t
       constexpr int U = kGroupsU<BITS>, CL = kGroupsCL<BITS>;
       const dim3 grid(static_cast<unsigned>((n4 + 256 * U * CL - 1) / (256 * U * CL)), gy);
       switch (g4) {
-        case 8: hipLaunchKernelGGL((requant_groups_kernel<BITS, 8, U, CL, kFastDiv, BATCHED>), grid, blk, 0, st, a); break;
-        case 16: hipLaunchKernelGGL((requant_groups_kernel<BITS, 16, U, CL, kFastDiv, BATCHED>), grid, blk, 0, st, a); break;
-        case 32: hipLaunchKernelGGL((requant_groups_kernel<BITS, 32, U, CL, kFastDiv, BATCHED>), grid, blk, 0, st, a); break;
-        default: hipLaunchKernelGGL((requant_groups_kernel<BITS, 64, U, CL, kFastDiv, BATCHED>), grid, blk, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((requant_groups_kernel<BITS, 8, U, CL, kGroupsFast<BITS>, BATCHED>), grid, blk, 0, st, a); break;
+        case 16: hipLaunchKernelGGL((requant_groups_kernel<BITS, 16, U, CL, kGroupsFast<BITS>, BATCHED>), grid, blk, 0, st, a); break;
+        case 32: hipLaunchKernelGGL((requant_groups_kernel<BITS, 32, U, CL, kGroupsFast<BITS>, BATCHED>), grid, blk, 0, st, a); break;
+        default: hipLaunchKernelGGL((requant_groups_kernel<BITS, 64, U, CL, kGroupsFast<BITS>, BATCHED>), grid, blk, 0, st, a); break;
       }
     } else {
       if (a.packed != nullptr && BITS != 8)
@@ -59,7 +63,7 @@ int32_t launch_bits(const RequantArgs& a, int count, bool aligned16, hipStream_t
     const int64_t cols4 = cols / 4;
     if (vec_ok && cols4 <= 256 * 16) {
 #define MI355Q_ROWS(TPR, R)                                                            \
-  hipLaunchKernelGGL((requant_rows_kernel<BITS, TPR, R, kFastDiv, BATCHED>),                      \
+  hipLaunchKernelGGL((requant_rows_kernel<BITS, TPR, R, false, BATCHED, kRowsNT>),                      \
                      dim3(static_cast<unsigned>((rows + (256 / TPR) - 1) / (256 / TPR)), gy), \
                      blk, 0, st, a)
       if (cols4 <= 64) MI355Q_ROWS(64, 1);

@@ -31,6 +31,36 @@ __device__ __forceinline__ T* pick(const void* p, int t) {
   }
 }
 
+// Streaming access helpers: x is read exactly once and q is never re-read by this
+// kernel, so both can bypass cache retention (`nt`), see kbench for the effect.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ float4 load4(const float4* p) {
+  if constexpr (NT) {
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *p;
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void store1(uint32_t* p, uint32_t a) {
+  if constexpr (NT) __builtin_nontemporal_store(a, p); else *p = a;
+}
+template <bool NT>
+__device__ __forceinline__ void store2(uint32_t* p, uint32_t a, uint32_t b) {
+  if constexpr (NT) { u32x2_t v = {a, b}; __builtin_nontemporal_store(v, reinterpret_cast<u32x2_t*>(p)); }
+  else *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
+}
+template <bool NT>
+__device__ __forceinline__ void store4(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  if constexpr (NT) { u32x4_t v = {a, b, c, d}; __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p)); }
+  else *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
+}
+
 // bound -> scale (K2). ref: uniform_quantize_tensor.py:552-563, 577-581.
 template <int BITS, bool BLOCKWISE>
 __device__ __forceinline__ float make_scale(uint32_t absmax_bits, const float* clip,
@@ -111,7 +141,7 @@ __device__ __forceinline__ uint32_t pack_sub(const Quant4<BITS>& o) {  // 4 valu
 
 // Quantize CL consecutive float4 (idx4 = index of the first, in float4 units) and emit
 // them in the requested containers with the widest store the alignment allows.
-template <int BITS, int CL, bool FAST>
+template <int BITS, int CL, bool FAST, bool NT = false>
 __device__ __forceinline__ void emit(const float4 (&v)[CL], float s, int64_t idx4, int8_t* q,
                                      uint8_t* packed) {
   const float r = FAST ? 1.0f / s : 0.f;  // one IEEE division per call
@@ -126,21 +156,21 @@ __device__ __forceinline__ void emit(const float4 (&v)[CL], float s, int64_t idx
   const bool same = BITS == 8 && reinterpret_cast<int8_t*>(packed) == q;
   if (q != nullptr) {
     uint32_t* dst = reinterpret_cast<uint32_t*>(q) + idx4;
-    if constexpr (CL == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(w8[0], w8[1], w8[2], w8[3]);
-    else if constexpr (CL == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(w8[0], w8[1]);
-    else dst[0] = w8[0];
+    if constexpr (CL == 4) store4<NT>(dst, w8[0], w8[1], w8[2], w8[3]);
+    else if constexpr (CL == 2) store2<NT>(dst, w8[0], w8[1]);
+    else store1<NT>(dst, w8[0]);
   }
   if (packed != nullptr && !same) {
     if constexpr (BITS == 8) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(packed) + idx4;
-      if constexpr (CL == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(w8[0], w8[1], w8[2], w8[3]);
-      else if constexpr (CL == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(w8[0], w8[1]);
-      else dst[0] = w8[0];
+      if constexpr (CL == 4) store4<NT>(dst, w8[0], w8[1], w8[2], w8[3]);
+      else if constexpr (CL == 2) store2<NT>(dst, w8[0], w8[1]);
+      else store1<NT>(dst, w8[0]);
     } else if constexpr (BITS == 4) {  // 16 bits per float4
       uint16_t* dst = reinterpret_cast<uint16_t*>(packed) + idx4;
       if constexpr (CL == 4)
-        *reinterpret_cast<uint2*>(dst) = make_uint2(subw[0] | (subw[1] << 16), subw[2] | (subw[3] << 16));
-      else if constexpr (CL == 2) *reinterpret_cast<uint32_t*>(dst) = subw[0] | (subw[1] << 16);
+        store2<NT>(reinterpret_cast<uint32_t*>(dst), subw[0] | (subw[1] << 16), subw[2] | (subw[3] << 16));
+      else if constexpr (CL == 2) store1<NT>(reinterpret_cast<uint32_t*>(dst), subw[0] | (subw[1] << 16));
       else dst[0] = static_cast<uint16_t>(subw[0]);
     } else {  // 2 bit: 8 bits per float4
       uint8_t* dst = packed + idx4;
@@ -161,7 +191,7 @@ __device__ __forceinline__ uint32_t absmax4(float4 v) {
 // The tensor is a flat run of groups. Every lane owns CL consecutive float4
 // (G4/CL lanes share a group); a 256-thread block streams U tiles of 256*CL float4.
 // ------------------------------------------------------------------------
-template <int BITS, int G4, int U, int CL, bool FAST, bool BATCHED>
+template <int BITS, int G4, int U, int CL, bool FAST, bool BATCHED, bool NT = false>
 __global__ __launch_bounds__(256) void requant_groups_kernel(RequantArgs a) {
   static_assert(G4 % CL == 0 && G4 / CL >= 1, "group must be a multiple of the lane piece");
   constexpr int LPG = G4 / CL;  // lanes per group
@@ -182,7 +212,7 @@ __global__ __launch_bounds__(256) void requant_groups_kernel(RequantArgs a) {
     const int64_t i = base + static_cast<int64_t>(u) * 256 * CL;
 #pragma unroll
     for (int c = 0; c < CL; ++c)
-      v[u][c] = i < n4 ? x[i + c] : make_float4(0.f, 0.f, 0.f, 0.f);  // n4 % CL == 0 (G4 % CL == 0)
+      v[u][c] = i < n4 ? load4<NT>(x + i + c) : make_float4(0.f, 0.f, 0.f, 0.f);  // n4 % CL == 0
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -199,7 +229,7 @@ __global__ __launch_bounds__(256) void requant_groups_kernel(RequantArgs a) {
         scale[g] = s;
         if (scale_f16 != nullptr) scale_f16[g] = hb;
       }
-      emit<BITS, CL, FAST>(v[u], s, i, q, packed);
+      emit<BITS, CL, FAST, NT>(v[u], s, i, q, packed);
     }
   }
 }
@@ -209,7 +239,7 @@ __global__ __launch_bounds__(256) void requant_groups_kernel(RequantArgs a) {
 // row of cols4 <= TPR*R float4. TPR = 64 -> a wave owns the row (no LDS);
 // TPR = 256 -> the block owns the row (one LDS exchange).
 // ------------------------------------------------------------------------
-template <int BITS, int TPR, int R, bool FAST, bool BATCHED>
+template <int BITS, int TPR, int R, bool FAST, bool BATCHED, bool NT = false>
 __global__ __launch_bounds__(256) void requant_rows_kernel(RequantArgs a) {
   static_assert(TPR == 256 || (TPR <= kWave && (TPR & (TPR - 1)) == 0),
                 "a row is owned by part of a wave, one wave, or the whole 256-thread block");
@@ -231,7 +261,7 @@ __global__ __launch_bounds__(256) void requant_rows_kernel(RequantArgs a) {
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int c = j * TPR + lane;
-    v[j][0] = (live && c < cols4) ? x[row4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[j][0] = (live && c < cols4) ? load4<NT>(x + row4 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   uint32_t m = 0;
 #pragma unroll
@@ -250,7 +280,7 @@ __global__ __launch_bounds__(256) void requant_rows_kernel(RequantArgs a) {
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int c = j * TPR + lane;
-    if (c < cols4) emit<BITS, 1, FAST>(v[j], s, row4 + c, q, packed);
+    if (c < cols4) emit<BITS, 1, FAST, NT>(v[j], s, row4 + c, q, packed);
   }
 }
 

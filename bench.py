@@ -205,7 +205,7 @@ def main():
                    "sharding": f"tensor-buffers x{world} (no collective)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "kernel": "requant_rows_kernel<8,256,4,batched>",
+                     "traffic": traffic, "kernel": "requant_rows_kernel<8,256,4,ieee-div,batched,nt>",
                      "alg_bytes_per_launch": POOL * ALG_BYTES,
                      "launch_ms": round(kern_ms, 5)},
         "cpu_baseline": cpu_baseline(args.cpu_seconds),

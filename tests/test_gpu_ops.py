@@ -82,6 +82,31 @@ def test_requant_blockwise_matches_oracle(ops, shape, block, bits):
                             O.pack_data(bits, np.ravel(ref["quantized_data"]).view(np.uint8)))
 
 
+@pytest.mark.parametrize("bits", [4, 2])
+@pytest.mark.parametrize("block", [32, 128])
+def test_requant_blockwise_half_integer_quotients(ops, block, bits):
+  """The sub-byte blockwise kernel divides once per block and multiplies by the
+  reciprocal, falling back to the IEEE division near half-integer quotients. Plant
+  quotients k + 0.5 (+- a few ulps) everywhere except at the block maxima."""
+  rng = np.random.default_rng(block * bits)
+  w = rng.standard_normal((16, 4 * block)).astype(np.float32)
+  ref = O.min_max_quant_params(w, bits, True, f"BLOCKWISE_{block}")
+  scale = np.repeat(ref["scale"], block, axis=1)
+  qmax = 2 ** (bits - 1) - 1
+  is_max = np.abs(w) == np.repeat(np.abs(w).reshape(16, 4, block).max(axis=2), block, axis=1)
+  k = rng.integers(-qmax - 1, qmax + 1, size=w.shape).astype(np.float32)
+  planted = ((k + np.float32(0.5)) * scale).astype(np.float32)
+  ulps = rng.integers(-3, 4, size=w.shape).astype(np.int32)
+  planted = (planted.view(np.int32) + ulps).view(np.float32)
+  keep = is_max | (np.abs(planted) >= np.abs(w).reshape(16, 4, block).max(axis=2).repeat(block, axis=1))
+  w2 = np.where(keep, w, planted).astype(np.float32)
+  ref2 = O.min_max_quant_params(w2, bits, True, f"BLOCKWISE_{block}")
+  assert np.array_equal(ref2["scale"], ref["scale"])  # maxima untouched
+  r = ops.requant_sym(dev(w2), block=block, bits=bits, want_packed=True)
+  assert np.array_equal(host(r["q"]), ref2["quantized_data"])
+  assert np.array_equal(host(r["packed"]), O.pack_data(bits, np.ravel(ref2["quantized_data"]).view(np.uint8)))
+
+
 def test_requant_odd_block_falls_back_to_generic_kernel(ops):
   # block sizes outside {32,64,128,256} are not AEQ granularities but the ABI takes them
   w = rand(5, (6, 96))

@@ -147,21 +147,21 @@ static void run_interleaved(const Case& c, std::vector<Variant>& vs, int rounds,
   fflush(stdout);
 }
 
-template <int BITS, int TPR, int R, bool FAST>
+template <int BITS, int TPR, int R, bool FAST, bool NT = false>
 static Variant rows_variant(Case& c, const char* tag) {
   RequantArgs a{c.tx, c.tq, nullptr, c.ts, nullptr, nullptr, c.rows, c.cols, 0};
   if (c.packed_only) { a.q = nullptr; a.packed = c.tp; }
   dim3 grid((unsigned)((c.rows + (256 / TPR) - 1) / (256 / TPR)), c.pool);
-  return Variant{tag, [=] { hipLaunchKernelGGL((requant_rows_kernel<BITS, TPR, R, FAST, true>), grid, dim3(256), 0, 0, a); }, c.packed_only, {}, ""};
+  return Variant{tag, [=] { hipLaunchKernelGGL((requant_rows_kernel<BITS, TPR, R, FAST, true, NT>), grid, dim3(256), 0, 0, a); }, c.packed_only, {}, ""};
 }
 
-template <int BITS, int G4, int U, int CL, bool FAST>
+template <int BITS, int G4, int U, int CL, bool FAST, bool NT = false>
 static Variant groups_variant(Case& c, const char* tag) {
   RequantArgs a{c.tx, nullptr, c.tp, c.ts, c.t16, nullptr, c.rows, c.cols, c.block};
   if (!c.packed_only) { a.q = c.tq; a.packed = nullptr; }
   int64_t n4 = c.rows * c.cols / 4;
   dim3 grid((unsigned)((n4 + 256 * U * CL - 1) / (256 * U * CL)), c.pool);
-  return Variant{tag, [=] { hipLaunchKernelGGL((requant_groups_kernel<BITS, G4, U, CL, FAST, true>), grid, dim3(256), 0, 0, a); }, c.packed_only, {}, ""};
+  return Variant{tag, [=] { hipLaunchKernelGGL((requant_groups_kernel<BITS, G4, U, CL, FAST, true, NT>), grid, dim3(256), 0, 0, a); }, c.packed_only, {}, ""};
 }
 
 int main(int argc, char** argv) {
@@ -176,8 +176,8 @@ int main(int argc, char** argv) {
     alloc_case(c, 1.0f, mode);
     std::vector<Variant> vs;
     vs.push_back(rows_variant<8, 256, 4, false>(c, "rows TPR=256 R=4 ieee"));
-    vs.push_back(rows_variant<8, 256, 4, true>(c, "rows TPR=256 R=4 fast"));
-    vs.push_back(rows_variant<8, 64, 16, false>(c, "rows TPR=64 R=16 ieee"));
+    vs.push_back(rows_variant<8, 256, 4, false, true>(c, "rows TPR=256 R=4 ieee nt"));
+    vs.push_back(rows_variant<8, 256, 8, false>(c, "rows TPR=256 R=8(pred) ieee"));
     run_interleaved(c, vs, rounds, 30);
     {
       RequantArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 4096, 4096, 0};
@@ -219,6 +219,8 @@ int main(int argc, char** argv) {
     std::vector<Variant> vs;
     vs.push_back(groups_variant<4, 32, 4, 1, false>(c, "groups U=4 CL=1 ieee"));
     vs.push_back(groups_variant<4, 32, 1, 2, false>(c, "groups U=1 CL=2 ieee"));
+    vs.push_back(groups_variant<4, 32, 1, 2, false, true>(c, "groups U=1 CL=2 ieee nt"));
+    vs.push_back(groups_variant<4, 32, 2, 2, false, true>(c, "groups U=2 CL=2 ieee nt"));
     vs.push_back(groups_variant<4, 32, 2, 2, false>(c, "groups U=2 CL=2 ieee"));
     vs.push_back(groups_variant<4, 32, 3, 2, false>(c, "groups U=3 CL=2 ieee"));
     vs.push_back(groups_variant<4, 32, 4, 2, false>(c, "groups U=4 CL=2 ieee"));
