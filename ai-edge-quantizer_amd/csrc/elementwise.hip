@@ -56,7 +56,23 @@ __global__ __launch_bounds__(256) void minmax_runs_kernel(
   const int64_t beg = s * chunk;
   const int64_t end = beg + chunk < len ? beg + chunk : len;
   MinMax a = mm_identity();
-  if (outer == 1) {
+  if (outer == 1 && ((reinterpret_cast<uintptr_t>(x + c * inner + beg) & 15) == 0)) {
+    // 16-byte loads, two in flight per lane
+    const float* p = x + c * inner;
+    const float4* p4 = reinterpret_cast<const float4*>(p + beg);
+    const int64_t n4 = (end - beg) / 4;
+    int64_t i = lane;
+    for (; i + kWave < n4; i += 2 * kWave) {
+      const float4 v = p4[i], w = p4[i + kWave];
+      mm_add(a, v.x); mm_add(a, v.y); mm_add(a, v.z); mm_add(a, v.w);
+      mm_add(a, w.x); mm_add(a, w.y); mm_add(a, w.z); mm_add(a, w.w);
+    }
+    for (; i < n4; i += kWave) {
+      const float4 v = p4[i];
+      mm_add(a, v.x); mm_add(a, v.y); mm_add(a, v.z); mm_add(a, v.w);
+    }
+    for (int64_t e = beg + n4 * 4 + lane; e < end; e += kWave) mm_add(a, p[e]);
+  } else if (outer == 1) {
     const float* p = x + c * inner;
     int64_t e = beg + lane;
     for (; e + 3 * kWave < end; e += 4 * kWave) {
@@ -184,6 +200,43 @@ __global__ __launch_bounds__(256) void quantize_kernel(
       float r = __builtin_rintf(v);
       r = fminf(fmaxf(r, lo), hi);
       q[e] = sat_cast<OutT>(r, v != v);
+    }
+  }
+}
+
+// Fast path of the above: float32 scale, int8 containers, inner % 4 == 0 and 16-byte
+// aligned buffers -- each lane owns whole float4 pieces (one channel lookup per piece),
+// four pieces in flight, dword stores.
+__global__ __launch_bounds__(256) void quantize_vec4_kernel(
+    const float4* __restrict__ x, int64_t n4, int64_t channels, int64_t inner4,
+    const float* __restrict__ scale, const int32_t* __restrict__ zp, int zp_via_f64,
+    float lo, float hi, uint32_t* __restrict__ q) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; base < n4; base += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = base + u * stride;
+      v[u] = i < n4 ? x[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = base + u * stride;
+      if (i >= n4) continue;
+      const int64_t c = channels == 1 ? 0 : (i / inner4) % channels;
+      const float s = scale[c];
+      const int z = zp ? zp[c] : 0;
+      const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      uint32_t w = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = in[k] / s;
+        t = zp_via_f64 ? static_cast<float>(static_cast<double>(t) + static_cast<double>(z))
+                       : t + static_cast<float>(z);
+        const int qi = round_clip(t, lo, hi);
+        w |= static_cast<uint32_t>(qi & 0xFF) << (8 * k);
+      }
+      q[i] = w;
     }
   }
 }
@@ -419,6 +472,16 @@ int32_t launch_quantize(const float* x, int64_t n, int64_t channels, int64_t inn
                         int out_bits, void* q, hipStream_t st) {
   const dim3 grid(grid_for(n)), blk(256);
   const ScaleT* s = static_cast<const ScaleT*>(scale);
+  if constexpr (sizeof(ScaleT) == 4) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(q)) & 15u) == 0;
+    if (out_bits == 8 && inner % 4 == 0 && aligned) {
+      hipLaunchKernelGGL(quantize_vec4_kernel, dim3(grid_for(n / 4, 4)), blk, 0, st,
+                         reinterpret_cast<const float4*>(x), n / 4, channels, inner / 4, s, zp, zp_via_f64,
+                         lo, hi, static_cast<uint32_t*>(q));
+      MI355Q_CHECK_LAUNCH("quantize launch");
+      return MI355Q_OK;
+    }
+  }
   switch (out_bits) {
     case 8: hipLaunchKernelGGL((quantize_kernel<ScaleT, int8_t>), grid, blk, 0, st, x, n, channels, inner, s, zp, zp_via_f64, lo, hi, static_cast<int8_t*>(q)); break;
     case 16: hipLaunchKernelGGL((quantize_kernel<ScaleT, int16_t>), grid, blk, 0, st, x, n, channels, inner, s, zp, zp_via_f64, lo, hi, static_cast<int16_t*>(q)); break;

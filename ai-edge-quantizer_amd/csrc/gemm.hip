@@ -12,8 +12,8 @@
 // sgemm-class numerics; see MI355X_MICROARCH.md.
 //
 // Structure: 256 threads = 4 waves in a 2x2 grid; each wave owns a 2x2 arrangement
-// of MFMA tiles (block tile 128x128 for float, 64x64 for double). K is consumed
-// BK = 16 at a time through LDS tiles stored k-major ([k][i]) so that an MFMA operand
+// of MFMA tiles (32x32 for float -> block tile 128x128, 16x16 for double -> 64x64).
+// K is consumed BK = 16 at a time through LDS tiles stored k-major ([k][i]) so that an MFMA operand
 // fragment (lane -> (i = lane % T, k = lane / T)) is one conflict-free ds_read per
 // lane. The LDS tiles are double buffered: the 16-byte global loads of tile t+1 are
 // issued before the MFMAs of tile t and land in the other buffer afterwards, one
@@ -25,15 +25,15 @@
 namespace mi355q {
 namespace {
 
-constexpr int BK = 16;
-
 template <typename T>
 struct Tile;
 template <>
 struct Tile<float> {
   static constexpr int MF = 32;   // MFMA tile edge
   static constexpr int KF = 2;    // k per MFMA
-  static constexpr int BM = 128;  // block tile edge (2 waves x 2 MFMA tiles x 32)
+  static constexpr int TM = 2;    // MFMA tiles per wave along each of i, j
+  static constexpr int BM = 128;  // block tile edge = 2 waves x TM x MF
+  static constexpr int BK = 16;   // k per LDS stage
   static constexpr int VEC = 4;   // elements per 16-byte load
   using Acc = __attribute__((ext_vector_type(16))) float;
   using Vec = float4;
@@ -42,7 +42,11 @@ template <>
 struct Tile<double> {
   static constexpr int MF = 16;
   static constexpr int KF = 4;
-  static constexpr int BM = 64;  // 2 waves x 2 MFMA tiles x 16
+  // 2x2 tiles per wave: a 4x4 arrangement (128x128 block) needs 128 accumulator + 188
+  // other VGPRs -> 1 wave/SIMD, and measured 2.6x slower than this shape on MI355X.
+  static constexpr int TM = 2;
+  static constexpr int BM = 64;   // 2 waves x 2 tiles x 16
+  static constexpr int BK = 16;
   static constexpr int VEC = 2;
   using Acc = __attribute__((ext_vector_type(4))) double;
   using Vec = double2;
@@ -78,7 +82,7 @@ template <typename T>
 __device__ __forceinline__ void load_tile(Stage<T>& st, const T* __restrict__ base, long long s_m,
                                           long long s_k, int m0, int k0, int M, int K, int mode, int tid) {
   using TL = Tile<T>;
-  constexpr int BM = TL::BM, VEC = TL::VEC;
+  constexpr int BM = TL::BM, VEC = TL::VEC, BK = TL::BK;
   using Vec = typename TL::Vec;
   const bool inside = m0 + BM <= M && k0 + BK <= K;
   if (mode == kMFast && inside) {
@@ -109,12 +113,12 @@ __device__ __forceinline__ void load_tile(Stage<T>& st, const T* __restrict__ ba
   }
 }
 
-// Registers -> LDS tile [BK][BM + PAD] (k-major).
+// Registers -> LDS tile [BK][LD] (k-major).
 template <typename T, int LD>
 __device__ __forceinline__ void store_tile(const Stage<T>& st, T (*lds)[LD], int m0, int k0, int M, int K,
                                            int mode, int tid) {
   using TL = Tile<T>;
-  constexpr int BM = TL::BM, VEC = TL::VEC;
+  constexpr int BM = TL::BM, VEC = TL::VEC, BK = TL::BK;
   using Vec = typename TL::Vec;
   const bool inside = m0 + BM <= M && k0 + BK <= K;
   if (mode == kKFast && inside) {
@@ -137,9 +141,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g, int a_mode, int b_mode, int k_chunk,
                                                    T* __restrict__ partial) {
   using TL = Tile<T>;
-  constexpr int BM = TL::BM, MF = TL::MF, KF = TL::KF;
+  constexpr int BM = TL::BM, MF = TL::MF, KF = TL::KF, TM = TL::TM, BK = TL::BK;
   constexpr int LD = BM + TL::VEC;  // keeps every row 16-byte aligned, breaks the power-of-2 stride
   constexpr int NREG = sizeof(typename TL::Acc) / sizeof(T);
+  static_assert(BM * BK / TL::VEC == 512, "two 16-byte loads per thread per operand tile");
   __shared__ __attribute__((aligned(16))) T As[2][BK][LD];
   __shared__ __attribute__((aligned(16))) T Bs[2][BK][LD];
 
@@ -147,20 +152,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g, int a_mode, in
   if (g.lower_only && bj > bi) return;  // only tiles touching the lower triangle
   const int i0 = bi * BM, j0 = bj * BM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wi = (wave >> 1) * (2 * MF), wj = (wave & 1) * (2 * MF);
+  const int wi = (wave >> 1) * (TM * MF), wj = (wave & 1) * (TM * MF);
   const int fi = lane % MF, fk = lane / MF;
 
-  typename TL::Acc acc[2][2];
+  typename TL::Acc acc[TM][TM];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TM; ++b)
 #pragma unroll
       for (int r = 0; r < NREG; ++r) acc[a][b][r] = T(0);
 
   int k_begin = 0, k_end = g.K;
   if (g.k_mode == 1) k_end = min(g.K, i0 + BM);
-  if (g.k_mode == 2) k_begin = (max(i0, j0) / BK) * BK;
+  if (g.k_mode == 2) k_begin = (max(i0, j0) / BK) * BK;  // i0, j0 are multiples of BM >= BK
   if (k_chunk > 0) {  // split-K slice of this z
     k_begin = max(k_begin, static_cast<int>(blockIdx.z) * k_chunk);
     k_end = min(k_end, (static_cast<int>(blockIdx.z) + 1) * k_chunk);
@@ -184,12 +189,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g, int a_mode, in
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += KF) {
-      const T a0 = As[buf][kk + fk][wi + fi], a1 = As[buf][kk + fk][wi + MF + fi];
-      const T b0 = Bs[buf][kk + fk][wj + fi], b1 = Bs[buf][kk + fk][wj + MF + fi];
-      acc[0][0] = mfma(a0, b0, acc[0][0]);
-      acc[0][1] = mfma(a0, b1, acc[0][1]);
-      acc[1][0] = mfma(a1, b0, acc[1][0]);
-      acc[1][1] = mfma(a1, b1, acc[1][1]);
+      T af[TM], bf[TM];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        af[t] = As[buf][kk + fk][wi + t * MF + fi];
+        bf[t] = Bs[buf][kk + fk][wj + t * MF + fi];
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = mfma(af[a], bf[b], acc[a][b]);
     }
     if (more) {
       store_tile<T, LD>(sa, As[buf ^ 1], i0, kn, g.M, g.K, a_mode, tid);
@@ -200,9 +209,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g, int a_mode, in
   }
   // ---- epilogue
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TM; ++b)
 #pragma unroll
       for (int r = 0; r < NREG; ++r) {
         const long long i = i0 + wi + a * MF + acc_row(T(0), r, lane);
@@ -279,6 +288,7 @@ int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_
   const dim3 grid(static_cast<unsigned>((g.N + BM - 1) / BM), static_cast<unsigned>((g.M + BM - 1) / BM),
                   static_cast<unsigned>(slices));
   if (slices > 1) {
+    constexpr int BK = Tile<T>::BK;
     int chunk = (g.K + slices - 1) / slices;
     chunk = (chunk + BK - 1) / BK * BK;
     hipLaunchKernelGGL((gemm_kernel<T>), grid, dim3(256), 0, st, g, a_mode, b_mode, chunk,
