@@ -136,7 +136,7 @@ def main():
   achieved = POOL * ALG_BYTES / (kern_ms * 1e-3) / 1e9
 
   extras = {}
-  if args.extras and rank == 0:
+  if args.extras and rank == 0 and world == 1:
     # one 4096x4096 buffer per launch, rotating over the pool (launch-gap inclusive)
     outs = [ops.requant_sym(x, 0, 8) for x in xs[:2]]  # warm
     del outs
@@ -208,7 +208,7 @@ def main():
                      "traffic": traffic, "kernel": "requant_rows_kernel<8,256,4,ieee-div,batched,nt>",
                      "alg_bytes_per_launch": POOL * ALG_BYTES,
                      "launch_ms": round(kern_ms, 5)},
-        "cpu_baseline": cpu_baseline(args.cpu_seconds),
+        "cpu_baseline": cpu_baseline(args.cpu_seconds) if world == 1 else None,
         "extras": extras,
     }
     print(json.dumps(line), flush=True)

@@ -1,0 +1,135 @@
+"""Parity at (or near) BASELINE sizes: size-independent properties and oracle
+comparisons that finish in seconds on the host."""
+import warnings
+
+import numpy as np
+import pytest
+
+from golden_util import gen_c2
+from oracle import aeq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def m():
+  import torch
+  assert torch.cuda.is_available()
+  import __graft_entry__ as g
+  g.build()
+  import types
+  from mi355q import distributed, ops, qtyping
+  from mi355q.algorithms.uniform_quantize import gptq, hadamard_rotation, naive_min_max_quantize, octav
+  return types.SimpleNamespace(torch=torch, ops=ops, q=qtyping, gptq=gptq, had=hadamard_rotation,
+                               mm=naive_min_max_quantize, octav=octav, dist=distributed)
+
+
+def info_cfg(m, bits, gran, **algo):
+  q = m.q
+  cfg = q.TensorQuantizationConfig(num_bits=bits, symmetric=True, granularity=q.QuantGranularity[gran],
+                                   algorithm_params=algo)
+  return q.OpInfo(op=q.OperatorT(), op_name=q.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
+                  op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg)), cfg
+
+
+def test_c2_requant_is_idempotent_on_dequantized_weights(m):
+  """quantize(dequantize(q)) == q with the same scales: a size-independent property of a3."""
+  w = gen_c2()
+  x = m.torch.from_numpy(w).cuda()
+  r = m.ops.requant_sym(x, 0, 8)
+  deq = r["q"].to(m.torch.float32) * r["scale"].unsqueeze(1)
+  q2 = m.ops.quantize(deq, 1, 4096, 4096, r["scale"], None, 8, True)
+  assert m.torch.equal(q2, r["q"])
+  # |w - deq| <= scale/2 wherever the value is not clipped (it never is for min/max scales)
+  err = (x - deq).abs()
+  assert bool((err <= r["scale"].unsqueeze(1) * 0.5000001).all())
+
+
+def test_c3_shape_blockwise_scales_bound_every_block(m):
+  w = (np.random.default_rng(1003).standard_normal((1024, 11008), dtype=np.float32) * np.float32(0.02))
+  x = m.torch.from_numpy(w).cuda()
+  r = m.ops.requant_sym(x, 128, 4, want_packed=True, want_scale_f16=True)
+  ref = O.min_max_quant_params(w, 4, True, "BLOCKWISE_128")
+  assert np.array_equal(r["q"].cpu().numpy(), ref["quantized_data"])
+  assert np.array_equal(r["scale"].cpu().numpy(), ref["scale"])
+  q = r["q"].cpu().numpy()
+  assert q.min() >= -8 and q.max() <= 7
+  lo = (r["packed"].cpu().numpy() & 0xF).astype(np.int8)
+  hi = (r["packed"].cpu().numpy() >> 4).astype(np.int8)
+  unpacked = np.stack([lo, hi], 1).reshape(-1)
+  unpacked = np.where(unpacked > 7, unpacked - 16, unpacked).astype(np.int8)
+  assert np.array_equal(unpacked, q.reshape(-1))  # pack/unpack round trip
+
+
+def test_c4_parity_subset_16_samples_through_gather_and_replay(m):
+  """First 16 samples of the C4 workload shape (32 activation tensors of [1,256,4096]),
+  sentinels planted as in SURVEY 8d; world_size 1 path of the multi-GPU layer."""
+  rng = np.random.default_rng(44)
+  names = [f"act{i}" for i in range(32)]
+  samples = []
+  for s in range(16):
+    d = {}
+    for i, n in enumerate(names):
+      x = rng.standard_normal((1, 64, 4096), dtype=np.float32) * np.float32(1 + i / 8)
+      if (s * 32 + i) % 97 == 0:
+        x.reshape(-1)[:4] = [np.inf, -np.inf, 3.39e38, -3.39e38]
+      d[n] = x
+    samples.append(d)
+  stats = m.dist.local_activation_stats(samples, names)
+  assert stats.shape == (16, 32, 2)
+  stats = m.dist.gather_sample_stats(stats)
+  qsvs = m.dist.replay_qsv_updates(stats, names, [samples[0][n].shape for n in names])
+  ref = {}
+  for smp in samples:
+    for n in names:
+      r = O.activation_min_max(smp[n], -3e38, 3e38)
+      ref[n] = O.moving_average_update(ref.get(n), r)
+  for n in names:
+    assert np.array_equal(qsvs[n]["min"], ref[n]["min"]) and np.array_equal(qsvs[n]["max"], ref[n]["max"])
+  mm = m.dist.allreduce_min_max(stats)
+  for i, n in enumerate(names):
+    assert mm[i, 0] == min(O.activation_min_max(s[n], -3e38, 3e38)["min"].item() for s in samples)
+
+
+def test_hadamard_octav_4096_against_oracle(m):
+  """Hadamard(h=4096) + OCTAV int4 on 512 x 4096 (the C5 Hadamard shape, fewer rows so the
+  NumPy oracle finishes in seconds). T2: scales 1e-6 rel, ints +-1 on a tiny fraction."""
+  w = np.random.default_rng(55).standard_normal((512, 4096), dtype=np.float32)
+  info, cfg = info_cfg(m, 4, "CHANNELWISE")
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    ref = O.hadamard_quant_params(w, 4, "CHANNELWISE")
+  p = m.had.get_tensor_quant_params(info, cfg, w)
+  assert p.hadamard.hadamard_size == 4096
+  np.testing.assert_allclose(p.scale, ref["scale"], rtol=2e-6)
+  diff = np.abs(p.quantized_data.astype(np.int32) - ref["quantized_data"].astype(np.int32))
+  assert diff.max() <= 1 and (diff != 0).mean() <= 2e-4
+
+
+def test_octav_4096_rows_bit_exact(m):
+  w = np.random.default_rng(56).standard_normal((256, 4096), dtype=np.float32)
+  w[3] *= 40
+  info, cfg = info_cfg(m, 4, "CHANNELWISE")
+  ref = O.octav_quant_params(w, 4, "CHANNELWISE")
+  p = m.octav.get_tensor_quant_params(info, cfg, w)
+  assert np.array_equal(p.scale, ref["scale"]) and np.array_equal(p.quantized_data, ref["quantized_data"])
+
+
+def test_gptq_gemma_attention_shape_against_oracle(m):
+  """d = 2048 (Gemma-2B q/o projection), 256 output rows, Hessian from 4096 tokens."""
+  rng = np.random.default_rng(57)
+  d, rows = 2048, 256
+  w = (rng.standard_normal((rows, d)) * 0.02).astype(np.float32)
+  x = rng.standard_normal((8, 512, d)).astype(np.float32)
+  x[..., :16] *= 6
+  hg = m.gptq.hessian_of(x, np.array(8))
+  h = O.gptq_hessian(x)
+  assert np.max(np.abs(hg - h)) <= 3e-6 * np.abs(h).max()
+  info, cfg = info_cfg(m, 4, "CHANNELWISE")
+  ref = O.gptq_quant_params(w, 4, True, "CHANNELWISE",
+                            {"activation_tensor_qsv": {"hessian": h, "num_samples": 8}})
+  p = m.gptq.get_tensor_quant_params(info, cfg, w,
+                                     {"activation_tensor_qsv": {"hessian": hg, "num_samples": 8}})
+  assert np.array_equal(p.scale, ref["scale"])
+  diff = np.abs(p.quantized_data.astype(np.int32) - ref["quantized_data"].astype(np.int32))
+  assert diff.max() <= 1 and (diff != 0).mean() <= 2e-3
