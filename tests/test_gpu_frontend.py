@@ -226,28 +226,3 @@ def test_hadamard_recipe_materializes_rotation_instruction(m):
   with pytest.raises(NotImplementedError, match="graph rewriting"):
     m.quantizer.apply_quantize_tensor_transformations(model, params)
 
-
-def test_pipelined_weight_stream_matches_per_tensor_path(m):
-  from mi355q import pipeline
-  rng = np.random.default_rng(10)
-  ws = [rng.standard_normal(s).astype(np.float32) for s in ((64, 256), (8, 1024), (100, 128), (3, 5, 64), (256, 256))]
-  for block, bits, gran in ((0, 8, "CHANNELWISE"), (128, 4, "BLOCKWISE_128"), (0, 4, "CHANNELWISE")):
-    use = [w for w in ws if not block or w.shape[-1] % block == 0]
-    use = [w for w in use if block or w.ndim == 2 or True]
-    res = pipeline.requantize_weights(use, block, bits, want_q=True, want_packed=True, slots=2)
-    assert len(res) == len(use)
-    for w, r in zip(use, res):
-      if w.ndim == 3 and block:
-        w2 = w.reshape(-1, w.shape[-1])
-        ref = O.min_max_quant_params(w2, bits, True, gran)
-        assert np.array_equal(r.quantized_data.reshape(w2.shape), ref["quantized_data"])
-        continue
-      ref = O.min_max_quant_params(w, bits, True, gran)
-      assert np.array_equal(r.quantized_data, ref["quantized_data"])
-      assert np.array_equal(r.scale.reshape(ref["scale"].shape), ref["scale"])
-      assert np.array_equal(r.packed, O.pack_data(bits, np.ravel(ref["quantized_data"]).view(np.uint8)))
-      if block:
-        assert np.array_equal(r.scale_f16.reshape(ref["scale"].shape), O.blockwise_scale_f16(ref["scale"]))
-  assert pipeline.requantize_weights([], 0, 8) == []
-  with pytest.raises(TypeError):
-    pipeline.requantize_weights([np.zeros((4, 4), np.float64)], 0, 8)
