@@ -13,7 +13,6 @@ from collections.abc import Mapping, MutableMapping, Sequence
 from typing import Any
 
 import numpy as np
-import torch
 
 from ... import ops
 from ... import qtyping

@@ -82,7 +82,6 @@ def get_tensor_quant_params(
 # the tensor on the other side of the matmul gets an INSERT_(DECOMPOSED_)HADAMARD_
 # ROTATION instruction carrying the same params (the graph rewrite itself is
 # outside the hot path).
-from ..utils import common_utils as _cu  # noqa: E402
 from ...utils import tfl_flatbuffer_utils as _fb  # noqa: E402
 
 _T = qtyping.QuantTransformation

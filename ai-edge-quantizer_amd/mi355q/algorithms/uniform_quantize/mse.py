@@ -5,7 +5,6 @@ mi355q_mse_scale_f32 in NumPy's pairwise order (bit-identical scales).
 """
 from __future__ import annotations
 
-import dataclasses
 from typing import Any, Optional
 
 import numpy as np
@@ -14,7 +13,6 @@ from ... import ops
 from ... import qtyping
 from ... import runtime as rt
 from ..utils import common_utils
-from . import common_quantize
 from . import naive_min_max_quantize
 from . import uniform_quantize_tensor
 

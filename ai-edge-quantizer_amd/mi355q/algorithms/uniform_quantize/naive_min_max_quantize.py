@@ -14,7 +14,6 @@ from collections.abc import MutableMapping, Sequence
 from typing import Any, Optional
 
 import numpy as np
-import torch
 
 from ... import ops
 from ... import qtyping

@@ -7,6 +7,7 @@ bound = clip(max|x|, -c, c) -> scale -> quantize in one more pass.
 """
 from __future__ import annotations
 
+import dataclasses
 from typing import Any, Optional
 
 import numpy as np
@@ -120,5 +121,4 @@ def get_tensor_quant_params(
       scale=scale, zero_point=zp, num_bits=cfg.num_bits, symmetric=cfg.symmetric,
       quantized_dimension=quantized_dim, block_size=block_size)
   q = uniform_quantize_tensor.uniform_quantize(tensor_content, params, is_blockwise_quant=blockwise)
-  import dataclasses
   return dataclasses.replace(params, quantized_data=q)

@@ -10,10 +10,9 @@ activations; weights get it fused in-kernel, see naive_min_max_quantize).
 from __future__ import annotations
 
 import dataclasses
-from typing import Any, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
-import torch
 
 from ... import ops
 from ... import qtyping
