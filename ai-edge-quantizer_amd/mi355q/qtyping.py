@@ -47,6 +47,12 @@ class FrozenMapping(dict):
   def _readonly(self, *_, **__):
     raise TypeError("FrozenMapping is read-only")
 
+  def __deepcopy__(self, memo):
+    return FrozenMapping({copy.deepcopy(k, memo): copy.deepcopy(v, memo) for k, v in self.items()})
+
+  def __reduce__(self):
+    return (FrozenMapping, (dict(self),))
+
   __setitem__ = __delitem__ = clear = pop = popitem = setdefault = update = _readonly
 
 
@@ -275,7 +281,7 @@ def _plain_dict(obj) -> dict[str, Any]:
     for k, v in items:
       if v is None or (isinstance(v, Mapping) and not v):
         continue
-      out[k] = dict(v) if isinstance(v, Mapping) and not isinstance(v, dict) else v
+      out[k] = dict(v) if isinstance(v, Mapping) and type(v) is not dict else v
     return out
   return dataclasses.asdict(obj, dict_factory=factory)
 

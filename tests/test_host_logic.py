@@ -1,0 +1,230 @@
+"""CPU-only tests of the host side of the drop-in layer: value types, registry,
+recipe resolution, the O(#scales) parameter math and argument validation that
+happens before any kernel is launched."""
+import numpy as np
+import pytest
+
+from golden_util import case_names
+from oracle import aeq_oracle as O
+
+from mi355q import algorithm_manager as am
+from mi355q import algorithm_manager_api
+from mi355q import qtyping as q
+from mi355q import recipe, recipe_manager
+from mi355q.algorithms.uniform_quantize import (hadamard_rotation, mse, naive_min_max_quantize,
+                                                octav, uniform_quantize_tensor as uqt)
+from mi355q.algorithms.utils import common_utils
+from mi355q.transformations import quantize_tensor
+from mi355q.utils import qsv_utils, tfl_flatbuffer_utils
+
+
+def test_uniform_quant_params_value_equality():
+  a = q.UniformQuantParams(8, 0, np.array([1.0, 2.0], np.float32), np.zeros(2, np.int8),
+                           quantized_data=np.arange(4, dtype=np.int8))
+  b = q.UniformQuantParams(8, 0, np.array([1.0, 2.0], np.float32), np.zeros(2, np.int8),
+                           quantized_data=np.arange(4, dtype=np.int8))
+  assert a == b and a is not b
+  assert a != q.UniformQuantParams(8, 0, np.array([1.0, 2.5], np.float32), np.zeros(2, np.int8))
+  h = q.UniformQuantParams.HadamardRotationParams
+  assert h(np.ones(4, np.int8), 4) == h(np.ones(4, np.int8), 4)
+  assert h(np.ones(4, np.int8), 4) != h(np.ones(4, np.int8), 8)
+  with pytest.raises(TypeError):
+    hash(a)
+  with pytest.raises(Exception):
+    a.num_bits = 4  # frozen
+
+
+def test_tensor_quantization_config_dict_round_trip_and_legacy_block_size():
+  c = q.TensorQuantizationConfig.from_dict({"num_bits": 4, "block_size": 64, "max_hadamard_size": 128})
+  assert c.granularity == q.QuantGranularity.BLOCKWISE_64
+  assert c.algorithm_params == {"max_hadamard_size": 128} and hash(c) is not None
+  assert q.TensorQuantizationConfig.from_dict(c.to_dict()) == c
+  with pytest.raises(ValueError, match="Unsupported block size"):
+    q.TensorQuantizationConfig.from_dict({"num_bits": 4, "block_size": 48})
+  with pytest.raises(ValueError, match="integer activation but float weights"):
+    q.OpQuantizationConfig(activation_tensor_config=q.TensorQuantizationConfig(8),
+                           weight_tensor_config=q.TensorQuantizationConfig(16, dtype=q.TensorDataType.FLOAT))
+  with pytest.raises(ValueError, match="must be SRQ"):
+    q.OpQuantizationConfig(activation_tensor_config=q.TensorQuantizationConfig(8),
+                           weight_tensor_config=q.TensorQuantizationConfig(8))
+
+
+def test_registry_api_surface():
+  api = algorithm_manager_api.AlgorithmManagerApi()
+  fns = dict(init_qsv_func=lambda *a, **k: {}, calibration_func=lambda *a, **k: {"c": 1},
+             materialize_func=lambda *a, **k: ["m"])
+  api.register_quantized_op("alg", q.TFLOperationName.FULLY_CONNECTED, **fns)
+  assert api.is_algorithm_registered("alg") and api.is_op_registered("alg", q.TFLOperationName.FULLY_CONNECTED)
+  assert api.get_supported_ops("alg") == [q.TFLOperationName.FULLY_CONNECTED]
+  assert api.get_quantization_func("alg", q.TFLOperationName.FULLY_CONNECTED, q.QuantizeMode.MATERIALIZE)() == ["m"]
+  assert api.get_quantization_func("alg", q.TFLOperationName.FULLY_CONNECTED, q.QuantizeMode.CALIBRATE)() == {"c": 1}
+  assert api.get_update_qsv_func("alg", q.TFLOperationName.FULLY_CONNECTED) is qsv_utils.moving_average_update
+  with pytest.raises(ValueError, match="Unsupported operation"):
+    api.get_quantization_func("alg", q.TFLOperationName.CONV_2D, q.QuantizeMode.MATERIALIZE)
+  with pytest.raises(ValueError, match="Unregistered algorithm"):
+    api.get_supported_ops("nope")
+  with pytest.raises(ValueError, match="Config checking function"):
+    api.check_op_quantization_config("alg", q.TFLOperationName.FULLY_CONNECTED, q.OpQuantizationConfig())
+  api.check_op_quantization_config("alg", q.TFLOperationName.CONV_2D, q.OpQuantizationConfig(skip_checks=True))
+
+
+def test_module_registry_has_every_hot_path_algorithm():
+  for name in ("min_max_uniform_quantize", "OCTAV", "MSE", "GPTQ", "HADAMARD_ROTATION",
+               "DECOMPOSED_HADAMARD_ROTATION"):
+    assert am.is_algorithm_registered(name)
+    assert am.is_op_registered(name, q.TFLOperationName.FULLY_CONNECTED)
+  assert am.AlgorithmName("OCTAV") is am.AlgorithmName.OCTAV
+  assert am.get_update_qsv_func("GPTQ", q.TFLOperationName.FULLY_CONNECTED) is \
+      qsv_utils.gptq_and_moving_average_update
+  fn = am.get_quantization_func("OCTAV", q.TFLOperationName.FULLY_CONNECTED, q.QuantizeMode.MATERIALIZE)
+  assert fn.args == (octav.get_tensor_quant_params,)  # functools.partial(materialize, get_tensor_quant_params)
+
+
+def test_recipe_resolution_last_valid_match_wins():
+  rm = recipe_manager.RecipeManager()
+  rm.add_dynamic_config(".*", q.TFLOperationName.ALL_SUPPORTED, 8)
+  rm.add_dynamic_config("attn", q.TFLOperationName.FULLY_CONNECTED, 4,
+                        granularity=q.QuantGranularity.BLOCKWISE_32, algorithm_key="OCTAV")
+  rm.add_quantization_config("skip_me", q.TFLOperationName.FULLY_CONNECTED, algorithm_key="no_quantize")
+  FC = q.TFLOperationName.FULLY_CONNECTED
+  assert rm.get_quantization_configs(FC, "mlp/out;")[0] == "min_max_uniform_quantize"
+  alg, cfg = rm.get_quantization_configs(FC, "layer0/attn/q;")
+  assert alg == "OCTAV" and cfg.weight_tensor_config.granularity == q.QuantGranularity.BLOCKWISE_32
+  assert rm.get_quantization_configs(FC, "attn/skip_me;")[0] == "no_quantize"
+  # blockwise is not valid for the virtual INPUT op -> falls back to the earlier match
+  assert rm.get_quantization_configs(q.TFLOperationName.INPUT, "attn;")[0] == "min_max_uniform_quantize"
+  assert rm.get_quantization_configs(q.TFLOperationName.SOFTMAX, "x;")[0] == "no_quantize"
+  rt = recipe_manager.RecipeManager()
+  rt.load_quantization_recipe(rm.get_quantization_recipe())
+  assert rt.get_quantization_recipe() == rm.get_quantization_recipe()
+  assert not rm.need_calibration()
+  rs = recipe_manager.RecipeManager()
+  rs.load_quantization_recipe(recipe.static_wi8_ai8())
+  assert rs.need_calibration()
+  with pytest.raises(ValueError, match="Unsupported algorithm key"):
+    rm.add_quantization_config(".*", FC, algorithm_key="bogus")
+  assert recipe.dynamic_wi4b32_afp32()[0]["op_config"]["weight_tensor_config"]["granularity"] == \
+      q.QuantGranularity.BLOCKWISE_32
+
+
+@pytest.mark.parametrize("name", case_names("min_max"))
+def test_host_zp_scale_math_matches_reference(ref_cases, name):
+  """tensor_zp_scale_from_min_max (host NumPy, O(#scales)) against the reference's outputs."""
+  arrays, cases = ref_cases
+  c = cases[name]
+  w = arrays[f"{name}/w"]
+  mmv = O.init_tensor_min_max(w, c["granularity"], c["quantized_dimension"])
+  import warnings
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    zp, scale = uqt.tensor_zp_scale_from_min_max(mmv["min"], mmv["max"], c["num_bits"], c["symmetric"],
+                                                 q.QuantGranularity[c["granularity"]])
+  assert np.array_equal(scale, arrays[f"{name}/scale"], equal_nan=True)
+  assert np.array_equal(zp, arrays[f"{name}/zero_point"]) and zp.dtype == arrays[f"{name}/zero_point"].dtype
+
+
+def test_host_helpers_and_validation_errors():
+  assert uqt.get_quantized_range(uqt.IntType(4, True)) == (-8.0, 7.0)
+  assert uqt.extract_block_size_from_granularity(q.QuantGranularity.BLOCKWISE_128) == 128
+  assert uqt.extract_block_size_from_granularity(q.QuantGranularity.CHANNELWISE) == 0
+  assert uqt._channel_view((8, 3, 3, 16), (8, 1, 1, 1)) == (1, 8, 144)
+  assert uqt._channel_view((1, 3, 3, 24), (1, 1, 1, 24)) == (9, 24, 1)
+  assert uqt._channel_view((4, 5), (1, 1)) == (1, 1, 20)
+  with pytest.raises(NotImplementedError):
+    uqt._channel_view((4, 5, 6), (4, 1, 6))
+  x = np.array([-3.0, 1.3, 2.4, 16.0])
+  p = q.UniformQuantParams(4, 0, np.array([[[1.2666667]]]), np.array([[-6]]))
+  with pytest.raises(ValueError, match=r"Ranks of scales \(3\) and zps \(2\)"):
+    uqt.uniform_quantize(x, p)
+  with pytest.raises(ValueError, match="zero_points need to be"):
+    uqt.uniform_quantize(x, q.UniformQuantParams(8, 0, np.array([1.0]), np.array([0.5])))
+  with pytest.raises(ValueError, match="single element for scalar tensor"):
+    uqt.fix_quantization_params_rank(np.array(6.66), q.UniformQuantParams(8, 0, np.ones(2), np.zeros(2, np.int8)))
+  with pytest.raises(TypeError, match="not exactly representable"):
+    uqt._as_f32_exact(np.array([0.1], np.float64))
+  assert uqt._as_f32_exact(np.array([0.5, 3.0], np.float64)).dtype == np.float32
+  assert np.array_equal(uqt.round_to_bf16(np.array([1.0, 1.00390625, 1.01171875], np.float32)),
+                        O.round_to_bf16(np.array([1.0, 1.00390625, 1.01171875], np.float32)))
+
+
+def test_algorithm_argument_errors_raise_before_any_gpu_work():
+  cfg = q.TensorQuantizationConfig(num_bits=4, symmetric=False, granularity=q.QuantGranularity.CHANNELWISE)
+  info = q.OpInfo(op=q.OperatorT(), op_name=q.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=3,
+                  op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg))
+  w = np.ones((4, 4), np.float32)
+  with pytest.raises(ValueError, match="Unsupported symmetry"):
+    octav.get_tensor_quant_params(info, cfg, w)
+  with pytest.raises(ValueError, match="Unsupported symmetry"):
+    mse.get_tensor_quant_params(info, cfg, w)
+  bcfg = q.TensorQuantizationConfig(num_bits=4, granularity=q.QuantGranularity.BLOCKWISE_32)
+  with pytest.raises(ValueError, match="Blockwise quantization is not supported for MSE"):
+    mse.get_tensor_quant_params(info, bcfg, w)
+  with pytest.raises(ValueError, match="only supported for weight tensors"):
+    hadamard_rotation.get_tensor_quant_params(info, cfg, None)
+  with pytest.raises(ValueError, match="static quantization"):
+    hadamard_rotation.get_tensor_quant_params(info, cfg, w, {})
+  with pytest.raises(ValueError, match="rank >= 2"):
+    hadamard_rotation.get_tensor_quant_params(info, cfg, np.ones(4, np.float32))
+  with pytest.raises(ValueError, match=r"FULLY_CONNECTED\(index: 3\) not found in tensor_name_to_qsv"):
+    naive_min_max_quantize.get_tensor_quant_params(info, cfg, None, None)
+  with pytest.raises(ValueError, match="power of 2"):
+    hadamard_rotation._make_hadamard_matrix(12)
+  assert hadamard_rotation.hadamard_size_for(11008) == 256
+  assert hadamard_rotation.hadamard_size_for(4096, 100) == 64
+  assert np.array_equal(hadamard_rotation._make_hadamard_matrix(8), O.hadamard_matrix(8))
+
+
+def test_activation_params_from_qsv_need_no_gpu():
+  """tensor_content=None (activations): pure host math, same as the reference."""
+  for bits, sym in ((8, False), (8, True), (16, True)):
+    cfg = q.TensorQuantizationConfig(num_bits=bits, symmetric=sym)
+    info = q.OpInfo(op=q.OperatorT(), op_name=q.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
+                    op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg))
+    qsv = {"min": np.array([[-3.25]], np.float32), "max": np.array([[7.5]], np.float32)}
+    p = naive_min_max_quantize.get_tensor_quant_params(info, cfg, None, qsv)
+    zp, scale = O.zp_scale_from_min_max(qsv["min"], qsv["max"], bits, sym, "TENSORWISE")
+    assert p.quantized_data is None and np.array_equal(p.scale, scale) and np.array_equal(p.zero_point, zp)
+
+
+def test_transformation_table_and_dim_helpers():
+  T = q.QuantTransformation
+  w8 = q.TensorQuantizationConfig(8, granularity=q.QuantGranularity.CHANNELWISE)
+  drq = q.OpQuantizationConfig(weight_tensor_config=w8, compute_precision=q.ComputePrecision.INTEGER)
+  wo = q.OpQuantizationConfig(weight_tensor_config=w8, explicit_dequantize=True)
+  srq = q.OpQuantizationConfig(activation_tensor_config=q.TensorQuantizationConfig(8, symmetric=False),
+                               weight_tensor_config=w8, compute_precision=q.ComputePrecision.INTEGER)
+  g = common_utils.get_tensor_transformations
+  assert g(drq, True, True) == [T.QUANTIZE_TENSOR] and g(drq, True, False) == [T.NO_QUANTIZE]
+  assert g(wo, True, True) == [T.ADD_DEQUANTIZE] and g(wo, False, False) == [T.NO_QUANTIZE]
+  assert g(srq, True, False) == [T.ADD_QUANTIZE] and g(srq, True, True) == [T.QUANTIZE_TENSOR]
+  assert g(srq, False, False) == [T.ADD_DEQUANTIZE]
+  with pytest.raises(ValueError, match="Unsupported compute precision"):
+    g(q.OpQuantizationConfig(weight_tensor_config=w8), True, True)
+  assert common_utils.get_reduce_dims(0, (4, 5, 6)) == (1, 2) and common_utils.get_reduce_dims(None, (4,)) is None
+  info = q.OpInfo(q.OperatorT(), q.TFLOperationName.DEPTHWISE_CONV_2D, 0, drq)
+  assert common_utils.get_weight_quantized_dim(info, np.zeros((1, 3, 3, 8)), q.QuantGranularity.CHANNELWISE) == 3
+  assert tfl_flatbuffer_utils.TFL_OP_TO_BLOCKWISE_WEIGHT_QUANTIZED_DIM[q.TFLOperationName.EMBEDDING_LOOKUP] == 1
+  with pytest.raises(ValueError, match="Unsupported op for blockwise"):
+    common_utils.check_subchannel_config(
+        q.TFLOperationName.CONV_2D,
+        q.OpQuantizationConfig(weight_tensor_config=q.TensorQuantizationConfig(
+            4, granularity=q.QuantGranularity.BLOCKWISE_32)))
+  assert quantize_tensor.quant_params_to_tflite_type(4) == q.TensorType.INT4
+  assert quantize_tensor.quant_params_to_tflite_type(2) == q.TensorType.INT2
+  assert quantize_tensor.quant_params_to_tflite_type(8) == q.TensorType.INT8
+  assert quantize_tensor.quant_params_to_tflite_type(32) == q.TensorType.INT32
+  with pytest.raises(ValueError, match="Unsupported bitwidth"):
+    quantize_tensor.quant_params_to_tflite_type(128)
+
+
+def test_op_scope_and_tensor_data_views():
+  w = np.arange(12, dtype=np.float32).reshape(3, 4)
+  t = [q.TensorT(name=b"in", shape=[1, 4], buffer=0), q.TensorT(name=b"w", shape=[3, 4], buffer=1),
+       q.TensorT(name=b"out/a", shape=[1, 3], buffer=0), q.TensorT(name=b"out/b", shape=[1, 3], buffer=0)]
+  bufs = [q.BufferT(), q.BufferT(data=w.view(np.uint8).reshape(-1))]
+  op = q.OperatorT(inputs=[0, 1, -1], outputs=[2, 3])
+  assert tfl_flatbuffer_utils.get_op_scope(op, t) == "out/a;out/b;"
+  assert tfl_flatbuffer_utils.get_op_scope(q.OperatorT(inputs=[0], outputs=[]), t) == "in;"
+  assert tfl_flatbuffer_utils.get_tensor_data(t[0], bufs) is None
+  view = tfl_flatbuffer_utils.get_tensor_data(t[1], bufs)
+  assert np.array_equal(view, w) and np.shares_memory(view, bufs[1].data)  # zero copy
