@@ -148,6 +148,32 @@ struct OctavArgs {
   int* not_close;   // [max_iter] units whose guess still moved
 };
 
+struct OctavStep {
+  float next;
+  bool close;
+};
+
+// One Newton update from the two masked sums and their element counts
+// (ref octav.py:76-110), with NumPy's promotions spelled out.
+__device__ __forceinline__ OctavStep octav_step(float guess, float pos_sum, float neg_sum,
+                                                long long pos_count, long long neg_count,
+                                                long long len, float s, int count_is_f64) {
+  const float num = pos_sum - neg_sum;
+  float den = static_cast<float>(pos_count);
+  den = static_cast<float>(static_cast<double>(den) + static_cast<double>(neg_count));
+  den = den * (1.0f - s);
+  if (count_is_f64)
+    den = static_cast<float>(static_cast<double>(den) +
+                             static_cast<double>(s) * static_cast<double>(len));
+  else
+    den = den + s * static_cast<float>(len);
+  const float next = num / den;
+  // np.allclose(old, new): |old - new| <= atol + rtol * |new|, all float32
+  const float tol = 1e-8f + 1e-5f * fabsf(next);
+  const bool close = (fabsf(guess - next) <= tol && __builtin_isfinite(next)) || guess == next;
+  return {next, close};
+}
+
 template <bool USE_LDS>
 __global__ void octav_kernel(OctavArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -162,7 +188,6 @@ __global__ void octav_kernel(OctavArgs a) {
   if (!live) return;
 
   const int len = a.len;
-  const float one_minus_s = 1.0f - a.s;
   const float qnan = __builtin_nanf("");
   float guess = 1.0f;
   for (int it = 0; it < a.max_iter; ++it) {
@@ -176,26 +201,136 @@ __global__ void octav_kernel(OctavArgs a) {
     }
     pos.flush(u, lane);
     neg.flush(u, lane);
-    // ref octav.py:76-108, with NumPy's promotions spelled out
-    const float num = pos.acc - neg.acc;
-    float den = static_cast<float>(pos.count);
-    den = static_cast<float>(static_cast<double>(den) + static_cast<double>(neg.count));
-    den = den * one_minus_s;
-    if (a.count_is_f64)
-      den = static_cast<float>(static_cast<double>(den) +
-                               static_cast<double>(a.s) * static_cast<double>(len));
-    else
-      den = den + a.s * static_cast<float>(len);
-    const float next = num / den;
-    // np.allclose(old, new): |old - new| <= atol + rtol * |new|, all float32
-    const float tol = 1e-8f + 1e-5f * fabsf(next);
-    const bool close = (fabsf(guess - next) <= tol && __builtin_isfinite(next)) || guess == next;
+    const OctavStep st = octav_step(guess, pos.acc, neg.acc, pos.count, neg.count, len, a.s,
+                                    a.count_is_f64);
     if (lane == 0) {
-      a.hist[static_cast<long long>(it) * a.units + unit] = next;
-      if (!close) atomicAdd(&a.not_close[it], 1);
+      a.hist[static_cast<long long>(it) * a.units + unit] = st.next;
+      if (!st.close) atomicAdd(&a.not_close[it], 1);
     }
-    guess = next;
+    guess = st.next;
   }
+}
+
+// ---- general [outer, channels, inner] view: unit c = the `outer` segments x[o, c, :] -----
+// NumPy hands each contiguous segment to the inner loop separately and keeps one running
+// total per channel: acc = acc + pairwise(run) for every run of every segment, in order
+// (tests/test_numpy_sum_model.py::test_mixed_reductions). One wave per channel; segments are
+// read from global memory (L2-resident after the first Newton iteration).
+__global__ void octav_seg_kernel(OctavArgs a, long long channels, long long outer) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const long long c = static_cast<long long>(blockIdx.x) * (blockDim.x / kWave) + wave;
+  if (c >= channels) return;
+  const int inner = a.len;
+  const float qnan = __builtin_nanf("");
+  float guess = 1.0f;
+  for (int it = 0; it < a.max_iter; ++it) {
+    RunSum pos, neg;
+    long long npos = 0, nneg = 0;
+    const float hi = guess, lo = -guess;
+    for (long long o = 0; o < outer; ++o) {
+      const float* u = a.x + (o * channels + c) * inner;
+      for (int base = 0; base < inner; base += kWave) {
+        const int i = base + lane;
+        const float v = i < inner ? u[i] : qnan;
+        pos.feed(__ballot(v >= hi), base, v, u, lane);
+        neg.feed(__ballot(v <= lo), base, v, u, lane);
+      }
+      pos.flush(u, lane);
+      neg.flush(u, lane);
+      npos += pos.count;
+      nneg += neg.count;
+      pos.count = neg.count = 0;
+    }
+    const OctavStep st = octav_step(guess, pos.acc, neg.acc, npos, nneg, outer * inner, a.s, 1);
+    if (lane == 0) {
+      a.hist[static_cast<long long>(it) * a.units + c] = st.next;
+      if (!st.close) atomicAdd(&a.not_close[it], 1);
+    }
+    guess = st.next;
+  }
+}
+
+__global__ void mse_scale_seg_kernel(const float* __restrict__ x, long long outer, long long channels,
+                                     int inner, float multiplier, float* __restrict__ scale) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const long long c = static_cast<long long>(blockIdx.x) * (blockDim.x / kWave) + wave;
+  if (c >= channels) return;
+  float acc = 0.f;
+  bool first = true;
+  for (long long o = 0; o < outer; ++o) {
+    const float* u = x + (o * channels + c) * inner;
+    for (int k = 0; k < inner; k += kChunk) {
+      const int n = inner - k < kChunk ? inner - k : kChunk;
+      const float part = pairwise_sum<true, 8>(u + k, n, lane);
+      acc = first ? part : acc + part;
+      first = false;
+    }
+  }
+  const float mean = acc / static_cast<float>(outer * inner);
+  if (lane == 0) scale[c] = multiplier * __builtin_sqrtf(mean);
+}
+
+// ---- channel-last units: x viewed as [outer, channels], one unit per channel -------------
+// NumPy reduces the leading axes of a C-contiguous array row by row (`out[c] += x[o, c]`,
+// masked elements skipped), i.e. each channel is a plain left-to-right float32 sum over o
+// (tests/numpy_sum_model.py states and checks this). One lane per channel keeps that order and
+// makes every load a coalesced row segment.
+constexpr int kColsUnroll = 8;
+
+__global__ __launch_bounds__(256) void octav_cols_kernel(OctavArgs a, long long channels) {
+  const long long c = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= channels) return;
+  const long long outer = a.len;
+  float guess = 1.0f;
+  for (int it = 0; it < a.max_iter; ++it) {
+    const float hi = guess, lo = -guess;
+    float pos = 0.f, neg = 0.f;
+    long long npos = 0, nneg = 0;
+    const float* p = a.x + c;
+    long long o = 0;
+    for (; o + kColsUnroll <= outer; o += kColsUnroll) {
+      float v[kColsUnroll];
+#pragma unroll
+      for (int k = 0; k < kColsUnroll; ++k) v[k] = p[static_cast<long long>(k) * channels];
+#pragma unroll
+      for (int k = 0; k < kColsUnroll; ++k) {
+        if (v[k] >= hi) { pos = pos + v[k]; ++npos; }
+        if (v[k] <= lo) { neg = neg + v[k]; ++nneg; }
+      }
+      p += kColsUnroll * channels;
+    }
+    for (; o < outer; ++o, p += channels) {
+      const float v = *p;
+      if (v >= hi) { pos = pos + v; ++npos; }
+      if (v <= lo) { neg = neg + v; ++nneg; }
+    }
+    const OctavStep st = octav_step(guess, pos, neg, npos, nneg, outer, a.s, a.count_is_f64);
+    a.hist[static_cast<long long>(it) * a.units + c] = st.next;
+    if (!st.close) atomicAdd(&a.not_close[it], 1);
+    guess = st.next;
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_scale_cols_kernel(const float* __restrict__ x, long long outer,
+                                                            long long channels, float multiplier,
+                                                            float* __restrict__ scale) {
+  const long long c = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= channels) return;
+  const float* p = x + c;
+  float acc = 0.f;
+  long long o = 0;
+  for (; o + kColsUnroll <= outer; o += kColsUnroll) {
+    float v[kColsUnroll];
+#pragma unroll
+    for (int k = 0; k < kColsUnroll; ++k) v[k] = p[static_cast<long long>(k) * channels];
+#pragma unroll
+    for (int k = 0; k < kColsUnroll; ++k) acc = acc + v[k] * v[k];
+    p += kColsUnroll * channels;
+  }
+  for (; o < outer; ++o, p += channels) acc = acc + (*p) * (*p);
+  scale[c] = multiplier * __builtin_sqrtf(acc / static_cast<float>(outer));
 }
 
 // The reference stops at the first iteration where *every* unit is close
@@ -319,6 +454,75 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
   hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
                      hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
   MI355Q_CHECK_LAUNCH("octav pick launch");
+  return MI355Q_OK;
+}
+
+extern "C" int32_t mi355q_octav_clip_nd_f32(const float* x, int64_t outer, int64_t channels,
+                                            int64_t inner, int32_t bits, int32_t max_iter,
+                                            float exponent_divisor, int32_t early_stop, float* clip_out,
+                                            int32_t* iters_out, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  if (outer == 1)  // contiguous units: the LDS-staged kernel
+    return mi355q_octav_clip_f32(x, channels, inner, bits, max_iter, exponent_divisor, early_stop, 1,
+                                 clip_out, iters_out, workspace, workspace_bytes, stream);
+  clear_error();
+  if (outer < 0 || channels < 0 || inner < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (max_iter < 1 || max_iter > 64) return fail(MI355Q_BAD_ARG, "max_iter must be in [1, 64]");
+  if (bits < 1 || bits > 16) return fail(MI355Q_BAD_ARG, "bits must be in [1, 16]");
+  if (channels == 0) return MI355Q_OK;
+  if (outer == 0 || inner == 0) return fail(MI355Q_BAD_SHAPE, "empty reduction unit");
+  if (outer > 0x7FFFFFFFLL || inner > 0x7FFFFFFFLL - 64 || outer * inner > 0x7FFFFFFFLL)
+    return fail(MI355Q_UNSUPPORTED, "reduction unit too large");
+  if (!x || !clip_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  const size_t need = mi355q_octav_workspace_bytes(channels, max_iter);
+  if (!workspace || workspace_bytes < need)
+    return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  hipStream_t st = as_stream(stream);
+  float* hist = static_cast<float*>(workspace);
+  int* not_close = reinterpret_cast<int*>(hist + channels * max_iter);
+  if (hipMemsetAsync(not_close, 0, 64 * sizeof(int), st) != hipSuccess)
+    return fail(MI355Q_HIP_ERROR, "hipMemsetAsync failed");
+  double p4 = 1.0;
+  for (int i = 0; i < bits; ++i) p4 *= 0.25;
+  const float s = static_cast<float>(p4 / static_cast<double>(exponent_divisor));
+  // an axis is always given in this form, so s * N is evaluated in float64
+  if (inner == 1) {
+    OctavArgs a{x, channels, static_cast<int>(outer), 0, max_iter, 1, s, hist, not_close};
+    hipLaunchKernelGGL(octav_cols_kernel, dim3(static_cast<unsigned>((channels + 255) / 256)), dim3(256), 0,
+                       st, a, static_cast<long long>(channels));
+  } else {
+    OctavArgs a{x, channels, static_cast<int>(inner), 0, max_iter, 1, s, hist, not_close};
+    hipLaunchKernelGGL(octav_seg_kernel, dim3(static_cast<unsigned>((channels + 3) / 4)), dim3(4 * kWave), 0,
+                       st, a, static_cast<long long>(channels), static_cast<long long>(outer));
+  }
+  MI355Q_CHECK_LAUNCH("octav nd launch");
+  hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((channels + 255) / 256)), dim3(256), 0, st,
+                     hist, not_close, static_cast<long long>(channels), max_iter, early_stop, clip_out,
+                     iters_out);
+  MI355Q_CHECK_LAUNCH("octav pick launch");
+  return MI355Q_OK;
+}
+
+extern "C" int32_t mi355q_mse_scale_nd_f32(const float* x, int64_t outer, int64_t channels,
+                                           int64_t inner, float multiplier, float* scale_out,
+                                           void* stream) {
+  if (outer == 1) return mi355q_mse_scale_f32(x, channels, inner, multiplier, scale_out, stream);
+  clear_error();
+  if (outer < 0 || channels < 0 || inner < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (channels == 0) return MI355Q_OK;
+  if (outer == 0 || inner == 0) return fail(MI355Q_BAD_SHAPE, "empty reduction unit");
+  if (inner > 0x7FFFFFFFLL - 64) return fail(MI355Q_UNSUPPORTED, "inner too large");
+  if (!x || !scale_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  hipStream_t st = as_stream(stream);
+  if (inner == 1)
+    hipLaunchKernelGGL(mse_scale_cols_kernel, dim3(static_cast<unsigned>((channels + 255) / 256)), dim3(256),
+                       0, st, x, static_cast<long long>(outer), static_cast<long long>(channels),
+                       multiplier, scale_out);
+  else
+    hipLaunchKernelGGL(mse_scale_seg_kernel, dim3(static_cast<unsigned>((channels + 3) / 4)), dim3(4 * kWave),
+                       0, st, x, static_cast<long long>(outer), static_cast<long long>(channels),
+                       static_cast<int>(inner), multiplier, scale_out);
+  MI355Q_CHECK_LAUNCH("mse nd launch");
   return MI355Q_OK;
 }
 

@@ -13,6 +13,7 @@ import enum
 import functools
 
 from . import algorithm_manager_api
+from . import default_policy
 from . import qtyping
 from .algorithms.uniform_quantize import common_quantize
 from .algorithms.uniform_quantize import gptq
@@ -60,12 +61,14 @@ _MATERIALIZERS = {
     _Op.CONV_2D: common_quantize.materialize_fc_conv,
     _Op.DEPTHWISE_CONV_2D: common_quantize.materialize_fc_conv,
     _Op.EMBEDDING_LOOKUP: common_quantize.materialize_embedding_lookup,
+    _Op.BATCH_MATMUL: common_quantize.materialize_batch_matmul,
+    _Op.CONV_2D_TRANSPOSE: common_quantize.materialize_conv2d_transpose,
 }
 
 
 def _register_weight_algorithm(name, module, ops, calibration_func, update_qsv_func):
   register_op_quant_config_validation_func(name, common_quantize.check_op_quantization_config)
-  register_config_check_policy_func(name, None)
+  register_config_check_policy_func(name, default_policy.DEFAULT_CONFIG_CHECK_POLICY)
   for op in ops:
     register_quantized_op(
         name, op, naive_min_max_quantize.init_qsvs, calibration_func=calibration_func,
@@ -95,7 +98,7 @@ for _name, _fc, _emb in (
      hadamard_rotation.materialize_fully_connected_decomposed,
      hadamard_rotation.materialize_embedding_lookup_decomposed)):
   register_op_quant_config_validation_func(_name, common_quantize.check_op_quantization_config)
-  register_config_check_policy_func(_name, None)
+  register_config_check_policy_func(_name, default_policy.DEFAULT_CONFIG_CHECK_POLICY)
   for _op, _fn in ((_Op.FULLY_CONNECTED, _fc), (_Op.EMBEDDING_LOOKUP, _emb)):
     register_quantized_op(_name, _op, naive_min_max_quantize.init_qsvs,
                           calibration_func=naive_min_max_quantize.min_max_calibrate,

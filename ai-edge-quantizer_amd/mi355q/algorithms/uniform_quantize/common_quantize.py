@@ -12,6 +12,7 @@ from typing import Any, Optional
 
 import numpy as np
 
+from ... import default_policy
 from ... import ops
 from ... import qtyping
 from ... import runtime as rt
@@ -29,7 +30,7 @@ def check_if_quantized(tensor: Any) -> bool:
 
 def check_op_quantization_config(op_name, op_quant_config: qtyping.OpQuantizationConfig,
                                  config_check_policy=None) -> None:
-  """ref :49-89 without the JSON policy table (recipe policy is out of the hot path)."""
+  """ref :49-90; the policy table is default_policy.py's rule form."""
   w = op_quant_config.weight_tensor_config
   if w is None:
     raise ValueError("Weight tensor quantization is required for min/max uniform quantization.")
@@ -41,6 +42,9 @@ def check_op_quantization_config(op_name, op_quant_config: qtyping.OpQuantizatio
   if op_quant_config.min_weight_elements < 0:
     raise ValueError(f"min_weight_elements must be non-negative for op: {op_name} with"
                      f" config: {op_quant_config}.")
+  if op_quant_config.compute_precision in (qtyping.ComputePrecision.INTEGER,
+                                           qtyping.ComputePrecision.FLOAT):
+    default_policy.check_if_valid_op_config(op_name, op_quant_config, config_check_policy)
   common_utils.check_subchannel_config(op_name, op_quant_config)
 
 
@@ -197,6 +201,32 @@ def materialize_fc_conv(get_tensor_quant_params_fn, op_info: qtyping.OpInfo,
       tensor_quant_params_cache=tensor_quant_params_cache, inputs_to_ignore=ignored)
   _materialize_bias_for_fc_conv_ops(op_info, graph_info, params, input_index, weight_index,
                                     bias_index)
+  return params
+
+
+def materialize_batch_matmul(get_tensor_quant_params_fn, op_info, graph_info, tensor_name_to_qsv,
+                             tensor_quant_params_cache):
+  """BATCH_MATMUL: a standard op; a constant rhs is the weight (ref :234-248)."""
+  return common_utils.materialize_standard_op(
+      op_info, graph_info, tensor_name_to_qsv, get_tensor_quant_params_fn,
+      tensor_quant_params_cache=tensor_quant_params_cache)
+
+
+def materialize_conv2d_transpose(get_tensor_quant_params_fn, op_info, graph_info,
+                                 tensor_name_to_qsv, tensor_quant_params_cache):
+  """TRANSPOSE_CONV: inputs are (output_shape, weight, input, bias) (ref :579-636)."""
+  shape_index, weight_index, input_index, bias_index = 0, 1, 2, 3
+  ignored = [shape_index, bias_index]
+  if _are_weights_too_small(op_info, graph_info, weight_index):
+    ignored.append(weight_index)
+  params = common_utils.materialize_standard_op(
+      op_info, graph_info, tensor_name_to_qsv, get_tensor_quant_params_fn,
+      tensor_quant_params_cache=tensor_quant_params_cache, inputs_to_ignore=ignored)
+  if len(params) < 2:
+    raise ValueError("Materialize standard op should return at least two tensors for"
+                     " conv2d_transpose.")
+  _materialize_bias_for_fc_conv_ops(op_info, graph_info, params, op_input_index=input_index,
+                                    op_weight_index=weight_index, op_bias_index=bias_index)
   return params
 
 

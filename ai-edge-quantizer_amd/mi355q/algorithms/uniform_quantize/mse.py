@@ -49,19 +49,21 @@ def get_tensor_quant_params(
   quantized_dim = common_utils.get_weight_quantized_dim(op_info, tensor_content, cfg.granularity)
   if cfg.num_bits not in _MSE_QUANT_MULS:
     raise KeyError(cfg.num_bits)
+  shape = tensor_content.shape
   if quantized_dim is None:
-    units, out_shape = 1, (1,) * tensor_content.ndim
-  elif all(d == 1 for d in tensor_content.shape[:quantized_dim]):
-    units = tensor_content.shape[quantized_dim]
-    out_shape = tuple(d if i == quantized_dim else 1 for i, d in enumerate(tensor_content.shape))
+    outer, units, out_shape = 1, 1, (1,) * tensor_content.ndim
   else:
-    raise NotImplementedError("MSE over non-contiguous reduction units")
+    outer = int(np.prod(shape[:quantized_dim], dtype=np.int64))
+    units = shape[quantized_dim]
+    out_shape = tuple(d if i == quantized_dim else 1 for i, d in enumerate(shape))
   x = uniform_quantize_tensor._as_f32_exact(tensor_content)  # pylint: disable=protected-access
+  if x.size == 0:
+    raise ValueError("MSE quantization of an empty tensor")
+  inner = x.size // (outer * units)
   rt.require_gpu()
   xd = rt.to_device(x.reshape(-1))
-  scale_d = ops.mse_scale(xd, units, x.size // units, _MSE_QUANT_MULS[cfg.num_bits])
-  narrow = cfg.num_bits >= 8
-  q = ops.quantize(xd, 1, units, x.size // units, scale_d, None, cfg.num_bits, narrow,
+  scale_d = ops.mse_scale_nd(xd, outer, units, inner, _MSE_QUANT_MULS[cfg.num_bits])
+  q = ops.quantize(xd, outer, units, inner, scale_d, None, cfg.num_bits, cfg.num_bits >= 8,
                    zp_via_f64=True)
   scale = rt.to_numpy(scale_d).reshape(out_shape)
   return qtyping.UniformQuantParams(

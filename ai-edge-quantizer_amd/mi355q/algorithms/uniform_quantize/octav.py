@@ -24,16 +24,22 @@ ALGORITHM_KEY = "OCTAV"
 
 
 def _unit_view(x: np.ndarray, axis):
-  """(units, unit_len) when reducing over `axis` leaves contiguous units, else None."""
+  """(outer, channels, inner) such that reducing over `axis` reduces x viewed as
+  [outer, channels, inner] over its first and last axis; None when no such view exists
+  (two kept axes separated by a reduced one)."""
   if axis is None:
-    return 1, int(x.size)
+    return 1, 1, int(x.size)
   axis = (axis,) if isinstance(axis, int) else tuple(axis)
-  keep = [d for d in range(x.ndim) if d not in axis]
-  if keep and max(keep) > min(axis):  # a kept dim inside/after the reduced ones
-    if any(x.shape[d] != 1 for d in keep if d > min(axis)):
-      return None
-  units = int(np.prod([x.shape[d] for d in keep], dtype=np.int64)) if keep else 1
-  return units, int(x.size // max(units, 1))
+  keep = [d for d in range(x.ndim) if d not in axis and x.shape[d] != 1]
+  reduced = [d for d in axis if x.shape[d] != 1]
+  if not keep or not reduced or max(keep) < min(reduced):   # units are contiguous runs
+    units = int(np.prod([x.shape[d] for d in keep], dtype=np.int64)) if keep else 1
+    return 1, units, int(x.size // max(units, 1))
+  if any(d in reduced for d in range(keep[0], keep[-1])):
+    return None
+  channels = int(np.prod([x.shape[d] for d in keep], dtype=np.int64))
+  outer = int(np.prod(x.shape[:keep[0]], dtype=np.int64))
+  return outer, channels, int(x.size // (outer * channels))
 
 
 def _guess_clipping_with_octav(x: np.ndarray, bits: int, axis, max_iterations: int,
@@ -49,13 +55,18 @@ def _guess_clipping_with_octav(x: np.ndarray, bits: int, axis, max_iterations: i
     reduced = (1,) * x.ndim if max_iterations > 0 and x.ndim > 0 else (1,)
   view = _unit_view(x, axis)
   if view is None:
-    raise NotImplementedError("OCTAV over non-contiguous reduction units")
+    raise NotImplementedError("OCTAV with two kept axes separated by a reduced one")
   if x.size == 0:
     return np.ones(reduced, dtype=np.float32)
   xf = uniform_quantize_tensor._as_f32_exact(x)  # pylint: disable=protected-access
   rt.require_gpu()
-  clip, _ = ops.octav_clip(rt.to_device(xf.reshape(-1)), view[0], view[1], bits, max_iterations,
-                           exponent_divisor, early_stop, axis_given=axis is not None)
+  xd = rt.to_device(xf.reshape(-1))
+  if view[0] == 1:
+    clip, _ = ops.octav_clip(xd, view[1], view[2], bits, max_iterations, exponent_divisor,
+                             early_stop, axis_given=axis is not None)
+  else:
+    clip, _ = ops.octav_clip_nd(xd, view[0], view[1], view[2], bits, max_iterations,
+                                exponent_divisor, early_stop)
   return rt.to_numpy(clip).reshape(reduced)
 
 

@@ -247,6 +247,37 @@ def octav_clip(x: torch.Tensor, units: int, unit_len: int, bits: int, max_iter: 
   return clip, iters
 
 
+def octav_clip_nd(x: torch.Tensor, outer: int, channels: int, inner: int, bits: int,
+                  max_iter: int = 10, exponent_divisor: float = 3.0, early_stop: bool = True):
+  """K5 over the [outer, channels, inner] view: one clipping constant per channel."""
+  rt.require_gpu()
+  x = _f32(x)
+  if x.numel() != outer * channels * inner:
+    raise ValueError("shape view does not match numel")
+  clip = rt.empty((channels,), torch.float32)
+  iters = rt.empty((1,), torch.int32)
+  L = _ffi.lib()
+  nbytes = L.mi355q_octav_workspace_bytes(channels, max_iter)
+  ws = rt.empty((max(nbytes, 1),), torch.uint8)
+  _ffi.check(L.mi355q_octav_clip_nd_f32(
+      rt.ptr(x), outer, channels, inner, bits, max_iter, np.float32(exponent_divisor),
+      1 if early_stop else 0, rt.ptr(clip), rt.ptr(iters), rt.ptr(ws), nbytes, rt.stream_ptr()))
+  return clip, iters
+
+
+def mse_scale_nd(x: torch.Tensor, outer: int, channels: int, inner: int,
+                 multiplier: float) -> torch.Tensor:
+  """a14 over the [outer, channels, inner] view: scale[c] = multiplier * sqrt(mean(x[:, c, :]**2))."""
+  rt.require_gpu()
+  x = _f32(x)
+  if x.numel() != outer * channels * inner:
+    raise ValueError("shape view does not match numel")
+  scale = rt.empty((channels,), torch.float32)
+  _ffi.check(_ffi.lib().mi355q_mse_scale_nd_f32(rt.ptr(x), outer, channels, inner,
+                                                np.float32(multiplier), rt.ptr(scale), rt.stream_ptr()))
+  return scale
+
+
 def mse_scale(x: torch.Tensor, units: int, unit_len: int, multiplier: float) -> torch.Tensor:
   """a14. scale[u] = multiplier * sqrt(mean(x_u**2)). ref: mse.py:100-109."""
   rt.require_gpu()

@@ -3,7 +3,7 @@
 Restatement of the op loop of ref: params_generator.py:69-185 for the ops this
 build registers: for every subgraph op (+ the virtual INPUT / OUTPUT ops) resolve
 the recipe, look the materializer up in the registry and merge the per-tensor
-results. Ops outside the registry get NO_QUANTIZE. (Buffer-sharing fix-ups of the
+results. Ops the recipe / policy leaves alone get NO_QUANTIZE. (Buffer-sharing fix-ups of the
 reference, ref :291-463, concern graph surgery and are not restated.)
 """
 from __future__ import annotations
@@ -11,6 +11,7 @@ from __future__ import annotations
 from typing import Any, Optional
 
 from . import algorithm_manager
+from . import default_policy
 from . import qtyping
 from .algorithms.utils import common_utils
 from .utils import tfl_flatbuffer_utils
@@ -57,7 +58,8 @@ class ParamsGenerator:
           " can be obtained by running calibration on sample dataset.")
     model_qsvs = model_qsvs if model_qsvs is not None else {}
     codes = self.float_model.operatorCodes
-    for subgraph in self.float_model.subgraphs:
+    skip_subgraphs: set[int] = set()     # decompositions of composite ops left unquantized
+    for sg_ind, subgraph in enumerate(self.float_model.subgraphs):
       graph_info = qtyping.GraphInfo(subgraph.tensors, self.float_model.buffers)
       ops = list(subgraph.operators) + tfl_flatbuffer_utils.get_subgraph_input_output_operators(subgraph)
       for op_id, op in enumerate(ops):
@@ -71,7 +73,10 @@ class ParamsGenerator:
             continue
         scope = tfl_flatbuffer_utils.get_op_scope(op, subgraph.tensors)
         alg, cfg = model_recipe_manager.get_quantization_configs(op_key, scope)
+        if sg_ind in skip_subgraphs or default_policy.is_non_quantizable_composite_op(op):
+          alg = algorithm_manager.AlgorithmName.NO_QUANTIZE
         if alg == algorithm_manager.AlgorithmName.NO_QUANTIZE:
+          skip_subgraphs.update(tfl_flatbuffer_utils.get_op_side_effect_subgraphs(op))
           self._merge(self._no_quant_results(op_id, op, subgraph.tensors))
           continue
         fn = algorithm_manager.get_quantization_func(alg, op_key, qtyping.QuantizeMode.MATERIALIZE)

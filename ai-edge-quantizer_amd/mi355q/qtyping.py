@@ -36,6 +36,13 @@ QuantizationDetails = schema.QuantizationDetails
 QuantizationParametersT = schema.QuantizationParametersT
 BlockwiseQuantizationT = schema.BlockwiseQuantizationT
 FullyConnectedOptionsT = schema.FullyConnectedOptionsT
+BatchMatMulOptionsT = schema.BatchMatMulOptionsT
+StableHLOCompositeOptionsT = schema.StableHLOCompositeOptionsT
+SignatureDefT = schema.SignatureDefT
+TensorMapT = schema.TensorMapT
+MetadataT = schema.MetadataT
+BuiltinOptions = schema.BuiltinOptions
+BuiltinOptions2 = schema.BuiltinOptions2
 
 
 class FrozenMapping(dict):

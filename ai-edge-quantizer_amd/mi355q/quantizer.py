@@ -1,41 +1,80 @@
-"""Quantizer facade for in-memory models (ref: quantizer.py:131-620).
+"""Quantizer facade: `.tflite` in, quantized `.tflite` out (ref: quantizer.py:59-620).
 
-Covers the weight-requantization flow of the hot path: load a recipe, generate
-parameters through the registry, and apply the QUANTIZE_TENSOR transformation
-(pack + store + metadata). Transformations that need graph surgery (Q/DQ insertion,
-Hadamard op insertion) and .tflite (de)serialization are outside this build's scope
- and raise NotImplementedError.
+Covers the weight-requantization flow of the hot path: read the model (zero-copy views of the
+mmap'd file), load a recipe, generate parameters through the registry (GPU kernels), apply the
+QUANTIZE_TENSOR transformation (pack + store + metadata) and serialize. Calibration by running
+the float model (LiteRT interpreter) and model validation are outside this build's scope;
+calibration results (QSVs) are passed in.
 """
 from __future__ import annotations
 
 import dataclasses
-from typing import Any, Optional
+import json
+import os
+import pathlib
+from typing import Any, Optional, Union
 
+from . import model_modifier
 from . import params_generator
 from . import qtyping
 from . import recipe_manager
-from .transformations import quantize_tensor
-from .transformations import transformation_utils
 from .utils import tfl_flatbuffer_utils
+from .utils import tflite_flatbuffer
 
-_T = qtyping.QuantTransformation
+apply_quantize_tensor_transformations = model_modifier.apply_quantize_tensor_transformations
+
+Path = Union[str, pathlib.Path]
 
 
 @dataclasses.dataclass(frozen=True)
 class QuantizationResult:
+  """recipe + the serialized quantized model (ref :59-128)."""
   recipe: qtyping.ModelQuantizationRecipe
   quantized_model: Optional[Any]
 
+  def save(self, save_folder: Path, model_name: str, overwrite: bool = False) -> None:
+    os.makedirs(save_folder, exist_ok=True)
+    self.export_model(str(pathlib.Path(save_folder) / f"{model_name}.tflite"), overwrite)
+    recipe_path = pathlib.Path(save_folder) / (model_name + "_recipe.json")
+    tfl_flatbuffer_utils.set_file_contents(recipe_path, json.dumps(self.recipe).encode())
+
+  def export_model(self, filepath: Path, overwrite: bool = False) -> None:
+    if self.quantized_model is None:
+      raise RuntimeError("No quantized model to save. Make sure .quantize() is called.")
+    if os.path.exists(filepath) and not overwrite:
+      raise ValueError(
+          f"The model {filepath} already exists in the folder. Please consider change the model"
+          " name or specify overwrite=True to overwrite the model if needed.")
+    tfl_flatbuffer_utils.set_file_contents(filepath, self.quantized_model)
+
 
 class Quantizer:
-  def __init__(self, float_model: Any, quantization_recipe: Optional[qtyping.ModelQuantizationRecipe] = None):
-    self.float_model = float_model
+  """`float_model`: a `.tflite` path, model bytes, or an already parsed ModelT tree."""
+
+  def __init__(self, float_model: Any,
+               quantization_recipe: Optional[Union[Path, qtyping.ModelQuantizationRecipe]] = None):
+    if isinstance(float_model, (str, pathlib.Path)):
+      self._float_model_buffer = tfl_flatbuffer_utils.get_model_content(float_model)
+      self.float_model = tfl_flatbuffer_utils.read_model(self._float_model_buffer)
+    elif isinstance(float_model, (bytes, bytearray, memoryview)):
+      self._float_model_buffer = memoryview(float_model)
+      self.float_model = tfl_flatbuffer_utils.read_model(self._float_model_buffer)
+    elif isinstance(float_model, tflite_flatbuffer.TableT):
+      self._float_model_buffer = None
+      self.float_model = float_model
+    else:
+      raise ValueError("Unsupported float_model type: %s" % type(float_model).__name__)
     self._recipe_manager = recipe_manager.RecipeManager()
     self._result = QuantizationResult([{}], None)
+    self.quantized_model_object: Optional[Any] = None
     if quantization_recipe is not None:
       self.load_quantization_recipe(quantization_recipe)
 
-  def load_quantization_recipe(self, recipe: qtyping.ModelQuantizationRecipe) -> None:
+  def load_quantization_recipe(self, recipe: Union[Path, qtyping.ModelQuantizationRecipe]) -> None:
+    """A recipe list, or the path of a recipe .json (ref :195-205)."""
+    if isinstance(recipe, (str, pathlib.Path)):
+      with open(recipe, "r", encoding="utf-8") as f:
+        recipe = json.load(f)
     self._recipe_manager.load_quantization_recipe(recipe)
 
   def get_quantization_recipe(self) -> qtyping.ModelQuantizationRecipe:
@@ -44,40 +83,17 @@ class Quantizer:
   def need_calibration(self) -> bool:
     return self._recipe_manager.need_calibration()
 
-  def quantize(self, calibration_result: Optional[dict[str, qtyping.QSV]] = None) -> QuantizationResult:
-    """Quantizes the model IN PLACE (buffers, tensor types, quantization records)."""
+  def quantize(self, calibration_result: Optional[dict[str, qtyping.QSV]] = None,
+               serialize_to_path: Optional[Path] = None) -> QuantizationResult:
+    """The float model is left untouched; the result holds the serialized quantized model
+    (also written to `serialize_to_path` when given). `quantized_model_object` keeps the
+    quantized ModelT tree for inspection."""
     if not self.get_quantization_recipe():
       raise RuntimeError("Can not quantize without a quantization recipe.")
     params = params_generator.ParamsGenerator(self.float_model).generate_quantization_parameters(
         self._recipe_manager, calibration_result)
-    apply_quantize_tensor_transformations(self.float_model, params)
-    self._result = QuantizationResult(self.get_quantization_recipe(), self.float_model)
+    modifier = model_modifier.ModelModifier(self.float_model)
+    serialized = modifier.modify_model(params, serialize_to_path=serialize_to_path)
+    self.quantized_model_object = modifier.quantized_model_object
+    self._result = QuantizationResult(self.get_quantization_recipe(), serialized)
     return self._result
-
-
-def apply_quantize_tensor_transformations(model: Any, params: dict[str, qtyping.TensorTransformationParams]) -> None:
-  """QUANTIZE_TENSOR for every constant whose consumers all ask for it with equal
-  parameters (the case the reference's instruction generator leaves as a single
-  QUANTIZE_TENSOR instruction)."""
-  buffer_origin: dict[int, Any] = {}
-  for sg in model.subgraphs:
-    n_before = len(sg.tensors)
-    for tid in range(n_before):
-      tensor = sg.tensors[tid]
-      p = params.get(tfl_flatbuffer_utils.get_tensor_name(tensor))
-      if p is None:
-        continue
-      links = list(p.consumers or []) + ([p.producer] if p.producer is not None else [])
-      wanted = {t for link in links for t in link.transformations}
-      if wanted <= {_T.NO_QUANTIZE}:
-        continue
-      if wanted != {_T.QUANTIZE_TENSOR}:
-        raise NotImplementedError(
-            f"tensor {p.tensor_name}: transformations {sorted(t.name for t in wanted)} need graph"
-            " rewriting, which is outside this build's scope")
-      first = links[0].parameters
-      if any(link.parameters != first for link in links[1:]):
-        raise NotImplementedError(f"tensor {p.tensor_name}: consumers disagree on parameters")
-      quantize_tensor.quantize_tensor(transformation_utils.TransformationInput(
-          tensor_id=tid, model=model, subgraph=sg, producer=-1, consumers=[], quant_params=first,
-          buffer_origin=buffer_origin))

@@ -1,16 +1,16 @@
-"""Minimal stand-ins for the LiteRT flatbuffer object API used on the hot path.
+"""TFLite schema types used around the hot path.
 
-The reference takes these types from `ai_edge_litert.tools.flatbuffer_utils`
-(ref: qtyping.py:37-79). Only plain attribute containers are needed around the
-calibration / requantization path: tensors, operators, buffers and the
-quantization records that transformations/quantize_tensor.py fills in. Field
-names follow the TFLite schema's object API so a real `TensorT` etc. can be
-passed in unchanged (duck typing).
+The reference takes these from `ai_edge_litert.tools.flatbuffer_utils` (ref: qtyping.py:37-79).
+The table classes (`ModelT`, `TensorT`, ...) are the object tree of this build's own flatbuffer
+reader / writer (`utils/tflite_flatbuffer.py`); field names follow the flatbuffers object API, so
+models parsed from `.tflite` files and models assembled in memory are the same kind of object.
 """
 from __future__ import annotations
 
 import enum
 from typing import Any, Optional
+
+from .utils import tflite_flatbuffer as _fb
 
 
 class TensorType(enum.IntEnum):
@@ -53,75 +53,62 @@ class QuantizationDetails(enum.IntEnum):
   BlockwiseQuantization = 2
 
 
-class BuiltinOperator(enum.IntEnum):
-  """Subset of the TFLite BuiltinOperator codes (the ops this build materializes)."""
-  ADD = 0
-  AVERAGE_POOL_2D = 1
-  CONCATENATION = 2
-  CONV_2D = 3
-  DEPTHWISE_CONV_2D = 4
-  EMBEDDING_LOOKUP = 7
-  FULLY_CONNECTED = 9
-  CUSTOM = 32
-  TRANSPOSE_CONV = 67
-  BATCH_MATMUL = 126
+# BuiltinOperator codes 0..161 in schema order (checked against the op each of the reference's
+# single-op test models holds), plus the StableHLO composite op.
+_BUILTIN_OPERATOR_NAMES = """
+    ADD AVERAGE_POOL_2D CONCATENATION CONV_2D DEPTHWISE_CONV_2D DEPTH_TO_SPACE DEQUANTIZE EMBEDDING_LOOKUP
+    FLOOR FULLY_CONNECTED HASHTABLE_LOOKUP L2_NORMALIZATION L2_POOL_2D LOCAL_RESPONSE_NORMALIZATION
+    LOGISTIC LSH_PROJECTION LSTM MAX_POOL_2D MUL RELU RELU_N1_TO_1 RELU6 RESHAPE RESIZE_BILINEAR
+    RNN SOFTMAX SPACE_TO_DEPTH SVDF TANH CONCAT_EMBEDDINGS SKIP_GRAM CALL CUSTOM EMBEDDING_LOOKUP_SPARSE
+    PAD UNIDIRECTIONAL_SEQUENCE_RNN GATHER BATCH_TO_SPACE_ND SPACE_TO_BATCH_ND TRANSPOSE MEAN
+    SUB DIV SQUEEZE UNIDIRECTIONAL_SEQUENCE_LSTM STRIDED_SLICE BIDIRECTIONAL_SEQUENCE_RNN EXP
+    TOPK_V2 SPLIT LOG_SOFTMAX DELEGATE BIDIRECTIONAL_SEQUENCE_LSTM CAST PRELU MAXIMUM ARG_MAX
+    MINIMUM LESS NEG PADV2 GREATER GREATER_EQUAL LESS_EQUAL SELECT SLICE SIN TRANSPOSE_CONV SPARSE_TO_DENSE
+    TILE EXPAND_DIMS EQUAL NOT_EQUAL LOG SUM SQRT RSQRT SHAPE POW ARG_MIN FAKE_QUANT REDUCE_PROD
+    REDUCE_MAX PACK LOGICAL_OR ONE_HOT LOGICAL_AND LOGICAL_NOT UNPACK REDUCE_MIN FLOOR_DIV REDUCE_ANY
+    SQUARE ZEROS_LIKE FILL FLOOR_MOD RANGE RESIZE_NEAREST_NEIGHBOR LEAKY_RELU SQUARED_DIFFERENCE
+    MIRROR_PAD ABS SPLIT_V UNIQUE CEIL REVERSE_V2 ADD_N GATHER_ND COS WHERE RANK ELU REVERSE_SEQUENCE
+    MATRIX_DIAG QUANTIZE MATRIX_SET_DIAG ROUND HARD_SWISH IF WHILE NON_MAX_SUPPRESSION_V4 NON_MAX_SUPPRESSION_V5
+    SCATTER_ND SELECT_V2 DENSIFY SEGMENT_SUM BATCH_MATMUL PLACEHOLDER_FOR_GREATER_OP_CODES CUMSUM
+    CALL_ONCE BROADCAST_TO RFFT2D CONV_3D IMAG REAL COMPLEX_ABS HASHTABLE HASHTABLE_FIND HASHTABLE_IMPORT
+    HASHTABLE_SIZE REDUCE_ALL CONV_3D_TRANSPOSE VAR_HANDLE READ_VARIABLE ASSIGN_VARIABLE BROADCAST_ARGS
+    RANDOM_STANDARD_NORMAL BUCKETIZE RANDOM_UNIFORM MULTINOMIAL GELU DYNAMIC_UPDATE_SLICE RELU_0_TO_1
+    UNSORTED_SEGMENT_PROD UNSORTED_SEGMENT_MAX UNSORTED_SEGMENT_SUM ATAN2 UNSORTED_SEGMENT_MIN
+    SIGN BITCAST BITWISE_XOR RIGHT_SHIFT
+""".split()
+BuiltinOperator = enum.IntEnum(
+    "BuiltinOperator",
+    {**{n: i for i, n in enumerate(_BUILTIN_OPERATOR_NAMES)}, "STABLEHLO_COMPOSITE": 206})
 
 
-class _Record:
-  _fields: dict[str, Any] = {}
-
-  def __init__(self, **kw):
-    for k, v in self._fields.items():
-      setattr(self, k, v() if callable(v) else v)
-    for k, v in kw.items():
-      setattr(self, k, v)
-
-  def __repr__(self):
-    body = ", ".join(f"{k}={getattr(self, k)!r}" for k in self._fields)
-    return f"{type(self).__name__}({body})"
+class BuiltinOptions(enum.IntEnum):
+  """Union codes of the option tables this build reads field by field."""
+  NONE = 0
+  FullyConnectedOptions = 8
+  ReshapeOptions = 17
+  DequantizeOptions = 38
+  QuantizeOptions = 89
 
 
-class BufferT(_Record):
-  _fields = {"data": None, "offset": 0, "size": 0}
+class BuiltinOptions2(enum.IntEnum):
+  NONE = 0
+  StableHLOCompositeOptions = 21
 
 
-class BlockwiseQuantizationT(_Record):
-  _fields = {"scales": 0, "zeroPoints": 0, "blockSize": 0}
-
-
-class QuantizationParametersT(_Record):
-  _fields = {"min": None, "max": None, "scale": None, "zeroPoint": None,
-             "detailsType": QuantizationDetails.NONE, "details": None,
-             "quantizedDimension": 0}
-
-
-class TensorT(_Record):
-  _fields = {"shape": None, "type": TensorType.FLOAT32, "buffer": 0, "name": None,
-             "quantization": None, "isVariable": False, "shapeSignature": None,
-             "hasRank": False}
-
-
-class FullyConnectedOptionsT(_Record):
-  _fields = {"fusedActivationFunction": 0, "weightsFormat": 0, "keepNumDims": False,
-             "asymmetricQuantizeInputs": False, "quantizedBiasType": 0}
-
-
-class OperatorT(_Record):
-  _fields = {"opcodeIndex": 0, "inputs": None, "outputs": None, "builtinOptionsType": 0,
-             "builtinOptions": None, "customOptions": None}
-
-
-class OperatorCodeT(_Record):
-  _fields = {"deprecatedBuiltinCode": 0, "customCode": None, "version": 1, "builtinCode": 0}
-
-
-class SubGraphT(_Record):
-  _fields = {"tensors": list, "inputs": list, "outputs": list, "operators": list, "name": None}
-
-
-class ModelT(_Record):
-  _fields = {"version": 3, "operatorCodes": list, "subgraphs": list, "description": None,
-             "buffers": list, "metadataBuffer": None, "metadata": None, "signatureDefs": None}
+ModelT = _fb.ModelT
+SubGraphT = _fb.SubGraphT
+TensorT = _fb.TensorT
+BufferT = _fb.BufferT
+OperatorT = _fb.OperatorT
+OperatorCodeT = _fb.OperatorCodeT
+QuantizationParametersT = _fb.QuantizationParametersT
+BlockwiseQuantizationT = _fb.BlockwiseQuantizationT
+FullyConnectedOptionsT = _fb.FullyConnectedOptionsT
+BatchMatMulOptionsT = _fb.BatchMatMulOptionsT
+StableHLOCompositeOptionsT = _fb.StableHLOCompositeOptionsT
+SignatureDefT = _fb.SignatureDefT
+TensorMapT = _fb.TensorMapT
+MetadataT = _fb.MetadataT
 
 
 def tensor_name(tensor: Any) -> Optional[str]:

@@ -27,25 +27,63 @@ class TransformationInput:
   buffer_origin: dict[int, Any] = dataclasses.field(default_factory=dict)
 
 
-def add_new_constant_buffer(data: np.ndarray, model: Any) -> int:
-  """Appends a buffer holding `data`'s bytes; returns its id."""
+def _content_key(view: np.ndarray):
+  return (view.size, view[:16].tobytes())
+
+
+def get_constant_buffer(data: np.ndarray, model: Any, force_duplicate_buffer: bool = False) -> int:
+  """Id of a buffer holding exactly `data`'s bytes; appended when the model has none.
+
+  Same sharing rule as ref :119-164: the lookup table is built once per model from the buffers
+  present at that time (a later buffer with equal bytes shadows an earlier one) and only grows
+  by the buffers added through this function.
+  """
+  view = np.ravel(np.ascontiguousarray(data)).view(np.uint8)
+  table = getattr(model, "_buffers_by_content", None)
+  if table is None:
+    table = {}
+    for i, b in enumerate(model.buffers):
+      if b.data is not None:
+        d = np.ravel(np.asarray(b.data)).view(np.uint8)
+        _remember(table, d, i)
+    model._buffers_by_content = table
+  if not force_duplicate_buffer:
+    for held, idx in table.get(_content_key(view), ()):
+      if held.size == view.size and np.array_equal(held, view):
+        return idx
   buf = qtyping.BufferT()
-  buf.data = np.frombuffer(np.ascontiguousarray(data).tobytes(), dtype=np.uint8)
+  buf.data = view
   buf.offset = 0
   buf.size = 0
   model.buffers.append(buf)
+  _remember(table, view, len(model.buffers) - 1)
   return len(model.buffers) - 1
 
 
+def _remember(table: dict, view: np.ndarray, idx: int) -> None:
+  bucket = table.setdefault(_content_key(view), [])
+  for n, (held, _) in enumerate(bucket):
+    if held.size == view.size and np.array_equal(held, view):
+      bucket[n] = (held, idx)
+      return
+  bucket.append((view, idx))
+
+
+def add_new_constant_buffer(data: np.ndarray, model: Any) -> int:
+  return get_constant_buffer(data, model)
+
+
 def add_new_constant_tensor(tensor_name: bytes, data: np.ndarray, tensor_type, subgraph: Any,
-                            model: Any, tensor_shape=None, force_duplicate_tensor_name=False) -> int:
-  """Appends a constant tensor (and its buffer) to the subgraph; returns its id."""
-  del force_duplicate_tensor_name
+                            model: Any, tensor_shape=None, force_duplicate_buffer: bool = False,
+                            quantization=None) -> int:
+  """Appends a constant tensor to the subgraph (its buffer is shared with an existing one of
+  equal content unless `force_duplicate_buffer`); returns the tensor id (ref :167-247)."""
   t = qtyping.TensorT()
   t.shape = list(data.shape) if tensor_shape is None else list(tensor_shape)
-  t.buffer = add_new_constant_buffer(data, model)
+  t.buffer = get_constant_buffer(data, model, force_duplicate_buffer)
   t.type = tensor_type
   t.name = tensor_name
+  t.quantization = quantization
   subgraph.tensors.append(t)
   return len(subgraph.tensors) - 1
 

@@ -1,16 +1,23 @@
 """Tensor-buffer access helpers and the op -> quantized-dimension tables.
 
 ref: utils/tfl_flatbuffer_utils.py:34-112 (tables), :236-263 (get_tensor_name /
-get_tensor_data). Model file I/O lives elsewhere (out of the hot path).
+get_tensor_data), :115-163 (model file I/O, on this build's own flatbuffer reader/writer).
 """
 from __future__ import annotations
 
-from typing import Any, Optional
+import collections
+import mmap
+import os
+import pathlib
+from typing import Any, Optional, Union
 
 import numpy as np
 
 from .. import qtyping
 from .. import schema
+from . import tflite_flatbuffer
+
+Path = Union[str, pathlib.Path]
 
 _Op = qtyping.TFLOperationName
 
@@ -29,13 +36,12 @@ TFL_OP_TO_BLOCKWISE_WEIGHT_QUANTIZED_DIM = qtyping.FrozenMapping({
     _Op.EMBEDDING_LOOKUP: 1,
 })
 
+# Every TFLOperationName that names a builtin op maps to the BuiltinOperator of the same name;
+# CONV_2D_TRANSPOSE is the schema's TRANSPOSE_CONV (ref :34-89).
 TFL_OP_NAME_TO_CODE = qtyping.FrozenMapping({
-    _Op.FULLY_CONNECTED: schema.BuiltinOperator.FULLY_CONNECTED,
-    _Op.BATCH_MATMUL: schema.BuiltinOperator.BATCH_MATMUL,
-    _Op.CONV_2D: schema.BuiltinOperator.CONV_2D,
-    _Op.DEPTHWISE_CONV_2D: schema.BuiltinOperator.DEPTHWISE_CONV_2D,
+    **{name: schema.BuiltinOperator[name.name] for name in _Op
+       if name.name in schema.BuiltinOperator.__members__},
     _Op.CONV_2D_TRANSPOSE: schema.BuiltinOperator.TRANSPOSE_CONV,
-    _Op.EMBEDDING_LOOKUP: schema.BuiltinOperator.EMBEDDING_LOOKUP,
 })
 TFL_OP_CODE_TO_NAME = qtyping.FrozenMapping({v: k for k, v in TFL_OP_NAME_TO_CODE.items()})
 
@@ -84,3 +90,55 @@ def get_op_scope(op: Any, subgraph_tensors: list[Any], max_length: int = 10000) 
   picked = names(op.outputs) or names(op.inputs)
   scope = ";".join(picked) + (";" if picked else "")
   return scope[:max_length]
+
+
+# ---- model file I/O (ref :115-163) --------------------------------------------------------
+
+def get_model_content(tflite_path: Path) -> memoryview:
+  """Read-only, memory-mapped bytes of the model file (weights are paged in on demand)."""
+  with open(tflite_path, "rb") as f:
+    if os.fstat(f.fileno()).st_size == 0:
+      raise ValueError(f"{tflite_path} is empty")
+    return memoryview(mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ))
+
+
+def get_model_buffer(tflite_path: Path) -> bytearray:
+  """A mutable copy of the model file."""
+  with open(tflite_path, "rb") as f:
+    return bytearray(f.read())
+
+
+def read_model(tflite_model) -> Any:
+  """`.tflite` path or bytes -> ModelT tree whose constant data are zero-copy views."""
+  if isinstance(tflite_model, (str, pathlib.Path)):
+    return tflite_flatbuffer.read_model(get_model_content(tflite_model))
+  if isinstance(tflite_model, (bytes, bytearray, memoryview, mmap.mmap)):
+    return tflite_flatbuffer.read_model(tflite_model)
+  raise ValueError("Unsupported tflite_model type: %s" % type(tflite_model).__name__)
+
+
+def write_model(model: Any, output_tflite_file: Path) -> None:
+  """Serialize (all buffers inline) and write to `output_tflite_file`."""
+  set_file_contents(output_tflite_file, tflite_flatbuffer.write_model(model))
+
+
+def set_file_contents(path: Path, data) -> None:
+  with open(path, "wb") as f:
+    f.write(data)
+
+
+def get_op_side_effect_subgraphs(op: Any) -> list[int]:
+  """Subgraphs an op invokes: a composite op's decomposition (ref :342-359)."""
+  opts = getattr(op, "builtinOptions2", None)
+  if isinstance(opts, schema.StableHLOCompositeOptionsT):
+    return [opts.decompositionSubgraphIndex]
+  return []
+
+
+def buffer_to_tensors(model: Any) -> dict[int, list[Any]]:
+  """buffer id -> tensors using it, in first-use order (ref :215-223)."""
+  out: dict[int, list[Any]] = collections.defaultdict(list)
+  for sg in model.subgraphs:
+    for t in sg.tensors:
+      out[t.buffer].append(t)
+  return out

@@ -189,6 +189,17 @@ int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t unit_len, i
                               int32_t max_iter, float exponent_divisor, int32_t early_stop,
                               int32_t count_is_f64, float* clip_out, int32_t* iters_out,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* General form: x is viewed as [outer, channels, inner] row-major and channel c's unit is the
+ * `outer` segments x[o, c, :] (the reduction NumPy does when a middle or last axis is the
+ * quantized dimension: DEPTHWISE_CONV_2D weights, BATCH_MATMUL right-hand sides; ref
+ * octav.py:186-199 with common_utils.get_reduce_dims). NumPy keeps one running float32 total
+ * per channel and adds each segment's runs to it in order; inner == 1 is a plain left-to-right
+ * column sum, outer == 1 is the contiguous form above.
+ * workspace: mi355q_octav_workspace_bytes(channels, max_iter). */
+int32_t mi355q_octav_clip_nd_f32(const float* x, int64_t outer, int64_t channels, int64_t inner,
+                                 int32_t bits, int32_t max_iter, float exponent_divisor,
+                                 int32_t early_stop, float* clip_out, int32_t* iters_out,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * a14 -- MSE scale: scale[u] = multiplier * sqrt(mean(x_u^2)), NumPy-order exact.
@@ -196,6 +207,9 @@ int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t unit_len, i
  * ------------------------------------------------------------------------ */
 int32_t mi355q_mse_scale_f32(const float* x, int64_t units, int64_t unit_len, float multiplier,
                              float* scale_out, void* stream);
+/* [outer, channels, inner] view, one scale per channel (see mi355q_octav_clip_nd_f32). */
+int32_t mi355q_mse_scale_nd_f32(const float* x, int64_t outer, int64_t channels, int64_t inner,
+                                float multiplier, float* scale_out, void* stream);
 
 /* ------------------------------------------------------------------------
  * K6 -- block-diagonal Hadamard rotation: out = reshape(x, (n_vec, h)) @ (H_h / sqrt(h)),

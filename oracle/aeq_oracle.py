@@ -313,12 +313,16 @@ def quantize_bias(bias: np.ndarray, in_scale, w_scale, in_num_bits: int = 8):
 # a4: min/max algorithm
 # --------------------------------------------------------------------------
 
-def weight_quantized_dim(granularity: str, op: str = "FULLY_CONNECTED"):
-  """ref: common_utils.py:1162-1193 + tfl_flatbuffer_utils.py:95-106 (no BMM)."""
+def weight_quantized_dim(granularity: str, op: str = "FULLY_CONNECTED", rank: int = 2,
+                         adj_y: bool = False):
+  """ref: common_utils.py:1162-1193 + tfl_flatbuffer_utils.py:95-106; BATCH_MATMUL's
+  right-hand side uses its last axis (second to last when adj_y), ref common_utils.py:1143-1159."""
   cw = {"FULLY_CONNECTED": 0, "DEPTHWISE_CONV_2D": 3, "CONV_2D": 0,
         "EMBEDDING_LOOKUP": 0, "CONV_2D_TRANSPOSE": 0}
   bw = {"FULLY_CONNECTED": 1, "EMBEDDING_LOOKUP": 1}
   if str(granularity).endswith(CHANNELWISE):
+    if op == "BATCH_MATMUL":
+      return rank - 2 if adj_y else rank - 1
     return cw.get(op)
   if is_blockwise(granularity):
     return bw[op]
@@ -328,7 +332,7 @@ def weight_quantized_dim(granularity: str, op: str = "FULLY_CONNECTED"):
 def min_max_quant_params(w, num_bits: int, symmetric: bool, granularity: str,
                          op: str = "FULLY_CONNECTED", qsv=None) -> dict:
   """ref: algorithms/uniform_quantize/naive_min_max_quantize.py:34-110."""
-  qdim = weight_quantized_dim(granularity, op)
+  qdim = weight_quantized_dim(granularity, op, np.ndim(w))
   if qsv is None or "min" not in qsv:
     if w is None:
       raise ValueError("not found in tensor_name_to_qsv")
@@ -404,12 +408,12 @@ def octav_clip(x: np.ndarray, bits: int, axis, max_iterations: int = 10,
 
 
 def octav_quant_params(w, num_bits: int, granularity: str,
-                       op: str = "FULLY_CONNECTED", symmetric: bool = True) -> dict:
+                       op: str = "FULLY_CONNECTED", symmetric: bool = True, adj_y: bool = False) -> dict:
   """ref: octav.py:115-227 (weights; min/max computed on the spot)."""
   if not symmetric:
     raise ValueError(f"Unsupported symmetry: {symmetric}. OCTAV supports symmetric"
                      " quantization only for now.")
-  qdim = weight_quantized_dim(granularity, op)
+  qdim = weight_quantized_dim(granularity, op, np.ndim(w), adj_y)
   mm = init_tensor_min_max(w, granularity, qdim)
   if is_blockwise(granularity):
     b = block_size_of(granularity)
@@ -637,7 +641,7 @@ def gptq_quant_params(w, num_bits: int, symmetric: bool, granularity: str,
                       qsv=None, op: str = "FULLY_CONNECTED") -> dict:
   """ref: gptq.py:219-300."""
   act = qsv.get("activation_tensor_qsv") if qsv else None
-  qdim = weight_quantized_dim(granularity, op)
+  qdim = weight_quantized_dim(granularity, op, np.ndim(w))
   mm = qsv if (qsv is not None and "min" in qsv) else init_tensor_min_max(
       w, granularity, qdim)
   zp, scale = zp_scale_from_min_max(mm["min"], mm["max"], num_bits, symmetric,
@@ -660,14 +664,14 @@ _MSE_MUL = {8: 0.05408, 4: 0.37755}
 
 
 def mse_quant_params(w, num_bits: int, granularity: str,
-                     op: str = "FULLY_CONNECTED", symmetric: bool = True) -> dict:
+                     op: str = "FULLY_CONNECTED", symmetric: bool = True, adj_y: bool = False) -> dict:
   """scale = k * sqrt(mean(x^2)). ref: algorithms/uniform_quantize/mse.py:36-128."""
   if is_blockwise(granularity):
     raise ValueError("Blockwise quantization is not supported for MSE quantization.")
   if not symmetric:
     raise ValueError(f"Unsupported symmetry: {symmetric}. MSE supports symmetric"
                      " quantization only for now.")
-  qdim = weight_quantized_dim(granularity, op)
+  qdim = weight_quantized_dim(granularity, op, np.ndim(w), adj_y)
   dims = reduce_dims_for(qdim, w.shape)
   scale = _MSE_MUL[num_bits] * np.sqrt(np.mean(w**2, axis=dims, keepdims=True))
   zp = np.zeros_like(scale, dtype=np.int32)

@@ -22,6 +22,7 @@ import hashlib
 import json
 import os
 import sys
+sys.dont_write_bytecode = True  # never leave .pyc files in the read-only reference tree
 import types
 import warnings
 

@@ -34,3 +34,43 @@ def gen_c2(seed=1234, shape=(4096, 4096)):
 def gen_c3(layer: int, shape=(4096, 11008)):
   return np.random.default_rng(1000 + layer).standard_normal(
       shape, dtype=np.float32) * np.float32(0.02)
+
+
+def describe_model(model):
+  """Payload-level description of a ModelT tree: every tensor's type / shape / buffer /
+  quantization record and the SHA-256 of every buffer. Same structure as the `result` entries
+  of tests/golden/ref_model_cases.json (written by tests/golden/gen/make_model_golden.py)."""
+  import hashlib
+
+  def digest(a):
+    return hashlib.sha256(bytes(a)).hexdigest()
+
+  out = dict(n_buffers=len(model.buffers), subgraphs=[], buffers=[])
+  for b in model.buffers:
+    if b.data is None:
+      out["buffers"].append(None)
+    else:
+      raw = np.ravel(np.asarray(b.data)).view(np.uint8)
+      out["buffers"].append(dict(nbytes=int(raw.nbytes), sha256=digest(raw)))
+  for sg in model.subgraphs:
+    tensors = []
+    for t in sg.tensors:
+      name = t.name.decode() if isinstance(t.name, (bytes, bytearray)) else str(t.name)
+      rec = dict(name=name, type=int(t.type), shape=None if t.shape is None else [int(s) for s in t.shape],
+                 buffer=int(t.buffer))
+      q = t.quantization
+      if q is not None:
+        qr = dict(quantized_dimension=int(q.quantizedDimension), details_type=int(q.detailsType))
+        for k, want in (("scale", np.float32), ("zeroPoint", np.int64), ("min", np.float32), ("max", np.float32)):
+          a = getattr(q, k, None)
+          if a is not None:
+            a = np.asarray(a).astype(want)
+            qr[k] = dict(n=int(a.size), sha256=digest(a.tobytes()), head=[float(x) for x in a.ravel()[:4]])
+        if q.details is not None and int(q.detailsType) == 2:
+          qr["blockwise"] = dict(scales=int(q.details.scales), zero_points=int(q.details.zeroPoints),
+                                 block_size=int(q.details.blockSize))
+        rec["quantization"] = qr
+      tensors.append(rec)
+    out["subgraphs"].append(dict(tensors=tensors, n_operators=len(sg.operators or []),
+                                 inputs=[int(i) for i in sg.inputs], outputs=[int(i) for i in sg.outputs]))
+  return out

@@ -56,3 +56,45 @@ def plain_sum(x):
     p = pairwise(x[i:i + CHUNK])
     acc = p if acc is None else F(acc + p)
   return acc
+
+
+def column_sums(x2, mask2=None):
+  """np.sum(x, axis=<all leading axes>[, where=mask]) of a C-contiguous array viewed as
+  [outer, channels]: NumPy walks it row by row, so each channel is a left-to-right float32
+  sum over `outer` (masked-out elements skipped)."""
+  acc = np.zeros(x2.shape[1], F)
+  for o in range(x2.shape[0]):
+    nxt = (acc + x2[o]).astype(F)
+    acc = nxt if mask2 is None else np.where(mask2[o], nxt, acc)
+  return acc
+
+
+def segment_sums(x3, mask3=None):
+  """np.sum(x, axis=(0, 2)[, where=mask]) of a C-contiguous [outer, channels, inner] array:
+  one running total per channel; every segment x[o, c, :] is handed to the inner loop on its
+  own (8192-element chunks and runs restart at the segment start) and added in order."""
+  outer, channels, inner = x3.shape
+  out = np.zeros(channels, F)
+  for c in range(channels):
+    acc = None
+    for o in range(outer):
+      seg = x3[o, c]
+      if mask3 is None:
+        for i in range(0, inner, CHUNK):
+          p = pairwise(seg[i:i + CHUNK])
+          acc = p if acc is None else F(acc + p)
+      else:
+        acc = F(0.0) if acc is None else acc
+        msk = mask3[o, c]
+        i = 0
+        while i < inner:
+          if not msk[i]:
+            i += 1
+            continue
+          j = i
+          while j < inner and msk[j] and j // CHUNK == i // CHUNK:
+            j += 1
+          acc = F(acc + pairwise(seg[i:j]))
+          i = j
+    out[c] = acc
+  return out

@@ -140,6 +140,43 @@ def test_octav_dense_and_degenerate_rows_bit_exact(m):
                           O.octav_clip(w, 4, (1,), 10, 3.0))
 
 
+@pytest.mark.parametrize("shape,op,adj_y", [
+    ((1, 3, 3, 64), "DEPTHWISE_CONV_2D", False), ((1, 5, 5, 700), "DEPTHWISE_CONV_2D", False),
+    ((96, 130), "BATCH_MATMUL", False), ((4, 33, 257), "BATCH_MATMUL", False),
+    ((5000, 8), "BATCH_MATMUL", False),
+    ((2, 16, 8), "BATCH_MATMUL", True), ((3, 40, 300), "BATCH_MATMUL", True),
+    ((2, 5, 9000), "BATCH_MATMUL", True), ((7, 130, 5), "BATCH_MATMUL", True)])
+def test_octav_and_mse_strided_units_bit_exact(m, shape, op, adj_y):
+  """Quantized dimension = last or a middle axis: NumPy keeps one running total per channel
+  and adds the segments x[o, c, :] to it in order; the column / segment kernels keep that
+  order (oracle = the reference's own np.sum calls)."""
+  q = m.qtyping
+  rng = np.random.default_rng(sum(shape))
+  w = rng.standard_normal(shape).astype(np.float32)
+  qd = len(shape) - 2 if adj_y else len(shape) - 1
+  idx = [slice(None)] * len(shape)
+  idx[qd] = 1
+  w[tuple(idx)] *= 40.0                  # a channel with outliers
+  idx[qd] = 2
+  w[tuple(idx)] = 0.0                    # an all-zero channel
+  ax = tuple(d for d in range(len(shape)) if d != qd)
+  for bits in (4, 8):
+    for early in (True, False):
+      ref = O.octav_clip(w, bits, ax, 10, 3.0, early_stop=early)
+      got = m.octav._guess_clipping_with_octav(w, bits, ax, 10, 3.0, early_stop=early)
+      assert got.shape == ref.shape and np.array_equal(got, ref, equal_nan=True)
+    cfg = q.TensorQuantizationConfig(num_bits=bits, symmetric=True, granularity=q.QuantGranularity.CHANNELWISE)
+    info = q.OpInfo(op=q.OperatorT(builtinOptions=q.BatchMatMulOptionsT(adjY=adj_y)),
+                    op_name=q.TFLOperationName[op], subgraph_op_index=0,
+                    op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg))
+    for mod, ref in ((m.octav, O.octav_quant_params(w, bits, "CHANNELWISE", op=op, adj_y=adj_y)),
+                     (m.mse, O.mse_quant_params(w, bits, "CHANNELWISE", op=op, adj_y=adj_y))):
+      p = mod.get_tensor_quant_params(info, cfg, w, {"min": w.min(), "max": w.max()})
+      assert p.quantized_dimension == qd == ref["quantized_dimension"]
+      assert np.array_equal(p.scale, ref["scale"], equal_nan=True)
+      assert np.array_equal(p.quantized_data, ref["quantized_data"])
+
+
 def test_octav_anchor_digest(m, ref_digests):
   d = ref_digests["octav_anchor"]
   w = np.random.default_rng(d["seed"]).standard_normal(tuple(d["shape"]), dtype=np.float32)

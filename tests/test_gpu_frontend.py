@@ -32,7 +32,7 @@ def build_fc_model(m, w, bias=None):
 
   def tensor(name, shape, buf, typ=q.TensorType.FLOAT32):
     return q.TensorT(name=name.encode(), shape=list(shape), buffer=buf, type=typ)
-  model = q.ModelT()
+  model = q.ModelT(version=3)
   model.buffers = [q.BufferT(), q.BufferT(data=w.view(np.uint8).reshape(-1)), q.BufferT()]
   sg = q.SubGraphT()
   sg.tensors = [tensor("x", (1, w.shape[1]), 0), tensor("w", w.shape, 1), tensor("y", (1, w.shape[0]), 2)]
@@ -58,7 +58,12 @@ def test_c1_quantizer_matches_reference_orchestration(m, ref_cases, ref_digests,
   qz = m.quantizer.Quantizer(model, c["recipe"])
   assert qz.get_quantization_recipe()[0]["algorithm_key"] == c["recipe"][0]["algorithm_key"]
   res = qz.quantize()
-  assert res.quantized_model is model
+  # the float model is untouched; the result is the serialized .tflite, re-read here
+  assert int(sg.tensors[1].type) == int(m.q.TensorType.FLOAT32) and sg.tensors[1].quantization is None
+  assert np.array_equal(np.asarray(model.buffers[1].data), w.view(np.uint8).reshape(-1))
+  from mi355q.utils import tfl_flatbuffer_utils
+  model = tfl_flatbuffer_utils.read_model(bytes(res.quantized_model))
+  sg = model.subgraphs[0]
   wt = sg.tensors[1]
   assert int(wt.type) == c["tensor_type"]
   buf = np.asarray(model.buffers[1].data).view(np.uint8)

@@ -91,8 +91,8 @@ def test_recipe_resolution_last_valid_match_wins():
   alg, cfg = rm.get_quantization_configs(FC, "layer0/attn/q;")
   assert alg == "OCTAV" and cfg.weight_tensor_config.granularity == q.QuantGranularity.BLOCKWISE_32
   assert rm.get_quantization_configs(FC, "attn/skip_me;")[0] == "no_quantize"
-  # blockwise is not valid for the virtual INPUT op -> falls back to the earlier match
-  assert rm.get_quantization_configs(q.TFLOperationName.INPUT, "attn;")[0] == "min_max_uniform_quantize"
+  # the policy has no DRQ entry for the virtual INPUT op (ref default_policy.py:278-289)
+  assert rm.get_quantization_configs(q.TFLOperationName.INPUT, "attn;")[0] == "no_quantize"
   assert rm.get_quantization_configs(q.TFLOperationName.SOFTMAX, "x;")[0] == "no_quantize"
   rt = recipe_manager.RecipeManager()
   rt.load_quantization_recipe(rm.get_quantization_recipe())
@@ -228,3 +228,42 @@ def test_op_scope_and_tensor_data_views():
   assert tfl_flatbuffer_utils.get_tensor_data(t[0], bufs) is None
   view = tfl_flatbuffer_utils.get_tensor_data(t[1], bufs)
   assert np.array_equal(view, w) and np.shares_memory(view, bufs[1].data)  # zero copy
+
+
+def test_config_check_policy_equals_reference_acceptance_set():
+  """default_policy.py's rule form accepts exactly the (op, config) pairs the reference's
+  unrolled JSON policy holds (tests/golden/ref_policy.json, recorded from the real reference),
+  and nothing else over the whole config grid."""
+  import itertools
+  import json as _json
+  import os as _os
+  from mi355q import default_policy
+  path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "ref_policy.json")
+  ref = {op: {tuple(r) for r in rows} for op, rows in _json.load(open(path))["policy"].items()}
+  pol = default_policy.DEFAULT_CONFIG_CHECK_POLICY
+  assert {o.value for o in pol.keys()} == set(ref)
+  G, P = q.QuantGranularity, q.ComputePrecision
+  grans = [G.TENSORWISE, G.CHANNELWISE, G.BLOCKWISE_32, G.BLOCKWISE_64, G.BLOCKWISE_128, G.BLOCKWISE_256]
+  n_ok = 0
+  for op in q.TFLOperationName:
+    for act in [None] + [(b, s, g) for b in (8, 16) for s in (True, False) for g in (G.TENSORWISE, G.CHANNELWISE)]:
+      for wb, ws, wg, prec, dq in itertools.product((2, 4, 8), (True, False), grans, (P.INTEGER, P.FLOAT), (True, False)):
+        if act is not None and prec != P.INTEGER:
+          continue                       # rejected by OpQuantizationConfig itself
+        cfg = q.OpQuantizationConfig(
+            activation_tensor_config=None if act is None else q.TensorQuantizationConfig(act[0], act[1], act[2]),
+            weight_tensor_config=q.TensorQuantizationConfig(wb, ws, wg), compute_precision=prec,
+            explicit_dequantize=dq, min_weight_elements=7)
+        row = (None if act is None else act[0], None if act is None else act[1],
+               None if act is None else act[2].value, wb, ws, wg.value, prec.value, dq)
+        want = row in ref.get(op.value, ())
+        assert pol.accepts(op, cfg) == want, (op, row)
+        n_ok += want
+  assert n_ok == sum(len(v) for v in ref.values())
+  with pytest.raises(ValueError, match="Unsupported op for"):
+    default_policy.check_if_valid_op_config(
+        q.TFLOperationName.BATCH_MATMUL,
+        q.OpQuantizationConfig(weight_tensor_config=q.TensorQuantizationConfig(4, True, G.CHANNELWISE),
+                               compute_precision=P.INTEGER), pol)
+  with pytest.raises(ValueError, match="No policy was specified at all"):
+    default_policy.check_if_valid_op_config(q.TFLOperationName.FULLY_CONNECTED, q.OpQuantizationConfig(), None)
