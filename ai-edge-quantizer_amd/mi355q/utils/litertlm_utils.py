@@ -1,0 +1,196 @@
+"""`.litertlm` container pass-through (ref: utils/litertlm_utils.py:69-283, aeq.py:61-181).
+
+A LiteRT-LM file is: 8 magic bytes `LITERTLM`, three little-endian u32 version numbers, 4 zero
+bytes, the u64 end offset of the header flatbuffer (file offset 24), the header flatbuffer at
+offset 32 (system metadata + one record per section: key/value items, begin/end offsets, data
+type), then the sections at 16 KiB-aligned offsets. The reference reads and re-packs the header
+through the third-party `litert_lm_builder` wheel; here the header is parsed with this build's
+own flatbuffer reader (full byte accounting, so an unknown layout is refused) and re-serialized
+by **patching the section offsets in place** in a verbatim copy of the header - every other
+byte of it (system metadata, item order, unknown value types) is carried unchanged. (The
+reference additionally re-stamps system metadata through the wheel; that step is third-party
+behaviour and is not reproduced.)
+"""
+from __future__ import annotations
+
+import mmap
+import os
+import pathlib
+import struct
+from typing import Any, Mapping, Optional, Union
+
+from . import tfl_flatbuffer_utils
+from . import tflite_flatbuffer as fb
+
+Path = Union[str, pathlib.Path]
+
+HEADER_MAGIC_BYTES = b"LITERTLM"
+HEADER_END_LOCATION_BYTE_OFFSET = 24
+HEADER_BEGIN_BYTE_OFFSET = 32
+BLOCK_SIZE = 16 * 1024
+
+
+class AnySectionDataType:
+  NONE = 0
+  GenericBinaryData = 1
+  Deprecated = 2
+  TFLiteModel = 3
+
+
+_STRING_VALUE = 9     # VData union member holding a string
+
+# Header schema (checked field by field against the reference's .litertlm test fixture: the
+# parse accounts for every byte of the header).
+fb.SCHEMA.update({
+    "LiteRTLMMetaData": [("systemMetadata", ("tab", "SystemMetadata")),
+                         ("sectionMetadata", ("tab", "SectionMetadata"))],
+    "SystemMetadata": [("entries", ("vec_tab", "KeyValuePair"))],
+    "SectionMetadata": [("objects", ("vec_tab", "SectionObject"))],
+    "SectionObject": [("items", ("vec_tab", "KeyValuePair")), ("beginOffset", "u64", 0),
+                      ("endOffset", "u64", 0), ("dataType", "u8", 0)],
+    "KeyValuePair": [("key", "str"), ("valueType", "u8", 0),
+                     ("value", ("union", "valueType", {_STRING_VALUE: "StringValue"}))],
+    "StringValue": [("value", "str")],
+})
+for _t in ("LiteRTLMMetaData", "SystemMetadata", "SectionMetadata", "SectionObject", "KeyValuePair",
+           "StringValue"):
+  fb.CLASSES[_t] = type(_t + "T", (fb.TableT,), {"_table": _t})
+SectionObjectT = fb.CLASSES["SectionObject"]
+
+
+def _text(v: Any) -> Any:
+  return v.decode("utf-8") if isinstance(v, (bytes, bytearray)) else v
+
+
+def _scalar_of(value: Any) -> Any:
+  """Python value of a VData member: the string, or field 0 of a one-scalar table."""
+  if isinstance(value, fb.TableT):
+    return _text(value.value)
+  return value
+
+
+class LiteRTLMFile:
+  """Sections of a `.litertlm` file (memory mapped, nothing is copied until serialize)."""
+
+  def __init__(self, path: Path):
+    self._path = path
+    self._buf = tfl_flatbuffer_utils.get_model_content(path)
+    if bytes(self._buf[:8]) != HEADER_MAGIC_BYTES:
+      raise ValueError(f"{path} is not a LiteRT-LM file (bad magic)")
+    self.version = struct.unpack_from("<III", self._buf, 8)
+    self._header_end = struct.unpack_from("<Q", self._buf, HEADER_END_LOCATION_BYTE_OFFSET)[0]
+    if not HEADER_BEGIN_BYTE_OFFSET < self._header_end <= len(self._buf):
+      raise ValueError(f"{path}: header end offset {self._header_end} is out of range")
+    header = self._buf[HEADER_BEGIN_BYTE_OFFSET:self._header_end]
+    reader = fb._Reader(header)  # pylint: disable=protected-access
+    reader.mark(0, 4)
+    self._offset_fields: list[tuple[int, int]] = []   # (begin, end) field positions per section
+    self._metadata = reader.table(reader.u32(0), "LiteRTLMMetaData")
+    reader.verify_coverage(0, len(header))
+    self._sections = list((self._metadata.sectionMetadata and self._metadata.sectionMetadata.objects) or [])
+    self._locate_offset_fields(reader)
+    for s in self._sections:
+      if not self._header_end <= s.beginOffset <= s.endOffset <= len(self._buf):
+        raise ValueError(f"{path}: section [{s.beginOffset}, {s.endOffset}) is out of range")
+
+  def _locate_offset_fields(self, reader) -> None:
+    """Positions (inside the header) of every section's begin/end offset scalars, for patching."""
+    root = reader.u32(0)
+    fields, _ = reader.table_header(root)
+    sm = root + fields[1]
+    sm = sm + reader.u32(sm)
+    sm_fields, _ = reader.table_header(sm)
+    vec = sm + sm_fields[0]
+    vec = vec + reader.u32(vec)
+    for i in range(reader.u32(vec)):
+      at = vec + 4 + 4 * i
+      obj = at + reader.u32(at)
+      f, _ = reader.table_header(obj)
+      begin = obj + f[1] if len(f) > 1 and f[1] else -1
+      end = obj + f[2] if len(f) > 2 and f[2] else -1
+      self._offset_fields.append((begin, end))
+
+  @property
+  def sections(self) -> list[Any]:
+    return self._sections
+
+  def get_system_metadata(self) -> dict[str, Any]:
+    sm = self._metadata.systemMetadata
+    return {_text(e.key): _scalar_of(e.value) for e in (sm.entries if sm and sm.entries else [])}
+
+  def get_section_metadata(self, section_id: int) -> dict[str, Any]:
+    return {_text(i.key): _scalar_of(i.value) for i in (self._sections[section_id].items or [])}
+
+  def get_model_type(self, section_id: int) -> Optional[str]:
+    v = self.get_section_metadata(section_id).get("model_type")
+    return v if isinstance(v, str) else None
+
+  def get_section_buffer(self, section_id: int) -> memoryview:
+    s = self._sections[section_id]
+    return self._buf[s.beginOffset:s.endOffset]
+
+  def read_model(self, section_id: int) -> Optional[Any]:
+    if self._sections[section_id].dataType != AnySectionDataType.TFLiteModel:
+      return None
+    return tfl_flatbuffer_utils.read_model(self.get_section_buffer(section_id))
+
+  def serialize(self, path: Path, section_data_overrides: Mapping[int, Any]) -> int:
+    """Writes the file again with some sections replaced; returns the number of bytes written.
+    Sections keep their order and start at BLOCK_SIZE-aligned offsets (ref :176-283)."""
+    if not self._sections:
+      raise ValueError("LiteRT-LM file has no sections")
+    offsets = [min(s.beginOffset for s in self._sections)]
+    lengths = []
+    for sid, s in enumerate(self._sections):
+      data = section_data_overrides.get(sid)
+      n = len(data) if data is not None and len(data) else s.endOffset - s.beginOffset
+      lengths.append(n)
+      offsets.append((offsets[-1] + n + BLOCK_SIZE - 1) & ~(BLOCK_SIZE - 1))
+    header = bytearray(self._buf[:self._header_end])
+    for sid, (begin_at, end_at) in enumerate(self._offset_fields):
+      if begin_at < 0 or end_at < 0:
+        raise ValueError("section record without stored offsets cannot be re-addressed in place")
+      struct.pack_into("<Q", header, HEADER_BEGIN_BYTE_OFFSET + begin_at, offsets[sid])
+      struct.pack_into("<Q", header, HEADER_BEGIN_BYTE_OFFSET + end_at, offsets[sid] + lengths[sid])
+    total = offsets[-2] + lengths[-1]
+    with open(path, "w+b") as f:
+      f.truncate(total)
+      out = mmap.mmap(f.fileno(), total)
+    out[:len(header)] = header
+    for sid in range(len(self._sections)):
+      data = section_data_overrides.get(sid)
+      if data is None or not len(data):
+        data = self.get_section_buffer(sid)
+      out[offsets[sid]:offsets[sid] + lengths[sid]] = memoryview(data).cast("B")
+    out.flush()
+    out.close()
+    return total
+
+
+def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path,
+                      overwrite: bool = False) -> int:
+  """Quantizes every TFLite section that has a recipe and re-packs the container.
+
+  `recipe` is one recipe (list) applied to every model, or a mapping model_type -> recipe with
+  an optional "default" entry (ref aeq.py:61-181). Returns the size of the written file.
+  """
+  from .. import quantizer   # deferred: quantizer imports this package's utils
+  if os.path.exists(output_path) and not overwrite:
+    raise ValueError(f"The model {output_path} already exists. Specify overwrite=True to replace it.")
+  recipes = recipe if isinstance(recipe, Mapping) else {"default": recipe}
+  src = LiteRTLMFile(litertlm_path)
+  replaced: dict[int, Any] = {}
+  for sid, section in enumerate(src.sections):
+    if section.dataType != AnySectionDataType.TFLiteModel:
+      continue
+    model_type = src.get_model_type(sid)
+    if model_type is None:
+      continue
+    model_recipe = recipes.get(model_type, recipes.get("default"))
+    if model_recipe is None:
+      continue
+    result = quantizer.Quantizer(src.get_section_buffer(sid), model_recipe).quantize()
+    replaced[sid] = result.quantized_model
+  if not replaced:
+    raise ValueError("No models were quantized, not creating output file.")
+  return src.serialize(output_path, replaced)

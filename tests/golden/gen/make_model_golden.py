@@ -192,5 +192,82 @@ def main():
   print("wrote", len(cases), "cases")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--srq" not in sys.argv:
   main()
+
+
+# ---------------------------------------------------------------------------------------
+# static (SRQ) recipes: what ParamsGenerator hands the transformation layer for every tensor
+# ---------------------------------------------------------------------------------------
+SRQ_MODELS = ["single_fc_bias", "single_fc_no_bias", "single_fc", "single_depthwise_conv2d_bias",
+              "single_conv2d_transpose_bias", "single_fc_bias_relu"]
+
+
+def _params_summary(p):
+  if p is None:
+    return None
+  out = dict(kind=type(p).__name__, num_bits=int(p.num_bits))
+  if hasattr(p, "scale"):
+    sc = np.asarray(p.scale)
+    zp = None if p.zero_point is None else np.asarray(p.zero_point)
+    out.update(symmetric=bool(p.symmetric), quantized_dimension=p.quantized_dimension,
+               block_size=int(getattr(p, "block_size", 0) or 0),
+               scale=dict(shape=list(sc.shape), dtype=str(sc.dtype), sha256=sha(np.ascontiguousarray(sc).tobytes()),
+                          head=[float(x) for x in sc.ravel()[:3]]),
+               zero_point=None if zp is None else dict(shape=list(zp.shape), dtype=str(zp.dtype),
+                                                       sha256=sha(np.ascontiguousarray(zp).tobytes()),
+                                                       head=[int(x) for x in zp.ravel()[:3]]))
+    qd = p.quantized_data
+    out["quantized_data"] = None if qd is None else dict(
+        shape=list(np.shape(qd)), dtype=str(np.asarray(qd).dtype), sha256=sha(np.ascontiguousarray(qd).tobytes()))
+  return out
+
+
+def srq_cases():
+  from ai_edge_quantizer import recipe as ref_recipe
+  out = {}
+  for name in SRQ_MODELS:
+    for rname, rcp in (("static_wi8_ai8", ref_recipe.static_wi8_ai8()), ("static_wi8_ai16", ref_recipe.static_wi8_ai16())):
+      path = os.path.join(REF, "tests/models", name + ".tflite")
+      shutil.copyfile(path, os.path.join(GOLDEN, "models", name + ".tflite"))
+      model = to_bags(fb.read_model(open(path, "rb").read()))
+      # synthetic calibration result: an (asymmetric) range for every non-constant tensor
+      rng = np.random.default_rng(len(name) * 7 + len(rname))
+      qsvs = {}
+      for sg in model.subgraphs:
+        for t in sg.tensors:
+          if model.buffers[t.buffer].data is None:
+            lo, hi = sorted(rng.uniform(-6, 6, 2))
+            qsvs[t.name.decode()] = {"min": np.array([[min(lo, -0.1)]], np.float32),
+                                     "max": np.array([[max(hi, 0.1)]], np.float32)}
+      rm = recipe_manager.RecipeManager()
+      rm.load_quantization_recipe(rcp)
+      key = f"{name}/{rname}"
+      try:
+        with warnings.catch_warnings():
+          warnings.simplefilter("ignore")
+          params = params_generator.ParamsGenerator(model).generate_quantization_parameters(rm, qsvs)
+      except Exception as e:
+        out[key] = dict(model=name, recipe=rcp, error=type(e).__name__, message=str(e)[:300])
+        print("err ", key, type(e).__name__, str(e)[:100])
+        continue
+      rec = {}
+      for tname, tp in params.items():
+        links = []
+        for role, link_list in (("producer", [tp.producer] if tp.producer is not None else []),
+                                ("consumer", tp.consumers or [])):
+          for link in link_list:
+            links.append(dict(role=role, op=int(link.subgraph_op_id),
+                              transformations=[t.name for t in link.transformations],
+                              parameters=_params_summary(link.parameters)))
+        rec[tname] = links
+      out[key] = dict(model=name, recipe=rcp, qsvs={k: {"min": float(v["min"].ravel()[0]), "max": float(v["max"].ravel()[0])}
+                                                     for k, v in qsvs.items()}, params=rec)
+      print("ok  ", key)
+  with open(os.path.join(GOLDEN, "ref_srq_params.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_model_golden.py (srq_cases)", numpy=np.__version__,
+                   cases=json.loads(json.dumps(out, default=str))), f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__" and "--srq" in sys.argv:
+  srq_cases()
