@@ -1,14 +1,14 @@
 """Produces the serialized quantized model (ref: model_modifier.py:90-391).
 
 `ModelModifier.modify_model` works on a structural copy of the float model whose arrays are
-views (the float model and its mmap'd weights are never written), applies the QUANTIZE_TENSOR
-transformation in the reference's tensor processing order, and serializes with this build's own
-flatbuffer writer: inline when the large buffers total < 256 KiB, otherwise buffers >= 1 KiB go
+views (the float model and its mmap'd weights are never written), turns the parameters into
+transformation instructions, applies them in the reference's tensor processing order, and
+serializes with this build's own flatbuffer writer: inline when the large buffers total < 256 KiB, otherwise buffers >= 1 KiB go
 behind the flatbuffer at 16-byte aligned offsets (`Buffer.offset/size`), written straight into
 an mmap of the output file when a path is given.
 
-Transformations that rewrite the graph (ADD_QUANTIZE / ADD_DEQUANTIZE / Hadamard op insertion /
-buffer or tensor duplication) are outside this build's scope and raise NotImplementedError.
+QUANTIZE_TENSOR, ADD_QUANTIZE, ADD_DEQUANTIZE and constant duplication are applied; Hadamard /
+multiply op insertion is outside this build's scope and raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -18,8 +18,8 @@ from typing import Any, Optional
 import numpy as np
 
 from . import qtyping
-from .transformations import quantize_tensor
-from .transformations import transformation_utils
+from . import transformation_instruction_generator
+from . import transformation_performer
 from .utils import tfl_flatbuffer_utils
 from .utils import tflite_flatbuffer
 
@@ -55,38 +55,37 @@ def tensor_processing_order(names: set[str], model: Any) -> list[str]:
   return order
 
 
-def _instruction(p: qtyping.TensorTransformationParams):
-  """The single QUANTIZE_TENSOR instruction of a tensor, None for NO_QUANTIZE, or raises."""
-  links = list(p.consumers or []) + ([p.producer] if p.producer is not None else [])
-  wanted = {t for link in links for t in link.transformations}
-  if wanted <= {_T.NO_QUANTIZE}:
-    return None
-  if wanted != {_T.QUANTIZE_TENSOR}:
-    raise NotImplementedError(
-        f"tensor {p.tensor_name}: transformations {sorted(t.name for t in wanted)} need graph"
-        " rewriting, which is outside this build's scope")
-  first = links[0].parameters
-  if any(link.parameters != first for link in links[1:]):
-    raise NotImplementedError(f"tensor {p.tensor_name}: consumers disagree on parameters")
-  return first
+def apply_transformations(model: Any, params: dict[str, qtyping.TensorTransformationParams]):
+  """Parameters -> instructions -> graph edits, in the reference's tensor processing order.
+  Returns the instructions (for signature fix-ups)."""
+  insts = transformation_instruction_generator.TransformationInstructionsGenerator(
+  ).quant_params_to_transformation_insts(params, model)
+  transformation_performer.TransformationPerformer().transform_graph(
+      insts, model, tensor_processing_order(set(insts), model))
+  return insts
 
 
-def apply_quantize_tensor_transformations(model: Any, params: dict[str, qtyping.TensorTransformationParams]) -> None:
-  """QUANTIZE_TENSOR for every constant whose consumers all ask for it with equal parameters
-  (the case the reference's instruction generator leaves as a single QUANTIZE_TENSOR
-  instruction). As in the reference, a tensor name resolves to its last occurrence in the
-  model (transformation_instruction_generator.py:237-245)."""
-  where: dict[str, tuple[Any, int]] = {}
-  for sg in model.subgraphs:
-    for tid, tensor in enumerate(sg.tensors):
-      where[tfl_flatbuffer_utils.get_tensor_name(tensor)] = (sg, tid)
-  todo = {name: inst for name, p in params.items() if (inst := _instruction(p)) is not None}
-  buffer_origin: dict[int, Any] = {}
-  for name in tensor_processing_order(set(todo), model):
-    sg, tid = where[name]
-    quantize_tensor.quantize_tensor(transformation_utils.TransformationInput(
-        tensor_id=tid, model=model, subgraph=sg, producer=-1, consumers=[], quant_params=todo[name],
-        buffer_origin=buffer_origin))
+# name kept for callers of the first, QUANTIZE_TENSOR-only version of this module
+apply_quantize_tensor_transformations = apply_transformations
+
+
+def _inserted_before_output(insts, kind) -> bool:
+  return any(inst.transformation == kind and inst.consumers == [-1]
+             for tti in insts.values() for inst in (tti.instructions or []))
+
+
+def _repoint_signature_outputs(model: Any, suffix: str) -> None:
+  """A Q / DQ op inserted in front of a graph output created `<name><suffix>`; signature
+  outputs that named the old tensor follow it (ref :201-255)."""
+  for sig in model.signatureDefs or []:
+    sg = model.subgraphs[sig.subgraphIndex]
+    for out_id in sg.outputs:
+      new_name = tfl_flatbuffer_utils.get_tensor_name(sg.tensors[out_id])
+      for item in sig.outputs or []:
+        old = tfl_flatbuffer_utils.get_tensor_name(sg.tensors[item.tensorIndex])
+        if old + suffix == new_name:
+          item.tensorIndex = out_id
+          break
 
 
 def _large_buffer_bytes(model: Any) -> int:
@@ -129,6 +128,10 @@ class ModelModifier:
                    enable_progress_bar: Optional[bool] = None):
     del enable_progress_bar
     quantized = copy_with_views(self._model)
-    apply_quantize_tensor_transformations(quantized, params)
+    insts = apply_transformations(quantized, params)
+    if _inserted_before_output(insts, _T.ADD_DEQUANTIZE):
+      _repoint_signature_outputs(quantized, "_dequant")
+    if _inserted_before_output(insts, _T.ADD_QUANTIZE):
+      _repoint_signature_outputs(quantized, "_quantized")
     self.quantized_model_object = quantized
     return serialize_model(quantized, serialize_to_path)

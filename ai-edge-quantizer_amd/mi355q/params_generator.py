@@ -3,8 +3,8 @@
 Restatement of the op loop of ref: params_generator.py:69-185 for the ops this
 build registers: for every subgraph op (+ the virtual INPUT / OUTPUT ops) resolve
 the recipe, look the materializer up in the registry and merge the per-tensor
-results. Ops the recipe / policy leaves alone get NO_QUANTIZE. (Buffer-sharing fix-ups of the
-reference, ref :291-463, concern graph surgery and are not restated.)
+results. Ops the recipe / policy leaves alone get NO_QUANTIZE; constants shared between
+differently quantized users are marked for duplication (ref :291-463).
 """
 from __future__ import annotations
 
@@ -17,15 +17,112 @@ from .algorithms.utils import common_utils
 from .utils import tfl_flatbuffer_utils
 
 
+_T = qtyping.QuantTransformation
+_FLOAT_SOURCE = (_T.ADD_QUANTIZE, _T.NO_QUANTIZE, _T.INSERT_HADAMARD_ROTATION,
+                 _T.INSERT_DECOMPOSED_HADAMARD_ROTATION, _T.INSERT_MULTIPLY)
+_QUANTIZED_SOURCE = (_T.QUANTIZE_TENSOR, _T.ADD_DEQUANTIZE)
+
+
+def _links_compatible(a: qtyping.OpToTensorParams, b: qtyping.OpToTensorParams) -> bool:
+  """Can two ops read the same stored tensor? Same request, or both read it as float, or both
+  read it quantized with equal parameters (ref :527-559)."""
+  if a.transformations == b.transformations and (
+      a.parameters == b.parameters or (a.parameters is None and b.parameters is None)):
+    return True
+  if a.transformations[0] in _FLOAT_SOURCE and b.transformations[0] in _FLOAT_SOURCE:
+    return True
+  return (a.transformations[0] in _QUANTIZED_SOURCE and b.transformations[0] in _QUANTIZED_SOURCE
+          and a.parameters == b.parameters)
+
+
 class ParamsGenerator:
   def __init__(self, float_tflite: Any):
     self.float_model = float_tflite
     self.model_quant_results: dict[str, qtyping.TensorTransformationParams] = {}
     self._tensor_quant_params_cache = common_utils.TensorQuantParamsCache()
+    self.buffer_to_tensors = tfl_flatbuffer_utils.buffer_to_tensors(float_tflite)
+    seen: set[str] = set()
+    for sg in float_tflite.subgraphs:
+      for t in sg.tensors:
+        name = tfl_flatbuffer_utils.get_tensor_name(t)
+        if name in seen:
+          raise ValueError(
+              "Tensor name %s is not unique in the model. Please check your model and rename the"
+              " tensor as ParamsGenerator assumes tensor names are unique." % name)
+        seen.add(name)
+
+  # ---- shared constants (ref :291-463) -----------------------------------------------------
+  def _is_constant(self, tensor: Any) -> bool:
+    return self.float_model.buffers[tensor.buffer].data is not None
+
+  def _consumers_agree(self, tensor: Any) -> bool:
+    p = self.model_quant_results.get(tfl_flatbuffer_utils.get_tensor_name(tensor))
+    if p is None or p.consumers is None or len(p.consumers) < 2:
+      return True
+    if all(_links_compatible(c, p.consumers[0]) for c in p.consumers[1:]):
+      return True
+    if self._is_constant(tensor):
+      return False
+    raise RuntimeError(
+        f"The tensor {tensor.name} consumers do not have the same quantization parameters. Please"
+        " modify your quantization recipe to make sure the two tensors have the same quantization"
+        " settings.")
+
+  def _tensors_agree(self, t1: Any, t2: Any) -> bool:
+    p1 = self.model_quant_results.get(tfl_flatbuffer_utils.get_tensor_name(t1))
+    p2 = self.model_quant_results.get(tfl_flatbuffer_utils.get_tensor_name(t2))
+    if p1 is None or p2 is None:
+      return True
+    ok = True
+    if p1.producer is None or p2.producer is None:
+      ok = p1.producer == p2.producer
+    else:
+      ok = _links_compatible(p1.producer, p2.producer)
+    if ok:
+      if p1.consumers is None or p2.consumers is None:
+        ok = p1.consumers == p2.consumers
+      else:
+        ok = _links_compatible(p1.consumers[0], p2.consumers[0])
+    if ok:
+      return True
+    if self._is_constant(t1):
+      return False
+    raise RuntimeError(
+        f"The tensors {t1.name} and {t2.name} do not have the same quantization parameters even"
+        " though they share the same buffer. Please modify your quantization recipe to make sure"
+        " the two tensors have the same quantization settings.")
+
+  def _check_and_fix_buffer_sharing(self) -> None:
+    """A constant whose consumers disagree is marked for tensor duplication; constants sharing
+    a buffer but not a quantization are marked for buffer duplication (all but the last user
+    of the buffer). The marks are DUPLICATE_* transformations put first for every consumer."""
+    dup_buffers, dup_tensors = [], []
+    for buffer_idx, tensors in self.buffer_to_tensors.items():
+      if not tensors or buffer_idx == 0:
+        continue
+      for t in tensors:
+        if not self._consumers_agree(t):
+          dup_tensors.append(tfl_flatbuffer_utils.get_tensor_name(t))
+      if tfl_flatbuffer_utils.get_tensor_name(tensors[0]) in dup_tensors:
+        dup_buffers.append(buffer_idx)
+        continue
+      for t2 in tensors[1:]:
+        if (tfl_flatbuffer_utils.get_tensor_name(t2) in dup_tensors
+            or not self._tensors_agree(tensors[0], t2)):
+          dup_buffers.append(buffer_idx)
+          break
+    for buffer_idx in dup_buffers:
+      for t in self.buffer_to_tensors[buffer_idx][:-1]:
+        for link in self.model_quant_results[tfl_flatbuffer_utils.get_tensor_name(t)].consumers:
+          link.transformations.insert(0, _T.DUPLICATE_BUFFER)
+    for name in dup_tensors:
+      for link in self.model_quant_results[name].consumers:
+        link.transformations.insert(0, _T.DUPLICATE_TENSOR)
 
   def _no_quant_results(self, op_id: int, op: Any, tensors: list[Any]):
-    link = qtyping.OpToTensorParams(subgraph_op_id=op_id,
-                                    transformations=[qtyping.QuantTransformation.NO_QUANTIZE])
+    def link():   # a fresh record per tensor: duplication marks are inserted in place later
+      return qtyping.OpToTensorParams(subgraph_op_id=op_id,
+                                      transformations=[qtyping.QuantTransformation.NO_QUANTIZE])
     out = []
     for ids, inbound in ((op.inputs, True), (op.outputs, False)):
       for tid in ids:
@@ -33,8 +130,8 @@ class ParamsGenerator:
           continue
         name = tfl_flatbuffer_utils.get_tensor_name(tensors[tid])
         out.append(qtyping.TensorTransformationParams(
-            tensor_name=name, consumers=[link] if inbound else None,
-            producer=None if inbound else link))
+            tensor_name=name, consumers=[link()] if inbound else None,
+            producer=None if inbound else link()))
     return out
 
   def _merge(self, results) -> None:
@@ -83,4 +180,5 @@ class ParamsGenerator:
         self._merge(fn(op_info=qtyping.OpInfo(op, op_key, op_id, cfg), graph_info=graph_info,
                        tensor_name_to_qsv=model_qsvs,
                        tensor_quant_params_cache=self._tensor_quant_params_cache))
+    self._check_and_fix_buffer_sharing()
     return self.model_quant_results

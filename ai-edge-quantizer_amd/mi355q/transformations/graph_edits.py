@@ -1,0 +1,96 @@
+"""Transformations that change the graph around a tensor: Q / DQ op insertion and constant
+duplication (ref: transformations/quant_insert.py, dequant_insert.py, duplicate_buffer.py,
+duplicate_tensor.py). Pure flatbuffer bookkeeping; the arithmetic lives in quantize_tensor.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+from .. import qtyping
+from ..utils import tfl_flatbuffer_utils
+from . import quantize_tensor
+from . import transformation_utils
+
+_Input = transformation_utils.TransformationInput
+
+
+def _raw_name(tensor: Any) -> bytes:
+  return tensor.name if isinstance(tensor.name, (bytes, bytearray)) else str(tensor.name).encode()
+
+
+def _splice_after(ti: _Input, new_tensor_id: int, op: Any) -> int:
+  """Re-route the listed consumers (and graph outputs) from the tensor to `new_tensor_id` and
+  insert `op` right before the first of them - or right after the producer when that comes
+  later. Returns the op's index."""
+  sg = ti.subgraph
+  for consumer in ti.consumers:
+    inputs = sg.operators[consumer].inputs
+    for k, tid in enumerate(inputs):
+      if tid == ti.tensor_id:
+        inputs[k] = new_tensor_id
+  for k, tid in enumerate(sg.outputs):
+    if tid == ti.tensor_id:
+      sg.outputs[k] = new_tensor_id
+  at = max(ti.producer + 1, min(ti.consumers))
+  sg.operators.insert(at, op)
+  return at
+
+
+def insert_quant(ti: _Input) -> qtyping.TransformationInfo:
+  """float tensor -> QUANTIZE -> `<name>_quantized` for the given consumers (ref quant_insert.py)."""
+  code = transformation_utils.add_op_code(qtyping.BuiltinOperator.QUANTIZE, ti.model.operatorCodes)
+  tensor = ti.subgraph.tensors[ti.tensor_id]
+  new_id = transformation_utils.add_new_activation_tensor(
+      _raw_name(tensor) + b"_quantized", tensor.shape, qtyping.TensorType.FLOAT32, ti.subgraph)
+  quantize_tensor.quantize_tensor(_Input(new_id, ti.model, ti.subgraph, ti.producer, ti.consumers,
+                                         ti.quant_params))
+  op = qtyping.OperatorT(opcodeIndex=code, inputs=[ti.tensor_id], outputs=[new_id])
+  at = _splice_after(ti, new_id, op)
+  return qtyping.TransformationInfo(op_id=at, num_ops_added=1, output_tensor_id=new_id)
+
+
+def insert_dequant(ti: _Input) -> qtyping.TransformationInfo:
+  """the tensor becomes integer; DEQUANTIZE -> `<name>_dequant` feeds the given consumers
+  (ref dequant_insert.py)."""
+  code = transformation_utils.add_op_code(qtyping.BuiltinOperator.DEQUANTIZE, ti.model.operatorCodes)
+  tensor = ti.subgraph.tensors[ti.tensor_id]
+  new_id = transformation_utils.add_new_activation_tensor(
+      _raw_name(tensor) + b"_dequant", tensor.shape, qtyping.TensorType.FLOAT32, ti.subgraph)
+  op = qtyping.OperatorT(opcodeIndex=code, inputs=[ti.tensor_id], outputs=[new_id])
+  quantize_tensor.quantize_tensor(ti)
+  at = _splice_after(ti, new_id, op)
+  return qtyping.TransformationInfo(op_id=at, num_ops_added=1, output_tensor_id=new_id)
+
+
+def _constant_bytes(ti: _Input, what: str):
+  tensor = ti.subgraph.tensors[ti.tensor_id]
+  data = ti.model.buffers[tensor.buffer].data
+  if data is None:
+    raise ValueError(f"{what} transformation supports only constant tensors. Tensor"
+                     f" {tfl_flatbuffer_utils.get_tensor_name(tensor)} is not constant.")
+  return tensor, data
+
+
+def duplicate_buffer(ti: _Input) -> qtyping.TransformationInfo:
+  """Give the tensor a private copy of its (shared) buffer (ref duplicate_buffer.py)."""
+  tensor, data = _constant_bytes(ti, "Duplicate Buffer")
+  tensor.buffer = transformation_utils.get_constant_buffer(data, ti.model, force_duplicate_buffer=True)
+  return qtyping.TransformationInfo(op_id=0, num_ops_added=0, output_tensor_id=ti.tensor_id)
+
+
+def duplicate_tensor(ti: _Input) -> qtyping.TransformationInfo:
+  """`<name>_duplicated_<id>` with its own buffer, consumed by the given ops instead of the
+  original (ref duplicate_tensor.py)."""
+  tensor, data = _constant_bytes(ti, "Duplicate Tensor")
+  name = tfl_flatbuffer_utils.get_tensor_name(tensor)
+  new_id = transformation_utils.add_new_constant_tensor(
+      f"{name}_duplicated".encode(), data, tensor.type, ti.subgraph, ti.model,
+      tensor_shape=tensor.shape, force_duplicate_buffer=True)
+  ti.subgraph.tensors[new_id].name += f"_{new_id}".encode()
+  for consumer in ti.consumers:
+    inputs = ti.subgraph.operators[consumer].inputs
+    for k, tid in enumerate(inputs):
+      if tid == ti.tensor_id:
+        inputs[k] = new_id
+        break
+  return qtyping.TransformationInfo(op_id=0, num_ops_added=0, output_tensor_id=new_id)

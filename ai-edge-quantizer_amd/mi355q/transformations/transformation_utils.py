@@ -88,6 +88,41 @@ def add_new_constant_tensor(tensor_name: bytes, data: np.ndarray, tensor_type, s
   return len(subgraph.tensors) - 1
 
 
+def add_op_code(op_code: int, model_op_codes: list[Any], custom_op_name: Optional[str] = None) -> int:
+  """Index of the operator code in the model, appended when absent (ref :80-116)."""
+  if op_code == qtyping.BuiltinOperator.CUSTOM and custom_op_name is None:
+    raise ValueError("Custom string is required for custom op code.")
+  for i, existing in enumerate(model_op_codes):
+    if existing.builtinCode == op_code and (custom_op_name is None
+                                            or existing.customCode == custom_op_name):
+      return i
+  code = qtyping.OperatorCodeT()
+  code.builtinCode = int(op_code)
+  if custom_op_name is not None:
+    code.customCode = custom_op_name
+  model_op_codes.append(code)
+  return len(model_op_codes) - 1
+
+
+def add_new_activation_tensor(tensor_name: bytes, shape, tensor_type, subgraph: Any,
+                              quantization=None) -> int:
+  """Appends a non-constant tensor (buffer 0); a dynamic dimension (-1) goes to
+  shapeSignature with 1 in shape (ref :250-284)."""
+  t = qtyping.TensorT()
+  shape = None if shape is None else list(shape)
+  if shape is not None and -1 in shape:
+    t.shapeSignature = shape
+    t.shape = [1 if d == -1 else d for d in shape]
+  else:
+    t.shape = shape
+  t.type = tensor_type
+  t.name = tensor_name
+  t.quantization = quantization
+  t.buffer = 0
+  subgraph.tensors.append(t)
+  return len(subgraph.tensors) - 1
+
+
 def pack_data(bitwidth: int, data: np.ndarray) -> np.ndarray:
   """int4 / int2 packing, element 0 in the lowest bits (ref :293-353), on the GPU.
 

@@ -62,6 +62,9 @@ RECIPES = {
     "dynamic_wi8_octav": recipe.dynamic_wi8_afp32(algorithm_key="OCTAV"),
     "dynamic_wi4b32_afp32": recipe.dynamic_wi4b32_afp32(),
     "dynamic_legacy_wi8_afp32": json.load(open(os.path.join(REF, "recipes/dynamic_legacy_wi8_afp32_recipe.json"))),
+    "weight_only_wi8_afp32": recipe.weight_only_wi8_afp32(),
+    "weight_only_wi4_afp32": recipe.weight_only_wi4_afp32(),
+    "default_af32w8float": json.load(open(os.path.join(REF, "recipes/default_af32w8float_recipe.json"))),
 }
 
 _SHIM_CLASS = {
@@ -117,17 +120,21 @@ def describe(model):
                                  block_size=int(q.details.blockSize))
         rec["quantization"] = qr
       tensors.append(rec)
-    out["subgraphs"].append(dict(tensors=tensors, n_operators=len(sg.operators or []),
+    ops = [[int(model.operatorCodes[op.opcodeIndex].builtinCode), [int(i) for i in op.inputs],
+            [int(i) for i in op.outputs]] for op in (sg.operators or [])]
+    out["subgraphs"].append(dict(tensors=tensors, n_operators=len(sg.operators or []), operators=ops,
                                  inputs=[int(i) for i in sg.inputs], outputs=[int(i) for i in sg.outputs]))
+  out["signatures"] = [[int(sig.subgraphIndex), [int(i.tensorIndex) for i in (sig.inputs or [])],
+                        [int(i.tensorIndex) for i in (sig.outputs or [])]] for sig in (model.signatureDefs or [])]
   return out
 
 
-def run(model_name, recipe_name, rcp):
+def run(model_name, recipe_name, rcp, qsvs=None):
   path = os.path.join(REF, "tests/models", model_name + ".tflite")
   model = to_bags(fb.read_model(open(path, "rb").read()))
   rm = recipe_manager.RecipeManager()
   rm.load_quantization_recipe(rcp)
-  if rm.need_calibration():
+  if rm.need_calibration() and qsvs is None:
     return None
   orig = fbu.get_tensor_data
   # blockwise scales pass through `.astype(ml_dtypes.bfloat16)`: hand weights over as the
@@ -137,7 +144,7 @@ def run(model_name, recipe_name, rcp):
   try:
     with warnings.catch_warnings():
       warnings.simplefilter("ignore")
-      params = params_generator.ParamsGenerator(model).generate_quantization_parameters(rm)
+      params = params_generator.ParamsGenerator(model).generate_quantization_parameters(rm, qsvs)
       mod = model_modifier.ModelModifier(model)
       mod._serialize_small_model = lambda m: m
       mod._serialize_model = lambda m, packed, serialize_to_path=None: m
@@ -188,7 +195,7 @@ def main():
     json.dump(dict(generator="tests/golden/gen/make_model_golden.py",
                    reference_version=open("/root/reference/VERSION").read().strip(),
                    numpy=np.__version__, cases=json.loads(json.dumps(cases, default=str))),
-              f, indent=1, sort_keys=True)
+              f, separators=(",", ":"), sort_keys=True)
   print("wrote", len(cases), "cases")
 
 
@@ -262,11 +269,12 @@ def srq_cases():
                               parameters=_params_summary(link.parameters)))
         rec[tname] = links
       out[key] = dict(model=name, recipe=rcp, qsvs={k: {"min": float(v["min"].ravel()[0]), "max": float(v["max"].ravel()[0])}
-                                                     for k, v in qsvs.items()}, params=rec)
+                                                     for k, v in qsvs.items()}, params=rec,
+                      result=run(name, rname, rcp, qsvs))
       print("ok  ", key)
   with open(os.path.join(GOLDEN, "ref_srq_params.json"), "w") as f:
     json.dump(dict(generator="tests/golden/gen/make_model_golden.py (srq_cases)", numpy=np.__version__,
-                   cases=json.loads(json.dumps(out, default=str))), f, indent=1, sort_keys=True)
+                   cases=json.loads(json.dumps(out, default=str))), f, separators=(",", ":"), sort_keys=True)
 
 
 if __name__ == "__main__" and "--srq" in sys.argv:

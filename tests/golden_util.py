@@ -71,6 +71,10 @@ def describe_model(model):
                                  block_size=int(q.details.blockSize))
         rec["quantization"] = qr
       tensors.append(rec)
-    out["subgraphs"].append(dict(tensors=tensors, n_operators=len(sg.operators or []),
+    ops = [[int(model.operatorCodes[op.opcodeIndex].builtinCode), [int(i) for i in op.inputs],
+            [int(i) for i in op.outputs]] for op in (sg.operators or [])]
+    out["subgraphs"].append(dict(tensors=tensors, n_operators=len(sg.operators or []), operators=ops,
                                  inputs=[int(i) for i in sg.inputs], outputs=[int(i) for i in sg.outputs]))
+  out["signatures"] = [[int(sig.subgraphIndex), [int(i.tensorIndex) for i in (sig.inputs or [])],
+                        [int(i.tensorIndex) for i in (sig.outputs or [])]] for sig in (model.signatureDefs or [])]
   return out

@@ -228,6 +228,6 @@ def test_hadamard_recipe_materializes_rotation_instruction(m):
   wp = params["w"].consumers[0]
   assert wp.transformations == [q.QuantTransformation.QUANTIZE_TENSOR]
   assert wp.parameters.hadamard.hadamard_size == 64
-  with pytest.raises(NotImplementedError, match="graph rewriting"):
+  with pytest.raises(NotImplementedError, match="INSERT_DECOMPOSED_HADAMARD_ROTATION rewrites the graph"):
     m.quantizer.apply_quantize_tensor_transformations(model, params)
 
