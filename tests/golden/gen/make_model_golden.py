@@ -199,7 +199,7 @@ def main():
   print("wrote", len(cases), "cases")
 
 
-if __name__ == "__main__" and "--srq" not in sys.argv:
+if __name__ == "__main__" and "--srq" not in sys.argv and "--insts" not in sys.argv:
   main()
 
 
@@ -279,3 +279,63 @@ def srq_cases():
 
 if __name__ == "__main__" and "--srq" in sys.argv:
   srq_cases()
+
+
+# ---------------------------------------------------------------------------------------
+# instruction generator known answers: synthetic per-tensor parameters -> instruction lists
+# ---------------------------------------------------------------------------------------
+def instruction_cases():
+  import itertools
+  from ai_edge_quantizer import transformation_instruction_generator as tig
+  T = qtyping.QuantTransformation
+  path = os.path.join(REF, "tests/models", "branching_conv_fc.tflite")
+  model = to_bags(fb.read_model(open(path, "rb").read()))
+  gen = tig.TransformationInstructionsGenerator()
+  gen.flatbuffer_model = model
+  gen._create_tensor_name_to_graph_info_map()
+  # a tensor with several consumers
+  sg = model.subgraphs[0]
+  info = max(gen._tensor_name_to_graph_info.items(), key=lambda kv: len(kv[1].consumers))
+  name, gi = info
+  consumers = list(gi.consumers)
+
+  def qp(k):
+    return qtyping.UniformQuantParams(num_bits=8, quantized_dimension=None,
+                                      scale=np.array([0.1 * (k + 1)], np.float32),
+                                      zero_point=np.array([k], np.int64), symmetric=False)
+  P = [qp(0), qp(1)]
+  consumer_options = [([T.ADD_QUANTIZE], 0), ([T.ADD_QUANTIZE], 1), ([T.NO_QUANTIZE], None),
+                      ([T.ADD_QUANTIZE, T.ADD_DEQUANTIZE], 0)]
+  producer_options = [None, ([T.ADD_DEQUANTIZE], 0), ([T.NO_QUANTIZE], None), ([T.ADD_DEQUANTIZE], 1)]
+  out = []
+  for prod in producer_options:
+    for combo in itertools.product(range(len(consumer_options)), repeat=len(consumers)):
+      def link(op_id, opt):
+        tr, k = opt
+        return qtyping.OpToTensorParams(subgraph_op_id=op_id, transformations=list(tr),
+                                        parameters=None if k is None else P[k])
+      param = qtyping.TensorTransformationParams(
+          tensor_name=name,
+          producer=None if prod is None else link(gi.producer, prod),
+          consumers=[link(c, consumer_options[i]) for c, i in zip(consumers, combo)])
+      # graph info lists are mutated by the generator: rebuild per case
+      gen._create_tensor_name_to_graph_info_map()
+      rec = dict(producer=None if prod is None else [[t.name for t in prod[0]], prod[1]],
+                 consumers=[[[t.name for t in consumer_options[i][0]], consumer_options[i][1]] for i in combo])
+      try:
+        res = gen._quant_params_to_transformation_insts(param)
+        rec["instructions"] = [[i.transformation.name, int(i.tensor_id), int(i.producer), [int(c) for c in i.consumers],
+                                None if i.parameters is None else int(np.asarray(i.parameters.zero_point).ravel()[0])]
+                               for i in res.instructions]
+      except Exception as e:
+        rec["error"] = type(e).__name__
+      out.append(rec)
+  with open(os.path.join(GOLDEN, "ref_instruction_cases.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_model_golden.py (instruction_cases)",
+                   model="branching_conv_fc", tensor=name, op_ids=[int(c) for c in consumers],
+                   producer_op=int(gi.producer), cases=out), f, separators=(",", ":"), sort_keys=True)
+  print("instruction cases:", len(out), "tensor", name, consumers, gi.producer)
+
+
+if __name__ == "__main__" and "--insts" in sys.argv:
+  instruction_cases()

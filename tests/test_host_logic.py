@@ -267,3 +267,44 @@ def test_config_check_policy_equals_reference_acceptance_set():
                                compute_precision=P.INTEGER), pol)
   with pytest.raises(ValueError, match="No policy was specified at all"):
     default_policy.check_if_valid_op_config(q.TFLOperationName.FULLY_CONNECTED, q.OpQuantizationConfig(), None)
+
+
+def test_transformation_instructions_match_reference_known_answers():
+  """256 synthetic (producer, consumers) parameter combinations for one tensor of
+  branching_conv_fc: horizontal grouping, DQ.Q cancellation, requantization, DQ kept for float
+  consumers, validity errors - all as the real reference's generator answers
+  (tests/golden/ref_instruction_cases.json)."""
+  import json as _json
+  import os as _os
+  from mi355q import transformation_instruction_generator as tig
+  here = _os.path.dirname(_os.path.abspath(__file__))
+  ref = _json.load(open(_os.path.join(here, "golden", "ref_instruction_cases.json")))
+  model = tfl_flatbuffer_utils.read_model(_os.path.join(here, "golden", "models", ref["model"] + ".tflite"))
+  T = q.QuantTransformation
+
+  def qp(k):
+    return q.UniformQuantParams(num_bits=8, quantized_dimension=None, scale=np.array([0.1 * (k + 1)], np.float32),
+                                zero_point=np.array([k], np.int64), symmetric=False)
+  P = [qp(0), qp(1)]
+
+  def link(op_id, spec):
+    names, k = spec
+    return q.OpToTensorParams(subgraph_op_id=op_id, transformations=[T[n] for n in names],
+                              parameters=None if k is None else P[k])
+  n_err = 0
+  for case in ref["cases"]:
+    gen = tig.TransformationInstructionsGenerator(model)       # fresh graph info (lists are consumed)
+    param = q.TensorTransformationParams(
+        tensor_name=ref["tensor"],
+        producer=None if case["producer"] is None else link(ref["producer_op"], case["producer"]),
+        consumers=[link(op, spec) for op, spec in zip(ref["op_ids"], case["consumers"])])
+    if "error" in case:
+      n_err += 1
+      with pytest.raises(ValueError):
+        gen.tensor_instructions(param)
+      continue
+    got = [[i.transformation.name, i.tensor_id, i.producer, list(i.consumers),
+            None if i.parameters is None else int(np.asarray(i.parameters.zero_point).ravel()[0])]
+           for i in gen.tensor_instructions(param).instructions]
+    assert got == case["instructions"], case
+  assert 0 < n_err < len(ref["cases"])
