@@ -50,13 +50,34 @@ def fused_weight_layout(tensor_content: np.ndarray, granularity, quantized_dim):
 
 def fused_symmetric_requant(tensor_content: np.ndarray, layout, num_bits: int,
                             clip: Optional[np.ndarray] = None):
-  """Runs mi355q_requant_sym_f32; returns (scale f32 [n_scales], q int8 like tensor)."""
+  """Runs mi355q_requant_sym_f32; returns (scale f32 [n_scales], q int8 like tensor).
+
+  For sub-byte widths the same launch also emits the packed bytes the QUANTIZE_TENSOR
+  transformation stores (ref transformation_utils.py:293-353); they ride along on the returned
+  array's `packed` attribute so the model writer does not have to upload q again to pack it.
+  """
   rows, cols, block = layout
   rt.require_gpu()
   x = rt.to_device(tensor_content.reshape(rows, cols))
   c = None if clip is None else rt.to_device(np.ascontiguousarray(clip, np.float32).reshape(-1))
-  r = ops.requant_sym(x, block, num_bits, clip=c, want_q=True)
-  return rt.to_numpy(r["scale"]).reshape(-1), rt.to_numpy(r["q"]).reshape(tensor_content.shape)
+  # the vectorized kernels pack; the generic fallback (odd widths) does not (mi355q.h)
+  sub_byte = (num_bits in (2, 4) and cols % 4 == 0
+              and (block in (32, 64, 128, 256) or (block == 0 and cols <= 16384)))
+  r = ops.requant_sym(x, block, num_bits, clip=c, want_q=True, want_packed=sub_byte)
+  q = rt.to_numpy(r["q"]).reshape(tensor_content.shape)
+  if sub_byte:
+    q = q.view(PackedCarrier)
+    q.packed = rt.to_numpy(r["packed"])
+  return rt.to_numpy(r["scale"]).reshape(-1), q
+
+
+class PackedCarrier(np.ndarray):
+  """int8 quantized values (a plain ndarray in every respect) + the packed bytes of the same
+  values as produced by the kernel that quantized them. Views / copies drop the attribute."""
+  packed: Optional[np.ndarray] = None
+
+  def __array_finalize__(self, obj):
+    self.packed = None
 
 
 def scale_shape_for(tensor_content: np.ndarray, granularity, quantized_dim) -> tuple[int, ...]:

@@ -86,7 +86,8 @@ def quantize_tensor(ti: transformation_utils.TransformationInput) -> qtyping.Tra
         logging.warning("Quantized data for tensor %s is overriding other previously quantized"
                         " data in buffer %s.", tensor.name, buffer_id)
       ti.buffer_origin[buffer_id] = p
-      ti.model.buffers[buffer_id].data = transformation_utils.pack_data(
+      ready = getattr(p.quantized_data, "packed", None)    # packed by the quantizing launch
+      ti.model.buffers[buffer_id].data = ready if ready is not None else transformation_utils.pack_data(
           p.num_bits, np.ravel(np.asarray(p.quantized_data)).view(np.uint8))
   if isinstance(p, qtyping.UniformQuantParams):
     tensor.quantization = (_perform_channelwise_quantization(ti) if p.block_size == 0
