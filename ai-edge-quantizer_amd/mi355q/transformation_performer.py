@@ -33,8 +33,9 @@ class TransformationPerformer:
         _T.DUPLICATE_BUFFER: graph_edits.duplicate_buffer,
         _T.DUPLICATE_TENSOR: graph_edits.duplicate_tensor,
         _T.EMULATED_SUBCHANNEL: _unsupported("EMULATED_SUBCHANNEL (deprecated in the reference)"),
-        _T.INSERT_HADAMARD_ROTATION: _unsupported("INSERT_HADAMARD_ROTATION"),
-        _T.INSERT_DECOMPOSED_HADAMARD_ROTATION: _unsupported("INSERT_DECOMPOSED_HADAMARD_ROTATION"),
+        # the custom-op form stores its options as a FlexBuffer (third-party encoder, unpinned)
+        _T.INSERT_HADAMARD_ROTATION: _unsupported("INSERT_HADAMARD_ROTATION (custom op with FlexBuffer options)"),
+        _T.INSERT_DECOMPOSED_HADAMARD_ROTATION: graph_edits.insert_decomposed_hadamard_rotation,
         _T.INSERT_MULTIPLY: _unsupported("INSERT_MULTIPLY"),
     }
     self._current_index: list[list[int]] = []    # [subgraph][float op index] -> index now

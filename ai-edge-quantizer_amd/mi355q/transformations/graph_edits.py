@@ -6,6 +6,8 @@ from __future__ import annotations
 
 from typing import Any
 
+import numpy as np
+
 from .. import qtyping
 from ..utils import tfl_flatbuffer_utils
 from . import quantize_tensor
@@ -94,3 +96,85 @@ def duplicate_tensor(ti: _Input) -> qtyping.TransformationInfo:
         inputs[k] = new_id
         break
   return qtyping.TransformationInfo(op_id=0, num_ops_added=0, output_tensor_id=new_id)
+
+
+def _op_code_of(ti: _Input, op_index: int) -> int:
+  return ti.model.operatorCodes[ti.subgraph.operators[op_index].opcodeIndex].builtinCode
+
+
+def _sylvester_hadamard(size: int) -> np.ndarray:
+  """H_size / sqrt(size) (float64 until the caller casts), ref insert_decomposed_...py:57-79."""
+  if size <= 0 or size & (size - 1):
+    raise ValueError("Hadamard matrix size must be a power of 2. ")
+  h = base = np.array([[1, 1], [1, -1]])
+  n = 2
+  while n < size:
+    h = np.kron(h, base)
+    n *= 2
+  return h / np.sqrt(size)
+
+
+def insert_decomposed_hadamard_rotation(ti: _Input) -> qtyping.TransformationInfo:
+  """x -> RESHAPE(-1, h) -> FULLY_CONNECTED with H_h / sqrt(h) -> RESHAPE(x.shape), feeding the
+  FULLY_CONNECTED consumers (or everything after an EMBEDDING_LOOKUP producer) whose weights
+  were rotated by the same matrix (ref insert_decomposed_hadamard_rotation.py:82-265)."""
+  p = ti.quant_params
+  if not isinstance(p, qtyping.UniformQuantParams):
+    raise ValueError("Hadamard rotation supports uniform quantization only")
+  if p.hadamard is None:
+    raise ValueError("Hadamard rotation quantization params are not set but op insertion is"
+                     " requested.")
+  sg, model = ti.subgraph, ti.model
+  tensor = sg.tensors[ti.tensor_id]
+  if tensor.type != qtyping.TensorType.FLOAT32:
+    raise ValueError(f"The Hadamard rotation op supports float32 tensors only. Got {tensor.type}"
+                     " tensor.")
+  name = _raw_name(tensor)
+  h = int(p.hadamard.hadamard_size)
+  flat = [int(np.prod(tensor.shape)) // h, h]
+  i32, f32 = qtyping.TensorType.INT32, qtyping.TensorType.FLOAT32
+  pre_shape = transformation_utils.add_new_constant_tensor(
+      name + b"_prerotate_shape", np.array(flat, np.int32), i32, sg, model)
+  pre_out = transformation_utils.add_new_activation_tensor(name + b"_prerotate_reshaped", flat, f32, sg)
+  reshape_code = transformation_utils.add_op_code(qtyping.BuiltinOperator.RESHAPE, model.operatorCodes, "RESHAPE")
+  pre = qtyping.OperatorT(opcodeIndex=reshape_code, inputs=[ti.tensor_id, pre_shape], outputs=[pre_out])
+  matrix = transformation_utils.add_new_constant_tensor(
+      name + b"_hadamard_matrix", _sylvester_hadamard(h).astype(np.float32), f32, sg, model,
+      allow_tensor_sharing=True)
+  rotated = transformation_utils.add_new_activation_tensor(name + b"_rotated", flat, f32, sg)
+  fc_code = transformation_utils.add_op_code(qtyping.BuiltinOperator.FULLY_CONNECTED, model.operatorCodes,
+                                             "FULLY_CONNECTED")
+  fc = qtyping.OperatorT(opcodeIndex=fc_code, inputs=[pre_out, matrix], outputs=[rotated],
+                         builtinOptionsType=int(qtyping.BuiltinOptions.FullyConnectedOptions),
+                         builtinOptions=qtyping.FullyConnectedOptionsT(fusedActivationFunction=0))
+  post_code = transformation_utils.add_op_code(qtyping.BuiltinOperator.RESHAPE, model.operatorCodes, "RESHAPE")
+  post_shape = transformation_utils.add_new_constant_tensor(
+      name + b"_postrotate_shape", np.array(tensor.shape, np.int32), i32, sg, model)
+  post_out = transformation_utils.add_new_activation_tensor(name + b"_postrotate_reshaped", tensor.shape, f32, sg)
+  post = qtyping.OperatorT(opcodeIndex=post_code, inputs=[rotated, post_shape], outputs=[post_out])
+
+  after_embedding = (ti.producer != -1
+                     and _op_code_of(ti, ti.producer) == qtyping.BuiltinOperator.EMBEDDING_LOOKUP)
+  if after_embedding:
+    for consumer in ti.consumers:
+      if consumer == -1:
+        continue
+      inputs = sg.operators[consumer].inputs
+      for k, tid in enumerate(inputs):
+        if tid == ti.tensor_id:
+          inputs[k] = post_out
+    for k, tid in enumerate(sg.outputs):
+      if tid == ti.tensor_id:
+        sg.outputs[k] = post_out
+  else:
+    updated = False
+    for consumer in ti.consumers:
+      if _op_code_of(ti, consumer) == qtyping.BuiltinOperator.FULLY_CONNECTED:
+        sg.operators[consumer].inputs[0] = post_out
+        updated = True
+    if not updated:
+      raise ValueError("The Hadamard rotation op supports embedding lookup and fully connected"
+                       " ops only, but no such ops were found.")
+  at = max(ti.producer + 1, min(ti.consumers))
+  sg.operators[at:at] = [pre, fc, post]
+  return qtyping.TransformationInfo(op_id=at, num_ops_added=3, output_tensor_id=post_out)

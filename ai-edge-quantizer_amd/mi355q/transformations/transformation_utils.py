@@ -75,16 +75,31 @@ def add_new_constant_buffer(data: np.ndarray, model: Any) -> int:
 
 def add_new_constant_tensor(tensor_name: bytes, data: np.ndarray, tensor_type, subgraph: Any,
                             model: Any, tensor_shape=None, force_duplicate_buffer: bool = False,
-                            quantization=None) -> int:
+                            quantization=None, allow_tensor_sharing: bool = False) -> int:
   """Appends a constant tensor to the subgraph (its buffer is shared with an existing one of
-  equal content unless `force_duplicate_buffer`); returns the tensor id (ref :167-247)."""
+  equal content unless `force_duplicate_buffer`); returns the tensor id. With
+  `allow_tensor_sharing` an existing tensor with the same buffer, shape, type and
+  quantized-or-not state is returned instead (ref :167-247)."""
+  buffer_id = get_constant_buffer(data, model, force_duplicate_buffer)
+  shape = list(data.shape) if tensor_shape is None else list(tensor_shape)
+  lookup = getattr(subgraph, "_tensor_lookup", None)
+  if allow_tensor_sharing and not force_duplicate_buffer:
+    if lookup is None:
+      lookup = {(t.buffer, tuple(t.shape or ()), int(t.type), t.quantization is not None): i
+                for i, t in enumerate(subgraph.tensors)}
+      subgraph._tensor_lookup = lookup
+    hit = lookup.get((buffer_id, tuple(shape), int(tensor_type), quantization is not None))
+    if hit is not None:
+      return hit
   t = qtyping.TensorT()
-  t.shape = list(data.shape) if tensor_shape is None else list(tensor_shape)
-  t.buffer = get_constant_buffer(data, model, force_duplicate_buffer)
+  t.shape = shape
+  t.buffer = buffer_id
   t.type = tensor_type
   t.name = tensor_name
   t.quantization = quantization
   subgraph.tensors.append(t)
+  if lookup is not None:
+    lookup[(buffer_id, tuple(shape), int(tensor_type), quantization is not None)] = len(subgraph.tensors) - 1
   return len(subgraph.tensors) - 1
 
 

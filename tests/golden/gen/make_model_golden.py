@@ -95,11 +95,18 @@ def sha(b) -> str:
   return hashlib.sha256(bytes(b)).hexdigest()
 
 
-def describe(model):
-  out = dict(n_buffers=len(model.buffers), subgraphs=[],
-             buffers=[None if b.data is None else
-                      dict(nbytes=int(np.asarray(b.data).nbytes), sha256=sha(np.ravel(np.asarray(b.data)).view(np.uint8)))
-                      for b in model.buffers])
+def describe(model, raw=False):
+  import base64
+
+  def buf(b):
+    if b.data is None:
+      return None
+    flat = np.ravel(np.asarray(b.data)).view(np.uint8)
+    rec = dict(nbytes=int(flat.nbytes), sha256=sha(flat))
+    if raw and flat.nbytes <= 65536:      # rotated weights are compared with a tolerance
+      rec["b64"] = base64.b64encode(flat.tobytes()).decode()
+    return rec
+  out = dict(n_buffers=len(model.buffers), subgraphs=[], buffers=[buf(b) for b in model.buffers])
   for sg in model.subgraphs:
     tensors = []
     for t in sg.tensors:
@@ -151,7 +158,15 @@ def run(model_name, recipe_name, rcp, qsvs=None):
       quantized = mod.modify_model(params)
   finally:
     fbu.get_tensor_data = orig
-  return describe(quantized)
+  return describe(quantized, raw="hadamard" in recipe_name)
+
+
+HADAMARD_RECIPES = {
+    "dynamic_wi4_afp32_hadamard": json.load(open(os.path.join(REF, "recipes/dynamic_wi4_afp32_hadamard_recipe.json"))),
+    "dynamic_wi8_afp32_hadamard": json.load(open(os.path.join(REF, "recipes/dynamic_wi8_afp32_hadamard_recipe.json"))),
+}
+HADAMARD_MODELS = ["single_fc", "single_fc_bias", "embedding_lookup", "weight_sharing_fcs", "conv_fc_mnist",
+                   "branching_conv_fc", "constant_tensor_and_buffer_only_sharing_weight_fcs"]
 
 
 def policy_table():
@@ -190,6 +205,15 @@ def main():
       except Exception as e:  # the reference itself rejects this combination
         cases[key] = dict(model=name, recipe_name=rname, recipe=rcp, error=type(e).__name__,
                           message=str(e)[:300])
+        print("err ", key, type(e).__name__, str(e)[:120])
+  for name in HADAMARD_MODELS:
+    for rname, rcp in HADAMARD_RECIPES.items():
+      key = f"{name}/{rname}"
+      try:
+        cases[key] = dict(model=name, recipe_name=rname, recipe=rcp, result=run(name, rname, rcp))
+        print("ok  ", key)
+      except Exception as e:
+        cases[key] = dict(model=name, recipe_name=rname, recipe=rcp, error=type(e).__name__, message=str(e)[:300])
         print("err ", key, type(e).__name__, str(e)[:120])
   with open(os.path.join(GOLDEN, "ref_model_cases.json"), "w") as f:
     json.dump(dict(generator="tests/golden/gen/make_model_golden.py",

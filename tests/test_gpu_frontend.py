@@ -228,6 +228,20 @@ def test_hadamard_recipe_materializes_rotation_instruction(m):
   wp = params["w"].consumers[0]
   assert wp.transformations == [q.QuantTransformation.QUANTIZE_TENSOR]
   assert wp.parameters.hadamard.hadamard_size == 64
-  with pytest.raises(NotImplementedError, match="INSERT_DECOMPOSED_HADAMARD_ROTATION rewrites the graph"):
-    m.quantizer.apply_quantize_tensor_transformations(model, params)
+  n_ops = len(sg.operators)
+  m.quantizer.apply_quantize_tensor_transformations(model, params)
+  assert len(sg.operators) == n_ops + 3              # RESHAPE -> FC(H / sqrt(h)) -> RESHAPE in front of the FC
+  codes = [model.operatorCodes[op.opcodeIndex].builtinCode for op in sg.operators]
+  B = q.BuiltinOperator
+  assert codes == [B.RESHAPE, B.FULLY_CONNECTED, B.RESHAPE, B.FULLY_CONNECTED]
+  hm = sg.tensors[sg.operators[1].inputs[1]]
+  H = np.asarray(model.buffers[hm.buffer].data).view(np.float32).reshape(64, 64)
+  assert np.allclose(H @ H.T, np.eye(64), atol=1e-6) and sg.operators[3].inputs[0] == sg.operators[2].outputs[0]
+  # the custom-op form needs FlexBuffer-encoded options (third-party encoder): refused loudly
+  rm2 = m.rm.RecipeManager()
+  rm2.load_quantization_recipe(m.recipe.dynamic_wi8_afp32(algorithm_key="HADAMARD_ROTATION"))
+  model2, _ = build_fc_model(m, w, bias)
+  params2 = params_generator.ParamsGenerator(model2).generate_quantization_parameters(rm2)
+  with pytest.raises(NotImplementedError, match="INSERT_HADAMARD_ROTATION"):
+    m.quantizer.apply_quantize_tensor_transformations(model2, params2)
 
