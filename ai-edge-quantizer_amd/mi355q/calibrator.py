@@ -1,0 +1,147 @@
+"""Calibration driver: per-sample tensor contents -> model QSVs (ref: calibrator.py:191-582).
+
+The reference obtains every intermediate tensor of a sample by running the float model in the
+LiteRT interpreter with `preserve_all_tensors` (a third-party runtime that is absent here) and
+then walks the graph calling the registered calibration functions. This class is that walk:
+the per-sample *tensor name -> content* map comes from the caller (an interpreter the caller
+owns, recorded activations, or synthetic tensors) either directly as the dataset elements or
+through a `tensor_provider(signature_key, sample) -> map` callback. Statistics run on the GPU
+through the registered calibration functions (`min_max_calibrate`, `gptq.calibrate`).
+"""
+from __future__ import annotations
+
+import copy
+import json
+from typing import Any, Callable, Iterable, Mapping, Optional
+
+import numpy as np
+
+from . import algorithm_manager
+from . import default_policy
+from . import qtyping
+from . import recipe_manager
+from .utils import qsv_utils
+from .utils import tfl_flatbuffer_utils
+
+_MISSING = object()
+TensorProvider = Callable[[Optional[str], Any], Mapping[str, np.ndarray]]
+
+
+class _QsvEncoder(json.JSONEncoder):
+  def default(self, o):
+    if isinstance(o, np.ndarray):
+      return o.tolist()
+    if isinstance(o, np.generic):
+      return o.item()
+    return super().default(o)
+
+
+class Calibrator:
+  def __init__(self, float_tflite: Any, tensor_provider: Optional[TensorProvider] = None,
+               qsv_update_func: Any = _MISSING):
+    self._flatbuffer_model = (float_tflite if hasattr(float_tflite, "subgraphs")
+                              else tfl_flatbuffer_utils.read_model(float_tflite))
+    self._tensor_provider = tensor_provider
+    self._is_custom_qsv_update_func = qsv_update_func is not _MISSING
+    self._qsv_update_func = (qsv_update_func if self._is_custom_qsv_update_func
+                             else qsv_utils.moving_average_update)
+    self._tensor_content_map: dict[str, Any] = {}
+    self._model_qsvs: dict[str, qtyping.QSV] = {}
+    self._metadata: dict[str, Any] = {"num_samples_calibrated": 0}
+
+  # ---- signatures ---------------------------------------------------------------------------
+  def get_signature_list(self) -> list[str]:
+    return [s.signatureKey.decode("utf-8") if isinstance(s.signatureKey, (bytes, bytearray))
+            else s.signatureKey for s in (self._flatbuffer_model.signatureDefs or [])]
+
+  def _main_subgraph(self, signature_key: Optional[str]) -> int:
+    sigs = self._flatbuffer_model.signatureDefs or []
+    if signature_key is None:
+      if len(sigs) > 1:
+        raise ValueError("signature_key is required for a model with several signatures")
+      return sigs[0].subgraphIndex if sigs else 0
+    for s in sigs:
+      key = s.signatureKey.decode("utf-8") if isinstance(s.signatureKey, (bytes, bytearray)) else s.signatureKey
+      if key == signature_key:
+        return s.subgraphIndex
+    raise ValueError(f"signature {signature_key!r} not found in the model")
+
+  # ---- one sample (ref :501-582) ---------------------------------------------------------------
+  def _update_qsvs(self, op_qsvs: dict[str, qtyping.QSV], ignore: set[str], update_func) -> set[str]:
+    updated = set()
+    for name, qsv in op_qsvs.items():
+      if name in ignore:
+        continue
+      if name not in self._model_qsvs:
+        self._model_qsvs[name] = qsv
+      else:
+        self._model_qsvs[name] = update_func(self._model_qsvs[name], qsv)
+      updated.add(name)
+    return updated
+
+  def _calibrate_step(self, signature_key: Optional[str], data: Any,
+                      model_recipe_manager: recipe_manager.RecipeManager) -> None:
+    contents = self._tensor_provider(signature_key, data) if self._tensor_provider else data
+    if not isinstance(contents, Mapping):
+      raise TypeError("a calibration sample must be a {tensor name: ndarray} map (or pass a"
+                      " tensor_provider that turns samples into one)")
+    self._tensor_content_map.update(contents)
+    codes = self._flatbuffer_model.operatorCodes
+    updated: set[str] = set()
+    todo = [self._main_subgraph(signature_key)]
+    while todo:
+      sg = self._flatbuffer_model.subgraphs[todo.pop()]
+      graph_info = qtyping.GraphInfo(sg.tensors, self._flatbuffer_model.buffers)
+      ops = list(sg.operators) + tfl_flatbuffer_utils.get_subgraph_input_output_operators(sg)
+      for op in ops:
+        if isinstance(op, qtyping.IOOperator):
+          op_key = op.op_key
+        else:
+          op_key = tfl_flatbuffer_utils.TFL_OP_CODE_TO_NAME.get(codes[op.opcodeIndex].builtinCode)
+          if op_key is None:
+            continue
+        scope = tfl_flatbuffer_utils.get_op_scope(op, sg.tensors)
+        alg, _ = model_recipe_manager.get_quantization_configs(op_key, scope)
+        if alg == algorithm_manager.AlgorithmName.NO_QUANTIZE:
+          continue
+        if default_policy.is_non_quantizable_composite_op(op):
+          continue
+        calibrate = algorithm_manager.get_quantization_func(alg, op_key, qtyping.QuantizeMode.CALIBRATE)
+        op_qsvs = calibrate(op, graph_info, self._tensor_content_map)
+        update = (self._qsv_update_func if self._is_custom_qsv_update_func
+                  else algorithm_manager.get_update_qsv_func(alg, op_key))
+        updated |= self._update_qsvs(op_qsvs, updated, update)
+        todo.extend(tfl_flatbuffer_utils.get_op_side_effect_subgraphs(op))
+
+  # ---- public API (ref :312-392) -----------------------------------------------------------------
+  def calibrate(self, calibration_dataset: Mapping[Optional[str], Iterable[Any]],
+                model_recipe_manager: recipe_manager.RecipeManager, cache_output: bool = False) -> None:
+    del cache_output   # model outputs are the caller's: nothing is executed here
+    for signature_key, dataset in calibration_dataset.items():
+      for data in dataset:
+        self._metadata["num_samples_calibrated"] += 1
+        self._calibrate_step(signature_key, data, model_recipe_manager)
+
+  def get_model_qsvs(self) -> dict[str, qtyping.QSV]:
+    return self._model_qsvs
+
+  def reset_model_qsvs(self) -> None:
+    self._model_qsvs = {}
+    self._metadata = {"num_samples_calibrated": 0}
+
+  def load_model_qsvs(self, model_qsvs: Any) -> None:
+    if isinstance(model_qsvs, str):
+      with open(model_qsvs, "r", encoding="utf-8") as f:
+        blob = json.load(f)
+      raw = blob.get("model_qsvs", blob)
+      self._model_qsvs = {name: {k: np.asarray(v, np.float32 if k in ("min", "max") else None)
+                                 for k, v in qsv.items()} for name, qsv in raw.items()}
+      self._metadata = dict(blob.get("metadata", {}))
+      self._metadata["num_samples_calibrated"] = self._metadata.get("num_samples_calibrated", 0)
+    else:
+      self._model_qsvs = copy.deepcopy(model_qsvs)
+
+  def save_calibration_result(self, file_path: str, extra_metadata: Optional[dict[str, Any]] = None) -> None:
+    with open(file_path, "w", encoding="utf-8") as f:
+      json.dump({"model_qsvs": self._model_qsvs, "metadata": {**self._metadata, **(extra_metadata or {})}},
+                f, cls=_QsvEncoder)

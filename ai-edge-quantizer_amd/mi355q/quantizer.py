@@ -14,6 +14,7 @@ import os
 import pathlib
 from typing import Any, Optional, Union
 
+from . import calibrator
 from . import model_modifier
 from . import params_generator
 from . import qtyping
@@ -82,6 +83,19 @@ class Quantizer:
 
   def need_calibration(self) -> bool:
     return self._recipe_manager.need_calibration()
+
+  def calibrate(self, calibration_data: dict, previous_calibration_result: Optional[dict] = None,
+                tensor_provider: Optional[Any] = None) -> dict[str, qtyping.QSV]:
+    """Model QSVs from per-sample tensor contents (ref :369-413). The reference runs the float
+    model in the LiteRT interpreter to obtain those tensors; here each sample is the
+    {tensor name: ndarray} map itself, or `tensor_provider(signature_key, sample)` returns it."""
+    if not self.need_calibration():
+      return {}
+    calib = calibrator.Calibrator(self.float_model, tensor_provider=tensor_provider)
+    if previous_calibration_result is not None:
+      calib.load_model_qsvs(previous_calibration_result)
+    calib.calibrate(calibration_data, self._recipe_manager)
+    return calib.get_model_qsvs()
 
   def quantize(self, calibration_result: Optional[dict[str, qtyping.QSV]] = None,
                serialize_to_path: Optional[Path] = None) -> QuantizationResult:

@@ -308,3 +308,30 @@ def test_transformation_instructions_match_reference_known_answers():
            for i in gen.tensor_instructions(param).instructions]
     assert got == case["instructions"], case
   assert 0 < n_err < len(ref["cases"])
+
+
+def test_calibrator_bookkeeping_without_gpu(tmp_path):
+  """Signature lookup, sample typing, QSV save / load - the parts of the calibrator that do
+  not touch the GPU."""
+  import os as _os
+  from mi355q import calibrator
+  here = _os.path.dirname(_os.path.abspath(__file__))
+  c = calibrator.Calibrator(_os.path.join(here, "golden", "models", "two_signatures.tflite"))
+  assert sorted(c.get_signature_list()) == ["add", "multiply"]
+  with pytest.raises(ValueError, match="signature_key is required"):
+    c._main_subgraph(None)
+  with pytest.raises(ValueError, match="not found"):
+    c._main_subgraph("nope")
+  rm = recipe_manager.RecipeManager()
+  rm.load_quantization_recipe(recipe.static_wi8_ai8())
+  with pytest.raises(TypeError, match="tensor name"):
+    c.calibrate({"add": [np.zeros(3, np.float32)]}, rm)
+  c.load_model_qsvs({"t": {"min": np.array([[-1.0]], np.float32), "max": np.array([[2.0]], np.float32)}})
+  p = str(tmp_path / "qsv.json")
+  c.save_calibration_result(p, {"note": "x"})
+  d = calibrator.Calibrator(_os.path.join(here, "golden", "models", "two_signatures.tflite"))
+  d.load_model_qsvs(p)
+  assert d.get_model_qsvs()["t"]["max"].dtype == np.float32 and d.get_model_qsvs()["t"]["max"][0, 0] == 2.0
+  assert d._metadata["note"] == "x" and d._metadata["num_samples_calibrated"] == 1   # counted before the step ran, as in the reference
+  d.reset_model_qsvs()
+  assert d.get_model_qsvs() == {}
