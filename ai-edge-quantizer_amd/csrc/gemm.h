@@ -18,6 +18,7 @@ struct GemmArgs {
   int lower_only;      // write only j <= i (square C), skip tiles above the diagonal
   int k_mode;          // 0: all k; 1: A(i,k) == 0 for k > i (lower-triangular A): k < i0+BM;
                        // 2: A(i,k) == 0 for k < i and B(k,j) == 0 for k < j: k >= max(i0, j0)
+                       // 3: B(k,j) == 0 for k < j (lower-triangular B): k >= j0
 };
 
 // Number of K slices launch_gemm would use for this shape (1 = no split) and the

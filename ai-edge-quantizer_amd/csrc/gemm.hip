@@ -35,6 +35,8 @@ struct Tile<float> {
   static constexpr int BM = 128;  // block tile edge = 2 waves x TM x MF
   static constexpr int BK = 16;   // k per LDS stage
   static constexpr int VEC = 4;   // elements per 16-byte load
+  static constexpr bool DBUF = true;  // two LDS buffers (one barrier per K step)
+  using Elem = float;
   using Acc = __attribute__((ext_vector_type(16))) float;
   using Vec = float4;
 };
@@ -42,12 +44,30 @@ template <>
 struct Tile<double> {
   static constexpr int MF = 16;
   static constexpr int KF = 4;
-  // 2x2 tiles per wave: a 4x4 arrangement (128x128 block) needs 128 accumulator + 188
-  // other VGPRs -> 1 wave/SIMD, and measured 2.6x slower than this shape on MI355X.
   static constexpr int TM = 2;
   static constexpr int BM = 64;   // 2 waves x 2 tiles x 16
   static constexpr int BK = 16;
   static constexpr int VEC = 2;
+  static constexpr bool DBUF = true;
+  using Elem = double;
+  using Acc = __attribute__((ext_vector_type(4))) double;
+  using Vec = double2;
+};
+// Large FP64 shapes: at 64x64 the kernel needs 16 B / cycle / CU from L2 (9.8 TB/s chip-wide)
+// and saturates near 40 TFLOP/s; a 128x128 block halves that. Each wave owns 4x4 MFMA tiles
+// (128 accumulator registers, kept in AccVGPRs); one LDS buffer (33 KB) is refilled from
+// registers behind a second barrier - a K step is 64 MFMAs = 4096 cycles per wave, so the two
+// barriers cost ~2 %, and fragments are double-buffered in registers by hand so the single
+// resident wave per SIMD never waits on ds_read.
+struct TileF64Big {
+  static constexpr int MF = 16;
+  static constexpr int KF = 4;
+  static constexpr int TM = 4;
+  static constexpr int BM = 128;
+  static constexpr int BK = 16;
+  static constexpr int VEC = 2;
+  static constexpr bool DBUF = false;
+  using Elem = double;
   using Acc = __attribute__((ext_vector_type(4))) double;
   using Vec = double2;
 };
@@ -71,35 +91,36 @@ __device__ __forceinline__ double comp(const double2& v, int c) { return c == 0 
 // How one operand tile (BM x BK, "m" = the non-k index) is fetched.
 enum LoadMode { kGeneric = 0, kMFast = 1, kKFast = 2 };
 
-// Per-thread staging registers of one operand tile: 2 x 16 bytes.
-template <typename T>
+// Per-thread staging registers of one operand tile: NL x 16 bytes.
+template <typename TL>
 struct Stage {
-  typename Tile<T>::Vec v[2];
+  static constexpr int NL = TL::BM * TL::BK / TL::VEC / 256;
+  typename TL::Vec v[NL];
 };
 
 // Global -> registers. p(m, k) = base + m*s_m + k*s_k; the tile origin is (m0, k0).
-template <typename T>
-__device__ __forceinline__ void load_tile(Stage<T>& st, const T* __restrict__ base, long long s_m,
+template <typename TL>
+__device__ __forceinline__ void load_tile(Stage<TL>& st, const typename TL::Elem* __restrict__ base, long long s_m,
                                           long long s_k, int m0, int k0, int M, int K, int mode, int tid) {
-  using TL = Tile<T>;
-  constexpr int BM = TL::BM, VEC = TL::VEC, BK = TL::BK;
+  using T = typename TL::Elem;
+  constexpr int BM = TL::BM, VEC = TL::VEC, BK = TL::BK, NL = Stage<TL>::NL;
   using Vec = typename TL::Vec;
   const bool inside = m0 + BM <= M && k0 + BK <= K;
   if (mode == kMFast && inside) {
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < NL; ++l) {
       const int e = tid + 256 * l, mv = e % (BM / VEC), k = e / (BM / VEC);
       st.v[l] = *reinterpret_cast<const Vec*>(base + (m0 + mv * VEC) * s_m + static_cast<long long>(k0 + k) * s_k);
     }
   } else if (mode == kKFast && inside) {
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < NL; ++l) {
       const int e = tid + 256 * l, kv = e % (BK / VEC), m = e / (BK / VEC);
       st.v[l] = *reinterpret_cast<const Vec*>(base + static_cast<long long>(m0 + m) * s_m + (k0 + kv * VEC) * s_k);
     }
   } else {  // generic strides, ragged edges: scalar loads in the kMFast register layout
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < NL; ++l) {
       const int e = tid + 256 * l, mv = e % (BM / VEC), k = e / (BM / VEC);
       T tmp[VEC];
 #pragma unroll
@@ -114,39 +135,39 @@ __device__ __forceinline__ void load_tile(Stage<T>& st, const T* __restrict__ ba
 }
 
 // Registers -> LDS tile [BK][LD] (k-major).
-template <typename T, int LD>
-__device__ __forceinline__ void store_tile(const Stage<T>& st, T (*lds)[LD], int m0, int k0, int M, int K,
-                                           int mode, int tid) {
-  using TL = Tile<T>;
-  constexpr int BM = TL::BM, VEC = TL::VEC, BK = TL::BK;
+template <typename TL, int LD>
+__device__ __forceinline__ void store_tile(const Stage<TL>& st, typename TL::Elem (*lds)[LD], int m0, int k0,
+                                           int M, int K, int mode, int tid) {
+  constexpr int BM = TL::BM, VEC = TL::VEC, BK = TL::BK, NL = Stage<TL>::NL;
   using Vec = typename TL::Vec;
   const bool inside = m0 + BM <= M && k0 + BK <= K;
   if (mode == kKFast && inside) {
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < NL; ++l) {
       const int e = tid + 256 * l, kv = e % (BK / VEC), m = e / (BK / VEC);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) lds[kv * VEC + c][m] = comp(st.v[l], c);
     }
   } else {
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < NL; ++l) {
       const int e = tid + 256 * l, mv = e % (BM / VEC), k = e / (BM / VEC);
       *reinterpret_cast<Vec*>(&lds[k][mv * VEC]) = st.v[l];
     }
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g, int a_mode, int b_mode, int k_chunk,
-                                                   T* __restrict__ partial) {
-  using TL = Tile<T>;
+template <typename TL>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<typename TL::Elem> g, int a_mode, int b_mode,
+                                                   int k_chunk, typename TL::Elem* __restrict__ partial) {
+  using T = typename TL::Elem;
   constexpr int BM = TL::BM, MF = TL::MF, KF = TL::KF, TM = TL::TM, BK = TL::BK;
   constexpr int LD = BM + TL::VEC;  // keeps every row 16-byte aligned, breaks the power-of-2 stride
   constexpr int NREG = sizeof(typename TL::Acc) / sizeof(T);
-  static_assert(BM * BK / TL::VEC == 512, "two 16-byte loads per thread per operand tile");
-  __shared__ __attribute__((aligned(16))) T As[2][BK][LD];
-  __shared__ __attribute__((aligned(16))) T Bs[2][BK][LD];
+  constexpr int NBUF = TL::DBUF ? 2 : 1;
+  static_assert(BM * BK / TL::VEC % 256 == 0, "whole 16-byte loads per thread per operand tile");
+  __shared__ __attribute__((aligned(16))) T As[NBUF][BK][LD];
+  __shared__ __attribute__((aligned(16))) T Bs[NBUF][BK][LD];
 
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (g.lower_only && bj > bi) return;  // only tiles touching the lower triangle
@@ -166,46 +187,83 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g, int a_mode, in
   int k_begin = 0, k_end = g.K;
   if (g.k_mode == 1) k_end = min(g.K, i0 + BM);
   if (g.k_mode == 2) k_begin = (max(i0, j0) / BK) * BK;  // i0, j0 are multiples of BM >= BK
+  if (g.k_mode == 3) k_begin = (j0 / BK) * BK;
   if (k_chunk > 0) {  // split-K slice of this z
     k_begin = max(k_begin, static_cast<int>(blockIdx.z) * k_chunk);
     k_end = min(k_end, (static_cast<int>(blockIdx.z) + 1) * k_chunk);
   }
 
-  Stage<T> sa, sb;
+  Stage<TL> sa, sb;
   if (k_begin < k_end) {
-    load_tile<T>(sa, g.A, g.a_i, g.a_k, i0, k_begin, g.M, g.K, a_mode, tid);
-    load_tile<T>(sb, g.B, g.b_j, g.b_k, j0, k_begin, g.N, g.K, b_mode, tid);
-    store_tile<T, LD>(sa, As[0], i0, k_begin, g.M, g.K, a_mode, tid);
-    store_tile<T, LD>(sb, Bs[0], j0, k_begin, g.N, g.K, b_mode, tid);
+    load_tile<TL>(sa, g.A, g.a_i, g.a_k, i0, k_begin, g.M, g.K, a_mode, tid);
+    load_tile<TL>(sb, g.B, g.b_j, g.b_k, j0, k_begin, g.N, g.K, b_mode, tid);
+    store_tile<TL, LD>(sa, As[0], i0, k_begin, g.M, g.K, a_mode, tid);
+    store_tile<TL, LD>(sb, Bs[0], j0, k_begin, g.N, g.K, b_mode, tid);
   }
   __syncthreads();
   int buf = 0;
+#if defined(MI355Q_GEMM_UNROLL1)
+#pragma unroll 1
+#endif
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
     const int kn = k0 + BK;
     const bool more = kn < k_end;
     if (more) {  // next tile's global loads fly while this tile's MFMAs run
-      load_tile<T>(sa, g.A, g.a_i, g.a_k, i0, kn, g.M, g.K, a_mode, tid);
-      load_tile<T>(sb, g.B, g.b_j, g.b_k, j0, kn, g.N, g.K, b_mode, tid);
+      load_tile<TL>(sa, g.A, g.a_i, g.a_k, i0, kn, g.M, g.K, a_mode, tid);
+      load_tile<TL>(sb, g.B, g.b_j, g.b_k, j0, kn, g.N, g.K, b_mode, tid);
+    }
+#if defined(MI355Q_GEMM_PIN)
+    if constexpr (!TL::DBUF) __builtin_amdgcn_sched_barrier(0);  // loads first, then the MFMA block
+#endif
+    // operand fragments are double-buffered in registers: the ds_reads of k-substep s+1 are
+    // issued before the MFMAs of substep s
+    T af[2][TM], bf[2][TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      af[0][t] = As[buf][fk][wi + t * MF + fi];
+      bf[0][t] = Bs[buf][fk][wj + t * MF + fi];
     }
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += KF) {
-      T af[TM], bf[TM];
+    for (int s = 0; s < BK / KF; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < BK / KF) {
 #pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        af[t] = As[buf][kk + fk][wi + t * MF + fi];
-        bf[t] = Bs[buf][kk + fk][wj + t * MF + fi];
+        for (int t = 0; t < TM; ++t) {
+          af[cur ^ 1][t] = As[buf][(s + 1) * KF + fk][wi + t * MF + fi];
+          bf[cur ^ 1][t] = Bs[buf][(s + 1) * KF + fk][wj + t * MF + fi];
+        }
       }
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = mfma(af[a], bf[b], acc[a][b]);
+        for (int b = 0; b < TM; ++b) acc[a][b] = mfma(af[cur][a], bf[cur][b], acc[a][b]);
+#if defined(MI355Q_GEMM_SCHED)
+      // interleave: one ds_read behind every second MFMA of this substep
+#pragma unroll
+      for (int q = 0; q < 2 * TM; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TM / (2 * TM), 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // DS read
+      }
+#endif
     }
-    if (more) {
-      store_tile<T, LD>(sa, As[buf ^ 1], i0, kn, g.M, g.K, a_mode, tid);
-      store_tile<T, LD>(sb, Bs[buf ^ 1], j0, kn, g.N, g.K, b_mode, tid);
+    if constexpr (TL::DBUF) {
+      if (more) {
+        store_tile<TL, LD>(sa, As[buf ^ 1], i0, kn, g.M, g.K, a_mode, tid);
+        store_tile<TL, LD>(sb, Bs[buf ^ 1], j0, kn, g.N, g.K, b_mode, tid);
+      }
+      __syncthreads();
+      buf ^= 1;
+    } else {
+#if defined(MI355Q_GEMM_PIN)
+      __builtin_amdgcn_sched_barrier(0);  // keep all MFMAs of this K step ahead of the barrier
+#endif
+      __syncthreads();  // everyone is done reading the tile
+      if (more) {
+        store_tile<TL, LD>(sa, As[0], i0, kn, g.M, g.K, a_mode, tid);
+        store_tile<TL, LD>(sb, Bs[0], j0, kn, g.N, g.K, b_mode, tid);
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    buf ^= 1;
   }
   // ---- epilogue
 #pragma unroll
@@ -274,12 +332,11 @@ int gemm_pick_splitk(int M, int N, int K) {
   return s < 1 ? 1 : s;
 }
 
-template <typename T>
-int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_t splitk_ws_bytes) {
-  if (g.M <= 0 || g.N <= 0) return MI355Q_OK;
-  constexpr int BM = Tile<T>::BM;
-  const int a_mode = pick_mode<T>(g.A, g.a_i, g.a_k);
-  const int b_mode = pick_mode<T>(g.B, g.b_j, g.b_k);
+template <typename TL>
+int32_t launch_with(const GemmArgs<typename TL::Elem>& g, hipStream_t st, void* splitk_ws, size_t splitk_ws_bytes,
+                    int a_mode, int b_mode) {
+  using T = typename TL::Elem;
+  constexpr int BM = TL::BM;
   int slices = 1;
   if (splitk_ws != nullptr && g.k_mode == 0) {
     slices = gemm_pick_splitk<T>(g.M, g.N, g.K);
@@ -288,10 +345,10 @@ int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_
   const dim3 grid(static_cast<unsigned>((g.N + BM - 1) / BM), static_cast<unsigned>((g.M + BM - 1) / BM),
                   static_cast<unsigned>(slices));
   if (slices > 1) {
-    constexpr int BK = Tile<T>::BK;
+    constexpr int BK = TL::BK;
     int chunk = (g.K + slices - 1) / slices;
     chunk = (chunk + BK - 1) / BK * BK;
-    hipLaunchKernelGGL((gemm_kernel<T>), grid, dim3(256), 0, st, g, a_mode, b_mode, chunk,
+    hipLaunchKernelGGL((gemm_kernel<TL>), grid, dim3(256), 0, st, g, a_mode, b_mode, chunk,
                        static_cast<T*>(splitk_ws));
     MI355Q_CHECK_LAUNCH("gemm launch");
     long long n = static_cast<long long>(g.M) * g.N;
@@ -300,10 +357,30 @@ int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_
                        static_cast<const T*>(splitk_ws), slices);
     MI355Q_CHECK_LAUNCH("gemm split-k reduce launch");
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T>), grid, dim3(256), 0, st, g, a_mode, b_mode, 0, static_cast<T*>(nullptr));
+    hipLaunchKernelGGL((gemm_kernel<TL>), grid, dim3(256), 0, st, g, a_mode, b_mode, 0, static_cast<T*>(nullptr));
     MI355Q_CHECK_LAUNCH("gemm launch");
   }
   return MI355Q_OK;
+}
+
+template <typename T>
+int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_t splitk_ws_bytes) {
+  if (g.M <= 0 || g.N <= 0) return MI355Q_OK;
+  const int a_mode = pick_mode<T>(g.A, g.a_i, g.a_k);
+  const int b_mode = pick_mode<T>(g.B, g.b_j, g.b_k);
+  if constexpr (sizeof(T) == 8) {
+    // the 128x128 tile pays when there are enough of them to fill the chip; k_mode offsets are
+    // multiples of the block edge either way
+    const long long tiles128 = static_cast<long long>((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const bool splitk = splitk_ws != nullptr && g.k_mode == 0 && gemm_pick_splitk<T>(g.M, g.N, g.K) > 1;
+#if defined(MI355Q_GEMM_BIG)   // tuning hook (tools/gemm_bench.py): off until the 128x128 loop is lean
+    if (tiles128 >= 256 && !splitk)
+#else
+    if (false && tiles128 >= 256 && !splitk)
+#endif
+      return launch_with<TileF64Big>(g, st, nullptr, 0, a_mode, b_mode);
+  }
+  return launch_with<Tile<T>>(g, st, splitk_ws, splitk_ws_bytes, a_mode, b_mode);
 }
 
 template int32_t launch_gemm<float>(const GemmArgs<float>&, hipStream_t, void*, size_t);

@@ -74,51 +74,90 @@ __global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __
 // Unblocked lower Cholesky of the nb x nb diagonal block at (k,k) followed by the
 // inverse of that triangular factor. L_kk goes back into `a`; inv(L_kk) (zeros above
 // the diagonal, identity padding past nb) goes to `dinv` (NB x NB, row-major): the
-// panel solve and the triangular-inverse sweep then are plain MFMA GEMMs.
+// panel solve and the triangular-inverse merge then are plain MFMA GEMMs.
 // info != 0 if a pivot is not positive.
+//
+// This kernel sits on the serial critical path (one workgroup per 64 columns), so it is
+// latency-tuned: the block lives in registers while it is factored (thread t owns row t/4,
+// columns 16*(t%4)..+15; one column broadcast through LDS and two barriers per step), and
+// the inverse is built by pairwise merging in LDS (levels s = 1, 2, ..., 32:
+// X21 = -X22 (L21 X11), 12 barriers in total) instead of 64 serial forward substitutions.
+__device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // c <= r
+
 __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ a, int d, int k, int nb,
                                                        double* __restrict__ dinv, int* info) {
-  __shared__ double s[NB][NB + 1];
-  __shared__ double x[NB][NB + 1];
-  for (int e = threadIdx.x; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    s[r][c] = (r < nb && c <= r) ? a[static_cast<long long>(k + r) * d + k + c] : 0.0;
-    x[r][c] = 0.0;
+  __shared__ double Lp[NB * (NB + 1) / 2];   // packed lower triangles
+  __shared__ double Xp[NB * (NB + 1) / 2];
+  __shared__ double T[NB * NB / 4];          // per level: all pairs' s x s products (32 * s values)
+  __shared__ double col[NB];
+  __shared__ double piv;
+  const int t = threadIdx.x, r = t >> 2, cq = t & 3;
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = cq * 16 + i;
+    v[i] = (r < nb && c <= r) ? a[static_cast<long long>(k + r) * d + k + c] : 0.0;
   }
-  __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    if (threadIdx.x == 0) {
-      const double v = s[j][j];
-      if (!(v > 0.0)) atomicCAS(info, 0, k + j + 1);
-      s[j][j] = __builtin_sqrt(v);
-    }
-    __syncthreads();
-    if (threadIdx.x > j && threadIdx.x < nb) s[threadIdx.x][j] /= s[j][j];
-    __syncthreads();
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
-      const int r = e / NB, c = e % NB;
-      if (c > j && r >= c && r < nb) s[r][c] -= s[r][j] * s[c][j];
-    }
-    __syncthreads();
-  }
-  // inverse: thread c solves L x = e_c by forward substitution
-  const int c = threadIdx.x;
-  if (c < NB) {
-    if (c < nb) {
-      for (int r = c; r < nb; ++r) {
-        double v = (r == c) ? 1.0 : 0.0;
-        for (int m = c; m < r; ++m) v -= s[r][m] * x[m][c];
-        x[r][c] = v / s[r][r];
+#pragma unroll
+  for (int jq = 0; jq < 4; ++jq) {
+#pragma unroll
+    for (int ji = 0; ji < 16; ++ji) {
+      const int j = jq * 16 + ji;
+      if (j < nb) {  // uniform
+        if (r == j && cq == jq) {
+          double p = v[ji];
+          if (!(p > 0.0)) atomicCAS(info, 0, k + j + 1);
+          p = __builtin_sqrt(p);
+          v[ji] = p;
+          piv = p;
+        }
+        __syncthreads();
+        if (cq == jq && r >= j) {
+          if (r > j) v[ji] = v[ji] / piv;
+          col[r] = v[ji];
+        }
+        __syncthreads();
+        const double lr = col[r];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int c = cq * 16 + i;
+          if (c > j && r >= c) v[i] -= lr * col[c];
+        }
       }
-    } else {
-      x[c][c] = 1.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = cq * 16 + i;
+    if (c <= r) {
+      const double val = r < nb ? v[i] : (c == r ? 1.0 : 0.0);
+      Lp[tri(r, c)] = val;
+      if (r < nb) a[static_cast<long long>(k + r) * d + k + c] = val;
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < NB * NB; e += 256) {
-    const int r = e / NB, cc = e % NB;
-    if (r < nb && cc <= r) a[static_cast<long long>(k + r) * d + k + cc] = s[r][cc];
-    dinv[e] = x[r][cc];
+  if (t < NB) Xp[tri(t, t)] = 1.0 / Lp[tri(t, t)];
+  __syncthreads();
+  for (int s = 1; s < NB; s <<= 1) {
+    const int outs = (NB / 2) * s;  // pairs * s * s
+    for (int o = t; o < outs; o += 256) {   // T = L21 X11
+      const int bb = o % s, aa = (o / s) % s, p = (o / (s * s)) * 2 * s;
+      double acc = 0.0;
+      for (int m = bb; m < s; ++m) acc += Lp[tri(p + s + aa, p + m)] * Xp[tri(p + m, p + bb)];
+      T[o] = acc;
+    }
+    __syncthreads();
+    for (int o = t; o < outs; o += 256) {   // X21 = -X22 T
+      const int bb = o % s, aa = (o / s) % s, pr = o / (s * s), p = pr * 2 * s;
+      double acc = 0.0;
+      for (int m = 0; m <= aa; ++m) acc += Xp[tri(p + s + aa, p + s + m)] * T[(pr * s + m) * s + bb];
+      Xp[tri(p + s + aa, p + bb)] = -acc;
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < NB * NB; e += 256) {
+    const int rr = e / NB, cc = e % NB;
+    dinv[e] = cc <= rr ? Xp[tri(rr, cc)] : 0.0;
   }
 }
 
@@ -346,23 +385,26 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
     }
   }
   MI355Q_CHECK_LAUNCH("gptq cholesky launch");
-  // ---- in-place inverse of the lower-triangular factor, block columns right to left
-  // (LAPACK dtrtri order):  A21 <- -(A22^-1 * A21) * A11^-1 ;  A11 <- A11^-1
-  for (int jb = nblocks - 1; jb >= 0; --jb) {
-    const int k = jb * NB;
-    const int nb = d - k < NB ? d - k : NB;
-    const int m = d - k - nb;
-    if (m > 0) {
-      double* a21 = a + static_cast<long long>(k + nb) * d + k;
-      double* a22 = a + static_cast<long long>(k + nb) * d + k + nb;  // already inverted
-      const double* inv11 = dinv + static_cast<size_t>(jb) * NB * NB;
-      GemmArgs<double> g1{a22, d, 1, a21, d, 1, panel, NB, 1, m, nb, m, 1.0, 0.0, 0, 1};
-      if (int32_t s = launch_gemm<double>(g1, st)) return s;
-      GemmArgs<double> g2{panel, NB, 1, inv11, NB, 1, a21, d, 1, m, nb, nb, -1.0, 0.0, 0, 0};
-      if (int32_t s = launch_gemm<double>(g2, st)) return s;
+  // ---- in-place inverse of the lower-triangular factor by pairwise merging: the diagonal
+  // NB-blocks are already inverted; at level s every pair of adjacent inverted blocks
+  //   [ L11^-1        0     ]
+  //   [ L21        L22^-1   ]      becomes one inverted block with  L21 <- -L22^-1 (L21 L11^-1).
+  // All flops are in large triangular-operand GEMMs (two per pair); `out` is free until the
+  // final product and holds the intermediate L21 L11^-1.
+  hipLaunchKernelGGL(put_diag_inverses_kernel, dim3(nblocks), dim3(256), 0, st, a, d, dinv, 0);
+  for (long long s = NB; s < d; s *= 2) {
+    for (long long p = 0; p + s < d; p += 2 * s) {
+      const int n2 = static_cast<int>(d - (p + s) < s ? d - (p + s) : s);
+      const int n1 = static_cast<int>(s);
+      double* l11 = a + p * d + p;                 // n1 x n1, inverted, lower
+      double* l21 = a + (p + s) * d + p;           // n2 x n1
+      double* l22 = a + (p + s) * d + (p + s);     // n2 x n2, inverted, lower
+      double* t = out;                             // n2 x n1 scratch, row stride n1
+      GemmArgs<double> g1{l21, d, 1, l11, d, 1, t, n1, 1, n2, n1, n1, 1.0, 0.0, 0, 3};
+      if (int32_t e = launch_gemm<double>(g1, st)) return e;
+      GemmArgs<double> g2{l22, d, 1, t, n1, 1, l21, d, 1, n2, n1, n2, -1.0, 0.0, 0, 1};
+      if (int32_t e = launch_gemm<double>(g2, st)) return e;
     }
-    // A11 <- A11^-1 (the next, more leftward, step reads it as part of its A22^-1)
-    hipLaunchKernelGGL(put_diag_inverses_kernel, dim3(1), dim3(256), 0, st, a, d, dinv, jb);
   }
   MI355Q_CHECK_LAUNCH("gptq trtri launch");
   // ---- H^-1 = L^-T L^-1 : out(i,j) = sum_k Linv[k][i] * Linv[k][j], k >= max(i,j); lower half
