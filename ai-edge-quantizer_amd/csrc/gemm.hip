@@ -20,7 +20,13 @@
 // barrier per K step. Long-K / few-tile shapes (the Hessian at d = 2048: K = 65536,
 // 256 tiles) are split along K over gridDim.z into a workspace and summed in a fixed
 // order by a second kernel (deterministic, unlike atomics).
+#include <type_traits>
+
 #include "gemm.h"
+
+#ifndef MI355Q_BIG_MIN_K
+#define MI355Q_BIG_MIN_K 256   // below this the 128x128 tile's prologue / epilogue dominate
+#endif
 
 namespace mi355q {
 namespace {
@@ -286,6 +292,193 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<typename TL::Elem> g
       }
 }
 
+// ---- lean main loop for the common case -------------------------------------------------
+// Whole tiles only (M, N multiples of BM; the K range a multiple of BK) and both operands in a
+// 16-byte-loadable layout known at compile time: no per-step mode or bounds decisions, one
+// 64-bit pointer per operand advanced by a constant. With one wave per SIMD (the 128x128 FP64
+// tile) every issue slot between MFMAs counts - the generic kernel above spends ~6 extra
+// instructions per MFMA on that bookkeeping and reaches 50 % MFMA-busy where this loop is
+// MFMA-bound.
+template <typename TL, int MODE>
+struct FastOperand {
+  using T = typename TL::Elem;
+  using Vec = typename TL::Vec;
+  static constexpr int BM = TL::BM, BK = TL::BK, VEC = TL::VEC, NL = Stage<TL>::NL;
+  const T* p;          // this thread's first element of the current K step
+  long long step;      // elements per K step
+  long long lstride;   // elements between this thread's consecutive loads
+  int lds_a, lds_b;    // LDS coordinates of load 0 (see store)
+
+  __device__ __forceinline__ void init(const T* base, long long s_m, long long s_k, int m0, int k0, int tid) {
+    if constexpr (MODE == kMFast) {       // m contiguous: a load is VEC consecutive m at one k
+      constexpr int PER_K = BM / VEC;     // loads per k row
+      const int mv = tid % PER_K, k = tid / PER_K;
+      p = base + (m0 + mv * VEC) + static_cast<long long>(k0 + k) * s_k;
+      lstride = static_cast<long long>(256 / PER_K) * s_k;
+      lds_a = k;
+      lds_b = mv * VEC;
+    } else {                              // k contiguous: a load is VEC consecutive k at one m
+      constexpr int PER_M = BK / VEC;
+      const int kv = tid % PER_M, m = tid / PER_M;
+      p = base + static_cast<long long>(m0 + m) * s_m + (k0 + kv * VEC);
+      lstride = static_cast<long long>(256 / PER_M) * s_m;
+      lds_a = kv * VEC;
+      lds_b = m;
+    }
+    step = static_cast<long long>(BK) * s_k;
+  }
+  // Unconditional on purpose: a load guarded by `if (more)` makes the compiler merge the two
+  // register states right behind the branch, i.e. wait for the loads before the MFMAs. On the
+  // last K step the current tile is simply fetched again (and never stored).
+  __device__ __forceinline__ void load(Stage<TL>& st, bool more) {
+    const T* q = more ? p : p - step;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) st.v[l] = *reinterpret_cast<const Vec*>(q + l * lstride);
+    p += step;
+  }
+  template <int LD>
+  __device__ __forceinline__ void store(const Stage<TL>& st, T (*lds)[LD]) const {
+    if constexpr (MODE == kMFast) {
+      constexpr int KSTEP = 256 / (BM / VEC);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) *reinterpret_cast<Vec*>(&lds[lds_a + l * KSTEP][lds_b]) = st.v[l];
+    } else {
+      constexpr int MSTEP = 256 / (BK / VEC);
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) lds[lds_a + c][lds_b + l * MSTEP] = comp(st.v[l], c);
+    }
+  }
+};
+
+template <typename TL, int AMODE, int BMODE>
+__device__ __forceinline__ void gemm_fast_body(const GemmArgs<typename TL::Elem>& g, int k_chunk,
+                                               typename TL::Elem* __restrict__ partial) {
+  using T = typename TL::Elem;
+  constexpr int BM = TL::BM, MF = TL::MF, KF = TL::KF, TM = TL::TM, BK = TL::BK;
+  constexpr int LD = BM + TL::VEC;
+  constexpr int NREG = sizeof(typename TL::Acc) / sizeof(T);
+  constexpr int NBUF = TL::DBUF ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) T As[NBUF][BK][LD];
+  __shared__ __attribute__((aligned(16))) T Bs[NBUF][BK][LD];
+
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (g.lower_only && bj > bi) return;
+  const int i0 = bi * BM, j0 = bj * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = (wave >> 1) * (TM * MF), wj = (wave & 1) * (TM * MF);
+  const int fi = lane % MF, fk = lane / MF;
+
+  typename TL::Acc acc[TM][TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) acc[a][b][r] = T(0);
+
+  int k_begin = 0, k_end = g.K;
+  if (g.k_mode == 1) k_end = min(g.K, i0 + BM);
+  if (g.k_mode == 2) k_begin = max(i0, j0);
+  if (g.k_mode == 3) k_begin = j0;
+  if (k_chunk > 0) {
+    k_begin = max(k_begin, static_cast<int>(blockIdx.z) * k_chunk);
+    k_end = min(k_end, (static_cast<int>(blockIdx.z) + 1) * k_chunk);
+  }
+  const int steps = (k_end - k_begin) / BK;
+
+  FastOperand<TL, AMODE> fa;
+  FastOperand<TL, BMODE> fb;
+  fa.init(g.A, g.a_i, g.a_k, i0, k_begin, tid);
+  fb.init(g.B, g.b_j, g.b_k, j0, k_begin, tid);
+  Stage<TL> sa, sb;
+  if (steps > 0) {
+    fa.load(sa, true);
+    fb.load(sb, true);
+    fa.template store<LD>(sa, As[0]);
+    fb.template store<LD>(sb, Bs[0]);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int it = 0; it < steps; ++it) {
+    const bool more = it + 1 < steps;
+    fa.load(sa, more);
+    fb.load(sb, more);
+    T af[2][TM], bf[2][TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      af[0][t] = As[buf][fk][wi + t * MF + fi];
+      bf[0][t] = Bs[buf][fk][wj + t * MF + fi];
+    }
+#pragma unroll
+    for (int s = 0; s < BK / KF; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < BK / KF) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          af[cur ^ 1][t] = As[buf][(s + 1) * KF + fk][wi + t * MF + fi];
+          bf[cur ^ 1][t] = Bs[buf][(s + 1) * KF + fk][wj + t * MF + fi];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = mfma(af[cur][a], bf[cur][b], acc[a][b]);
+    }
+    if constexpr (TL::DBUF) {
+      if (more) {
+        fa.template store<LD>(sa, As[buf ^ 1]);
+        fb.template store<LD>(sb, Bs[buf ^ 1]);
+      }
+      __syncthreads();
+      buf ^= 1;
+    } else {
+      __syncthreads();
+      if (more) {
+        fa.template store<LD>(sa, As[0]);
+        fb.template store<LD>(sb, Bs[0]);
+      }
+      __syncthreads();
+    }
+  }
+  const bool diag = g.lower_only && bi == bj;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) {
+        const long long i = i0 + wi + a * MF + acc_row(T(0), r, lane);
+        const long long j = j0 + wj + b * MF + fi;
+        if (!diag || j <= i) {
+          if (partial != nullptr) {
+            partial[(static_cast<long long>(blockIdx.z) * g.M + i) * g.N + j] = acc[a][b][r];
+          } else {
+            T* c = g.C + i * g.c_i + j * g.c_j;
+            const T p = g.alpha * acc[a][b][r];
+            *c = (g.beta == T(0)) ? p : g.beta * (*c) + p;
+          }
+        }
+      }
+}
+
+template <typename TL, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs<typename TL::Elem> g, int k_chunk,
+                                                        typename TL::Elem* __restrict__ partial) {
+  gemm_fast_body<TL, AMODE, BMODE>(g, k_chunk, partial);
+}
+
+// The 128x128 FP64 tile needs > 256 registers per lane (128 accumulators in AccVGPRs + staging
+// + fragments): tell the compiler it owns the whole 512-entry file (one wave per SIMD), or it
+// budgets for two waves, spills the staging registers to scratch and shuffles accumulators
+// between AccVGPRs and VGPRs every K step.
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void gemm_fast_big_kernel(GemmArgs<double> g, int k_chunk, double* __restrict__ partial) {
+  gemm_fast_body<TileF64Big, AMODE, BMODE>(g, k_chunk, partial);
+}
+
 // C = beta*C + alpha * (partial[0] + partial[1] + ... ), slices added in order.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs<T> g, const T* __restrict__ partial,
@@ -344,10 +537,44 @@ int32_t launch_with(const GemmArgs<typename TL::Elem>& g, hipStream_t st, void* 
   }
   const dim3 grid(static_cast<unsigned>((g.N + BM - 1) / BM), static_cast<unsigned>((g.M + BM - 1) / BM),
                   static_cast<unsigned>(slices));
+  // whole tiles + 16-byte loadable operands: the lean kernel
+  const bool whole = g.M % BM == 0 && g.N % BM == 0 && g.K % TL::BK == 0 && a_mode != kGeneric &&
+                     b_mode != kGeneric;
+  int chunk = 0;
   if (slices > 1) {
     constexpr int BK = TL::BK;
-    int chunk = (g.K + slices - 1) / slices;
+    chunk = (g.K + slices - 1) / slices;
     chunk = (chunk + BK - 1) / BK * BK;
+  }
+#if defined(MI355Q_GEMM_NOFAST)
+  if (false) {
+#else
+  if (whole) {
+#endif
+    T* part = slices > 1 ? static_cast<T*>(splitk_ws) : nullptr;
+#define MI355Q_FAST(AM, BMO)                                                                        \
+  do {                                                                                               \
+    if constexpr (std::is_same_v<TL, TileF64Big>)                                                    \
+      hipLaunchKernelGGL((gemm_fast_big_kernel<AM, BMO>), grid, dim3(256), 0, st, g, chunk, part);   \
+    else                                                                                             \
+      hipLaunchKernelGGL((gemm_fast_kernel<TL, AM, BMO>), grid, dim3(256), 0, st, g, chunk, part);   \
+  } while (0)
+    if (a_mode == kMFast && b_mode == kMFast) MI355Q_FAST(kMFast, kMFast);
+    else if (a_mode == kMFast) MI355Q_FAST(kMFast, kKFast);
+    else if (b_mode == kMFast) MI355Q_FAST(kKFast, kMFast);
+    else MI355Q_FAST(kKFast, kKFast);
+#undef MI355Q_FAST
+    MI355Q_CHECK_LAUNCH("gemm launch");
+    if (slices > 1) {
+      long long n = static_cast<long long>(g.M) * g.N;
+      unsigned blocks = static_cast<unsigned>((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, g,
+                         static_cast<const T*>(splitk_ws), slices);
+      MI355Q_CHECK_LAUNCH("gemm split-k reduce launch");
+    }
+    return MI355Q_OK;
+  }
+  if (slices > 1) {
     hipLaunchKernelGGL((gemm_kernel<TL>), grid, dim3(256), 0, st, g, a_mode, b_mode, chunk,
                        static_cast<T*>(splitk_ws));
     MI355Q_CHECK_LAUNCH("gemm launch");
@@ -373,12 +600,13 @@ int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_
     // multiples of the block edge either way
     const long long tiles128 = static_cast<long long>((g.M + 127) / 128) * ((g.N + 127) / 128);
     const bool splitk = splitk_ws != nullptr && g.k_mode == 0 && gemm_pick_splitk<T>(g.M, g.N, g.K) > 1;
-#if defined(MI355Q_GEMM_BIG)   // tuning hook (tools/gemm_bench.py): off until the 128x128 loop is lean
-    if (tiles128 >= 256 && !splitk)
-#else
-    if (false && tiles128 >= 256 && !splitk)
-#endif
+    const bool whole128 = g.M % 128 == 0 && g.N % 128 == 0 && g.K % 16 == 0 && a_mode != kGeneric &&
+                          b_mode != kGeneric;
+#if !defined(MI355Q_GEMM_NOBIG)   // tuning hook (tools/gemm_bench.py)
+    // triangular outputs (lower_only) leave the chip half empty at the tail with tiles this big
+    if (tiles128 >= 256 && !splitk && whole128 && g.K >= MI355Q_BIG_MIN_K && !g.lower_only)
       return launch_with<TileF64Big>(g, st, nullptr, 0, a_mode, b_mode);
+#endif
   }
   return launch_with<Tile<T>>(g, st, splitk_ws, splitk_ws_bytes, a_mode, b_mode);
 }
