@@ -78,54 +78,114 @@ __global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __
 // info != 0 if a pivot is not positive.
 //
 // This kernel sits on the serial critical path (one workgroup per 64 columns), so it is
-// latency-tuned: the block lives in registers while it is factored (thread t owns row t/4,
-// columns 16*(t%4)..+15; one column broadcast through LDS and two barriers per step), and
+// latency-tuned: the block lives in registers while it is factored (lane = row, wave w owns
+// columns 16w..16w+15; a 16-column panel is factored inside its wave with v_readlane
+// broadcasts and applied to the waves on its right as a rank-16 update: 4 barriers), and
 // the inverse is built by pairwise merging in LDS (levels s = 1, 2, ..., 32:
 // X21 = -X22 (L21 X11), 12 barriers in total) instead of 64 serial forward substitutions.
 __device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // c <= r
+
+__device__ __forceinline__ double lane_bcast64(double v, int src_lane) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane(static_cast<int>(bits), src_lane);
+  const int hi = __builtin_amdgcn_readlane(static_cast<int>(bits >> 32), src_lane);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
+// One level of the in-LDS inverse: every pair of adjacent inverted S-blocks becomes one
+// inverted 2S-block. Fixed trip counts (terms outside the triangles are masked, the LDS index
+// clamped) so the S loads of a dot product are all in flight at once.
+template <int S>
+__device__ __forceinline__ void merge_level(const double* __restrict__ Lp, double* __restrict__ Xp,
+                                            double* __restrict__ T, int t) {
+  constexpr int OUTS = (NB / 2) * S;  // pairs * S * S
+  for (int o = t; o < OUTS; o += 256) {   // T = L21 X11
+    const int bb = o % S, aa = (o / S) % S, p = (o / (S * S)) * 2 * S;
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      const int mm = m < bb ? bb : m;
+      const double term = Lp[tri(p + S + aa, p + mm)] * Xp[tri(p + mm, p + bb)];
+      acc += m < bb ? 0.0 : term;
+    }
+    T[o] = acc;
+  }
+  __syncthreads();
+  for (int o = t; o < OUTS; o += 256) {   // X21 = -X22 T
+    const int bb = o % S, aa = (o / S) % S, pr = o / (S * S), p = pr * 2 * S;
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      const int mm = m > aa ? aa : m;
+      const double term = Xp[tri(p + S + aa, p + S + mm)] * T[(pr * S + mm) * S + bb];
+      acc += m > aa ? 0.0 : term;
+    }
+    Xp[tri(p + S + aa, p + bb)] = -acc;
+  }
+  __syncthreads();
+}
 
 __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ a, int d, int k, int nb,
                                                        double* __restrict__ dinv, int* info) {
   __shared__ double Lp[NB * (NB + 1) / 2];   // packed lower triangles
   __shared__ double Xp[NB * (NB + 1) / 2];
   __shared__ double T[NB * NB / 4];          // per level: all pairs' s x s products (32 * s values)
-  __shared__ double col[NB];
-  __shared__ double piv;
-  const int t = threadIdx.x, r = t >> 2, cq = t & 3;
+  __shared__ double P[2][NB][17];            // the last two factored 64 x 16 panels
+  const int t = threadIdx.x, r = t & 63, cq = t >> 6;   // wave cq owns columns 16*cq..+15 of every row
+#if defined(MI355Q_POTF2_PROF)   // tools/kbench/potf2_bench.hip: phase stamps behind the dinv block
+  long long* prof = reinterpret_cast<long long*>(dinv + NB * NB);
+  int stamp = 0;
+#define MI355Q_STAMP() do { if (t == 0) prof[stamp] = __builtin_readcyclecounter(); ++stamp; } while (0)
+#else
+#define MI355Q_STAMP() do { } while (0)
+#endif
+  MI355Q_STAMP();
   double v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = cq * 16 + i;
     v[i] = (r < nb && c <= r) ? a[static_cast<long long>(k + r) * d + k + c] : 0.0;
   }
+  MI355Q_STAMP();
+  // Left to right over the four 16-column panels. The owning wave factors its panel alone
+  // (lane = row, pivots and multipliers broadcast with v_readlane: no barrier inside a panel),
+  // publishes it, and the waves to its right apply it as one rank-16 update.
 #pragma unroll
   for (int jq = 0; jq < 4; ++jq) {
+    double (*pan)[17] = P[jq & 1];
+    if (cq == jq) {  // wave-uniform
 #pragma unroll
-    for (int ji = 0; ji < 16; ++ji) {
-      const int j = jq * 16 + ji;
-      if (j < nb) {  // uniform
-        if (r == j && cq == jq) {
-          double p = v[ji];
-          if (!(p > 0.0)) atomicCAS(info, 0, k + j + 1);
-          p = __builtin_sqrt(p);
-          v[ji] = p;
-          piv = p;
-        }
-        __syncthreads();
-        if (cq == jq && r >= j) {
-          if (r > j) v[ji] = v[ji] / piv;
-          col[r] = v[ji];
-        }
-        __syncthreads();
-        const double lr = col[r];
+      for (int ji = 0; ji < 16; ++ji) {
+        const int j = jq * 16 + ji;
+        if (j < nb) {  // uniform
+          const double p = lane_bcast64(v[ji], j);
+          if (!(p > 0.0) && r == 0) atomicCAS(info, 0, k + j + 1);
+          // 1/sqrt(p): hardware estimate + two Newton steps, computed by every lane
+          double y = __builtin_amdgcn_rsq(p);
+          y = y * (1.5 - 0.5 * p * y * y);
+          y = y * (1.5 - 0.5 * p * y * y);
+          v[ji] = r == j ? p * y : v[ji] * y;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int c = cq * 16 + i;
-          if (c > j && r >= c) v[i] -= lr * col[c];
+          for (int i = ji + 1; i < 16; ++i) v[i] -= v[ji] * lane_bcast64(v[ji], jq * 16 + i);
         }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pan[r][i] = v[i];
+    }
+    __syncthreads();
+    if (cq > jq) {
+      double mine[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) mine[jj] = pan[r][jj];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = cq * 16 + i;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) v[i] -= mine[jj] * pan[c][jj];
       }
     }
   }
+  MI355Q_STAMP();
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = cq * 16 + i;
@@ -138,27 +198,25 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ a, 
   __syncthreads();
   if (t < NB) Xp[tri(t, t)] = 1.0 / Lp[tri(t, t)];
   __syncthreads();
-  for (int s = 1; s < NB; s <<= 1) {
-    const int outs = (NB / 2) * s;  // pairs * s * s
-    for (int o = t; o < outs; o += 256) {   // T = L21 X11
-      const int bb = o % s, aa = (o / s) % s, p = (o / (s * s)) * 2 * s;
-      double acc = 0.0;
-      for (int m = bb; m < s; ++m) acc += Lp[tri(p + s + aa, p + m)] * Xp[tri(p + m, p + bb)];
-      T[o] = acc;
-    }
-    __syncthreads();
-    for (int o = t; o < outs; o += 256) {   // X21 = -X22 T
-      const int bb = o % s, aa = (o / s) % s, pr = o / (s * s), p = pr * 2 * s;
-      double acc = 0.0;
-      for (int m = 0; m <= aa; ++m) acc += Xp[tri(p + s + aa, p + s + m)] * T[(pr * s + m) * s + bb];
-      Xp[tri(p + s + aa, p + bb)] = -acc;
-    }
-    __syncthreads();
-  }
+  MI355Q_STAMP();
+  merge_level<1>(Lp, Xp, T, t);
+  MI355Q_STAMP();
+  merge_level<2>(Lp, Xp, T, t);
+  MI355Q_STAMP();
+  merge_level<4>(Lp, Xp, T, t);
+  MI355Q_STAMP();
+  merge_level<8>(Lp, Xp, T, t);
+  MI355Q_STAMP();
+  merge_level<16>(Lp, Xp, T, t);
+  MI355Q_STAMP();
+  merge_level<32>(Lp, Xp, T, t);
+  MI355Q_STAMP();
   for (int e = t; e < NB * NB; e += 256) {
     const int rr = e / NB, cc = e % NB;
     dinv[e] = cc <= rr ? Xp[tri(rr, cc)] : 0.0;
   }
+  MI355Q_STAMP();
+#undef MI355Q_STAMP
 }
 
 // dst[i, 0:nb] (row stride ld_dst) = src[i, 0:nb] (row stride ld_src), i < m
@@ -362,26 +420,42 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   hipLaunchKernelGGL(copy_damped_lower_kernel, dim3(grid1d(static_cast<long long>(d) * d)), dim3(256), 0, st,
                      hessian, d, scal, damp_factor, a);
   MI355Q_CHECK_LAUNCH("gptq damp launch");
-  // ---- blocked right-looking Cholesky (lower), FP64. Per 64-column step:
+  // ---- blocked right-looking Cholesky (lower), FP64, two levels. Per 64-column step:
   //   diagonal block: factor + invert (one workgroup)
   //   panel:    L21 = A21 * inv(L11)^T                      (MFMA GEMM)
   //   trailing: A22 -= L21 * L21^T, lower triangle only     (MFMA GEMM)
-  for (int kb = 0; kb < nblocks; ++kb) {
-    const int k = kb * NB;
-    const int nb = d - k < NB ? d - k : NB;
-    double* inv11 = dinv + static_cast<size_t>(kb) * NB * NB;
-    hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, inv11, info_out);
-    const int m = d - k - nb;
-    if (m > 0) {
-      double* a21 = a + static_cast<long long>(k + nb) * d + k;
-      double* a22 = a + static_cast<long long>(k + nb) * d + k + nb;
-      // panel(i,j) = sum_c A21[i][c] * inv11[j][c]
-      GemmArgs<double> gs{a21, d, 1, inv11, 1, NB, panel, NB, 1, m, nb, nb, 1.0, 0.0, 0, 0};
-      if (int32_t s = launch_gemm<double>(gs, st)) return s;
-      hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m) * nb)), dim3(256), 0, st,
-                         panel, static_cast<long long>(NB), a21, static_cast<long long>(d), m, nb);
-      GemmArgs<double> gt{panel, NB, 1, panel, 1, NB, a22, d, 1, m, m, nb, -1.0, 1.0, 1, 0};
-      if (int32_t s = launch_gemm<double>(gt, st)) return s;
+  // A rank-64 update of the whole trailing matrix is memory-bound (it reads and writes
+  // (d-k)^2/2 doubles for 64 flops each), so the 64-column steps only update the rest of their
+  // own 512-column outer block; the matrix behind it gets one rank-512 update per outer block.
+  constexpr int OB = 8 * NB;
+  for (int k0 = 0; k0 < d; k0 += OB) {
+    const int ob = d - k0 < OB ? d - k0 : OB;
+    for (int k = k0; k < k0 + ob; k += NB) {
+      const int nb = k0 + ob - k < NB ? k0 + ob - k : NB;
+      double* inv11 = dinv + static_cast<size_t>(k / NB) * NB * NB;
+      hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, inv11, info_out);
+      const int m = d - k - nb;            // rows below the diagonal block
+      const int w = k0 + ob - k - nb;      // columns left in this outer block
+      if (m > 0) {
+        double* a21 = a + static_cast<long long>(k + nb) * d + k;
+        double* a22 = a + static_cast<long long>(k + nb) * d + k + nb;
+        // panel(i,j) = sum_c A21[i][c] * inv11[j][c]
+        GemmArgs<double> gs{a21, d, 1, inv11, 1, NB, panel, NB, 1, m, nb, nb, 1.0, 0.0, 0, 0};
+        if (int32_t e = launch_gemm<double>(gs, st)) return e;
+        hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m) * nb)), dim3(256), 0, st,
+                           panel, static_cast<long long>(NB), a21, static_cast<long long>(d), m, nb);
+        if (w > 0) {
+          GemmArgs<double> gt{panel, NB, 1, panel, 1, NB, a22, d, 1, m, w, nb, -1.0, 1.0, 1, 0};
+          if (int32_t e = launch_gemm<double>(gt, st)) return e;
+        }
+      }
+    }
+    const int m2 = d - k0 - ob;
+    if (m2 > 0) {
+      const double* l = a + static_cast<long long>(k0 + ob) * d + k0;   // m2 x ob, finished columns
+      double* c = a + static_cast<long long>(k0 + ob) * d + k0 + ob;
+      GemmArgs<double> gu{l, d, 1, l, 1, d, c, d, 1, m2, m2, ob, -1.0, 1.0, 1, 0};
+      if (int32_t e = launch_gemm<double>(gu, st)) return e;
     }
   }
   MI355Q_CHECK_LAUNCH("gptq cholesky launch");
