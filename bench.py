@@ -90,10 +90,18 @@ def main():
   local = int(os.environ.get("LOCAL_RANK", "0"))
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU (no CPU fallback on the product path)")
+  # MI355Q_BENCH_BACKEND=gloo lets the N > 1 control path (barriers, max-reduce, rank-0 line) be
+  # exercised on a one-GPU box: all ranks then share cuda:0 (RCCL refuses duplicate devices)
+  backend = os.environ.get("MI355Q_BENCH_BACKEND", "nccl")
+  if backend != "nccl":
+    local = local % torch.cuda.device_count()
   torch.cuda.set_device(local)
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if backend == "nccl":
+      dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+      dist.init_process_group(backend)
 
   import __graft_entry__ as g
   g.build()
