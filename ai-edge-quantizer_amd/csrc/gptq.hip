@@ -270,64 +270,89 @@ struct ApplyArgs {
   int8_t* q;            // [rows, d]
 };
 
+// One 64-column block of the OBS sweep (ref gptq.py:180-212): columns are visited left to
+// right; each is quantized and its error pushed into the columns to its right - a dependent
+// chain of 64 quantize -> divide -> update steps per row. A row is spread over 16 lanes
+// (4 consecutive columns each), so the update is 4 multiply-subtracts per lane and 16 rows fit
+// in a workgroup: 16x the rows-only parallelism of one thread per row (2048 rows: 128
+// workgroups instead of 8) and a chain that is quantize-latency bound.
+constexpr int kRowLanes = 16;           // lanes per row
+constexpr int kColsPerLane = NB / kRowLanes;
+
 template <typename ST>
 __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
-  __shared__ float h[NB][NB + 1];
+  __shared__ __attribute__((aligned(16))) float h[NB][NB];
+  __shared__ float hd[NB];
   for (int e = threadIdx.x; e < NB * NB; e += 256) {
     const int r = e / NB, c = e % NB;
-    h[r][c] = (r < a.nb && c < a.nb) ? a.hinv[static_cast<long long>(a.c0 + r) * a.d + a.c0 + c] : 0.f;
+    const float v = (r < a.nb && c < a.nb) ? a.hinv[static_cast<long long>(a.c0 + r) * a.d + a.c0 + c] : 0.f;
+    h[r][c] = v;
+    if (r == c) hd[r] = v;
   }
   __syncthreads();
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= a.rows) return;
-  float* wrow = a.w + static_cast<long long>(r) * a.d + a.c0;
-  float w[NB];
+  const int l = threadIdx.x % kRowLanes;              // which 4 columns
+  const int r = blockIdx.x * (256 / kRowLanes) + threadIdx.x / kRowLanes;
+  const bool live = r < a.rows;
+  const int rr = live ? r : a.rows - 1;               // idle lanes shadow the last row, write nothing
+  float* wrow = a.w + static_cast<long long>(rr) * a.d + a.c0;
+  float w[kColsPerLane];
 #pragma unroll
-  for (int j = 0; j < NB; ++j) w[j] = j < a.nb ? wrow[j] : 0.f;
+  for (int k = 0; k < kColsPerLane; ++k) {
+    const int c = l * kColsPerLane + k;
+    w[k] = c < a.nb ? wrow[c] : 0.f;
+  }
   const ST* sc = static_cast<const ST*>(a.scale);
+  const int group_base = (threadIdx.x & 63) & ~(kRowLanes - 1);
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    if (i < a.nb) {
+    if (i < a.nb) {  // uniform
       const int col = a.c0 + i;
+      const float wi = __shfl(w[i % kColsPerLane], group_base + i / kColsPerLane, 64);
       long long si = 0;
-      if (a.scale_mode == 1) si = r;
-      if (a.scale_mode == 2) si = static_cast<long long>(r) * a.nblk + col / a.block_size;
+      if (a.scale_mode == 1) si = rr;
+      if (a.scale_mode == 2) si = static_cast<long long>(rr) * a.nblk + col / a.block_size;
       const ST s = sc[si];
       const int z = a.zp ? a.zp[si] : 0;
-      // quantize (ref gptq.py:191-195 -> uniform_quantize)
+      // quantize (ref gptq.py:191-195 -> uniform_quantize); every lane of the row computes it
       int qi;
       float e;
       if constexpr (sizeof(ST) == 8) {
-        const double v = static_cast<double>(w[i]) / s + static_cast<double>(z);
-        double rr = __builtin_rint(v);
-        rr = fmin(fmax(rr, static_cast<double>(a.lo)), static_cast<double>(a.hi));
-        qi = (v != v) ? 0 : static_cast<int>(rr);
+        const double v = static_cast<double>(wi) / s + static_cast<double>(z);
+        double q = __builtin_rint(v);
+        q = fmin(fmax(q, static_cast<double>(a.lo)), static_cast<double>(a.hi));
+        qi = (v != v) ? 0 : static_cast<int>(q);
         int dd = qi - z;
         if (a.diff_bits == 8) dd = static_cast<int8_t>(dd);
         const double dq = static_cast<double>(dd) * s;
-        e = static_cast<float>(static_cast<double>(w[i]) - dq);  // np.subtract(f32, f64, out=f32)
+        e = static_cast<float>(static_cast<double>(wi) - dq);  // np.subtract(f32, f64, out=f32)
       } else {
-        float v = w[i] / s;
+        float v = wi / s;
         v = a.zp_via_f64 ? static_cast<float>(static_cast<double>(v) + static_cast<double>(z))
                          : v + static_cast<float>(z);
-        float rr = __builtin_rintf(v);
-        rr = fminf(fmaxf(rr, a.lo), a.hi);
-        qi = (v != v) ? 0 : static_cast<int>(rr);
+        float q = __builtin_rintf(v);
+        q = fminf(fmaxf(q, a.lo), a.hi);
+        qi = (v != v) ? 0 : static_cast<int>(q);
         int dd = qi - z;
         if (a.diff_bits == 8) dd = static_cast<int8_t>(dd);
         const float dq = static_cast<float>(dd) * s;
-        e = w[i] - dq;
+        e = wi - dq;
       }
-      a.q[static_cast<long long>(r) * a.d + col] = static_cast<int8_t>(qi);
-      e = e / h[i][i];
-      a.err[static_cast<long long>(r) * NB + i] = e;
+      e = e / hd[i];
+      if (live && l == i / kColsPerLane) {
+        a.q[static_cast<long long>(r) * a.d + col] = static_cast<int8_t>(qi);
+        a.err[static_cast<long long>(r) * NB + i] = e;
+      }
       // intra-block rank-1 update: w[:, j] -= outer(err, hinv[c, j]) (product rounded, then subtracted)
+      const float4 hrow = *reinterpret_cast<const float4*>(&h[i][l * kColsPerLane]);
+      const float hv[4] = {hrow.x, hrow.y, hrow.z, hrow.w};
 #pragma unroll
-      for (int j = i + 1; j < NB; ++j) {
-        const float p = e * h[i][j];
-        w[j] = w[j] - p;
+      for (int k = 0; k < kColsPerLane; ++k) {
+        if (l * kColsPerLane + k > i) {
+          const float p = e * hv[k];
+          w[k] = w[k] - p;
+        }
       }
-    } else {
+    } else if (live && l == i / kColsPerLane) {
       a.err[static_cast<long long>(r) * NB + i] = 0.f;
     }
   }
@@ -528,7 +553,7 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
   for (int c0 = 0; c0 < a.d; c0 += NB) {
     a.c0 = c0;
     a.nb = a.d - c0 < NB ? a.d - c0 : NB;
-    const dim3 grid(static_cast<unsigned>((rows + 255) / 256));
+    const dim3 grid(static_cast<unsigned>((rows + (256 / kRowLanes) - 1) / (256 / kRowLanes)));
     if (scale_is_f64)
       hipLaunchKernelGGL((gptq_block_kernel<double>), grid, dim3(256), 0, st, a);
     else
