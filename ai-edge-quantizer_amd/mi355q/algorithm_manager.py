@@ -80,14 +80,17 @@ def _register_weight_algorithm(name, module, ops, calibration_func, update_qsv_f
 _register_weight_algorithm(AlgorithmName.MIN_MAX_UNIFORM_QUANT, naive_min_max_quantize,
                            list(_MATERIALIZERS), naive_min_max_quantize.min_max_calibrate,
                            qsv_utils.moving_average_update)
-# OCTAV (ref :237-320) and MSE (ref :385-419): same op tables, min/max calibration
-for _name, _mod in ((AlgorithmName.OCTAV, octav), (AlgorithmName.MSE, mse)):
-  _register_weight_algorithm(_name, _mod, list(_MATERIALIZERS),
-                             naive_min_max_quantize.min_max_calibrate,
-                             qsv_utils.moving_average_update)
-# GPTQ (ref :421-451): Hessian-collecting calibration + Hessian-merging QSV update
-_register_weight_algorithm(AlgorithmName.GPTQ, gptq,
-                           [_Op.INPUT, _Op.OUTPUT, _Op.FULLY_CONNECTED], gptq.calibrate,
+# OCTAV (ref :237-320): the min/max op table, min/max calibration
+_register_weight_algorithm(AlgorithmName.OCTAV, octav, list(_MATERIALIZERS),
+                           naive_min_max_quantize.min_max_calibrate, qsv_utils.moving_average_update)
+# MSE (ref :385-419): weights of matmul / convolution style ops only
+_register_weight_algorithm(AlgorithmName.MSE, mse,
+                           [_Op.FULLY_CONNECTED, _Op.EMBEDDING_LOOKUP, _Op.CONV_2D,
+                            _Op.DEPTHWISE_CONV_2D, _Op.CONV_2D_TRANSPOSE],
+                           naive_min_max_quantize.min_max_calibrate, qsv_utils.moving_average_update)
+# GPTQ (ref :421-451): FULLY_CONNECTED only; Hessian-collecting calibration + Hessian-merging
+# QSV update
+_register_weight_algorithm(AlgorithmName.GPTQ, gptq, [_Op.FULLY_CONNECTED], gptq.calibrate,
                            qsv_utils.gptq_and_moving_average_update)
 
 # Hadamard rotation (ref :322-383): whole-op materializers, no partial

@@ -65,6 +65,11 @@ RECIPES = {
     "weight_only_wi8_afp32": recipe.weight_only_wi8_afp32(),
     "weight_only_wi4_afp32": recipe.weight_only_wi4_afp32(),
     "default_af32w8float": json.load(open(os.path.join(REF, "recipes/default_af32w8float_recipe.json"))),
+    "default_af32w4float": json.load(open(os.path.join(REF, "recipes/default_af32w4float_recipe.json"))),
+    "dynamic_wi2c_afp32": recipe.dynamic_wi2c_afp32(),
+    "dynamic_wi8_mse": recipe.dynamic_wi8_afp32(algorithm_key="MSE"),
+    "dynamic_wi4_octav": recipe.dynamic_wi4_afp32(algorithm_key="OCTAV"),
+    "dynamic_wi8_tensorwise": recipe.dynamic_wi8c_afp32(granularity=qtyping.QuantGranularity.TENSORWISE),
 }
 
 _SHIM_CLASS = {
