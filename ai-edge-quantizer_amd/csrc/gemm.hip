@@ -208,9 +208,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<typename TL::Elem> g
   }
   __syncthreads();
   int buf = 0;
-#if defined(MI355Q_GEMM_UNROLL1)
-#pragma unroll 1
-#endif
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
     const int kn = k0 + BK;
     const bool more = kn < k_end;
@@ -218,9 +215,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<typename TL::Elem> g
       load_tile<TL>(sa, g.A, g.a_i, g.a_k, i0, kn, g.M, g.K, a_mode, tid);
       load_tile<TL>(sb, g.B, g.b_j, g.b_k, j0, kn, g.N, g.K, b_mode, tid);
     }
-#if defined(MI355Q_GEMM_PIN)
-    if constexpr (!TL::DBUF) __builtin_amdgcn_sched_barrier(0);  // loads first, then the MFMA block
-#endif
     // operand fragments are double-buffered in registers: the ds_reads of k-substep s+1 are
     // issued before the MFMAs of substep s
     T af[2][TM], bf[2][TM];
@@ -243,14 +237,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<typename TL::Elem> g
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = mfma(af[cur][a], bf[cur][b], acc[a][b]);
-#if defined(MI355Q_GEMM_SCHED)
-      // interleave: one ds_read behind every second MFMA of this substep
-#pragma unroll
-      for (int q = 0; q < 2 * TM; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, TM * TM / (2 * TM), 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // DS read
-      }
-#endif
     }
     if constexpr (TL::DBUF) {
       if (more) {
@@ -260,9 +246,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<typename TL::Elem> g
       __syncthreads();
       buf ^= 1;
     } else {
-#if defined(MI355Q_GEMM_PIN)
-      __builtin_amdgcn_sched_barrier(0);  // keep all MFMAs of this K step ahead of the barrier
-#endif
       __syncthreads();  // everyone is done reading the tile
       if (more) {
         store_tile<TL, LD>(sa, As[0], i0, kn, g.M, g.K, a_mode, tid);

@@ -4,7 +4,7 @@
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 \
             SQ_INSTS_VALU_MFMA_MOPS_F64 -d gpurun_out/gptq_pmc -o p -- python tools/path_bench.py --big
   python tools/make_gptq_profiles.py gpurun_out/gptq_pmc > gpurun_out/r01_gptq_mfma_util.txt
-  rocprofv3 --kernel-trace -d gpurun_out/hinv_trace -o p -- python tools/_hinv_prof.py 16384
+  rocprofv3 --kernel-trace -d gpurun_out/hinv_trace -o p -- python tools/hinv_profile.py 16384
   python tools/make_gptq_profiles.py --phases gpurun_out/hinv_trace > gpurun_out/r01_hinv_phases.txt
 """
 import glob
