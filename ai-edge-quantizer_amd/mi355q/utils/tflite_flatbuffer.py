@@ -207,12 +207,11 @@ class OpaqueTableT:
 # Reader
 # --------------------------------------------------------------------------------------
 class _Reader:
-  def __init__(self, buf, fb_end: Optional[int] = None):
+  def __init__(self, buf):
     self.mv = memoryview(buf).cast("B") if not isinstance(buf, memoryview) else buf.cast("B")
     self.u8 = np.frombuffer(self.mv, dtype=np.uint8)
     self.n = len(self.mv)
-    self.spans: list[tuple[int, int]] = []
-    self.fb_end = fb_end
+    self.spans: list[tuple[int, int]] = []   # byte ranges claimed by parsed objects
 
   # -- primitive access --------------------------------------------------------------
   def _check(self, pos: int, size: int, what: str):
@@ -357,10 +356,6 @@ def read_model(buf, verify: bool = True) -> TableT:
   r.mark(0, 8 if has_ident else 4)
   model = r.table(root, "Model")
   # External buffers: data live after the flatbuffer proper.
-  fb_end = r.n
-  ext = [(b.offset, b.size) for b in model.buffers or [] if b.offset > 1 and b.size > 0]
-  if ext:
-    fb_end = min(o for o, _ in ext)
   for b in model.buffers or []:
     if b.offset > 1 and b.size > 0:
       r._check(b.offset, b.size, "external buffer")
