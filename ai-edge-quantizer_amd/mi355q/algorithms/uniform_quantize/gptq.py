@@ -44,7 +44,7 @@ def calibrate(tfl_op, graph_info: qtyping.GraphInfo,
   return out
 
 
-def hessian_of(tensor_content: np.ndarray, num_samples) -> np.ndarray:
+def hessian_of(tensor_content: np.ndarray, num_samples):
   """(2.0 / num_samples) * x.T.dot(x), x = content.reshape(-1, last) (ref :100-107).
 
   float32 content: X^T X on the FP32 MFMA units, scaled into float64 (NumPy's
@@ -54,8 +54,8 @@ def hessian_of(tensor_content: np.ndarray, num_samples) -> np.ndarray:
   x = np.ascontiguousarray(tensor_content.reshape([-1, tensor_content.shape[-1]]))
   alpha = 2.0 / np.asarray(num_samples)
   rt.require_gpu()
-  if x.dtype == np.float32:
-    return rt.to_numpy(ops.gptq_xtx(rt.to_device(x), float(alpha)))
+  if x.dtype == np.float32:   # stays in HBM: merged per sample and consumed by the GPU again
+    return rt.HbmArray(ops.gptq_xtx(rt.to_device(x), float(alpha)))
   if x.dtype == np.float64:
     xd = rt.to_device(x)
     return alpha * rt.to_numpy(ops.gemm(xd, xd, trans_a=True))
@@ -64,12 +64,27 @@ def hessian_of(tensor_content: np.ndarray, num_samples) -> np.ndarray:
 
 def _prepare_hessian_inverse(hessian: np.ndarray, damp_factor: float = 0.01) -> np.ndarray:
   """Damped inverse through Cholesky; float32 result (ref :111-128)."""
-  rt.require_gpu()
-  h = rt.to_device(np.ascontiguousarray(hessian, dtype=np.float64))
-  hinv, info = ops.gptq_hinv(h, damp_factor)
+  hinv, info = _device_hessian_inverse(hessian, damp_factor)
   if int(info.item()) != 0:
     raise np.linalg.LinAlgError("Matrix is not positive definite")
   return rt.to_numpy(hinv)
+
+
+def _device_hessian_inverse(hessian, damp_factor: float = 0.01):
+  """(hinv float32 [d,d], info) on the device. A Hessian that lives in HBM remembers its
+  inverse: q / k / v (and gate / up) share one input activation, hence one Hessian."""
+  rt.require_gpu()
+  if isinstance(hessian, rt.HbmArray):
+    key = ("hinv", float(damp_factor))
+    if key not in hessian.cache:
+      hessian.cache[key] = ops.gptq_hinv(rt.on_device(hessian, torch_f64()), damp_factor)
+    return hessian.cache[key]
+  return ops.gptq_hinv(rt.to_device(np.ascontiguousarray(hessian, dtype=np.float64)), damp_factor)
+
+
+def torch_f64():
+  import torch
+  return torch.float64
 
 
 def _apply_gptq(tensor_content: np.ndarray, quant_params: qtyping.UniformQuantParams,
@@ -85,8 +100,7 @@ def _apply_gptq(tensor_content: np.ndarray, quant_params: qtyping.UniformQuantPa
     raise TypeError("GPTQ expects a 2-D float32 weight")
   rt.require_gpu()
   rows, d = tensor_content.shape
-  h = rt.to_device(np.ascontiguousarray(activation_tensor_qsv["hessian"], dtype=np.float64))
-  hinv, info = ops.gptq_hinv(h, 0.01)
+  hinv, info = _device_hessian_inverse(activation_tensor_qsv["hessian"], 0.01)
   scale, zp = quant_params.scale, quant_params.zero_point
   blockwise = uniform_quantize_tensor.is_blockwise(tensor_quant_config.granularity)
   if blockwise:

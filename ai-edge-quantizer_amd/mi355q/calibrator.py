@@ -33,6 +33,8 @@ class _QsvEncoder(json.JSONEncoder):
       return o.tolist()
     if isinstance(o, np.generic):
       return o.item()
+    if hasattr(o, "__array__"):          # results kept in HBM (runtime.HbmArray)
+      return np.asarray(o).tolist()
     return super().default(o)
 
 

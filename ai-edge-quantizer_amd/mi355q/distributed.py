@@ -205,6 +205,8 @@ def allreduce_hessian(weighted_sum, num_samples: int, group=None):
   (ref: utils/qsv_utils.py:71-88) over all samples yields up to FP64 rounding.
   """
   rank, world = _world(group)
+  if hasattr(weighted_sum, "device_tensor"):      # runtime.HbmArray: reduce it where it lives
+    weighted_sum = weighted_sum.device_tensor
   is_np = isinstance(weighted_sum, np.ndarray)
   t = torch.from_numpy(np.ascontiguousarray(weighted_sum)) if is_np else weighted_sum
   n = torch.tensor([int(num_samples)], dtype=torch.int64)

@@ -50,6 +50,96 @@ def to_device(a, dtype=None) -> torch.Tensor:
   return t.to(device(), non_blocking=True)
 
 
+class HbmArray:
+  """A result that lives in HBM and reaches the host only if somebody asks for it.
+
+  QSV entries are `Any` in the reference's interface (qtyping.QSV); a GPTQ Hessian is d x d
+  float64 (2 GiB at d = 16384) that the calibration loop merges once per sample and the weight
+  update consumes on the GPU again, so copying it out and back for every step would make
+  PCIe the bottleneck of the whole algorithm. NumPy consumers still work: `np.asarray(h)`,
+  `h.shape`, `h.dtype`, indexing and arithmetic all go through a cached host copy made on
+  first use.
+  """
+  __array_priority__ = 100.0
+
+  def __init__(self, tensor: torch.Tensor):
+    self.device_tensor = tensor
+    self._host = None
+    self.cache: dict = {}          # derived device results (e.g. the damped inverse)
+
+  @property
+  def shape(self):
+    return tuple(self.device_tensor.shape)
+
+  @property
+  def ndim(self) -> int:
+    return self.device_tensor.dim()
+
+  @property
+  def dtype(self):
+    return np.dtype(str(self.device_tensor.dtype).replace("torch.", ""))
+
+  @property
+  def size(self) -> int:
+    return self.device_tensor.numel()
+
+  def numpy(self) -> np.ndarray:
+    if self._host is None:
+      self._host = self.device_tensor.cpu().numpy()
+    return self._host
+
+  def __array__(self, dtype=None, copy=None):
+    a = self.numpy()
+    return a if dtype is None else a.astype(dtype, copy=False)
+
+  def __len__(self) -> int:
+    return self.shape[0]
+
+  def __getitem__(self, idx):
+    return self.numpy()[idx]
+
+  def tolist(self):
+    return self.numpy().tolist()
+
+  def __getattr__(self, name):
+    # anything else an ndarray offers (.T, .reshape, .sum, ...) is answered by the host copy
+    if name.startswith("__"):
+      raise AttributeError(name)
+    return getattr(self.numpy(), name)
+
+  def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+    host = [x.numpy() if isinstance(x, HbmArray) else x for x in inputs]
+    return getattr(ufunc, method)(*host, **kwargs)
+
+  def __repr__(self):
+    return f"HbmArray(shape={self.shape}, dtype={self.dtype})"
+
+
+def _host_operator(name):
+  def op(self, other):
+    other = other.numpy() if isinstance(other, HbmArray) else other
+    return getattr(self.numpy(), name)(other)
+  op.__name__ = name
+  return op
+
+
+for _name in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__",
+              "__rtruediv__", "__matmul__", "__rmatmul__", "__eq__", "__ne__", "__lt__", "__le__",
+              "__gt__", "__ge__"):
+  setattr(HbmArray, _name, _host_operator(_name))
+HbmArray.__hash__ = object.__hash__
+HbmArray.__neg__ = lambda self: -self.numpy()
+HbmArray.__abs__ = lambda self: abs(self.numpy())
+
+
+def on_device(a, dtype=None) -> torch.Tensor:
+  """Device tensor of `a` without a copy when `a` already lives in HBM."""
+  if isinstance(a, HbmArray):
+    t = a.device_tensor
+    return t if dtype is None or t.dtype == dtype else t.to(dtype)
+  return to_device(a, dtype)
+
+
 def empty(shape, dtype) -> torch.Tensor:
   return torch.empty(shape, dtype=dtype, device=device())
 

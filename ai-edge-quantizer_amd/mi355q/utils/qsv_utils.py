@@ -40,15 +40,19 @@ def _gptq_merge_hessian(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> tuple[Any, in
   total = n0 + n1
   if total == 0:
     return new_qsv["hessian"], 0
-  h0, h1 = np.asarray(qsv["hessian"]), np.asarray(new_qsv["hessian"])
+  h0, h1 = qsv["hessian"], new_qsv["hessian"]
+  if not (hasattr(h0, "dtype") and hasattr(h1, "dtype")):
+    h0, h1 = np.asarray(h0), np.asarray(h1)
   if h0.dtype == np.float64 and h1.dtype == np.float64 and h0.ndim == 2 and h0.shape == h1.shape \
       and h0.shape[0] == h0.shape[1]:
     from .. import ops
     from .. import runtime as rt
     rt.require_gpu()
-    merged = ops.gptq_hessian_merge(rt.to_device(h0), float(n0), rt.to_device(h1), float(n1))
-    return rt.to_numpy(merged), total
-  return (h0 * n0 + h1 * n1) / total, total
+    merged = ops.gptq_hessian_merge(rt.on_device(h0), float(n0), rt.on_device(h1), float(n1))
+    # Hessians that were produced on the GPU stay there (see runtime.HbmArray)
+    resident = isinstance(h0, rt.HbmArray) or isinstance(h1, rt.HbmArray)
+    return (rt.HbmArray(merged) if resident else rt.to_numpy(merged)), total
+  return (np.asarray(h0) * n0 + np.asarray(h1) * n1) / total, total
 
 
 def gptq_and_moving_average_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qtyping.QSV:

@@ -237,3 +237,28 @@ def test_medium_size_against_oracle(m):
     e = (w - q.astype(np.float32) * ref["scale"]).astype(np.float64)
     return np.einsum("ri,ij,rj->", e, h, e)
   assert loss(p.quantized_data) < loss(plain)
+
+
+def test_hessians_stay_in_hbm_and_behave_like_arrays(m):
+  """calibrate() hands out HBM-resident Hessians (runtime.HbmArray): merging and the weight
+  update never copy them to the host, NumPy code that touches them still works, and the
+  damped inverse is computed once per Hessian (q / k / v share their input's)."""
+  from mi355q import runtime as rt
+  from mi355q.utils import qsv_utils
+  rng = np.random.default_rng(0)
+  x1, x2 = (rng.standard_normal((1, 24, 64)).astype(np.float32) for _ in range(2))
+  h1, h2 = m.gptq.hessian_of(x1, np.array(1)), m.gptq.hessian_of(x2, np.array(1))
+  assert isinstance(h1, rt.HbmArray) and h1._host is None                # nothing copied yet
+  q1 = {"min": np.float32(-1), "max": np.float32(1), "hessian": h1, "num_samples": 1}
+  q2 = {"min": np.float32(-2), "max": np.float32(2), "hessian": h2, "num_samples": 1}
+  merged = qsv_utils.gptq_and_moving_average_update(q1, q2)
+  assert isinstance(merged["hessian"], rt.HbmArray) and h1._host is None and h2._host is None
+  want = (O.gptq_hessian(x1) + O.gptq_hessian(x2)) / 2
+  assert np.max(np.abs(np.asarray(merged["hessian"]) - want)) <= 2e-6 * np.abs(want).max()
+  assert merged["hessian"].T.shape == (64, 64) and (merged["hessian"] - want).dtype == np.float64
+  a = m.gptq._device_hessian_inverse(merged["hessian"])
+  b = m.gptq._device_hessian_inverse(merged["hessian"])
+  assert a[0] is b[0]                                                    # cached on the Hessian
+  mixed = qsv_utils.gptq_and_moving_average_update(
+      {**q1, "hessian": np.asarray(h1)}, {**q2, "hessian": np.asarray(h2)})
+  assert isinstance(mixed["hessian"], np.ndarray) and np.array_equal(mixed["hessian"], np.asarray(merged["hessian"]))
