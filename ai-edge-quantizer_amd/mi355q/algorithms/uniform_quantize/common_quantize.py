@@ -98,6 +98,10 @@ def get_activation_min_max(tensor_content: np.ndarray,
   shape = (1,) * tensor_content.ndim
   if tensor_content.size == 0:
     raise ValueError("zero-size array to reduction operation minimum which has no identity")
+  rec = rt.staged(tensor_content)        # reduced already with the rest of this sample?
+  if rec is not None and (rec["lo"], rec["hi"]) == (valid_float_range_min, valid_float_range_max):
+    mn, mx = rec["minmax"]
+    return {"min": np.reshape(mn, shape), "max": np.reshape(mx, shape)}
   is_int = np.issubdtype(tensor_content.dtype, np.integer)
   # The kernel reads float32; other dtypes are accepted when the conversion is exact
   # (integers below 2^24, float64 holding float32 values) so min / max are unchanged.

@@ -51,9 +51,13 @@ def hessian_of(tensor_content: np.ndarray, num_samples):
   promotion of `2.0 / np.array(n)`). float64 content (the reference's own test
   feeds 1e39): the FP64 MFMA GEMM.
   """
-  x = np.ascontiguousarray(tensor_content.reshape([-1, tensor_content.shape[-1]]))
   alpha = 2.0 / np.asarray(num_samples)
   rt.require_gpu()
+  rec = rt.staged(tensor_content)        # the calibrator put this sample's activations in HBM
+  if rec is not None and tensor_content.dtype == np.float32:
+    xd = rec["dev"].reshape(-1, tensor_content.shape[-1])
+    return rt.HbmArray(ops.gptq_xtx(xd, float(alpha)))
+  x = np.ascontiguousarray(tensor_content.reshape([-1, tensor_content.shape[-1]]))
   if x.dtype == np.float32:   # stays in HBM: merged per sample and consumed by the GPU again
     return rt.HbmArray(ops.gptq_xtx(rt.to_device(x), float(alpha)))
   if x.dtype == np.float64:

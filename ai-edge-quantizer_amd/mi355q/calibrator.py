@@ -18,8 +18,10 @@ import numpy as np
 
 from . import algorithm_manager
 from . import default_policy
+from . import ops
 from . import qtyping
 from . import recipe_manager
+from . import runtime as rt
 from .utils import qsv_utils
 from .utils import tfl_flatbuffer_utils
 
@@ -88,14 +90,22 @@ class Calibrator:
       raise TypeError("a calibration sample must be a {tensor name: ndarray} map (or pass a"
                       " tensor_provider that turns samples into one)")
     self._tensor_content_map.update(contents)
+    self._stage_sample(signature_key, contents, model_recipe_manager)
+    try:
+      self._walk(signature_key, model_recipe_manager)
+    finally:
+      rt.clear_calibration_step()
+
+  def _ops_to_calibrate(self, signature_key, model_recipe_manager):
+    """(subgraph, graph_info, op, op_key, algorithm) of every op the recipe calibrates, in the
+    reference's visiting order (main subgraph first, then subgraphs its ops invoke)."""
     codes = self._flatbuffer_model.operatorCodes
-    updated: set[str] = set()
     todo = [self._main_subgraph(signature_key)]
     while todo:
       sg = self._flatbuffer_model.subgraphs[todo.pop()]
       graph_info = qtyping.GraphInfo(sg.tensors, self._flatbuffer_model.buffers)
-      ops = list(sg.operators) + tfl_flatbuffer_utils.get_subgraph_input_output_operators(sg)
-      for op in ops:
+      ops_ = list(sg.operators) + tfl_flatbuffer_utils.get_subgraph_input_output_operators(sg)
+      for op in ops_:
         if isinstance(op, qtyping.IOOperator):
           op_key = op.op_key
         else:
@@ -108,12 +118,41 @@ class Calibrator:
           continue
         if default_policy.is_non_quantizable_composite_op(op):
           continue
-        calibrate = algorithm_manager.get_quantization_func(alg, op_key, qtyping.QuantizeMode.CALIBRATE)
-        op_qsvs = calibrate(op, graph_info, self._tensor_content_map)
-        update = (self._qsv_update_func if self._is_custom_qsv_update_func
-                  else algorithm_manager.get_update_qsv_func(alg, op_key))
-        updated |= self._update_qsvs(op_qsvs, updated, update)
+        yield sg, graph_info, op, op_key, alg
         todo.extend(tfl_flatbuffer_utils.get_op_side_effect_subgraphs(op))
+
+  def _stage_sample(self, signature_key, contents, model_recipe_manager) -> None:
+    """Every float32 activation the walk will read goes to HBM once and gets its (min, max)
+    from one batched launch (the per-op calibration functions then find it staged)."""
+    from .algorithms.uniform_quantize import common_quantize
+    lo, hi = -3e38, 3e38                      # the calibration functions' default valid_range
+    wanted: dict[int, np.ndarray] = {}
+    for sg, graph_info, op, _, _ in self._ops_to_calibrate(signature_key, model_recipe_manager):
+      for tid in common_quantize.get_tensor_indices_requiring_calibration(op, graph_info):
+        tensor = sg.tensors[tid]
+        if self._flatbuffer_model.buffers[tensor.buffer].data is not None:
+          continue
+        arr = self._tensor_content_map.get(tfl_flatbuffer_utils.get_tensor_name(tensor))
+        if isinstance(arr, np.ndarray) and arr.dtype == np.float32 and arr.size:
+          wanted[id(arr)] = arr
+    if not wanted:
+      return
+    rt.require_gpu()
+    arrays = list(wanted.values())
+    dev = [rt.to_device(np.ascontiguousarray(a).reshape(-1)) for a in arrays]
+    mm = rt.to_numpy(ops.act_minmax(dev, lo, hi)).astype(np.float32)
+    rt.stage_calibration_step({
+        id(a): {"host": a, "dev": d, "lo": lo, "hi": hi, "minmax": (mm[i, 0], mm[i, 1])}
+        for i, (a, d) in enumerate(zip(arrays, dev))})
+
+  def _walk(self, signature_key, model_recipe_manager) -> None:
+    updated: set[str] = set()
+    for _, graph_info, op, op_key, alg in self._ops_to_calibrate(signature_key, model_recipe_manager):
+      calibrate = algorithm_manager.get_quantization_func(alg, op_key, qtyping.QuantizeMode.CALIBRATE)
+      op_qsvs = calibrate(op, graph_info, self._tensor_content_map)
+      update = (self._qsv_update_func if self._is_custom_qsv_update_func
+                else algorithm_manager.get_update_qsv_func(alg, op_key))
+      updated |= self._update_qsvs(op_qsvs, updated, update)
 
   # ---- public API (ref :312-392) -----------------------------------------------------------------
   def calibrate(self, calibration_dataset: Mapping[Optional[str], Iterable[Any]],

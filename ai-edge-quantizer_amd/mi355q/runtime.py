@@ -140,6 +140,28 @@ def on_device(a, dtype=None) -> torch.Tensor:
   return to_device(a, dtype)
 
 
+# ---- calibration-step staging ----------------------------------------------------------------
+# While the calibrator walks the ops of one sample, every activation it will touch is already in
+# HBM with its (min, max): staged once, reduced in one batched launch. Keyed by the identity of
+# the host array the caller supplied (the entry keeps that array alive, so ids cannot be reused).
+_STEP_STAGE: dict[int, dict] = {}
+
+
+def stage_calibration_step(entries: dict[int, dict]) -> None:
+  _STEP_STAGE.clear()
+  _STEP_STAGE.update(entries)
+
+
+def clear_calibration_step() -> None:
+  _STEP_STAGE.clear()
+
+
+def staged(host_array):
+  """The staging record of `host_array` ({"host", "dev", "lo", "hi", "minmax"}) or None."""
+  rec = _STEP_STAGE.get(id(host_array))
+  return rec if rec is not None and rec["host"] is host_array else None
+
+
 def empty(shape, dtype) -> torch.Tensor:
   return torch.empty(shape, dtype=dtype, device=device())
 
