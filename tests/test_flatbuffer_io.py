@@ -164,3 +164,30 @@ def test_constant_buffer_sharing_follows_reference_rule():
   assert tu.get_constant_buffer(np.arange(5, dtype=np.float32), model, force_duplicate_buffer=True) == 5
   tid = tu.add_new_constant_tensor(b"t", np.arange(5, dtype=np.float32), q.TensorType.FLOAT32, sg, model)
   assert sg.tensors[tid].buffer == 5 and sg.tensors[tid].shape == [5]
+
+
+def test_corrupted_files_are_refused_cleanly():
+  """Byte flips, truncation and random 32-bit words: the reader either parses (the damage hit
+  payload bytes or padding) or raises FlatbufferError - never another exception, never a hang
+  (uoffsets only point forward, every access is bounds-checked first)."""
+  rng = np.random.default_rng(0)
+  small = [p for p in MODELS if os.path.getsize(p) < 6000]
+  outcomes = {"ok": 0, "refused": 0}
+  for it in range(1500):
+    data = bytearray(open(small[it % len(small)], "rb").read())
+    mode = it % 3
+    if mode == 0:
+      for _ in range(int(rng.integers(1, 4))):
+        data[int(rng.integers(0, len(data)))] = int(rng.integers(0, 256))
+    elif mode == 1:
+      data = data[:int(rng.integers(0, len(data)))]
+    else:
+      i = int(rng.integers(0, len(data) - 4))
+      data[i:i + 4] = int(rng.integers(0, 2**32)).to_bytes(4, "little")
+    try:
+      m = fb.read_model(bytes(data))
+      fb.write_model(m)
+      outcomes["ok"] += 1
+    except fb.FlatbufferError:
+      outcomes["refused"] += 1
+  assert outcomes["refused"] > 500 and outcomes["ok"] > 100
