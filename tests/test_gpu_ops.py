@@ -349,3 +349,31 @@ def test_c3_full_size_digest(ops, ref_digests, layer):
   assert sha(host(r["q"])) == d["q"]
   assert sha(host(r["scale"])) == d["scale"]
   assert sha(host(r["scale_f16"])) == d["scale_f16"]
+
+
+@pytest.mark.parametrize("h", [2, 16, 128, 256, 512, 1024, 2048, 4096, 8192])
+def test_hadamard_rotate_all_sizes_partial_tiles_and_in_place(h):
+  """Both FWHT kernels (radix-2 in LDS below 256 / above 4096, radix-16 tile kernel between)
+  against the dense H / sqrt(h) product in float64: T2 (only the float32 add order differs),
+  including a vector count that leaves the last 4096-element tile partly empty, and out == x."""
+  import torch
+  from mi355q import ops
+  import oracle.aeq_oracle as O
+  rng = np.random.default_rng(h)
+  n_vec = max(3, (3 * 4096) // h + 5)               # not a whole number of tiles
+  x = rng.standard_normal((n_vec, h)).astype(np.float32)
+  hm = O.hadamard_matrix(h).astype(np.float64)
+  want = x.astype(np.float64) @ hm
+  xd = torch.from_numpy(x).cuda()
+  got = ops.hadamard_rotate(xd, h).cpu().numpy()
+  assert got.shape == x.shape and got.dtype == np.float32
+  tol = 2e-6 * np.abs(x).max(axis=1, keepdims=True) * np.sqrt(h)
+  assert np.all(np.abs(got - want) <= tol)
+  # an involution up to rounding: H / sqrt(h) is symmetric and orthogonal
+  back = ops.hadamard_rotate(torch.from_numpy(got).cuda(), h).cpu().numpy()
+  assert np.all(np.abs(back - x) <= 2 * tol + 1e-6)
+  # in place through the C ABI (out == x is allowed by include/mi355q.h)
+  from mi355q import _ffi, runtime as rt
+  inplace = torch.from_numpy(x).cuda()
+  _ffi.check(_ffi.lib().mi355q_hadamard_rotate_f32(rt.ptr(inplace), n_vec, h, rt.ptr(inplace), rt.stream_ptr()))
+  assert np.array_equal(inplace.cpu().numpy(), got)
