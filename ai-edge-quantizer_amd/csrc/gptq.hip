@@ -85,6 +85,10 @@ __global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __
 // X21 = -X22 (L21 X11), 12 barriers in total) instead of 64 serial forward substitutions.
 __device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // c <= r
 
+__device__ __forceinline__ float lane_bcast32(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
 __device__ __forceinline__ double lane_bcast64(double v, int src_lane) {
   const long long bits = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_readlane(static_cast<int>(bits), src_lane);
@@ -302,17 +306,38 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
     w[k] = c < a.nb ? wrow[c] : 0.f;
   }
   const ST* sc = static_cast<const ST*>(a.scale);
-  const int group_base = (threadIdx.x & 63) & ~(kRowLanes - 1);
+  const int group = (threadIdx.x & 63) / kRowLanes;    // which of the wave's 4 rows
+  // Scale / zero point change at most every 32 columns when the block size is a multiple of 32
+  // (all BLOCKWISE_* granularities; the block starts at a multiple of 64): two loads per kernel,
+  // none inside the dependent chain.
+  auto scale_index = [&](int col) -> long long {
+    if (a.scale_mode == 1) return rr;
+    if (a.scale_mode == 2) return static_cast<long long>(rr) * a.nblk + col / a.block_size;
+    return 0;
+  };
+  const bool per_step = a.scale_mode == 2 && a.block_size % 32 != 0;
+  const long long si0 = scale_index(a.c0), si1 = scale_index(a.c0 + (a.nb > 32 ? 32 : 0));
+  const ST s_lo = sc[si0], s_hi = sc[si1];
+  const int z_lo = a.zp ? a.zp[si0] : 0, z_hi = a.zp ? a.zp[si1] : 0;
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     if (i < a.nb) {  // uniform
       const int col = a.c0 + i;
-      const float wi = __shfl(w[i % kColsPerLane], group_base + i / kColsPerLane, 64);
-      long long si = 0;
-      if (a.scale_mode == 1) si = rr;
-      if (a.scale_mode == 2) si = static_cast<long long>(rr) * a.nblk + col / a.block_size;
-      const ST s = sc[si];
-      const int z = a.zp ? a.zp[si] : 0;
+      // column i of each of the wave's rows lives in lane 16*g + i/4: four uniform readlanes
+      // and a select instead of a ds_bpermute round trip
+      const float mine = w[i % kColsPerLane];
+      const float w0 = lane_bcast32(mine, 0 * kRowLanes + i / kColsPerLane);
+      const float w1 = lane_bcast32(mine, 1 * kRowLanes + i / kColsPerLane);
+      const float w2 = lane_bcast32(mine, 2 * kRowLanes + i / kColsPerLane);
+      const float w3 = lane_bcast32(mine, 3 * kRowLanes + i / kColsPerLane);
+      const float wi = group == 0 ? w0 : group == 1 ? w1 : group == 2 ? w2 : w3;
+      ST s = i < 32 ? s_lo : s_hi;
+      int z = i < 32 ? z_lo : z_hi;
+      if (per_step) {  // uniform; odd block sizes (the reference's tests use them): look it up
+        const long long si = scale_index(col);
+        s = sc[si];
+        z = a.zp ? a.zp[si] : 0;
+      }
       // quantize (ref gptq.py:191-195 -> uniform_quantize); every lane of the row computes it
       int qi;
       float e;
@@ -347,10 +372,9 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
       const float hv[4] = {hrow.x, hrow.y, hrow.z, hrow.w};
 #pragma unroll
       for (int k = 0; k < kColsPerLane; ++k) {
-        if (l * kColsPerLane + k > i) {
-          const float p = e * hv[k];
-          w[k] = w[k] - p;
-        }
+        const float p = e * hv[k];
+        const float updated = w[k] - p;
+        w[k] = (l * kColsPerLane + k > i) ? updated : w[k];   // select, not a branch
       }
     } else if (live && l == i / kColsPerLane) {
       a.err[static_cast<long long>(r) * NB + i] = 0.f;
@@ -534,6 +558,7 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
   if (scale_mode == 2 && (block_size <= 0 || d % block_size != 0))
     return fail(MI355Q_BAD_SHAPE, "Quantized dimension %lld is not divisible by block size %d.",
                 static_cast<long long>(d), block_size);
+
   if (!w || !hinv || !scale || !q_out) return fail(MI355Q_BAD_ARG, "null pointer");
   const size_t need = mi355q_gptq_apply_workspace_bytes(rows, d);
   if (!workspace || workspace_bytes < need)
