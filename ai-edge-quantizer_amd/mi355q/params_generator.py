@@ -145,17 +145,14 @@ class ParamsGenerator:
       if r.consumers:
         cur.consumers = (cur.consumers or []) + list(r.consumers)
 
-  def generate_quantization_parameters(self, model_recipe_manager,
-                                       model_qsvs: Optional[dict[str, qtyping.QSV]] = None,
-                                       enable_progress_bar: bool | None = None):
-    del enable_progress_bar
-    if model_recipe_manager.need_calibration() and not model_qsvs:
-      raise RuntimeError(
-          "Model quantization statistics values (QSVs) are required for the input recipe. This"
-          " can be obtained by running calibration on sample dataset.")
-    model_qsvs = model_qsvs if model_qsvs is not None else {}
+  def plan_ops(self, model_recipe_manager) -> list[tuple]:
+    """The op walk without any arithmetic: one (graph_info, op, op_id, op_key, algorithm, config)
+    item per real or virtual op, in the reference's order; algorithm NO_QUANTIZE (config None) for
+    ops the recipe, the policy or a skipped composite leaves alone (ref :100-160)."""
     codes = self.float_model.operatorCodes
+    no_q = algorithm_manager.AlgorithmName.NO_QUANTIZE
     skip_subgraphs: set[int] = set()     # decompositions of composite ops left unquantized
+    items = []
     for sg_ind, subgraph in enumerate(self.float_model.subgraphs):
       graph_info = qtyping.GraphInfo(subgraph.tensors, self.float_model.buffers)
       ops = list(subgraph.operators) + tfl_flatbuffer_utils.get_subgraph_input_output_operators(subgraph)
@@ -166,19 +163,42 @@ class ParamsGenerator:
           code = codes[op.opcodeIndex].builtinCode
           op_key = tfl_flatbuffer_utils.TFL_OP_CODE_TO_NAME.get(code)
           if op_key is None:
-            self._merge(self._no_quant_results(op_id, op, subgraph.tensors))
+            items.append((graph_info, op, op_id, None, no_q, None))
             continue
         scope = tfl_flatbuffer_utils.get_op_scope(op, subgraph.tensors)
         alg, cfg = model_recipe_manager.get_quantization_configs(op_key, scope)
         if sg_ind in skip_subgraphs or default_policy.is_non_quantizable_composite_op(op):
-          alg = algorithm_manager.AlgorithmName.NO_QUANTIZE
-        if alg == algorithm_manager.AlgorithmName.NO_QUANTIZE:
+          alg = no_q
+        if alg == no_q:
           skip_subgraphs.update(tfl_flatbuffer_utils.get_op_side_effect_subgraphs(op))
-          self._merge(self._no_quant_results(op_id, op, subgraph.tensors))
-          continue
-        fn = algorithm_manager.get_quantization_func(alg, op_key, qtyping.QuantizeMode.MATERIALIZE)
-        self._merge(fn(op_info=qtyping.OpInfo(op, op_key, op_id, cfg), graph_info=graph_info,
-                       tensor_name_to_qsv=model_qsvs,
-                       tensor_quant_params_cache=self._tensor_quant_params_cache))
+          cfg = None
+        items.append((graph_info, op, op_id, op_key, alg, cfg))
+    return items
+
+  def materialize_op(self, item: tuple, model_qsvs: dict[str, qtyping.QSV]):
+    """Per-tensor results of one planned op (the GPU work happens here)."""
+    graph_info, op, op_id, op_key, alg, cfg = item
+    if alg == algorithm_manager.AlgorithmName.NO_QUANTIZE:
+      return self._no_quant_results(op_id, op, graph_info.subgraph_tensors)
+    fn = algorithm_manager.get_quantization_func(alg, op_key, qtyping.QuantizeMode.MATERIALIZE)
+    return fn(op_info=qtyping.OpInfo(op, op_key, op_id, cfg), graph_info=graph_info,
+              tensor_name_to_qsv=model_qsvs, tensor_quant_params_cache=self._tensor_quant_params_cache)
+
+  def finish(self, per_op_results) -> dict[str, qtyping.TensorTransformationParams]:
+    """Merges per-op results (in plan order) and applies the shared-constant fix-ups."""
+    for results in per_op_results:
+      self._merge(results)
     self._check_and_fix_buffer_sharing()
     return self.model_quant_results
+
+  def generate_quantization_parameters(self, model_recipe_manager,
+                                       model_qsvs: Optional[dict[str, qtyping.QSV]] = None,
+                                       enable_progress_bar: bool | None = None):
+    del enable_progress_bar
+    if model_recipe_manager.need_calibration() and not model_qsvs:
+      raise RuntimeError(
+          "Model quantization statistics values (QSVs) are required for the input recipe. This"
+          " can be obtained by running calibration on sample dataset.")
+    model_qsvs = model_qsvs if model_qsvs is not None else {}
+    return self.finish(self.materialize_op(item, model_qsvs)
+                       for item in self.plan_ops(model_recipe_manager))

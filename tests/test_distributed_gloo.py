@@ -104,17 +104,82 @@ def _worker_shard_quantize(rank, world, port, out):
   dist.destroy_process_group()
 
 
-def _run(worker, world=2):
+def _register_oracle_algorithm():
+  """Re-registers the min/max key, in this test process only, with the CPU oracle as
+  get_tensor_quant_params, so that the model-level sharding logic can run without a GPU (the
+  product algorithms need one)."""
+  import functools
+  from mi355q import algorithm_manager as am, default_policy, qtyping
+  from mi355q.algorithms.uniform_quantize import common_quantize, naive_min_max_quantize
+  from oracle import aeq_oracle as O
+  key = am.AlgorithmName.MIN_MAX_UNIFORM_QUANT.value
+
+  def get_tensor_quant_params(op_info, cfg, tensor_content=None, tensor_qsv=None):
+    g = cfg.granularity
+    r = O.min_max_quant_params(tensor_content, cfg.num_bits, cfg.symmetric,
+                               getattr(g, "name", str(g)), op=op_info.op_name.name, qsv=tensor_qsv)
+    return qtyping.UniformQuantParams(**r)
+  for op, fn in am._MATERIALIZERS.items():
+    am.register_quantized_op(key, op, naive_min_max_quantize.init_qsvs,
+                             calibration_func=naive_min_max_quantize.min_max_calibrate,
+                             materialize_func=functools.partial(fn, get_tensor_quant_params),
+                             update_qsv_func=None)
+  del default_policy, common_quantize
+  return key
+
+
+_MODEL_CASES = [("conv_fc_mnist.tflite", 8, "CHANNELWISE"), ("toy_model_with_kv_cache_multi_signature.tflite", 8, "CHANNELWISE"),
+                ("weight_sharing_fcs.tflite", 8, "CHANNELWISE")]
+
+
+def _model_recipe(key, bits, gran):
+  return [dict(regex=".*", operation="*", algorithm_key=key, op_config=dict(
+      weight_tensor_config=dict(num_bits=bits, symmetric=True, granularity=gran, dtype="INT"),
+      compute_precision="INTEGER", explicit_dequantize=False, skip_checks=False, min_weight_elements=0))]
+
+
+def _worker_model(rank, world, port, out):
+  dist = _setup(rank, world, port)
+  from mi355q import distributed as D, quantizer
+  key = _register_oracle_algorithm()
+  got = []
+  for name, bits, gran in _MODEL_CASES:
+    path = os.path.join(ROOT, "tests", "golden", "models", name)
+    recipe = _model_recipe(key, bits, gran)
+    sharded = D.quantize_model_sharded(path, recipe)
+    single = bytes(quantizer.Quantizer(path, recipe).quantize().quantized_model) if rank == 0 else None
+    got.append((None if sharded is None else bytes(sharded), single))
+  out.put((rank, got))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def _run(worker, world=2, timeout=300):
   ctx = mp.get_context("spawn")
-  q = ctx.SimpleQueue()
+  q = ctx.Queue()
   port = _free_port()
   procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
   for p in procs:
     p.start()
-  results = [q.get() for _ in range(world)]
-  for p in procs:
-    p.join(120)
-    assert p.exitcode == 0
+  results = []
+  try:
+    import queue as _queue
+    import time
+    deadline = time.time() + timeout
+    while len(results) < world:
+      try:
+        results.append(q.get(timeout=1.0))
+      except _queue.Empty:
+        dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+        assert not dead, f"worker exited with {dead}"
+        assert time.time() < deadline, "workers timed out"
+    for p in procs:
+      p.join(120)
+      assert p.exitcode == 0
+  finally:
+    for p in procs:
+      if p.is_alive():
+        p.kill()
   return sorted(results, key=lambda r: r[0])
 
 
@@ -177,3 +242,9 @@ def test_tensor_sharded_quantize_gathers_everything_on_rank0():
   assert seen0 and seen1  # both ranks did work
   for n, w in tensors.items():
     assert np.array_equal(res0[n], O.min_max_quant_params(w, 8, True, "CHANNELWISE")["quantized_data"])
+
+
+def test_model_level_sharded_quantize_equals_single_process():
+  (r0, got0), (r1, got1) = _run(_worker_model)
+  for (sharded, single), (other, _) in zip(got0, got1):
+    assert other is None and sharded is not None and sharded == single
