@@ -59,6 +59,15 @@ PROTOTYPES = {
     "mi355q_gptq_apply_workspace_bytes": (c_size, [c_i64, c_i64]),
     "mi355q_gptq_apply_f32": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32,
                                       c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_oscar_col_sumsq_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_ptr]),
+    "mi355q_oscar_group_terms_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_i32, c_ptr, c_ptr, c_ptr,
+                                             c_ptr, c_ptr]),
+    "mi355q_oscar_winner_energy_f64": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_i32, c_ptr, c_ptr]),
+    "mi355q_oscar_clip_workspace_bytes": (c_i32, [c_i64, c_i64, c_i64, ctypes.POINTER(ctypes.c_size_t)]),
+    "mi355q_oscar_clip_bounds_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
+                                             c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_oscar_quantize_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i32, c_i32,
+                                          c_ptr, c_ptr]),
 }
 
 STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "BAD_SHAPE", -3: "UNSUPPORTED", -4: "HIP_ERROR"}

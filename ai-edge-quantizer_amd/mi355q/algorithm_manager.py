@@ -21,6 +21,7 @@ from .algorithms.uniform_quantize import hadamard_rotation
 from .algorithms.uniform_quantize import mse
 from .algorithms.uniform_quantize import naive_min_max_quantize
 from .algorithms.uniform_quantize import octav
+from .algorithms.uniform_quantize import oscar
 from .utils import qsv_utils
 
 _Op = qtyping.TFLOperationName
@@ -51,7 +52,7 @@ class AlgorithmName(str, enum.Enum):
   DECOMPOSED_HADAMARD_ROTATION = hadamard_rotation.DECOMPOSED_ALGORITHM_KEY
   MSE = mse.ALGORITHM_KEY
   GPTQ = gptq.ALGORITHM_KEY
-  OSCAR = "OSCAR"
+  OSCAR = oscar.ALGORITHM_KEY
 
 
 _MATERIALIZERS = {
@@ -92,6 +93,14 @@ _register_weight_algorithm(AlgorithmName.MSE, mse,
 # QSV update
 _register_weight_algorithm(AlgorithmName.GPTQ, gptq, [_Op.FULLY_CONNECTED], gptq.calibrate,
                            qsv_utils.gptq_and_moving_average_update)
+
+# OSCAR (ref :453-480): FULLY_CONNECTED only, whole-op materializer, mu2-collecting calibration
+register_op_quant_config_validation_func(AlgorithmName.OSCAR, common_quantize.check_op_quantization_config)
+register_config_check_policy_func(AlgorithmName.OSCAR, default_policy.DEFAULT_CONFIG_CHECK_POLICY)
+register_quantized_op(AlgorithmName.OSCAR, _Op.FULLY_CONNECTED, naive_min_max_quantize.init_qsvs,
+                      calibration_func=oscar.calibrate,
+                      materialize_func=oscar.materialize_fully_connected,
+                      update_qsv_func=qsv_utils.oscar_and_moving_average_update)
 
 # Hadamard rotation (ref :322-383): whole-op materializers, no partial
 for _name, _fc, _emb in (

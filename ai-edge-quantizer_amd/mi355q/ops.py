@@ -384,3 +384,72 @@ def gptq_apply(w: torch.Tensor, hinv: torch.Tensor, scale: torch.Tensor,
       1 if narrow else 0, 1 if zp_via_f64 else 0, diff_bits, rt.ptr(q), rt.ptr(ws), nbytes,
       rt.stream_ptr()))
   return q
+
+
+# ------------------------------------------------------------------------ OSCAR (f4) ---
+def _f64_dev(a) -> torch.Tensor:
+  return rt.to_device(np.ascontiguousarray(a, dtype=np.float64))
+
+
+def oscar_col_sumsq(x: torch.Tensor, mean: bool) -> torch.Tensor:
+  """x float32 [rows, d] -> float64 [d]: sum_r x[r, j]^2, rows in order (/ rows when mean)."""
+  rt.require_gpu()
+  x = _f32(x)
+  rows, d = x.shape
+  out = rt.empty((d,), torch.float64)
+  _ffi.check(_ffi.lib().mi355q_oscar_col_sumsq_f32(rt.ptr(x), rows, d, int(mean), rt.ptr(out),
+                                                   rt.stream_ptr()))
+  return out
+
+
+def oscar_group_terms(w: torch.Tensor, s: torch.Tensor, g: int):
+  """(sums float64 [d/g], winner int32 [n, d/g], wsq float64 [n, d/g]) for scales s float64 [d]."""
+  rt.require_gpu()
+  w = _f32(w)
+  n, d = w.shape
+  groups = d // g
+  top2 = rt.empty((groups * n,), torch.float64)
+  winner = rt.empty((n, groups), torch.int32)
+  wsq = rt.empty((n, groups), torch.float64)
+  sums = rt.empty((groups,), torch.float64)
+  _ffi.check(_ffi.lib().mi355q_oscar_group_terms_f32(
+      rt.ptr(w), rt.ptr(s), n, d, g, rt.ptr(top2), rt.ptr(winner), rt.ptr(wsq), rt.ptr(sums),
+      rt.stream_ptr()))
+  return sums, winner, wsq
+
+
+def oscar_winner_energy(winner: torch.Tensor, wsq: torch.Tensor, d: int, g: int) -> torch.Tensor:
+  rt.require_gpu()
+  n = winner.shape[0]
+  eff = rt.empty((d,), torch.float64)
+  _ffi.check(_ffi.lib().mi355q_oscar_winner_energy_f64(rt.ptr(winner), rt.ptr(wsq), n, d, g,
+                                                       rt.ptr(eff), rt.stream_ptr()))
+  return eff
+
+
+def oscar_clip_bounds(w: torch.Tensor, s: torch.Tensor, masses: torch.Tensor, g: int,
+                      u: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+  """Optimal clip bound (float64) of every g-element segment of the flattened weight."""
+  import ctypes
+  rt.require_gpu()
+  w = _f32(w)
+  n, d = w.shape
+  need = ctypes.c_size_t(0)
+  _ffi.check(_ffi.lib().mi355q_oscar_clip_workspace_bytes(n, d, g, ctypes.byref(need)))
+  ws = rt.empty((need.value,), torch.uint8)
+  bounds = rt.empty((n * d // g,), torch.float64)
+  _ffi.check(_ffi.lib().mi355q_oscar_clip_bounds_f32(
+      rt.ptr(w), rt.ptr(s), rt.ptr(masses), n, d, g, rt.ptr(u), rt.ptr(noise), rt.ptr(bounds),
+      rt.ptr(ws), need.value, rt.stream_ptr()))
+  return bounds
+
+
+def oscar_quantize(w: torch.Tensor, s: torch.Tensor, scale: torch.Tensor, g: int, qlo: int,
+                   qhi: int) -> torch.Tensor:
+  rt.require_gpu()
+  w = _f32(w)
+  n, d = w.shape
+  out = rt.empty((n, d), torch.int8)
+  _ffi.check(_ffi.lib().mi355q_oscar_quantize_f32(rt.ptr(w), rt.ptr(s), rt.ptr(scale), n, d, g, qlo,
+                                                  qhi, rt.ptr(out), rt.stream_ptr()))
+  return out

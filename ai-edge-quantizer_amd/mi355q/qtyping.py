@@ -37,6 +37,8 @@ QuantizationParametersT = schema.QuantizationParametersT
 BlockwiseQuantizationT = schema.BlockwiseQuantizationT
 FullyConnectedOptionsT = schema.FullyConnectedOptionsT
 BatchMatMulOptionsT = schema.BatchMatMulOptionsT
+MulOptionsT = schema.MulOptionsT
+ActivationFunctionType = schema.ActivationFunctionType
 StableHLOCompositeOptionsT = schema.StableHLOCompositeOptionsT
 SignatureDefT = schema.SignatureDefT
 TensorMapT = schema.TensorMapT

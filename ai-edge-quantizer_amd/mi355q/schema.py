@@ -86,6 +86,7 @@ class BuiltinOptions(enum.IntEnum):
   NONE = 0
   FullyConnectedOptions = 8
   ReshapeOptions = 17
+  MulOptions = 21
   DequantizeOptions = 38
   QuantizeOptions = 89
 
@@ -105,6 +106,7 @@ QuantizationParametersT = _fb.QuantizationParametersT
 BlockwiseQuantizationT = _fb.BlockwiseQuantizationT
 FullyConnectedOptionsT = _fb.FullyConnectedOptionsT
 BatchMatMulOptionsT = _fb.BatchMatMulOptionsT
+MulOptionsT = _fb.MulOptionsT
 StableHLOCompositeOptionsT = _fb.StableHLOCompositeOptionsT
 SignatureDefT = _fb.SignatureDefT
 TensorMapT = _fb.TensorMapT
@@ -114,3 +116,12 @@ MetadataT = _fb.MetadataT
 def tensor_name(tensor: Any) -> Optional[str]:
   n = tensor.name
   return n.decode("utf-8") if isinstance(n, (bytes, bytearray)) else n
+
+
+class ActivationFunctionType(enum.IntEnum):
+  NONE = 0
+  RELU = 1
+  RELU_N1_TO_1 = 2
+  RELU6 = 3
+  TANH = 4
+  SIGN_BIT = 5

@@ -36,7 +36,7 @@ class TransformationPerformer:
         # the custom-op form stores its options as a FlexBuffer (third-party encoder, unpinned)
         _T.INSERT_HADAMARD_ROTATION: _unsupported("INSERT_HADAMARD_ROTATION (custom op with FlexBuffer options)"),
         _T.INSERT_DECOMPOSED_HADAMARD_ROTATION: graph_edits.insert_decomposed_hadamard_rotation,
-        _T.INSERT_MULTIPLY: _unsupported("INSERT_MULTIPLY"),
+        _T.INSERT_MULTIPLY: graph_edits.insert_multiply,
     }
     self._current_index: list[list[int]] = []    # [subgraph][float op index] -> index now
     self._inserted: list[list[int]] = []         # [subgraph] -> index now of each inserted op

@@ -178,3 +178,44 @@ def insert_decomposed_hadamard_rotation(ti: _Input) -> qtyping.TransformationInf
   at = max(ti.producer + 1, min(ti.consumers))
   sg.operators[at:at] = [pre, fc, post]
   return qtyping.TransformationInfo(op_id=at, num_ops_added=3, output_tensor_id=post_out)
+
+
+def insert_multiply(ti: _Input) -> qtyping.TransformationInfo:
+  """x -> MUL(x, multiplier) feeding the FULLY_CONNECTED consumers whose weight columns OSCAR
+  scaled by 1/multiplier; the constant is shared between ops asking for the same vector
+  (ref insert_multiply.py:24-129)."""
+  p = ti.quant_params
+  if not isinstance(p, qtyping.UniformQuantParams):
+    raise ValueError("Insert multiply supports uniform quantization only.")
+  if p.custom_algorithm_param is None or "multiplier" not in p.custom_algorithm_param:
+    raise ValueError('Custom algorithm parameter "multiplier" is not set but multiply op'
+                     " insertion is requested.")
+  sg, model = ti.subgraph, ti.model
+  tensor = sg.tensors[ti.tensor_id]
+  if tensor.type != qtyping.TensorType.FLOAT32:
+    raise ValueError(f"The insert multiply op supports float32 tensors only. Got {tensor.type}"
+                     " tensor.")
+  name = _raw_name(tensor)
+  f32 = qtyping.TensorType.FLOAT32
+  multiplier = transformation_utils.add_new_constant_tensor(
+      name + b"_multiplier", np.asarray(p.custom_algorithm_param["multiplier"], dtype=np.float32),
+      f32, sg, model, allow_tensor_sharing=True)
+  shape = list(tensor.shapeSignature if tensor.shapeSignature is not None else tensor.shape)
+  scaled = transformation_utils.add_new_activation_tensor(name + b"_scaled", shape, f32, sg)
+  code = transformation_utils.add_op_code(qtyping.BuiltinOperator.MUL, model.operatorCodes, "MUL")
+  mul = qtyping.OperatorT(
+      opcodeIndex=code, inputs=[ti.tensor_id, multiplier], outputs=[scaled],
+      builtinOptionsType=int(qtyping.BuiltinOptions.MulOptions),
+      builtinOptions=qtyping.MulOptionsT(
+          fusedActivationFunction=int(qtyping.ActivationFunctionType.NONE)))
+  updated = False
+  for consumer in ti.consumers:
+    if _op_code_of(ti, consumer) == qtyping.BuiltinOperator.FULLY_CONNECTED:
+      sg.operators[consumer].inputs[0] = scaled
+      updated = True
+  if not updated:
+    raise ValueError("The insert multiply op supports fully connected consumers only, but no"
+                     " such ops were found.")
+  at = max(ti.producer + 1, min(ti.consumers))
+  sg.operators.insert(at, mul)
+  return qtyping.TransformationInfo(op_id=at, num_ops_added=1, output_tensor_id=scaled)

@@ -55,6 +55,30 @@ def _gptq_merge_hessian(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> tuple[Any, in
   return (np.asarray(h0) * n0 + np.asarray(h1) * n1) / total, total
 
 
+def _oscar_merge_mu2(qsv1: qtyping.QSV, qsv2: qtyping.QSV):
+  """Sample-weighted mean of the second-moment vectors (ref :125-158)."""
+  if "mu2" not in qsv1 and "mu2" not in qsv2:
+    return None, 0
+  if "mu2" not in qsv1:
+    return qsv2.get("mu2"), qsv2.get("num_samples", 0)
+  if "mu2" not in qsv2:
+    return qsv1.get("mu2"), qsv1.get("num_samples", 0)
+  n0, n1 = qsv1.get("num_samples", 0), qsv2.get("num_samples", 0)
+  total = n0 + n1
+  if total == 0:
+    return qsv2["mu2"], 0
+  return (qsv1["mu2"] * n0 + qsv2["mu2"] * n1) / total, total
+
+
+def oscar_and_moving_average_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qtyping.QSV:
+  """EMA for min/max + sample-weighted mean for mu2 (ref :161-171). O(channels) host math."""
+  if not qsv:
+    return new_qsv
+  out = moving_average_update(qsv, new_qsv)
+  out["mu2"], out["num_samples"] = _oscar_merge_mu2(qsv, new_qsv)
+  return out
+
+
 def gptq_and_moving_average_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qtyping.QSV:
   """EMA for min/max + sample-weighted mean for the Hessian (ref :71-102)."""
   if not qsv:

@@ -46,7 +46,7 @@ _NP = {"bool": np.bool_, "i8": np.int8, "u8": np.uint8, "i16": np.int16, "u16": 
 
 # Union member tables of QuantizationDetails / SparseIndexVector / the option unions that hold
 # offsets. Everything else in BuiltinOptions / BuiltinOptions2 is carried opaquely.
-_BUILTIN_OPTIONS = {3: "ConcatEmbeddingsOptions", 8: "FullyConnectedOptions", 17: "ReshapeOptions",
+_BUILTIN_OPTIONS = {3: "ConcatEmbeddingsOptions", 8: "FullyConnectedOptions", 17: "ReshapeOptions", 21: "MulOptions",
                     30: "SqueezeOptions", 101: "BatchMatMulOptions", 111: "VarHandleOptions",
                     115: "BucketizeOptions"}
 _BUILTIN_OPTIONS2 = {21: "StableHLOCompositeOptions"}
@@ -102,6 +102,7 @@ SCHEMA: dict[str, list[tuple]] = {
     "FullyConnectedOptions": [("fusedActivationFunction", "i8", 0), ("weightsFormat", "i8", 0),
                               ("keepNumDims", "bool", False), ("asymmetricQuantizeInputs", "bool", False),
                               ("quantizedBiasType", "i8", 0)],
+    "MulOptions": [("fusedActivationFunction", "i8", 0)],     # written by INSERT_MULTIPLY
     "BatchMatMulOptions": [("adjX", "bool", False), ("adjY", "bool", False),
                            ("asymmetricQuantizeInputs", "bool", False)],
     # Option tables that hold offsets.
@@ -169,6 +170,7 @@ StableHLOCompositeOptionsT = CLASSES["StableHLOCompositeOptions"]
 ReshapeOptionsT = CLASSES["ReshapeOptions"]
 FullyConnectedOptionsT = CLASSES["FullyConnectedOptions"]
 BatchMatMulOptionsT = CLASSES["BatchMatMulOptions"]
+MulOptionsT = CLASSES["MulOptions"]
 # union type code of each typed option table (Operator.builtinOptionsType / builtinOptions2Type)
 BUILTIN_OPTIONS_CODE = {v: k for k, v in _BUILTIN_OPTIONS.items()}
 BUILTIN_OPTIONS2_CODE = {v: k for k, v in _BUILTIN_OPTIONS2.items()}

@@ -290,6 +290,48 @@ int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d, const flo
                               int32_t zp_via_f64, int32_t diff_bits, int8_t* q_out, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * f4 -- OSCAR (activation-aware channel scaling + optimal clipping), FULLY_CONNECTED weights
+ * w float32 [n, d] (n output channels, d input channels). All arithmetic FP64 as in the
+ * reference; summation orders are NumPy's. The O(d) vector algebra between these calls
+ * (geometric-mean normalisation, clamps) is host NumPy, as in the reference.
+ * ref: algorithms/uniform_quantize/oscar.py
+ * ------------------------------------------------------------------------ */
+/* out[j] = sum_r x[r, j]^2 (rows added in order), divided by rows when mean != 0.
+ *   mean=1: calibration statistic mu2 = np.mean(x*x, axis=0)            (ref oscar.py:318-324)
+ *   mean=0: column energies (w*w).sum(0)                                 (ref oscar.py:224) */
+int32_t mi355q_oscar_col_sumsq_f32(const float* x, int64_t rows, int64_t d, int32_t mean,
+                                   double* out, void* stream);
+/* Per (row, group of g consecutive columns; g == d or g in {32,64,128,256}):
+ *   top = max_j |w[r,j]| * s[j], winner = first argmax, wsq = w[r, winner]^2;
+ *   sums_out[k] = np.sum over rows of top^2 for group k (8192-chunk pairwise order).
+ * The objective of ref oscar.py:175-194 is sum_k sums_out[k] * mass_k (host); winner / wsq
+ * feed mi355q_oscar_winner_energy_f64 (ref oscar.py:236-246).
+ *   top2_workspace double [d/g * n]; winner_out int32 [n, d/g]; wsq_out double [n, d/g] */
+int32_t mi355q_oscar_group_terms_f32(const float* w, const double* s, int64_t n, int64_t d,
+                                     int32_t g, double* top2_workspace, int32_t* winner_out,
+                                     double* wsq_out, double* sums_out, void* stream);
+/* eff_out[j] = sum over rows in order of wsq[r, j/g] where winner[r, j/g] == j
+ * (np.add.at(a_eff, j_star, w[rows, j_star]**2), ref oscar.py:243-246). */
+int32_t mi355q_oscar_winner_energy_f64(const int32_t* winner, const double* wsq, int64_t n,
+                                       int64_t d, int32_t g, double* eff_out, void* stream);
+/* Optimal clip bound of every segment of g consecutive elements of the flattened [n, d]
+ * matrix (g divides d, or g == n*d for TENSORWISE): stable descending sort of |w|*s carrying
+ * the masses m[j], sequential running sums, closed-form candidate per breakpoint interval,
+ * first minimum (ref oscar.py:62-108). u[k] = M_k/(6 qmax^2), noise[k] = M_k/(12 qmax^2) with
+ * M_k the group's total mass + 1e-12, k = column group (host FP64).
+ *   bounds_out double [n*d/g]; workspace: mi355q_oscar_clip_workspace_bytes(n, d, g) */
+int32_t mi355q_oscar_clip_workspace_bytes(int64_t n, int64_t d, int64_t g, size_t* bytes_out);
+int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s, const double* m, int64_t n,
+                                     int64_t d, int64_t g, const double* u, const double* noise,
+                                     double* bounds_out, void* workspace, size_t workspace_bytes,
+                                     void* stream);
+/* out = clip(rint((w * s[j]) / scale[segment]), qlo, qhi) with FP64 product and quotient
+ * (uniform_quantize of the FP64 scaled weight, ref oscar.py:470-478). scale double [n*d/g]. */
+int32_t mi355q_oscar_quantize_f32(const float* w, const double* s, const double* scale, int64_t n,
+                                  int64_t d, int64_t g, int32_t qlo, int32_t qhi, int8_t* out,
+                                  void* stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -678,3 +678,177 @@ def mse_quant_params(w, num_bits: int, granularity: str,
   q = uniform_quantize(w, scale, zp, num_bits, True, quantized_dim=qdim)
   return dict(scale=scale, zero_point=zp, num_bits=num_bits, symmetric=True,
               quantized_dimension=qdim, block_size=0, quantized_data=q)
+
+
+# --------------------------------------------------------------------------
+# f4: OSCAR (activation-aware channel scaling + optimal clipping), all FP64
+# --------------------------------------------------------------------------
+
+_OSCAR_TINY = 1e-12
+_OSCAR_S_RANGE = (1e-4, 1e4)
+
+
+def oscar_mu2(x: np.ndarray) -> np.ndarray:
+  """Per-channel (trailing axis) second moment of one activation sample.
+  ref: algorithms/uniform_quantize/oscar.py:318-324."""
+  x2 = np.asarray(x, np.float64).reshape([-1, np.shape(x)[-1]])
+  return np.mean(x2 * x2, axis=0)
+
+
+def oscar_and_moving_average_update(qsv, new_qsv):
+  """EMA for min/max, sample-weighted mean for mu2. ref: utils/qsv_utils.py:125-171."""
+  if not qsv:
+    return new_qsv
+  out = moving_average_update(qsv, new_qsv)
+  has0, has1 = "mu2" in qsv, "mu2" in new_qsv
+  if not has0 and not has1:
+    out["mu2"], out["num_samples"] = None, 0
+  elif not has0:
+    out["mu2"], out["num_samples"] = new_qsv.get("mu2"), new_qsv.get("num_samples", 0)
+  elif not has1:
+    out["mu2"], out["num_samples"] = qsv.get("mu2"), qsv.get("num_samples", 0)
+  else:
+    n0, n1 = qsv.get("num_samples", 0), new_qsv.get("num_samples", 0)
+    if n0 + n1 == 0:
+      out["mu2"], out["num_samples"] = new_qsv["mu2"], 0
+    else:
+      out["mu2"] = (qsv["mu2"] * n0 + new_qsv["mu2"] * n1) / (n0 + n1)
+      out["num_samples"] = n0 + n1
+  return out
+
+
+def oscar_floor_masses(mu2) -> np.ndarray:
+  """Dead channels get a small positive mass. ref: oscar.py:56-59."""
+  mu2 = np.asarray(mu2, np.float64)
+  return np.maximum(mu2, float(np.max(mu2)) * 1e-8 + _OSCAR_TINY)
+
+
+def oscar_group_clip(mag: np.ndarray, masses: np.ndarray, qmax: int) -> np.ndarray:
+  """Per row of `mag` [n, g]: the clip bound c minimising
+      c^2 * M / (12 qmax^2) + sum_j max(mag_j - c, 0)^2 * m_j,   M = sum(m) + tiny.
+  With the k largest magnitudes clipped the objective is a quadratic in c, so every
+  segment between consecutive sorted magnitudes has a closed-form candidate; the best of
+  the g candidates and the "clip nothing" one wins. ref: oscar.py:62-108."""
+  n = mag.shape[0]
+  by_size = np.argsort(-mag, axis=1)
+  top = np.take_along_axis(mag, by_size, 1)
+  m = masses[by_size]
+  total = float(masses.sum()) + _OSCAR_TINY
+  run_m = np.cumsum(m, 1)
+  run_am = np.cumsum(top * m, 1)
+  run_a2m = np.cumsum(top * top * m, 1)
+  cand = 2.0 * run_am / (total / (6.0 * qmax * qmax) + 2.0 * run_m)
+  floor = np.concatenate([top[:, 1:], np.zeros((n, 1))], 1)
+  cand = np.clip(cand, floor, top)
+  noise = total / (12.0 * qmax * qmax)
+  err = (cand ** 2) * noise + run_a2m - 2.0 * cand * run_am + (cand ** 2) * run_m
+  all_c = np.concatenate([top[:, :1], cand], 1)
+  all_e = np.concatenate([(top[:, :1] ** 2) * noise, err], 1)
+  return all_c[np.arange(n), np.argmin(all_e, 1)]
+
+
+def oscar_scale_objective(w: np.ndarray, s: np.ndarray, mu2: np.ndarray, block: int) -> float:
+  """sum over groups of (sum of squared per-row group maxima of |w|*s) * (group mass of
+  mu2 / s^2). ref: oscar.py:175-194."""
+  m = mu2 / (s * s)
+  mag = np.abs(w) * s
+  d = w.shape[1]
+  g = block if (block and d % block == 0) else d
+  total = 0.0
+  for lo in range(0, d, g):
+    top = mag[:, lo:lo + g].max(1)
+    total += float((top * top).sum()) * float(m[lo:lo + g].sum())
+  return total
+
+
+def oscar_channel_scales(w: np.ndarray, mu2: np.ndarray, block: int = 0, iters: int = 3):
+  """Per-input-channel scales s (or None when identity is at least as good) and the gain.
+  ref: oscar.py:197-263."""
+  d = mu2.size
+  mu2 = oscar_floor_masses(mu2)
+  mu = np.sqrt(mu2)
+
+  def unit_geomean(v):
+    v = v / np.exp(np.mean(np.log(v)))
+    return np.clip(v, *_OSCAR_S_RANGE)
+
+  col_energy = (w * w).sum(0) + _OSCAR_TINY
+  at_identity = oscar_scale_objective(w, np.ones(d), mu2, block)
+  s = unit_geomean(np.sqrt(mu / np.sqrt(col_energy)))
+  best_loss, best_s = oscar_scale_objective(w, s, mu2, block), s
+  g = block if (block and w.shape[1] % block == 0) else w.shape[1]
+  rows = np.arange(w.shape[0])
+  for _ in range(iters):
+    eff = np.zeros(d)
+    mag = np.abs(w) * s
+    for lo in range(0, w.shape[1], g):
+      winner = lo + np.argmax(mag[:, lo:lo + g], 1)
+      np.add.at(eff, winner, w[rows, winner] ** 2)
+    eff = np.maximum(eff, 0.25 * col_energy)
+    target = unit_geomean(np.sqrt(mu / np.sqrt(eff)))
+    s = unit_geomean(np.sqrt(s * target))
+    loss = oscar_scale_objective(w, s, mu2, block)
+    if loss < best_loss:
+      best_loss, best_s = loss, s
+  if best_loss >= at_identity:
+    return None, 1.0
+  return best_s, at_identity / max(best_loss, _OSCAR_TINY)
+
+
+def oscar_clip_bounds(w: np.ndarray, mu2, num_bits: int, granularity: str) -> np.ndarray:
+  """Clip bounds in the shape min/max QSVs have. ref: oscar.py:327-383 (+ :111-153)."""
+  w = np.asarray(w, np.float64)
+  if w.ndim != 2:
+    raise ValueError(f"OSCAR expects 2-D weights for FULLY_CONNECTED, got {w.shape}")
+  n, d = w.shape
+  masses = np.ones(d) if mu2 is None else np.asarray(mu2, np.float64).ravel()
+  if masses.size != d:
+    raise ValueError(f"OSCAR: activation mu2 has {masses.size} channels but FULLY_CONNECTED"
+                     f" weights of shape {w.shape} expect {d}.")
+  masses = oscar_floor_masses(masses)
+  qmax = 2 ** (num_bits - 1) - 1
+  mag = np.abs(w)
+  if granularity == TENSORWISE:
+    return oscar_group_clip(mag.reshape(1, n * d), np.tile(masses, n), qmax).reshape((1,) * 2)
+  if granularity == CHANNELWISE:
+    return oscar_group_clip(mag, masses, qmax).reshape(n, 1)
+  if is_blockwise(granularity):
+    b = block_size_of(granularity)
+    if d % b:
+      raise ValueError(f"Block size {b} must divide the reduction dimension {d} of"
+                       f" FULLY_CONNECTED weights with shape {w.shape}.")
+    out = np.empty((n, d // b))
+    for k in range(d // b):
+      out[:, k] = oscar_group_clip(mag[:, k * b:(k + 1) * b], masses[k * b:(k + 1) * b], qmax)
+    return out
+  raise ValueError(f"Unsupported granularity: {granularity}")
+
+
+def oscar_quant_params(w, mu2, num_bits: int, granularity: str, symmetric: bool = True) -> dict:
+  """FULLY_CONNECTED weight -> scales s, W' = W*s quantized with the optimal bounds, and the
+  activation multiplier 1/s (float32). ref: oscar.py:400-478, 541-551."""
+  if not symmetric:
+    raise ValueError("OSCAR supports symmetric weight quantization only, got asymmetric"
+                     " config for op FULLY_CONNECTED.")
+  w = np.asarray(w, np.float64)
+  d = w.shape[1]
+  block = block_size_of(granularity) if is_blockwise(granularity) else 0
+  s = None
+  if mu2 is not None:
+    masses = np.asarray(mu2, np.float64).ravel()
+    if masses.size != d:
+      raise ValueError(f"OSCAR: activation mu2 has {masses.size} channels but FULLY_CONNECTED"
+                       f" weights of shape {w.shape} expect {d}.")
+    s, _ = oscar_channel_scales(w, masses, block)
+  if s is None:
+    s = np.ones(d, np.float64)
+  scaled = w * s
+  scaled_masses = None if mu2 is None else np.asarray(mu2, np.float64).ravel() / (s * s)
+  bounds = oscar_clip_bounds(scaled, scaled_masses, num_bits, granularity)
+  zp, scale = zp_scale_from_min_max(-bounds, bounds, num_bits, True, granularity, None)
+  qdim = weight_quantized_dim(granularity, "FULLY_CONNECTED", 2)
+  q = uniform_quantize(scaled, scale, zp, num_bits, True, quantized_dim=qdim, block_size=block,
+                       is_blockwise_quant=is_blockwise(granularity))
+  return dict(scale=scale, zero_point=zp, num_bits=num_bits, symmetric=True,
+              quantized_dimension=qdim, block_size=block, quantized_data=q,
+              multiplier=(1.0 / s).astype(np.float32))

@@ -520,7 +520,112 @@ def c1_cases():
     DIGESTS[name] = dict(buffer=sha(ARR[f"{name}/buffer"]))
 
 
+# ------------------------------------------------------------------ OSCAR ---
+def oscar_cases():
+  """Separate payload (ref_oscar_cases.npz/json): stage outputs + final parameters of the
+  reference's OSCAR on seeded problems. The reference strips array subclasses (np.asarray), so
+  the bf16 stand-in is attached where its FP64 bounds enter tensor_zp_scale_from_min_max."""
+  from ai_edge_quantizer.algorithms.uniform_quantize import oscar
+  real = oscar.uniform_quantize_tensor.tensor_zp_scale_from_min_max
+
+  def bf16_aware(mn, mx, *a, **k):
+    return real(np.asarray(mn).view(ml_dtypes.Bf16Aware), np.asarray(mx).view(ml_dtypes.Bf16Aware), *a, **k)
+  arr, cases = {}, []
+
+  def problem(seed, n, d, kind):
+    rng = np.random.default_rng(seed)
+    w = rng.normal(size=(n, d)).astype(np.float32)
+    w[:, :4] *= 20.0
+    mu2 = np.exp(rng.normal(size=d))
+    mu2[4:8] *= 100.0
+    if kind == "dead":            # dead channels + a zero weight column
+      mu2[::5] = 0.0
+      w[:, 9] = 0.0
+    elif kind == "flat":          # scaling cannot help: identity wins
+      w = rng.normal(size=(n, d)).astype(np.float32)
+      mu2 = np.ones(d)
+    elif kind == "grid":          # many equal magnitudes (ties), uniform masses
+      w = np.round(w * 2) / 2
+      mu2 = None
+    elif kind == "nomu2":
+      mu2 = None
+    return w.astype(np.float32), mu2
+
+  specs = [
+      ("oscar_cw_i4", 0, 16, 32, 4, G.CHANNELWISE, "std"),
+      ("oscar_b32_i4", 1, 8, 64, 4, G.BLOCKWISE_32, "std"),
+      ("oscar_tw_i4", 2, 6, 40, 4, G.TENSORWISE, "std"),
+      ("oscar_cw_i8", 3, 24, 96, 8, G.CHANNELWISE, "std"),
+      ("oscar_cw_i4_nomu2", 4, 16, 64, 4, G.CHANNELWISE, "nomu2"),
+      ("oscar_b32_i4_nomu2", 5, 12, 128, 4, G.BLOCKWISE_32, "nomu2"),
+      ("oscar_cw_i4_dead", 6, 20, 50, 4, G.CHANNELWISE, "dead"),
+      ("oscar_cw_i4_flat", 7, 16, 48, 4, G.CHANNELWISE, "flat"),
+      ("oscar_cw_i4_grid", 8, 16, 200, 4, G.CHANNELWISE, "grid"),
+      ("oscar_b64_i4", 9, 40, 512, 4, G.BLOCKWISE_64, "std"),
+      ("oscar_b128_i8", 10, 10, 384, 8, G.BLOCKWISE_128, "std"),
+      ("oscar_cw_i4_wide", 11, 5, 3000, 4, G.CHANNELWISE, "std"),
+      ("oscar_cw_i4_tall", 12, 700, 24, 4, G.CHANNELWISE, "std"),
+      ("oscar_b32_i4_big", 13, 300, 1024, 4, G.BLOCKWISE_32, "std"),
+      ("oscar_cw_i2", 14, 16, 64, 2, G.CHANNELWISE, "std"),
+      ("oscar_tw_i8_nomu2", 15, 9, 33, 8, G.TENSORWISE, "nomu2"),
+  ]
+  oscar.uniform_quantize_tensor.tensor_zp_scale_from_min_max = bf16_aware
+  try:
+    for name, seed, n, d, bits, gran, kind in specs:
+      w, mu2 = problem(1000 + seed, n, d, kind)
+      cfg = cfg_of(bits, True, gran)
+      qsv = None if mu2 is None else {"mu2": mu2}
+      res = oscar.get_tensor_quant_params(op_info(OPN.FULLY_CONNECTED, cfg), cfg, w, qsv)
+      arr[f"{name}/w"] = w
+      if mu2 is not None:
+        arr[f"{name}/mu2"] = mu2
+        block = uqt.extract_block_size_from_granularity(gran) if uqt.is_blockwise(gran) else 0
+        s, gain = oscar._compute_channel_scales(np.asarray(w, np.float64), np.asarray(mu2, np.float64), block)
+        if s is not None:
+          arr[f"{name}/s"] = s
+      mult = res.custom_algorithm_param["multiplier"]
+      s64 = 1.0 if mu2 is None else (np.ones(d) if f"{name}/s" not in arr else arr[f"{name}/s"])
+      arr[f"{name}/bounds"] = oscar.get_clip_bounds(
+          OPN.FULLY_CONNECTED, np.asarray(w, np.float64) * s64,
+          None if mu2 is None else np.asarray(mu2, np.float64) / (s64 * s64), bits, gran)
+      arr[f"{name}/scale"] = plain(res.scale)
+      arr[f"{name}/zero_point"] = plain(res.zero_point)
+      arr[f"{name}/q"] = plain(res.quantized_data)
+      arr[f"{name}/multiplier"] = plain(mult)
+      cases.append(dict(name=name, num_bits=bits, granularity=gran.name, has_mu2=mu2 is not None,
+                        scaled=f"{name}/s" in arr, quantized_dimension=res.quantized_dimension,
+                        block_size=res.block_size, scale_dtype=str(np.asarray(res.scale).dtype)))
+  finally:
+    oscar.uniform_quantize_tensor.tensor_zp_scale_from_min_max = real
+
+  # calibration statistic + its merge rule
+  rng = np.random.default_rng(1100)
+  xs = [(rng.standard_normal((b, 5, 24)) * (1 + i)).astype(np.float32) for i, b in enumerate([1, 3, 2, 1])]
+  qsv = None
+  for i, x in enumerate(xs):
+    arr[f"oscar_calib/x{i}"] = x
+    xx = np.asarray(x, np.float64).reshape([-1, x.shape[-1]])
+    new = common_quantize.get_activation_min_max(x, valid_float_range_min=-3e38, valid_float_range_max=3e38)
+    new["num_samples"] = np.array(x.shape[0])
+    new["mu2"] = np.mean(xx * xx, axis=0)       # oscar.calibrate's statistic (oscar.py:318-324)
+    arr[f"oscar_calib/mu2_{i}"] = new["mu2"]
+    qsv = qsv_utils.oscar_and_moving_average_update(qsv, new)
+    arr[f"oscar_calib/merged_mu2_{i}"] = np.asarray(qsv["mu2"])
+    arr[f"oscar_calib/merged_min_{i}"] = np.asarray(qsv["min"])
+  cases.append(dict(name="oscar_calib", steps=len(xs), num_samples=int(qsv["num_samples"])))
+
+  np.savez_compressed(os.path.join(GOLDEN, "ref_oscar_cases.npz"), **arr)
+  with open(os.path.join(GOLDEN, "ref_oscar_cases.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_golden.py --oscar", numpy=np.__version__,
+                   reference_version=open("/root/reference/VERSION").read().strip(), cases=cases),
+              f, indent=1, sort_keys=True)
+  print(f"wrote {len(arr)} OSCAR arrays, {len(cases)} cases")
+
+
 def main():
+  if "--oscar" in sys.argv:
+    oscar_cases()
+    return
   # cross-check the bf16 stand-in against an independent implementation
   import torch
   probe = np.random.default_rng(5).standard_normal(200000).astype(np.float32)

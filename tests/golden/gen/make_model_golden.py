@@ -228,7 +228,7 @@ def main():
   print("wrote", len(cases), "cases")
 
 
-if __name__ == "__main__" and "--srq" not in sys.argv and "--insts" not in sys.argv:
+if __name__ == "__main__" and not {"--srq", "--insts", "--oscar"} & set(sys.argv):
   main()
 
 
@@ -368,3 +368,69 @@ def instruction_cases():
 
 if __name__ == "__main__" and "--insts" in sys.argv:
   instruction_cases()
+
+
+# ---------------------------------------------------------------- OSCAR, model level ---
+OSCAR_MODELS = ["single_fc", "single_fc_bias", "weight_sharing_fcs", "conv_fc_mnist", "branching_conv_fc",
+                "toy_model_with_kv_cache_multi_signature"]
+
+
+def oscar_recipe(bits, gran, precision="INTEGER", explicit=False):
+  return [dict(regex=".*", operation="FULLY_CONNECTED", algorithm_key="OSCAR", op_config=dict(
+      weight_tensor_config=dict(num_bits=bits, symmetric=True, granularity=gran, dtype="INT"),
+      compute_precision=precision, explicit_dequantize=explicit, skip_checks=False,
+      min_weight_elements=0))]
+
+
+def oscar_qsvs(model, seed):
+  """Synthetic calibration result: a range + a second-moment vector over the trailing axis for
+  every runtime tensor (regenerated from `seed` by the test)."""
+  rng = np.random.default_rng(seed)
+  qsvs = {}
+  for sg in model.subgraphs:
+    for t in sg.tensors:
+      if model.buffers[t.buffer].data is None and len(t.shape):
+        lo, hi = sorted(rng.uniform(-6, 6, 2))
+        mu2 = np.exp(rng.normal(size=int(t.shape[-1])) * 1.5)
+        qsvs[t.name.decode()] = {"min": np.array([[min(lo, -0.1)]], np.float32),
+                                 "max": np.array([[max(hi, 0.1)]], np.float32),
+                                 "mu2": mu2, "num_samples": 7}
+  return qsvs
+
+
+def oscar_model_cases():
+  from ai_edge_quantizer.algorithms.uniform_quantize import oscar
+  real = oscar.uniform_quantize_tensor.tensor_zp_scale_from_min_max
+  oscar.uniform_quantize_tensor.tensor_zp_scale_from_min_max = lambda mn, mx, *a, **k: real(
+      np.asarray(mn).view(ml_dtypes.Bf16Aware), np.asarray(mx).view(ml_dtypes.Bf16Aware), *a, **k)
+  out = {}
+  try:
+    for i, name in enumerate(OSCAR_MODELS):
+      shutil.copyfile(os.path.join(REF, "tests/models", name + ".tflite"),
+                      os.path.join(GOLDEN, "models", name + ".tflite"))
+      model = to_bags(fb.read_model(open(os.path.join(REF, "tests/models", name + ".tflite"), "rb").read()))
+      for rname, rcp in (("oscar_wi4_cw", oscar_recipe(4, "CHANNELWISE")),
+                         ("oscar_wi4_b32", oscar_recipe(4, "BLOCKWISE_32")),
+                         ("oscar_wi8_cw_weight_only", oscar_recipe(8, "CHANNELWISE", "FLOAT", True))):
+        for with_mu2 in (True, False):
+          seed = 4000 + i
+          qsvs = oscar_qsvs(model, seed) if with_mu2 else {}
+          key = f"{name}/{rname}/{'mu2' if with_mu2 else 'nomu2'}"
+          try:
+            res = run(name, rname, rcp, qsvs)
+          except Exception as e:
+            out[key] = dict(model=name, recipe=rcp, seed=seed, with_mu2=with_mu2, error=type(e).__name__,
+                            message=str(e)[:300])
+            print("err ", key, type(e).__name__, str(e)[:100])
+            continue
+          out[key] = dict(model=name, recipe=rcp, seed=seed, with_mu2=with_mu2, result=res)
+          print("ok  ", key)
+  finally:
+    oscar.uniform_quantize_tensor.tensor_zp_scale_from_min_max = real
+  with open(os.path.join(GOLDEN, "ref_oscar_model_cases.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_model_golden.py --oscar", numpy=np.__version__,
+                   cases=out), f, separators=(",", ":"), sort_keys=True)
+
+
+if __name__ == "__main__" and "--oscar" in sys.argv:
+  oscar_model_cases()

@@ -335,3 +335,77 @@ def test_calibrator_bookkeeping_without_gpu(tmp_path):
   assert d._metadata["note"] == "x" and d._metadata["num_samples_calibrated"] == 1   # counted before the step ran, as in the reference
   d.reset_model_qsvs()
   assert d.get_model_qsvs() == {}
+
+
+def _fc_model_for_multiply():
+  """x[1,8] -> FC(w0) -> y0 and x -> FC(w1) -> y1 (two consumers of one activation)."""
+  tensors = [q.TensorT(name=b"x", shape=[1, 8], type=0, buffer=0),
+             q.TensorT(name=b"w0", shape=[4, 8], type=0, buffer=1),
+             q.TensorT(name=b"w1", shape=[4, 8], type=0, buffer=2),
+             q.TensorT(name=b"y0", shape=[1, 4], type=0, buffer=0),
+             q.TensorT(name=b"y1", shape=[1, 4], type=0, buffer=0)]
+  ops = [q.OperatorT(opcodeIndex=0, inputs=[0, 1, -1], outputs=[3]),
+         q.OperatorT(opcodeIndex=0, inputs=[0, 2, -1], outputs=[4])]
+  sg = q.SubGraphT(tensors=tensors, operators=ops, inputs=[0], outputs=[3, 4])
+  w = np.arange(32, dtype=np.float32)
+  return q.ModelT(version=3, subgraphs=[sg], operatorCodes=[q.OperatorCodeT(builtinCode=int(q.BuiltinOperator.FULLY_CONNECTED))],
+                  buffers=[q.BufferT(), q.BufferT(data=w.view(np.uint8)), q.BufferT(data=(w + 1).view(np.uint8))])
+
+
+def test_insert_multiply_edits_the_graph_like_the_reference():
+  """ref: transformations/insert_multiply_test.py (graph shape, sharing, error behaviour)."""
+  from mi355q.transformations import graph_edits, transformation_utils
+  mult = np.linspace(0.5, 2.0, 8).astype(np.float32)
+  params = q.UniformQuantParams(num_bits=4, quantized_dimension=0, scale=np.ones((4, 1), np.float32),
+                                zero_point=np.zeros((4, 1), np.int8), custom_algorithm_param={"multiplier": mult})
+  model = _fc_model_for_multiply()
+  sg = model.subgraphs[0]
+
+  def ti(consumers, tensor_id=0, p=params):
+    return transformation_utils.TransformationInput(tensor_id=tensor_id, model=model, subgraph=sg, producer=-1,
+                                                    consumers=consumers, quant_params=p)
+  info = graph_edits.insert_multiply(ti([0]))
+  assert (info.op_id, info.num_ops_added) == (0, 1) and len(sg.tensors) == 7 and len(sg.operators) == 3
+  mul = sg.operators[0]
+  assert model.operatorCodes[mul.opcodeIndex].builtinCode == q.BuiltinOperator.MUL
+  assert mul.inputs[0] == 0 and mul.outputs == [info.output_tensor_id]
+  assert mul.builtinOptionsType == q.BuiltinOptions.MulOptions and mul.builtinOptions.fusedActivationFunction == 0
+  mt = sg.tensors[mul.inputs[1]]
+  assert mt.type == q.TensorType.FLOAT32 and mt.name == b"x_multiplier" and list(mt.shape) == [8]
+  assert np.array_equal(tfl_flatbuffer_utils.get_tensor_data(mt, model.buffers), mult)
+  assert sg.tensors[info.output_tensor_id].name == b"x_scaled" and list(sg.tensors[info.output_tensor_id].shape) == [1, 8]
+  assert sg.operators[1].inputs[0] == info.output_tensor_id       # the FC consumer was re-pointed
+  assert sg.operators[2].inputs[0] == 0                            # the other one was not asked
+  # a second insertion with the same vector shares the constant tensor
+  info2 = graph_edits.insert_multiply(ti([2]))
+  assert sg.operators[info2.op_id].inputs[1] == mul.inputs[1]
+  # the edited model serializes and re-reads (typed MulOptions table)
+  from mi355q.utils import tflite_flatbuffer as fb
+  again = fb.read_model(bytes(fb.write_model(model)))
+  assert [o.builtinOptionsType for o in again.subgraphs[0].operators].count(int(q.BuiltinOptions.MulOptions)) == 2
+  # errors
+  with pytest.raises(ValueError, match="uniform quantization only"):
+    graph_edits.insert_multiply(ti([0], p=q.NonLinearQuantParams(num_bits=16, quantized_data=None)))
+  with pytest.raises(ValueError, match='"multiplier" is not set'):
+    graph_edits.insert_multiply(ti([0], p=q.UniformQuantParams(num_bits=4, quantized_dimension=0, scale=np.ones(1, np.float32),
+                                                                zero_point=np.zeros(1, np.int8))))
+  sg.tensors[0].type = int(q.TensorType.INT8)
+  with pytest.raises(ValueError, match="float32 tensors only"):
+    graph_edits.insert_multiply(ti([0]))
+  sg.tensors[0].type = 0
+  model.operatorCodes[0].builtinCode = int(q.BuiltinOperator.ADD)
+  with pytest.raises(ValueError, match="fully connected consumers only"):
+    graph_edits.insert_multiply(ti([1]))
+
+
+def test_oscar_registration_and_qsv_merge():
+  from mi355q.algorithms.uniform_quantize import oscar
+  assert am.AlgorithmName.OSCAR == "OSCAR" and am.get_supported_ops("OSCAR") == [q.TFLOperationName.FULLY_CONNECTED]
+  assert am.get_update_qsv_func("OSCAR", q.TFLOperationName.FULLY_CONNECTED) is qsv_utils.oscar_and_moving_average_update
+  assert am.get_quantization_func("OSCAR", q.TFLOperationName.FULLY_CONNECTED, q.QuantizeMode.CALIBRATE) is oscar.calibrate
+  a = {"min": np.float32(-1), "max": np.float32(2), "mu2": np.array([1.0, 3.0]), "num_samples": 2}
+  b = {"min": np.float32(-3), "max": np.float32(1), "mu2": np.array([5.0, 1.0]), "num_samples": 6}
+  got, want = qsv_utils.oscar_and_moving_average_update(a, b), O.oscar_and_moving_average_update(a, b)
+  assert np.array_equal(got["mu2"], want["mu2"]) and got["num_samples"] == 8
+  assert got["min"] == want["min"] and got["max"] == want["max"]
+  assert qsv_utils.oscar_and_moving_average_update(None, b) is b

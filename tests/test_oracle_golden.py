@@ -1,6 +1,8 @@
 """Pins oracle/aeq_oracle.py against (i) the reference's own known-answer test
 vectors and (ii) outputs of the real reference recorded by
 tests/golden/gen/make_golden.py. CPU only."""
+import json
+import os
 import warnings
 
 import numpy as np
@@ -408,3 +410,54 @@ def test_octav_anchor_digest(ref_digests):
   w = np.random.default_rng(d["seed"]).standard_normal(tuple(d["shape"]), dtype=np.float32)
   r = O.octav_quant_params(w, 4, "CHANNELWISE")
   assert sha(r["quantized_data"]) == d["q"] and sha(r["scale"]) == d["scale"]
+
+
+# ------------------------------------------------------------------ OSCAR (f4) ---
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_oscar_cases.json")) as _f:
+  _OSCAR = {c["name"]: c for c in json.load(_f)["cases"]}
+
+
+@pytest.fixture(scope="module")
+def oscar_arrays():
+  return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_oscar_cases.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(n for n in _OSCAR if n != "oscar_calib"))
+def test_oscar_matches_reference(oscar_arrays, name):
+  """Channel scales, clip bounds, scale (FP64, or bf16-rounded float32 for blockwise), int
+  weights and the float32 multiplier of the real reference's OSCAR, stage by stage."""
+  z, c = oscar_arrays, _OSCAR[name]
+  w = z[f"{name}/w"]
+  mu2 = z[f"{name}/mu2"] if c["has_mu2"] else None
+  s64 = np.ones(w.shape[1])
+  if mu2 is not None:
+    block = O.block_size_of(c["granularity"]) if O.is_blockwise(c["granularity"]) else 0
+    s, gain = O.oscar_channel_scales(np.asarray(w, np.float64), np.asarray(mu2, np.float64), block)
+    assert (s is not None) == c["scaled"]
+    if s is not None:
+      _eq(s, z[f"{name}/s"])
+      s64 = s
+  _eq(O.oscar_clip_bounds(np.asarray(w, np.float64) * s64, None if mu2 is None else mu2 / (s64 * s64),
+                          c["num_bits"], c["granularity"]), z[f"{name}/bounds"])
+  r = O.oscar_quant_params(w, mu2, c["num_bits"], c["granularity"])
+  _eq(r["scale"], z[f"{name}/scale"])
+  assert str(r["scale"].dtype) == c["scale_dtype"]
+  _eq(r["quantized_data"], z[f"{name}/q"])
+  _eq(r["multiplier"], z[f"{name}/multiplier"])
+  assert np.array_equal(r["zero_point"], z[f"{name}/zero_point"])
+  assert r["quantized_dimension"] == c["quantized_dimension"] and r["block_size"] == c["block_size"]
+
+
+def test_oscar_calibration_statistic_and_merge_match_reference(oscar_arrays):
+  z, c = oscar_arrays, _OSCAR["oscar_calib"]
+  q = None
+  for i in range(c["steps"]):
+    x = z[f"oscar_calib/x{i}"]
+    new = O.activation_min_max(x, -3e38, 3e38)
+    new["num_samples"] = np.array(x.shape[0])
+    new["mu2"] = O.oscar_mu2(x)
+    _eq(new["mu2"], z[f"oscar_calib/mu2_{i}"])
+    q = O.oscar_and_moving_average_update(q, new)
+    _eq(np.asarray(q["mu2"]), z[f"oscar_calib/merged_mu2_{i}"])
+    _eq(q["min"], z[f"oscar_calib/merged_min_{i}"])
+  assert int(q["num_samples"]) == c["num_samples"]
