@@ -13,6 +13,7 @@
 //                  minimum
 //   quantize       clip(rint((w*s) / scale)) with FP64 product and quotient
 // Compiled with -ffp-contract=off: none of the FP64 expressions may be fused.
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -74,8 +75,8 @@ __device__ __forceinline__ Top shfl_xor_top(const Top& t, int off) {
 }
 
 // Blockwise groups (g in {32, 64, 128, 256}, d % g == 0): a lane owns 4 consecutive columns,
-// g/4 lanes form a group. top2 is laid out [G][n] so that the per-group sum runs over a
-// contiguous vector; winner / wsq are [n][G].
+// g/4 lanes form a group. top2 / winner / wsq are laid out [G][n]: the per-group sum and the
+// winners' accumulation both walk one group's rows as a contiguous vector.
 template <int LANES>
 __global__ __launch_bounds__(256) void group_top_block_kernel(
     const float* __restrict__ w, const double* __restrict__ s, int64_t n, int64_t d, int32_t g,
@@ -103,12 +104,11 @@ __global__ __launch_bounds__(256) void group_top_block_kernel(
     if (beats(o, best)) best = o;
   }
   if (live && (threadIdx.x & (LANES - 1)) == 0) {
-    const int64_t G = d / g;
     const int64_t k = j0 / g;
     top2[k * n + r] = best.v * best.v;
-    winner[r * G + k] = best.j;
+    winner[k * n + r] = best.j;
     const double t = static_cast<double>(best.w);
-    wsq[r * G + k] = t * t;
+    wsq[k * n + r] = t * t;
   }
 }
 
@@ -176,52 +176,130 @@ __device__ double pairwise_f64(const double* a, int64_t n) {
   return pairwise_f64(a, n2) + pairwise_f64(a + n2, n - n2);
 }
 
-// np.sum of a contiguous FP64 vector: 8192-element chunks added in order, each pairwise. The
-// chunks of one vector are summed by different lanes and combined in order by lane 0.
+// Leaves of pairwise_f64's recursion over [lo, lo + n), in order.
+__device__ void pairwise_leaves(int32_t lo, int32_t n, int32_t* leaf_lo, int32_t* leaf_n,
+                                int32_t* count) {
+  if (n <= 128) {
+    leaf_lo[*count] = lo;
+    leaf_n[*count] = n;
+    ++*count;
+    return;
+  }
+  int32_t n2 = n / 2;
+  n2 -= n2 % 8;
+  pairwise_leaves(lo, n2, leaf_lo, leaf_n, count);
+  pairwise_leaves(lo + n2, n - n2, leaf_lo, leaf_n, count);
+}
+
+// The recursion again, with the leaves' sums already known (consumed in order).
+__device__ double pairwise_combine(int32_t n, const double* leaf_sum, int32_t* next) {
+  if (n <= 128) return leaf_sum[(*next)++];
+  int32_t n2 = n / 2;
+  n2 -= n2 % 8;
+  const double left = pairwise_combine(n2, leaf_sum, next);
+  return left + pairwise_combine(n - n2, leaf_sum, next);
+}
+
+// np.sum of a contiguous FP64 vector: 8192-element chunks added in order, each pairwise. One
+// wave per vector: lane 0 lists the <= 128 leaves of a chunk; 8 lanes share a leaf, one per
+// accumulator of NumPy's unrolled loop (so a wave reads 8 x 64 B runs per step), the
+// accumulators are folded pairwise by an xor butterfly, which is the ((r0+r1)+(r2+r3))+... tree;
+// lane 0 folds the leaf sums in the recursion's order.
 __global__ __launch_bounds__(64) void group_sum_kernel(const double* __restrict__ top2, int64_t n,
                                                        double* __restrict__ sums) {
+  __shared__ int32_t leaf_lo[128], leaf_n[128], leaves;
+  __shared__ double leaf_sum[128];
   const double* a = top2 + static_cast<int64_t>(blockIdx.x) * n;
-  const int64_t chunks = (n + 8191) / 8192;
+  const int lane = threadIdx.x, k = lane & 7, slot = lane >> 3;
   double total = 0.0;
-  for (int64_t base = 0; base < chunks; base += 64) {
-    const int64_t c = base + threadIdx.x;
-    double part = 0.0;
-    if (c < chunks) {
-      const int64_t lo = c * 8192;
-      part = pairwise_f64(a + lo, (n - lo < 8192) ? n - lo : 8192);
+  for (int64_t lo = 0; lo < n; lo += 8192) {
+    const int32_t len = static_cast<int32_t>((n - lo < 8192) ? n - lo : 8192);
+    if (lane == 0) {
+      int32_t c = 0;
+      pairwise_leaves(0, len, leaf_lo, leaf_n, &c);
+      leaves = c;
     }
-    const int64_t here = (chunks - base < 64) ? chunks - base : 64;
-    for (int64_t k = 0; k < here; ++k) {
-      const double p = __shfl(part, static_cast<int>(k), kWave);
-      total = (base == 0 && k == 0) ? p : total + p;
+    __syncthreads();
+    for (int32_t base = 0; base < leaves; base += 8) {
+      const int32_t leaf = base + slot;
+      const bool live = leaf < leaves;
+      const double* p = a + lo + (live ? leaf_lo[leaf] : 0);
+      const int32_t ln = live ? leaf_n[leaf] : 0;
+      double res = 0.0;
+      if (ln < 8) {                                  // short leaf: plain left-to-right sum
+        for (int32_t i = 0; i < ln; ++i) res = res + p[i];
+      } else {
+        double v[16];                                // all loads first, then the ordered adds
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (8 * (u + 1) <= ln) ? p[8 * u + k] : 0.0;
+        double r = v[0];
+#pragma unroll
+        for (int u = 1; u < 16; ++u)
+          if (8 * (u + 1) <= ln) r = r + v[u];
+        int32_t i = ln & ~7;
+        r = r + __shfl_xor(r, 1, kWave);             // IEEE addition commutes: both partners agree
+        r = r + __shfl_xor(r, 2, kWave);
+        r = r + __shfl_xor(r, 4, kWave);
+        for (; i < ln; ++i) r = r + p[i];
+        res = r;
+      }
+      if (live && k == 0) leaf_sum[leaf] = res;
     }
+    __syncthreads();
+    if (lane == 0) {
+      int32_t next = 0;
+      const double part = pairwise_combine(len, leaf_sum, &next);
+      total = (lo == 0) ? part : total + part;
+    }
+    __syncthreads();
   }
-  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+  if (lane == 0) sums[blockIdx.x] = total;
 }
 
 // -------------------------------------------------------------- winner_energy ---
-// eff[j] = sum over rows, in order, of wsq[r][group(j)] where winner[r][group(j)] == j.
-__global__ __launch_bounds__(64) void winner_energy_kernel(const int32_t* __restrict__ winner,
-                                                           const double* __restrict__ wsq,
-                                                           int64_t n, int64_t d, int32_t g,
-                                                           double* __restrict__ eff) {
-  const int64_t j = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
-  if (j >= d) return;
-  const int64_t G = d / g;
-  const int64_t k = j / g;
+// eff[j] = sum over rows, in order, of wsq[group(j)][r] where winner[group(j)][r] == j.
+// blockIdx.x = group, blockIdx.y = 256-column slice of it: the block stages 1024 rows of the
+// group's winner / wsq vectors in LDS (coalesced), then every column walks them in order; all
+// lanes read the same LDS word (broadcast).
+__global__ __launch_bounds__(256) void winner_energy_kernel(const int32_t* __restrict__ winner,
+                                                            const double* __restrict__ wsq,
+                                                            int64_t n, int64_t d, int32_t g,
+                                                            double* __restrict__ eff) {
+  constexpr int ROWS = 1024;
+  __shared__ int32_t win[ROWS];
+  __shared__ double sq[ROWS];
+  const int64_t k = blockIdx.x;
+  const int32_t jg = static_cast<int32_t>(blockIdx.y) * 256 + threadIdx.x;   // column within group
+  const int32_t j = static_cast<int32_t>(k * g) + jg;
+  const int32_t* wk = winner + k * n;
+  const double* sk = wsq + k * n;
   double acc = 0.0;
-  int64_t r = 0;
-  for (; r + 8 <= n; r += 8) {
-    int32_t wj[8];
+  for (int64_t base = 0; base < n; base += ROWS) {
+    const int32_t here = static_cast<int32_t>((n - base < ROWS) ? n - base : ROWS);
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < here; i += 256) {
+      win[i] = wk[base + i];
+      sq[i] = sk[base + i];
+    }
+    __syncthreads();
+    if (jg < g) {
+      // branch-free: adding +0.0 leaves a non-negative running sum unchanged, bit for bit
+      int32_t i = 0;
+      for (; i + 8 <= here; i += 8) {
+        int32_t wi[8];
+        double si[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) wj[u] = winner[(r + u) * G + k];
+        for (int u = 0; u < 8; ++u) {
+          wi[u] = win[i + u];
+          si[u] = sq[i + u];
+        }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (wj[u] == j) acc = acc + wsq[(r + u) * G + k];
+        for (int u = 0; u < 8; ++u) acc = acc + (wi[u] == j ? si[u] : 0.0);
+      }
+      for (; i < here; ++i) acc = acc + (win[i] == j ? sq[i] : 0.0);
+    }
   }
-  for (; r < n; ++r)
-    if (winner[r * G + k] == j) acc = acc + wsq[r * G + k];
-  eff[j] = acc;
+  if (jg < g) eff[j] = acc;
 }
 
 // ---------------------------------------------------------------- clip_bounds ---
@@ -242,19 +320,147 @@ struct SegmentStart {
   __host__ __device__ uint32_t operator()(uint32_t i) const { return i * g; }
 };
 
+// Stable descending sort of every segment of g <= P (P a power of two, 32..8192) elements in
+// LDS: bitonic network on (key, position) pairs -- the position breaks ties, so the result is
+// the stable order. A 256-thread block sorts a tile of TILE / P consecutive segments; keys are
+// computed on the fly (|w| * s), the sorted keys and the masses of their columns are written
+// out in the natural [segment][rank] layout, or rank-major ([rank][segment]) for short segments
+// so that the scan kernel's lanes (one per segment) read consecutive addresses.
+constexpr int kSortThreads = 256;
+
+// +1 every 8 and every 32 elements: the 8-element register blocks (stride 8) and the rank-major
+// store (stride P >= 32) both spread over the banks
+__host__ __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 3) + (i >> 5); }
+
+// (key, position) pairs are distinct, so this is a strict total order: exactly one of
+// sorts_before(a, b), sorts_before(b, a) holds. Bitwise operators: no short-circuit branches.
+__device__ __forceinline__ bool sorts_before(double ka, uint32_t ia, double kb, uint32_t ib) {
+  return (ka > kb) | ((ka == kb) & (ia < ib));
+}
+
+// LEVELS consecutive compare-exchange levels (distances j, j/2, ...) of the bitonic network on
+// 2^LEVELS elements held in registers: one LDS read and one write per element instead of LEVELS.
+template <int LEVELS>
+__device__ __forceinline__ void sort_levels(double* key, uint16_t* pos, int tile, int P, int k,
+                                            int j) {
+  constexpr int N = 1 << LEVELS;
+  const int low = j >> (LEVELS - 1);                 // smallest distance of this round
+  for (int t = threadIdx.x; t < tile / N; t += kSortThreads) {
+    // spread t around LEVELS zero bits at the positions of the distances
+    const int base = ((t & ~(low - 1)) << LEVELS) | (t & (low - 1));
+    const bool desc = ((base & (P - 1)) & k) == 0;
+    double kv[N];
+    uint32_t pv[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      const int at = lds_pad(base + c * low);
+      kv[c] = key[at];
+      pv[c] = pos[at];
+    }
+#pragma unroll
+    for (int lvl = LEVELS - 1; lvl >= 0; --lvl) {    // distance low << lvl
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        if ((c >> lvl) & 1) continue;
+        const int o = c | (1 << lvl);
+        const bool swap = sorts_before(kv[o], pv[o], kv[c], pv[c]) == desc;
+        const double tk = swap ? kv[o] : kv[c];
+        kv[o] = swap ? kv[c] : kv[o];
+        kv[c] = tk;
+        const uint32_t tp = swap ? pv[o] : pv[c];
+        pv[o] = swap ? pv[c] : pv[o];
+        pv[c] = tp;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      const int at = lds_pad(base + c * low);
+      key[at] = kv[c];
+      pos[at] = static_cast<uint16_t>(pv[c]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kSortThreads) void sort_tile_kernel(
+    const float* __restrict__ w, const double* __restrict__ s, const double* __restrict__ m,
+    int64_t segments, int32_t g, int32_t P, int32_t tile, int64_t d, int32_t transposed,
+    double* __restrict__ keys_out, double* __restrict__ vals_out) {
+  extern __shared__ unsigned char lds_raw[];
+  double* key = reinterpret_cast<double*>(lds_raw);
+  uint16_t* pos = reinterpret_cast<uint16_t*>(key + lds_pad(tile) + 1);
+  const int segs_per_tile = tile / P;
+  const int64_t seg0 = static_cast<int64_t>(blockIdx.x) * segs_per_tile;
+  const int64_t segs_here = (segments - seg0 < segs_per_tile) ? segments - seg0 : segs_per_tile;
+
+  for (int e = threadIdx.x; e < tile; e += kSortThreads) {
+    const int sl = e / P, i = e - sl * P;
+    double k = -1.0;                 // padding sorts behind every real magnitude
+    if (sl < segs_here && i < g) {
+      const int64_t ge = (seg0 + sl) * g + i;
+      k = fabs(static_cast<double>(w[ge])) * s[ge % d];
+    }
+    key[lds_pad(e)] = k;
+    pos[lds_pad(e)] = static_cast<uint16_t>(i);
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1) {
+    int j = k >> 1;
+    while (j > 0) {        // up to three consecutive levels per LDS round trip
+      if (j >= 4) {
+        sort_levels<3>(key, pos, tile, P, k, j);
+        j >>= 3;
+      } else if (j == 2) {
+        sort_levels<2>(key, pos, tile, P, k, j);
+        j = 0;
+      } else {
+        sort_levels<1>(key, pos, tile, P, k, j);
+        j = 0;
+      }
+      __syncthreads();
+    }
+  }
+  if (transposed) {
+    // consecutive threads -> consecutive segments of the tile, same rank
+    for (int e = threadIdx.x; e < segs_per_tile * g; e += kSortThreads) {
+      const int i = e / segs_per_tile, sl = e - i * segs_per_tile;
+      if (sl < segs_here) {
+        const int at = lds_pad(sl * P + i);
+        const int64_t seg = seg0 + sl;
+        keys_out[static_cast<int64_t>(i) * segments + seg] = key[at];
+        vals_out[static_cast<int64_t>(i) * segments + seg] = m[(seg * g + pos[at]) % d];
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < tile; e += kSortThreads) {
+      const int sl = e / P, i = e - sl * P;
+      if (sl < segs_here && i < g) {
+        const int at = lds_pad(e);
+        const int64_t seg = seg0 + sl;
+        keys_out[seg * g + i] = key[at];
+        vals_out[seg * g + i] = m[(seg * g + pos[at]) % d];
+      }
+    }
+  }
+}
+
 // One lane per sorted segment: running sums in order, the candidate of every breakpoint
 // interval, first minimum. u = M / (6 qmax^2), noise = M / (12 qmax^2) per group (host FP64).
+// Element i of segment seg lives at seg * seg_stride + i * elem_stride (natural layout: g, 1;
+// transposed layout of the tile sort for short segments: 1, segments -> coalesced lanes).
 template <int BATCH>
 __global__ __launch_bounds__(64) void clip_scan_kernel(const double* __restrict__ keys,
                                                        const double* __restrict__ vals,
                                                        int64_t segments, int64_t g, int64_t G,
+                                                       int64_t seg_stride, int64_t elem_stride,
                                                        const double* __restrict__ u,
                                                        const double* __restrict__ noise,
-                                                       double* __restrict__ bounds) {
+                                                       double qmax, int32_t blockwise,
+                                                       double* __restrict__ bounds,
+                                                       double* __restrict__ scale) {
   const int64_t seg = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
   if (seg >= segments) return;
-  const double* a = keys + seg * g;
-  const double* m = vals + seg * g;
+  const double* a = keys + seg * seg_stride;
+  const double* m = vals + seg * seg_stride;
   const double uk = u[seg % G], nk = noise[seg % G];
   double run_m = 0.0, run_am = 0.0, run_a2m = 0.0;
   const double a0 = a[0];
@@ -264,8 +470,8 @@ __global__ __launch_bounds__(64) void clip_scan_kernel(const double* __restrict_
     double ab[BATCH + 1], mb[BATCH];
 #pragma unroll
     for (int t = 0; t < BATCH; ++t) {
-      mb[t] = (i + t < g) ? m[i + t] : 0.0;
-      ab[t + 1] = (i + t + 1 < g) ? a[i + t + 1] : 0.0;
+      mb[t] = (i + t < g) ? m[(i + t) * elem_stride] : 0.0;
+      ab[t + 1] = (i + t + 1 < g) ? a[(i + t + 1) * elem_stride] : 0.0;
     }
     ab[0] = cur;
 #pragma unroll
@@ -287,7 +493,98 @@ __global__ __launch_bounds__(64) void clip_scan_kernel(const double* __restrict_
     }
     cur = ab[BATCH];
   }
-  bounds[seg] = best_c;
+  if (bounds) bounds[seg] = best_c;
+  if (scale) {
+    // tensor_zp_scale_from_min_max(-c, c, symmetric): bound = max(c, 1e-9), scale = bound / qmax;
+    // blockwise scales go FP64 -> float32 -> bfloat16 -> float16 (ref uniform_quantize_tensor.py
+    // :553-581; no clipping values on this path)
+    double sc = fmax(best_c, 1e-9) / qmax;
+    if (blockwise) {
+      uint16_t half_bits;
+      sc = static_cast<double>(round_scale_blockwise(static_cast<float>(sc), &half_bits));
+    }
+    scale[seg] = sc;
+  }
+}
+
+// The same scan with one WAVE per segment, for few long segments (a lane per segment would leave
+// most of the chip idle): the three running sums are carried lane to lane in order (one masked
+// add + readlane per lane and sum), the candidate of every breakpoint interval is then evaluated
+// by all 64 lanes at once, and the first minimum is an (error, index) butterfly.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(b), lane);
+  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(b >> 32), lane);
+  return __builtin_bit_cast(double, (static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+__global__ __launch_bounds__(256) void clip_scan_wave_kernel(
+    const double* __restrict__ keys, const double* __restrict__ vals, int64_t segments, int64_t g,
+    int64_t G, const double* __restrict__ u, const double* __restrict__ noise, double qmax,
+    int32_t blockwise, double* __restrict__ bounds, double* __restrict__ scale) {
+  const int64_t seg = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (seg >= segments) return;                       // whole waves leave together
+  const int lane = threadIdx.x & 63;
+  const double* a = keys + seg * g;
+  const double* m = vals + seg * g;
+  const double uk = u[seg % G], nk = noise[seg % G];
+  const double a0 = a[0];
+  double best_c = a0, best_e = (a0 * a0) * nk;       // the "clip nothing" candidate, index -1
+  int64_t best_i = -1;
+  double carry_m = 0.0, carry_am = 0.0, carry_a2m = 0.0;
+  for (int64_t base = 0; base < g; base += 64) {
+    const int64_t i = base + lane;
+    const bool live = i < g;
+    const double ai = live ? a[i] : 0.0;
+    const double mi = live ? m[i] : 0.0;
+    const double lower = (i + 1 < g) ? a[i + 1] : 0.0;
+    const double am = ai * mi, a2m = (ai * ai) * mi;
+    double run_m = 0.0, run_am = 0.0, run_a2m = 0.0;
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+      if (lane == t) {
+        run_m = carry_m + mi;
+        run_am = carry_am + am;
+        run_a2m = carry_a2m + a2m;
+      }
+      carry_m = readlane_f64(run_m, t);
+      carry_am = readlane_f64(run_am, t);
+      carry_a2m = readlane_f64(run_a2m, t);
+    }
+    if (live) {
+      double c = (2.0 * run_am) / (uk + 2.0 * run_m);
+      c = fmin(fmax(c, lower), ai);
+      const double c2 = c * c;
+      const double e = ((c2 * nk + run_a2m) - (2.0 * c) * run_am) + c2 * run_m;
+      if (e < best_e) {
+        best_e = e;
+        best_c = c;
+        best_i = i;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double oe = __shfl_xor(best_e, off, kWave);
+    const double oc = __shfl_xor(best_c, off, kWave);
+    const int64_t oi = __shfl_xor(best_i, off, kWave);
+    if (oe < best_e || (oe == best_e && oi < best_i)) {
+      best_e = oe;
+      best_c = oc;
+      best_i = oi;
+    }
+  }
+  if (lane == 0) {
+    if (bounds) bounds[seg] = best_c;
+    if (scale) {
+      double sc = fmax(best_c, 1e-9) / qmax;
+      if (blockwise) {
+        uint16_t half_bits;
+        sc = static_cast<double>(round_scale_blockwise(static_cast<float>(sc), &half_bits));
+      }
+      scale[seg] = sc;
+    }
+  }
 }
 
 // ------------------------------------------------------------------- quantize ---
@@ -320,7 +617,7 @@ extern "C" int32_t mi355q_oscar_col_sumsq_f32(const float* x, int64_t rows, int6
   if (rows <= 0 || d <= 0) return fail(MI355Q_BAD_SHAPE, "oscar_col_sumsq: rows=%lld d=%lld",
                                        (long long)rows, (long long)d);
   const unsigned blocks = static_cast<unsigned>((d + 63) / 64);
-  hipLaunchKernelGGL(col_sumsq_kernel<16>, dim3(blocks), dim3(64), 0, as_stream(stream), x, rows, d,
+  hipLaunchKernelGGL(col_sumsq_kernel<64>, dim3(blocks), dim3(64), 0, as_stream(stream), x, rows, d,
                      mean, out);
   MI355Q_CHECK_LAUNCH("oscar_col_sumsq");
   return MI355Q_OK;
@@ -372,8 +669,9 @@ extern "C" int32_t mi355q_oscar_winner_energy_f64(const int32_t* winner, const d
   if (n <= 0 || d <= 0 || g <= 0 || d % g)
     return fail(MI355Q_BAD_SHAPE, "oscar_winner_energy: n=%lld d=%lld g=%d", (long long)n,
                 (long long)d, g);
-  hipLaunchKernelGGL(winner_energy_kernel, dim3(static_cast<unsigned>((d + 63) / 64)), dim3(64), 0,
-                     as_stream(stream), winner, wsq, n, d, g, eff_out);
+  hipLaunchKernelGGL(winner_energy_kernel,
+                     dim3(static_cast<unsigned>(d / g), static_cast<unsigned>((g + 255) / 256)),
+                     dim3(256), 0, as_stream(stream), winner, wsq, n, d, g, eff_out);
   MI355Q_CHECK_LAUNCH("oscar_winner_energy");
   return MI355Q_OK;
 }
@@ -413,12 +711,14 @@ extern "C" int32_t mi355q_oscar_clip_workspace_bytes(int64_t n, int64_t d, int64
 
 extern "C" int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s, const double* m,
                                                 int64_t n, int64_t d, int64_t g, const double* u,
-                                                const double* noise, double* bounds_out,
-                                                void* workspace, size_t workspace_bytes,
-                                                void* stream) {
+                                                const double* noise, int32_t qmax,
+                                                int32_t blockwise_scale, double* bounds_out,
+                                                double* scale_out, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
   clear_error();
-  if (!w || !s || !m || !u || !noise || !bounds_out || !workspace)
+  if (!w || !s || !m || !u || !noise || (!bounds_out && !scale_out) || !workspace)
     return fail(MI355Q_BAD_ARG, "oscar_clip_bounds: null pointer");
+  if (qmax <= 0) return fail(MI355Q_BAD_ARG, "oscar_clip_bounds: qmax=%d", qmax);
   size_t need = 0;
   int32_t st_code = mi355q_oscar_clip_workspace_bytes(n, d, g, &need);
   if (st_code != MI355Q_OK) return st_code;
@@ -438,24 +738,57 @@ extern "C" int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s,
   double* vals_out = reinterpret_cast<double*>(base + 3 * slab);
   void* tmp = base + 4 * slab;
   size_t tmp_bytes = need - 4 * slab;
-  hipLaunchKernelGGL(sort_keys_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
-                     st, w, s, m, total, d, keys_in, vals_in);
-  MI355Q_CHECK_LAUNCH("oscar_sort_keys");
-  hipError_t e;
-  if (segments == 1) {
-    e = rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
-                                       static_cast<size_t>(total), 0, 64, st);
+  int64_t seg_stride = g, elem_stride = 1;
+  if (g <= 8192 && g >= 2 && !getenv("MI355Q_OSCAR_LIBSORT")) {
+    int32_t P = 32;
+    while (P < g) P <<= 1;
+    const int32_t tile = P > 4096 ? P : 4096;
+    const int32_t transposed = P <= 256;
+    const size_t lds = (static_cast<size_t>(lds_pad(tile)) + 2) * (sizeof(double) + sizeof(uint16_t));
+    const int64_t tiles = (segments + tile / P - 1) / (tile / P);
+    if (lds > 64 * 1024) {
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tile_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          static_cast<int>(lds));
+      if (ea != hipSuccess) return fail(MI355Q_HIP_ERROR, "oscar sort LDS: %s", hipGetErrorString(ea));
+    }
+    hipLaunchKernelGGL(sort_tile_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kSortThreads), lds, st,
+                       w, s, m, segments, static_cast<int32_t>(g), P, tile, d, transposed, keys_out,
+                       vals_out);
+    MI355Q_CHECK_LAUNCH("oscar_sort_tile");
+    if (transposed) {
+      seg_stride = 1;
+      elem_stride = segments;
+    }
   } else {
-    auto begin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0),
-                                                  SegmentStart{static_cast<uint32_t>(g)});
-    e = rocprim::segmented_radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, keys_out, vals_in,
-                                                 vals_out, static_cast<size_t>(total),
-                                                 static_cast<unsigned>(segments), begin, begin + 1,
-                                                 0, 64, st);
+    hipLaunchKernelGGL(sort_keys_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
+                       0, st, w, s, m, total, d, keys_in, vals_in);
+    MI355Q_CHECK_LAUNCH("oscar_sort_keys");
+    hipError_t e;
+    if (segments == 1) {
+      e = rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                         static_cast<size_t>(total), 0, 64, st);
+    } else {
+      auto begin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0),
+                                                    SegmentStart{static_cast<uint32_t>(g)});
+      e = rocprim::segmented_radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, keys_out, vals_in,
+                                                   vals_out, static_cast<size_t>(total),
+                                                   static_cast<unsigned>(segments), begin, begin + 1,
+                                                   0, 64, st);
+    }
+    if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "oscar sort: %s", hipGetErrorString(e));
   }
-  if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "oscar sort: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(clip_scan_kernel<8>, dim3(static_cast<unsigned>((segments + 63) / 64)), dim3(64),
-                     0, st, keys_out, vals_out, segments, g, G, u, noise, bounds_out);
+  if (elem_stride == 1 && g >= 256 && segments < 4096) {
+    // a lane per segment would fill fewer than 64 waves; the wave form costs ~70 SIMD cycles per
+    // element instead of ~6 but runs on segments (not segments / 64) waves
+    hipLaunchKernelGGL(clip_scan_wave_kernel, dim3(static_cast<unsigned>((segments + 3) / 4)), dim3(256),
+                       0, st, keys_out, vals_out, segments, g, G, u, noise, static_cast<double>(qmax),
+                       blockwise_scale, bounds_out, scale_out);
+  } else {
+    hipLaunchKernelGGL(clip_scan_kernel<8>, dim3(static_cast<unsigned>((segments + 63) / 64)), dim3(64),
+                       0, st, keys_out, vals_out, segments, g, G, seg_stride, elem_stride, u, noise,
+                       static_cast<double>(qmax), blockwise_scale, bounds_out, scale_out);
+  }
   MI355Q_CHECK_LAUNCH("oscar_clip_scan");
   return MI355Q_OK;
 }

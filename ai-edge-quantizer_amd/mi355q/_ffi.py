@@ -65,7 +65,7 @@ PROTOTYPES = {
     "mi355q_oscar_winner_energy_f64": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_i32, c_ptr, c_ptr]),
     "mi355q_oscar_clip_workspace_bytes": (c_i32, [c_i64, c_i64, c_i64, ctypes.POINTER(ctypes.c_size_t)]),
     "mi355q_oscar_clip_bounds_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
-                                             c_ptr, c_ptr, c_size, c_ptr]),
+                                             c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_oscar_quantize_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i32, c_i32,
                                           c_ptr, c_ptr]),
 }

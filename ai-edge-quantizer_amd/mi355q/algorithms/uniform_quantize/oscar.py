@@ -161,18 +161,21 @@ def calibrate(tfl_op, graph_info: qtyping.GraphInfo,
 
 
 def _clip_bounds_device(wd, s: np.ndarray, col_mu2: np.ndarray, num_bits: int,
-                        granularity: qtyping.QuantGranularity, ndim: int = 2) -> np.ndarray:
-  """Bounds of W*s in the shape min/max QSVs have (ref :327-383); col_mu2 unfloored masses."""
+                        granularity: qtyping.QuantGranularity, ndim: int = 2, want: str = "bounds"):
+  """Bounds of W*s in the shape min/max QSVs have (ref :327-383); col_mu2 unfloored masses.
+  want="scale": the device tensor of symmetric scales derived from the bounds instead (float64
+  values, flat) plus the parameter shape -- the bounds never visit the host."""
   n, d = wd.shape
   qmax = 2 ** (num_bits - 1) - 1
   masses = _floor_positive(col_mu2)
+  blockwise = uniform_quantize_tensor.is_blockwise(granularity)
   if granularity == qtyping.QuantGranularity.TENSORWISE:
     g, shape = n * d, (1,) * ndim
     totals = np.array([float(np.tile(masses, n).sum()) + _EPS])
   elif granularity == qtyping.QuantGranularity.CHANNELWISE:
     g, shape = d, (n, 1)
     totals = np.array([float(masses.sum()) + _EPS])
-  elif uniform_quantize_tensor.is_blockwise(granularity):
+  elif blockwise:
     g = uniform_quantize_tensor.extract_block_size_from_granularity(granularity)
     if _Op.FULLY_CONNECTED not in tfl_flatbuffer_utils.TFL_OP_TO_BLOCKWISE_WEIGHT_QUANTIZED_DIM:
       raise ValueError(f"Blockwise granularity is not supported for op: {_Op.FULLY_CONNECTED}")
@@ -185,8 +188,12 @@ def _clip_bounds_device(wd, s: np.ndarray, col_mu2: np.ndarray, num_bits: int,
     raise ValueError(f"Unsupported granularity: {granularity}")
   u = totals / (6.0 * qmax * qmax)
   noise = totals / (12.0 * qmax * qmax)
-  bounds = ops.oscar_clip_bounds(wd, ops._f64_dev(s), ops._f64_dev(masses), g,  # pylint: disable=protected-access
-                                 ops._f64_dev(u), ops._f64_dev(noise))  # pylint: disable=protected-access
+  f64 = ops._f64_dev  # pylint: disable=protected-access
+  bounds, scale = ops.oscar_clip_bounds(wd, f64(s), f64(masses), g, f64(u), f64(noise), qmax,
+                                        blockwise_scale=blockwise, want_bounds=want == "bounds",
+                                        want_scale=want == "scale")
+  if want == "scale":
+    return scale, shape
   return rt.to_numpy(bounds).reshape(shape)
 
 
@@ -236,16 +243,20 @@ def _compute_oscar_weight_quant_params(op_info: qtyping.OpInfo,
     s = np.ones(in_ch, dtype=np.float64)
   col = (np.ones(in_ch) if mu2 is None
          else _columns_of(op_info.op_name, w, np.asarray(mu2, np.float64).ravel() / (s * s)))
-  bounds = _clip_bounds_device(wd, s, col, cfg.num_bits, granularity)
-  zp, scale = uniform_quantize_tensor.tensor_zp_scale_from_min_max(
-      -bounds, bounds, cfg.num_bits, cfg.symmetric, granularity, None)
+  # tensor_zp_scale_from_min_max(-bounds, bounds, ...) of a symmetric signed target happens in
+  # the scan kernel's epilogue: scale = max(bound, 1e-9) / qmax (blockwise: bf16 / f16 rounded),
+  # zero point 0 (ref :437-445)
+  scale_d, shape = _clip_bounds_device(wd, s, col, cfg.num_bits, granularity, want="scale")
   quantized_dim = common_utils.get_weight_quantized_dim(op_info, w, granularity)
   narrow = bool(cfg.symmetric and cfg.num_bits >= 8)
-  qmin, qmax = uniform_quantize_tensor.get_quantized_range(
-      uniform_quantize_tensor.IntType(cfg.num_bits, True))
-  g = n * in_ch // scale.size
-  q = ops.oscar_quantize(wd, ops._f64_dev(s), ops._f64_dev(scale.reshape(-1)), g,  # pylint: disable=protected-access
+  qtype = uniform_quantize_tensor.IntType(cfg.num_bits, True)
+  qmin, qmax = uniform_quantize_tensor.get_quantized_range(qtype)
+  q = ops.oscar_quantize(wd, ops._f64_dev(s), scale_d, n * in_ch // scale_d.numel(),  # pylint: disable=protected-access
                          int(qmin) + (1 if narrow else 0), int(qmax))
+  scale = rt.to_numpy(scale_d).reshape(shape)
+  if blockwise:
+    scale = scale.astype(np.float32)         # exact: the values are float16-representable
+  zp = uniform_quantize_tensor.assign_quantized_type(np.zeros_like(scale, dtype=np.int32), qtype)
   return qtyping.UniformQuantParams(
       scale=scale, zero_point=zp, num_bits=cfg.num_bits, symmetric=cfg.symmetric,
       quantized_dimension=quantized_dim, block_size=block_size,

@@ -403,14 +403,14 @@ def oscar_col_sumsq(x: torch.Tensor, mean: bool) -> torch.Tensor:
 
 
 def oscar_group_terms(w: torch.Tensor, s: torch.Tensor, g: int):
-  """(sums float64 [d/g], winner int32 [n, d/g], wsq float64 [n, d/g]) for scales s float64 [d]."""
+  """(sums float64 [d/g], winner int32 [d/g, n], wsq float64 [d/g, n]) for scales s float64 [d]."""
   rt.require_gpu()
   w = _f32(w)
   n, d = w.shape
   groups = d // g
   top2 = rt.empty((groups * n,), torch.float64)
-  winner = rt.empty((n, groups), torch.int32)
-  wsq = rt.empty((n, groups), torch.float64)
+  winner = rt.empty((groups, n), torch.int32)
+  wsq = rt.empty((groups, n), torch.float64)
   sums = rt.empty((groups,), torch.float64)
   _ffi.check(_ffi.lib().mi355q_oscar_group_terms_f32(
       rt.ptr(w), rt.ptr(s), n, d, g, rt.ptr(top2), rt.ptr(winner), rt.ptr(wsq), rt.ptr(sums),
@@ -420,7 +420,7 @@ def oscar_group_terms(w: torch.Tensor, s: torch.Tensor, g: int):
 
 def oscar_winner_energy(winner: torch.Tensor, wsq: torch.Tensor, d: int, g: int) -> torch.Tensor:
   rt.require_gpu()
-  n = winner.shape[0]
+  n = winner.shape[1]
   eff = rt.empty((d,), torch.float64)
   _ffi.check(_ffi.lib().mi355q_oscar_winner_energy_f64(rt.ptr(winner), rt.ptr(wsq), n, d, g,
                                                        rt.ptr(eff), rt.stream_ptr()))
@@ -428,8 +428,10 @@ def oscar_winner_energy(winner: torch.Tensor, wsq: torch.Tensor, d: int, g: int)
 
 
 def oscar_clip_bounds(w: torch.Tensor, s: torch.Tensor, masses: torch.Tensor, g: int,
-                      u: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
-  """Optimal clip bound (float64) of every g-element segment of the flattened weight."""
+                      u: torch.Tensor, noise: torch.Tensor, qmax: int, blockwise_scale: bool = False,
+                      want_bounds: bool = True, want_scale: bool = False):
+  """Optimal clip bound (float64) of every g-element segment of the flattened weight and / or
+  the symmetric scale derived from it (float64 values; float16-representable when blockwise)."""
   import ctypes
   rt.require_gpu()
   w = _f32(w)
@@ -437,11 +439,12 @@ def oscar_clip_bounds(w: torch.Tensor, s: torch.Tensor, masses: torch.Tensor, g:
   need = ctypes.c_size_t(0)
   _ffi.check(_ffi.lib().mi355q_oscar_clip_workspace_bytes(n, d, g, ctypes.byref(need)))
   ws = rt.empty((need.value,), torch.uint8)
-  bounds = rt.empty((n * d // g,), torch.float64)
+  bounds = rt.empty((n * d // g,), torch.float64) if want_bounds else None
+  scale = rt.empty((n * d // g,), torch.float64) if want_scale else None
   _ffi.check(_ffi.lib().mi355q_oscar_clip_bounds_f32(
-      rt.ptr(w), rt.ptr(s), rt.ptr(masses), n, d, g, rt.ptr(u), rt.ptr(noise), rt.ptr(bounds),
-      rt.ptr(ws), need.value, rt.stream_ptr()))
-  return bounds
+      rt.ptr(w), rt.ptr(s), rt.ptr(masses), n, d, g, rt.ptr(u), rt.ptr(noise), int(qmax),
+      int(blockwise_scale), rt.ptr(bounds), rt.ptr(scale), rt.ptr(ws), need.value, rt.stream_ptr()))
+  return bounds, scale
 
 
 def oscar_quantize(w: torch.Tensor, s: torch.Tensor, scale: torch.Tensor, g: int, qlo: int,

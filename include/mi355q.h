@@ -307,11 +307,11 @@ int32_t mi355q_oscar_col_sumsq_f32(const float* x, int64_t rows, int64_t d, int3
  *   sums_out[k] = np.sum over rows of top^2 for group k (8192-chunk pairwise order).
  * The objective of ref oscar.py:175-194 is sum_k sums_out[k] * mass_k (host); winner / wsq
  * feed mi355q_oscar_winner_energy_f64 (ref oscar.py:236-246).
- *   top2_workspace double [d/g * n]; winner_out int32 [n, d/g]; wsq_out double [n, d/g] */
+ *   top2_workspace double [d/g * n]; winner_out int32 [d/g, n]; wsq_out double [d/g, n] */
 int32_t mi355q_oscar_group_terms_f32(const float* w, const double* s, int64_t n, int64_t d,
                                      int32_t g, double* top2_workspace, int32_t* winner_out,
                                      double* wsq_out, double* sums_out, void* stream);
-/* eff_out[j] = sum over rows in order of wsq[r, j/g] where winner[r, j/g] == j
+/* eff_out[j] = sum over rows in order of wsq[j/g, r] where winner[j/g, r] == j
  * (np.add.at(a_eff, j_star, w[rows, j_star]**2), ref oscar.py:243-246). */
 int32_t mi355q_oscar_winner_energy_f64(const int32_t* winner, const double* wsq, int64_t n,
                                        int64_t d, int32_t g, double* eff_out, void* stream);
@@ -320,11 +320,16 @@ int32_t mi355q_oscar_winner_energy_f64(const int32_t* winner, const double* wsq,
  * the masses m[j], sequential running sums, closed-form candidate per breakpoint interval,
  * first minimum (ref oscar.py:62-108). u[k] = M_k/(6 qmax^2), noise[k] = M_k/(12 qmax^2) with
  * M_k the group's total mass + 1e-12, k = column group (host FP64).
- *   bounds_out double [n*d/g]; workspace: mi355q_oscar_clip_workspace_bytes(n, d, g) */
+ * scale_out (optional) is tensor_zp_scale_from_min_max(-bound, bound) of the symmetric signed
+ * target: max(bound, 1e-9) / qmax, and with blockwise_scale != 0 rounded FP64 -> float32 ->
+ * bfloat16 -> float16 (ref uniform_quantize_tensor.py:553-581), stored as double.
+ *   bounds_out / scale_out double [n*d/g], either may be NULL;
+ *   workspace: mi355q_oscar_clip_workspace_bytes(n, d, g) */
 int32_t mi355q_oscar_clip_workspace_bytes(int64_t n, int64_t d, int64_t g, size_t* bytes_out);
 int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s, const double* m, int64_t n,
                                      int64_t d, int64_t g, const double* u, const double* noise,
-                                     double* bounds_out, void* workspace, size_t workspace_bytes,
+                                     int32_t qmax, int32_t blockwise_scale, double* bounds_out,
+                                     double* scale_out, void* workspace, size_t workspace_bytes,
                                      void* stream);
 /* out = clip(rint((w * s[j]) / scale[segment]), qlo, qhi) with FP64 product and quotient
  * (uniform_quantize of the FP64 scaled weight, ref oscar.py:470-478). scale double [n*d/g]. */
