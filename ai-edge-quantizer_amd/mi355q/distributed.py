@@ -242,7 +242,7 @@ def allreduce_min_max(local_stats: np.ndarray, group=None) -> np.ndarray:
   return np.stack([mn, mx], axis=-1)
 
 
-# ------------------------------------------------------------ GPTQ Hessian ---
+# ---------------------------------------------- GPTQ Hessian / OSCAR mu2 ---
 def allreduce_hessian(weighted_sum, num_samples: int, group=None):
   """Merges per-rank Hessian statistics into the global sample-weighted mean.
 
@@ -251,6 +251,8 @@ def allreduce_hessian(weighted_sum, num_samples: int, group=None):
   nccl); num_samples = sum_i n_i. Returns (H, total_samples) with
   H = sum_all / total, which is what chaining _gptq_merge_hessian
   (ref: utils/qsv_utils.py:71-88) over all samples yields up to FP64 rounding.
+  OSCAR's per-channel second moment merges by the same sample-weighted mean
+  (_oscar_merge_mu2, ref: utils/qsv_utils.py:125-158): pass sum_i n_i * mu2_i and sum_i n_i.
   """
   rank, world = _world(group)
   if hasattr(weighted_sum, "device_tensor"):      # runtime.HbmArray: reduce it where it lives
@@ -267,3 +269,6 @@ def allreduce_hessian(weighted_sum, num_samples: int, group=None):
   total = int(n.item())
   h = t / total if total else t
   return (h.cpu().numpy() if is_np else h), total
+
+
+allreduce_second_moment = allreduce_hessian   # OSCAR mu2: same sample-weighted mean

@@ -134,3 +134,45 @@ def test_activation_statistics_random(seed):
     got = common_quantize.get_activation_min_max(x, -3e38, 3e38)
   for key in ("min", "max"):
     assert got[key].shape == ref[key].shape and np.array_equal(got[key], ref[key], equal_nan=True), (k, shape)
+
+
+# ------------------------------------------------------------------------------ OSCAR (f4) ---
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_oscar_any_shape(seed):
+  """FULLY_CONNECTED weights of random shape / granularity / bit width with random activation
+  masses (dead channels, huge dynamic range, sometimes none at all): channel scales, FP64 or
+  bf16-rounded scales, ints and the float32 multiplier equal the oracle's, bit for bit."""
+  from mi355q.algorithms.uniform_quantize import oscar
+  rng = np.random.default_rng(9000 + seed)
+  gran = ["CHANNELWISE", "CHANNELWISE", "BLOCKWISE_32", "BLOCKWISE_64", "BLOCKWISE_128", "BLOCKWISE_256",
+          "TENSORWISE"][int(rng.integers(0, 7))]
+  bits = [4, 4, 8, 2][int(rng.integers(0, 4))]
+  rows = int(rng.integers(1, 400))
+  if gran.startswith("BLOCKWISE"):
+    cols = int(gran.split("_")[1]) * int(rng.integers(1, 9))
+  elif gran == "TENSORWISE":
+    rows, cols = int(rng.integers(1, 40)), int(rng.integers(1, 300))
+  else:
+    cols = int(rng.integers(1, 2500))
+  w = rng.standard_normal((rows, cols)).astype(np.float32) * np.float32(10.0 ** rng.uniform(-3, 2))
+  style = int(rng.integers(0, 5))
+  if style == 0:
+    w[:, : max(1, cols // 10)] *= 30.0
+  elif style == 1:
+    w[rng.random((rows, cols)) < 0.3] = 0.0
+  elif style == 2:
+    w = (np.round(w / np.abs(w).max() * 6) / 6).astype(np.float32)          # heavy ties
+  mu2 = np.exp(rng.normal(size=cols) * rng.uniform(0.1, 3.0))
+  if style == 2 or rng.random() < 0.15:
+    mu2 = None                          # ties + non-uniform masses depend on NumPy's unstable argsort
+  elif rng.random() < 0.3:
+    mu2[rng.random(cols) < 0.2] = 0.0
+  from mi355q import qtyping as q
+  cfg = q.TensorQuantizationConfig(num_bits=bits, symmetric=True, granularity=q.QuantGranularity[gran])
+  info = q.OpInfo(op=q.OperatorT(), op_name=q.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
+                  op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg))
+  res = oscar.get_tensor_quant_params(info, cfg, w, None if mu2 is None else {"mu2": mu2})
+  ref = O.oscar_quant_params(w, mu2, bits, gran)
+  assert np.array_equal(res.custom_algorithm_param["multiplier"], ref["multiplier"])
+  assert res.scale.dtype == ref["scale"].dtype and np.array_equal(res.scale, ref["scale"])
+  assert np.array_equal(res.quantized_data, ref["quantized_data"])
