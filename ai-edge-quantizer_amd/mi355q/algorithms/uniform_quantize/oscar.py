@@ -66,6 +66,12 @@ def _weight_on_device(w):
   """float32 [n, d] device copy. The reference widens to FP64 first; float32 -> FP64 is exact, so
   the kernels widen element by element instead."""
   w = np.asarray(w)
+  if w.dtype == np.float64:       # accepted when it is a widened float32 tensor (the model's dtype)
+    narrow = w.astype(np.float32)
+    if not np.array_equal(narrow.astype(np.float64), w):
+      raise TypeError("OSCAR GPU path expects float32 weights (float64 values that are not"
+                      " float32-representable were passed)")
+    w = narrow
   if w.dtype != np.float32:
     raise TypeError(f"OSCAR GPU path expects float32 weights, got {w.dtype}")
   return rt.to_device(w)
@@ -100,11 +106,19 @@ class _Objective:
     return rt.to_numpy(ops.oscar_winner_energy(self.winner, self.wsq, self.d, self.g))
 
 
+def _channel_scale_objective(w, s: np.ndarray, mu2: np.ndarray, block_size: int) -> float:
+  """Total quantization proxy objective for scales s on weight w (ref :175-194)."""
+  rt.require_gpu()
+  wd = w if not isinstance(w, np.ndarray) else _weight_on_device(w)
+  return _Objective(wd, np.asarray(mu2, np.float64), block_size)(np.asarray(s, np.float64))
+
+
 def _compute_channel_scales(w, mu2: np.ndarray, block_size: int = 0, num_iters: int = 3):
   """(s, gain): per-input-channel scales, or (None, 1.0) when identity is at least as good
   (ref :197-263). `w` float32 ndarray or device tensor."""
   rt.require_gpu()
   wd = w if not isinstance(w, np.ndarray) else _weight_on_device(w)
+  mu2 = np.asarray(mu2, np.float64)
   in_ch = mu2.size
   mu2 = _floor_positive(mu2)
   mu = np.sqrt(mu2)
