@@ -64,7 +64,19 @@ _MATERIALIZERS = {
     _Op.EMBEDDING_LOOKUP: common_quantize.materialize_embedding_lookup,
     _Op.BATCH_MATMUL: common_quantize.materialize_batch_matmul,
     _Op.CONV_2D_TRANSPOSE: common_quantize.materialize_conv2d_transpose,
+    # ops that only carry activations: quantized under static (SRQ) recipes
+    _Op.SOFTMAX: common_quantize.materialize_softmax_and_logistic,
+    _Op.LOGISTIC: common_quantize.materialize_softmax_and_logistic,
+    _Op.TANH: common_quantize.materialize_tanh,
+    _Op.STABLEHLO_COMPOSITE: common_quantize.materialize_composite,
 }
+for _name in ("RESHAPE", "AVERAGE_POOL_2D", "TRANSPOSE", "GELU", "ADD", "SUB", "MUL", "MEAN", "RSQRT",
+              "CONCATENATION", "STRIDED_SLICE", "SPLIT", "SLICE", "SUM", "SELECT", "SELECT_V2",
+              "DYNAMIC_UPDATE_SLICE", "PAD", "SQUARED_DIFFERENCE", "MAX_POOL_2D", "RESIZE_BILINEAR",
+              "RESIZE_NEAREST_NEIGHBOR", "GATHER_ND", "PACK", "UNPACK", "DIV", "BROADCAST_TO", "SQRT",
+              "GATHER", "HARD_SWISH", "MAXIMUM", "PADV2", "REDUCE_MIN", "EQUAL", "NOT_EQUAL",
+              "MIRROR_PAD", "SPACE_TO_DEPTH", "RELU"):
+  _MATERIALIZERS[_Op[_name]] = getattr(common_quantize, "materialize_" + _name.lower())
 
 
 def _register_weight_algorithm(name, module, ops, calibration_func, update_qsv_func):

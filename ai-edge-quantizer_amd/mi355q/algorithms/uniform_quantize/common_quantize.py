@@ -250,3 +250,69 @@ def materialize_input(get_tensor_quant_params_fn, op_info, graph_info, tensor_na
 
 
 materialize_output = materialize_input
+
+
+# ---- the ops that only carry activations (ref :127-304, 416-516, 639-1201) ---------------------
+# One row per op: (scale constraint, operand positions that are never quantized -- shapes, axes,
+# indices, conditions). The fixed-output ops list the parameters their TFLite kernels hard-code.
+_C = common_utils.OpQuantConstraint
+_ACTIVATION_OP_RULES = {
+    "composite": (_C.NO_CONSTRAIN, ()), "add": (_C.NO_CONSTRAIN, ()), "sub": (_C.NO_CONSTRAIN, ()),
+    "mul": (_C.NO_CONSTRAIN, ()), "div": (_C.NO_CONSTRAIN, ()), "gelu": (_C.NO_CONSTRAIN, ()),
+    "rsqrt": (_C.NO_CONSTRAIN, ()), "sqrt": (_C.NO_CONSTRAIN, ()), "hard_swish": (_C.NO_CONSTRAIN, ()),
+    "relu": (_C.NO_CONSTRAIN, ()), "equal": (_C.NO_CONSTRAIN, ()), "not_equal": (_C.NO_CONSTRAIN, ()),
+    "squared_difference": (_C.NO_CONSTRAIN, ()), "sum": (_C.NO_CONSTRAIN, (1,)),
+    "mean": (_C.NO_CONSTRAIN, (1,)),
+    "reshape": (_C.SAME_AS_INPUT_SCALE, (1,)), "transpose": (_C.SAME_AS_INPUT_SCALE, (1,)),
+    "average_pool_2d": (_C.SAME_AS_INPUT_SCALE, ()), "max_pool_2d": (_C.SAME_AS_INPUT_SCALE, ()),
+    "space_to_depth": (_C.SAME_AS_INPUT_SCALE, ()), "unpack": (_C.SAME_AS_INPUT_SCALE, ()),
+    "slice": (_C.SAME_AS_INPUT_SCALE, (1, 2)), "strided_slice": (_C.SAME_AS_INPUT_SCALE, (1, 2, 3)),
+    "split": (_C.SAME_AS_INPUT_SCALE, (0,)), "pad": (_C.SAME_AS_INPUT_SCALE, (1,)),
+    "mirror_pad": (_C.SAME_AS_INPUT_SCALE, (1,)), "resize_bilinear": (_C.SAME_AS_INPUT_SCALE, (1,)),
+    "resize_nearest_neighbor": (_C.SAME_AS_INPUT_SCALE, (1,)), "gather_nd": (_C.SAME_AS_INPUT_SCALE, (1,)),
+    "gather": (_C.SAME_AS_INPUT_SCALE, (1,)), "broadcast_to": (_C.SAME_AS_INPUT_SCALE, (1,)),
+    "reduce_min": (_C.SAME_AS_INPUT_SCALE, (1,)),
+    "concatenation": (_C.SAME_AS_OUTPUT_SCALE, ()), "maximum": (_C.SAME_AS_OUTPUT_SCALE, ()),
+    "pack": (_C.SAME_AS_OUTPUT_SCALE, ()), "select": (_C.SAME_AS_OUTPUT_SCALE, (0,)),
+    "select_v2": (_C.SAME_AS_OUTPUT_SCALE, (0,)), "padv2": (_C.SAME_AS_OUTPUT_SCALE, (1,)),
+    "dynamic_update_slice": (_C.SAME_AS_OUTPUT_SCALE, (2,)),
+}
+
+
+def _activation_op_materializer(name: str, constraint, ignored: tuple):
+  def materialize(get_tensor_quant_params_fn, op_info, graph_info, tensor_name_to_qsv,
+                  tensor_quant_params_cache):
+    return common_utils.materialize_standard_op(
+        op_info, graph_info, tensor_name_to_qsv, get_tensor_quant_params_fn,
+        tensor_quant_params_cache, constraint=constraint, inputs_to_ignore=list(ignored) or None)
+  materialize.__name__ = materialize.__qualname__ = f"materialize_{name}"
+  materialize.__doc__ = (f"tfl.{name}: {constraint.name}"
+                         + (f", operands {list(ignored)} left alone" if ignored else "") + ".")
+  return materialize
+
+
+for _name, (_constraint, _ignored) in _ACTIVATION_OP_RULES.items():
+  globals()[f"materialize_{_name}"] = _activation_op_materializer(_name, _constraint, _ignored)
+
+
+def _fixed(num_bits: int, scale: float, zero_point: int, symmetric: bool) -> qtyping.UniformQuantParams:
+  return qtyping.UniformQuantParams(num_bits=num_bits, quantized_dimension=None, scale=np.array(scale),
+                                    zero_point=np.array(zero_point), symmetric=symmetric)
+
+
+def materialize_softmax_and_logistic(get_tensor_quant_params_fn, op_info, graph_info,
+                                     tensor_name_to_qsv, tensor_quant_params_cache):
+  """Output in [0, 1): 1/256 with zero point -128 at 8 bits, 1/32768 at 16 (ref :195-231)."""
+  fixed = {8: _fixed(8, 1.0 / 256, -128, False), 16: _fixed(16, 1.0 / 32768, 0, True)}
+  return common_utils.materialize_op_with_output_activation_constraint(
+      op_info, graph_info, tensor_name_to_qsv, fixed, get_tensor_quant_params_fn,
+      tensor_quant_params_cache)
+
+
+def materialize_tanh(get_tensor_quant_params_fn, op_info, graph_info, tensor_name_to_qsv,
+                     tensor_quant_params_cache):
+  """Output in [-1, 1): 2^-(bits-1), zero point 0 (ref :639-666)."""
+  fixed = {bits: _fixed(bits, 1.0 / (1 << (bits - 1)), 0, bits == 16) for bits in (8, 16)}
+  return common_utils.materialize_op_with_output_activation_constraint(
+      op_info, graph_info, tensor_name_to_qsv, fixed, get_tensor_quant_params_fn,
+      tensor_quant_params_cache)

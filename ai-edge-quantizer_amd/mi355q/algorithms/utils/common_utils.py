@@ -5,12 +5,14 @@ algorithms/utils/common_utils.py that sit on the calibration / requantization
 path: the quant-params cache (ref :48-77), activation-QSV injection for GPTQ
 (ref :182-216), the per-tensor wrapper that calls get_tensor_quant_params
 (ref :219-291), the WEIGHT_ONLY / DRQ / SRQ transformation table
-(ref :1068-1121) and the quantized-dimension helpers (ref :1162-1207).
-Scale-constraint propagation between ops (SAME_AS_INPUT_SCALE, ...) is graph
-bookkeeping outside the hot path and is not restated.
+(ref :1068-1121), the quantized-dimension helpers (ref :1162-1207) and the
+scale constraints that tie an op's tensors together (same-as-input, same-as-output,
+fixed output; ref :167-179, 381-590, 878-1065).
 """
 from __future__ import annotations
 
+import dataclasses
+import enum
 from typing import Any, Optional, Sequence
 
 import numpy as np
@@ -161,26 +163,156 @@ def _tensor_params(tensor, is_inbounding_tensor, op_info, graph_info, tensor_nam
                                           is_constant)
 
 
+class OpQuantConstraint(enum.Enum):
+  """How an op ties the scales of its tensors (ref :167-179)."""
+  NO_CONSTRAIN = 0
+  SAME_AS_INPUT_SCALE = 1    # transpose / reshape / split ...: every tensor uses the input's scale
+  SAME_AS_OUTPUT_SCALE = 2   # concatenation ...: every tensor uses the output's scale
+  FIXED_OUTPUT_SCALE = 3     # softmax / logistic / tanh: the kernel dictates the output scale
+
+
+def _get_min_max_from_quant_params(quant_params: qtyping.UniformQuantParams):
+  """The float range a set of (single-scale) quantization parameters can represent: dequantized
+  qmin / qmax, mirrored when symmetric (ref :858-875). O(1) host math with the dtype flow of
+  `uniform_dequantize(np.array(q), params)`: float64 scalars."""
+  from ..uniform_quantize import uniform_quantize_tensor  # (circular at import time)
+  qmin, qmax = uniform_quantize_tensor.get_quantized_range(
+      uniform_quantize_tensor.IntType(quant_params.num_bits, True))
+  scale, zp = quant_params.scale, quant_params.zero_point
+  if np.ndim(scale) != 0:
+    if np.size(scale) != 1 or np.size(zp) != 1:
+      raise ValueError("Scale and zero_point must contain single element for scalar tensor."
+                       f" Got scale: {scale}, zero_point: {zp}")
+    scale, zp = np.array(np.asarray(scale).item()), np.array(np.asarray(zp).item())
+  lo = np.multiply(np.array(qmin) - zp, scale)
+  hi = np.multiply(np.array(qmax) - zp, scale)
+  if quant_params.symmetric:
+    lo = -hi
+  return lo, hi
+
+
+def _with_given_params(tensors, quant_params, is_inbounding_tensor, op_info, graph_info,
+                       tensor_name_to_qsv, get_tensor_quant_params_fn, cache):
+  """Every tensor takes `quant_params`; constants are quantized with them (ref :381-437)."""
+  from ..uniform_quantize import uniform_quantize_tensor
+  if quant_params is not None and quant_params.quantized_data is not None:
+    quant_params = dataclasses.replace(quant_params, quantized_data=None)
+  out = []
+  for tensor in tensors:
+    data = tfl_flatbuffer_utils.get_tensor_data(tensor, graph_info.buffers)
+    params = quant_params
+    if quant_params is not None and data is not None:
+      params = dataclasses.replace(
+          quant_params, quantized_data=uniform_quantize_tensor.uniform_quantize(data, quant_params))
+    out.append(_tensor_params(tensor, is_inbounding_tensor, op_info, graph_info, tensor_name_to_qsv,
+                              get_tensor_quant_params_fn, cache, quant_params=params))
+  return out
+
+
+def _same_as_input_scale(inputs, outputs, op_info, graph_info, tensor_name_to_qsv, fn, cache):
+  """ref :440-524. The outputs inherit the (single) input's parameters AND its QSV, so that
+  ops further down see the range that will actually be used."""
+  if len(inputs) != 1:
+    raise ValueError("Trying to get a single tensor params with a list of multiple tensor with"
+                     f" size {len(inputs)}.")
+  first = _tensor_params(inputs[0], True, op_info, graph_info, tensor_name_to_qsv, fn, cache)
+  params = first.consumers[0].parameters
+  if not isinstance(params, qtyping.UniformQuantParams):
+    raise ValueError("_materialize_standard_op_with_same_as_input_scale only supports"
+                     f" UniformQuantParams. For tensor {first.tensor_name}, got {type(params)}")
+  out = [first] + _with_given_params(outputs, params, False, op_info, graph_info,
+                                     tensor_name_to_qsv, fn, cache)
+  qsv = tensor_name_to_qsv.get(first.tensor_name)
+  if qsv is None:
+    if tfl_flatbuffer_utils.get_tensor_data(inputs[0], graph_info.buffers) is None:
+      raise ValueError(f"Input tensor qsv is None for tensor {first.tensor_name}.")
+    lo, hi = _get_min_max_from_quant_params(params)      # a constant input: range of its params
+    qsv = {"min": lo, "max": hi}
+  for tensor in outputs:
+    tensor_name_to_qsv[tfl_flatbuffer_utils.get_tensor_name(tensor)] = qsv
+  return out
+
+
+def _same_as_output_scale(inputs, outputs, op_info, graph_info, tensor_name_to_qsv, fn, cache):
+  """ref :527-590."""
+  if len(outputs) != 1:
+    raise ValueError("Trying to get a single tensor params with a list of multiple tensor with"
+                     f" size {len(outputs)}.")
+  last = _tensor_params(outputs[0], False, op_info, graph_info, tensor_name_to_qsv, fn, cache)
+  params = None
+  if last.producer is not None:
+    params = last.producer.parameters
+    if not isinstance(params, qtyping.UniformQuantParams):
+      raise ValueError("_materialize_standard_op_with_same_as_output_scale only supports"
+                       f" UniformQuantParams. For tensor {last.tensor_name}, got {type(params)}")
+  return _with_given_params(inputs, params, True, op_info, graph_info, tensor_name_to_qsv, fn,
+                            cache) + [last]
+
+
 def materialize_standard_op(op_info: qtyping.OpInfo, graph_info: qtyping.GraphInfo,
                             tensor_name_to_qsv: dict[str, Any], get_tensor_quant_params_fn,
                             tensor_quant_params_cache: TensorQuantParamsCache,
+                            constraint: OpQuantConstraint = OpQuantConstraint.NO_CONSTRAIN,
                             inputs_to_ignore: Optional[Sequence[int]] = None,
                             outputs_to_ignore: Optional[Sequence[int]] = None):
-  """Per-tensor params for an op without scale constraints (ref :878-984,
-  NO_CONSTRAIN branch). Order: inputs then outputs; missing (-1) tensors are
-  skipped; non-float32 and ignored tensors get NO_QUANTIZE."""
-  ignore_in, ignore_out = set(inputs_to_ignore or []), set(outputs_to_ignore or [])
+  """Per-tensor params of an op (ref :878-984). Result order: inputs then outputs, missing (-1)
+  tensors skipped; ignored positions and non-float32 tensors get NO_QUANTIZE; the others follow
+  the op's scale constraint."""
+  tensors = graph_info.subgraph_tensors
+  is_f32 = lambda tid: int(tensors[tid].type) == int(qtyping.TensorType.FLOAT32)  # noqa: E731
+  chosen, skipped = {}, {}
+  for inbound, ids, ignore in ((True, op_info.op.inputs, set(inputs_to_ignore or [])),
+                               (False, op_info.op.outputs, set(outputs_to_ignore or []))):
+    # (the reference looks the dtype of index -1 up as well: Python's last tensor)
+    keep = [k for k, tid in enumerate(ids) if k not in ignore and is_f32(tid)]
+    chosen[inbound] = [tensors[tid] for k, tid in enumerate(ids) if tid != -1 and k in keep]
+    skipped[inbound] = [k for k, tid in enumerate(ids) if tid != -1 and k not in keep]
+  args = (op_info, graph_info, tensor_name_to_qsv, get_tensor_quant_params_fn, tensor_quant_params_cache)
+  if not chosen[True] and not chosen[False]:
+    params = []
+  elif constraint == OpQuantConstraint.SAME_AS_INPUT_SCALE:
+    params = _same_as_input_scale(chosen[True], chosen[False], *args)
+  elif constraint == OpQuantConstraint.SAME_AS_OUTPUT_SCALE:
+    params = _same_as_output_scale(chosen[True], chosen[False], *args)
+  else:
+    params = ([_tensor_params(t, True, *args) for t in chosen[True]]
+              + [_tensor_params(t, False, *args) for t in chosen[False]])
+  # weave the NO_QUANTIZE records of the skipped tensors back in, in operand order
+  params = iter(params)
   out = []
-  for inbound, ids, ignored in ((True, op_info.op.inputs, ignore_in),
-                                (False, op_info.op.outputs, ignore_out)):
-    for pos, tid in enumerate(ids):
+  for inbound, ids in ((True, op_info.op.inputs), (False, op_info.op.outputs)):
+    for k, tid in enumerate(ids):
       if tid == -1:
         continue
-      tensor = graph_info.subgraph_tensors[tid]
-      name = tfl_flatbuffer_utils.get_tensor_name(tensor)
-      if pos in ignored or int(tensor.type) != int(qtyping.TensorType.FLOAT32):
-        out.append(_no_quantize_params(name, op_info, inbound))
+      if k in skipped[inbound]:
+        out.append(_no_quantize_params(tfl_flatbuffer_utils.get_tensor_name(tensors[tid]), op_info, inbound))
       else:
-        out.append(_tensor_params(tensor, inbound, op_info, graph_info, tensor_name_to_qsv,
-                                  get_tensor_quant_params_fn, tensor_quant_params_cache))
+        out.append(next(params))
   return out
+
+
+def materialize_op_with_output_activation_constraint(
+    op_info: qtyping.OpInfo, graph_info: qtyping.GraphInfo, tensor_name_to_qsv: dict[str, Any],
+    output_activation_constraints: dict[int, qtyping.UniformQuantParams], get_tensor_quant_params_fn,
+    tensor_quant_params_cache: TensorQuantParamsCache):
+  """Ops whose kernels hard-code the output scale (ref :987-1065): under SRQ the output takes
+  the fixed parameters for the activation bit width, and its QSV becomes their range."""
+  if len(op_info.op.outputs) != 1:
+    raise ValueError("Materialize op with output activation constraint only supports ops with a"
+                     " single output tensor.")
+  params = materialize_standard_op(op_info, graph_info, tensor_name_to_qsv, get_tensor_quant_params_fn,
+                                   tensor_quant_params_cache, constraint=OpQuantConstraint.FIXED_OUTPUT_SCALE)
+  last = params[-1]
+  act = op_info.op_quant_config.activation_tensor_config
+  if act is not None and last.producer is not None:
+    if act.num_bits not in output_activation_constraints:
+      raise ValueError("Output activation constraints dictionary does not contain entity for"
+                       f" activation num bits {act.num_bits}.")
+    fixed = output_activation_constraints[act.num_bits]
+    last.producer = qtyping.OpToTensorParams(subgraph_op_id=last.producer.subgraph_op_id,
+                                             transformations=last.producer.transformations,
+                                             parameters=fixed)
+    lo, hi = _get_min_max_from_quant_params(fixed)
+    tensor_name_to_qsv[last.tensor_name]["min"] = lo
+    tensor_name_to_qsv[last.tensor_name]["max"] = hi
+  return params

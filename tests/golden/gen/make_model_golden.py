@@ -228,7 +228,7 @@ def main():
   print("wrote", len(cases), "cases")
 
 
-if __name__ == "__main__" and not {"--srq", "--insts", "--oscar"} & set(sys.argv):
+if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more"} & set(sys.argv):
   main()
 
 
@@ -434,3 +434,92 @@ def oscar_model_cases():
 
 if __name__ == "__main__" and "--oscar" in sys.argv:
   oscar_model_cases()
+
+
+# ------------------------------------------------ static recipes on EVERY reference test model ---
+def srq_all_cases():
+  """static_wi8_ai8 / static_wi8_ai16 over all of the reference's test models (every op kind the
+  registry knows: scale constraints, fixed output scales, ignored operands), with a synthetic
+  calibration result. Records per-tensor parameters and the quantized model (or the error)."""
+  import zlib
+  from ai_edge_quantizer import recipe as ref_recipe
+  out = {}
+  names = sorted(f[:-7] for f in os.listdir(os.path.join(REF, "tests/models")) if f.endswith(".tflite"))
+  for name in names:
+    if name in SRQ_MODELS:
+      continue                                   # already in ref_srq_params.json
+    path = os.path.join(REF, "tests/models", name + ".tflite")
+    shutil.copyfile(path, os.path.join(GOLDEN, "models", name + ".tflite"))
+    for rname, rcp in (("static_wi8_ai8", ref_recipe.static_wi8_ai8()), ("static_wi8_ai16", ref_recipe.static_wi8_ai16())):
+      model = to_bags(fb.read_model(open(path, "rb").read()))
+      rng = np.random.default_rng(zlib.crc32(f"{name}/{rname}".encode()))
+      qsvs = {}
+      for sg in model.subgraphs:
+        for t in sg.tensors:
+          if model.buffers[t.buffer].data is None:
+            lo, hi = sorted(rng.uniform(-6, 6, 2))
+            qsvs[t.name.decode()] = {"min": np.array([[min(lo, -0.1)]], np.float32),
+                                     "max": np.array([[max(hi, 0.1)]], np.float32)}
+      seed_qsvs = {k: {"min": float(v["min"].ravel()[0]), "max": float(v["max"].ravel()[0])} for k, v in qsvs.items()}
+      key = f"{name}/{rname}"
+      rm = recipe_manager.RecipeManager()
+      rm.load_quantization_recipe(rcp)
+      try:
+        with warnings.catch_warnings():
+          warnings.simplefilter("ignore")
+          params = params_generator.ParamsGenerator(model).generate_quantization_parameters(rm, dict(qsvs))
+          rec = {}
+          for tname, tp in params.items():
+            links = []
+            for role, link_list in (("producer", [tp.producer] if tp.producer is not None else []),
+                                    ("consumer", tp.consumers or [])):
+              for link in link_list:
+                links.append(dict(role=role, op=int(link.subgraph_op_id),
+                                  transformations=[t.name for t in link.transformations],
+                                  parameters=_params_summary(link.parameters)))
+            rec[tname] = links
+          result = run(name, rname, rcp, dict(qsvs))
+      except Exception as e:
+        out[key] = dict(model=name, recipe=rcp, qsvs=seed_qsvs, error=type(e).__name__, message=str(e)[:300])
+        print("err ", key, type(e).__name__, str(e)[:120])
+        continue
+      out[key] = dict(model=name, recipe=rcp, qsvs=seed_qsvs, params=rec, result=result)
+      print("ok  ", key)
+  with open(os.path.join(GOLDEN, "ref_srq_all_params.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_model_golden.py --srq-all", numpy=np.__version__,
+                   cases=json.loads(json.dumps(out, default=str))), f, separators=(",", ":"), sort_keys=True)
+
+
+if __name__ == "__main__" and "--srq-all" in sys.argv:
+  srq_all_cases()
+
+
+# ------------------------------------ dynamic / weight-only recipes on the remaining test models ---
+def more_model_cases():
+  """The models ref_model_cases.json does not cover (single-op models of every registered op,
+  already-quantized models, composites) under four dynamic-range / weight-only recipes."""
+  names = sorted(f[:-7] for f in os.listdir(os.path.join(REF, "tests/models")) if f.endswith(".tflite"))
+  recipes = {k: RECIPES[k] for k in ("dynamic_wi8_afp32", "dynamic_wi4_afp32", "weight_only_wi8_afp32",
+                                     "default_af32w8float")}
+  cases = {}
+  for name in names:
+    if name in MODELS or name == "toy_model_with_kv_cache_multi_signature":
+      continue
+    shutil.copyfile(os.path.join(REF, "tests/models", name + ".tflite"),
+                    os.path.join(GOLDEN, "models", name + ".tflite"))
+    for rname, rcp in recipes.items():
+      key = f"{name}/{rname}"
+      try:
+        cases[key] = dict(model=name, recipe_name=rname, recipe=rcp, result=run(name, rname, rcp))
+        print("ok  ", key)
+      except Exception as e:
+        cases[key] = dict(model=name, recipe_name=rname, recipe=rcp, error=type(e).__name__, message=str(e)[:300])
+        print("err ", key, type(e).__name__, str(e)[:120])
+  with open(os.path.join(GOLDEN, "ref_model_cases_more.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_model_golden.py --more", numpy=np.__version__,
+                   cases=json.loads(json.dumps(cases, default=str))), f, separators=(",", ":"), sort_keys=True)
+  print("wrote", len(cases), "cases")
+
+
+if __name__ == "__main__" and "--more" in sys.argv:
+  more_model_cases()
