@@ -228,7 +228,7 @@ def main():
   print("wrote", len(cases), "cases")
 
 
-if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more"} & set(sys.argv):
+if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more", "--mixed"} & set(sys.argv):
   main()
 
 
@@ -437,20 +437,21 @@ if __name__ == "__main__" and "--oscar" in sys.argv:
 
 
 # ------------------------------------------------ static recipes on EVERY reference test model ---
-def srq_all_cases():
+def srq_all_cases(names=None, recipes=None, out_name="ref_srq_all_params.json", skip_covered=True):
   """static_wi8_ai8 / static_wi8_ai16 over all of the reference's test models (every op kind the
   registry knows: scale constraints, fixed output scales, ignored operands), with a synthetic
   calibration result. Records per-tensor parameters and the quantized model (or the error)."""
   import zlib
   from ai_edge_quantizer import recipe as ref_recipe
   out = {}
-  names = sorted(f[:-7] for f in os.listdir(os.path.join(REF, "tests/models")) if f.endswith(".tflite"))
+  names = names or sorted(f[:-7] for f in os.listdir(os.path.join(REF, "tests/models")) if f.endswith(".tflite"))
+  recipes = recipes or (("static_wi8_ai8", ref_recipe.static_wi8_ai8()), ("static_wi8_ai16", ref_recipe.static_wi8_ai16()))
   for name in names:
-    if name in SRQ_MODELS:
+    if skip_covered and name in SRQ_MODELS:
       continue                                   # already in ref_srq_params.json
     path = os.path.join(REF, "tests/models", name + ".tflite")
     shutil.copyfile(path, os.path.join(GOLDEN, "models", name + ".tflite"))
-    for rname, rcp in (("static_wi8_ai8", ref_recipe.static_wi8_ai8()), ("static_wi8_ai16", ref_recipe.static_wi8_ai16())):
+    for rname, rcp in recipes:
       model = to_bags(fb.read_model(open(path, "rb").read()))
       rng = np.random.default_rng(zlib.crc32(f"{name}/{rname}".encode()))
       qsvs = {}
@@ -485,8 +486,8 @@ def srq_all_cases():
         continue
       out[key] = dict(model=name, recipe=rcp, qsvs=seed_qsvs, params=rec, result=result)
       print("ok  ", key)
-  with open(os.path.join(GOLDEN, "ref_srq_all_params.json"), "w") as f:
-    json.dump(dict(generator="tests/golden/gen/make_model_golden.py --srq-all", numpy=np.__version__,
+  with open(os.path.join(GOLDEN, out_name), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_model_golden.py --srq-all / --mixed", numpy=np.__version__,
                    cases=json.loads(json.dumps(out, default=str))), f, separators=(",", ":"), sort_keys=True)
 
 
@@ -523,3 +524,28 @@ def more_model_cases():
 
 if __name__ == "__main__" and "--more" in sys.argv:
   more_model_cases()
+
+
+def mixed_cases():
+  """Recipes that mix modes per op: the shipped sample_advanced_usage recipe (static int8
+  everywhere, weight-only int4 FULLY_CONNECTED, CONV_2D left alone) and static int8 with OCTAV
+  weights / int4 weights for FULLY_CONNECTED."""
+  adv = json.load(open(os.path.join(REF, "recipes/sample_advanced_usage_recipe.json")))
+  from ai_edge_quantizer import recipe as ref_recipe
+  octav = json.loads(json.dumps(ref_recipe.static_wi8_ai8()))
+  for e in octav:
+    e["algorithm_key"] = "OCTAV"
+  w4 = json.loads(json.dumps(ref_recipe.static_wi8_ai8())) + [dict(
+      regex=".*", operation="FULLY_CONNECTED", algorithm_key="min_max_uniform_quantize", op_config=dict(
+          activation_tensor_config=dict(num_bits=8, symmetric=False, granularity="TENSORWISE", dtype="INT"),
+          weight_tensor_config=dict(num_bits=4, symmetric=True, granularity="CHANNELWISE", dtype="INT"),
+          compute_precision="INTEGER", explicit_dequantize=False, skip_checks=False, min_weight_elements=0))]
+  srq_all_cases(names=["conv_fc_mnist", "branching_conv_fc", "toy_model_with_kv_cache_multi_signature",
+                       "weight_sharing_fcs", "single_fc_bias_logistic", "sdpa_composite", "two_signatures",
+                       "single_fc_bias", "partly_quantized_mnist"],
+                recipes=(("sample_advanced_usage", adv), ("static_octav_wi8_ai8", octav), ("static_wi4_ai8_fc", w4)),
+                out_name="ref_mixed_params.json", skip_covered=False)
+
+
+if __name__ == "__main__" and "--mixed" in sys.argv:
+  mixed_cases()
