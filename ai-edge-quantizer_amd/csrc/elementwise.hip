@@ -608,6 +608,38 @@ extern "C" int32_t mi355q_pack_bits(const int8_t* q, int64_t n, int32_t bits, ui
   return MI355Q_OK;
 }
 
+// float32 -> float16, round to nearest even, overflow to inf, subnormal halves kept: what
+// ndarray.astype(np.float16) does (ref: algorithms/nonlinear_quantize/float_casting.py:157-160).
+__global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__ x, int64_t n,
+                                                       _Float16* __restrict__ out) {
+  const int64_t quad = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t e = quad * 4;
+  if (e + 4 <= n && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(out) & 7) == 0) {
+    const float4 v = *reinterpret_cast<const float4*>(x + e);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 h;
+    h.x = static_cast<_Float16>(v.x);
+    h.y = static_cast<_Float16>(v.y);
+    h.z = static_cast<_Float16>(v.z);
+    h.w = static_cast<_Float16>(v.w);
+    *reinterpret_cast<h4*>(out + e) = h;
+  } else {
+    for (int64_t i = e; i < n && i < e + 4; ++i) out[i] = static_cast<_Float16>(x[i]);
+  }
+}
+
+extern "C" int32_t mi355q_cast_f32_to_f16(const float* x, int64_t n, uint16_t* out, void* stream) {
+  clear_error();
+  if (n < 0) return fail(MI355Q_BAD_ARG, "negative size");
+  if (n == 0) return MI355Q_OK;
+  if (!x || !out) return fail(MI355Q_BAD_ARG, "null pointer");
+  hipLaunchKernelGGL(cast_f16_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, as_stream(stream), x,
+                     n, reinterpret_cast<_Float16*>(out));
+  MI355Q_CHECK_LAUNCH("cast_f16 launch");
+  return MI355Q_OK;
+}
+
 extern "C" size_t mi355q_act_minmax_workspace_bytes(int32_t count) {
   return count > 0 ? static_cast<size_t>(count) * kActBlocks * 5 * sizeof(float) : 0;
 }

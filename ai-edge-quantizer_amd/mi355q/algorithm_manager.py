@@ -15,6 +15,7 @@ import functools
 from . import algorithm_manager_api
 from . import default_policy
 from . import qtyping
+from .algorithms.nonlinear_quantize import float_casting
 from .algorithms.uniform_quantize import common_quantize
 from .algorithms.uniform_quantize import gptq
 from .algorithms.uniform_quantize import hadamard_rotation
@@ -45,7 +46,7 @@ class AlgorithmName(str, enum.Enum):
   """ref :65-75 (keys of algorithms outside the hot path are kept for recipe compatibility)."""
   NO_QUANTIZE = "no_quantize"
   MIN_MAX_UNIFORM_QUANT = naive_min_max_quantize.ALGORITHM_KEY
-  FLOAT_CASTING = "float_casting"
+  FLOAT_CASTING = float_casting.ALGORITHM_KEY
   DEQUANTIZED_WEIGHT_RECOVERY = "dequantized_weight_recovery"
   OCTAV = octav.ALGORITHM_KEY
   HADAMARD_ROTATION = hadamard_rotation.CUSTOM_OP_ALGORITHM_KEY
@@ -105,6 +106,17 @@ _register_weight_algorithm(AlgorithmName.MSE, mse,
 # QSV update
 _register_weight_algorithm(AlgorithmName.GPTQ, gptq, [_Op.FULLY_CONNECTED], gptq.calibrate,
                            qsv_utils.gptq_and_moving_average_update)
+
+# float casting (ref :166-235): FP16 weights behind a DEQUANTIZE op; its own config check, empty policy
+register_op_quant_config_validation_func(AlgorithmName.FLOAT_CASTING, float_casting.check_op_quantization_config)
+register_config_check_policy_func(AlgorithmName.FLOAT_CASTING, qtyping.ConfigCheckPolicyDict())
+for _op, _fn in ((_Op.FULLY_CONNECTED, float_casting.materialize_fc_conv),
+                 (_Op.CONV_2D, float_casting.materialize_fc_conv),
+                 (_Op.DEPTHWISE_CONV_2D, float_casting.materialize_fc_conv),
+                 (_Op.CONV_2D_TRANSPOSE, float_casting.materialize_conv2d_transpose),
+                 (_Op.EMBEDDING_LOOKUP, float_casting.materialize_embedding_lookup)):
+  register_quantized_op(AlgorithmName.FLOAT_CASTING, _op, float_casting.init_qsvs,
+                        calibration_func=float_casting.calibrate, materialize_func=_fn)
 
 # OSCAR (ref :453-480): FULLY_CONNECTED only, whole-op materializer, mu2-collecting calibration
 register_op_quant_config_validation_func(AlgorithmName.OSCAR, common_quantize.check_op_quantization_config)

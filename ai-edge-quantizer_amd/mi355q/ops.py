@@ -178,6 +178,15 @@ def pack_bits(q: torch.Tensor, bits: int) -> torch.Tensor:
   return out
 
 
+def cast_f16(x: torch.Tensor) -> torch.Tensor:
+  """float32 -> float16 (RNE), same shape. ref: nonlinear_quantize/float_casting.py:157-160."""
+  rt.require_gpu()
+  x = _f32(x)
+  out = rt.empty(tuple(x.shape), torch.float16)
+  _ffi.check(_ffi.lib().mi355q_cast_f32_to_f16(rt.ptr(x), x.numel(), rt.ptr(out), rt.stream_ptr()))
+  return out
+
+
 class ActMinMaxBatch:
   """Pre-staged K7 launch over a fixed list of float32 device tensors (<= 65535).
 

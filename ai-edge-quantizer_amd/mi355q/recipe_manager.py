@@ -68,7 +68,10 @@ class RecipeManager:
   def add_weight_only_config(self, regex: str, operation_name, num_bits: int,
                              granularity=qtyping.QuantGranularity.CHANNELWISE,
                              algorithm_key: str = AlgorithmName.MIN_MAX_UNIFORM_QUANT) -> None:
-    w = _TCfg(num_bits=num_bits, symmetric=True, granularity=granularity)
+    # integer weights, except float_casting's FP16 (ref :335-341)
+    dtype = (qtyping.TensorDataType.FLOAT if algorithm_key == AlgorithmName.FLOAT_CASTING
+             else qtyping.TensorDataType.INT)
+    w = _TCfg(num_bits=num_bits, symmetric=True, granularity=granularity, dtype=dtype)
     self.add_quantization_config(
         regex, operation_name,
         _Cfg(weight_tensor_config=w, compute_precision=qtyping.ComputePrecision.FLOAT,

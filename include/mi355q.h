@@ -144,6 +144,13 @@ int32_t mi355q_dequantize_f32(const void* q, int32_t in_bits, int64_t outer,
                               int32_t out_is_f64, void* out, void* stream);
 
 /* ------------------------------------------------------------------------
+ * float_casting -- float32 weights stored as float16 (round to nearest even, overflow -> inf,
+ * subnormals kept), i.e. `weight.astype(np.float16)`.
+ * ref: algorithms/nonlinear_quantize/float_casting.py:157-160, 272-275
+ * ------------------------------------------------------------------------ */
+int32_t mi355q_cast_f32_to_f16(const float* x, int64_t n, uint16_t* out, void* stream);
+
+/* ------------------------------------------------------------------------
  * K4 -- bit packing of int4 / int2 values held in int8 containers.
  * ref: transformations/transformation_utils.py:293-353 (pack_data)
  * out has ceil(n * bits / 8) bytes; element 0 sits in the lowest bits; the ragged

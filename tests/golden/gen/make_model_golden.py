@@ -228,7 +228,7 @@ def main():
   print("wrote", len(cases), "cases")
 
 
-if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more", "--mixed"} & set(sys.argv):
+if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more", "--mixed", "--fp16"} & set(sys.argv):
   main()
 
 
@@ -549,3 +549,33 @@ def mixed_cases():
 
 if __name__ == "__main__" and "--mixed" in sys.argv:
   mixed_cases()
+
+
+# --------------------------------------------------------------------------- float casting ---
+def fp16_cases():
+  """Weight-only FP16 (algorithm "float_casting") on the models that carry weights."""
+  def rcp(operation):
+    return [dict(regex=".*", operation=operation, algorithm_key="float_casting", op_config=dict(
+        weight_tensor_config=dict(num_bits=16, symmetric=True, granularity="CHANNELWISE", dtype="FLOAT"),
+        compute_precision="FLOAT", explicit_dequantize=True, skip_checks=False, min_weight_elements=0))]
+  recipes = {"fp16_all": rcp("*"), "fp16_fc": rcp("FULLY_CONNECTED")}
+  cases = {}
+  for name in ["single_fc", "single_fc_bias", "single_fc_no_bias", "conv_fc_mnist", "embedding_lookup",
+               "single_conv2d_transpose_bias", "single_depthwise_conv2d_bias", "weight_sharing_fcs",
+               "toy_model_with_kv_cache_multi_signature", "branching_conv_fc",
+               "constant_tensor_and_buffer_only_sharing_weight_fcs", "bmm_constant_input", "two_signatures"]:
+    for rname, r in recipes.items():
+      key = f"{name}/{rname}"
+      try:
+        cases[key] = dict(model=name, recipe_name=rname, recipe=r, result=run(name, rname, r))
+        print("ok  ", key)
+      except Exception as e:
+        cases[key] = dict(model=name, recipe_name=rname, recipe=r, error=type(e).__name__, message=str(e)[:300])
+        print("err ", key, type(e).__name__, str(e)[:120])
+  with open(os.path.join(GOLDEN, "ref_fp16_cases.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_model_golden.py --fp16", numpy=np.__version__,
+                   cases=json.loads(json.dumps(cases, default=str))), f, separators=(",", ":"), sort_keys=True)
+
+
+if __name__ == "__main__" and "--fp16" in sys.argv:
+  fp16_cases()

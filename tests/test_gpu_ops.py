@@ -377,3 +377,18 @@ def test_hadamard_rotate_all_sizes_partial_tiles_and_in_place(h):
   inplace = torch.from_numpy(x).cuda()
   _ffi.check(_ffi.lib().mi355q_hadamard_rotate_f32(rt.ptr(inplace), n_vec, h, rt.ptr(inplace), rt.stream_ptr()))
   assert np.array_equal(inplace.cpu().numpy(), got)
+
+
+def test_cast_f16_matches_numpy_astype():
+  """float_casting's cast: round to nearest even, overflow -> inf, subnormal halves, NaN."""
+  import torch
+  from mi355q import ops, runtime as rt
+  rng = np.random.default_rng(77)
+  x = np.concatenate([
+      rng.standard_normal(100003).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 6, 100003).astype(np.float32),
+      np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 70000.0, -1e9, 5.96e-8, 2.98e-8, 2.99e-8, 6.1e-5, 6.09e-5,
+                np.inf, -np.inf, np.nan, 1.0009765625, 1.00048828125, 1.00146484375], np.float32)])
+  for arr in (x, x[1:], x[:7], x[3:4]):           # aligned, misaligned, tiny
+    got = rt.to_numpy(ops.cast_f16(rt.to_device(arr)))
+    want = arr.astype(np.float16)
+    assert got.dtype == np.float16 and np.array_equal(got.view(np.uint16), want.view(np.uint16))
