@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256) void sort_keys_kernel(const float* __restrict_
   const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (e >= total) return;
   const int64_t j = e % d;
-  keys[e] = fabs(static_cast<double>(w[e])) * s[j];
-  vals[e] = m[j];
+  keys[e] = s ? fabs(static_cast<double>(w[e])) * s[j] : fabs(static_cast<double>(w[e]));
+  vals[e] = m ? m[j] : 0.0;
 }
 
 struct SegmentStart {
@@ -397,7 +397,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_tile_kernel(
     double k = -1.0;                 // padding sorts behind every real magnitude
     if (sl < segs_here && i < g) {
       const int64_t ge = (seg0 + sl) * g + i;
-      k = fabs(static_cast<double>(w[ge])) * s[ge % d];
+      k = fabs(static_cast<double>(w[ge]));
+      if (s) k = k * s[ge % d];
     }
     key[lds_pad(e)] = k;
     pos[lds_pad(e)] = static_cast<uint16_t>(i);
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_tile_kernel(
         const int at = lds_pad(sl * P + i);
         const int64_t seg = seg0 + sl;
         keys_out[static_cast<int64_t>(i) * segments + seg] = key[at];
-        vals_out[static_cast<int64_t>(i) * segments + seg] = m[(seg * g + pos[at]) % d];
+        if (m) vals_out[static_cast<int64_t>(i) * segments + seg] = m[(seg * g + pos[at]) % d];
       }
     }
   } else {
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_tile_kernel(
         const int at = lds_pad(e);
         const int64_t seg = seg0 + sl;
         keys_out[seg * g + i] = key[at];
-        vals_out[seg * g + i] = m[(seg * g + pos[at]) % d];
+        if (m) vals_out[seg * g + i] = m[(seg * g + pos[at]) % d];
       }
     }
   }
@@ -587,6 +588,73 @@ __global__ __launch_bounds__(256) void clip_scan_wave_kernel(
   }
 }
 
+// ------------------------------------------------- dequantized weight recovery ---
+// ref: algorithms/uniform_quantize/dequantized_weight_recovery.py:48-61, 118-186. The scale of a
+// group of fake-quantized weights is the smallest positive step between its sorted magnitudes
+// (with 0 appended). The minimum is order independent, so after the segment sort every element
+// compares with its successor and the per-segment minimum is an atomic on the (positive) bit
+// pattern. rounded != 0: the reference works in float32 there (steps rounded to float32, only
+// steps > float32(1e-9) count, floor float32(1e-9)); rounded == 0 (TENSORWISE): float64, every
+// positive step counts, floor 1e-9.
+__global__ __launch_bounds__(256) void gap_init_kernel(uint64_t* __restrict__ best, int64_t segments) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < segments) best[i] = 0x7FF0000000000000ull;   // +inf
+}
+
+__global__ __launch_bounds__(256) void gap_kernel(const double* __restrict__ keys, int64_t total,
+                                                  int64_t g, int32_t rounded,
+                                                  uint64_t* __restrict__ best) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int64_t seg = e / g, i = e - seg * g;
+  const double a = keys[e];
+  const double b = (i + 1 < g) ? keys[e + 1] : 0.0;     // descending order; the appended 0 is last
+  double step = a - b;                                   // exact: both are float32 magnitudes
+  bool counts;
+  if (rounded) {
+    const float f = static_cast<float>(step);
+    counts = f > 1e-9f;
+    step = static_cast<double>(f);
+  } else {
+    counts = step > 0.0;
+  }
+  if (counts) {
+    const uint64_t bits = __builtin_bit_cast(uint64_t, step);
+    if (bits < best[seg]) atomicMin(reinterpret_cast<unsigned long long*>(best + seg),
+                                    static_cast<unsigned long long>(bits));
+  }
+}
+
+__global__ __launch_bounds__(256) void gap_final_kernel(uint64_t* __restrict__ best, int64_t segments,
+                                                        int32_t rounded) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= segments) return;
+  const double v = __builtin_bit_cast(double, best[i]);
+  const double floor_v = rounded ? static_cast<double>(1e-9f) : 1e-9;
+  const double out = (best[i] == 0x7FF0000000000000ull) ? floor_v : fmax(v, floor_v);
+  best[i] = __builtin_bit_cast(uint64_t, out);
+}
+
+// max over all elements of |q * scale - w| in FP64 (int32 * float32 promotes to float64 in
+// NumPy); NaN wins, as np.max propagates it.
+__global__ __launch_bounds__(256) void recover_error_kernel(const float* __restrict__ w,
+                                                            const int8_t* __restrict__ q,
+                                                            const double* __restrict__ scale,
+                                                            int64_t total, int64_t g,
+                                                            uint64_t* __restrict__ worst) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  double diff = 0.0;
+  if (e < total) diff = fabs(static_cast<double>(q[e]) * scale[e / g] - static_cast<double>(w[e]));
+  uint64_t bits = __builtin_bit_cast(uint64_t, diff) & 0x7FFFFFFFFFFFFFFFull;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const uint64_t o = __shfl_xor(static_cast<unsigned long long>(bits), off, kWave);
+    bits = o > bits ? o : bits;
+  }
+  if ((threadIdx.x & 63) == 0 && bits > *worst)
+    atomicMax(reinterpret_cast<unsigned long long*>(worst), static_cast<unsigned long long>(bits));
+}
+
 // ------------------------------------------------------------------- quantize ---
 __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ w,
                                                        const double* __restrict__ s,
@@ -709,27 +777,19 @@ extern "C" int32_t mi355q_oscar_clip_workspace_bytes(int64_t n, int64_t d, int64
   return MI355Q_OK;
 }
 
-extern "C" int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s, const double* m,
-                                                int64_t n, int64_t d, int64_t g, const double* u,
-                                                const double* noise, int32_t qmax,
-                                                int32_t blockwise_scale, double* bounds_out,
-                                                double* scale_out, void* workspace,
-                                                size_t workspace_bytes, void* stream) {
-  clear_error();
-  if (!w || !s || !m || !u || !noise || (!bounds_out && !scale_out) || !workspace)
-    return fail(MI355Q_BAD_ARG, "oscar_clip_bounds: null pointer");
-  if (qmax <= 0) return fail(MI355Q_BAD_ARG, "oscar_clip_bounds: qmax=%d", qmax);
-  size_t need = 0;
-  int32_t st_code = mi355q_oscar_clip_workspace_bytes(n, d, g, &need);
-  if (st_code != MI355Q_OK) return st_code;
-  if (workspace_bytes < need)
-    return fail(MI355Q_BAD_ARG, "oscar_clip_bounds: workspace %zu < %zu", workspace_bytes, need);
-  if (g != n * d && d % g)
-    return fail(MI355Q_BAD_SHAPE, "oscar_clip_bounds: g=%lld does not divide d=%lld", (long long)g,
-                (long long)d);
-  hipStream_t st = as_stream(stream);
+namespace {
+struct Sorted {
+  const double* keys;
+  const double* vals;
+  int64_t seg_stride, elem_stride;
+};
+
+// Stable descending sort of every g-element segment of |w| * s (s == NULL: |w|) carrying m[column]
+// (m == NULL: nothing): the in-LDS tile sort for g <= 8192, the library radix sort otherwise.
+int32_t sort_segments(const float* w, const double* s, const double* m, int64_t n, int64_t d,
+                      int64_t g, bool allow_rank_major, void* workspace, size_t need, hipStream_t st,
+                      Sorted* out) {
   const int64_t total = n * d, segments = total / g;
-  const int64_t G = (g == total) ? 1 : d / g;
   const size_t slab = align256(static_cast<size_t>(total) * sizeof(double));
   char* base = static_cast<char*>(workspace);
   double* keys_in = reinterpret_cast<double*>(base);
@@ -739,11 +799,12 @@ extern "C" int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s,
   void* tmp = base + 4 * slab;
   size_t tmp_bytes = need - 4 * slab;
   int64_t seg_stride = g, elem_stride = 1;
+  (void)vals_in;
   if (g <= 8192 && g >= 2 && !getenv("MI355Q_OSCAR_LIBSORT")) {
     int32_t P = 32;
     while (P < g) P <<= 1;
     const int32_t tile = P > 4096 ? P : 4096;
-    const int32_t transposed = P <= 256;
+    const int32_t transposed = (P <= 256 && allow_rank_major) ? 1 : 0;
     const size_t lds = (static_cast<size_t>(lds_pad(tile)) + 2) * (sizeof(double) + sizeof(uint16_t));
     const int64_t tiles = (segments + tile / P - 1) / (tile / P);
     if (lds > 64 * 1024) {
@@ -778,6 +839,41 @@ extern "C" int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s,
     }
     if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "oscar sort: %s", hipGetErrorString(e));
   }
+  out->keys = keys_out;
+  out->vals = vals_out;
+  out->seg_stride = seg_stride;
+  out->elem_stride = elem_stride;
+  return MI355Q_OK;
+}
+}  // namespace
+
+extern "C" int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s, const double* m,
+                                                int64_t n, int64_t d, int64_t g, const double* u,
+                                                const double* noise, int32_t qmax,
+                                                int32_t blockwise_scale, double* bounds_out,
+                                                double* scale_out, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (!w || !s || !m || !u || !noise || (!bounds_out && !scale_out) || !workspace)
+    return fail(MI355Q_BAD_ARG, "oscar_clip_bounds: null pointer");
+  if (qmax <= 0) return fail(MI355Q_BAD_ARG, "oscar_clip_bounds: qmax=%d", qmax);
+  size_t need = 0;
+  int32_t st_code = mi355q_oscar_clip_workspace_bytes(n, d, g, &need);
+  if (st_code != MI355Q_OK) return st_code;
+  if (workspace_bytes < need)
+    return fail(MI355Q_BAD_ARG, "oscar_clip_bounds: workspace %zu < %zu", workspace_bytes, need);
+  if (g != n * d && d % g)
+    return fail(MI355Q_BAD_SHAPE, "oscar_clip_bounds: g=%lld does not divide d=%lld", (long long)g,
+                (long long)d);
+  hipStream_t st = as_stream(stream);
+  const int64_t total = n * d, segments = total / g;
+  const int64_t G = (g == total) ? 1 : d / g;
+  Sorted sorted;
+  st_code = sort_segments(w, s, m, n, d, g, true, workspace, need, st, &sorted);
+  if (st_code != MI355Q_OK) return st_code;
+  const double* keys_out = sorted.keys;
+  const double* vals_out = sorted.vals;
+  const int64_t seg_stride = sorted.seg_stride, elem_stride = sorted.elem_stride;
   if (elem_stride == 1 && g >= 256 && segments < 4096) {
     // a lane per segment would fill fewer than 64 waves; the wave form costs ~70 SIMD cycles per
     // element instead of ~6 but runs on segments (not segments / 64) waves
@@ -806,5 +902,47 @@ extern "C" int32_t mi355q_oscar_quantize_f32(const float* w, const double* s, co
                      as_stream(stream), w, s, scale, total, d, g, static_cast<double>(qlo),
                      static_cast<double>(qhi), out);
   MI355Q_CHECK_LAUNCH("oscar_quantize");
+  return MI355Q_OK;
+}
+
+extern "C" int32_t mi355q_dwr_scales_f32(const float* w, int64_t n, int64_t d, int64_t g,
+                                         int32_t rounded, double* scale_out, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (!w || !scale_out || !workspace) return fail(MI355Q_BAD_ARG, "dwr_scales: null pointer");
+  size_t need = 0;
+  int32_t code = mi355q_oscar_clip_workspace_bytes(n, d, g, &need);
+  if (code != MI355Q_OK) return code;
+  if (workspace_bytes < need)
+    return fail(MI355Q_BAD_ARG, "dwr_scales: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t st = as_stream(stream);
+  const int64_t total = n * d, segments = total / g;
+  Sorted sorted;
+  code = sort_segments(w, nullptr, nullptr, n, d, g, false, workspace, need, st, &sorted);
+  if (code != MI355Q_OK) return code;
+  uint64_t* best = reinterpret_cast<uint64_t*>(scale_out);
+  hipLaunchKernelGGL(gap_init_kernel, dim3(static_cast<unsigned>((segments + 255) / 256)), dim3(256), 0,
+                     st, best, segments);
+  hipLaunchKernelGGL(gap_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
+                     sorted.keys, total, g, rounded, best);
+  hipLaunchKernelGGL(gap_final_kernel, dim3(static_cast<unsigned>((segments + 255) / 256)), dim3(256), 0,
+                     st, best, segments, rounded);
+  MI355Q_CHECK_LAUNCH("dwr_scales");
+  return MI355Q_OK;
+}
+
+extern "C" int32_t mi355q_dwr_max_error_f32(const float* w, const int8_t* q, const double* scale,
+                                            int64_t total, int64_t g, double* max_out,
+                                            void* stream) {
+  clear_error();
+  if (!w || !q || !scale || !max_out) return fail(MI355Q_BAD_ARG, "dwr_max_error: null pointer");
+  if (total <= 0 || g <= 0 || total % g)
+    return fail(MI355Q_BAD_SHAPE, "dwr_max_error: total=%lld g=%lld", (long long)total, (long long)g);
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(max_out, 0, sizeof(double), st);
+  if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "dwr_max_error: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(recover_error_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
+                     0, st, w, q, scale, total, g, reinterpret_cast<uint64_t*>(max_out));
+  MI355Q_CHECK_LAUNCH("dwr_max_error");
   return MI355Q_OK;
 }

@@ -69,6 +69,8 @@ PROTOTYPES = {
                                              c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_oscar_quantize_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i32, c_i32,
                                           c_ptr, c_ptr]),
+    "mi355q_dwr_scales_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_dwr_max_error_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
 }
 
 STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "BAD_SHAPE", -3: "UNSUPPORTED", -4: "HIP_ERROR"}

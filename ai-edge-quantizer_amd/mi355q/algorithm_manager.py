@@ -17,6 +17,7 @@ from . import default_policy
 from . import qtyping
 from .algorithms.nonlinear_quantize import float_casting
 from .algorithms.uniform_quantize import common_quantize
+from .algorithms.uniform_quantize import dequantized_weight_recovery
 from .algorithms.uniform_quantize import gptq
 from .algorithms.uniform_quantize import hadamard_rotation
 from .algorithms.uniform_quantize import mse
@@ -47,7 +48,7 @@ class AlgorithmName(str, enum.Enum):
   NO_QUANTIZE = "no_quantize"
   MIN_MAX_UNIFORM_QUANT = naive_min_max_quantize.ALGORITHM_KEY
   FLOAT_CASTING = float_casting.ALGORITHM_KEY
-  DEQUANTIZED_WEIGHT_RECOVERY = "dequantized_weight_recovery"
+  DEQUANTIZED_WEIGHT_RECOVERY = dequantized_weight_recovery.ALGORITHM_KEY
   OCTAV = octav.ALGORITHM_KEY
   HADAMARD_ROTATION = hadamard_rotation.CUSTOM_OP_ALGORITHM_KEY
   DECOMPOSED_HADAMARD_ROTATION = hadamard_rotation.DECOMPOSED_ALGORITHM_KEY
@@ -117,6 +118,18 @@ for _op, _fn in ((_Op.FULLY_CONNECTED, float_casting.materialize_fc_conv),
                  (_Op.EMBEDDING_LOOKUP, float_casting.materialize_embedding_lookup)):
   register_quantized_op(AlgorithmName.FLOAT_CASTING, _op, float_casting.init_qsvs,
                         calibration_func=float_casting.calibrate, materialize_func=_fn)
+
+# dequantized weight recovery (ref :203-235): re-derives the integers of fake-quantized weights
+register_op_quant_config_validation_func(AlgorithmName.DEQUANTIZED_WEIGHT_RECOVERY,
+                                         common_quantize.check_op_quantization_config)
+register_config_check_policy_func(AlgorithmName.DEQUANTIZED_WEIGHT_RECOVERY,
+                                  default_policy.DEFAULT_CONFIG_CHECK_POLICY)
+for _op in (_Op.FULLY_CONNECTED, _Op.CONV_2D, _Op.EMBEDDING_LOOKUP):
+  register_quantized_op(
+      AlgorithmName.DEQUANTIZED_WEIGHT_RECOVERY, _op, dequantized_weight_recovery.init_qsvs,
+      calibration_func=dequantized_weight_recovery.calibrate,
+      materialize_func=functools.partial(_MATERIALIZERS[_op],
+                                         dequantized_weight_recovery.get_tensor_quant_params))
 
 # OSCAR (ref :453-480): FULLY_CONNECTED only, whole-op materializer, mu2-collecting calibration
 register_op_quant_config_validation_func(AlgorithmName.OSCAR, common_quantize.check_op_quantization_config)

@@ -465,3 +465,29 @@ def oscar_quantize(w: torch.Tensor, s: torch.Tensor, scale: torch.Tensor, g: int
   _ffi.check(_ffi.lib().mi355q_oscar_quantize_f32(rt.ptr(w), rt.ptr(s), rt.ptr(scale), n, d, g, qlo,
                                                   qhi, rt.ptr(out), rt.stream_ptr()))
   return out
+
+
+# ------------------------------------------------------- dequantized weight recovery ---
+def dwr_scales(w: torch.Tensor, g: int, rounded: bool) -> torch.Tensor:
+  """float64 [n*d/g]: smallest positive step of every g-element segment's sorted magnitudes."""
+  import ctypes
+  rt.require_gpu()
+  w = _f32(w)
+  n, d = w.shape
+  need = ctypes.c_size_t(0)
+  _ffi.check(_ffi.lib().mi355q_oscar_clip_workspace_bytes(n, d, g, ctypes.byref(need)))
+  ws = rt.empty((need.value,), torch.uint8)
+  out = rt.empty((n * d // g,), torch.float64)
+  _ffi.check(_ffi.lib().mi355q_dwr_scales_f32(rt.ptr(w), n, d, g, int(rounded), rt.ptr(out), rt.ptr(ws),
+                                              need.value, rt.stream_ptr()))
+  return out
+
+
+def dwr_max_error(w: torch.Tensor, q: torch.Tensor, scale: torch.Tensor, g: int) -> float:
+  """max |q * scale - w| over the tensor (float64; NaN if any element is NaN)."""
+  rt.require_gpu()
+  w = _f32(w)
+  out = rt.empty((1,), torch.float64)
+  _ffi.check(_ffi.lib().mi355q_dwr_max_error_f32(rt.ptr(w), rt.ptr(q), rt.ptr(scale), w.numel(), g,
+                                                 rt.ptr(out), rt.stream_ptr()))
+  return float(out.item())

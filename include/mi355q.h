@@ -344,6 +344,23 @@ int32_t mi355q_oscar_quantize_f32(const float* w, const double* s, const double*
                                   int64_t d, int64_t g, int32_t qlo, int32_t qhi, int8_t* out,
                                   void* stream);
 
+/* ------------------------------------------------------------------------
+ * dequantized_weight_recovery -- scales of fake-quantized (QAT) weights and the recovery check.
+ * ref: algorithms/uniform_quantize/dequantized_weight_recovery.py:48-61, 118-186, 30-45
+ * ------------------------------------------------------------------------ */
+/* scale_out[k] = smallest positive step between the sorted magnitudes (0 appended) of segment k
+ * of g consecutive elements of w [n, d] (g divides d, or g == n*d), floored at 1e-9.
+ *   rounded != 0: float32 arithmetic of the channel- / blockwise path (steps rounded to float32,
+ *   only steps > float32(1e-9) count, floor float32(1e-9)); rounded == 0: the TENSORWISE path's
+ *   float64. workspace: mi355q_oscar_clip_workspace_bytes(n, d, g). */
+int32_t mi355q_dwr_scales_f32(const float* w, int64_t n, int64_t d, int64_t g, int32_t rounded,
+                              double* scale_out, void* workspace, size_t workspace_bytes,
+                              void* stream);
+/* *max_out = max |q * scale[e / g] - w| in FP64 (NaN if any), the quantity
+ * _validate_recovered_weights compares with its tolerance. */
+int32_t mi355q_dwr_max_error_f32(const float* w, const int8_t* q, const double* scale, int64_t total,
+                                 int64_t g, double* max_out, void* stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -852,3 +852,50 @@ def oscar_quant_params(w, mu2, num_bits: int, granularity: str, symmetric: bool 
   return dict(scale=scale, zero_point=zp, num_bits=num_bits, symmetric=True,
               quantized_dimension=qdim, block_size=block, quantized_data=q,
               multiplier=(1.0 / s).astype(np.float32))
+
+
+# --------------------------------------------------------------------------
+# dequantized weight recovery (fake-quantized weights -> their integers)
+# --------------------------------------------------------------------------
+
+def dwr_scales(w: np.ndarray, quantized_dim, block: int = 0, min_scale: float = 1e-9) -> np.ndarray:
+  """Per-group smallest positive step between sorted magnitudes, 0 included.
+  ref: algorithms/uniform_quantize/dequantized_weight_recovery.py:48-61, 118-186."""
+  mag = np.abs(w)
+  if quantized_dim is None:
+    vals = np.unique(np.append(np.ravel(mag), 0))           # promotes to float64
+    step = float(np.maximum(np.min(np.diff(vals)), min_scale)) if vals.size > 1 else min_scale
+    return np.array([[step]])
+  if block > 0:
+    rows = mag.reshape(-1, block) if quantized_dim == mag.ndim - 1 else None
+    shape = list(mag.shape)
+    shape[quantized_dim] //= block
+  else:
+    rows = np.moveaxis(mag, quantized_dim, 0).reshape(mag.shape[quantized_dim], -1)
+    shape = [1] * mag.ndim
+    shape[quantized_dim] = mag.shape[quantized_dim]
+  rows = np.sort(np.hstack([rows, np.zeros((rows.shape[0], 1), rows.dtype)]), axis=1)
+  steps = np.diff(rows, axis=1)
+  least = np.min(np.where(steps > 1e-9, steps, np.inf), axis=1)
+  out = np.maximum(least, min_scale)
+  out[out == np.inf] = min_scale
+  return out.reshape(shape)
+
+
+def dwr_quant_params(w, num_bits: int, granularity: str, op: str = "FULLY_CONNECTED",
+                     check: bool = True) -> dict:
+  """ref: dequantized_weight_recovery.py:189-283 (symmetric weights only)."""
+  block = block_size_of(granularity) if is_blockwise(granularity) else 0
+  qdim = weight_quantized_dim(granularity, op, np.ndim(w))
+  scale = dwr_scales(w, qdim, block)
+  zp = np.zeros_like(scale, dtype=np.int32)
+  q = uniform_quantize(w, scale, zp, num_bits, True, quantized_dim=qdim, block_size=block,
+                       is_blockwise_quant=is_blockwise(granularity))
+  if check:
+    back = uniform_dequantize(q, scale, zp, quantized_dim=qdim, block_size=block)
+    worst = np.ravel(np.abs(back - w)).max()
+    if worst > 1e-4:
+      raise RuntimeError("Failed to recover the original quantized values from dequantized values."
+                         f" Max diff between recovered and original values: {worst} (tolerance: 0.0001)")
+  return dict(scale=scale, zero_point=zp, num_bits=num_bits, symmetric=True, quantized_dimension=qdim,
+              block_size=block, quantized_data=q)

@@ -622,9 +622,79 @@ def oscar_cases():
   print(f"wrote {len(arr)} OSCAR arrays, {len(cases)} cases")
 
 
+def dwr_cases():
+  """dequantized_weight_recovery on seeded fake-quantized weights -> ref_dwr_cases.npz/json."""
+  from ai_edge_quantizer.algorithms.uniform_quantize import dequantized_weight_recovery as dwr
+  arr, cases = {}, []
+  specs = [
+      ("dwr_cw_i4", 0, (24, 96), 4, G.CHANNELWISE, "FULLY_CONNECTED"),
+      ("dwr_cw_i8", 1, (16, 300), 8, G.CHANNELWISE, "FULLY_CONNECTED"),
+      ("dwr_b32_i4", 2, (12, 128), 4, G.BLOCKWISE_32, "FULLY_CONNECTED"),
+      ("dwr_b128_i4", 3, (6, 512), 4, G.BLOCKWISE_128, "FULLY_CONNECTED"),
+      ("dwr_tw_i8", 4, (10, 40), 8, G.TENSORWISE, "FULLY_CONNECTED"),
+      ("dwr_conv_cw_i8", 5, (8, 3, 3, 5), 8, G.CHANNELWISE, "CONV_2D"),
+      ("dwr_emb_cw_i4", 6, (50, 64), 4, G.CHANNELWISE, "EMBEDDING_LOOKUP"),
+      ("dwr_cw_i4_sparse", 7, (20, 64), 4, G.CHANNELWISE, "FULLY_CONNECTED"),
+      ("dwr_cw_i4_wide", 8, (3, 5000), 4, G.CHANNELWISE, "FULLY_CONNECTED"),
+      ("dwr_tw_i4_tiny_scale", 9, (8, 16), 4, G.TENSORWISE, "FULLY_CONNECTED"),
+  ]
+  for name, seed, shape, bits, gran, op in specs:
+    rng = np.random.default_rng(2000 + seed)
+    qmax = 2 ** (bits - 1) - 1
+    q = rng.integers(-qmax, qmax + 1, size=shape).astype(np.int8)
+    if "sparse" in name:
+      q[rng.random(shape) < 0.7] = 0
+      q[3] = 0                                   # an all-zero row: scale falls back to 1e-9
+    if gran == G.TENSORWISE:
+      scale = np.float32(3e-10 if "tiny" in name else 0.0123)
+      w = (q.astype(np.float32) * scale).astype(np.float32)
+    elif uqt.is_blockwise(gran):
+      b = uqt.extract_block_size_from_granularity(gran)
+      sc = (rng.random((shape[0], shape[1] // b)).astype(np.float32) * 0.05 + 0.001)
+      w = (q.reshape(shape[0], -1, b).astype(np.float32) * sc[:, :, None]).reshape(shape).astype(np.float32)
+    else:
+      sc = (rng.random((shape[0],) + (1,) * (len(shape) - 1)).astype(np.float32) * 0.05 + 0.001)
+      w = (q.astype(np.float32) * sc).astype(np.float32)
+    cfg = cfg_of(bits, True, gran)
+    info = op_info(OPN[op], cfg)
+    arr[f"{name}/w"] = w
+    try:
+      res = dwr.get_tensor_quant_params(info, cfg, as_input(w, gran))
+    except Exception as e:
+      cases.append(dict(name=name, num_bits=bits, granularity=gran.name, op=op, error=type(e).__name__,
+                        message=str(e)[:200]))
+      print("err", name, str(e)[:150])
+      continue
+    arr[f"{name}/scale"] = plain(res.scale)
+    arr[f"{name}/zero_point"] = plain(res.zero_point)
+    arr[f"{name}/q"] = plain(res.quantized_data)
+    cases.append(dict(name=name, num_bits=bits, granularity=gran.name, op=op,
+                      quantized_dimension=res.quantized_dimension, block_size=res.block_size,
+                      scale_dtype=str(np.asarray(res.scale).dtype), recovered=bool(np.array_equal(res.quantized_data, q))))
+    print("ok ", name, res.scale.dtype, res.scale.shape, cases[-1]["recovered"])
+  # not fake-quantized at all: the reference refuses
+  w = np.random.default_rng(2099).standard_normal((16, 64)).astype(np.float32)
+  arr["dwr_random/w"] = w
+  cfg = cfg_of(4, True, G.CHANNELWISE)
+  try:
+    dwr.get_tensor_quant_params(op_info(OPN.FULLY_CONNECTED, cfg), cfg, w)
+    raise SystemExit("expected a failure")
+  except RuntimeError as e:
+    cases.append(dict(name="dwr_random", num_bits=4, granularity="CHANNELWISE", op="FULLY_CONNECTED",
+                      error="RuntimeError", message=str(e)[:400]))
+  np.savez_compressed(os.path.join(GOLDEN, "ref_dwr_cases.npz"), **arr)
+  with open(os.path.join(GOLDEN, "ref_dwr_cases.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_golden.py --dwr", numpy=np.__version__, cases=cases), f,
+              indent=1, sort_keys=True)
+  print(f"wrote {len(arr)} DWR arrays, {len(cases)} cases")
+
+
 def main():
   if "--oscar" in sys.argv:
     oscar_cases()
+    return
+  if "--dwr" in sys.argv:
+    dwr_cases()
     return
   # cross-check the bf16 stand-in against an independent implementation
   import torch

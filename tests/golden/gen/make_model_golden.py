@@ -228,7 +228,7 @@ def main():
   print("wrote", len(cases), "cases")
 
 
-if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more", "--mixed", "--fp16"} & set(sys.argv):
+if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more", "--mixed", "--fp16", "--dwr"} & set(sys.argv):
   main()
 
 
@@ -579,3 +579,51 @@ def fp16_cases():
 
 if __name__ == "__main__" and "--fp16" in sys.argv:
   fp16_cases()
+
+
+# ------------------------------------------------------------- dequantized weight recovery ---
+def dwr_model_cases():
+  """The reference's fake-quantized FC models under dequantized_weight_recovery recipes (matching
+  and mismatching granularities: the mismatches are refused by the reference)."""
+  os.makedirs(os.path.join(GOLDEN, "models", "dequantized_weights"), exist_ok=True)
+  # the recovered scales are plain ndarrays (np.hstack drops the bf16-aware subclass of the shim):
+  # re-register the algorithm through the reference's own registry API with a wrapper that only
+  # re-attaches the subclass, so that quantize_tensor's `.astype(ml_dtypes.bfloat16)` resolves
+  import dataclasses
+  import functools
+  from ai_edge_quantizer import algorithm_manager as ref_am
+  from ai_edge_quantizer.algorithms.uniform_quantize import common_quantize as ref_cq
+  from ai_edge_quantizer.algorithms.uniform_quantize import dequantized_weight_recovery as ref_dwr
+
+  def bf16_aware_params(*a, **k):
+    res = ref_dwr.get_tensor_quant_params(*a, **k)
+    return dataclasses.replace(res, scale=np.asarray(res.scale).view(ml_dtypes.Bf16Aware))
+  ref_am.register_quantized_op(
+      algorithm_key="dequantized_weight_recovery", tfl_op_name=qtyping.TFLOperationName.FULLY_CONNECTED,
+      init_qsv_func=ref_dwr.init_qsvs, calibration_func=ref_dwr.calibrate,
+      materialize_func=functools.partial(ref_cq.materialize_fc_conv, bf16_aware_params))
+
+  def rcp(gran, precision="INTEGER", explicit=False):
+    return [dict(regex=".*", operation="FULLY_CONNECTED", algorithm_key="dequantized_weight_recovery", op_config=dict(
+        weight_tensor_config=dict(num_bits=4, symmetric=True, granularity=gran, dtype="INT"),
+        compute_precision=precision, explicit_dequantize=explicit, skip_checks=False, min_weight_elements=0))]
+  cases = {}
+  for stem in ("channel_i4rangedvalues_fc", "tensor_i4rangedvalues_fc", "blockwise_i4rangedvalues_fc"):
+    name = "dequantized_weights/" + stem
+    shutil.copyfile(os.path.join(REF, "tests/models", name + ".tflite"), os.path.join(GOLDEN, "models", name + ".tflite"))
+    for rname, r in (("dwr_cw", rcp("CHANNELWISE")), ("dwr_tw", rcp("TENSORWISE")), ("dwr_b32", rcp("BLOCKWISE_32")),
+                     ("dwr_cw_weight_only", rcp("CHANNELWISE", "FLOAT", True))):
+      key = f"{name}/{rname}"
+      try:
+        cases[key] = dict(model=name, recipe_name=rname, recipe=r, result=run(name, rname, r))
+        print("ok  ", key)
+      except Exception as e:
+        cases[key] = dict(model=name, recipe_name=rname, recipe=r, error=type(e).__name__, message=str(e)[:300])
+        print("err ", key, type(e).__name__, str(e)[:150])
+  with open(os.path.join(GOLDEN, "ref_dwr_model_cases.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_model_golden.py --dwr", numpy=np.__version__,
+                   cases=json.loads(json.dumps(cases, default=str))), f, separators=(",", ":"), sort_keys=True)
+
+
+if __name__ == "__main__" and "--dwr" in sys.argv:
+  dwr_model_cases()

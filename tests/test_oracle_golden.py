@@ -461,3 +461,25 @@ def test_oscar_calibration_statistic_and_merge_match_reference(oscar_arrays):
     _eq(np.asarray(q["mu2"]), z[f"oscar_calib/merged_mu2_{i}"])
     _eq(q["min"], z[f"oscar_calib/merged_min_{i}"])
   assert int(q["num_samples"]) == c["num_samples"]
+
+
+# ------------------------------------------------------------ dequantized weight recovery ---
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_dwr_cases.json")) as _f:
+  _DWR = {c["name"]: c for c in json.load(_f)["cases"]}
+
+
+@pytest.mark.parametrize("name", sorted(_DWR))
+def test_dequantized_weight_recovery_matches_reference(name):
+  z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_dwr_cases.npz"))
+  c = _DWR[name]
+  w = z[f"{name}/w"]
+  if "error" in c:
+    with pytest.raises(RuntimeError, match="Failed to recover the original quantized values"):
+      O.dwr_quant_params(w, c["num_bits"], c["granularity"], c["op"])
+    return
+  r = O.dwr_quant_params(w, c["num_bits"], c["granularity"], c["op"])
+  _eq(r["scale"], z[f"{name}/scale"])
+  assert str(r["scale"].dtype) == c["scale_dtype"]
+  _eq(r["quantized_data"], z[f"{name}/q"])
+  assert np.array_equal(r["zero_point"], z[f"{name}/zero_point"])
+  assert r["quantized_dimension"] == c["quantized_dimension"] and r["block_size"] == c["block_size"]
