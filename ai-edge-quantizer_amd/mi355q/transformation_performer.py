@@ -24,6 +24,11 @@ def _unsupported(name: str):
   return fn
 
 
+def _deprecated(_):
+  raise NotImplementedError("This transformation is deprecated. Please contact AI Edge Quantizer team"
+                            " if you see this error.")
+
+
 class TransformationPerformer:
   def __init__(self):
     self._apply = {
@@ -32,7 +37,7 @@ class TransformationPerformer:
         _T.ADD_DEQUANTIZE: graph_edits.insert_dequant,
         _T.DUPLICATE_BUFFER: graph_edits.duplicate_buffer,
         _T.DUPLICATE_TENSOR: graph_edits.duplicate_tensor,
-        _T.EMULATED_SUBCHANNEL: _unsupported("EMULATED_SUBCHANNEL (deprecated in the reference)"),
+        _T.EMULATED_SUBCHANNEL: _deprecated,      # ref transformation_utils.py:286-290
         # the custom-op form stores its options as a FlexBuffer (third-party encoder, unpinned)
         _T.INSERT_HADAMARD_ROTATION: _unsupported("INSERT_HADAMARD_ROTATION (custom op with FlexBuffer options)"),
         _T.INSERT_DECOMPOSED_HADAMARD_ROTATION: graph_edits.insert_decomposed_hadamard_rotation,
