@@ -326,7 +326,7 @@ struct SegmentStart {
 // computed on the fly (|w| * s), the sorted keys and the masses of their columns are written
 // out in the natural [segment][rank] layout, or rank-major ([rank][segment]) for short segments
 // so that the scan kernel's lanes (one per segment) read consecutive addresses.
-constexpr int kSortThreads = 256;
+constexpr int kSortThreadsMax = 1024;
 
 // +1 every 8 and every 32 elements: the 8-element register blocks (stride 8) and the rank-major
 // store (stride P >= 32) both spread over the banks
@@ -345,7 +345,7 @@ __device__ __forceinline__ void sort_levels(double* key, uint16_t* pos, int tile
                                             int j) {
   constexpr int N = 1 << LEVELS;
   const int low = j >> (LEVELS - 1);                 // smallest distance of this round
-  for (int t = threadIdx.x; t < tile / N; t += kSortThreads) {
+  for (int t = threadIdx.x; t < tile / N; t += blockDim.x) {
     // spread t around LEVELS zero bits at the positions of the distances
     const int base = ((t & ~(low - 1)) << LEVELS) | (t & (low - 1));
     const bool desc = ((base & (P - 1)) & k) == 0;
@@ -381,7 +381,7 @@ __device__ __forceinline__ void sort_levels(double* key, uint16_t* pos, int tile
   }
 }
 
-__global__ __launch_bounds__(kSortThreads) void sort_tile_kernel(
+__global__ __launch_bounds__(kSortThreadsMax) void sort_tile_kernel(
     const float* __restrict__ w, const double* __restrict__ s, const double* __restrict__ m,
     int64_t segments, int32_t g, int32_t P, int32_t tile, int64_t d, int32_t transposed,
     double* __restrict__ keys_out, double* __restrict__ vals_out) {
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_tile_kernel(
   const int64_t seg0 = static_cast<int64_t>(blockIdx.x) * segs_per_tile;
   const int64_t segs_here = (segments - seg0 < segs_per_tile) ? segments - seg0 : segs_per_tile;
 
-  for (int e = threadIdx.x; e < tile; e += kSortThreads) {
+  for (int e = threadIdx.x; e < tile; e += blockDim.x) {
     const int sl = e / P, i = e - sl * P;
     double k = -1.0;                 // padding sorts behind every real magnitude
     if (sl < segs_here && i < g) {
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_tile_kernel(
   }
   if (transposed) {
     // consecutive threads -> consecutive segments of the tile, same rank
-    for (int e = threadIdx.x; e < segs_per_tile * g; e += kSortThreads) {
+    for (int e = threadIdx.x; e < segs_per_tile * g; e += blockDim.x) {
       const int i = e / segs_per_tile, sl = e - i * segs_per_tile;
       if (sl < segs_here) {
         const int at = lds_pad(sl * P + i);
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_tile_kernel(
       }
     }
   } else {
-    for (int e = threadIdx.x; e < tile; e += kSortThreads) {
+    for (int e = threadIdx.x; e < tile; e += blockDim.x) {
       const int sl = e / P, i = e - sl * P;
       if (sl < segs_here && i < g) {
         const int at = lds_pad(e);
@@ -442,6 +442,31 @@ __global__ __launch_bounds__(kSortThreads) void sort_tile_kernel(
       }
     }
   }
+}
+
+// Stable merge of the two sorted halves of every g-element segment (descending; on equal keys
+// the first half -- the lower original positions -- goes first): every element finds its rank by
+// a binary search in the other half.
+__global__ __launch_bounds__(256) void merge_halves_kernel(const double* __restrict__ keys,
+                                                           const double* __restrict__ vals,
+                                                           int64_t total, int64_t g,
+                                                           double* __restrict__ keys_out,
+                                                           double* __restrict__ vals_out) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int64_t h = g / 2, seg = e / g, i = e - seg * g;
+  const double k = keys[e];
+  const bool first = i < h;
+  const double* other = keys + seg * g + (first ? h : 0);
+  int64_t lo = 0, hi = h;                  // count of the other half's elements that go before k
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    const bool before = first ? other[mid] > k : other[mid] >= k;
+    if (before) lo = mid + 1; else hi = mid;
+  }
+  const int64_t at = seg * g + (first ? i : i - h) + lo;
+  keys_out[at] = k;
+  if (vals) vals_out[at] = vals[e];
 }
 
 // One lane per sorted segment: running sums in order, the candidate of every breakpoint
@@ -508,17 +533,12 @@ __global__ __launch_bounds__(64) void clip_scan_kernel(const double* __restrict_
   }
 }
 
-// The same scan with one WAVE per segment, for few long segments (a lane per segment would leave
-// most of the chip idle): the three running sums are carried lane to lane in order (one masked
-// add + readlane per lane and sum), the candidate of every breakpoint interval is then evaluated
-// by all 64 lanes at once, and the first minimum is an (error, index) butterfly.
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  const uint64_t b = __builtin_bit_cast(uint64_t, v);
-  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(b), lane);
-  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(b >> 32), lane);
-  return __builtin_bit_cast(double, (static_cast<uint64_t>(hi) << 32) | lo);
-}
-
+// The same scan with one WAVE per segment, for long segments (a lane per segment leaves most of
+// the chip idle and walks memory with a stride). 64 elements at a time: the lanes put the three
+// addends of their element in LDS; lanes 0..2 each own one running sum, read its 64 addends
+// into registers, add them in order (the carry never leaves the lane) and write the 64 prefix
+// values back; every lane then evaluates the candidate of its element, and the first minimum is
+// an (error, index) butterfly.
 __global__ __launch_bounds__(256) void clip_scan_wave_kernel(
     const double* __restrict__ keys, const double* __restrict__ vals, int64_t segments, int64_t g,
     int64_t G, const double* __restrict__ u, const double* __restrict__ noise, double qmax,
@@ -532,26 +552,37 @@ __global__ __launch_bounds__(256) void clip_scan_wave_kernel(
   const double a0 = a[0];
   double best_c = a0, best_e = (a0 * a0) * nk;       // the "clip nothing" candidate, index -1
   int64_t best_i = -1;
-  double carry_m = 0.0, carry_am = 0.0, carry_a2m = 0.0;
+  __shared__ double addend[4][3][64], prefix[4][3][64];
+  double (*add_w)[64] = addend[threadIdx.x >> 6];
+  double (*pre_w)[64] = prefix[threadIdx.x >> 6];
+  const int chain = lane < 3 ? lane : 0;             // lanes >= 3 shadow chain 0, results unused
+  double acc = 0.0;                                  // this chain's running sum across chunks
   for (int64_t base = 0; base < g; base += 64) {
     const int64_t i = base + lane;
     const bool live = i < g;
     const double ai = live ? a[i] : 0.0;
     const double mi = live ? m[i] : 0.0;
     const double lower = (i + 1 < g) ? a[i + 1] : 0.0;
-    const double am = ai * mi, a2m = (ai * ai) * mi;
-    double run_m = 0.0, run_am = 0.0, run_a2m = 0.0;
+    add_w[0][lane] = mi;
+    add_w[1][lane] = ai * mi;
+    add_w[2][lane] = (ai * ai) * mi;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the wave's LDS writes landed
+    double v[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) v[t] = add_w[chain][t];
 #pragma unroll
     for (int t = 0; t < 64; ++t) {
-      if (lane == t) {
-        run_m = carry_m + mi;
-        run_am = carry_am + am;
-        run_a2m = carry_a2m + a2m;
-      }
-      carry_m = readlane_f64(run_m, t);
-      carry_am = readlane_f64(run_am, t);
-      carry_a2m = readlane_f64(run_a2m, t);
+      acc = acc + v[t];
+      v[t] = acc;
     }
+    if (lane < 3) {
+#pragma unroll
+      for (int t = 0; t < 64; ++t) pre_w[chain][t] = v[t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const double run_m = pre_w[0][lane], run_am = pre_w[1][lane], run_a2m = pre_w[2][lane];
     if (live) {
       double c = (2.0 * run_am) / (uk + 2.0 * run_m);
       c = fmin(fmax(c, lower), ai);
@@ -799,8 +830,15 @@ int32_t sort_segments(const float* w, const double* s, const double* m, int64_t 
   void* tmp = base + 4 * slab;
   size_t tmp_bytes = need - 4 * slab;
   int64_t seg_stride = g, elem_stride = 1;
-  (void)vals_in;
-  if (g <= 8192 && g >= 2 && !getenv("MI355Q_OSCAR_LIBSORT")) {
+  // MI355Q_OSCAR_LIBSORT: A/B switch to the library radix sort (tools/oscar_bench.py)
+  const bool two_runs = g > 8192 && g <= 16384 && g % 2 == 0;   // sort halves in LDS, then merge
+  if ((g <= 8192 || two_runs) && g >= 2 && !getenv("MI355Q_OSCAR_LIBSORT")) {
+    const int64_t g_full = g;
+    if (two_runs) {
+      g /= 2;
+      allow_rank_major = false;
+    }
+    const int64_t segments = total / g;
     int32_t P = 32;
     while (P < g) P <<= 1;
     const int32_t tile = P > 4096 ? P : 4096;
@@ -813,10 +851,17 @@ int32_t sort_segments(const float* w, const double* s, const double* m, int64_t 
                                           static_cast<int>(lds));
       if (ea != hipSuccess) return fail(MI355Q_HIP_ERROR, "oscar sort LDS: %s", hipGetErrorString(ea));
     }
-    hipLaunchKernelGGL(sort_tile_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kSortThreads), lds, st,
-                       w, s, m, segments, static_cast<int32_t>(g), P, tile, d, transposed, keys_out,
-                       vals_out);
+    const int threads = tile >= 8192 ? 1024 : 512;   // measured best of {256, 512, 1024} per tile size
+    hipLaunchKernelGGL(sort_tile_kernel, dim3(static_cast<unsigned>(tiles)), dim3(threads), lds, st,
+                       w, s, m, segments, static_cast<int32_t>(g), P, tile, d, transposed,
+                       two_runs ? keys_in : keys_out, two_runs ? vals_in : vals_out);
     MI355Q_CHECK_LAUNCH("oscar_sort_tile");
+    if (two_runs) {
+      hipLaunchKernelGGL(merge_halves_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
+                         0, st, keys_in, m ? vals_in : nullptr, total, g_full, keys_out, vals_out);
+      MI355Q_CHECK_LAUNCH("oscar_merge_halves");
+      g = g_full;
+    }
     if (transposed) {
       seg_stride = 1;
       elem_stride = segments;
@@ -874,9 +919,9 @@ extern "C" int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s,
   const double* keys_out = sorted.keys;
   const double* vals_out = sorted.vals;
   const int64_t seg_stride = sorted.seg_stride, elem_stride = sorted.elem_stride;
-  if (elem_stride == 1 && g >= 256 && segments < 4096) {
-    // a lane per segment would fill fewer than 64 waves; the wave form costs ~70 SIMD cycles per
-    // element instead of ~6 but runs on segments (not segments / 64) waves
+  if (elem_stride == 1 && g >= 256 && segments < 12288) {
+    // the wave form costs ~40 SIMD cycles per element instead of ~6, but runs on `segments` (not
+    // segments / 64) waves: measured faster up to ~12k long segments (4096 x 4096: 0.73 vs 1.27 ms)
     hipLaunchKernelGGL(clip_scan_wave_kernel, dim3(static_cast<unsigned>((segments + 3) / 4)), dim3(256),
                        0, st, keys_out, vals_out, segments, g, G, u, noise, static_cast<double>(qmax),
                        blockwise_scale, bounds_out, scale_out);

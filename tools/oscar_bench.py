@@ -72,11 +72,14 @@ def main():
         cfg = qtyping.TensorQuantizationConfig(num_bits=4, symmetric=True, granularity=qtyping.QuantGranularity[gran])
         info = qtyping.OpInfo(op=qtyping.OperatorT(), op_name=qtyping.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
                               op_quant_config=qtyping.OpQuantizationConfig(weight_tensor_config=cfg))
-        oscar.get_tensor_quant_params(info, cfg, wh, {"mu2": mu2})
-        t = time.perf_counter()
-        oscar.get_tensor_quant_params(info, cfg, wh, {"mu2": mu2})
+        best = None
+        for _ in range(4):          # the first calls grow the caching allocator (GiB-sized workspaces)
+          t = time.perf_counter()
+          oscar.get_tensor_quant_params(info, cfg, wh, {"mu2": mu2})
+          dt = time.perf_counter() - t
+          best = dt if best is None else min(best, dt)
         print(json.dumps(dict(stage="api_get_tensor_quant_params", shape=shape, granularity=gran,
-                              seconds=round(time.perf_counter() - t, 4))), flush=True)
+                              seconds=round(best, 4))), flush=True)
 
 
 if __name__ == "__main__":
