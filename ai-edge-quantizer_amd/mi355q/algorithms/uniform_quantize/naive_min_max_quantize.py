@@ -48,6 +48,9 @@ def fused_weight_layout(tensor_content: np.ndarray, granularity, quantized_dim):
   return None
 
 
+_KEEP_IN_HBM_BYTES = 4 << 20
+
+
 def fused_symmetric_requant(tensor_content: np.ndarray, layout, num_bits: int,
                             clip: Optional[np.ndarray] = None):
   """Runs mi355q_requant_sym_f32; returns (scale f32 [n_scales], q int8 like tensor).
@@ -64,6 +67,13 @@ def fused_symmetric_requant(tensor_content: np.ndarray, layout, num_bits: int,
   sub_byte = (num_bits in (2, 4) and cols % 4 == 0
               and (block in (32, 64, 128, 256) or (block == 0 and cols <= 16384)))
   r = ops.requant_sym(x, block, num_bits, clip=c, want_q=True, want_packed=sub_byte)
+  if tensor_content.nbytes >= _KEEP_IN_HBM_BYTES:
+    # large weights stay in HBM until the model writer copies them (packed bytes for sub-byte
+    # types) straight into the output file's mapping; NumPy consumers get a host copy on demand
+    q = rt.HbmArray(r["q"].reshape(tensor_content.shape))
+    if sub_byte:
+      q.packed = rt.HbmArray(r["packed"])
+    return rt.to_numpy(r["scale"]).reshape(-1), q
   q = rt.to_numpy(r["q"]).reshape(tensor_content.shape)
   if sub_byte:
     q = q.view(PackedCarrier)

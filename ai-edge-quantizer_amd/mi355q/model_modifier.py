@@ -92,7 +92,7 @@ def _large_buffer_bytes(model: Any) -> int:
   total = 0
   for b in model.buffers or []:
     if b.data is not None:
-      n = np.asarray(b.data).nbytes if isinstance(b.data, np.ndarray) else len(b.data)
+      n = b.data.nbytes if hasattr(b.data, "nbytes") else len(b.data)
       if n >= _MIN_EXTERNAL_BUFFER_BYTES:
         total = (total + n + 15) & ~15
   return total
@@ -101,6 +101,9 @@ def _large_buffer_bytes(model: Any) -> int:
 def serialize_model(model: Any, serialize_to_path: Optional[tfl_flatbuffer_utils.Path] = None):
   """ref :184-199 (layout choice), :290-391 (the two serializers)."""
   if _large_buffer_bytes(model) < _INLINE_LIMIT_BYTES:
+    for b in model.buffers or []:
+      if hasattr(b.data, "copy_into"):        # device resident: the inline writer wants bytes
+        b.data = np.ravel(np.asarray(b.data)).view(np.uint8)
     out = tflite_flatbuffer.write_model(model)
     if serialize_to_path:
       tfl_flatbuffer_utils.set_file_contents(serialize_to_path, out)

@@ -66,6 +66,20 @@ class HbmArray:
     self.device_tensor = tensor
     self._host = None
     self.cache: dict = {}          # derived device results (e.g. the damped inverse)
+    self.packed = None             # quantized weights: the packed bytes of the same launch
+
+  @property
+  def nbytes(self) -> int:
+    return self.device_tensor.numel() * self.device_tensor.element_size()
+
+  def copy_into(self, dst: np.ndarray) -> None:
+    """D2H straight into `dst` (a writable uint8 view of, e.g., the output file's mapping)."""
+    if self._host is not None:
+      dst[:] = np.ravel(self._host).view(np.uint8)
+      return
+    with warnings.catch_warnings():
+      warnings.simplefilter("ignore")
+      torch.from_numpy(dst).copy_(self.device_tensor.contiguous().reshape(-1).view(torch.uint8))
 
   @property
   def shape(self):

@@ -87,6 +87,8 @@ def quantize_tensor(ti: transformation_utils.TransformationInput) -> qtyping.Tra
                         " data in buffer %s.", tensor.name, buffer_id)
       ti.buffer_origin[buffer_id] = p
       ready = getattr(p.quantized_data, "packed", None)    # packed by the quantizing launch
+      if ready is None and p.num_bits == 8 and hasattr(p.quantized_data, "copy_into"):
+        ready = p.quantized_data                           # int8 in HBM: its bytes are the buffer
       ti.model.buffers[buffer_id].data = ready if ready is not None else transformation_utils.pack_data(
           p.num_bits, np.ravel(np.asarray(p.quantized_data)).view(np.uint8))
   if isinstance(p, qtyping.UniformQuantParams):

@@ -55,6 +55,8 @@ def get_tensor_data(tensor: Any, buffers: list[Any]) -> Optional[np.ndarray]:
   raw = buffers[tensor.buffer].data
   if raw is None:
     return None
+  if hasattr(raw, "copy_into"):          # quantized data still in HBM (runtime.HbmArray)
+    raw = np.ravel(np.asarray(raw)).view(np.uint8)
   dtype = schema.NUMPY_DTYPE[schema.TensorType(tensor.type)]
   data = raw if isinstance(raw, np.ndarray) and raw.dtype == np.dtype(dtype) \
       else np.frombuffer(raw, dtype=dtype)

@@ -593,15 +593,24 @@ def serialize_with_external_buffers(model, min_size_bytes: int = 1024,
   `sink(total_bytes)` may return a writable buffer (e.g. an mmap of the output file) to build
   into; otherwise a bytearray is returned. Buffer payloads may be NumPy arrays of any dtype.
   """
-  ext: dict[int, memoryview] = {}
+  ext: dict[int, Any] = {}      # buffer id -> memoryview of its bytes, or a device-resident payload
+  sizes: dict[int, int] = {}
   packed = 0
   for i, buf in enumerate(model.buffers or []):
     d = buf.data
     if d is None:
       continue
+    if hasattr(d, "copy_into"):   # lives on an accelerator: copies itself into the output mapping
+      if d.nbytes >= min_size_bytes:
+        ext[i], sizes[i] = d, d.nbytes
+        packed = _round_up_16(packed + d.nbytes)
+      else:
+        buf.data = np.ravel(np.asarray(d)).view(np.uint8)
+      continue
     arr = d if isinstance(d, np.ndarray) else np.frombuffer(bytes(d), dtype=np.uint8)
     if arr.nbytes >= min_size_bytes:
       ext[i] = memoryview(np.ascontiguousarray(arr).reshape(-1).view(np.uint8))
+      sizes[i] = arr.nbytes
       packed = _round_up_16(packed + arr.nbytes)
   saved = {}
   for i in ext:
@@ -622,11 +631,15 @@ def serialize_with_external_buffers(model, min_size_bytes: int = 1024,
     cursor = start
     for i, view in ext.items():
       buf = model.buffers[i]
-      for fname, value in (("offset", cursor), ("size", len(view))):
+      n = sizes[i]
+      for fname, value in (("offset", cursor), ("size", n)):
         pos = total_fb - patch[(id(buf), fname)]
         out[pos:pos + 8] = struct.pack("<Q", value)
-      out[cursor:cursor + len(view)] = view
-      cursor = _round_up_16(cursor + len(view))
+      if hasattr(view, "copy_into"):
+        view.copy_into(np.frombuffer(out, dtype=np.uint8, count=n, offset=cursor))
+      else:
+        out[cursor:cursor + n] = view
+      cursor = _round_up_16(cursor + n)
   finally:
     for i, (d, o, s) in saved.items():
       buf = model.buffers[i]
