@@ -1,6 +1,7 @@
 """Model-level tensor sharding on the GPU: two ranks (gloo rendezvous, both on cuda:0) quantize a
 model file with the product algorithms and rank 0's file must equal the single-process file."""
 import os
+import sys
 
 import pytest
 
@@ -45,3 +46,34 @@ def test_two_ranks_quantize_model_files_like_one():
   for case, (sharded, single), (other, _) in zip(_CASES, got0, got1):
     assert other is None and sharded is not None, case
     assert sharded == single, case
+
+
+def _worker_rccl_single(rank, world, port, out):
+  """World of one over RCCL ("nccl" backend): the collectives take the HBM code path."""
+  import numpy as np
+  import torch
+  for p in (os.path.join(ROOT, "ai-edge-quantizer_amd"), ROOT):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+  import torch.distributed as dist
+  torch.cuda.set_device(0)
+  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+  from mi355q import distributed as D, runtime as rt
+  assert D._comm_device().type == "cuda"
+  rng = np.random.default_rng(3)
+  h = rng.standard_normal((64, 64))
+  got, total = D.allreduce_hessian(rt.HbmArray(torch.from_numpy(h * 5).cuda()), 5)
+  ok = bool(np.allclose(got.cpu().numpy(), h) and total == 5)
+  stats = rng.standard_normal((7, 3, 2)).astype(np.float32)
+  ok &= bool(np.array_equal(D.gather_sample_stats(stats), stats))
+  mm = D.allreduce_min_max(stats)
+  ok &= bool(np.array_equal(mm[:, 0], stats[..., 0].min(0)) and np.array_equal(mm[:, 1], stats[..., 1].max(0)))
+  out.put((0, ok))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_collectives_over_rccl_world_of_one():
+  (_, ok), = _run(_worker_rccl_single, world=1, timeout=600)
+  assert ok
