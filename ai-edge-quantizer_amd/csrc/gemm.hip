@@ -346,8 +346,18 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs<typename TL::Elem>
   __shared__ __attribute__((aligned(16))) T As[NBUF][BK][LD];
   __shared__ __attribute__((aligned(16))) T Bs[NBUF][BK][LD];
 
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (g.lower_only && bj > bi) return;
+  int bi = blockIdx.y, bj = blockIdx.x;
+  if (g.lower_only == 2) {
+    // triangular grid: block r of nt (nt + 1) / 2, the longest tile rows (most K work under the
+    // k_modes) first; no empty blocks above the diagonal
+    const int r = static_cast<int>(gridDim.x) - 1 - static_cast<int>(blockIdx.x);
+    bi = static_cast<int>((__builtin_sqrt(8.0 * r + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= r) ++bi;
+    while (bi * (bi + 1) / 2 > r) --bi;
+    bj = r - bi * (bi + 1) / 2;
+  } else if (g.lower_only && bj > bi) {
+    return;
+  }
   const int i0 = bi * BM, j0 = bj * BM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = (wave >> 1) * (TM * MF), wj = (wave & 1) * (TM * MF);
@@ -535,12 +545,19 @@ int32_t launch_with(const GemmArgs<typename TL::Elem>& g, hipStream_t st, void* 
   if (whole) {
 #endif
     T* part = slices > 1 ? static_cast<T*>(splitk_ws) : nullptr;
+    GemmArgs<T> h = g;
+    dim3 fgrid = grid;
+    if (g.lower_only && g.M == g.N) {
+      const unsigned nt = grid.y;
+      h.lower_only = 2;
+      fgrid = dim3(nt * (nt + 1) / 2, 1, grid.z);
+    }
 #define MI355Q_FAST(AM, BMO)                                                                        \
   do {                                                                                               \
     if constexpr (std::is_same_v<TL, TileF64Big>)                                                    \
-      hipLaunchKernelGGL((gemm_fast_big_kernel<AM, BMO>), grid, dim3(256), 0, st, g, chunk, part);   \
+      hipLaunchKernelGGL((gemm_fast_big_kernel<AM, BMO>), fgrid, dim3(256), 0, st, h, chunk, part);  \
     else                                                                                             \
-      hipLaunchKernelGGL((gemm_fast_kernel<TL, AM, BMO>), grid, dim3(256), 0, st, g, chunk, part);   \
+      hipLaunchKernelGGL((gemm_fast_kernel<TL, AM, BMO>), fgrid, dim3(256), 0, st, h, chunk, part);  \
   } while (0)
     if (a_mode == kMFast && b_mode == kMFast) MI355Q_FAST(kMFast, kMFast);
     else if (a_mode == kMFast) MI355Q_FAST(kMFast, kKFast);
@@ -585,9 +602,13 @@ int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_
     const bool splitk = splitk_ws != nullptr && g.k_mode == 0 && gemm_pick_splitk<T>(g.M, g.N, g.K) > 1;
     const bool whole128 = g.M % 128 == 0 && g.N % 128 == 0 && g.K % 16 == 0 && a_mode != kGeneric &&
                           b_mode != kGeneric;
+#ifndef MI355Q_BIG_MIN_TRI_TILES
+#define MI355Q_BIG_MIN_TRI_TILES 1024
+#endif
 #if !defined(MI355Q_GEMM_NOBIG)   // tuning hook (tools/gemm_bench.py)
     // triangular outputs (lower_only) leave the chip half empty at the tail with tiles this big
-    if (tiles128 >= 256 && !splitk && whole128 && g.K >= MI355Q_BIG_MIN_K && !g.lower_only)
+    if (tiles128 >= 256 && !splitk && whole128 && g.K >= MI355Q_BIG_MIN_K &&
+        (!g.lower_only || tiles128 >= MI355Q_BIG_MIN_TRI_TILES))
       return launch_with<TileF64Big>(g, st, nullptr, 0, a_mode, b_mode);
 #endif
   }

@@ -437,6 +437,64 @@ extern "C" int32_t mi355q_gptq_hessian_merge_f64(const double* h_cur, double n_c
   return MI355Q_OK;
 }
 
+namespace {
+// Look-ahead for the blocked Cholesky: the rank-512 update of the matrix behind the next outer
+// block runs on a side stream while the caller's stream already factors that next block (serial
+// 64 x 64 diagonal work and small GEMMs that would otherwise leave the chip idle).
+// One side stream + two events per device, created on first use, released by mi355q_shutdown().
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t panel_done = nullptr, update_done = nullptr;
+  bool tried = false;
+};
+SideStream g_side[64];
+
+SideStream* side_stream() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& s = g_side[dev];
+  if (!s.tried) {
+    s.tried = true;
+    if (getenv("MI355Q_NO_LOOKAHEAD")) return nullptr;
+    // non-blocking: the caller's stream is usually the legacy default stream, which serializes
+    // with every blocking stream (hipExtStreamCreateWithCUMask only makes blocking ones)
+    // lowest priority: when both queues have workgroups to place, the caller's small kernels go first
+    hipStream_t st = nullptr;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamDestroy(st);
+      return nullptr;
+    }
+    s.stream = st;
+    s.panel_done = a;
+    s.update_done = b;
+  }
+  return s.stream ? &s : nullptr;
+}
+}  // namespace
+
+extern "C" int32_t mi355q_shutdown(void) {
+  clear_error();
+  for (SideStream& s : g_side) {
+    if (s.stream) {
+      (void)hipStreamSynchronize(s.stream);
+      (void)hipEventDestroy(s.panel_done);
+      (void)hipEventDestroy(s.update_done);
+      (void)hipStreamDestroy(s.stream);
+    }
+    s = SideStream();
+  }
+  return MI355Q_OK;
+}
+
 extern "C" size_t mi355q_gptq_hinv_workspace_bytes(int64_t d) {
   // two d x d FP64 matrices + a d x NB panel + one NB x NB inverse per diagonal block + scalars
   if (d <= 0) return 0;
@@ -477,6 +535,8 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   // (d-k)^2/2 doubles for 64 flops each), so the 64-column steps only update the rest of their
   // own 512-column outer block; the matrix behind it gets one rank-512 update per outer block.
   constexpr int OB = 8 * NB;
+  SideStream* side = d >= 4096 ? side_stream() : nullptr;
+  bool side_busy = false;
   for (int k0 = 0; k0 < d; k0 += OB) {
     const int ob = d - k0 < OB ? d - k0 : OB;
     for (int k = k0; k < k0 + ob; k += NB) {
@@ -503,10 +563,35 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
     if (m2 > 0) {
       const double* l = a + static_cast<long long>(k0 + ob) * d + k0;   // m2 x ob, finished columns
       double* c = a + static_cast<long long>(k0 + ob) * d + k0 + ob;
-      GemmArgs<double> gu{l, d, 1, l, 1, d, c, d, 1, m2, m2, ob, -1.0, 1.0, 1, 0};
-      if (int32_t e = launch_gemm<double>(gu, st)) return e;
+      const int next = m2 < OB ? m2 : OB;       // width of the next outer block
+      if (side == nullptr || m2 - next < 2048) {
+        GemmArgs<double> gu{l, d, 1, l, 1, d, c, d, 1, m2, m2, ob, -1.0, 1.0, 1, 0};
+        if (int32_t e = launch_gemm<double>(gu, st)) return e;
+      } else {
+        // the strip the next outer block lives in: here, now (it must also wait for the side
+        // stream's previous update, which wrote the same strip)
+        if (side_busy && hipStreamWaitEvent(st, side->update_done, 0) != hipSuccess)
+          return fail(MI355Q_HIP_ERROR, "look-ahead: wait failed");
+        if (hipEventRecord(side->panel_done, st) != hipSuccess)
+          return fail(MI355Q_HIP_ERROR, "look-ahead: record failed");
+        GemmArgs<double> strip{l, d, 1, l, 1, d, c, d, 1, m2, next, ob, -1.0, 1.0, 1, 0};
+        if (int32_t e = launch_gemm<double>(strip, st)) return e;
+        // everything behind that strip: on the side stream, overlapping the next block's
+        // factorization (disjoint columns)
+        if (hipStreamWaitEvent(side->stream, side->panel_done, 0) != hipSuccess)
+          return fail(MI355Q_HIP_ERROR, "look-ahead: wait failed");
+        const double* l2 = l + static_cast<long long>(next) * d;
+        double* c2 = c + static_cast<long long>(next) * d + next;
+        GemmArgs<double> rest{l2, d, 1, l2, 1, d, c2, d, 1, m2 - next, m2 - next, ob, -1.0, 1.0, 1, 0};
+        if (int32_t e = launch_gemm<double>(rest, side->stream)) return e;
+        if (hipEventRecord(side->update_done, side->stream) != hipSuccess)
+          return fail(MI355Q_HIP_ERROR, "look-ahead: record failed");
+        side_busy = true;
+      }
     }
   }
+  if (side_busy && hipStreamWaitEvent(st, side->update_done, 0) != hipSuccess)
+    return fail(MI355Q_HIP_ERROR, "look-ahead: wait failed");
   MI355Q_CHECK_LAUNCH("gptq cholesky launch");
   // ---- in-place inverse of the lower-triangular factor by pairwise merging: the diagonal
   // NB-blocks are already inverted; at level s every pair of adjacent inverted blocks

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "mi355q_gptq_xtx_f32": (c_i32, [c_ptr, c_i64, c_i64, c_f64, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_gptq_hessian_merge_f64": (c_i32, [c_ptr, c_f64, c_ptr, c_f64, c_i64, c_ptr, c_ptr]),
     "mi355q_gptq_hinv_workspace_bytes": (c_size, [c_i64]),
+    "mi355q_shutdown": (c_i32, []),
     "mi355q_gptq_hinv_f64": (c_i32, [c_ptr, c_i64, c_f64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_gptq_apply_workspace_bytes": (c_size, [c_i64, c_i64]),
     "mi355q_gptq_apply_f32": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32,

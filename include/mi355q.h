@@ -273,6 +273,9 @@ int32_t mi355q_gptq_hessian_merge_f64(const double* h_cur, double n_cur, const d
  * workspace: mi355q_gptq_hinv_workspace_bytes(d) bytes.
  * ------------------------------------------------------------------------ */
 size_t mi355q_gptq_hinv_workspace_bytes(int64_t d);
+/* Releases the per-device side stream + events the blocked Cholesky creates on first use for
+ * its look-ahead (the only state the library keeps between calls). Safe to call at any time. */
+int32_t mi355q_shutdown(void);
 int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d, double damp_factor, float* hinv_out,
                              int32_t* info_out, void* workspace, size_t workspace_bytes,
                              void* stream);

@@ -121,6 +121,31 @@ def test_hessian_inverse_larger_and_not_positive_definite(m):
     m.gptq._prepare_hessian_inverse(bad)
 
 
+def test_hessian_inverse_with_cholesky_lookahead(m):
+  """d >= 4096: the rank-512 updates behind the next outer block run on the library's side
+  stream while the caller's stream factors that block; checked against the exact FP64 inverse
+  computed on the device (torch.linalg, checker only) and for run-to-run determinism."""
+  import torch
+  d = 4608
+  gen = torch.Generator(device="cuda").manual_seed(7)
+  x = torch.randn((2 * d, d), generator=gen, device="cuda", dtype=torch.float64)
+  h = (x.T @ x) / (2 * d)
+  dg = torch.diagonal(h)
+  damped = h + torch.diag(torch.full((d,), 0.01 * float(dg.mean()), device="cuda", dtype=torch.float64))
+  exact = torch.linalg.inv(damped)
+  first, info = m.ops.gptq_hinv(h.contiguous(), 0.01)
+  assert int(info.item()) == 0
+  err = float((first.double() - exact).abs().max() / exact.abs().max())
+  assert err <= 1e-6, err
+  assert torch.equal(first, first.T)
+  again, _ = m.ops.gptq_hinv(h.contiguous(), 0.01)
+  assert torch.equal(first, again)                 # same launches, same order: bit-identical
+  from mi355q import _ffi
+  assert _ffi.lib().mi355q_shutdown() == 0         # releases the side stream; the next call re-creates it
+  third, _ = m.ops.gptq_hinv(h.contiguous(), 0.01)
+  assert torch.equal(first, third)
+
+
 def _apply_with_reference_hinv(m, arrays, name, c):
   w, scale, zp = arrays[f"{name}/w"], arrays[f"{name}/scale"], arrays[f"{name}/zero_point"]
   rows, d = w.shape
