@@ -19,6 +19,8 @@ struct GemmArgs {
   int k_mode;          // 0: all k; 1: A(i,k) == 0 for k > i (lower-triangular A): k < i0+BM;
                        // 2: A(i,k) == 0 for k < i and B(k,j) == 0 for k < j: k >= max(i0, j0)
                        // 3: B(k,j) == 0 for k < j (lower-triangular B): k >= j0
+  int batch;           // > 1: grid.z independent problems of this shape; operand b starts
+  long long sa, sb, sc;  //      batch strides (elements) after problem b - 1 (no split-K then)
 };
 
 // Number of K slices launch_gemm would use for this shape (1 = no split) and the

@@ -163,6 +163,16 @@ __device__ __forceinline__ void store_tile(const Stage<TL>& st, typename TL::Ele
   }
 }
 
+template <typename T>
+__device__ __forceinline__ void batch_offset(GemmArgs<T>& g) {
+  if (g.batch > 1) {
+    const long long b = blockIdx.z;
+    g.A += b * g.sa;
+    g.B += b * g.sb;
+    g.C += b * g.sc;
+  }
+}
+
 template <typename TL>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<typename TL::Elem> g, int a_mode, int b_mode,
                                                    int k_chunk, typename TL::Elem* __restrict__ partial) {
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<typename TL::Elem> g
   constexpr int NREG = sizeof(typename TL::Acc) / sizeof(T);
   constexpr int NBUF = TL::DBUF ? 2 : 1;
   static_assert(BM * BK / TL::VEC % 256 == 0, "whole 16-byte loads per thread per operand tile");
+  batch_offset(g);
   __shared__ __attribute__((aligned(16))) T As[NBUF][BK][LD];
   __shared__ __attribute__((aligned(16))) T Bs[NBUF][BK][LD];
 
@@ -357,6 +368,8 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs<typename TL::Elem>
     bj = r - bi * (bi + 1) / 2;
   } else if (g.lower_only && bj > bi) {
     return;
+  } else if (g.k_mode == 1) {
+    bi = static_cast<int>(gridDim.y) - 1 - bi;   // K grows with the tile row: longest rows first
   }
   const int i0 = bi * BM, j0 = bj * BM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -459,6 +472,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs<typename TL::Elem>
 template <typename TL, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs<typename TL::Elem> g, int k_chunk,
                                                         typename TL::Elem* __restrict__ partial) {
+  batch_offset(g);
   gemm_fast_body<TL, AMODE, BMODE>(g, k_chunk, partial);
 }
 
@@ -469,6 +483,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs<typename TL::El
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void gemm_fast_big_kernel(GemmArgs<double> g, int k_chunk, double* __restrict__ partial) {
+  batch_offset(g);
   gemm_fast_body<TileF64Big, AMODE, BMODE>(g, k_chunk, partial);
 }
 
@@ -524,12 +539,15 @@ int32_t launch_with(const GemmArgs<typename TL::Elem>& g, hipStream_t st, void* 
   using T = typename TL::Elem;
   constexpr int BM = TL::BM;
   int slices = 1;
+  if (g.batch > 1) {
+    splitk_ws = nullptr;
+  }
   if (splitk_ws != nullptr && g.k_mode == 0) {
     slices = gemm_pick_splitk<T>(g.M, g.N, g.K);
     if (static_cast<size_t>(slices) * g.M * g.N * sizeof(T) > splitk_ws_bytes) slices = 1;
   }
   const dim3 grid(static_cast<unsigned>((g.N + BM - 1) / BM), static_cast<unsigned>((g.M + BM - 1) / BM),
-                  static_cast<unsigned>(slices));
+                  static_cast<unsigned>(g.batch > 1 ? g.batch : slices));
   // whole tiles + 16-byte loadable operands: the lean kernel
   const bool whole = g.M % BM == 0 && g.N % BM == 0 && g.K % TL::BK == 0 && a_mode != kGeneric &&
                      b_mode != kGeneric;

@@ -601,7 +601,22 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   // final product and holds the intermediate L21 L11^-1.
   hipLaunchKernelGGL(put_diag_inverses_kernel, dim3(nblocks), dim3(256), 0, st, a, d, dinv, 0);
   for (long long s = NB; s < d; s *= 2) {
-    for (long long p = 0; p + s < d; p += 2 * s) {
+    // the pairs of one level are independent and (but for a ragged last one) equally shaped:
+    // the low levels, hundreds of one-tile GEMMs, go out as two batched launches per level
+    long long first = 0;
+    const long long full = (d - s) / (2 * s) + ((d - s) % (2 * s) >= s ? 1 : 0);   // pairs with n2 == s
+    if (full >= 2 && s <= 2048) {
+      const int n = static_cast<int>(s);
+      const long long hop = 2 * s * (static_cast<long long>(d) + 1);
+      GemmArgs<double> g1{a + s * d, d, 1, a, d, 1, out, n, 1, n, n, n, 1.0, 0.0, 0, 3,
+                          static_cast<int>(full), hop, hop, s * s};
+      if (int32_t e = launch_gemm<double>(g1, st)) return e;
+      GemmArgs<double> g2{a + s * d + s, d, 1, out, n, 1, a + s * d, d, 1, n, n, n, -1.0, 0.0, 0, 1,
+                          static_cast<int>(full), hop, s * s, hop};
+      if (int32_t e = launch_gemm<double>(g2, st)) return e;
+      first = full * 2 * s;
+    }
+    for (long long p = first; p + s < d; p += 2 * s) {
       const int n2 = static_cast<int>(d - (p + s) < s ? d - (p + s) : s);
       const int n1 = static_cast<int>(s);
       double* l11 = a + p * d + p;                 // n1 x n1, inverted, lower
