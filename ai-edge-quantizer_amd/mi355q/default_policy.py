@@ -8,7 +8,10 @@ ignores `min_weight_elements` and `algorithm_params` exactly like the reference'
 """
 from __future__ import annotations
 
+import collections
+import copy
 import dataclasses
+import json
 from typing import Any, Optional
 
 from . import qtyping
@@ -113,6 +116,54 @@ class ConfigCheckPolicy:
 
 
 DEFAULT_CONFIG_CHECK_POLICY = ConfigCheckPolicy()
+
+
+class ListedConfigPolicy(collections.OrderedDict):
+  """A policy given as data: op -> the list of accepted configs (what a user's policy .json
+  unrolls to; the reference's `ConfigCheckPolicyDict`). A config is accepted when, with
+  `min_weight_elements` and the tensors' `algorithm_params` neutralised, it equals one of the
+  listed ones (ref algorithms/utils/common_utils.py:130-151)."""
+
+  def accepts(self, op_name, op_quant_config: qtyping.OpQuantizationConfig) -> bool:
+    probe = dataclasses.replace(op_quant_config, min_weight_elements=0)
+    for side in ("weight_tensor_config", "activation_tensor_config"):
+      cfg = getattr(probe, side)
+      if cfg is not None:
+        probe = dataclasses.replace(probe, **{side: dataclasses.replace(cfg, algorithm_params={})})
+    return probe in self[op_name]
+
+
+def _unroll_json_config(entry: dict) -> list[qtyping.OpQuantizationConfig]:
+  """One policy entry lists alternatives for `symmetric` and `granularity` per tensor: every
+  combination becomes a config (ref :339-399)."""
+  def tensor_configs(spec):
+    return [qtyping.TensorQuantizationConfig.from_dict(dict(
+        num_bits=spec["num_bits"], symmetric=sym, granularity=gran, dtype=spec["dtype"]))
+            for sym in spec["symmetric"] for gran in spec["granularity"]]
+  acts = tensor_configs(entry["activation_tensor_config"]) if "activation_tensor_config" in entry else []
+  out, seen_weights = [], []
+  for w in tensor_configs(entry["weight_tensor_config"]):
+    seen_weights.append(w)
+    # (without activation configs the reference re-lists every weight config seen so far: the
+    # duplicates do not change what the policy accepts, but the order is kept the same)
+    for act, weight in ([(a, w) for a in acts] if acts else [(None, sw) for sw in seen_weights]):
+      out.append(qtyping.OpQuantizationConfig(
+          activation_tensor_config=act, weight_tensor_config=weight,
+          compute_precision=entry["compute_precision"], explicit_dequantize=entry["explicit_dequantize"]))
+  return out
+
+
+def update_default_config_policy(raw_json_policy: str) -> ListedConfigPolicy:
+  """A policy .json ({"configs": {name: entry}, "ops_per_config": {name: [ops]}}) as a
+  ListedConfigPolicy (ref :402-420)."""
+  content = json.loads(raw_json_policy)
+  policy = ListedConfigPolicy()
+  for name, ops in content["ops_per_config"].items():
+    unrolled = _unroll_json_config(content["configs"][name])
+    for op in ops:
+      op_name = qtyping.TFLOperationName(op)
+      policy[op_name] = copy.deepcopy(unrolled) + (policy[op_name] if op_name in policy else [])
+  return policy
 
 
 def check_if_valid_op_config(op_name, op_quant_config: qtyping.OpQuantizationConfig,

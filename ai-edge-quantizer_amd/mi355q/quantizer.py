@@ -14,7 +14,9 @@ import os
 import pathlib
 from typing import Any, Optional, Union
 
+from . import algorithm_manager
 from . import calibrator
+from . import default_policy
 from . import model_modifier
 from . import params_generator
 from . import qtyping
@@ -25,6 +27,16 @@ from .utils import tflite_flatbuffer
 apply_quantize_tensor_transformations = model_modifier.apply_quantize_tensor_transformations
 
 Path = Union[str, pathlib.Path]
+
+
+class _Flag(int):
+  """A bool-valued int that can also be called (`qt.need_calibration` / `qt.need_calibration()`)."""
+
+  def __call__(self) -> bool:
+    return bool(self)
+
+  def __repr__(self) -> str:
+    return repr(bool(self))
 
 
 @dataclasses.dataclass(frozen=True)
@@ -81,15 +93,48 @@ class Quantizer:
   def get_quantization_recipe(self) -> qtyping.ModelQuantizationRecipe:
     return self._recipe_manager.get_quantization_recipe()
 
-  def need_calibration(self) -> bool:
-    return self._recipe_manager.need_calibration()
+  @property
+  def need_calibration(self) -> "_Flag":
+    """A property in the reference (`qt.need_calibration`); also callable here."""
+    return _Flag(self._recipe_manager.need_calibration())
+
+  def load_config_policy(self, filename: Path) -> None:
+    """A user policy .json replaces the min/max algorithm's config check policy (ref :207-222)."""
+    with open(filename, "r", encoding="utf-8") as f:
+      policy = default_policy.update_default_config_policy(f.read())
+    algorithm_manager.register_config_check_policy_func(
+        algorithm_manager.AlgorithmName.MIN_MAX_UNIFORM_QUANT, policy)
+
+  def update_quantization_recipe(self, regex: str, operation_name, op_config=None,
+                                 algorithm_key: str = algorithm_manager.AlgorithmName.MIN_MAX_UNIFORM_QUANT):
+    """ref :233-262."""
+    self._recipe_manager.add_quantization_config(regex, operation_name, op_config, algorithm_key)
+
+  def add_dynamic_config(self, regex: str, operation_name, num_bits: int,
+                         granularity=qtyping.QuantGranularity.CHANNELWISE,
+                         algorithm_key: str = algorithm_manager.AlgorithmName.MIN_MAX_UNIFORM_QUANT):
+    """ref :264-289."""
+    self._recipe_manager.add_dynamic_config(regex, operation_name, num_bits, granularity, algorithm_key)
+
+  def add_weight_only_config(self, regex: str, operation_name, num_bits: int,
+                             granularity=qtyping.QuantGranularity.CHANNELWISE,
+                             algorithm_key: str = algorithm_manager.AlgorithmName.MIN_MAX_UNIFORM_QUANT):
+    """ref :291-316."""
+    self._recipe_manager.add_weight_only_config(regex, operation_name, num_bits, granularity, algorithm_key)
+
+  def add_static_config(self, regex: str, operation_name, activation_num_bits: int, weight_num_bits: int,
+                        weight_granularity=qtyping.QuantGranularity.CHANNELWISE,
+                        algorithm_key: str = algorithm_manager.AlgorithmName.MIN_MAX_UNIFORM_QUANT):
+    """ref :318-352."""
+    self._recipe_manager.add_static_config(regex, operation_name, activation_num_bits, weight_num_bits,
+                                           weight_granularity, algorithm_key)
 
   def calibrate(self, calibration_data: dict, previous_calibration_result: Optional[dict] = None,
                 tensor_provider: Optional[Any] = None) -> dict[str, qtyping.QSV]:
     """Model QSVs from per-sample tensor contents (ref :369-413). The reference runs the float
     model in the LiteRT interpreter to obtain those tensors; here each sample is the
     {tensor name: ndarray} map itself, or `tensor_provider(signature_key, sample)` returns it."""
-    if not self.need_calibration():
+    if not self.need_calibration:
       return {}
     calib = calibrator.Calibrator(self.float_model, tensor_provider=tensor_provider)
     if previous_calibration_result is not None:

@@ -62,3 +62,13 @@ dynamic_wi4b64_afp32 = lambda **kw: _dynamic_wix_afp32(num_bits=4, granularity=_
 dynamic_wi4b128_afp32 = lambda **kw: _dynamic_wix_afp32(num_bits=4, granularity=_G.BLOCKWISE_128, **kw)  # noqa: E731
 dynamic_wi8c_hr_afp32 = lambda **kw: dynamic_wi8c_afp32(algorithm_key=AlgorithmName.DECOMPOSED_HADAMARD_ROTATION, **kw)  # noqa: E731
 dynamic_wi4c_hr_afp32 = lambda **kw: dynamic_wi4c_afp32(algorithm_key=AlgorithmName.DECOMPOSED_HADAMARD_ROTATION, **kw)  # noqa: E731
+
+
+def dynamic_legacy_wi8_afp32():
+  """dynamic_wi8_afp32 for models first quantized with the older TFLite tooling: only weights of
+  at least 1024 elements are quantized (ref :43-78)."""
+  return [dict(regex=".*", operation="*", algorithm_key="min_max_uniform_quantize", op_config=dict(
+      weight_tensor_config=dict(num_bits=8, symmetric=True, granularity="CHANNELWISE", dtype="INT",
+                                block_size=0),
+      compute_precision="INTEGER", explicit_dequantize=False, skip_checks=False,
+      min_weight_elements=1024))]

@@ -409,3 +409,49 @@ def test_oscar_registration_and_qsv_merge():
   assert np.array_equal(got["mu2"], want["mu2"]) and got["num_samples"] == 8
   assert got["min"] == want["min"] and got["max"] == want["max"]
   assert qsv_utils.oscar_and_moving_average_update(None, b) is b
+
+
+def test_quantizer_recipe_editing_api_and_policy_file(tmp_path):
+  """Quantizer's recipe-editing methods (ref quantizer.py:207-352) and a user policy .json."""
+  import json as _json
+  from mi355q import default_policy, quantizer
+  model_path = str(tmp_path / "m.tflite")
+  from mi355q.utils import tflite_flatbuffer as fb
+  open(model_path, "wb").write(fb.write_model(_fc_model_for_multiply()))
+  qz = quantizer.Quantizer(model_path)
+  assert not qz.need_calibration and not qz.need_calibration()         # property (reference) and call
+  qz.add_dynamic_config(".*", q.TFLOperationName.FULLY_CONNECTED, num_bits=4)
+  qz.add_weight_only_config("w1", q.TFLOperationName.FULLY_CONNECTED, num_bits=8)
+  assert [r["op_config"]["compute_precision"] for r in qz.get_quantization_recipe()] == ["INTEGER", "FLOAT"]
+  qz.add_static_config(".*", q.TFLOperationName.ALL_SUPPORTED, activation_num_bits=8, weight_num_bits=8)
+  assert qz.need_calibration and qz.need_calibration() is True
+  qz.update_quantization_recipe(".*", q.TFLOperationName.FULLY_CONNECTED, algorithm_key="no_quantize")
+  assert [r["algorithm_key"] for r in qz.get_quantization_recipe() if r["operation"] == "FULLY_CONNECTED"
+          and r["regex"] == ".*"] == ["no_quantize"]
+  assert recipe.dynamic_legacy_wi8_afp32()[0]["op_config"]["min_weight_elements"] == 1024
+  # a policy file: int8 weight-only for FULLY_CONNECTED and nothing else
+  policy_json = _json.dumps({
+      "configs": {"only": {"weight_tensor_config": {"num_bits": 8, "symmetric": [True],
+                                                    "granularity": ["CHANNELWISE", "TENSORWISE"], "dtype": "INT"},
+                           "explicit_dequantize": True, "compute_precision": "FLOAT"}},
+      "ops_per_config": {"only": ["FULLY_CONNECTED"]}})
+  policy = default_policy.update_default_config_policy(policy_json)
+  fc, cfg = q.TFLOperationName.FULLY_CONNECTED, q.OpQuantizationConfig
+  ok = cfg(weight_tensor_config=q.TensorQuantizationConfig(num_bits=8, granularity=q.QuantGranularity.TENSORWISE),
+           compute_precision=q.ComputePrecision.FLOAT, explicit_dequantize=True, min_weight_elements=77)
+  default_policy.check_if_valid_op_config(fc, ok, policy)
+  with pytest.raises(ValueError, match="was not found in the policy"):
+    default_policy.check_if_valid_op_config(
+        fc, cfg(weight_tensor_config=q.TensorQuantizationConfig(num_bits=4), compute_precision=q.ComputePrecision.FLOAT,
+                explicit_dequantize=True), policy)
+  with pytest.raises(ValueError, match="No policy was specified for op"):
+    default_policy.check_if_valid_op_config(q.TFLOperationName.CONV_2D, ok, policy)
+  path = tmp_path / "policy.json"
+  path.write_text(policy_json)
+  try:
+    qz.load_config_policy(str(path))
+    with pytest.raises(ValueError, match="was not found in the policy"):
+      am.check_op_quantization_config("min_max_uniform_quantize", fc, cfg(
+          weight_tensor_config=q.TensorQuantizationConfig(num_bits=4), compute_precision=q.ComputePrecision.INTEGER))
+  finally:
+    am.register_config_check_policy_func("min_max_uniform_quantize", default_policy.DEFAULT_CONFIG_CHECK_POLICY)
