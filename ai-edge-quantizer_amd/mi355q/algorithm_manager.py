@@ -4,8 +4,10 @@ Same surface as ref: algorithm_manager.py:43-75 (singleton + re-exported bound
 methods + AlgorithmName) and the same registration pattern
 (ref :150-164, 310-320, 365-383, 406-419, 437-451):
 `functools.partial(materialize_fn, <alg>.get_tensor_quant_params)`.
-Registered here: the weight-bearing ops of the hot path (FULLY_CONNECTED, CONV_2D,
-DEPTHWISE_CONV_2D, EMBEDDING_LOOKUP) plus the virtual INPUT / OUTPUT ops.
+Registered here, as there: the 50-op tables of min/max and OCTAV (the weight-bearing ops, the
+virtual INPUT / OUTPUT ops and every activation-only op that static recipes quantize), MSE,
+GPTQ, both Hadamard forms, OSCAR, float_casting and dequantized_weight_recovery -- all ten
+algorithm keys, GPU backed.
 """
 from __future__ import annotations
 

@@ -1,9 +1,9 @@
-"""Statistics collection and FC / conv / embedding materializers, GPU backed.
+"""Statistics collection and the op materializers, GPU backed.
 
-Mirror of the hot-path tail of the reference's common_quantize.py
-(ref: algorithms/uniform_quantize/common_quantize.py:1311-1495) plus the three
-materializers the registry binds for weight-bearing ops (ref :251-266, :306-396,
-:519-576). Min / max reductions run in libmi355q (K1, K7).
+Mirror of the reference's common_quantize.py (ref: algorithms/uniform_quantize/common_quantize.py):
+the hot-path tail (:1311-1495: min/max of weights and activations, K1 / K7 in libmi355q), the
+materializers of the weight-bearing ops (:251-266, :306-396, :519-636) and, from one rule table,
+those of the activation-only ops (:127-304, :416-516, :639-1201).
 """
 from __future__ import annotations
 
