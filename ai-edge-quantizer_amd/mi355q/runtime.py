@@ -128,6 +128,24 @@ class HbmArray:
   def __repr__(self):
     return f"HbmArray(shape={self.shape}, dtype={self.dtype})"
 
+  def __reduce__(self):
+    # crosses process boundaries (gather of sharded results) as host data
+    return (_host_carrier, (self.numpy(), None if self.packed is None else np.asarray(self.packed)))
+
+
+class HostCarrier(np.ndarray):
+  """What an HbmArray unpickles to: a plain ndarray (+ the packed bytes that rode along)."""
+  packed = None
+
+  def __array_finalize__(self, obj):
+    self.packed = None
+
+
+def _host_carrier(values: np.ndarray, packed):
+  out = values.view(HostCarrier)
+  out.packed = packed
+  return out
+
 
 def _host_operator(name):
   def op(self, other):

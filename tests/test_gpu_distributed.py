@@ -26,10 +26,43 @@ def _recipe(key, bits, gran):
       compute_precision="INTEGER", explicit_dequantize=False, skip_checks=False, min_weight_elements=0))]
 
 
+def _big_fc_model(path):
+  """Two FULLY_CONNECTED layers of 8 MiB each: their quantized weights stay in HBM on the rank
+  that made them and cross to rank 0 as host data."""
+  import numpy as np
+  from mi355q import qtyping as q
+  from mi355q.utils import tflite_flatbuffer as fb
+  rng = np.random.default_rng(5)
+  model = q.ModelT(version=3)
+  model.buffers = [q.BufferT()]
+  sg = q.SubGraphT(name=b"main", inputs=[0], outputs=[4], tensors=[q.TensorT(name=b"x", shape=[1, 1024], buffer=0)], operators=[])
+  for i in range(2):
+    w = rng.standard_normal((2048 if i == 0 else 1024, 1024 if i == 0 else 2048)).astype(np.float32)
+    model.buffers.append(q.BufferT(data=w.reshape(-1).view(np.uint8)))
+    sg.tensors.append(q.TensorT(name=f"w{i}".encode(), shape=list(w.shape), buffer=len(model.buffers) - 1))
+    sg.tensors.append(q.TensorT(name=f"y{i}".encode(), shape=[1, w.shape[0]], buffer=0))
+    sg.operators.append(q.OperatorT(inputs=[2 * i, 2 * i + 1, -1], outputs=[2 * i + 2], builtinOptionsType=8,
+                                    builtinOptions=q.FullyConnectedOptionsT()))
+  model.operatorCodes = [q.OperatorCodeT(builtinCode=9, deprecatedBuiltinCode=9)]
+  model.subgraphs = [sg]
+  open(path, "wb").write(fb.write_model(model))
+
+
 def _worker(rank, world, port, out):
   dist = _setup(rank, world, port)
   from mi355q import distributed as D, quantizer
   got = []
+  big = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mi355q_big_fc_{port}.tflite")
+  if rank == 0:
+    _big_fc_model(big)
+  dist.barrier()
+  for key, bits, gran in (("min_max_uniform_quantize", 4, "BLOCKWISE_128"), ("min_max_uniform_quantize", 8, "CHANNELWISE")):
+    sharded = D.quantize_model_sharded(big, _recipe(key, bits, gran))
+    single = bytes(quantizer.Quantizer(big, _recipe(key, bits, gran)).quantize().quantized_model) if rank == 0 else None
+    got.append((None if sharded is None else bytes(sharded), single))
+  dist.barrier()
+  if rank == 0:
+    os.remove(big)
   for name, key, bits, gran in _CASES:
     path = os.path.join(ROOT, "tests", "golden", "models", name)
     sharded = D.quantize_model_sharded(path, _recipe(key, bits, gran))
@@ -42,8 +75,8 @@ def _worker(rank, world, port, out):
 
 def test_two_ranks_quantize_model_files_like_one():
   (r0, got0), (r1, got1) = _run(_worker, timeout=600)
-  assert len(got0) == len(_CASES)
-  for case, (sharded, single), (other, _) in zip(_CASES, got0, got1):
+  assert len(got0) == len(_CASES) + 2
+  for case, (sharded, single), (other, _) in zip([("big", 4), ("big", 8)] + _CASES, got0, got1):
     assert other is None and sharded is not None, case
     assert sharded == single, case
 
