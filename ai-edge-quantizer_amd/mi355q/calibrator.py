@@ -52,6 +52,7 @@ class Calibrator:
     self._tensor_content_map: dict[str, Any] = {}
     self._model_qsvs: dict[str, qtyping.QSV] = {}
     self._metadata: dict[str, Any] = {"num_samples_calibrated": 0}
+    self._recording: Optional[list] = None     # record_step(): events instead of merges
 
   # ---- signatures ---------------------------------------------------------------------------
   def get_signature_list(self) -> list[str]:
@@ -150,9 +151,41 @@ class Calibrator:
     for _, graph_info, op, op_key, alg in self._ops_to_calibrate(signature_key, model_recipe_manager):
       calibrate = algorithm_manager.get_quantization_func(alg, op_key, qtyping.QuantizeMode.CALIBRATE)
       op_qsvs = calibrate(op, graph_info, self._tensor_content_map)
+      if self._recording is not None:
+        # sample-sharded calibration: keep this sample's statistics as events; another process
+        # replays all samples' events in dataset order (distributed.calibrate_sharded)
+        for name, qsv in op_qsvs.items():
+          if name not in updated:
+            self._recording.append((name, str(getattr(alg, "value", alg)), str(getattr(op_key, "value", op_key)), qsv))
+            updated.add(name)
+        continue
       update = (self._qsv_update_func if self._is_custom_qsv_update_func
                 else algorithm_manager.get_update_qsv_func(alg, op_key))
       updated |= self._update_qsvs(op_qsvs, updated, update)
+
+  def record_step(self, signature_key: Optional[str], data: Any,
+                  model_recipe_manager: recipe_manager.RecipeManager) -> list[tuple]:
+    """One calibration step whose per-tensor statistics are returned as
+    (tensor name, algorithm, op, qsv) events instead of being merged into the model QSVs."""
+    self._recording = []
+    try:
+      self._calibrate_step(signature_key, data, model_recipe_manager)
+      return self._recording
+    finally:
+      self._recording = None
+
+  def replay(self, steps: Iterable[list[tuple]]) -> None:
+    """Merges recorded steps, in the order given, exactly as calibrating those samples here would
+    have (first sighting of a tensor sets its QSV, later ones go through the op's update rule)."""
+    for events in steps:
+      self._metadata["num_samples_calibrated"] += 1
+      for name, alg, op_key, qsv in events:
+        if name not in self._model_qsvs:
+          self._model_qsvs[name] = qsv
+          continue
+        update = (self._qsv_update_func if self._is_custom_qsv_update_func
+                  else algorithm_manager.get_update_qsv_func(alg, qtyping.TFLOperationName(op_key)))
+        self._model_qsvs[name] = update(self._model_qsvs[name], qsv)
 
   # ---- public API (ref :312-392) -----------------------------------------------------------------
   def calibrate(self, calibration_dataset: Mapping[Optional[str], Iterable[Any]],

@@ -154,6 +154,82 @@ def _worker_model(rank, world, port, out):
   dist.destroy_process_group()
 
 
+def _register_oracle_calibration():
+  """min/max calibration through the oracle (the product function needs a GPU)."""
+  from mi355q import algorithm_manager as am
+  from mi355q.algorithms.uniform_quantize import common_quantize, naive_min_max_quantize
+  from mi355q.utils import tfl_flatbuffer_utils as fu
+  from oracle import aeq_oracle as O
+
+  def calibrate(tfl_op, graph_info, tensor_content_map, inputs_to_ignore=None, outputs_to_ignore=None,
+                valid_range=(-3e38, 3e38)):
+    out = {}
+    for tid in common_quantize.get_tensor_indices_requiring_calibration(tfl_op, graph_info, inputs_to_ignore,
+                                                                        outputs_to_ignore):
+      tensor = graph_info.subgraph_tensors[tid]
+      if fu.get_tensor_data(tensor, graph_info.buffers) is not None:
+        continue
+      name = fu.get_tensor_name(tensor)
+      x = tensor_content_map[name]
+      qsv = O.activation_min_max(x, *valid_range)
+      qsv["num_samples"] = np.array(x.shape[0] if x.ndim > 0 else 1)
+      out[name] = qsv
+    return out
+  key = am.AlgorithmName.MIN_MAX_UNIFORM_QUANT.value
+  for op in am.get_supported_ops(key):
+    am.register_quantized_op(key, op, naive_min_max_quantize.init_qsvs, calibration_func=calibrate,
+                             materialize_func=lambda *a, **k: [])
+  return calibrate
+
+
+def _calibration_samples(n=9):
+  rng = np.random.default_rng(123)
+  return [{"x": (rng.standard_normal((1, 8)) * (1 + s)).astype(np.float32),
+           "y": (rng.standard_normal((1, 4)) * (2 + s)).astype(np.float32)} for s in range(n)]
+
+
+def _tiny_fc(path):
+  from mi355q import qtyping as q
+  from mi355q.utils import tflite_flatbuffer as fb
+  w = np.arange(32, dtype=np.float32).reshape(4, 8) / 7
+  model = q.ModelT(version=3, buffers=[q.BufferT(), q.BufferT(data=w.reshape(-1).view(np.uint8))],
+                   operatorCodes=[q.OperatorCodeT(builtinCode=9, deprecatedBuiltinCode=9)])
+  sg = q.SubGraphT(name=b"main", inputs=[0], outputs=[2],
+                   tensors=[q.TensorT(name=b"x", shape=[1, 8], buffer=0), q.TensorT(name=b"w", shape=[4, 8], buffer=1),
+                            q.TensorT(name=b"y", shape=[1, 4], buffer=0)],
+                   operators=[q.OperatorT(inputs=[0, 1, -1], outputs=[2], builtinOptionsType=8,
+                                          builtinOptions=q.FullyConnectedOptionsT())])
+  model.subgraphs = [sg]
+  model.signatureDefs = [q.SignatureDefT(signatureKey=b"serving_default", subgraphIndex=0,
+                                         inputs=[q.TensorMapT(name=b"x", tensorIndex=0)],
+                                         outputs=[q.TensorMapT(name=b"y", tensorIndex=2)])]
+  open(path, "wb").write(fb.write_model(model))
+
+
+def _worker_calibrate_model(rank, world, port, out):
+  dist = _setup(rank, world, port)
+  from mi355q import calibrator, distributed as D, recipe, recipe_manager
+  from mi355q.utils import tfl_flatbuffer_utils as fu
+  _register_oracle_calibration()
+  calibrator.Calibrator._stage_sample = lambda *a, **k: None      # HBM staging needs a GPU; test process only
+  path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mi355q_tiny_fc_{port}_{rank}.tflite")
+  _tiny_fc(path)
+  data = {"serving_default": _calibration_samples()}
+  rcp = recipe.static_wi8_ai8()
+  got = D.calibrate_sharded(path, rcp, data)
+  rm = recipe_manager.RecipeManager()
+  rm.load_quantization_recipe(rcp)
+  single = calibrator.Calibrator(fu.read_model(path))
+  single.calibrate(data, rm)
+  want = single.get_model_qsvs()
+  os.remove(path)
+  same = set(got) == set(want) and all(
+      np.array_equal(got[n][k], want[n][k]) for n in want for k in ("min", "max") if k in want[n])
+  out.put((rank, same, sorted(got), float(np.ravel(got["x"]["max"])[0])))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
 def _run(worker, world=2, timeout=300):
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
@@ -248,3 +324,9 @@ def test_model_level_sharded_quantize_equals_single_process():
   (r0, got0), (r1, got1) = _run(_worker_model)
   for (sharded, single), (other, _) in zip(got0, got1):
     assert other is None and sharded is not None and sharded == single
+
+
+def test_model_level_sample_sharded_calibration_equals_single_process():
+  (r0, same0, names0, x0), (r1, same1, names1, x1) = _run(_worker_calibrate_model)
+  assert same0 and same1 and names0 == names1 and x0 == x1
+  assert "x" in names0 and "y" in names0

@@ -110,3 +110,42 @@ def _worker_rccl_single(rank, world, port, out):
 def test_collectives_over_rccl_world_of_one():
   (_, ok), = _run(_worker_rccl_single, world=1, timeout=600)
   assert ok
+
+
+def _worker_calibrate(rank, world, port, out):
+  dist = _setup(rank, world, port)
+  import numpy as np
+  from mi355q import calibrator, distributed as D, recipe, recipe_manager
+  from mi355q.utils import tfl_flatbuffer_utils as fu
+  from test_distributed_gloo import _tiny_fc
+  path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mi355q_tiny_fc_{port}_{rank}.tflite")
+  _tiny_fc(path)
+  rng = np.random.default_rng(31)
+  data = {"serving_default": [{"x": (rng.standard_normal((1 + s % 3, 8)) * (1 + s)).astype(np.float32),
+                               "y": (rng.standard_normal((1 + s % 3, 4)) * 3).astype(np.float32)} for s in range(11)]}
+  oscar_static = [dict(regex=".*", operation="FULLY_CONNECTED", algorithm_key="OSCAR", op_config=dict(
+      activation_tensor_config=dict(num_bits=8, symmetric=False, granularity="TENSORWISE", dtype="INT"),
+      weight_tensor_config=dict(num_bits=8, symmetric=True, granularity="CHANNELWISE", dtype="INT"),
+      compute_precision="INTEGER", explicit_dequantize=False, skip_checks=False, min_weight_elements=0))]
+  ok = True
+  for rcp, keys in ((recipe.static_wi8_ai8(), ("min", "max")), (oscar_static, ("min", "max", "mu2", "num_samples"))):
+    got = D.calibrate_sharded(path, rcp, data)
+    rm = recipe_manager.RecipeManager()
+    rm.load_quantization_recipe(rcp)
+    single = calibrator.Calibrator(fu.read_model(path))
+    single.calibrate(data, rm)
+    want = single.get_model_qsvs()
+    ok &= set(got) == set(want) and all(np.array_equal(np.asarray(got[n][k]), np.asarray(want[n][k]))
+                                       for n in want for k in keys if k in want[n])
+    ok &= all(k in got["x"] for k in keys)
+  os.remove(path)
+  out.put((rank, bool(ok)))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_ranks_calibrate_like_one():
+  """Samples sharded over two ranks, events gathered and replayed: the QSVs (moving-average
+  min/max; OSCAR's sample-weighted mu2) equal the single-process ones bit for bit."""
+  (r0, ok0), (r1, ok1) = _run(_worker_calibrate, timeout=600)
+  assert ok0 and ok1
