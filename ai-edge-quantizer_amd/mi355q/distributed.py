@@ -43,9 +43,12 @@ def init(backend: Optional[str] = None) -> tuple[int, int]:
   if not dist.is_initialized():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     use_gpu = torch.cuda.is_available()
+    # MI355Q_DIST_BACKEND=gloo: several ranks on a box with fewer GPUs (tests): they share devices
+    backend = backend or os.environ.get("MI355Q_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
     if use_gpu:
-      torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"))
+      local = int(os.environ.get("LOCAL_RANK", "0"))
+      torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
+    dist.init_process_group(backend)
   return rank, world
 
 
