@@ -182,16 +182,17 @@ template <typename ScaleT, typename OutT>
 __global__ __launch_bounds__(256) void quantize_kernel(
     const float* __restrict__ x, int64_t n, int64_t channels, int64_t inner,
     const ScaleT* __restrict__ scale, const int32_t* __restrict__ zp, int zp_via_f64,
-    float lo, float hi, OutT* __restrict__ q) {
+    double lo64, double hi64, OutT* __restrict__ q) {
+  const float lo = static_cast<float>(lo64), hi = static_cast<float>(hi64);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
     const int64_t c = channels == 1 ? 0 : (e / inner) % channels;
     const int z = zp ? zp[c] : 0;
     if constexpr (sizeof(ScaleT) == 8) {
-      // float64 scale: NumPy promotes the whole chain to float64
+      // float64 scale: NumPy promotes the whole chain to float64 (bounds exact up to 32 bits)
       double v = static_cast<double>(x[e]) / scale[c] + static_cast<double>(z);
       double r = __builtin_rint(v);
-      r = fmin(fmax(r, static_cast<double>(lo)), static_cast<double>(hi));
+      r = fmin(fmax(r, lo64), hi64);
       q[e] = sat_cast<OutT>(r, v != v);
     } else {
       float v = x[e] / scale[c];
@@ -509,7 +510,7 @@ extern "C" int32_t mi355q_minmax_f32(const float* x, int64_t outer, int64_t chan
 namespace {
 template <typename ScaleT>
 int32_t launch_quantize(const float* x, int64_t n, int64_t channels, int64_t inner,
-                        const void* scale, const int32_t* zp, int zp_via_f64, float lo, float hi,
+                        const void* scale, const int32_t* zp, int zp_via_f64, double lo, double hi,
                         int out_bits, void* q, hipStream_t st) {
   const dim3 grid(grid_for(n)), blk(256);
   const ScaleT* s = static_cast<const ScaleT*>(scale);
@@ -518,7 +519,7 @@ int32_t launch_quantize(const float* x, int64_t n, int64_t channels, int64_t inn
     if (out_bits == 8 && inner % 4 == 0 && aligned) {
       hipLaunchKernelGGL(quantize_vec4_kernel, dim3(grid_for(n / 4, 4)), blk, 0, st,
                          reinterpret_cast<const float4*>(x), n / 4, channels, inner / 4, s, zp, zp_via_f64,
-                         lo, hi, static_cast<uint32_t*>(q));
+                         static_cast<float>(lo), static_cast<float>(hi), static_cast<uint32_t*>(q));
       MI355Q_CHECK_LAUNCH("quantize launch");
       return MI355Q_OK;
     }
@@ -549,10 +550,10 @@ extern "C" int32_t mi355q_quantize_f32(const float* x, int64_t outer, int64_t ch
   // Bounds as NumPy sees them: Python floats cast to the working float type.
   const double qmax = static_cast<double>((1LL << (bits - 1)) - 1);
   const double qmin = -static_cast<double>(1LL << (bits - 1));
-  const float lo = static_cast<float>(narrow ? qmin + 1.0 : qmin);
-  const float hi = static_cast<float>(qmax);
-  if (scale_is_f64 && bits > 24)
-    return fail(MI355Q_UNSUPPORTED, "float64 scale with bits > 24 is not supported");
+  // float32 scale: the chain stays float32 and NumPy casts the bounds to float32 (2^31 - 1
+  // rounds to 2^31); float64 scale: everything, bounds included, is float64
+  const double lo = narrow ? qmin + 1.0 : qmin;
+  const double hi = qmax;
   hipStream_t st = as_stream(stream);
   return scale_is_f64
              ? launch_quantize<double>(x, n, channels, inner, scale, zero_point, zp_via_f64, lo, hi, out_bits, q_out, st)

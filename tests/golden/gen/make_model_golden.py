@@ -141,8 +141,8 @@ def describe(model, raw=False):
   return out
 
 
-def run(model_name, recipe_name, rcp, qsvs=None):
-  path = os.path.join(REF, "tests/models", model_name + ".tflite")
+def run(model_name, recipe_name, rcp, qsvs=None, path=None):
+  path = path or os.path.join(REF, "tests/models", model_name + ".tflite")
   model = to_bags(fb.read_model(open(path, "rb").read()))
   rm = recipe_manager.RecipeManager()
   rm.load_quantization_recipe(rcp)
@@ -228,7 +228,7 @@ def main():
   print("wrote", len(cases), "cases")
 
 
-if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more", "--mixed", "--fp16", "--dwr"} & set(sys.argv):
+if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more", "--mixed", "--fp16", "--dwr", "--random"} & set(sys.argv):
   main()
 
 
@@ -627,3 +627,176 @@ def dwr_model_cases():
 
 if __name__ == "__main__" and "--dwr" in sys.argv:
   dwr_model_cases()
+
+
+# ----------------------------------------------------------------------- random graphs ---
+def random_graph(seed: int, wide: bool = False):
+  """A small random float graph built with this repository's own flatbuffer classes: chains and
+  fan-outs of the ops the registry knows (unary, binary with activation or constant operand,
+  shape-preserving data movement with constant index operands, FULLY_CONNECTED with shared or
+  private weights), several graph outputs. Shapes are nominal: the quantizer never checks them."""
+  from mi355q import qtyping as q
+  B = our_schema.BuiltinOperator
+  rng = np.random.default_rng(seed)
+  model = q.ModelT(version=3, description=b"mi355q random graph")
+  model.buffers = [q.BufferT()]
+  model.operatorCodes = []
+  sg = q.SubGraphT(name=b"main", tensors=[], operators=[], inputs=[], outputs=[])
+  codes = {}
+
+  def code(op):
+    if op not in codes:
+      model.operatorCodes.append(q.OperatorCodeT(builtinCode=int(op), deprecatedBuiltinCode=min(int(op), 127)))
+      codes[op] = len(model.operatorCodes) - 1
+    return codes[op]
+
+  def act(shape=(1, 8)):
+    sg.tensors.append(q.TensorT(name=f"t{len(sg.tensors)}".encode(), shape=list(shape), type=0, buffer=0))
+    return len(sg.tensors) - 1
+
+  def const(arr, ttype=0, share=None):
+    if share is None:
+      model.buffers.append(q.BufferT(data=np.ascontiguousarray(arr).reshape(-1).view(np.uint8)))
+      share = len(model.buffers) - 1
+    sg.tensors.append(q.TensorT(name=f"c{len(sg.tensors)}".encode(), shape=list(arr.shape), type=ttype, buffer=share))
+    return len(sg.tensors) - 1, share
+
+  live = [act() for _ in range(int(rng.integers(1, 3)))]
+  sg.inputs = list(live)
+  fc_weights = []
+  unary = [B.TANH, B.LOGISTIC, B.RELU, B.GELU, B.SQRT, B.RSQRT, B.HARD_SWISH, B.SOFTMAX]
+  binary = [B.ADD, B.SUB, B.MUL, B.DIV, B.MAXIMUM, B.SQUARED_DIFFERENCE]
+  moves = [(B.RESHAPE, np.array([1, 8], np.int32)), (B.TRANSPOSE, np.array([0, 1], np.int32)),
+           (B.PAD, np.zeros((2, 2), np.int32)), (B.MEAN, np.array([1], np.int32)), (B.SUM, np.array([1], np.int32))]
+  if wide:     # the second wave of graphs draws from more op kinds (multi-output, pooling, gathers)
+    moves += [(B.SLICE, None), (B.STRIDED_SLICE, None), (B.RESIZE_BILINEAR, np.array([2, 2], np.int32)),
+              (B.RESIZE_NEAREST_NEIGHBOR, np.array([2, 2], np.int32)), (B.GATHER, np.array([0, 1], np.int32)),
+              (B.BROADCAST_TO, np.array([1, 8], np.int32)), (B.MIRROR_PAD, np.zeros((2, 2), np.int32)),
+              (B.REDUCE_MIN, np.array([1], np.int32)), (B.GATHER_ND, np.array([[0]], np.int32))]
+    unary += [B.AVERAGE_POOL_2D, B.MAX_POOL_2D, B.SPACE_TO_DEPTH]
+    binary += [B.PACK, B.EQUAL, B.NOT_EQUAL]
+  for _ in range(int(rng.integers(3, 9))):
+    kinds = ["unary", "binary", "binary_const", "move", "fc", "fc", "concat"]
+    if wide:
+      kinds += ["split", "unpack", "select", "bmm", "embedding"]
+    kind = rng.choice(kinds)
+    x = int(rng.choice(live))
+    out = act()
+    if kind == "split":        # axis constant first, two outputs
+      c, _ = const(np.array(1, np.int32), ttype=2)
+      out2 = act()
+      sg.operators.append(q.OperatorT(opcodeIndex=code(B.SPLIT), inputs=[c, x], outputs=[out, out2]))
+      live += [out, out2]
+      continue
+    if kind == "unpack":
+      out2 = act()
+      sg.operators.append(q.OperatorT(opcodeIndex=code(B.UNPACK), inputs=[x], outputs=[out, out2]))
+      live += [out, out2]
+      continue
+    if kind == "select":       # boolean condition first
+      sg.tensors.append(q.TensorT(name=f"cond{len(sg.tensors)}".encode(), shape=[1, 8], type=6, buffer=0))
+      cond = len(sg.tensors) - 1
+      sg.inputs.append(cond)
+      op = q.OperatorT(opcodeIndex=code(B.SELECT_V2 if rng.random() < 0.5 else B.SELECT),
+                       inputs=[cond, x, int(rng.choice(live))], outputs=[out])
+      sg.operators.append(op)
+      live.append(out)
+      continue
+    if kind == "bmm":
+      c, _ = const(rng.standard_normal((1, 8, 8)).astype(np.float32))
+      op = q.OperatorT(opcodeIndex=code(B.BATCH_MATMUL), inputs=[x, c], outputs=[out], builtinOptionsType=101,
+                       builtinOptions=q.BatchMatMulOptionsT(adjY=bool(rng.random() < 0.5)))
+      sg.operators.append(op)
+      live.append(out)
+      continue
+    if kind == "embedding":
+      sg.tensors.append(q.TensorT(name=f"ids{len(sg.tensors)}".encode(), shape=[1], type=2, buffer=0))
+      ids = len(sg.tensors) - 1
+      sg.inputs.append(ids)
+      c, _ = const(rng.standard_normal((16, 32)).astype(np.float32))
+      sg.operators.append(q.OperatorT(opcodeIndex=code(B.EMBEDDING_LOOKUP), inputs=[ids, c], outputs=[out]))
+      live.append(out)
+      continue
+    if kind == "unary":
+      op = q.OperatorT(opcodeIndex=code(unary[int(rng.integers(len(unary)))]), inputs=[x], outputs=[out])
+    elif kind == "binary":
+      op = q.OperatorT(opcodeIndex=code(binary[int(rng.integers(len(binary)))]), inputs=[x, int(rng.choice(live))], outputs=[out])
+    elif kind == "binary_const":
+      c, _ = const(rng.standard_normal((1, 8)).astype(np.float32))
+      op = q.OperatorT(opcodeIndex=code(binary[int(rng.integers(3))]), inputs=[x, c], outputs=[out])
+    elif kind == "move":
+      bop, arg = moves[int(rng.integers(len(moves)))]
+      if arg is None:            # SLICE (begin, size) / STRIDED_SLICE (begin, end, strides)
+        extra = [const(np.array([0, 0], np.int32), ttype=2)[0] for _ in range(2 if bop == B.SLICE else 3)]
+        op = q.OperatorT(opcodeIndex=code(bop), inputs=[x] + extra, outputs=[out])
+      else:
+        c, _ = const(arg, ttype=2)
+        op = q.OperatorT(opcodeIndex=code(bop), inputs=[x, c], outputs=[out])
+    elif kind == "concat":
+      op = q.OperatorT(opcodeIndex=code(B.CONCATENATION), inputs=[x, int(rng.choice(live))], outputs=[out])
+    else:
+      if fc_weights and rng.random() < 0.35:          # a second tensor over the same weight buffer
+        w, _ = const(fc_weights[0][1], share=fc_weights[0][0])
+      else:
+        arr = rng.standard_normal((8, 8)).astype(np.float32) * np.float32(rng.uniform(0.1, 3))
+        w, bufid = const(arr)
+        fc_weights.append((bufid, arr))
+      ins = [x, w, -1]
+      if rng.random() < 0.5:
+        ins[2], _ = const(rng.standard_normal(8).astype(np.float32))
+      op = q.OperatorT(opcodeIndex=code(B.FULLY_CONNECTED), inputs=ins, outputs=[out], builtinOptionsType=8,
+                       builtinOptions=q.FullyConnectedOptionsT())
+    sg.operators.append(op)
+    live.append(out)
+  consumed = {t for op in sg.operators for t in op.inputs}
+  sg.outputs = [t for t in live if t not in consumed and t not in sg.inputs] or [live[-1]]
+  if rng.random() < 0.4 and len(live) > 2:
+    extra = int(rng.choice(live[1:-1]))
+    if extra not in sg.outputs and extra not in sg.inputs:
+      sg.outputs.append(extra)
+  model.subgraphs = [sg]
+  model.signatureDefs = [q.SignatureDefT(
+      signatureKey=b"serving_default", subgraphIndex=0,
+      inputs=[q.TensorMapT(name=sg.tensors[t].name, tensorIndex=t) for t in sg.inputs],
+      outputs=[q.TensorMapT(name=sg.tensors[t].name, tensorIndex=t) for t in sg.outputs])]
+  return model
+
+
+def random_graph_cases(count=96):
+  from ai_edge_quantizer import recipe as ref_recipe
+  os.makedirs(os.path.join(GOLDEN, "models", "random"), exist_ok=True)
+  out = {}
+  for seed in range(count):
+    model = random_graph(7000 + seed, wide=seed >= 48)
+    name = f"random/graph_{seed:02d}"
+    path = os.path.join(GOLDEN, "models", name + ".tflite")
+    with open(path, "wb") as f:
+      f.write(fb.write_model(model))
+    parsed = to_bags(fb.read_model(open(path, "rb").read()))
+    rng = np.random.default_rng(8000 + seed)
+    qsvs = {}
+    for t in parsed.subgraphs[0].tensors:
+      if parsed.buffers[t.buffer].data is None:
+        lo, hi = sorted(rng.uniform(-6, 6, 2))
+        qsvs[t.name.decode()] = {"min": np.array([[min(lo, -0.1)]], np.float32), "max": np.array([[max(hi, 0.1)]], np.float32)}
+    seed_qsvs = {k: {"min": float(v["min"].ravel()[0]), "max": float(v["max"].ravel()[0])} for k, v in qsvs.items()}
+    for rname, rcp, needs in (("static_wi8_ai8", ref_recipe.static_wi8_ai8(), True),
+                              ("static_wi8_ai16", ref_recipe.static_wi8_ai16(), True),
+                              ("dynamic_wi8_afp32", RECIPES["dynamic_wi8_afp32"], False),
+                              ("weight_only_wi4_afp32", RECIPES["weight_only_wi4_afp32"], False)):
+      key = f"{name}/{rname}"
+      try:
+        res = run(name, rname, rcp, {k: dict(v) for k, v in qsvs.items()} if needs else None, path=path)
+        out[key] = dict(model=name, recipe=rcp, qsvs=seed_qsvs if needs else None, result=res)
+        print("ok  ", key)
+      except Exception as e:
+        out[key] = dict(model=name, recipe=rcp, qsvs=seed_qsvs if needs else None, error=type(e).__name__,
+                        message=str(e)[:300])
+        print("err ", key, type(e).__name__, str(e)[:120])
+  with open(os.path.join(GOLDEN, "ref_random_graph_cases.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_model_golden.py --random", numpy=np.__version__,
+                   cases=json.loads(json.dumps(out, default=str))), f, separators=(",", ":"), sort_keys=True)
+
+
+if __name__ == "__main__" and "--random" in sys.argv:
+  random_graph_cases()
