@@ -228,7 +228,7 @@ def main():
   print("wrote", len(cases), "cases")
 
 
-if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more", "--mixed", "--fp16", "--dwr", "--random"} & set(sys.argv):
+if __name__ == "__main__" and not {"--srq", "--insts", "--oscar", "--srq-all", "--more", "--mixed", "--fp16", "--dwr", "--random", "--random-mixed"} & set(sys.argv):
   main()
 
 
@@ -798,5 +798,61 @@ def random_graph_cases(count=96):
                    cases=json.loads(json.dumps(out, default=str))), f, separators=(",", ":"), sort_keys=True)
 
 
-if __name__ == "__main__" and "--random" in sys.argv:
+if __name__ == "__main__" and "--random" in sys.argv[1:2]:
   random_graph_cases()
+
+
+def random_graph_mixed_cases():
+  """The second wave of random graphs under recipes that mix modes by scope and by op: float
+  islands inside static graphs, weight-only FULLY_CONNECTED next to static elementwise ops."""
+  from ai_edge_quantizer import recipe as ref_recipe
+  def act(bits, sym):
+    return dict(num_bits=bits, symmetric=sym, granularity="TENSORWISE", dtype="INT")
+  def w(bits, gran="CHANNELWISE"):
+    return dict(num_bits=bits, symmetric=True, granularity=gran, dtype="INT")
+  def entry(regex, op, key, **cfg):
+    return dict(regex=regex, operation=op, algorithm_key=key, op_config=dict(
+        skip_checks=False, min_weight_elements=0, **cfg)) if cfg else dict(regex=regex, operation=op, algorithm_key=key)
+  mm = "min_max_uniform_quantize"
+  srq8 = dict(activation_tensor_config=act(8, False), weight_tensor_config=w(8), compute_precision="INTEGER",
+              explicit_dequantize=False)
+  srq16 = dict(activation_tensor_config=act(16, True), weight_tensor_config=w(8), compute_precision="INTEGER",
+               explicit_dequantize=False)
+  recipes = {
+      "static8_fc_weight_only": [entry(".*", "*", mm, **srq8),
+                                 entry(".*[02468];", "FULLY_CONNECTED", mm, weight_tensor_config=w(8),
+                                       compute_precision="FLOAT", explicit_dequantize=True)],
+      "static16_float_island": [entry(".*", "*", mm, **srq16), entry("t[3-6];", "*", "no_quantize")],
+      "dynamic4_fc_static8_elementwise": [
+          entry(".*", "FULLY_CONNECTED", mm, weight_tensor_config=w(4), compute_precision="INTEGER",
+                explicit_dequantize=False),
+          entry(".*", "ADD", mm, **srq8), entry(".*", "MUL", mm, **srq8), entry(".*", "TANH", mm, **srq8)],
+  }
+  out = {}
+  for seed in range(48, 96):
+    name = f"random/graph_{seed:02d}"
+    path = os.path.join(GOLDEN, "models", name + ".tflite")
+    parsed = to_bags(fb.read_model(open(path, "rb").read()))
+    rng = np.random.default_rng(8000 + seed)
+    qsvs = {}
+    for t in parsed.subgraphs[0].tensors:
+      if parsed.buffers[t.buffer].data is None:
+        lo, hi = sorted(rng.uniform(-6, 6, 2))
+        qsvs[t.name.decode()] = {"min": np.array([[min(lo, -0.1)]], np.float32), "max": np.array([[max(hi, 0.1)]], np.float32)}
+    seed_qsvs = {k: {"min": float(v["min"].ravel()[0]), "max": float(v["max"].ravel()[0])} for k, v in qsvs.items()}
+    for rname, rcp in recipes.items():
+      key = f"{name}/{rname}"
+      try:
+        res = run(name, rname, rcp, {k: dict(v) for k, v in qsvs.items()}, path=path)
+        out[key] = dict(model=name, recipe=rcp, qsvs=seed_qsvs, result=res)
+        print("ok  ", key)
+      except Exception as e:
+        out[key] = dict(model=name, recipe=rcp, qsvs=seed_qsvs, error=type(e).__name__, message=str(e)[:300])
+        print("err ", key, type(e).__name__, str(e)[:140])
+  with open(os.path.join(GOLDEN, "ref_random_graph_mixed_cases.json"), "w") as f:
+    json.dump(dict(generator="tests/golden/gen/make_model_golden.py --random-mixed", numpy=np.__version__,
+                   cases=json.loads(json.dumps(out, default=str))), f, separators=(",", ":"), sort_keys=True)
+
+
+if __name__ == "__main__" and "--random-mixed" in sys.argv:
+  random_graph_mixed_cases()
