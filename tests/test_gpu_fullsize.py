@@ -133,3 +133,24 @@ def test_gptq_gemma_attention_shape_against_oracle(m):
   assert np.array_equal(p.scale, ref["scale"])
   diff = np.abs(p.quantized_data.astype(np.int32) - ref["quantized_data"].astype(np.int32))
   assert diff.max() <= 1 and (diff != 0).mean() <= 2e-3
+
+
+@pytest.mark.parametrize("gran", ["CHANNELWISE", "BLOCKWISE_32"])
+def test_oscar_layer_sized_weight_against_oracle(gran):
+  """OSCAR at a layer-sized weight (2048 x 4096): 4096-element LDS sort tiles and the
+  wave-per-row scan (channelwise), rank-major sorted blocks and the lane-per-block scan
+  (blockwise), 8192-chunk pairwise sums over 2048 rows -- bit for bit against the oracle."""
+  from mi355q import qtyping as q
+  from mi355q.algorithms.uniform_quantize import oscar
+  rng = np.random.default_rng(99)
+  w = rng.standard_normal((2048, 4096)).astype(np.float32) * np.float32(0.02)
+  w[:, :64] *= 12.0
+  mu2 = np.exp(rng.normal(size=4096) * 1.5)
+  cfg = q.TensorQuantizationConfig(num_bits=4, symmetric=True, granularity=q.QuantGranularity[gran])
+  info = q.OpInfo(op=q.OperatorT(), op_name=q.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
+                  op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg))
+  res = oscar.get_tensor_quant_params(info, cfg, w, {"mu2": mu2})
+  ref = O.oscar_quant_params(w, mu2, 4, gran)
+  assert np.array_equal(res.custom_algorithm_param["multiplier"], ref["multiplier"])
+  assert res.scale.dtype == ref["scale"].dtype and np.array_equal(res.scale, ref["scale"])
+  assert np.array_equal(res.quantized_data, ref["quantized_data"])
