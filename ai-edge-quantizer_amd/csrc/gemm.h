@@ -15,7 +15,9 @@ struct GemmArgs {
   long long c_i, c_j;
   int M, N, K;
   T alpha, beta;       // C = beta*C + alpha*(A.B); beta == 0 never reads C
-  int lower_only;      // write only j <= i (square C), skip tiles above the diagonal
+  int lower_only;      // write only j <= i (square C), skip tiles above the diagonal; 1: triangular
+                       // launch grid (no empty workgroups), 3: square grid with early exit (keeps
+                       // blockIdx.x = tile column, i.e. one set of B panels per XCD's L2, for long K)
   int k_mode;          // 0: all k; 1: A(i,k) == 0 for k > i (lower-triangular A): k < i0+BM;
                        // 2: A(i,k) == 0 for k < i and B(k,j) == 0 for k < j: k >= max(i0, j0)
                        // 3: B(k,j) == 0 for k < j (lower-triangular B): k >= j0
@@ -26,9 +28,9 @@ struct GemmArgs {
 // Number of K slices launch_gemm would use for this shape (1 = no split) and the
 // workspace that needs; pass a workspace to launch_gemm to allow the split.
 template <typename T>
-int gemm_pick_splitk(int M, int N, int K);
+int gemm_pick_splitk(int M, int N, int K, bool lower_only = false);
 template <typename T>
-size_t gemm_splitk_workspace_bytes(int M, int N, int K);
+size_t gemm_splitk_workspace_bytes(int M, int N, int K, bool lower_only = false);
 
 template <typename T>
 int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws = nullptr,

@@ -516,15 +516,19 @@ int pick_mode(const T* base, long long s_m, long long s_k) {
 }  // namespace
 
 template <typename T>
-size_t gemm_splitk_workspace_bytes(int M, int N, int K) {
-  const int s = gemm_pick_splitk<T>(M, N, K);
+size_t gemm_splitk_workspace_bytes(int M, int N, int K, bool lower_only) {
+  const int s = gemm_pick_splitk<T>(M, N, K, lower_only);
   return s > 1 ? static_cast<size_t>(s) * M * N * sizeof(T) : 0;
 }
 
 template <typename T>
-int gemm_pick_splitk(int M, int N, int K) {
+int gemm_pick_splitk(int M, int N, int K, bool lower_only) {
   constexpr int BM = Tile<T>::BM;
-  const long long tiles = static_cast<long long>((M + BM - 1) / BM) * ((N + BM - 1) / BM);
+  long long tiles = static_cast<long long>((M + BM - 1) / BM) * ((N + BM - 1) / BM);
+  if (lower_only && M == N) {           // only the tiles on and below the diagonal are launched
+    const long long nt = (M + BM - 1) / BM;
+    tiles = nt * (nt + 1) / 2;
+  }
   if (tiles >= 1024 || K < 4096) return 1;
   int s = static_cast<int>((1024 + tiles - 1) / tiles);
   const int max_s = K / 1024;  // >= 1024 of K per slice
@@ -543,7 +547,7 @@ int32_t launch_with(const GemmArgs<typename TL::Elem>& g, hipStream_t st, void* 
     splitk_ws = nullptr;
   }
   if (splitk_ws != nullptr && g.k_mode == 0) {
-    slices = gemm_pick_splitk<T>(g.M, g.N, g.K);
+    slices = gemm_pick_splitk<T>(g.M, g.N, g.K, g.lower_only != 0);
     if (static_cast<size_t>(slices) * g.M * g.N * sizeof(T) > splitk_ws_bytes) slices = 1;
   }
   const dim3 grid(static_cast<unsigned>((g.N + BM - 1) / BM), static_cast<unsigned>((g.M + BM - 1) / BM),
@@ -565,7 +569,7 @@ int32_t launch_with(const GemmArgs<typename TL::Elem>& g, hipStream_t st, void* 
     T* part = slices > 1 ? static_cast<T*>(splitk_ws) : nullptr;
     GemmArgs<T> h = g;
     dim3 fgrid = grid;
-    if (g.lower_only && g.M == g.N) {
+    if (g.lower_only == 1 && g.M == g.N) {
       const unsigned nt = grid.y;
       h.lower_only = 2;
       fgrid = dim3(nt * (nt + 1) / 2, 1, grid.z);
@@ -617,7 +621,7 @@ int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_
     // the 128x128 tile pays when there are enough of them to fill the chip; k_mode offsets are
     // multiples of the block edge either way
     const long long tiles128 = static_cast<long long>((g.M + 127) / 128) * ((g.N + 127) / 128);
-    const bool splitk = splitk_ws != nullptr && g.k_mode == 0 && gemm_pick_splitk<T>(g.M, g.N, g.K) > 1;
+    const bool splitk = splitk_ws != nullptr && g.k_mode == 0 && gemm_pick_splitk<T>(g.M, g.N, g.K, g.lower_only != 0) > 1;
     const bool whole128 = g.M % 128 == 0 && g.N % 128 == 0 && g.K % 16 == 0 && a_mode != kGeneric &&
                           b_mode != kGeneric;
 #ifndef MI355Q_BIG_MIN_TRI_TILES
@@ -635,10 +639,10 @@ int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_
 
 template int32_t launch_gemm<float>(const GemmArgs<float>&, hipStream_t, void*, size_t);
 template int32_t launch_gemm<double>(const GemmArgs<double>&, hipStream_t, void*, size_t);
-template int gemm_pick_splitk<float>(int, int, int);
-template int gemm_pick_splitk<double>(int, int, int);
-template size_t gemm_splitk_workspace_bytes<float>(int, int, int);
-template size_t gemm_splitk_workspace_bytes<double>(int, int, int);
+template int gemm_pick_splitk<float>(int, int, int, bool);
+template int gemm_pick_splitk<double>(int, int, int, bool);
+template size_t gemm_splitk_workspace_bytes<float>(int, int, int, bool);
+template size_t gemm_splitk_workspace_bytes<double>(int, int, int, bool);
 
 }  // namespace mi355q
 

@@ -26,6 +26,29 @@ __global__ __launch_bounds__(256) void scale_to_f64_kernel(const float* __restri
     h[i] = alpha * static_cast<double>(p[i]);
 }
 
+// H = alpha * P for a symmetric P of which only the lower triangle (j <= i) was computed:
+// 32 x 32 tiles, the upper ones read their mirror tile through LDS (coalesced both ways).
+__global__ __launch_bounds__(256) void mirror_scale_to_f64_kernel(const float* __restrict__ p, int d,
+                                                                 double alpha, double* __restrict__ h) {
+  __shared__ float tile[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const bool upper = bj > bi;
+  const int si = upper ? bj : bi, sj = upper ? bi : bj;         // source tile (lower triangle)
+  for (int r = ty; r < 32; r += 8) {
+    const int i = si * 32 + r, j = sj * 32 + tx;
+    float v = 0.0f;
+    if (i < d && j < d) v = p[static_cast<long long>(i >= j ? i : j) * d + (i >= j ? j : i)];
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    if (i < d && j < d)
+      h[static_cast<long long>(i) * d + j] = alpha * static_cast<double>(upper ? tile[tx][r] : tile[r][tx]);
+  }
+}
+
 // (h0*n0 + h1*n1) / (n0+n1) in FP64, as NumPy evaluates it.
 __global__ __launch_bounds__(256) void hessian_merge_kernel(const double* __restrict__ h0, double n0,
                                                            const double* __restrict__ h1, double n1,
@@ -397,7 +420,7 @@ using namespace mi355q;
 extern "C" size_t mi355q_gptq_xtx_workspace_bytes(int64_t n, int64_t d) {
   if (d <= 0 || d > 0x7FFFFFFF || n > 0x7FFFFFFF) return 0;
   return static_cast<size_t>(d) * d * sizeof(float) +
-         gemm_splitk_workspace_bytes<float>(static_cast<int>(d), static_cast<int>(d), static_cast<int>(n < 0 ? 0 : n));
+         gemm_splitk_workspace_bytes<float>(static_cast<int>(d), static_cast<int>(d), static_cast<int>(n < 0 ? 0 : n), true);
 }
 
 extern "C" int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, double alpha,
@@ -414,12 +437,15 @@ extern "C" int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, dou
   hipStream_t st = as_stream(stream);
   float* p = static_cast<float*>(workspace);
   float* split_ws = p + d * d;
-  // P = X^T X : A(i,k) = X[k][i], B(k,j) = X[k][j]; long K is split over gridDim.z
+  // P = X^T X : A(i,k) = X[k][i], B(k,j) = X[k][j]; long K is split over gridDim.z. P is
+  // symmetric and P[i][j], P[j][i] are the same k-ordered sum of the same (commuting) products,
+  // so only the lower triangle is computed (triangular launch grid: half the flops) and mirrored.
   GemmArgs<float> g{x, 1, d, x, d, 1, p, d, 1, static_cast<int>(d), static_cast<int>(d),
-                    static_cast<int>(n), 1.0f, 0.0f, 0, 0};
+                    static_cast<int>(n), 1.0f, 0.0f, 1, 0};
   if (int32_t s = launch_gemm<float>(g, st, split_ws, need - static_cast<size_t>(d) * d * sizeof(float))) return s;
-  hipLaunchKernelGGL(scale_to_f64_kernel, dim3(grid1d(d * d)), dim3(256), 0, st, p,
-                     static_cast<long long>(d) * d, alpha, hessian_out);
+  const unsigned t32 = static_cast<unsigned>((d + 31) / 32);
+  hipLaunchKernelGGL(mirror_scale_to_f64_kernel, dim3(t32, t32), dim3(256), 0, st, p, static_cast<int>(d),
+                     alpha, hessian_out);
   MI355Q_CHECK_LAUNCH("hessian scale launch");
   return MI355Q_OK;
 }

@@ -107,9 +107,12 @@ def main():
     ntok = 65536 if d == 2048 else 16384
     x = torch.randn((ntok, d), generator=gen, device="cuda")
     ms = timed(lambda: ops.gptq_xtx(x, 2.0 / 128), 5 if d == 2048 else 2, warm=1)
-    flops = 2.0 * ntok * d * d
-    emit(op="gptq_hessian xtx (f32 MFMA)", d=d, tokens=ntok, ms=round(ms, 3),
-         TFLOPs=round(flops / ms / 1e9, 2), mfma_f32_peak=157.3)
+    flops = 2.0 * ntok * d * d            # of the full product; only the tiles on / below the
+    nt = d // 128                          # diagonal are computed (symmetric result, mirrored)
+    done = flops * (nt + 1) / (2 * nt)
+    emit(op="gptq_hessian xtx (f32 MFMA, lower triangle + mirror)", d=d, tokens=ntok, ms=round(ms, 3),
+         TFLOPs_executed=round(done / ms / 1e9, 2), TFLOPs_of_full_product=round(flops / ms / 1e9, 2),
+         mfma_f32_peak=157.3)
     h = ops.gptq_xtx(x, 2.0 / 128)
     del x
     ms = timed(lambda: ops.gptq_hinv(h), 3 if d == 2048 else 1, warm=1)
