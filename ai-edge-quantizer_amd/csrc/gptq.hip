@@ -19,13 +19,6 @@ namespace {
 constexpr int NB = 64;  // Cholesky / TRTRI block size and the reference's GPTQ blocksize
 
 // ------------------------------------------------------------ Hessian ----
-__global__ __launch_bounds__(256) void scale_to_f64_kernel(const float* __restrict__ p, long long n,
-                                                          double alpha, double* __restrict__ h) {
-  const long long stride = static_cast<long long>(gridDim.x) * 256;
-  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride)
-    h[i] = alpha * static_cast<double>(p[i]);
-}
-
 // H = alpha * P for a symmetric P of which only the lower triangle (j <= i) was computed:
 // 32 x 32 tiles, the upper ones read their mirror tile through LDS (coalesced both ways).
 __global__ __launch_bounds__(256) void mirror_scale_to_f64_kernel(const float* __restrict__ p, int d,
