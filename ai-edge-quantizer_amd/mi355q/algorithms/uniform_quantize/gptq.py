@@ -127,7 +127,8 @@ def _apply_gptq(tensor_content: np.ndarray, quant_params: qtyping.UniformQuantPa
                      quant_params.num_bits, narrow, zp.dtype.itemsize >= 4, diff_bits)
   if int(info.item()) != 0:
     raise np.linalg.LinAlgError("Matrix is not positive definite")
-  return dataclasses.replace(quant_params, quantized_data=rt.to_numpy(q))
+  return dataclasses.replace(quant_params, quantized_data=rt.quantized_result(
+      q, quant_params.num_bits, tensor_content.nbytes, tensor_content.shape))
 
 
 def get_tensor_quant_params(

@@ -69,4 +69,4 @@ def get_tensor_quant_params(
   return qtyping.UniformQuantParams(
       scale=scale, zero_point=np.zeros(scale.shape, np.int32), num_bits=cfg.num_bits,
       symmetric=cfg.symmetric, quantized_dimension=quantized_dim, block_size=0,
-      quantized_data=rt.to_numpy(q).reshape(tensor_content.shape))
+      quantized_data=rt.quantized_result(q, cfg.num_bits, tensor_content.nbytes, tensor_content.shape))

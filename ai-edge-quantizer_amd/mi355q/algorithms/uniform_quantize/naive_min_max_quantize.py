@@ -48,7 +48,6 @@ def fused_weight_layout(tensor_content: np.ndarray, granularity, quantized_dim):
   return None
 
 
-_KEEP_IN_HBM_BYTES = 4 << 20
 
 
 def fused_symmetric_requant(tensor_content: np.ndarray, layout, num_bits: int,
@@ -67,7 +66,7 @@ def fused_symmetric_requant(tensor_content: np.ndarray, layout, num_bits: int,
   sub_byte = (num_bits in (2, 4) and cols % 4 == 0
               and (block in (32, 64, 128, 256) or (block == 0 and cols <= 16384)))
   r = ops.requant_sym(x, block, num_bits, clip=c, want_q=True, want_packed=sub_byte)
-  if tensor_content.nbytes >= _KEEP_IN_HBM_BYTES:
+  if tensor_content.nbytes >= rt.KEEP_IN_HBM_BYTES:
     # large weights stay in HBM until the model writer copies them (packed bytes for sub-byte
     # types) straight into the output file's mapping; NumPy consumers get a host copy on demand
     q = rt.HbmArray(r["q"].reshape(tensor_content.shape))

@@ -275,7 +275,7 @@ def _compute_oscar_weight_quant_params(op_info: qtyping.OpInfo,
       scale=scale, zero_point=zp, num_bits=cfg.num_bits, symmetric=cfg.symmetric,
       quantized_dimension=quantized_dim, block_size=block_size,
       custom_algorithm_param={"multiplier": (1.0 / s).astype(np.float32)},
-      quantized_data=rt.to_numpy(q))
+      quantized_data=rt.quantized_result(q, cfg.num_bits, w.nbytes, w.shape))
 
 
 def get_tensor_quant_params(op_info: qtyping.OpInfo, tensor_quant_config: qtyping.TensorQuantizationConfig,

@@ -133,6 +133,25 @@ class HbmArray:
     return (_host_carrier, (self.numpy(), None if self.packed is None else np.asarray(self.packed)))
 
 
+KEEP_IN_HBM_BYTES = 4 << 20     # quantized weights of float tensors this large stay in HBM
+
+
+def quantized_result(q: torch.Tensor, num_bits: int, source_nbytes: int, shape=None):
+  """What a weight algorithm hands back as `quantized_data`: a host ndarray for ordinary
+  tensors; for large ones the device tensor itself (HbmArray, with the packed bytes of sub-byte
+  types made by one more launch), so that the model writer copies it straight into the output
+  file and NumPy consumers still get a host copy on demand."""
+  if shape is not None:
+    q = q.reshape(shape)
+  if source_nbytes < KEEP_IN_HBM_BYTES:
+    return to_numpy(q)
+  out = HbmArray(q)
+  if num_bits in (2, 4):
+    from . import ops
+    out.packed = HbmArray(ops.pack_bits(q, num_bits))
+  return out
+
+
 class HostCarrier(np.ndarray):
   """What an HbmArray unpickles to: a plain ndarray (+ the packed bytes that rode along)."""
   packed = None

@@ -72,14 +72,19 @@ def main():
         cfg = qtyping.TensorQuantizationConfig(num_bits=4, symmetric=True, granularity=qtyping.QuantGranularity[gran])
         info = qtyping.OpInfo(op=qtyping.OperatorT(), op_name=qtyping.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
                               op_quant_config=qtyping.OpQuantizationConfig(weight_tensor_config=cfg))
-        best = None
+        best = best_host = None
         for _ in range(4):          # the first calls grow the caching allocator (GiB-sized workspaces)
           t = time.perf_counter()
-          oscar.get_tensor_quant_params(info, cfg, wh, {"mu2": mu2})
+          res = oscar.get_tensor_quant_params(info, cfg, wh, {"mu2": mu2})
+          torch.cuda.synchronize()
           dt = time.perf_counter() - t
+          np.asarray(res.quantized_data)          # large results stay in HBM until somebody asks
+          dt_host = time.perf_counter() - t
           best = dt if best is None else min(best, dt)
+          best_host = dt_host if best_host is None else min(best_host, dt_host)
         print(json.dumps(dict(stage="api_get_tensor_quant_params", shape=shape, granularity=gran,
-                              seconds=round(best, 4))), flush=True)
+                              seconds=round(best, 4), seconds_with_int8_copied_to_host=round(best_host, 4))),
+              flush=True)
 
 
 if __name__ == "__main__":
