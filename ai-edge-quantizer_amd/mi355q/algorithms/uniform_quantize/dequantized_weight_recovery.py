@@ -40,8 +40,9 @@ def get_blockwise_shape(shape, quantized_dimension: int, block_size: int) -> tup
 
 def get_zp_scale_from_dequantized_symmetric_weights(
     dequant_vals: np.ndarray, quantized_dimension: Optional[int] = None, block_size: int = 0,
-    min_scale: float = 1e-9) -> tuple[np.ndarray, np.ndarray]:
-  """(zero points, scales) of symmetric fake-quantized weights (ref :118-186)."""
+    min_scale: float = 1e-9, resident=None) -> tuple[np.ndarray, np.ndarray]:
+  """(zero points, scales) of symmetric fake-quantized weights (ref :118-186). `resident` is
+  `dequant_vals` already in HBM (the caller uploads a weight once for all three kernels)."""
   if quantized_dimension not in (0, 1, None):
     raise ValueError(f"quantized_dimension must be 0, 1, or None. Got {quantized_dimension}")
   if min_scale != 1e-9:
@@ -51,7 +52,8 @@ def get_zp_scale_from_dequantized_symmetric_weights(
   if vals.dtype != np.float32:
     raise TypeError(f"dequantized weight recovery expects float32 weights, got {vals.dtype}")
   last = vals.shape[-1] if vals.ndim else 1
-  flat = rt.to_device(vals).reshape(-1, last)
+  dev = resident if resident is not None else rt.to_device(vals)
+  flat = dev.reshape(-1, last)
   if quantized_dimension is None:       # one group, float64 arithmetic (np.append(arr, 0) promotes)
     scale = rt.to_numpy(ops.dwr_scales(flat, vals.size, rounded=False)).reshape(1, 1)
   elif block_size > 0:
@@ -64,7 +66,7 @@ def get_zp_scale_from_dequantized_symmetric_weights(
       raise NotImplementedError("GPU path: channelwise groups along axis 0 only")
     rows = vals.shape[0]
     shape = (rows,) + (1,) * (vals.ndim - 1)
-    scale = rt.to_numpy(ops.dwr_scales(rt.to_device(vals).reshape(rows, -1), vals.size // rows,
+    scale = rt.to_numpy(ops.dwr_scales(dev.reshape(rows, -1), vals.size // rows,
                                        rounded=True)).astype(np.float32).reshape(shape)
   return np.zeros_like(scale, dtype=np.int32), scale
 
@@ -101,15 +103,24 @@ def get_tensor_quant_params(op_info: qtyping.OpInfo, tensor_quant_config: qtypin
   if not cfg.symmetric:
     raise ValueError("Only symmetric weights are supported for dequantized weight recovery.")
   quantized_dim = common_utils.get_weight_quantized_dim(op_info, tensor_content, cfg.granularity)
+  rt.require_gpu()
+  if np.asarray(tensor_content).dtype != np.float32:
+    raise TypeError(f"dequantized weight recovery expects float32 weights, got {tensor_content.dtype}")
+  resident = rt.to_device(tensor_content)
   zp, scale = get_zp_scale_from_dequantized_symmetric_weights(
-      dequant_vals=tensor_content, quantized_dimension=quantized_dim, block_size=block_size)
+      dequant_vals=tensor_content, quantized_dimension=quantized_dim, block_size=block_size,
+      resident=resident)
   params = qtyping.UniformQuantParams(scale=scale, zero_point=zp, num_bits=cfg.num_bits,
                                       symmetric=cfg.symmetric, quantized_dimension=quantized_dim,
                                       block_size=block_size)
-  q = uniform_quantize_tensor.uniform_quantize(tensor_content, params, is_blockwise_quant=blockwise)
+  q = uniform_quantize_tensor.uniform_quantize_on_device(tensor_content, params, blockwise,
+                                                         resident=resident)
+  if q is None:
+    return dataclasses.replace(params, quantized_data=uniform_quantize_tensor.uniform_quantize(
+        tensor_content, params, is_blockwise_quant=blockwise))
   if not op_info.op_quant_config.skip_checks:
     group = tensor_content.size // scale.size
-    worst = ops.dwr_max_error(rt.to_device(tensor_content).reshape(-1), rt.to_device(np.ascontiguousarray(q)).reshape(-1),
+    worst = ops.dwr_max_error(resident.reshape(-1), q.reshape(-1),
                               ops._f64_dev(scale.reshape(-1)), group)  # pylint: disable=protected-access
     if worst > 1e-4:
       base = ("Failed to recover the original quantized values from dequantized values. Max diff"
@@ -126,7 +137,8 @@ def get_tensor_quant_params(op_info: qtyping.OpInfo, tensor_quant_config: qtypin
                  " despite reasonable unique value count. Check if the weights are symmetric or if"
                  " tolerance is too tight.")
       raise RuntimeError(f"Failed to recover weights. Original error: {base}. {extra}")
-  return dataclasses.replace(params, quantized_data=q)
+  return dataclasses.replace(params, quantized_data=rt.quantized_result(
+      q, cfg.num_bits, tensor_content.nbytes, tensor_content.shape))
 
 
 def calibrate(tfl_op: Any, graph_info: qtyping.GraphInfo, tensor_content_map: dict[str, np.ndarray],

@@ -171,6 +171,18 @@ def uniform_quantize(tensor_data: np.ndarray, quantization_params: qtyping.Unifo
                      is_blockwise_quant: bool = False) -> np.ndarray:
   """q = cast(clip(rint(x / scale + zp))) on the GPU (ref :273-362)."""
   tensor_data = np.asarray(tensor_data)
+  q = uniform_quantize_on_device(tensor_data, quantization_params, is_blockwise_quant)
+  want = _get_numpy_dtype(IntType(quantization_params.num_bits, True))
+  if q is None:
+    return np.zeros(tensor_data.shape, want)
+  out = rt.to_numpy(q).reshape(tensor_data.shape)
+  return out if out.dtype == want else out.astype(want)
+
+
+def uniform_quantize_on_device(tensor_data: np.ndarray, quantization_params: qtyping.UniformQuantParams,
+                               is_blockwise_quant: bool = False, resident=None):
+  """The launch behind `uniform_quantize`: same checks, the result stays in HBM (flat device
+  tensor; None for an empty input). `resident` is `tensor_data` already uploaded as float32."""
   p = quantization_params
   block_view = None
   if is_blockwise_quant:
@@ -199,17 +211,14 @@ def uniform_quantize(tensor_data: np.ndarray, quantization_params: qtyping.Unifo
                      f" {zp.dtype}.")
   narrow = bool(p.symmetric and p.num_bits >= 8)
   if tensor_data.size == 0:
-    return np.zeros(tensor_data.shape, _get_numpy_dtype(IntType(p.num_bits, True)))
-  x = _as_f32_exact(tensor_data)
+    return None
   compute64 = np.result_type(tensor_data.dtype, scale.dtype) == np.float64
   outer, ch, inner = block_view or _channel_view(tensor_data.shape, scale.shape)
   s, z = _flat_params(scale, zp, compute64)
   rt.require_gpu()
-  q = ops.quantize(rt.to_device(x), outer, ch, inner, rt.to_device(s), rt.to_device(z),
-                   p.num_bits, narrow, zp_via_f64=zp.dtype.itemsize >= 4)
-  out = rt.to_numpy(q).reshape(tensor_data.shape)
-  want = _get_numpy_dtype(IntType(p.num_bits, True))
-  return out if out.dtype == want else out.astype(want)
+  x = resident if resident is not None else rt.to_device(_as_f32_exact(tensor_data))
+  return ops.quantize(x, outer, ch, inner, rt.to_device(s), rt.to_device(z),
+                      p.num_bits, narrow, zp_via_f64=zp.dtype.itemsize >= 4)
 
 
 def uniform_dequantize(tensor_data: np.ndarray,
