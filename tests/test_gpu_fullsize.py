@@ -154,3 +154,52 @@ def test_oscar_layer_sized_weight_against_oracle(gran):
   assert np.array_equal(res.custom_algorithm_param["multiplier"], ref["multiplier"])
   assert res.scale.dtype == ref["scale"].dtype and np.array_equal(res.scale, ref["scale"])
   assert np.array_equal(res.quantized_data, ref["quantized_data"])
+
+
+@pytest.fixture(scope="module")
+def embedding_table():
+  """A Gemma-sized embedding table: 256000 x 2048 float32 = 2 097 152 000 B (byte offsets pass
+  2^31 within the tensor)."""
+  rng = np.random.default_rng(4242)
+  base = rng.standard_normal((4000, 2048), dtype=np.float32) * np.float32(0.05)
+  w = np.empty((256000, 2048), np.float32)
+  for i in range(64):                     # 64 differently scaled copies: rows stay distinct in range
+    np.multiply(base, np.float32(0.5 + i / 16), out=w[i * 4000:(i + 1) * 4000])
+  w[-1, -1] = 3.0                         # the very last element must be seen
+  return w
+
+
+_ROW_SLICES = (slice(0, 96), slice(131000, 131200), slice(255904, 256000))
+
+
+@pytest.mark.parametrize("alg,bits,gran", [
+    ("min_max", 8, "CHANNELWISE"), ("min_max", 4, "BLOCKWISE_32"), ("min_max", 2, "BLOCKWISE_128"),
+    ("octav", 4, "CHANNELWISE"), ("mse", 4, "CHANNELWISE")])
+def test_embedding_table_over_2gib_matches_oracle_on_row_slices(m, embedding_table, alg, bits, gran):
+  from mi355q import qtyping as q
+  from mi355q.algorithms.uniform_quantize import mse
+  w = embedding_table
+  cfg = q.TensorQuantizationConfig(num_bits=bits, symmetric=True, granularity=q.QuantGranularity[gran])
+  info = q.OpInfo(op=q.OperatorT(), op_name=q.TFLOperationName.EMBEDDING_LOOKUP, subgraph_op_index=0,
+                  op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg))
+  mod = {"min_max": m.mm, "octav": m.octav, "mse": mse}[alg]
+  res = mod.get_tensor_quant_params(info, cfg, w)
+  got_q = np.asarray(res.quantized_data)
+  assert got_q.shape == w.shape and res.scale.shape[0] == w.shape[0]
+  for rows in _ROW_SLICES:                # rows are independent groups for these granularities
+    part = w[rows]
+    if alg == "min_max":
+      ref = O.min_max_quant_params(part, bits, True, gran, op="EMBEDDING_LOOKUP")
+    elif alg == "octav":
+      ref = O.octav_quant_params(part, bits, gran, op="EMBEDDING_LOOKUP")
+    else:
+      ref = O.mse_quant_params(part, bits, gran, op="EMBEDDING_LOOKUP")
+    assert res.scale.dtype == ref["scale"].dtype
+    assert np.array_equal(res.scale[rows], ref["scale"])
+    assert np.array_equal(got_q[rows], ref["quantized_data"])
+  if alg == "min_max" and gran == "CHANNELWISE":
+    assert got_q[-1, -1] == 127 and abs(int(got_q[-1].astype(np.int32)[:-1].max())) < 127
+  packed = getattr(res.quantized_data, "packed", None)
+  if packed is not None:                  # sub-byte results ride with their packed bytes
+    tail = np.asarray(packed).reshape(-1)[-(2048 * bits // 8):]
+    assert np.array_equal(tail, O.pack_data(bits, got_q[-1]))
