@@ -10,6 +10,7 @@ through the registered calibration functions (`min_max_calibrate`, `gptq.calibra
 """
 from __future__ import annotations
 
+import contextlib
 import copy
 import json
 from typing import Any, Callable, Iterable, Mapping, Optional
@@ -53,6 +54,7 @@ class Calibrator:
     self._model_qsvs: dict[str, qtyping.QSV] = {}
     self._metadata: dict[str, Any] = {"num_samples_calibrated": 0}
     self._recording: Optional[list] = None     # record_step(): events instead of merges
+    self._plans: Optional[dict] = None         # plan_once(): per-signature op lists
 
   # ---- signatures ---------------------------------------------------------------------------
   def get_signature_list(self) -> list[str]:
@@ -90,6 +92,9 @@ class Calibrator:
     if not isinstance(contents, Mapping):
       raise TypeError("a calibration sample must be a {tensor name: ndarray} map (or pass a"
                       " tensor_provider that turns samples into one)")
+    # activations that already live in HBM (torch tensors on the device, e.g. the outputs of a
+    # float run on this GPU) stay there: statistics are taken where they are
+    contents = {k: rt.resident_sample(v) for k, v in contents.items()}
     self._tensor_content_map.update(contents)
     self._stage_sample(signature_key, contents, model_recipe_manager)
     try:
@@ -97,7 +102,42 @@ class Calibrator:
     finally:
       rt.clear_calibration_step()
 
+  @contextlib.contextmanager
+  def plan_once(self):
+    """Inside this block the ops a signature calibrates (a function of the model, the recipe and
+    the registry only) and the tensors to stage for them are worked out once per signature
+    instead of once per sample: the scope matching and config checks behind them cost more host
+    time per sample than the statistics kernels take."""
+    outermost = self._plans is None
+    if outermost:
+      self._plans = {}
+    try:
+      yield self
+    finally:
+      if outermost:
+        self._plans = None
+
+  def _plan(self, signature_key, model_recipe_manager) -> dict:
+    key = (signature_key, id(model_recipe_manager))
+    plan = None if self._plans is None else self._plans.get(key)
+    if plan is None:
+      from .algorithms.uniform_quantize import common_quantize
+      ops_ = list(self._scan_ops_to_calibrate(signature_key, model_recipe_manager))
+      names: dict[str, None] = {}
+      for sg, graph_info, op, _, _ in ops_:
+        for tid in common_quantize.get_tensor_indices_requiring_calibration(op, graph_info):
+          tensor = sg.tensors[tid]
+          if self._flatbuffer_model.buffers[tensor.buffer].data is None:
+            names[tfl_flatbuffer_utils.get_tensor_name(tensor)] = None
+      plan = {"ops": ops_, "runtime_tensors": list(names)}
+      if self._plans is not None:
+        self._plans[key] = plan
+    return plan
+
   def _ops_to_calibrate(self, signature_key, model_recipe_manager):
+    return self._plan(signature_key, model_recipe_manager)["ops"]
+
+  def _scan_ops_to_calibrate(self, signature_key, model_recipe_manager):
     """(subgraph, graph_info, op, op_key, algorithm) of every op the recipe calibrates, in the
     reference's visiting order (main subgraph first, then subgraphs its ops invoke)."""
     codes = self._flatbuffer_model.operatorCodes
@@ -125,22 +165,18 @@ class Calibrator:
   def _stage_sample(self, signature_key, contents, model_recipe_manager) -> None:
     """Every float32 activation the walk will read goes to HBM once and gets its (min, max)
     from one batched launch (the per-op calibration functions then find it staged)."""
-    from .algorithms.uniform_quantize import common_quantize
     lo, hi = -3e38, 3e38                      # the calibration functions' default valid_range
     wanted: dict[int, np.ndarray] = {}
-    for sg, graph_info, op, _, _ in self._ops_to_calibrate(signature_key, model_recipe_manager):
-      for tid in common_quantize.get_tensor_indices_requiring_calibration(op, graph_info):
-        tensor = sg.tensors[tid]
-        if self._flatbuffer_model.buffers[tensor.buffer].data is not None:
-          continue
-        arr = self._tensor_content_map.get(tfl_flatbuffer_utils.get_tensor_name(tensor))
-        if isinstance(arr, np.ndarray) and arr.dtype == np.float32 and arr.size:
-          wanted[id(arr)] = arr
+    for name in self._plan(signature_key, model_recipe_manager)["runtime_tensors"]:
+      arr = self._tensor_content_map.get(name)
+      if isinstance(arr, (np.ndarray, rt.HbmArray)) and arr.dtype == np.float32 and arr.size:
+        wanted[id(arr)] = arr
     if not wanted:
       return
     rt.require_gpu()
     arrays = list(wanted.values())
-    dev = [rt.to_device(np.ascontiguousarray(a).reshape(-1)) for a in arrays]
+    dev = [a.device_tensor.contiguous().reshape(-1) if isinstance(a, rt.HbmArray)
+           else rt.to_device(np.ascontiguousarray(a).reshape(-1)) for a in arrays]
     mm = rt.to_numpy(ops.act_minmax(dev, lo, hi)).astype(np.float32)
     rt.stage_calibration_step({
         id(a): {"host": a, "dev": d, "lo": lo, "hi": hi, "minmax": (mm[i, 0], mm[i, 1])}
@@ -191,10 +227,11 @@ class Calibrator:
   def calibrate(self, calibration_dataset: Mapping[Optional[str], Iterable[Any]],
                 model_recipe_manager: recipe_manager.RecipeManager, cache_output: bool = False) -> None:
     del cache_output   # model outputs are the caller's: nothing is executed here
-    for signature_key, dataset in calibration_dataset.items():
-      for data in dataset:
-        self._metadata["num_samples_calibrated"] += 1
-        self._calibrate_step(signature_key, data, model_recipe_manager)
+    with self.plan_once():
+      for signature_key, dataset in calibration_dataset.items():
+        for data in dataset:
+          self._metadata["num_samples_calibrated"] += 1
+          self._calibrate_step(signature_key, data, model_recipe_manager)
 
   def get_model_qsvs(self) -> dict[str, qtyping.QSV]:
     return self._model_qsvs

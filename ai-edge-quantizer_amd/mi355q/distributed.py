@@ -174,10 +174,11 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
     return {}
   local = calibrator.Calibrator(qz.float_model, tensor_provider=tensor_provider)
   mine = []                                    # (signature index, sample index, events)
-  for sig_idx, (signature_key, dataset) in enumerate(calibration_data.items()):
-    samples = dataset if hasattr(dataset, "__len__") and hasattr(dataset, "__getitem__") else list(dataset)
-    for k in sample_shard(len(samples), rank, world):
-      mine.append((sig_idx, k, local.record_step(signature_key, samples[k], rm)))
+  with local.plan_once():
+    for sig_idx, (signature_key, dataset) in enumerate(calibration_data.items()):
+      samples = dataset if hasattr(dataset, "__len__") and hasattr(dataset, "__getitem__") else list(dataset)
+      for k in sample_shard(len(samples), rank, world):
+        mine.append((sig_idx, k, local.record_step(signature_key, samples[k], rm)))
   if world > 1:
     parts = [None] * world
     dist.all_gather_object(parts, mine, group=group)

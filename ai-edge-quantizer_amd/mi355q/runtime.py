@@ -36,6 +36,8 @@ def ptr(t) -> ctypes.c_void_p:
 
 def to_device(a, dtype=None) -> torch.Tensor:
   """NumPy (possibly a read-only mmap view) or torch tensor -> contiguous device tensor."""
+  if isinstance(a, HbmArray):
+    a = a.device_tensor
   if isinstance(a, torch.Tensor):
     t = a
     if dtype is not None and t.dtype != dtype:
@@ -181,6 +183,14 @@ for _name in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__
 HbmArray.__hash__ = object.__hash__
 HbmArray.__neg__ = lambda self: -self.numpy()
 HbmArray.__abs__ = lambda self: abs(self.numpy())
+
+
+def resident_sample(value):
+  """A calibration sample entry as the calibrator keeps it: device tensors become HbmArray (no
+  copy), host torch tensors become ndarrays, everything else is passed through."""
+  if isinstance(value, torch.Tensor):
+    return HbmArray(value.detach()) if value.is_cuda else value.detach().numpy()
+  return value
 
 
 def on_device(a, dtype=None) -> torch.Tensor:

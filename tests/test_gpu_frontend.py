@@ -247,3 +247,37 @@ def test_hadamard_recipe_materializes_rotation_instruction(m):
   with pytest.raises(NotImplementedError, match="INSERT_HADAMARD_ROTATION"):
     m.quantizer.apply_quantize_tensor_transformations(model2, params2)
 
+
+
+@pytest.mark.parametrize("alg", ["min_max_uniform_quantize", "GPTQ", "OSCAR"])
+def test_calibration_samples_resident_in_hbm_give_the_same_qsvs(m, alg):
+  """Samples handed over as device tensors (activations produced on this GPU) are calibrated where
+  they are: same QSVs, bit for bit, as the same samples handed over as host arrays."""
+  import torch
+  from mi355q import calibrator, runtime as rt
+  q = m.q
+  rng = np.random.default_rng(61)
+  w = (rng.standard_normal((24, 64)) * 0.05).astype(np.float32)
+  model, _ = build_fc_model(m, w)
+  model.signatureDefs = [q.SignatureDefT(signatureKey=b"serving_default", subgraphIndex=0)]
+  rm = m.rm.RecipeManager()
+  if alg == "min_max_uniform_quantize":
+    rm.load_quantization_recipe(m.recipe.static_wi8_ai8())
+  else:
+    rm.add_dynamic_config(".*", q.TFLOperationName.FULLY_CONNECTED, 4, algorithm_key=alg)
+  host = [{"x": rng.standard_normal((3, 7, 64), dtype=np.float32) * np.float32(1 + s),
+           "y": rng.standard_normal((3, 7, 24), dtype=np.float32)} for s in range(4)]
+  host[2]["x"][0, 0, 0] = np.inf
+  resident = [{k: torch.from_numpy(v).cuda() for k, v in s.items()} for s in host]
+  resident[1]["y"] = rt.HbmArray(resident[1]["y"])        # both spellings of "already in HBM"
+  resident[3]["x"] = torch.from_numpy(host[3]["x"])        # a host torch tensor is accepted as well
+  out = []
+  for data in (host, resident):
+    cal = calibrator.Calibrator(model)
+    cal.calibrate({"serving_default": data}, rm)
+    out.append(cal.get_model_qsvs())
+  assert set(out[0]) == set(out[1]) and out[0]
+  for name, qsv in out[0].items():
+    assert set(qsv) == set(out[1][name])
+    for key, val in qsv.items():
+      assert np.array_equal(np.asarray(val), np.asarray(out[1][name][key])), (name, key)
