@@ -48,7 +48,7 @@ def get_zp_scale_from_dequantized_symmetric_weights(
   if min_scale != 1e-9:
     raise NotImplementedError("the GPU kernel is built for the reference's min_scale of 1e-9")
   rt.require_gpu()
-  vals = np.asarray(dequant_vals)
+  vals = dequant_vals if isinstance(dequant_vals, rt.HbmArray) else np.asarray(dequant_vals)
   if vals.dtype != np.float32:
     raise TypeError(f"dequantized weight recovery expects float32 weights, got {vals.dtype}")
   last = vals.shape[-1] if vals.ndim else 1
@@ -104,7 +104,7 @@ def get_tensor_quant_params(op_info: qtyping.OpInfo, tensor_quant_config: qtypin
     raise ValueError("Only symmetric weights are supported for dequantized weight recovery.")
   quantized_dim = common_utils.get_weight_quantized_dim(op_info, tensor_content, cfg.granularity)
   rt.require_gpu()
-  if np.asarray(tensor_content).dtype != np.float32:
+  if tensor_content.dtype != np.float32:
     raise TypeError(f"dequantized weight recovery expects float32 weights, got {tensor_content.dtype}")
   resident = rt.to_device(tensor_content)
   zp, scale = get_zp_scale_from_dequantized_symmetric_weights(

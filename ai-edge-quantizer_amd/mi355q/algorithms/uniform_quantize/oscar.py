@@ -65,6 +65,8 @@ def _columns_of(op_name, w, mu2) -> np.ndarray:
 def _weight_on_device(w):
   """float32 [n, d] device copy. The reference widens to FP64 first; float32 -> FP64 is exact, so
   the kernels widen element by element instead."""
+  if isinstance(w, rt.HbmArray) and w.dtype == np.float32:
+    return w.device_tensor.contiguous()
   w = np.asarray(w)
   if w.dtype == np.float64:       # accepted when it is a widened float32 tensor (the model's dtype)
     narrow = w.astype(np.float32)

@@ -132,7 +132,10 @@ def _is_valid_quantization_params(tensor_data: np.ndarray,
 def _as_f32_exact(x: np.ndarray) -> np.ndarray:
   """The kernels read float32 tensor buffers (LiteRT weights). Other dtypes are
   accepted only when the conversion is lossless, so results equal the
-  reference's computation in the wider type."""
+  reference's computation in the wider type. A float32 tensor that already lives in HBM
+  (runtime.HbmArray) is passed through: the kernels read it where it is."""
+  if isinstance(x, rt.HbmArray) and x.dtype == np.float32:
+    return x
   x = np.asarray(x)
   if x.dtype == np.float32:
     return x
@@ -170,7 +173,8 @@ def _flat_params(scale: np.ndarray, zp: np.ndarray, compute64: bool):
 def uniform_quantize(tensor_data: np.ndarray, quantization_params: qtyping.UniformQuantParams,
                      is_blockwise_quant: bool = False) -> np.ndarray:
   """q = cast(clip(rint(x / scale + zp))) on the GPU (ref :273-362)."""
-  tensor_data = np.asarray(tensor_data)
+  if not isinstance(tensor_data, rt.HbmArray):
+    tensor_data = np.asarray(tensor_data)
   q = uniform_quantize_on_device(tensor_data, quantization_params, is_blockwise_quant)
   want = _get_numpy_dtype(IntType(quantization_params.num_bits, True))
   if q is None:

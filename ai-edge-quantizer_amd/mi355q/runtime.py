@@ -99,6 +99,15 @@ class HbmArray:
   def size(self) -> int:
     return self.device_tensor.numel()
 
+  def reshape(self, *shape):
+    """Another view of the same device memory (no copy, no host visit)."""
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+      shape = tuple(shape[0])
+    out = HbmArray(self.device_tensor.contiguous().reshape(tuple(int(d) for d in shape)))
+    if self._host is not None:
+      out._host = self._host.reshape(shape)  # pylint: disable=protected-access
+    return out
+
   def numpy(self) -> np.ndarray:
     if self._host is None:
       self._host = self.device_tensor.cpu().numpy()

@@ -271,3 +271,47 @@ def test_hadamard_rotation_is_orthogonal_at_full_size(m):
     assert np.max(np.abs(back - w)) < 2e-5
     ref = (w.reshape(-1, h)[:2] @ O.hadamard_matrix(h)).reshape(-1)
     assert np.max(np.abs(rot.reshape(-1)[: ref.size] - ref)) < 1e-5 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("alg,bits,gran", [
+    ("min_max", 8, "CHANNELWISE"), ("min_max", 4, "BLOCKWISE_32"), ("min_max", 8, "TENSORWISE"),
+    ("octav", 4, "CHANNELWISE"), ("octav", 4, "BLOCKWISE_64"), ("mse", 4, "CHANNELWISE"),
+    ("hadamard", 8, "CHANNELWISE"), ("oscar", 4, "CHANNELWISE"), ("oscar", 4, "BLOCKWISE_32"),
+    ("gptq", 4, "CHANNELWISE"), ("dwr", 4, "CHANNELWISE")])
+def test_weight_resident_in_hbm_gives_the_same_result(alg, bits, gran):
+  """`tensor_content` handed over as runtime.HbmArray (a float32 weight that already lives on the
+  GPU) is read where it is; results equal those for the same weight handed over as ndarray."""
+  import torch
+  import __graft_entry__ as g
+  g.build()
+  from mi355q import qtyping as q, runtime as rt
+  from mi355q.algorithms.uniform_quantize import (dequantized_weight_recovery, gptq, hadamard_rotation,
+                                                  mse, naive_min_max_quantize, octav, oscar)
+  rng = np.random.default_rng(2718)
+  w = (rng.standard_normal((96, 256)) * 0.05).astype(np.float32)
+  qsv = None
+  if alg == "dwr":
+    w = (np.rint(w / np.float32(0.02)).clip(-7, 7) * np.float32(0.02)).astype(np.float32)
+  if alg == "oscar":
+    qsv = {"mu2": np.exp(rng.normal(size=256))}
+  if alg == "gptq":
+    x = rng.standard_normal((512, 256))
+    qsv = {"activation_tensor_qsv": {"hessian": 2.0 / 512 * x.T @ x, "num_samples": np.array(512)}}
+  mod = dict(min_max=naive_min_max_quantize, octav=octav, mse=mse, hadamard=hadamard_rotation,
+             oscar=oscar, gptq=gptq, dwr=dequantized_weight_recovery)[alg]
+  cfg = q.TensorQuantizationConfig(num_bits=bits, symmetric=True, granularity=q.QuantGranularity[gran])
+  info = q.OpInfo(op=q.OperatorT(inputs=[0, 1, -1], outputs=[2]), op_name=q.TFLOperationName.FULLY_CONNECTED,
+                  subgraph_op_index=0,
+                  op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg, skip_checks=alg == "dwr"))
+  host = mod.get_tensor_quant_params(info, cfg, w, qsv)
+  resident = rt.HbmArray(torch.from_numpy(w).cuda())
+  dev = mod.get_tensor_quant_params(info, cfg, resident, qsv)
+  assert resident._host is None, "the resident weight was pulled to the host"  # pylint: disable=protected-access
+  for field in ("scale", "zero_point", "quantized_data", "hadamard"):
+    a, b = getattr(host, field, None), getattr(dev, field, None)
+    if a is None:
+      assert b is None
+    elif field == "hadamard":
+      assert a.hadamard_size == b.hadamard_size
+    else:
+      assert np.array_equal(np.asarray(a), np.asarray(b)), field
