@@ -81,12 +81,16 @@ __device__ __noinline__ float pairwise_sum(const float* a, int n, int lane) {
 struct RunSum {
   float acc = 0.f;
   unsigned count = 0;
-  int pend_start = 0;
+  int pend_start = 0;    // a run that touches the end of the last batch and may continue
   int pend_len = 0;
+  float pend_sum = 0.f;  // its left-to-right sum so far; meaningful while pend_len < 8
 
+  // A run shorter than 8 is summed left to right from 0, so the part seen so far is a valid
+  // prefix of that chain as long as the run stays shorter than 8; a run that reaches 8 switches
+  // to the eight-accumulator scheme and is summed from memory once its end is known.
   __device__ __forceinline__ void flush(const float* a, int lane) {
     if (pend_len > 0) {
-      acc = acc + pairwise_sum<false, 8>(a + pend_start, pend_len, lane);
+      acc = acc + (pend_len < 8 ? pend_sum : pairwise_sum<false, 8>(a + pend_start, pend_len, lane));
       pend_len = 0;
     }
   }
@@ -94,47 +98,85 @@ struct RunSum {
   // m: ballot of the selected lanes of the batch starting at element `base`;
   // v: this lane's element (lane l <-> element base + l); a: the unit.
   //
-  // Fast path (no run of 8+ lanes in the batch, nothing pending from the previous batch): every
-  // run is shorter than 8, so NumPy sums it left to right from 0. All runs are summed at once,
-  // lane-parallel: six rounds of "take my left neighbour's partial sum" (v_mov_b32_dpp
-  // wave_shr:1), then the run totals are added to the running total in lane order. A run that
-  // touches the batch end stays pending (it may continue, and then its length decides the
-  // summation scheme). Everything else takes the general per-run path.
+  // Fast path (no run of 8+ lanes in the batch; a run pending from the previous batch either
+  // ended there or continues here and still stays shorter than 8): all runs are summed at once,
+  // lane-parallel, by rounds of "left neighbour's partial sum + mine" (v_mov_b32_dpp
+  // wave_shr:1; lane 0 continues the pending chain), then the run totals are added to the
+  // running total in lane order. A run that touches the batch end stays pending with its partial
+  // sum. Everything else takes the general per-run path.
   __device__ __forceinline__ void feed(unsigned long long m, int base, float v, const float* a,
                                        int lane) {
     if ((base % kChunk) == 0 || (m & 1ull) == 0) flush(a, lane);
     count += static_cast<unsigned>(__builtin_popcountll(m));
     if (m == 0) return;
     const unsigned long long m4 = m & (m >> 1) & (m >> 2) & (m >> 3);
-    if ((m4 & (m4 >> 4)) != 0 || pend_len > 0) {
+    if ((m4 & (m4 >> 4)) != 0 || (pend_len > 0 && pend_len + __builtin_ctzll(~m) >= 8)) {
       feed_runs(m, base, v, a, lane);
       return;
     }
+    const float carry = pend_len > 0 ? pend_sum : 0.f;  // lane 0 continues the pending chain
+    pend_len = 0;
+    const bool sel = ((m >> lane) & 1ull) != 0;
+    float partial = sel ? (lane == 0 ? carry : 0.f) + v : 0.f;
+    const unsigned long long m2 = m & (m >> 1);
+    if (m2 != 0) {  // some run is longer than one element
+      // every lane repeats "left neighbour's partial + mine" (run starts keep their first sum): a
+      // lane at position p of its run is final after p rounds and a further round recomputes
+      // the same value, so the round count only has to reach the longest run
+      const bool cont = (((m2 << 1) >> lane) & 1ull) != 0;  // my left neighbour is in my run
+      const int rounds = (m2 & (m >> 2)) == 0 ? 1 : (m4 == 0 ? 2 : 6);
+      for (int t = 0; t < rounds; ++t) {
+        const float left = wave_shr1(partial);
+        if (cont) partial = left + v;
+      }
+    }
     unsigned long long mf = m;
-    if (m >> 63) {  // trailing run (1..7 lanes): defer
+    if (m >> 63) {  // trailing run (1..7 lanes): it may continue in the next batch
       const int t = __builtin_clzll(~m);
       mf = m & (~0ull >> t);
       pend_start = base + 64 - t;
       pend_len = t;
+      pend_sum = lane_bcast(partial, 63);
     }
-    if (mf == 0) return;
-    const bool sel = ((mf >> lane) & 1ull) != 0;
-    const unsigned long long below = ~mf & ((1ull << lane) - 1ull);
-    const int pos = lane - (below ? 64 - __builtin_clzll(below) : 0);  // index inside my run
-    float partial = sel ? 0.f + v : 0.f;
+    unsigned long long ends = mf & ~(mf >> 1);  // last lane of every finished run
+    const int k = __builtin_popcountll(ends);
+    if (k <= 3) {
+      while (ends != 0) {
+        acc = acc + lane_bcast(partial, __builtin_ctzll(ends));
+        ends &= ends - 1ull;
+      }
+      return;
+    }
+    // acc = (..((acc + R0) + R1)..) + R(k-1) without a scalar loop over set bits: the run totals
+    // are compacted to lanes 0..k-1 (one ds_permute; the other lanes park theirs above k), then
+    // every lane repeats x = left neighbour's x + R (lane 0's neighbour is acc). Lane j is final
+    // after j + 1 rounds and stays final, so k rounds (rounded up to the unroll) leave the
+    // total in lane k - 1.
+    const bool is_end = ((ends >> lane) & 1ull) != 0;
+    const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(ends >> 32),
+                                               __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(ends), 0));
+    const int dest = is_end ? rank : k + lane - rank;
+    const float r = __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(partial)));
+    float x = r;
+    for (int t = 0; t < k; t += 4) {
 #pragma unroll
-    for (int t = 1; t < 7; ++t) {
-      const float left = wave_shr1(partial);
-      if (sel && pos == t) partial = left + v;
+      for (int j = 0; j < 4; ++j) {
+        const float left = __int_as_float(__builtin_amdgcn_update_dpp(
+            __float_as_int(acc), __float_as_int(x), 0x138, 0xF, 0xF, false));
+        x = left + r;
+      }
     }
-    unsigned long long ends = mf & ~(mf >> 1);  // last lane of every run (bit 63 is never in mf)
-    while (ends != 0) {
-      acc = acc + lane_bcast(partial, __builtin_ctzll(ends));
-      ends &= ends - 1ull;
-    }
+    acc = lane_bcast(x, k - 1);
   }
 
-  // General path: runs one by one (long runs, runs continuing across batches).
+  // left-to-right sum of lanes s .. s+len-1 on top of `start` (len < 8)
+  __device__ __forceinline__ float chain(float start, float v, int s, int len) {
+    float rs = start;
+    for (int i = 0; i < len; ++i) rs = rs + lane_bcast(v, s + i);
+    return rs;
+  }
+
+  // General path: runs one by one (runs of 8+, runs that grow to 8+ across batches).
   __device__ __forceinline__ void feed_runs(unsigned long long m, int base, float v, const float* a,
                                             int lane) {
     while (m != 0) {
@@ -142,21 +184,25 @@ struct RunSum {
       const unsigned long long t = m >> s;
       const int len = (~t == 0) ? 64 - s : __builtin_ctzll(~t);
       if (s + len == 64) {  // touches the batch end: may continue in the next batch
-        if (pend_len > 0) {  // (only when s == 0)
+        if (pend_len > 0) {  // (only when s == 0: the whole batch belongs to the pending run)
           pend_len += len;
         } else {
           pend_start = base + s;
           pend_len = len;
+          if (len < 8) pend_sum = chain(0.f, v, s, len);
         }
         return;
       }
-      if (pend_len > 0) {  // run that started in an earlier batch ends here
-        pend_len += len;
-        flush(a, lane);
+      if (pend_len > 0) {  // run that started in an earlier batch ends here (s == 0)
+        if (pend_len + len < 8) {
+          acc = acc + chain(pend_sum, v, 0, len);
+          pend_len = 0;
+        } else {
+          pend_len += len;
+          flush(a, lane);
+        }
       } else if (len < 8) {  // sum straight from registers
-        float rs = 0.f;
-        for (int i = 0; i < len; ++i) rs = rs + lane_bcast(v, s + i);
-        acc = acc + rs;
+        acc = acc + chain(0.f, v, s, len);
       } else {
         acc = acc + pairwise_sum<false, 8>(a + base + s, len, lane);
       }
@@ -229,6 +275,17 @@ __device__ __forceinline__ void publish_moving(unsigned long long* flags, unsign
   if ((seen & moved) != moved) atomicOr(flags, moved);
 }
 
+// A Newton update that returns its own input (same value, hence the same two masks, the same
+// sums and the same update again) has reached an exact fixed point: every later iteration of
+// this unit would recompute the identical number and find it "close". The masks stop changing
+// after a handful of iterations on real weights, so the remaining passes over the unit are
+// skipped and their history entries filled in.
+__device__ __forceinline__ bool reached_fixed_point(float guess, float next) { return next == guess; }
+
+__device__ __forceinline__ void repeat_iterate(const OctavArgs& a, int it, long long unit, float value) {
+  for (int r = it + 1; r < a.max_iter; ++r) a.hist[static_cast<long long>(r) * a.units + unit] = value;
+}
+
 template <bool USE_LDS>
 __global__ void octav_kernel(OctavArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -252,8 +309,11 @@ __global__ void octav_kernel(OctavArgs a) {
     for (int base = 0; base < len; base += kWave) {
       const int i = base + lane;
       const float v = i < len ? u[i] : qnan;
-      pos.feed(__ballot(v >= hi), base, v, u, lane);
-      neg.feed(__ballot(v <= lo), base, v, u, lane);
+      const unsigned long long mp = __ballot(v >= hi), mn = __ballot(v <= lo);
+      // nothing selected and no run waiting for its end: the batch changes nothing
+      if ((mp | mn) == 0 && (pos.pend_len | neg.pend_len) == 0) continue;
+      pos.feed(mp, base, v, u, lane);
+      neg.feed(mn, base, v, u, lane);
     }
     pos.flush(u, lane);
     neg.flush(u, lane);
@@ -261,6 +321,10 @@ __global__ void octav_kernel(OctavArgs a) {
                                     a.count_is_f64);
     if (lane == 0) a.hist[static_cast<long long>(it) * a.units + unit] = st.next;
     if (!st.close) moved |= 1ull << it;
+    if (reached_fixed_point(guess, st.next)) {
+      if (lane == 0) repeat_iterate(a, it, unit, st.next);
+      break;
+    }
     guess = st.next;
   }
   if (lane == 0) publish_moving(a.moving, moved);
@@ -301,6 +365,10 @@ __global__ void octav_seg_kernel(OctavArgs a, long long channels, long long oute
     const OctavStep st = octav_step(guess, pos.acc, neg.acc, npos, nneg, outer * inner, a.s, 1);
     if (lane == 0) a.hist[static_cast<long long>(it) * a.units + c] = st.next;
     if (!st.close) moved |= 1ull << it;
+    if (reached_fixed_point(guess, st.next)) {
+      if (lane == 0) repeat_iterate(a, it, c, st.next);
+      break;
+    }
     guess = st.next;
   }
   if (lane == 0) publish_moving(a.moving, moved);
@@ -340,6 +408,7 @@ __global__ __launch_bounds__(256) void octav_cols_kernel(OctavArgs a, long long 
   const long long c = live ? c_raw : channels - 1;
   const long long outer = a.len;
   float guess = 1.0f;
+  bool settled = false;
   unsigned long long moved = 0;  // iterations in which this unit's guess still moved
   for (int it = 0; it < a.max_iter; ++it) {
     const float hi = guess, lo = -guess;
@@ -364,9 +433,14 @@ __global__ __launch_bounds__(256) void octav_cols_kernel(OctavArgs a, long long 
       if (v <= lo) { neg = neg + v; ++nneg; }
     }
     const OctavStep st = octav_step(guess, pos, neg, npos, nneg, outer, a.s, a.count_is_f64);
-    if (live) a.hist[static_cast<long long>(it) * a.units + c] = st.next;
-    if (live && !st.close) moved |= 1ull << it;
+    if (live && !settled) a.hist[static_cast<long long>(it) * a.units + c] = st.next;
+    if (live && !settled && !st.close) moved |= 1ull << it;
+    if (!settled && reached_fixed_point(guess, st.next)) {
+      settled = true;
+      if (live) repeat_iterate(a, it, c, st.next);
+    }
     guess = st.next;
+    if (__all(settled)) break;
   }
   // one lane per 64 channels publishes the union of the wave
   for (int off = kWave / 2; off > 0; off >>= 1) moved |= __shfl_xor(moved, off, kWave);
@@ -453,6 +527,8 @@ UnitPlan plan_units(int len) {
   constexpr size_t kBudget = 64 * 1024;  // per block: keeps >= 2 blocks per CU
   int waves = static_cast<int>(kBudget / (per_wave ? per_wave : 1));
   if (waves > 4) waves = 4;
+  // (one-wave blocks would fit ten 16 KB slices per CU instead of eight; measured 12 % slower:
+  // the loops are bound by scalar-instruction issue, not by waves in flight)
   if (waves >= 1) {
     p.use_lds = true;
     p.waves = waves;

@@ -47,11 +47,21 @@ def _rotate_with_diagonal_hadamard(tensor_content: np.ndarray, axis: int,
   if axis != tensor_content.ndim - 1:
     raise ValueError("Hadamard rotation is only supported for tensors with quantized"
                      " dimension 0 (rotate last dimension).")
+  rotated, h, vec = _rotate_in_hbm(tensor_content, axis, max_size)
+  return np.asarray(rotated), h, vec
+
+
+def _rotate_in_hbm(tensor_content, axis: int, max_size: int | None = None):
+  """The same, with the rotated tensor left in HBM (runtime.HbmArray) for the clip search and the
+  quantizing launch that follow."""
+  if axis != tensor_content.ndim - 1:
+    raise ValueError("Hadamard rotation is only supported for tensors with quantized"
+                     " dimension 0 (rotate last dimension).")
   h = hadamard_size_for(tensor_content.shape[axis], max_size)
   x = uniform_quantize_tensor._as_f32_exact(tensor_content)  # pylint: disable=protected-access
   rt.require_gpu()
   rotated = ops.hadamard_rotate(rt.to_device(x.reshape(-1)), max(h, 2) if h < 2 else h)
-  return rt.to_numpy(rotated).reshape(tensor_content.shape), h, np.ones(h, dtype=np.int8)
+  return rt.HbmArray(rotated.reshape(tuple(tensor_content.shape))), h, np.ones(h, dtype=np.int8)
 
 
 def get_tensor_quant_params(
@@ -65,7 +75,7 @@ def get_tensor_quant_params(
     raise ValueError("Hadamard rotation is not supported for static quantization.")
   if tensor_content.ndim < 2:
     raise ValueError("Hadamard rotation is only supported for tensors with rank >= 2.")
-  w_rot, h, vec = _rotate_with_diagonal_hadamard(
+  w_rot, h, vec = _rotate_in_hbm(
       tensor_content, axis=tensor_content.ndim - 1,
       max_size=tensor_quant_config.algorithm_params.get("max_hadamard_size"))
   p = octav.get_tensor_quant_params(op_info, tensor_quant_config, w_rot, tensor_qsv)

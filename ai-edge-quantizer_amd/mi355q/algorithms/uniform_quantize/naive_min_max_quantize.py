@@ -61,7 +61,10 @@ def fused_symmetric_requant(tensor_content: np.ndarray, layout, num_bits: int,
   rows, cols, block = layout
   rt.require_gpu()
   x = rt.to_device(tensor_content.reshape(rows, cols))
-  c = None if clip is None else rt.to_device(np.ascontiguousarray(clip, np.float32).reshape(-1))
+  if clip is not None:                # host values, or the device tensor a clip search left behind
+    clip = (rt.to_device(np.ascontiguousarray(clip, np.float32).reshape(-1))
+            if isinstance(clip, np.ndarray) else clip.reshape(-1))
+  c = clip
   # the vectorized kernels pack; the generic fallback (odd widths) does not (mi355q.h)
   sub_byte = (num_bits in (2, 4) and cols % 4 == 0
               and (block in (32, 64, 128, 256) or (block == 0 and cols <= 16384)))

@@ -101,16 +101,20 @@ def get_tensor_quant_params(
   if layout is not None:
     rows, cols, block = layout
     rt.require_gpu()
-    x = rt.to_device(tensor_content.reshape(rows, cols))
+    # one upload (none for a weight that is in HBM already); clip search, quantize and pack all
+    # read the resident copy, and large results stay in HBM for the model writer
+    resident = (tensor_content if isinstance(tensor_content, rt.HbmArray)
+                else rt.HbmArray(rt.to_device(tensor_content)))
+    x = rt.to_device(resident.reshape(rows, cols))
     units, unit_len = (rows * (cols // block), block) if block else (rows, cols)
     clip, _ = ops.octav_clip(x.view(-1), units, unit_len, cfg.num_bits, 10, 3.0, True, True)
-    r = ops.requant_sym(x, block, cfg.num_bits, clip=clip, want_q=True)
-    scale = rt.to_numpy(r["scale"]).reshape(
+    scale, q = naive_min_max_quantize.fused_symmetric_requant(resident, layout, cfg.num_bits, clip=clip)
+    scale = scale.reshape(
         naive_min_max_quantize.scale_shape_for(tensor_content, cfg.granularity, quantized_dim))
     return qtyping.UniformQuantParams(
         scale=scale, zero_point=np.zeros(scale.shape, np.int8), num_bits=cfg.num_bits,
         symmetric=True, quantized_dimension=quantized_dim, block_size=block_size,
-        quantized_data=rt.to_numpy(r["q"]).reshape(tensor_content.shape))
+        quantized_data=q)
 
   # ---- general path (TENSORWISE, supplied min/max, other layouts) ----
   if have_qsv:

@@ -1,0 +1,54 @@
+"""`get_tensor_quant_params` on weights that already live in HBM (runtime.HbmArray): what the
+public interface costs around the kernels when PCIe is out of the picture.
+
+  python tools/api_resident_bench.py [--reps 200]
+One JSON line per configuration: microseconds per call, weight GB/s, and the same for host arrays.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--reps", type=int, default=200)
+  a = ap.parse_args()
+  import __graft_entry__ as g
+  g.build()
+  import torch
+  from mi355q import qtyping as q, runtime as rt
+  from mi355q.algorithms.uniform_quantize import hadamard_rotation, naive_min_max_quantize, octav
+  rng = np.random.default_rng(12)
+  for name, mod, shape, bits, gran in (
+      ("C2 min/max int8 channelwise", naive_min_max_quantize, (4096, 4096), 8, "CHANNELWISE"),
+      ("C3 min/max int4 blockwise-128", naive_min_max_quantize, (4096, 11008), 4, "BLOCKWISE_128"),
+      ("OCTAV int4 channelwise", octav, (4096, 4096), 4, "CHANNELWISE"),
+      ("Hadamard + OCTAV int4 channelwise", hadamard_rotation, (4096, 4096), 4, "CHANNELWISE")):
+    w = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02)
+    cfg = q.TensorQuantizationConfig(num_bits=bits, symmetric=True, granularity=q.QuantGranularity[gran])
+    info = q.OpInfo(op=q.OperatorT(), op_name=q.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
+                    op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg))
+    out = {"workload": f"{name} {shape[0]}x{shape[1]} through get_tensor_quant_params"}
+    for label, content, reps in (("resident", rt.HbmArray(torch.from_numpy(w).cuda()), a.reps),
+                                 ("host", w, max(8, a.reps // 10))):
+      for _ in range(3):
+        mod.get_tensor_quant_params(info, cfg, content)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(reps):
+        mod.get_tensor_quant_params(info, cfg, content)
+      torch.cuda.synchronize()
+      dt = (time.perf_counter() - t0) / reps
+      out[f"{label}_us_per_call"] = round(dt * 1e6, 1)
+      out[f"{label}_weight_GBps"] = round(w.nbytes / dt / 1e9, 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+  main()
