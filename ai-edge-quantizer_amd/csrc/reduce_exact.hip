@@ -491,26 +491,167 @@ struct MseArgs {
   float* scale;
 };
 
-template <bool USE_LDS>
-__global__ void mse_scale_kernel(MseArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
-  const long long unit = static_cast<long long>(blockIdx.x) * (blockDim.x / kWave) + wave;
-  const bool live = unit < a.units;
-  const float* u = nullptr;
-  if (live)
-    u = stage_unit<USE_LDS>(a.x + unit * a.len, a.len, smem + static_cast<size_t>(wave) * a.lds_stride, lane);
-  if constexpr (USE_LDS) __syncthreads();
-  if (!live) return;
-  float acc = 0.f;
-  for (int c = 0; c < a.len; c += kChunk) {
-    const int n = a.len - c < kChunk ? a.len - c : kChunk;
-    const float part = pairwise_sum<true, 8>(u + c, n, lane);
-    acc = c == 0 ? part : acc + part;
+// Leaves of NumPy's pairwise recursion over [lo, lo + n), in order (n <= 8192: at most 128).
+__device__ void list_leaves(int lo, int n, int* leaf_lo, int* leaf_n, int* count) {
+  if (n <= 128) {
+    leaf_lo[*count] = lo;
+    leaf_n[*count] = n;
+    ++*count;
+    return;
   }
-  const float mean = acc / static_cast<float>(a.len);
-  if (lane == 0) a.scale[unit] = a.multiplier * __builtin_sqrtf(mean);
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  list_leaves(lo, n2, leaf_lo, leaf_n, count);
+  list_leaves(lo + n2, n - n2, leaf_lo, leaf_n, count);
+}
+
+// The recursion again with the leaves' sums known (consumed in order).
+__device__ float fold_leaves(int n, const float* leaf_sum, int* next) {
+  if (n <= 128) return leaf_sum[(*next)++];
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  const float left = fold_leaves(n2, leaf_sum, next);
+  return left + fold_leaves(n - n2, leaf_sum, next);
+}
+
+// sum(x*x) of contiguous units in NumPy's order, all lanes busy: a unit is a sequence of
+// 8192-element chunks added in order; a chunk is a tree of leaves of <= 128 elements; a leaf is
+// eight strided accumulators. One wave per unit; eight lanes share a leaf, one per accumulator
+// (a wave step reads eight 32-byte runs straight from global memory, every byte of every cache
+// line exactly once), the accumulators fold by an xor butterfly -- ((r0+r1)+(r2+r3))+((r4+r5)+
+// (r6+r7)), IEEE addition commutes so both partners agree -- and lane 0 folds the leaf sums in
+// the recursion's order. The two leaf tables a unit needs (full chunk, last chunk) are listed
+// once per block. This is the general form (any length); mse_scale_balanced_kernel below takes
+// the lengths whose tree is complete.
+__global__ __launch_bounds__(256) void mse_scale_leaves_kernel(MseArgs a) {
+  __shared__ int leaf_lo[2][128], leaf_n[2][128], leaves[2];
+  __shared__ float leaf_sum[4][128];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int k = lane & 7, slot = lane >> 3;
+  const int last_len = a.len - (a.len - 1) / kChunk * kChunk;  // 1 .. 8192
+  if (threadIdx.x == 0 || threadIdx.x == kWave) {
+    const int t = threadIdx.x == 0 ? 0 : 1;
+    int c = 0;
+    list_leaves(0, t == 0 ? (a.len < kChunk ? a.len : kChunk) : last_len, leaf_lo[t], leaf_n[t], &c);
+    leaves[t] = c;
+  }
+  __syncthreads();
+  const long long unit = static_cast<long long>(blockIdx.x) * 4 + wave;
+  const bool live_unit = unit < a.units;
+  const float* u = a.x + (live_unit ? unit : 0) * a.len;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < a.len; c0 += kChunk) {
+    const int n = a.len - c0 < kChunk ? a.len - c0 : kChunk;
+    const int t = (c0 + kChunk >= a.len) ? 1 : 0;
+    const int count = leaves[t];
+    for (int base = 0; base < count; base += 8) {
+      const int leaf = base + slot;
+      const bool live = leaf < count;
+      const float* p = u + c0 + (live ? leaf_lo[t][leaf] : 0);
+      const int ln = live ? leaf_n[t][leaf] : 0;
+      float res = 0.f;
+      if (ln < 8) {  // short leaf (only a chunk shorter than 8 has one): left to right
+        for (int i = 0; i < ln; ++i) res = res + p[i] * p[i];
+      } else {
+        float v[16];  // all loads first, then the ordered adds
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = (8 * (q + 1) <= ln) ? p[8 * q + k] : 0.f;
+        float r = v[0] * v[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q)
+          if (8 * (q + 1) <= ln) r = r + v[q] * v[q];
+        r = r + __shfl_xor(r, 1, kWave);
+        r = r + __shfl_xor(r, 2, kWave);
+        r = r + __shfl_xor(r, 4, kWave);
+        for (int i = ln & ~7; i < ln; ++i) r = r + p[i] * p[i];
+        res = r;
+      }
+      if (live && k == 0) leaf_sum[wave][leaf] = res;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      int next = 0;
+      const float part = fold_leaves(n, leaf_sum[wave], &next);
+      acc = c0 == 0 ? part : acc + part;
+    }
+    __syncthreads();
+  }
+  if (lane == 0 && live_unit) {
+    const float mean = acc / static_cast<float>(a.len);
+    a.scale[unit] = a.multiplier * __builtin_sqrtf(mean);
+  }
+}
+
+// n = leaf << depth with leaf <= 128 a multiple of 8: NumPy's recursion then halves exactly at
+// every level (n/2 is already a multiple of 8), so the chunk is 2^depth equal leaves at leaf
+// offsets i * leaf and the tree over them is the complete binary tree. True for the sizes real
+// layers have (4096 = 128 << 5, 11008 - 8192 = 88 << 5, 14336 - 8192 = 96 << 6, ...).
+bool balanced_chunk(int n, int* leaf, int* depth) {
+  int d = 0;
+  while ((n >> d) > 128) ++d;
+  const int l = n >> d;
+  if ((l << d) != n || l < 8 || (l % 8) != 0) return false;
+  *leaf = l;
+  *depth = d;
+  return true;
+}
+
+// The same sum for units whose chunks are balanced (every full chunk is: 8192 = 128 << 6): no
+// tables, no LDS, no serial fold. Eight lanes share a leaf as above; leaf index = 8 * step +
+// (lane >> 3), so the three lowest tree levels are lane butterflies (xor 8, 16, 32), and the
+// levels above pair whole steps, folded as they arrive like a binary counter (the step loop is
+// unrolled, so that is straight-line code).
+__global__ __launch_bounds__(256) void mse_scale_balanced_kernel(MseArgs a, int last_leaf, int last_depth) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int k = lane & 7, slot = lane >> 3;
+  const long long unit = static_cast<long long>(blockIdx.x) * 4 + wave;
+  if (unit >= a.units) return;
+  const float* u = a.x + unit * a.len;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < a.len; c0 += kChunk) {
+    const bool last = c0 + kChunk >= a.len;
+    const int leaf_len = last ? last_leaf : 128, depth = last ? last_depth : 6;
+    const int count = 1 << depth;
+    const int steps = count > 8 ? count >> 3 : 1;
+    float lvl0 = 0.f, lvl1 = 0.f, lvl2 = 0.f, x = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < steps) {
+        const int leaf = s * 8 + slot;
+        const float* p = u + c0 + static_cast<long long>(leaf < count ? leaf : 0) * leaf_len + k;
+        float v[16];  // all loads first, then the ordered adds
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = (8 * (q + 1) <= leaf_len) ? p[8 * q] : 0.f;
+        float r = v[0] * v[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q)
+          if (8 * (q + 1) <= leaf_len) r = r + v[q] * v[q];
+        r = r + __shfl_xor(r, 1, kWave);  // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); addition commutes
+        r = r + __shfl_xor(r, 2, kWave);
+        r = r + __shfl_xor(r, 4, kWave);
+        if (count > 1) r = r + __shfl_xor(r, 8, kWave);   // leaves 2i, 2i+1
+        if (count > 2) r = r + __shfl_xor(r, 16, kWave);
+        if (count > 4) r = r + __shfl_xor(r, 32, kWave);
+        x = r;  // the sum of this step's (up to) eight leaves
+        if (s & 1) {
+          x = lvl0 + x;
+          if (s & 2) {
+            x = lvl1 + x;
+            if (s & 4) x = lvl2 + x; else lvl2 = x;
+          } else {
+            lvl1 = x;
+          }
+        } else {
+          lvl0 = x;
+        }
+      }
+    }
+    acc = c0 == 0 ? x : acc + x;
+  }
+  if (lane == 0) {
+    const float mean = acc / static_cast<float>(a.len);
+    a.scale[unit] = a.multiplier * __builtin_sqrtf(mean);
+  }
 }
 
 struct UnitPlan {
@@ -670,15 +811,14 @@ extern "C" int32_t mi355q_mse_scale_f32(const float* x, int64_t units, int64_t u
   if (unit_len == 0) return fail(MI355Q_BAD_SHAPE, "empty reduction unit");
   if (unit_len > 0x7FFFFFFFLL - 64) return fail(MI355Q_UNSUPPORTED, "unit_len too large");
   if (!x || !scale_out) return fail(MI355Q_BAD_ARG, "null pointer");
-  const UnitPlan p = plan_units(static_cast<int>(unit_len));
-  MseArgs a{x, units, static_cast<int>(unit_len), p.lds_stride, multiplier, scale_out};
-  const dim3 blk(p.waves * kWave);
-  const dim3 grid(static_cast<unsigned>((units + p.waves - 1) / p.waves));
+  MseArgs a{x, units, static_cast<int>(unit_len), 0, multiplier, scale_out};
   hipStream_t st = as_stream(stream);
-  if (p.use_lds)
-    hipLaunchKernelGGL(mse_scale_kernel<true>, grid, blk, p.smem, st, a);
+  const dim3 grid(static_cast<unsigned>((units + 3) / 4)), blk(4 * kWave);
+  int leaf = 0, depth = 0;
+  if (balanced_chunk(a.len - (a.len - 1) / kChunk * kChunk, &leaf, &depth))
+    hipLaunchKernelGGL(mse_scale_balanced_kernel, grid, blk, 0, st, a, leaf, depth);
   else
-    hipLaunchKernelGGL(mse_scale_kernel<false>, grid, blk, 0, st, a);
+    hipLaunchKernelGGL(mse_scale_leaves_kernel, grid, blk, 0, st, a);
   MI355Q_CHECK_LAUNCH("mse_scale launch");
   return MI355Q_OK;
 }

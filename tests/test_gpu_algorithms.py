@@ -315,3 +315,19 @@ def test_weight_resident_in_hbm_gives_the_same_result(alg, bits, gran):
       assert a.hadamard_size == b.hadamard_size
     else:
       assert np.array_equal(np.asarray(a), np.asarray(b)), field
+
+
+@pytest.mark.parametrize("cols", [8, 96, 128, 256, 1000, 257, 2816, 4096, 5120, 8192, 8200, 11008,
+                                  14336, 16384, 16391, 7, 24576])
+def test_mse_row_sums_follow_numpy_order_for_every_row_length(m, cols):
+  """Channelwise MSE scales (float32 sum of squares per row) are bit-identical to NumPy's for row
+  lengths whose pairwise tree is complete (lane-butterfly kernel: 4096 = 128 << 5, 11008 = 8192 +
+  (88 << 5), ...), for ragged ones (leaf-table kernel) and for rows of several 8192-chunks."""
+  rng = np.random.default_rng(cols)
+  w = (rng.standard_normal((37, cols)) * rng.uniform(0.01, 3.0, size=(37, 1))).astype(np.float32)
+  cfg = m.qtyping.TensorQuantizationConfig(num_bits=4, symmetric=True,
+                                           granularity=m.qtyping.QuantGranularity.CHANNELWISE)
+  p = m.mse.get_tensor_quant_params(op_info(m, "FULLY_CONNECTED", cfg), cfg, w)
+  ref = O.mse_quant_params(w, 4, "CHANNELWISE")
+  assert np.array_equal(p.scale, ref["scale"])
+  assert np.array_equal(np.asarray(p.quantized_data), ref["quantized_data"])

@@ -23,11 +23,12 @@ def main():
   g.build()
   import torch
   from mi355q import qtyping as q, runtime as rt
-  from mi355q.algorithms.uniform_quantize import hadamard_rotation, naive_min_max_quantize, octav
+  from mi355q.algorithms.uniform_quantize import hadamard_rotation, mse, naive_min_max_quantize, octav
   rng = np.random.default_rng(12)
   for name, mod, shape, bits, gran in (
       ("C2 min/max int8 channelwise", naive_min_max_quantize, (4096, 4096), 8, "CHANNELWISE"),
       ("C3 min/max int4 blockwise-128", naive_min_max_quantize, (4096, 11008), 4, "BLOCKWISE_128"),
+      ("MSE int4 channelwise", mse, (4096, 4096), 4, "CHANNELWISE"),
       ("OCTAV int4 channelwise", octav, (4096, 4096), 4, "CHANNELWISE"),
       ("Hadamard + OCTAV int4 channelwise", hadamard_rotation, (4096, 4096), 4, "CHANNELWISE")):
     w = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02)
