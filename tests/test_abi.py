@@ -64,3 +64,45 @@ def test_product_path_refuses_to_run_without_gpu(lib):
   from mi355q import runtime
   with pytest.raises(RuntimeError, match="no CPU fallback"):
     runtime.require_gpu()
+
+
+_SWEEP = r"""
+import ctypes, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {pkg!r})
+from mi355q import _ffi
+L = _ffi.lib()
+bad = []
+for name, (res, args) in _ffi.PROTOTYPES.items():
+  # (device_info's pointers are optional outputs; without a device it reports HIP_ERROR)
+  if res is not _ffi.c_i32 or name in ("mi355q_version", "mi355q_shutdown", "mi355q_device_info"):
+    continue
+  for mode, size in (("sizes 8", 8), ("sizes -1", -1), ("sizes 0", 0), ("sizes 128", 128)):
+    vals = []
+    for a in args:
+      if a in (_ffi.c_i64, _ffi.c_i32):
+        vals.append(size)
+      elif a is _ffi.c_size:
+        vals.append(0)
+      elif a is ctypes.c_float or a is ctypes.c_double:
+        vals.append(1.0)
+      else:
+        vals.append(None)        # every pointer is null
+    st = getattr(L, name)(*vals)
+    msg = L.mi355q_last_error()
+    ok = (st == 0 and size == 0) or (st in (-1, -2, -3) and msg)
+    if not ok:
+      bad.append((name, mode, st, msg))
+print("SWEPT", bad)
+"""
+
+
+def test_every_entry_point_rejects_null_pointers_and_bad_sizes_without_a_gpu():
+  """All pointers null with sizes 8 / -1 / 0 / 128: every entry point must come back with
+  BAD_ARG / BAD_SHAPE / UNSUPPORTED and a message (or OK for an empty request) before it touches
+  the device -- in a child process, so that a missing check shows up as a failed test, not as a
+  crashed test run."""
+  import subprocess
+  code = _SWEEP.format(root=ROOT, pkg=os.path.join(ROOT, "ai-edge-quantizer_amd"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, r.stderr[-2000:]
+  assert r.stdout.strip().splitlines()[-1] == "SWEPT []", r.stdout[-2000:]
