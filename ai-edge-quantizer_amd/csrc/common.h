@@ -25,6 +25,20 @@ void clear_error();
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// NumPy's pairwise summation splits n > 128 at n/2 rounded down to a multiple of 8. When
+// n = leaf << depth with leaf <= 128 a multiple of 8, every split is exact, so the chunk is
+// 2^depth equal leaves at offsets i * leaf under the complete binary tree. True for the sizes
+// real layers have (4096 = 128 << 5, 11008 - 8192 = 88 << 5, 14336 - 8192 = 96 << 6, ...).
+static inline bool balanced_chunk(int n, int* leaf, int* depth) {
+  int d = 0;
+  while ((n >> d) > 128) ++d;
+  const int l = n >> d;
+  if ((l << d) != n || l < 8 || (l % 8) != 0) return false;
+  *leaf = l;
+  *depth = d;
+  return true;
+}
+
 // -------------------------------------------------------------- device side
 constexpr int kWave = 64;  // gfx950 wavefront
 

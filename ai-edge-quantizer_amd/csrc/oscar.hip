@@ -256,6 +256,60 @@ __global__ __launch_bounds__(64) void group_sum_kernel(const double* __restrict_
   if (lane == 0) sums[blockIdx.x] = total;
 }
 
+// The same sum when every chunk's tree is complete (balanced_chunk, common.h; n = 2048, 4096,
+// 16384, 11008, ... rows): leaf index = 8 * step + (lane >> 3), so the accumulators and the
+// three lowest tree levels are lane butterflies and the levels above fold whole steps like a
+// binary counter (unrolled: straight-line code). No leaf tables, no LDS, no serial fold -- with
+// one block per group (a single block for channelwise scales) that serial part was the kernel.
+__global__ __launch_bounds__(64) void group_sum_balanced_kernel(const double* __restrict__ top2, int64_t n,
+                                                                int last_leaf, int last_depth,
+                                                                double* __restrict__ sums) {
+  const double* a = top2 + static_cast<int64_t>(blockIdx.x) * n;
+  const int lane = threadIdx.x, k = lane & 7, slot = lane >> 3;
+  double total = 0.0;
+  for (int64_t lo = 0; lo < n; lo += 8192) {
+    const bool last = lo + 8192 >= n;
+    const int leaf_len = last ? last_leaf : 128, depth = last ? last_depth : 6;
+    const int count = 1 << depth;
+    const int steps = count > 8 ? count >> 3 : 1;
+    double lvl0 = 0.0, lvl1 = 0.0, lvl2 = 0.0, x = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < steps) {
+        const int leaf = s * 8 + slot;
+        const double* p = a + lo + static_cast<int64_t>(leaf < count ? leaf : 0) * leaf_len + k;
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = (8 * (q + 1) <= leaf_len) ? p[8 * q] : 0.0;
+        double r = v[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q)
+          if (8 * (q + 1) <= leaf_len) r = r + v[q];
+        r = r + __shfl_xor(r, 1, kWave);
+        r = r + __shfl_xor(r, 2, kWave);
+        r = r + __shfl_xor(r, 4, kWave);
+        if (count > 1) r = r + __shfl_xor(r, 8, kWave);
+        if (count > 2) r = r + __shfl_xor(r, 16, kWave);
+        if (count > 4) r = r + __shfl_xor(r, 32, kWave);
+        x = r;
+        if (s & 1) {
+          x = lvl0 + x;
+          if (s & 2) {
+            x = lvl1 + x;
+            if (s & 4) x = lvl2 + x; else lvl2 = x;
+          } else {
+            lvl1 = x;
+          }
+        } else {
+          lvl0 = x;
+        }
+      }
+    }
+    total = (lo == 0) ? x : total + x;
+  }
+  if (lane == 0) sums[blockIdx.x] = total;
+}
+
 // -------------------------------------------------------------- winner_energy ---
 // eff[j] = sum over rows, in order, of wsq[group(j)][r] where winner[group(j)][r] == j.
 // blockIdx.x = group, blockIdx.y = 256-column slice of it: the block stages 1024 rows of the
@@ -754,8 +808,13 @@ extern "C" int32_t mi355q_oscar_group_terms_f32(const float* w, const double* s,
 #undef MI355Q_LAUNCH_TOP
   }
   MI355Q_CHECK_LAUNCH("oscar_group_top");
-  hipLaunchKernelGGL(group_sum_kernel, dim3(static_cast<unsigned>(G)), dim3(64), 0, st,
-                     top2_workspace, n, sums_out);
+  int leaf = 0, depth = 0;
+  if (balanced_chunk(static_cast<int>(n - (n - 1) / 8192 * 8192), &leaf, &depth))
+    hipLaunchKernelGGL(group_sum_balanced_kernel, dim3(static_cast<unsigned>(G)), dim3(64), 0, st,
+                       top2_workspace, n, leaf, depth, sums_out);
+  else
+    hipLaunchKernelGGL(group_sum_kernel, dim3(static_cast<unsigned>(G)), dim3(64), 0, st,
+                       top2_workspace, n, sums_out);
   MI355Q_CHECK_LAUNCH("oscar_group_sum");
   return MI355Q_OK;
 }

@@ -582,21 +582,8 @@ __global__ __launch_bounds__(256) void mse_scale_leaves_kernel(MseArgs a) {
   }
 }
 
-// n = leaf << depth with leaf <= 128 a multiple of 8: NumPy's recursion then halves exactly at
-// every level (n/2 is already a multiple of 8), so the chunk is 2^depth equal leaves at leaf
-// offsets i * leaf and the tree over them is the complete binary tree. True for the sizes real
-// layers have (4096 = 128 << 5, 11008 - 8192 = 88 << 5, 14336 - 8192 = 96 << 6, ...).
-bool balanced_chunk(int n, int* leaf, int* depth) {
-  int d = 0;
-  while ((n >> d) > 128) ++d;
-  const int l = n >> d;
-  if ((l << d) != n || l < 8 || (l % 8) != 0) return false;
-  *leaf = l;
-  *depth = d;
-  return true;
-}
-
-// The same sum for units whose chunks are balanced (every full chunk is: 8192 = 128 << 6): no
+// The same sum for units whose chunks are balanced (common.h; every full chunk is: 8192 =
+// 128 << 6): no
 // tables, no LDS, no serial fold. Eight lanes share a leaf as above; leaf index = 8 * step +
 // (lane >> 3), so the three lowest tree levels are lane butterflies (xor 8, 16, 32), and the
 // levels above pair whole steps, folded as they arrive like a binary counter (the step loop is
