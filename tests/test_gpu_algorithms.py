@@ -331,3 +331,39 @@ def test_mse_row_sums_follow_numpy_order_for_every_row_length(m, cols):
   ref = O.mse_quant_params(w, 4, "CHANNELWISE")
   assert np.array_equal(p.scale, ref["scale"])
   assert np.array_equal(np.asarray(p.quantized_data), ref["quantized_data"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_octav_masked_sums_with_designed_run_lengths(m, seed):
+  """Selected elements come in runs whose lengths are drawn from {1..12, 55..70, 120..140, 300}
+  and whose positions fall anywhere relative to the kernel's 64-lane batches and NumPy's
+  8192-element chunks: runs that end exactly at a batch end, cross one with a total of 7 / 8 / 9
+  elements, span several batches, or straddle a chunk boundary (where NumPy cuts them). Unselected
+  elements are tiny, so the masks stay put over the iterations and every iteration exercises the
+  same pattern; rows of several lengths, both signs."""
+  rng = np.random.default_rng(1000 + seed)
+  lengths = [64, 100, 127, 128, 1000, 4096, 8192, 8192 + 37, 8192 + 64 + 7, 20000]
+  pool = np.concatenate([np.arange(1, 13), np.arange(55, 71), np.arange(120, 141), [300]])
+  for n in lengths:
+    rows = []
+    for _ in range(6):
+      sign = np.empty(n, np.float32)
+      big = np.zeros(n, bool)
+      i, on = 0, bool(rng.integers(2))
+      while i < n:
+        run = int(rng.choice(pool)) if on else int(rng.integers(1, 9))
+        big[i:i + run] = on
+        sign[i:i + run] = 1.0 if rng.integers(2) else -1.0
+        i += run
+        on = not on
+      mag = np.where(big, rng.uniform(1.0, 2.0, n), rng.uniform(1e-4, 2e-4, n)).astype(np.float32)
+      rows.append(mag * sign)
+    for cut in (7, 8, 9, 63, 64, 65):                  # runs ending right around the first batch end
+      row = np.full(n, 1e-4, np.float32)
+      row[max(0, 64 - cut):min(n, 64 + (cut % 5))] = 1.5
+      rows.append(row)
+    w = np.stack(rows)
+    for bits in (4, 8):
+      got = m.octav._guess_clipping_with_octav(w, bits, (1,), 10, 3.0)
+      ref = O.octav_clip(w, bits, (1,), 10, 3.0)
+      assert np.array_equal(got, ref), (n, bits)
