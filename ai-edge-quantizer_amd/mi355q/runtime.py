@@ -198,7 +198,10 @@ def resident_sample(value):
   """A calibration sample entry as the calibrator keeps it: device tensors become HbmArray (no
   copy), host torch tensors become ndarrays, everything else is passed through."""
   if isinstance(value, torch.Tensor):
-    return HbmArray(value.detach()) if value.is_cuda else value.detach().numpy()
+    value = value.detach()
+    if value.dtype == torch.bfloat16:     # NumPy has no bfloat16; widening to float32 is exact
+      value = value.float()
+    return HbmArray(value) if value.is_cuda else value.numpy()
   return value
 
 
