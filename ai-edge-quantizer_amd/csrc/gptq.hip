@@ -286,7 +286,8 @@ struct ApplyArgs {
   float lo, hi;
   int zp_via_f64;       // int32/int64 zero points are added in FP64
   int diff_bits;        // width of (q - zp) in dequantize (8: wraps like int8 - int8)
-  float* err;           // [rows, NB]
+  float* err;           // [rows, kErrLd]: this block's 64 columns start at err_col
+  int err_col;
   int8_t* q;            // [rows, d]
 };
 
@@ -296,6 +297,8 @@ struct ApplyArgs {
 // (4 consecutive columns each), so the update is 4 multiply-subtracts per lane and 16 rows fit
 // in a workgroup: 16x the rows-only parallelism of one thread per row (2048 rows: 128
 // workgroups instead of 8) and a chain that is quantize-latency bound.
+constexpr int kLazyBlocks = 4;          // blocks whose far update is applied together
+constexpr int kErrLd = kLazyBlocks * NB;
 constexpr int kRowLanes = 16;           // lanes per row
 constexpr int kColsPerLane = NB / kRowLanes;
 
@@ -303,13 +306,7 @@ template <typename ST>
 __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
   __shared__ __attribute__((aligned(16))) float h[NB][NB];
   __shared__ float hd[NB];
-  for (int e = threadIdx.x; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    const float v = (r < a.nb && c < a.nb) ? a.hinv[static_cast<long long>(a.c0 + r) * a.d + a.c0 + c] : 0.f;
-    h[r][c] = v;
-    if (r == c) hd[r] = v;
-  }
-  __syncthreads();
+  __shared__ float es[256 / kRowLanes][NB];
   const int l = threadIdx.x % kRowLanes;              // which 4 columns
   const int r = blockIdx.x * (256 / kRowLanes) + threadIdx.x / kRowLanes;
   const bool live = r < a.rows;
@@ -321,6 +318,45 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
     const int c = l * kColsPerLane + k;
     w[k] = c < a.nb ? wrow[c] : 0.f;
   }
+  // Errors of the earlier blocks of this group have not reached these columns yet (the host
+  // applies them to the columns beyond the group once per group): W[:, block] -= E_b @
+  // Hinv[block b, this block] for every earlier block b, each product summed over its 64 columns
+  // and then subtracted, as the reference's per-block matmul does (gptq.py:213-214). 64 x 64
+  // tiles through LDS; ~1.3 us per earlier block instead of a GEMM launch per block.
+  for (int pb = 0; pb < a.err_col; pb += NB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+      const int k = e / NB, c = e % NB;
+      h[k][c] = c < a.nb ? a.hinv[static_cast<long long>(a.c0 - a.err_col + pb + k) * a.d + a.c0 + c] : 0.f;
+    }
+    for (int e = threadIdx.x; e < (256 / kRowLanes) * NB; e += 256) {
+      const int rw = e / NB, k = e % NB;
+      const long long row = static_cast<long long>(blockIdx.x) * (256 / kRowLanes) + rw;
+      es[rw][k] = row < a.rows ? a.err[row * kErrLd + pb + k] : 0.f;
+    }
+    __syncthreads();
+    float sum[kColsPerLane];
+#pragma unroll
+    for (int k = 0; k < kColsPerLane; ++k) sum[k] = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < NB; ++k) {
+      const float ek = es[threadIdx.x / kRowLanes][k];
+      const float4 hrow = *reinterpret_cast<const float4*>(&h[k][l * kColsPerLane]);
+      const float hv[4] = {hrow.x, hrow.y, hrow.z, hrow.w};
+#pragma unroll
+      for (int j = 0; j < kColsPerLane; ++j) sum[j] = sum[j] + ek * hv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < kColsPerLane; ++j) w[j] = w[j] - sum[j];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int r2 = e / NB, c = e % NB;
+    const float v = (r2 < a.nb && c < a.nb) ? a.hinv[static_cast<long long>(a.c0 + r2) * a.d + a.c0 + c] : 0.f;
+    h[r2][c] = v;
+    if (r2 == c) hd[r2] = v;
+  }
+  __syncthreads();
   const ST* sc = static_cast<const ST*>(a.scale);
   const int group = (threadIdx.x & 63) / kRowLanes;    // which of the wave's 4 rows
   // Scale / zero point change at most every 32 columns when the block size is a multiple of 32
@@ -381,7 +417,7 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
       e = e / hd[i];
       if (live && l == i / kColsPerLane) {
         a.q[static_cast<long long>(r) * a.d + col] = static_cast<int8_t>(qi);
-        a.err[static_cast<long long>(r) * NB + i] = e;
+        a.err[static_cast<long long>(r) * kErrLd + a.err_col + i] = e;
       }
       // intra-block rank-1 update: w[:, j] -= outer(err, hinv[c, j]) (product rounded, then subtracted)
       const float4 hrow = *reinterpret_cast<const float4*>(&h[i][l * kColsPerLane]);
@@ -393,7 +429,7 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
         w[k] = (l * kColsPerLane + k > i) ? updated : w[k];   // select, not a branch
       }
     } else if (live && l == i / kColsPerLane) {
-      a.err[static_cast<long long>(r) * NB + i] = 0.f;
+      a.err[static_cast<long long>(r) * kErrLd + a.err_col + i] = 0.f;
     }
   }
 }
@@ -660,7 +696,7 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
 
 extern "C" size_t mi355q_gptq_apply_workspace_bytes(int64_t rows, int64_t d) {
   if (rows <= 0 || d <= 0) return 0;
-  return (static_cast<size_t>(rows) * d + static_cast<size_t>(rows) * NB) * sizeof(float);
+  return (static_cast<size_t>(rows) * d + static_cast<size_t>(rows) * kErrLd) * sizeof(float);
 }
 
 extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d, const float* hinv,
@@ -694,19 +730,28 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
   a.nblk = scale_mode == 2 ? static_cast<int>(d / block_size) : 1;
   a.lo = static_cast<float>(narrow ? qmin + 1 : qmin); a.hi = static_cast<float>(qmax);
   a.zp_via_f64 = zp_via_f64; a.diff_bits = diff_bits; a.err = err; a.q = q_out;
-  for (int c0 = 0; c0 < a.d; c0 += NB) {
-    a.c0 = c0;
-    a.nb = a.d - c0 < NB ? a.d - c0 : NB;
-    const dim3 grid(static_cast<unsigned>((rows + (256 / kRowLanes) - 1) / (256 / kRowLanes)));
-    if (scale_is_f64)
-      hipLaunchKernelGGL((gptq_block_kernel<double>), grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((gptq_block_kernel<float>), grid, dim3(256), 0, st, a);
-    const int c1 = c0 + a.nb;
-    if (c1 < a.d) {
-      // W[:, c1:] -= err[:, :nb] @ Hinv[c0:c1, c1:]     (ref gptq.py:213-214)
-      GemmArgs<float> g{err, NB, 1, hinv + static_cast<long long>(c0) * d + c1, d, 1, wc + c1, d, 1,
-                        a.rows, a.d - c1, a.nb, -1.0f, 1.0f, 0, 0};
+  // Lazy batch updates: a block's error reaches the later blocks of its own group of kLazyBlocks
+  // inside their block kernels (they are quantized next), the columns beyond the group once per
+  // group, as one K = 256 product instead of four K = 64 ones -- a quarter of the passes over the
+  // trailing matrix, which is what the K = 64 updates were bound by (43 % of HBM bandwidth).
+  // Same mathematics as ref gptq.py:213-214 applied block by block; the far columns see the four
+  // products summed inside one GEMM before the subtraction instead of four subtractions.
+  for (int g0 = 0; g0 < a.d; g0 += kErrLd) {
+    const int g1 = a.d - g0 < kErrLd ? a.d : g0 + kErrLd;
+    for (int c0 = g0; c0 < g1; c0 += NB) {
+      a.c0 = c0;
+      a.nb = g1 - c0 < NB ? g1 - c0 : NB;
+      a.err_col = c0 - g0;
+      const dim3 grid(static_cast<unsigned>((rows + (256 / kRowLanes) - 1) / (256 / kRowLanes)));
+      if (scale_is_f64)
+        hipLaunchKernelGGL((gptq_block_kernel<double>), grid, dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((gptq_block_kernel<float>), grid, dim3(256), 0, st, a);
+    }
+    if (g1 < a.d) {
+      // W[:, g1:] -= err[:, group] @ Hinv[g0:g1, g1:]
+      GemmArgs<float> g{err, kErrLd, 1, hinv + static_cast<long long>(g0) * d + g1, d, 1, wc + g1, d, 1,
+                        a.rows, a.d - g1, g1 - g0, -1.0f, 1.0f, 0, 0};
       if (int32_t s = launch_gemm<float>(g, st)) return s;
     }
   }
