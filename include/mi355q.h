@@ -284,7 +284,9 @@ int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d, double damp_facto
  * K10 -- GPTQ weight update + quantization: for each 64-column block, quantize
  * column by column with the up-front scales, propagate err/Hinv[c,c] to the rest
  * of the block (rank-1, FP32, product rounded before the subtraction as NumPy's
- * np.outer does) and then to all later columns with one MFMA GEMM.
+ * np.outer does) and then to all later columns with MFMA GEMMs (lazy batch
+ * updates: the later blocks of a group of four catch up inside their own
+ * kernel, the columns beyond the group get one K = 256 product per group).
  * ref: algorithms/uniform_quantize/gptq.py:131-216 (_apply_gptq, blocksize 64)
  *   w [rows, d] float32 (not modified); hinv float32 [d, d]
  *   scale_mode 0: scale[1] (TENSORWISE); 1: scale[rows] (CHANNELWISE);
