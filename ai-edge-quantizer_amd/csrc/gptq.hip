@@ -293,21 +293,24 @@ struct ApplyArgs {
 
 // One 64-column block of the OBS sweep (ref gptq.py:180-212): columns are visited left to
 // right; each is quantized and its error pushed into the columns to its right - a dependent
-// chain of 64 quantize -> divide -> update steps per row. A row is spread over 16 lanes
-// (4 consecutive columns each), so the update is 4 multiply-subtracts per lane and 16 rows fit
-// in a workgroup: 16x the rows-only parallelism of one thread per row (2048 rows: 128
-// workgroups instead of 8) and a chain that is quantize-latency bound.
+// chain of 64 quantize -> divide -> update steps per row. A row is spread over kRowLanes lanes
+// (NB / kRowLanes consecutive columns each): with 32 lanes the update is 2 multiply-subtracts per
+// lane, the column's value is fetched with 2 readlanes, and 2048 rows make 256 workgroups (one
+// thread per row made 8, 16 lanes per row 128); the chain is quantize-latency bound.
 constexpr int kLazyBlocks = 4;          // blocks whose far update is applied together
 constexpr int kErrLd = kLazyBlocks * NB;
-constexpr int kRowLanes = 16;           // lanes per row
-constexpr int kColsPerLane = NB / kRowLanes;
+// lanes per row: 32 while the rows alone cannot fill the part (the chain is latency-bound and
+// shorter with 2 columns per lane), 16 once they can (every lane of a row repeats the
+// quantization arithmetic, so fewer lanes per row is less total issue)
+inline int row_lanes_for(long long rows) { return rows >= 8192 ? 16 : 32; }
 
-template <typename ST>
+template <typename ST, int kRowLanes>
 __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
+  constexpr int kColsPerLane = NB / kRowLanes;
   __shared__ __attribute__((aligned(16))) float h[NB][NB];
   __shared__ float hd[NB];
   __shared__ float es[256 / kRowLanes][NB];
-  const int l = threadIdx.x % kRowLanes;              // which 4 columns
+  const int l = threadIdx.x % kRowLanes;              // which columns
   const int r = blockIdx.x * (256 / kRowLanes) + threadIdx.x / kRowLanes;
   const bool live = r < a.rows;
   const int rr = live ? r : a.rows - 1;               // idle lanes shadow the last row, write nothing
@@ -341,10 +344,9 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
 #pragma unroll 8
     for (int k = 0; k < NB; ++k) {
       const float ek = es[threadIdx.x / kRowLanes][k];
-      const float4 hrow = *reinterpret_cast<const float4*>(&h[k][l * kColsPerLane]);
-      const float hv[4] = {hrow.x, hrow.y, hrow.z, hrow.w};
+      const float* hp = &h[k][l * kColsPerLane];
 #pragma unroll
-      for (int j = 0; j < kColsPerLane; ++j) sum[j] = sum[j] + ek * hv[j];
+      for (int j = 0; j < kColsPerLane; ++j) sum[j] = sum[j] + ek * hp[j];
     }
 #pragma unroll
     for (int j = 0; j < kColsPerLane; ++j) w[j] = w[j] - sum[j];
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
   }
   __syncthreads();
   const ST* sc = static_cast<const ST*>(a.scale);
-  const int group = (threadIdx.x & 63) / kRowLanes;    // which of the wave's 4 rows
+  const int group = (threadIdx.x & 63) / kRowLanes;    // which of the wave's rows
   // Scale / zero point change at most every 32 columns when the block size is a multiple of 32
   // (all BLOCKWISE_* granularities; the block starts at a multiple of 64): two loads per kernel,
   // none inside the dependent chain.
@@ -375,14 +377,15 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
   for (int i = 0; i < NB; ++i) {
     if (i < a.nb) {  // uniform
       const int col = a.c0 + i;
-      // column i of each of the wave's rows lives in lane 16*g + i/4: four uniform readlanes
-      // and a select instead of a ds_bpermute round trip
+      // column i of each of the wave's rows lives in lane kRowLanes*g + i/kColsPerLane: uniform
+      // readlanes and selects instead of a ds_bpermute round trip
       const float mine = w[i % kColsPerLane];
-      const float w0 = lane_bcast32(mine, 0 * kRowLanes + i / kColsPerLane);
-      const float w1 = lane_bcast32(mine, 1 * kRowLanes + i / kColsPerLane);
-      const float w2 = lane_bcast32(mine, 2 * kRowLanes + i / kColsPerLane);
-      const float w3 = lane_bcast32(mine, 3 * kRowLanes + i / kColsPerLane);
-      const float wi = group == 0 ? w0 : group == 1 ? w1 : group == 2 ? w2 : w3;
+      float wi = lane_bcast32(mine, i / kColsPerLane);
+#pragma unroll
+      for (int g = 1; g < kWave / kRowLanes; ++g) {
+        const float wg = lane_bcast32(mine, g * kRowLanes + i / kColsPerLane);
+        wi = group == g ? wg : wi;
+      }
       ST s = i < 32 ? s_lo : s_hi;
       int z = i < 32 ? z_lo : z_hi;
       if (per_step) {  // uniform; odd block sizes (the reference's tests use them): look it up
@@ -420,8 +423,7 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
         a.err[static_cast<long long>(r) * kErrLd + a.err_col + i] = e;
       }
       // intra-block rank-1 update: w[:, j] -= outer(err, hinv[c, j]) (product rounded, then subtracted)
-      const float4 hrow = *reinterpret_cast<const float4*>(&h[i][l * kColsPerLane]);
-      const float hv[4] = {hrow.x, hrow.y, hrow.z, hrow.w};
+      const float* hv = &h[i][l * kColsPerLane];
 #pragma unroll
       for (int k = 0; k < kColsPerLane; ++k) {
         const float p = e * hv[k];
@@ -742,11 +744,16 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
       a.c0 = c0;
       a.nb = g1 - c0 < NB ? g1 - c0 : NB;
       a.err_col = c0 - g0;
-      const dim3 grid(static_cast<unsigned>((rows + (256 / kRowLanes) - 1) / (256 / kRowLanes)));
-      if (scale_is_f64)
-        hipLaunchKernelGGL((gptq_block_kernel<double>), grid, dim3(256), 0, st, a);
+      const int rl = row_lanes_for(rows);
+      const dim3 grid(static_cast<unsigned>((rows + (256 / rl) - 1) / (256 / rl)));
+      if (scale_is_f64 && rl == 32)
+        hipLaunchKernelGGL((gptq_block_kernel<double, 32>), grid, dim3(256), 0, st, a);
+      else if (scale_is_f64)
+        hipLaunchKernelGGL((gptq_block_kernel<double, 16>), grid, dim3(256), 0, st, a);
+      else if (rl == 32)
+        hipLaunchKernelGGL((gptq_block_kernel<float, 32>), grid, dim3(256), 0, st, a);
       else
-        hipLaunchKernelGGL((gptq_block_kernel<float>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gptq_block_kernel<float, 16>), grid, dim3(256), 0, st, a);
     }
     if (g1 < a.d) {
       // W[:, g1:] -= err[:, group] @ Hinv[g0:g1, g1:]
