@@ -304,8 +304,14 @@ constexpr int kErrLd = kLazyBlocks * NB;
 // quantization arithmetic, so fewer lanes per row is less total issue)
 inline int row_lanes_for(long long rows) { return rows >= 8192 ? 16 : 32; }
 
-template <typename ST, int kRowLanes>
-__global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
+// kPlain: a full 64-column block, no zero points, scales that change at most every 32 columns --
+// what symmetric weight recipes produce; the uniform conditions (ragged last block, per-column
+// scale lookup, zero-point sums, int8 wrap of q - zp) then drop out of the 64 unrolled column
+// steps at compile time (they were ~15 branches and half of the ~170 instructions per step).
+template <typename ST, int kRowLanes, bool kPlain>
+// (the 16-lane form runs where rows fill the part: capped at 128 VGPRs for 4 waves per SIMD;
+// the 32-lane form is latency-bound and keeps the registers its hoisted LDS loads want)
+__global__ __launch_bounds__(256, kRowLanes == 16 ? 4 : 1) void gptq_block_kernel(ApplyArgs a) {
   constexpr int kColsPerLane = NB / kRowLanes;
   __shared__ __attribute__((aligned(16))) float h[NB][NB];
   __shared__ float hd[NB];
@@ -369,14 +375,19 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
     if (a.scale_mode == 2) return static_cast<long long>(rr) * a.nblk + col / a.block_size;
     return 0;
   };
-  const bool per_step = a.scale_mode == 2 && a.block_size % 32 != 0;
+  const bool per_step = !kPlain && a.scale_mode == 2 && a.block_size % 32 != 0;
   const long long si0 = scale_index(a.c0), si1 = scale_index(a.c0 + (a.nb > 32 ? 32 : 0));
   const ST s_lo = sc[si0], s_hi = sc[si1];
-  const int z_lo = a.zp ? a.zp[si0] : 0, z_hi = a.zp ? a.zp[si1] : 0;
+  const bool with_zp = !kPlain && a.zp != nullptr;
+  const int z_lo = with_zp ? a.zp[si0] : 0, z_hi = with_zp ? a.zp[si1] : 0;
+  // every lane keeps the results of its own columns and stores them once, after the chain
+  int q_own[kColsPerLane];
+  float e_own[kColsPerLane];
+#pragma unroll
+  for (int k = 0; k < kColsPerLane; ++k) { q_own[k] = 0; e_own[k] = 0.f; }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    if (i < a.nb) {  // uniform
-      const int col = a.c0 + i;
+    if (kPlain || i < a.nb) {  // uniform
       // column i of each of the wave's rows lives in lane kRowLanes*g + i/kColsPerLane: uniform
       // readlanes and selects instead of a ds_bpermute round trip
       const float mine = w[i % kColsPerLane];
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
       ST s = i < 32 ? s_lo : s_hi;
       int z = i < 32 ? z_lo : z_hi;
       if (per_step) {  // uniform; odd block sizes (the reference's tests use them): look it up
-        const long long si = scale_index(col);
+        const long long si = scale_index(a.c0 + i);
         s = sc[si];
         z = a.zp ? a.zp[si] : 0;
       }
@@ -397,31 +408,32 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
       int qi;
       float e;
       if constexpr (sizeof(ST) == 8) {
-        const double v = static_cast<double>(wi) / s + static_cast<double>(z);
+        double v = static_cast<double>(wi) / s;
+        if (with_zp) v = v + static_cast<double>(z);  // uniform; a zero zero-point changes nothing
         double q = __builtin_rint(v);
         q = fmin(fmax(q, static_cast<double>(a.lo)), static_cast<double>(a.hi));
         qi = (v != v) ? 0 : static_cast<int>(q);
         int dd = qi - z;
-        if (a.diff_bits == 8) dd = static_cast<int8_t>(dd);
+        if (with_zp && a.diff_bits == 8) dd = static_cast<int8_t>(dd);  // (q itself fits int8)
         const double dq = static_cast<double>(dd) * s;
         e = static_cast<float>(static_cast<double>(wi) - dq);  // np.subtract(f32, f64, out=f32)
       } else {
         float v = wi / s;
-        v = a.zp_via_f64 ? static_cast<float>(static_cast<double>(v) + static_cast<double>(z))
-                         : v + static_cast<float>(z);
+        if (with_zp)  // uniform; without zero points (symmetric weights) the sum is v itself
+          v = a.zp_via_f64 ? static_cast<float>(static_cast<double>(v) + static_cast<double>(z))
+                           : v + static_cast<float>(z);
         float q = __builtin_rintf(v);
         q = fminf(fmaxf(q, a.lo), a.hi);
         qi = (v != v) ? 0 : static_cast<int>(q);
         int dd = qi - z;
-        if (a.diff_bits == 8) dd = static_cast<int8_t>(dd);
+        if (with_zp && a.diff_bits == 8) dd = static_cast<int8_t>(dd);
         const float dq = static_cast<float>(dd) * s;
         e = wi - dq;
       }
       e = e / hd[i];
-      if (live && l == i / kColsPerLane) {
-        a.q[static_cast<long long>(r) * a.d + col] = static_cast<int8_t>(qi);
-        a.err[static_cast<long long>(r) * kErrLd + a.err_col + i] = e;
-      }
+      const bool mine_col = l == i / kColsPerLane;
+      q_own[i % kColsPerLane] = mine_col ? qi : q_own[i % kColsPerLane];
+      e_own[i % kColsPerLane] = mine_col ? e : e_own[i % kColsPerLane];
       // intra-block rank-1 update: w[:, j] -= outer(err, hinv[c, j]) (product rounded, then subtracted)
       const float* hv = &h[i][l * kColsPerLane];
 #pragma unroll
@@ -430,8 +442,29 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(ApplyArgs a) {
         const float updated = w[k] - p;
         w[k] = (l * kColsPerLane + k > i) ? updated : w[k];   // select, not a branch
       }
-    } else if (live && l == i / kColsPerLane) {
-      a.err[static_cast<long long>(r) * kErrLd + a.err_col + i] = 0.f;
+    }
+  }
+  if (live) {
+    int8_t* qrow = a.q + static_cast<long long>(r) * a.d + a.c0 + l * kColsPerLane;
+    float* erow = a.err + static_cast<long long>(r) * kErrLd + a.err_col + l * kColsPerLane;
+    if (kPlain && (a.d % kColsPerLane) == 0) {  // one packed store each (c0 is a multiple of 64)
+      unsigned packed = 0;
+#pragma unroll
+      for (int k = 0; k < kColsPerLane; ++k) packed |= (static_cast<unsigned>(q_own[k]) & 0xFFu) << (8 * k);
+      if constexpr (kColsPerLane == 4) {
+        *reinterpret_cast<unsigned*>(qrow) = packed;
+        *reinterpret_cast<float4*>(erow) = make_float4(e_own[0], e_own[1], e_own[2], e_own[3]);
+      } else {
+        *reinterpret_cast<unsigned short*>(qrow) = static_cast<unsigned short>(packed);
+        *reinterpret_cast<float2*>(erow) = make_float2(e_own[0], e_own[1]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kColsPerLane; ++k) {
+        const int c = l * kColsPerLane + k;
+        if (c < a.nb) qrow[k] = static_cast<int8_t>(q_own[k]);
+        erow[k] = c < a.nb ? e_own[k] : 0.f;
+      }
     }
   }
 }
@@ -746,14 +779,16 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
       a.err_col = c0 - g0;
       const int rl = row_lanes_for(rows);
       const dim3 grid(static_cast<unsigned>((rows + (256 / rl) - 1) / (256 / rl)));
-      if (scale_is_f64 && rl == 32)
-        hipLaunchKernelGGL((gptq_block_kernel<double, 32>), grid, dim3(256), 0, st, a);
-      else if (scale_is_f64)
-        hipLaunchKernelGGL((gptq_block_kernel<double, 16>), grid, dim3(256), 0, st, a);
-      else if (rl == 32)
-        hipLaunchKernelGGL((gptq_block_kernel<float, 32>), grid, dim3(256), 0, st, a);
-      else
-        hipLaunchKernelGGL((gptq_block_kernel<float, 16>), grid, dim3(256), 0, st, a);
+      const bool plain = a.nb == NB && zero_point == nullptr && !(scale_mode == 2 && block_size % 32 != 0);
+#define MI355Q_BLOCK(ST, RL, PL) hipLaunchKernelGGL((gptq_block_kernel<ST, RL, PL>), grid, dim3(256), 0, st, a)
+      if (scale_is_f64) {
+        if (rl == 32) { if (plain) MI355Q_BLOCK(double, 32, true); else MI355Q_BLOCK(double, 32, false); }
+        else          { if (plain) MI355Q_BLOCK(double, 16, true); else MI355Q_BLOCK(double, 16, false); }
+      } else {
+        if (rl == 32) { if (plain) MI355Q_BLOCK(float, 32, true); else MI355Q_BLOCK(float, 32, false); }
+        else          { if (plain) MI355Q_BLOCK(float, 16, true); else MI355Q_BLOCK(float, 16, false); }
+      }
+#undef MI355Q_BLOCK
     }
     if (g1 < a.d) {
       // W[:, g1:] -= err[:, group] @ Hinv[g0:g1, g1:]
