@@ -120,7 +120,10 @@ def _apply_gptq(tensor_content: np.ndarray, quant_params: qtyping.UniformQuantPa
                      f" {zp.dtype}.")
   sdt = np.float64 if scale.dtype == np.float64 else np.float32
   s_dev = rt.to_device(np.ascontiguousarray(scale.reshape(-1), dtype=sdt))
-  z_dev = rt.to_device(np.ascontiguousarray(np.broadcast_to(zp, scale.shape).reshape(-1)).astype(np.int32))
+  # all-zero zero points (symmetric recipes) are passed as "none": same results, and the block
+  # kernel then runs its specialised form
+  z_dev = (rt.to_device(np.ascontiguousarray(np.broadcast_to(zp, scale.shape).reshape(-1)).astype(np.int32))
+           if np.any(zp) else None)
   narrow = bool(quant_params.symmetric and quant_params.num_bits >= 8)
   diff_bits = min(32, np.result_type(np.int8, zp.dtype).itemsize * 8)
   q = ops.gptq_apply(rt.to_device(tensor_content), hinv, s_dev, z_dev, mode, bs,

@@ -287,3 +287,29 @@ def test_hessians_stay_in_hbm_and_behave_like_arrays(m):
   mixed = qsv_utils.gptq_and_moving_average_update(
       {**q1, "hessian": np.asarray(h1)}, {**q2, "hessian": np.asarray(h2)})
   assert isinstance(mixed["hessian"], np.ndarray) and np.array_equal(mixed["hessian"], np.asarray(merged["hessian"]))
+
+
+@pytest.mark.parametrize("rows,d,mode,bs", [(96, 256, 1, 0), (40, 448, 2, 32), (8200, 128, 1, 0),
+                                            (33, 200, 1, 0), (64, 320, 0, 0)])
+def test_apply_specialised_and_general_block_kernels_agree(m, rows, d, mode, bs):
+  """Zero points given as an all-zero tensor take the general block kernel, zero points given as
+  none the specialised one (conditions resolved at compile time, results kept in registers and
+  stored packed); 16 and 32 lanes per row, ragged last block, in-group catch-up: same integers."""
+  torch = m.torch
+  gen = torch.Generator(device="cuda")
+  gen.manual_seed(rows * 7 + d)
+  x = torch.randn((2048, d), generator=gen, device="cuda")
+  hinv, info = m.ops.gptq_hinv(m.ops.gptq_xtx(x, 2.0 / 2048))
+  assert int(info.item()) == 0
+  w = torch.randn((rows, d), generator=gen, device="cuda") * 0.05
+  if mode == 0:
+    scale = (w.abs().amax() / 7).reshape(1)
+  elif mode == 1:
+    scale = (w.abs().amax(dim=1) / 7).contiguous()
+  else:
+    scale = (w.reshape(rows, d // bs, bs).abs().amax(dim=2) / 7).reshape(-1).contiguous()
+  zeros = torch.zeros(scale.numel(), dtype=torch.int32, device="cuda")
+  a = m.ops.gptq_apply(w, hinv, scale, None, mode, bs, 4, False, False, 8)
+  b = m.ops.gptq_apply(w, hinv, scale, zeros, mode, bs, 4, False, True, 32)
+  assert torch.equal(a, b)
+  assert int(a.to(torch.int32).abs().max()) <= 8 and int((a != 0).sum()) > 0
