@@ -262,6 +262,44 @@ __global__ __launch_bounds__(256) void dequantize_kernel(
   }
 }
 
+// Inverse of K4: one packed byte per loop step -> PER sign-extended int8 values (the int8
+// containers UniformQuantParams.quantized_data holds). Every thread expands 4 packed bytes.
+template <int BITS>
+__global__ __launch_bounds__(256) void unpack_kernel(const uint8_t* __restrict__ packed, int64_t n,
+                                                    int8_t* __restrict__ q) {
+  constexpr int PER = 8 / BITS;
+  const int64_t n_in = (n + PER - 1) / PER;
+  const int64_t words = (n_in + 3) / 4;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  const bool al = ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(q)) & 3) == 0;
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; w < words; w += stride) {
+    uint32_t v = 0;
+    if (al && w * 4 + 4 <= n_in) v = reinterpret_cast<const uint32_t*>(packed)[w];
+    else for (int b = 0; b < 4 && w * 4 + b < n_in; ++b) v |= static_cast<uint32_t>(packed[w * 4 + b]) << (8 * b);
+    const int64_t out0 = w * 4 * PER;
+    uint32_t o[PER];   // 4 * PER output bytes as PER dwords
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int idx = k * 4 + b;   // output element index within the group
+        const int field = static_cast<int>((v >> ((idx / PER) * 8 + (idx % PER) * BITS)) & ((1 << BITS) - 1));
+        const int val = (field ^ (1 << (BITS - 1))) - (1 << (BITS - 1));   // sign extend
+        acc |= static_cast<uint32_t>(val & 0xFF) << (8 * b);
+      }
+      o[k] = acc;
+    }
+    if (al && out0 + 4 * PER <= n) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) reinterpret_cast<uint32_t*>(q + out0)[k] = o[k];
+    } else {
+      for (int idx = 0; idx < 4 * PER && out0 + idx < n; ++idx)
+        q[out0 + idx] = static_cast<int8_t>((o[idx / 4] >> (8 * (idx % 4))) & 0xFF);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ K4 ---
 // Each thread builds 4 output bytes from 8 (int4) or 16 (int2) input bytes.
 template <int BITS>
@@ -606,6 +644,27 @@ extern "C" int32_t mi355q_pack_bits(const int8_t* q, int64_t n, int32_t bits, ui
     return fail(MI355Q_UNSUPPORTED, "pack_bits supports 2, 4 and 8 bits");
   }
   MI355Q_CHECK_LAUNCH("pack launch");
+  return MI355Q_OK;
+}
+
+extern "C" int32_t mi355q_unpack_bits(const uint8_t* packed, int64_t n, int32_t bits, int8_t* q_out,
+                                      void* stream) {
+  clear_error();
+  if (n < 0) return fail(MI355Q_BAD_ARG, "negative size");
+  if (n == 0) return MI355Q_OK;
+  if (!packed || !q_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  hipStream_t st = as_stream(stream);
+  if (bits == 8) {
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3(grid_for(n)), dim3(256), 0, st,
+                       reinterpret_cast<const int8_t*>(packed), n, reinterpret_cast<uint8_t*>(q_out));
+  } else if (bits == 4) {
+    hipLaunchKernelGGL((unpack_kernel<4>), dim3(grid_for((n + 7) / 8)), dim3(256), 0, st, packed, n, q_out);
+  } else if (bits == 2) {
+    hipLaunchKernelGGL((unpack_kernel<2>), dim3(grid_for((n + 15) / 16)), dim3(256), 0, st, packed, n, q_out);
+  } else {
+    return fail(MI355Q_UNSUPPORTED, "unpack_bits supports 2, 4 and 8 bits");
+  }
+  MI355Q_CHECK_LAUNCH("unpack launch");
   return MI355Q_OK;
 }
 

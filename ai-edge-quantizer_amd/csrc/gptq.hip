@@ -11,6 +11,9 @@
 // sgemm (FP32), scales it into FLOAT64 (the `2.0 / np.array(n)` factor promotes),
 // factors in FLOAT64 and inverts through FP32 LAPACK; here the whole inverse is
 // done in FP64 and cast to FP32 at the end (tolerance class T2).
+#include <cstdlib>
+#include <mutex>
+
 #include "gemm.h"
 
 namespace mi355q {
@@ -536,8 +539,22 @@ struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t panel_done = nullptr, update_done = nullptr;
   bool tried = false;
+  long long debug_delay_ticks = 0;   // MI355Q_DEBUG_SIDE_DELAY_US: see side_delay_kernel
 };
+
+// Test hook (tests/test_gpu_gptq.py): holds the side stream back for a while in front of every
+// look-ahead update, so that an ordering bug between the two streams shows up as a wrong inverse
+// instead of depending on how short the side GEMM happens to be. wall_clock64 ticks at 100 MHz.
+__global__ void side_delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 SideStream g_side[64];
+// One call at a time enqueues look-ahead work per process: the side stream and its two events
+// are shared by every caller of a device, and hipStreamWaitEvent captures the event's state at
+// the time of the call, so record/wait pairs of two host threads must not interleave. The lock
+// is held only while a call enqueues (the entry point never synchronizes).
+std::mutex g_side_mutex;
 
 SideStream* side_stream() {
   int dev = 0;
@@ -566,6 +583,7 @@ SideStream* side_stream() {
     s.stream = st;
     s.panel_done = a;
     s.update_done = b;
+    if (const char* us = getenv("MI355Q_DEBUG_SIDE_DELAY_US")) s.debug_delay_ticks = atoll(us) * 100;
   }
   return s.stream ? &s : nullptr;
 }
@@ -573,6 +591,7 @@ SideStream* side_stream() {
 
 extern "C" int32_t mi355q_shutdown(void) {
   clear_error();
+  std::lock_guard<std::mutex> lock(g_side_mutex);
   for (SideStream& s : g_side) {
     if (s.stream) {
       (void)hipStreamSynchronize(s.stream);
@@ -625,8 +644,16 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   // (d-k)^2/2 doubles for 64 flops each), so the 64-column steps only update the rest of their
   // own 512-column outer block; the matrix behind it gets one rank-512 update per outer block.
   constexpr int OB = 8 * NB;
+  std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
+  if (d >= 4096) side_lock.lock();
   SideStream* side = d >= 4096 ? side_stream() : nullptr;
   bool side_busy = false;
+  // Whatever way this call leaves the loop, the caller's stream waits for the side stream's last
+  // update: the workspace it writes belongs to the caller, who may free it right after an error.
+  struct JoinSide {
+    SideStream*& side; bool& busy; hipStream_t st;
+    ~JoinSide() { if (busy && side) (void)hipStreamWaitEvent(st, side->update_done, 0); }
+  } join_side{side, side_busy, st};
   for (int k0 = 0; k0 < d; k0 += OB) {
     const int ob = d - k0 < OB ? d - k0 : OB;
     for (int k = k0; k < k0 + ob; k += NB) {
@@ -655,6 +682,13 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
       double* c = a + static_cast<long long>(k0 + ob) * d + k0 + ob;
       const int next = m2 < OB ? m2 : OB;       // width of the next outer block
       if (side == nullptr || m2 - next < 2048) {
+        // the previous outer block's `rest` update may still be read-modify-writing this very
+        // trailing region on the side stream: it has to land before this update starts
+        if (side_busy) {
+          if (hipStreamWaitEvent(st, side->update_done, 0) != hipSuccess)
+            return fail(MI355Q_HIP_ERROR, "look-ahead: wait failed");
+          side_busy = false;
+        }
         GemmArgs<double> gu{l, d, 1, l, 1, d, c, d, 1, m2, m2, ob, -1.0, 1.0, 1, 0};
         if (int32_t e = launch_gemm<double>(gu, st)) return e;
       } else {
@@ -670,6 +704,8 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
         // factorization (disjoint columns)
         if (hipStreamWaitEvent(side->stream, side->panel_done, 0) != hipSuccess)
           return fail(MI355Q_HIP_ERROR, "look-ahead: wait failed");
+        if (side->debug_delay_ticks > 0)
+          hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(1), 0, side->stream, side->debug_delay_ticks);
         const double* l2 = l + static_cast<long long>(next) * d;
         double* c2 = c + static_cast<long long>(next) * d + next;
         GemmArgs<double> rest{l2, d, 1, l2, 1, d, c2, d, 1, m2 - next, m2 - next, ob, -1.0, 1.0, 1, 0};
@@ -680,8 +716,12 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
       }
     }
   }
-  if (side_busy && hipStreamWaitEvent(st, side->update_done, 0) != hipSuccess)
-    return fail(MI355Q_HIP_ERROR, "look-ahead: wait failed");
+  if (side_busy) {
+    if (hipStreamWaitEvent(st, side->update_done, 0) != hipSuccess)
+      return fail(MI355Q_HIP_ERROR, "look-ahead: wait failed");
+    side_busy = false;
+  }
+  if (side_lock.owns_lock()) side_lock.unlock();
   MI355Q_CHECK_LAUNCH("gptq cholesky launch");
   // ---- in-place inverse of the lower-triangular factor by pairwise merging: the diagonal
   // NB-blocks are already inverted; at level s every pair of adjacent inverted blocks

@@ -74,7 +74,10 @@ __device__ __forceinline__ float make_scale(uint32_t absmax_bits, const float* c
       pos = fminf(pos, 65280.0f * static_cast<float>((1 << BITS) - 1));
       neg = fmaxf(neg, -65280.0f * static_cast<float>(1 << BITS));
     }
-    bound = fminf(fmaxf(bound, neg), pos);  // np.clip(bound, neg, pos)
+    // np.clip(bound, neg, pos) = minimum(maximum(bound, neg), pos), both NaN-propagating:
+    // a NaN bound stays NaN (fminf / fmaxf would return the other operand), a NaN clip makes it NaN
+    if (bound == bound) bound = fminf(fmaxf(bound, neg), pos);
+    if (pos != pos) bound = pos;
   }
   float s = bound / QRange<BITS>::qmax;
   if constexpr (BLOCKWISE) s = round_scale_blockwise(s, half_bits);

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "mi355q_dequantize_f32": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i32,
                                       c_i32, c_ptr, c_ptr]),
     "mi355q_pack_bits": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr]),
+    "mi355q_unpack_bits": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr]),
     "mi355q_act_minmax_workspace_bytes": (c_size, [c_i32]),
     "mi355q_act_minmax_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_f32, c_f32, c_i32, c_ptr, c_ptr,
                                       c_size, c_ptr]),

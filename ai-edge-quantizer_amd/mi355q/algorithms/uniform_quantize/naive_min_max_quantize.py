@@ -17,6 +17,7 @@ import numpy as np
 
 from ... import ops
 from ... import qtyping
+from ... import requant_queue
 from ... import runtime as rt
 from ...utils import tfl_flatbuffer_utils
 from ..utils import common_utils
@@ -50,6 +51,24 @@ def fused_weight_layout(tensor_content: np.ndarray, granularity, quantized_dim):
 
 
 
+def packs_in_kernel(layout, num_bits: int) -> bool:
+  """The vectorized kernels pack sub-byte results; the generic fallback (odd widths) does not
+  (include/mi355q.h)."""
+  _, cols, block = layout
+  return (num_bits in (2, 4) and cols % 4 == 0
+          and (block in (32, 64, 128, 256) or (block == 0 and cols <= 16384)))
+
+
+_MIN_BATCHED_BYTES = 64 << 10
+
+
+def batchable(layout, tensor_content) -> bool:
+  """Tensors worth queueing for the batched launch (requant_queue): tiny ones are quantized on
+  the spot, their launch cost is the same either way."""
+  rows, cols, _ = layout
+  return rows * cols * 4 >= _MIN_BATCHED_BYTES
+
+
 def fused_symmetric_requant(tensor_content: np.ndarray, layout, num_bits: int,
                             clip: Optional[np.ndarray] = None):
   """Runs mi355q_requant_sym_f32; returns (scale f32 [n_scales], q int8 like tensor).
@@ -65,9 +84,7 @@ def fused_symmetric_requant(tensor_content: np.ndarray, layout, num_bits: int,
     clip = (rt.to_device(np.ascontiguousarray(clip, np.float32).reshape(-1))
             if isinstance(clip, np.ndarray) else clip.reshape(-1))
   c = clip
-  # the vectorized kernels pack; the generic fallback (odd widths) does not (mi355q.h)
-  sub_byte = (num_bits in (2, 4) and cols % 4 == 0
-              and (block in (32, 64, 128, 256) or (block == 0 and cols <= 16384)))
+  sub_byte = packs_in_kernel(layout, num_bits)
   r = ops.requant_sym(x, block, num_bits, clip=c, want_q=True, want_packed=sub_byte)
   if tensor_content.nbytes >= rt.KEEP_IN_HBM_BYTES:
     # large weights stay in HBM until the model writer copies them (packed bytes for sub-byte
@@ -121,6 +138,18 @@ def get_tensor_quant_params(
   if (not have_qsv and cfg.symmetric and cfg.num_bits in (2, 4, 8) and weight_cfg is not None
       and weight_cfg.granularity == cfg.granularity):
     layout = fused_weight_layout(tensor_content, cfg.granularity, quantized_dim)
+    queue = requant_queue.active()
+    if layout is not None and queue is not None and batchable(layout, tensor_content):
+      # inside ParamsGenerator's loop: enqueue, equally shaped weights leave in one launch
+      scale, q, slot = queue.submit(
+          tensor_content, layout, cfg.num_bits,
+          scale_shape_for(tensor_content, cfg.granularity, quantized_dim), packs_in_kernel(layout, cfg.num_bits))
+      params = qtyping.UniformQuantParams(
+          scale=scale, zero_point=np.zeros(scale.shape, np.int8), num_bits=cfg.num_bits,
+          symmetric=True, quantized_dimension=quantized_dim, block_size=block_size,
+          quantized_data=q)
+      queue.attach(slot, params)
+      return params
     if layout is not None:
       scale, q = fused_symmetric_requant(tensor_content, layout, cfg.num_bits)
       scale = scale.reshape(scale_shape_for(tensor_content, cfg.granularity, quantized_dim))

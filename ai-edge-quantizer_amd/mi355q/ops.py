@@ -178,6 +178,19 @@ def pack_bits(q: torch.Tensor, bits: int) -> torch.Tensor:
   return out
 
 
+def unpack_bits(packed: torch.Tensor, n: int, bits: int) -> torch.Tensor:
+  """Inverse of K4: n sign-extended int8 values from the packed bytes of one fused launch."""
+  rt.require_gpu()
+  if packed.dtype != torch.uint8 or not packed.is_cuda:
+    raise TypeError("unpack_bits expects a uint8 device tensor")
+  packed = packed.contiguous().view(-1)
+  if packed.numel() != -(-n * bits // 8):
+    raise ValueError("packed size does not match the element count")
+  out = rt.empty((n,), torch.int8)
+  _ffi.check(_ffi.lib().mi355q_unpack_bits(rt.ptr(packed), n, bits, rt.ptr(out), rt.stream_ptr()))
+  return out
+
+
 def cast_f16(x: torch.Tensor) -> torch.Tensor:
   """float32 -> float16 (RNE), same shape. ref: nonlinear_quantize/float_casting.py:157-160."""
   rt.require_gpu()

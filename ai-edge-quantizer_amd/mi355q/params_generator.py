@@ -13,6 +13,7 @@ from typing import Any, Optional
 from . import algorithm_manager
 from . import default_policy
 from . import qtyping
+from . import requant_queue
 from .algorithms.utils import common_utils
 from .utils import tfl_flatbuffer_utils
 
@@ -141,6 +142,10 @@ class ParamsGenerator:
         self.model_quant_results[r.tensor_name] = r
         continue
       if r.producer is not None:
+        if cur.producer is not None:      # a tensor has exactly one source op (ref :229-238)
+          raise RuntimeError(
+              "Tensor %s received multiple quantization parameters from the source op, which"
+              " should not happen as every tensor should have only one source op." % r.tensor_name)
         cur.producer = r.producer
       if r.consumers:
         cur.consumers = (cur.consumers or []) + list(r.consumers)
@@ -200,5 +205,10 @@ class ParamsGenerator:
           "Model quantization statistics values (QSVs) are required for the input recipe. This"
           " can be obtained by running calibration on sample dataset.")
     model_qsvs = model_qsvs if model_qsvs is not None else {}
-    return self.finish(self.materialize_op(item, model_qsvs)
-                       for item in self.plan_ops(model_recipe_manager))
+    # The op loop only enqueues the fused min/max weight requantizations; equally shaped weights
+    # leave in one batched launch per group when the queue flushes (requant_queue), at the latest
+    # before the shared-constant checks of finish() compare parameters by value.
+    with requant_queue.batching() as queue:
+      per_op = [self.materialize_op(item, model_qsvs) for item in self.plan_ops(model_recipe_manager)]
+    self.batch_stats = dict(queue.stats)
+    return self.finish(per_op)

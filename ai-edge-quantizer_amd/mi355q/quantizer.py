@@ -149,8 +149,9 @@ class Quantizer:
     quantized ModelT tree for inspection."""
     if not self.get_quantization_recipe():
       raise RuntimeError("Can not quantize without a quantization recipe.")
-    params = params_generator.ParamsGenerator(self.float_model).generate_quantization_parameters(
-        self._recipe_manager, calibration_result)
+    generator = params_generator.ParamsGenerator(self.float_model)
+    params = generator.generate_quantization_parameters(self._recipe_manager, calibration_result)
+    self.batch_stats = getattr(generator, "batch_stats", None)   # launches / tensors of the batched path
     modifier = model_modifier.ModelModifier(self.float_model)
     serialized = modifier.modify_model(params, serialize_to_path=serialize_to_path)
     self.quantized_model_object = modifier.quantized_model_object

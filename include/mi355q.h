@@ -158,6 +158,14 @@ int32_t mi355q_cast_f32_to_f16(const float* x, int64_t n, uint16_t* out, void* s
  * ------------------------------------------------------------------------ */
 int32_t mi355q_pack_bits(const int8_t* q, int64_t n, int32_t bits, uint8_t* out,
                          void* stream);
+/* The inverse: n sign-extended int8 values from ceil(n * bits / 8) packed bytes. The fused
+ * requantization of sub-byte targets writes only the packed bytes the model file stores
+ * (4.5 instead of 5.5 bytes of HBM traffic per int4 weight); the int8 containers of
+ * UniformQuantParams.quantized_data (ref: uniform_quantize_tensor.py:357-360 yields them,
+ * transformations/quantize_tensor.py:176-194 packs them) are produced from those bytes only
+ * if a caller actually reads them. */
+int32_t mi355q_unpack_bits(const uint8_t* packed, int64_t n, int32_t bits, int8_t* q_out,
+                           void* stream);
 
 /* ------------------------------------------------------------------------
  * K7 -- activation statistics: scalar min over x > lo, max over x < hi, with the

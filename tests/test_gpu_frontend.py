@@ -5,6 +5,8 @@ the same model (tests/golden/gen/make_golden.py::c1_cases), plus calibration flo
 import numpy as np
 import pytest
 
+import parity_rates
+
 from golden_util import case_names, sha
 from oracle import aeq_oracle as O
 
@@ -213,8 +215,7 @@ def test_gptq_calibrate_merge_and_quantize(m):
   p = params["w"].consumers[0].parameters
   oref = O.gptq_quant_params(w, 4, True, "CHANNELWISE", {"activation_tensor_qsv": ref})
   assert np.array_equal(p.scale, oref["scale"])
-  diff = np.abs(p.quantized_data.astype(np.int32) - oref["quantized_data"].astype(np.int32))
-  assert diff.max() <= 1 and (diff != 0).mean() <= 5e-3
+  parity_rates.check("gptq through ParamsGenerator (frontend)", p.quantized_data, oref["quantized_data"], parity_rates.T2)
 
 
 def test_hadamard_recipe_materializes_rotation_instruction(m):

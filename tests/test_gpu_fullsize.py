@@ -5,6 +5,8 @@ import warnings
 import numpy as np
 import pytest
 
+import parity_rates
+
 from golden_util import gen_c2
 from oracle import aeq_oracle as O
 
@@ -102,8 +104,7 @@ def test_hadamard_octav_4096_against_oracle(m):
   p = m.had.get_tensor_quant_params(info, cfg, w)
   assert p.hadamard.hadamard_size == 4096
   np.testing.assert_allclose(p.scale, ref["scale"], rtol=2e-6)
-  diff = np.abs(p.quantized_data.astype(np.int32) - ref["quantized_data"].astype(np.int32))
-  assert diff.max() <= 1 and (diff != 0).mean() <= 2e-4
+  parity_rates.check("hadamard(h=4096)+octav int4 512x4096 vs oracle", p.quantized_data, ref["quantized_data"], parity_rates.T2)
 
 
 def test_octav_4096_rows_bit_exact(m):
@@ -131,8 +132,8 @@ def test_gptq_gemma_attention_shape_against_oracle(m):
   p = m.gptq.get_tensor_quant_params(info, cfg, w,
                                      {"activation_tensor_qsv": {"hessian": hg, "num_samples": 8}})
   assert np.array_equal(p.scale, ref["scale"])
-  diff = np.abs(p.quantized_data.astype(np.int32) - ref["quantized_data"].astype(np.int32))
-  assert diff.max() <= 1 and (diff != 0).mean() <= 2e-3
+  parity_rates.check("gptq end to end [256,2048] int4 (own Hessian + inverse) vs oracle", p.quantized_data,
+                     ref["quantized_data"], parity_rates.T2)
 
 
 @pytest.mark.parametrize("gran", ["CHANNELWISE", "BLOCKWISE_32"])
