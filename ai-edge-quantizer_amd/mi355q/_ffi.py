@@ -73,9 +73,19 @@ PROTOTYPES = {
                                           c_ptr, c_ptr]),
     "mi355q_dwr_scales_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_dwr_max_error_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "mi355q_comm_unique_id": (c_i32, [c_ptr]),
+    "mi355q_comm_init_rank": (c_i32, [ctypes.POINTER(ctypes.c_void_p), c_i32, c_ptr, c_i32]),
+    "mi355q_comm_info": (c_i32, [c_ptr, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "mi355q_comm_destroy": (c_i32, [c_ptr]),
+    "mi355q_allgather_minmax": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    "mi355q_allreduce_minmax_f32": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    "mi355q_allreduce_sum_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr]),
+    "mi355q_allreduce_sum_f64": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr]),
+    "mi355q_allreduce_hessian_f64": (c_i32, [c_ptr, c_ptr, c_i64, c_f64, c_ptr]),
 }
 
-STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "BAD_SHAPE", -3: "UNSUPPORTED", -4: "HIP_ERROR"}
+STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "BAD_SHAPE", -3: "UNSUPPORTED", -4: "HIP_ERROR",
+                -5: "RCCL_ERROR"}
 
 
 class Mi355qError(RuntimeError):

@@ -210,14 +210,21 @@ class Calibrator:
     finally:
       self._recording = None
 
-  def replay(self, steps: Iterable[list[tuple]]) -> None:
+  def replay(self, steps: Iterable[list[tuple]],
+             update_overrides: Optional[Mapping[str, Callable]] = None) -> None:
     """Merges recorded steps, in the order given, exactly as calibrating those samples here would
-    have (first sighting of a tensor sets its QSV, later ones go through the op's update rule)."""
+    have (first sighting of a tensor sets its QSV, later ones go through the op's update rule).
+    `update_overrides` maps an event's algorithm tag to the rule to use instead (events whose
+    large statistics travel separately, distributed.calibrate_sharded)."""
+    update_overrides = update_overrides or {}
     for events in steps:
       self._metadata["num_samples_calibrated"] += 1
       for name, alg, op_key, qsv in events:
         if name not in self._model_qsvs:
           self._model_qsvs[name] = qsv
+          continue
+        if alg in update_overrides:
+          self._model_qsvs[name] = update_overrides[alg](self._model_qsvs[name], qsv)
           continue
         update = (self._qsv_update_func if self._is_custom_qsv_update_func
                   else algorithm_manager.get_update_qsv_func(alg, qtyping.TFLOperationName(op_key)))

@@ -15,11 +15,17 @@ and what it must reproduce:
   * the GPTQ Hessian is a sample-weighted mean (ref: utils/qsv_utils.py:71-88):
     ranks all-reduce(sum) num_samples-weighted partial Hessians and divide.
 
-Collectives run on the process group's device: HBM tensors with the "nccl"
-(= RCCL) backend, host tensors with "gloo" (CPU tests).
+Transport: with one process per GPU (process group backend "nccl") every data collective goes
+through libmi355q's own RCCL entry points (include/mi355q.h: mi355q_allgather_minmax,
+mi355q_allreduce_minmax_f32, mi355q_allreduce_sum_f64, mi355q_allreduce_hessian_f64) on a
+communicator created from a ncclUniqueId broadcast over the existing rendezvous; torch.distributed
+is the rendezvous, the barrier and the object gather of results. With the "gloo" backend (CPU
+tests, or several test ranks sharing one GPU -- RCCL refuses duplicate devices) the same
+functions move host tensors through torch.distributed instead.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import Any, Callable, Optional, Sequence
 
@@ -62,6 +68,56 @@ def _comm_device(group=None) -> torch.device:
   if dist.is_initialized() and dist.get_backend(group) == "nccl":
     return torch.device("cuda", torch.cuda.current_device())
   return torch.device("cpu")
+
+
+# --------------------------------------------------- RCCL via the C ABI ---
+_COMMS: dict[Any, ctypes.c_void_p] = {}
+
+
+def rccl_comm(group=None) -> Optional[ctypes.c_void_p]:
+  """libmi355q's RCCL communicator for `group` (created on first use), or None when the ranks
+  of the group cannot have one: no process group, or a host transport ("gloo")."""
+  if not dist.is_available() or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+    return None
+  key = "default" if group is None else id(group)
+  comm = _COMMS.get(key)
+  if comm is None:
+    comm = new_rccl_comm(dist.get_rank(group), dist.get_world_size(group),
+                         lambda uid: _broadcast_bytes(uid, group))
+    _COMMS[key] = comm
+  return comm
+
+
+def _broadcast_bytes(payload: Optional[bytes], group=None) -> bytes:
+  box = [payload]
+  src = 0 if group is None else dist.get_global_rank(group, 0)
+  dist.broadcast_object_list(box, src=src, group=group)
+  return box[0]
+
+
+def new_rccl_comm(rank: int, world: int, broadcast: Callable[[Optional[bytes]], bytes]) -> ctypes.c_void_p:
+  """ncclUniqueId from rank 0 -> `broadcast` (any rendezvous) -> ncclCommInitRank on every rank,
+  all through the C ABI. The calling process's current GPU becomes the communicator's device."""
+  from . import _ffi
+  from . import runtime as rt
+  rt.require_gpu()
+  L = _ffi.lib()
+  uid = None
+  if rank == 0:
+    buf = ctypes.create_string_buffer(128)
+    _ffi.check(L.mi355q_comm_unique_id(buf))
+    uid = buf.raw
+  uid = broadcast(uid)
+  comm = ctypes.c_void_p()
+  _ffi.check(L.mi355q_comm_init_rank(ctypes.byref(comm), world, uid, rank))
+  return comm
+
+
+def destroy_rccl_comms() -> None:
+  from . import _ffi
+  for comm in _COMMS.values():
+    _ffi.check(_ffi.lib().mi355q_comm_destroy(comm))
+  _COMMS.clear()
 
 
 # ------------------------------------------------- weight requantization ---
@@ -154,17 +210,56 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
 
 
 # ------------------------------------------------ activation calibration ---
+_HESSIAN_ASIDE = "GPTQ:hessian-set-aside"
+
+
+def _set_hessians_aside(events: list[tuple], running: dict[str, list]) -> list[tuple]:
+  """Takes the d x d Hessians out of one sample's statistics: each is merged into this rank's
+  running sample-weighted mean (on the device, the same _gptq_merge_hessian chain a single
+  process runs, ref utils/qsv_utils.py:71-102) and the record that travels to the other ranks
+  keeps only min / max / num_samples and the Hessian's order."""
+  out = []
+  for name, alg, op_key, qsv in events:
+    if not isinstance(qsv, dict) or "hessian" not in qsv:
+      out.append((name, alg, op_key, qsv))
+      continue
+    small = {k: v for k, v in qsv.items() if k != "hessian"}
+    h, n = qsv["hessian"], qsv["num_samples"]
+    small["hessian_dim"] = int(h.shape[0])
+    cur = running.get(name)
+    if cur is None:
+      running[name] = [h, n]
+    else:
+      cur[0], cur[1] = qsv_utils._gptq_merge_hessian(   # pylint: disable=protected-access
+          {"hessian": cur[0], "num_samples": cur[1]}, {"hessian": h, "num_samples": n})
+    out.append((name, _HESSIAN_ASIDE, op_key, small))
+  return out
+
+
+def _ema_and_count_update(qsv, new_qsv):
+  """The min / max / num_samples part of gptq_and_moving_average_update (ref :90-102)."""
+  out = qsv_utils.moving_average_update(qsv, new_qsv)
+  out["num_samples"] = qsv["num_samples"] + new_qsv["num_samples"]
+  for key in ("hessian", "hessian_dim"):
+    if key in qsv:
+      out[key] = qsv[key]
+  return out
+
+
 def calibrate_sharded(float_model, recipe, calibration_data, previous_calibration_result=None,
                       tensor_provider=None, group=None) -> dict:
   """`Quantizer(float_model, recipe).calibrate(calibration_data)` with every signature's samples
-  sharded contiguously over the ranks of `group` (BASELINE config 4: 512 samples over 8 GPUs).
+  sharded contiguously over the ranks of `group` (BASELINE config 4: 512 samples over 8 GPUs;
+  config 5: GPTQ Hessians).
 
   Each rank walks its samples on its GPU but keeps their per-tensor statistics as events
-  (Calibrator.record_step); the events are all-gathered and every rank replays all samples in
-  dataset order through the ops' own update rules. The result therefore equals the
-  single-process one bit for bit for every rule, including the order-dependent moving average
-  (statistics are a few floats per tensor and sample; GPTQ Hessians are d x d per sample -- for
-  those prefer allreduce_hessian, exact up to FP64 rounding). Returns the model QSVs on every rank.
+  (Calibrator.record_step); the events -- a few floats per tensor and sample -- are all-gathered
+  and every rank replays all samples in dataset order through the ops' own update rules, so
+  min / max (the order-dependent moving average) and OSCAR's mu2 equal the single-process result
+  bit for bit. GPTQ Hessians (d x d float64 per activation) never enter the gather: every rank
+  keeps the running mean over its own samples in HBM and the ranks combine them with one
+  all-reduce(sum) per distinct Hessian (merge_hessians_across_ranks, X2), exact up to FP64
+  rounding. Returns the model QSVs on every rank.
   """
   from . import calibrator, quantizer
   rank, world = _world(group)
@@ -174,11 +269,13 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
     return {}
   local = calibrator.Calibrator(qz.float_model, tensor_provider=tensor_provider)
   mine = []                                    # (signature index, sample index, events)
+  running: dict[str, list] = {}                # tensor name -> [Hessian mean over my samples, count]
   with local.plan_once():
     for sig_idx, (signature_key, dataset) in enumerate(calibration_data.items()):
       samples = dataset if hasattr(dataset, "__len__") and hasattr(dataset, "__getitem__") else list(dataset)
       for k in sample_shard(len(samples), rank, world):
-        mine.append((sig_idx, k, local.record_step(signature_key, samples[k], rm)))
+        events = local.record_step(signature_key, samples[k], rm)
+        mine.append((sig_idx, k, _set_hessians_aside(events, running)))
   if world > 1:
     parts = [None] * world
     dist.all_gather_object(parts, mine, group=group)
@@ -187,8 +284,27 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
   final = calibrator.Calibrator(qz.float_model, tensor_provider=tensor_provider)
   if previous_calibration_result is not None:
     final.load_model_qsvs(previous_calibration_result)
-  final.replay(events for _, _, events in mine)
-  return final.get_model_qsvs()
+  earlier = {name: (qsv["hessian"], qsv["num_samples"]) for name, qsv in final.get_model_qsvs().items()
+             if isinstance(qsv, dict) and "hessian" in qsv}
+  final.replay((events for _, _, events in mine), update_overrides={_HESSIAN_ASIDE: _ema_and_count_update})
+  totals: dict[str, list] = {}
+  for _, _, events in mine:
+    for name, alg, _, qsv in events:
+      if alg == _HESSIAN_ASIDE:
+        entry = totals.setdefault(name, [qsv["hessian_dim"], 0])
+        entry[1] += qsv["num_samples"]
+  merged = merge_hessians_across_ranks({n: (h, c) for n, (h, c) in running.items()},
+                                       {n: (d, c) for n, (d, c) in totals.items()}, group)
+  qsvs = final.get_model_qsvs()
+  for name, h in merged.items():
+    qsv = qsvs[name]
+    qsv.pop("hessian_dim", None)
+    if name in earlier:       # resumed calibration: the earlier result weighs in with its own count
+      h, _ = qsv_utils._gptq_merge_hessian(   # pylint: disable=protected-access
+          {"hessian": earlier[name][0], "num_samples": earlier[name][1]},
+          {"hessian": h, "num_samples": totals[name][1]})
+    qsv["hessian"] = h
+  return qsvs
 
 
 def sample_shard(num_samples: int, rank: int, world_size: int) -> range:
@@ -217,22 +333,39 @@ def local_activation_stats(samples: Sequence[dict[str, np.ndarray]], names: Sequ
 
 
 def gather_sample_stats(local_stats: np.ndarray, group=None) -> np.ndarray:
-  """All-gather of per-sample statistics -> [n_total_samples, ...] in dataset order.
+  """All-gather of per-sample statistics -> [n_total_samples, ...] in dataset order (X1).
 
   Shards may have different lengths (sample_shard); ranks exchange lengths first
-  and pad to the longest so that a single all_gather moves the payload.
+  and pad to the longest so that a single all-gather moves the payload.
   """
   rank, world = _world(group)
   local_stats = np.ascontiguousarray(local_stats, dtype=np.float32)
   if world == 1:
     return local_stats
+  tail = local_stats.shape[1:]
+  comm = rccl_comm(group)
+  if comm is not None:
+    from . import _ffi
+    from . import runtime as rt
+    L, dev = _ffi.lib(), rt.device()
+    n_local = torch.tensor([float(local_stats.shape[0])], dtype=torch.float32, device=dev)
+    counts_t = torch.empty((world,), dtype=torch.float32, device=dev)
+    _ffi.check(L.mi355q_allgather_minmax(comm, rt.ptr(n_local), 1, rt.ptr(counts_t), rt.stream_ptr()))
+    counts = [int(c) for c in counts_t.cpu().tolist()]
+    longest = max(counts)
+    padded = np.zeros((longest,) + tail, np.float32)
+    padded[: local_stats.shape[0]] = local_stats
+    mine = torch.from_numpy(padded).to(dev)
+    parts = torch.empty((world,) + tuple(padded.shape), dtype=torch.float32, device=dev)
+    _ffi.check(L.mi355q_allgather_minmax(comm, rt.ptr(mine), mine.numel(), rt.ptr(parts), rt.stream_ptr()))
+    host = parts.cpu().numpy()
+    return np.concatenate([host[r, :c] for r, c in enumerate(counts)], axis=0)
   dev = _comm_device(group)
   n_local = torch.tensor([local_stats.shape[0]], dtype=torch.int64, device=dev)
   counts = [torch.zeros_like(n_local) for _ in range(world)]
   dist.all_gather(counts, n_local, group=group)
   counts = [int(c.item()) for c in counts]
   longest = max(counts)
-  tail = local_stats.shape[1:]
   padded = np.zeros((longest,) + tail, np.float32)
   padded[: local_stats.shape[0]] = local_stats
   mine = torch.from_numpy(padded).to(dev)
@@ -264,7 +397,7 @@ def allreduce_min_max(local_stats: np.ndarray, group=None) -> np.ndarray:
   """Global [n_tensors, 2] (min, max) when the update rule is `min_max_update`.
 
   Associative and commutative, so one all-reduce(MIN) + one all-reduce(MAX) over
-  xGMI replaces the gather + replay.
+  xGMI (one RCCL group) replaces the gather + replay.
   """
   rank, world = _world(group)
   if local_stats.shape[0]:
@@ -274,15 +407,34 @@ def allreduce_min_max(local_stats: np.ndarray, group=None) -> np.ndarray:
     mn = np.full(local_stats.shape[1], np.inf, np.float32)
     mx = np.full(local_stats.shape[1], -np.inf, np.float32)
   if world > 1:
+    comm = rccl_comm(group)
     dev = _comm_device(group)
-    tmn, tmx = torch.from_numpy(np.ascontiguousarray(mn)).to(dev), torch.from_numpy(np.ascontiguousarray(mx)).to(dev)
-    dist.all_reduce(tmn, op=dist.ReduceOp.MIN, group=group)
-    dist.all_reduce(tmx, op=dist.ReduceOp.MAX, group=group)
+    tmn = torch.from_numpy(np.ascontiguousarray(mn, dtype=np.float32)).to(dev)
+    tmx = torch.from_numpy(np.ascontiguousarray(mx, dtype=np.float32)).to(dev)
+    if comm is not None:
+      from . import _ffi
+      from . import runtime as rt
+      _ffi.check(_ffi.lib().mi355q_allreduce_minmax_f32(comm, rt.ptr(tmn), rt.ptr(tmx), tmn.numel(),
+                                                         rt.stream_ptr()))
+    else:
+      dist.all_reduce(tmn, op=dist.ReduceOp.MIN, group=group)
+      dist.all_reduce(tmx, op=dist.ReduceOp.MAX, group=group)
     mn, mx = tmn.cpu().numpy(), tmx.cpu().numpy()
   return np.stack([mn, mx], axis=-1)
 
 
 # ---------------------------------------------- GPTQ Hessian / OSCAR mu2 ---
+def _sum_f64_across_ranks(t: torch.Tensor, group=None, comm=None) -> torch.Tensor:
+  """In-place all-reduce(sum) of a float64 tensor that this function's caller owns."""
+  if comm is not None:
+    from . import _ffi
+    from . import runtime as rt
+    _ffi.check(_ffi.lib().mi355q_allreduce_sum_f64(comm, rt.ptr(t), t.numel(), rt.stream_ptr()))
+  else:
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+  return t
+
+
 def allreduce_hessian(weighted_sum, num_samples: int, group=None):
   """Merges per-rank Hessian statistics into the global sample-weighted mean.
 
@@ -293,22 +445,68 @@ def allreduce_hessian(weighted_sum, num_samples: int, group=None):
   (ref: utils/qsv_utils.py:71-88) over all samples yields up to FP64 rounding.
   OSCAR's per-channel second moment merges by the same sample-weighted mean
   (_oscar_merge_mu2, ref: utils/qsv_utils.py:125-158): pass sum_i n_i * mu2_i and sum_i n_i.
+  The caller's array is never written (the collective runs on a copy).
   """
   rank, world = _world(group)
   if hasattr(weighted_sum, "device_tensor"):      # runtime.HbmArray: reduce it where it lives
     weighted_sum = weighted_sum.device_tensor
   is_np = isinstance(weighted_sum, np.ndarray)
-  t = torch.from_numpy(np.ascontiguousarray(weighted_sum)) if is_np else weighted_sum
-  n = torch.tensor([int(num_samples)], dtype=torch.int64)
+  t = torch.from_numpy(np.array(weighted_sum, dtype=np.float64)) if is_np else weighted_sum.double().clone()
+  n = torch.tensor([float(num_samples)], dtype=torch.float64)
   if world > 1:
+    comm = rccl_comm(group)
     dev = _comm_device(group)
-    t = t.to(dev)
-    n = n.to(dev)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
-  total = int(n.item())
+    t, n = t.to(dev), n.to(dev)
+    _sum_f64_across_ranks(t, group, comm)
+    _sum_f64_across_ranks(n, group, comm)
+  total = int(round(float(n.item())))
   h = t / total if total else t
   return (h.cpu().numpy() if is_np else h), total
 
 
 allreduce_second_moment = allreduce_hessian   # OSCAR mu2: same sample-weighted mean
+
+
+def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dict[str, tuple[int, float]],
+                                group=None) -> dict[str, Any]:
+  """X2: the sample-weighted mean of every GPTQ Hessian over all ranks.
+
+  local[name] = (H_rank, n_rank): this rank's running mean over its own samples (the chain of
+  _gptq_merge_hessian, ref utils/qsv_utils.py:71-102) and their sample count; names this rank
+  saw no sample of are simply absent. totals[name] = (d, N): Hessian order and the sample count
+  over all ranks (known to every rank from the gathered per-sample records, so no collective is
+  spent on counts). Per distinct Hessian, in sorted-name order on every rank: H_rank *= n_rank/N,
+  one in-place all-reduce(sum) of d*d float64 (32 MiB at d = 2048, 2 GiB at d = 16384) --
+  mi355q_allreduce_hessian_f64 over RCCL when ranks own GPUs; nothing d x d is ever pickled.
+  Returns {name: H} (runtime.HbmArray when the data lives in HBM).
+  """
+  rank, world = _world(group)
+  comm = rccl_comm(group) if world > 1 else None
+  out: dict[str, Any] = {}
+  on_gpu = torch.cuda.is_available()
+  if on_gpu:
+    from . import _ffi
+    from . import runtime as rt
+  for name in sorted(totals):
+    d, total = totals[name]
+    h, n_rank = local.get(name, (None, 0.0))
+    if world == 1:
+      out[name] = h
+      continue
+    weight = float(n_rank) / float(total) if total else 0.0
+    if on_gpu:
+      t = (torch.zeros((d, d), dtype=torch.float64, device=rt.device()) if h is None
+           else rt.on_device(h, torch.float64).clone())       # the QSV's own Hessian stays as it is
+      if comm is not None:
+        _ffi.check(_ffi.lib().mi355q_allreduce_hessian_f64(comm, rt.ptr(t), d, weight, rt.stream_ptr()))
+      else:                                                     # test transport: ranks share a GPU
+        host = (t * weight).cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t = host.to(rt.device())
+      out[name] = rt.HbmArray(t)
+    else:
+      t = torch.zeros((d, d), dtype=torch.float64) if h is None else torch.from_numpy(np.array(h, dtype=np.float64))
+      t *= weight
+      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+      out[name] = t.numpy()
+  return out

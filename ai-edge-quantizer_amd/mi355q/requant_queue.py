@@ -6,12 +6,17 @@ per tensor leaves the part ramping up and draining most of the time (63 % of the
 and a scale read-back per tensor adds a host synchronisation to every call (22 %). Inside
 `batching()` the fused symmetric min/max path therefore only *enqueues* its tensor; equally
 shaped tensors leave together through mi355q_requant_sym_f32_batched (one launch over the whole
-group, 76 % of the roofline at C2) and all scales of a flush come back in ONE device-to-host copy.
+group, 76 % of the roofline at C2). A flush never waits for the GPU: per-row scales come back
+through ONE asynchronous copy per wave into pinned memory, completed when the block exits (or
+when somebody reads a value), so the kernels of a wave run while the host walks the next ops.
 
 What a caller sees does not change:
-  * `UniformQuantParams.scale` is a float32 ndarray once the queue has been flushed (the queue
-    swaps the placeholder for the array); before that the placeholder behaves like one (any read
-    flushes first);
+  * per-channel / per-tensor `UniformQuantParams.scale` is a float32 ndarray once the block has
+    exited (the queue swaps the placeholder for the array); before that the placeholder behaves
+    like one (a read completes the wave first). Blockwise scales (one per 32..256 weights, 1.4 MB
+    per C3 layer) stay in HBM as an array-like `runtime.HbmArray` with the IEEE-half patterns the
+    model file stores (`.f16`, written by the same launch) beside them; they reach the host only
+    if somebody reads them;
   * `quantized_data` is a `runtime.HbmArray` as for every large weight: int8 values on demand, the
     bytes the model file stores (`.packed` for sub-byte types) copied straight from HBM by the
     writer. For int4 / int2 targets the launch writes ONLY the packed bytes (4.5 instead of 5.5
@@ -23,8 +28,9 @@ What a caller sees does not change:
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import os
-from typing import Callable, Optional
+from typing import Optional
 
 import numpy as np
 import torch
@@ -36,46 +42,52 @@ from . import runtime as rt
 # goes out in several waves; 288 GB of HBM hold the inputs and outputs of a wave many times over).
 DEFAULT_BUDGET_BYTES = int(os.environ.get("MI355Q_BATCH_BYTES", 48 << 30))
 # ... and the number of pending tensors: the GPU starts on a wave while the host walks on
-DEFAULT_BUDGET_TENSORS = int(os.environ.get("MI355Q_BATCH_TENSORS", 256))
+DEFAULT_BUDGET_TENSORS = int(os.environ.get("MI355Q_BATCH_TENSORS", 64))
 
-_TORCH_OF = {np.dtype(np.int8): torch.int8, np.dtype(np.uint8): torch.uint8,
-             np.dtype(np.float32): torch.float32}
+_I8, _U8, _F32, _F16 = np.dtype(np.int8), np.dtype(np.uint8), np.dtype(np.float32), np.dtype(np.float16)
 
 
 class PendingArray(rt.HbmArray):
   """An HbmArray whose device tensor does not exist yet: shape and dtype are known, the values
-  arrive when `resolve` runs (a queue flush, or the unpacking of packed bytes)."""
+  arrive when its wave has been issued (`source` = (group tensor, row)) or when its packed
+  sibling has been unpacked."""
 
-  def __init__(self, shape, dtype, resolve: Callable[[], None]):  # pylint: disable=super-init-not-called
-    self._shape = tuple(int(d) for d in shape)
-    self._dtype = np.dtype(dtype)
-    self._resolve = resolve
+  def __init__(self, shape, dtype, queue):  # pylint: disable=super-init-not-called
+    self._shape = shape
+    self._dtype = dtype
+    self._queue = queue
+    self._source = None        # (tensor [n, ...], index) once the wave is out
+    self._wave = None          # _Wave whose pinned copy carries the host values (scales)
+    self._host_at = None       # (offset, count) into the wave's host block
+    self._unpack = None        # (packed sibling, element count, bits)
     self._tensor = None
     self._host = None
     self.cache = {}
     self.packed = None
+    self.f16 = None
 
   @property
   def device_tensor(self) -> torch.Tensor:
     if self._tensor is None:
-      self._resolve()
-      if self._tensor is None:
-        raise RuntimeError("a pending result was not produced by its flush")
+      if self._unpack is not None:
+        from . import ops
+        packed, n, bits = self._unpack
+        self._tensor = ops.unpack_bits(packed.device_tensor, n, bits).reshape(self._shape)
+      else:
+        if self._source is None:
+          self._queue.flush()
+        group, i = self._source
+        self._tensor = group[i].reshape(self._shape)
     return self._tensor
 
   @device_tensor.setter
   def device_tensor(self, value) -> None:
     self._tensor = value
 
-  def fill(self, tensor: torch.Tensor, host: Optional[np.ndarray] = None) -> None:
-    self._tensor = tensor.reshape(self._shape)
-    if host is not None:
-      self._host = host.reshape(self._shape)
-    self._resolve = None
-
   @property
   def resolved(self) -> bool:
-    return self._tensor is not None
+    """Values exist on the device (issued, for queue outputs; unpacked, for int8 containers)."""
+    return self._tensor is not None or self._source is not None
 
   @property
   def shape(self):
@@ -91,7 +103,10 @@ class PendingArray(rt.HbmArray):
 
   @property
   def size(self) -> int:
-    return int(np.prod(self._shape, dtype=np.int64))
+    n = 1
+    for d in self._shape:
+      n *= d
+    return n
 
   @property
   def nbytes(self) -> int:
@@ -99,8 +114,13 @@ class PendingArray(rt.HbmArray):
 
   def numpy(self) -> np.ndarray:
     if self._host is None:
-      _ = self.device_tensor      # resolve (a flush may fill the host copy directly)
-    return super().numpy()
+      if self._unpack is None and self._source is None:
+        self._queue.flush()
+      if self._wave is not None:                 # rode along in the wave's pinned scale copy
+        self._host = self._wave.host_values(*self._host_at).reshape(self._shape)
+      else:
+        self._host = self.device_tensor.cpu().numpy()
+    return self._host
 
   def __repr__(self):
     state = "resolved" if self.resolved else "pending"
@@ -108,11 +128,38 @@ class PendingArray(rt.HbmArray):
 
 
 class _Slot:
-  __slots__ = ("x", "scale", "q", "packed", "params", "small")
+  __slots__ = ("x", "scale", "out", "params")
 
-  def __init__(self, x, scale, q, packed, small):
-    self.x, self.scale, self.q, self.packed, self.small = x, scale, q, packed, small
+  def __init__(self, x, scale, out):
+    self.x, self.scale, self.out = x, scale, out
     self.params = None
+
+
+class _Wave:
+  """The asynchronous device-to-host copy of one flush's per-row scales."""
+
+  def __init__(self, device_flat: torch.Tensor):
+    self._pinned = torch.empty(device_flat.shape, dtype=device_flat.dtype, pin_memory=True)
+    self._pinned.copy_(device_flat, non_blocking=True)
+    self._event = torch.cuda.Event()
+    self._event.record()
+    self._values = None
+    self.slots: list[_Slot] = []
+
+  def host_values(self, offset: int, count: int) -> np.ndarray:
+    if self._values is None:
+      self._event.synchronize()
+      self._values = self._pinned.numpy().copy()    # ordinary memory; the pinned block is recycled
+      self._pinned = None
+    return self._values[offset:offset + count]
+
+  def complete(self) -> None:
+    """Hands every per-row scale of the wave over as the ndarray the reference returns."""
+    for s in self.slots:
+      host = s.scale.numpy()
+      if s.params is not None and s.params.scale is s.scale:
+        object.__setattr__(s.params, "scale", host)
+    self.slots = []
 
 
 class RequantQueue:
@@ -125,42 +172,55 @@ class RequantQueue:
     self._groups: dict[tuple, list[_Slot]] = {}
     self._pending_bytes = 0
     self._pending = 0
+    self._waves: list[_Wave] = []
     self.stats = {"tensors": 0, "launches": 0, "flushes": 0, "scale_copies": 0}
 
   # ------------------------------------------------------------------------------- submit
   def submit(self, tensor_content, layout, num_bits: int, scale_shape, packable: bool):
-    """Enqueues one [rows, cols] weight; returns (scale, quantized_data) placeholders."""
+    """Enqueues one [rows, cols] weight; returns (scale, quantized_data, slot) placeholders."""
     rows, cols, block = layout
-    x = rt.to_device(tensor_content.reshape(rows, cols))
+    if isinstance(tensor_content, rt.HbmArray):
+      x = tensor_content.device_tensor
+      if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    else:
+      x = rt.to_device(tensor_content)
     if x.data_ptr() % 16:
       x = x.clone()                      # the batched kernel takes 16-byte aligned buffers
     shape = tuple(tensor_content.shape)
-    sub_byte = packable and num_bits in (2, 4)
-    scale = PendingArray(scale_shape, np.float32, self.flush)
-    packed = None
-    if sub_byte:
-      packed = PendingArray((rows * cols * num_bits // 8,), np.uint8, self.flush)
-      q = PendingArray(shape, np.int8, None)
-      q._resolve = _unpacker(q, packed, rows * cols, num_bits)   # pylint: disable=protected-access
-      q.packed = packed
+    scale = PendingArray(tuple(scale_shape), _F32, self)
+    if block:
+      scale.f16 = PendingArray(scale.shape, _F16, self)
+    if packable and num_bits != 8:
+      out = PendingArray((rows * cols * num_bits // 8,), _U8, self)
+      q = PendingArray(shape, _I8, self)
+      q._unpack = (out, rows * cols, num_bits)   # pylint: disable=protected-access
+      q.packed = out
+      sub_byte = True
     else:
-      q = PendingArray(shape, np.int8, self.flush)
-    nbytes = rows * cols * 4
-    slot = _Slot(x, scale, q, packed, nbytes < rt.KEEP_IN_HBM_BYTES)
-    self._groups.setdefault((rows, cols, block, num_bits, sub_byte), []).append(slot)
-    self._pending_bytes += nbytes
+      q = out = PendingArray(shape, _I8, self)
+      sub_byte = False
+    slot = _Slot(x, scale, out)
+    key = (rows, cols, block, num_bits, sub_byte)
+    group = self._groups.get(key)
+    if group is None:
+      group = self._groups[key] = []
+    group.append(slot)
+    self._pending_bytes += rows * cols * 4
     self._pending += 1
     return scale, q, slot
 
   def attach(self, slot: _Slot, params) -> None:
     """`params.scale` (a frozen dataclass field holding the placeholder) becomes the float32
-    ndarray itself when the slot's group has run."""
+    ndarray itself when the slot's wave has completed (per-row scales)."""
     slot.params = params
-    if self._pending_bytes >= self.budget_bytes or self._pending >= self.budget_tensors:
+    if self._pending >= self.budget_tensors or self._pending_bytes >= self.budget_bytes:
       self.flush()
 
   # -------------------------------------------------------------------------------- flush
   def flush(self) -> None:
+    """Issues everything pending: one launch per shape group, one asynchronous copy of the
+    per-row scales. Does not wait for the GPU."""
     if not self._groups:
       return
     groups, self._groups = self._groups, {}
@@ -168,54 +228,63 @@ class RequantQueue:
     self.stats["flushes"] += 1
     L = _ffi.lib()
     dev = rt.device()
-    issued = []
+    stream = rt.stream_ptr()
+    row_scales = []          # (slots, scale_all) of the groups whose scales go to the host
     for (rows, cols, block, bits, sub_byte), slots in groups.items():
       n = len(slots)
       nscale = rows * (cols // block) if block else rows
       out_bytes = rows * cols * bits // 8 if sub_byte else rows * cols
       scale_all = torch.empty((n, nscale), dtype=torch.float32, device=dev)
       out_all = torch.empty((n, out_bytes), dtype=torch.uint8 if sub_byte else torch.int8, device=dev)
-      # one H2D for the three pointer tables of the group
-      table = np.empty((3, n), np.int64)
+      f16_all = torch.empty((n, nscale), dtype=torch.float16, device=dev) if block else None
+      # one H2D for the pointer tables of the group
+      # (pinned staging: a pageable source would make the copy wait for the previous wave)
+      pinned = torch.empty((4, n), dtype=torch.int64, pin_memory=True)
+      table = pinned.numpy()
       table[0] = [s.x.data_ptr() for s in slots]
-      table[1] = out_all.data_ptr() + np.arange(n, dtype=np.int64) * out_bytes
-      table[2] = scale_all.data_ptr() + np.arange(n, dtype=np.int64) * (nscale * 4)
-      tab = torch.from_numpy(table).to(dev)
+      steps = np.arange(n, dtype=np.int64)
+      table[1] = out_all.data_ptr() + steps * out_bytes
+      table[2] = scale_all.data_ptr() + steps * (nscale * 4)
+      table[3] = f16_all.data_ptr() + steps * (nscale * 2) if block else 0
+      tab = pinned.to(dev, non_blocking=True)
       base = tab.data_ptr()
       for first in range(0, n, 65535):       # blockIdx.y limit of one launch
         cnt = min(65535, n - first)
-        ptr = lambda row: rt.ctypes.c_void_p(base + (row * n + first) * 8)   # noqa: E731
+        ptr = lambda row: ctypes.c_void_p(base + (row * n + first) * 8)   # noqa: E731
         _ffi.check(L.mi355q_requant_sym_f32_batched(
             ptr(0), cnt, rows, cols, block, bits, None if sub_byte else ptr(1),
-            ptr(1) if sub_byte else None, ptr(2), None, rt.stream_ptr()))
+            ptr(1) if sub_byte else None, ptr(2), ptr(3) if block else None, stream))
         self.stats["launches"] += 1
       self.stats["tensors"] += n
-      issued.append((slots, scale_all, out_all, sub_byte, tab))
-    # every scale of the flush in one device-to-host copy (the only synchronisation)
-    flat = torch.cat([g[1].reshape(-1) for g in issued]) if len(issued) > 1 else issued[0][1].reshape(-1)
-    host_scales = flat.cpu().numpy()
-    self.stats["scale_copies"] += 1
-    pos = 0
-    for slots, scale_all, out_all, sub_byte, _ in issued:
-      nscale = scale_all.shape[1]
-      host_out = None
-      if all(s.small for s in slots):        # small results: one copy for the whole group
-        host_out = out_all.cpu().numpy()
       for i, s in enumerate(slots):
-        h = host_scales[pos:pos + nscale]
-        pos += nscale
-        s.scale.fill(scale_all[i], h)
-        (s.packed if sub_byte else s.q).fill(out_all[i], None if host_out is None else host_out[i])
-        if s.params is not None and s.params.scale is s.scale:
-          object.__setattr__(s.params, "scale", s.scale._host)   # pylint: disable=protected-access
-        s.x = None                            # the FP32 copy in HBM is no longer needed
+        s.scale._source = (scale_all, i)       # pylint: disable=protected-access
+        s.out._source = (out_all, i)           # pylint: disable=protected-access
+        if block:
+          s.scale.f16._source = (f16_all, i)   # pylint: disable=protected-access
+        s.x = None                             # the FP32 copy in HBM is no longer needed
+      if not block:
+        row_scales.append((slots, scale_all))
+      del tab                                  # (stream-ordered allocator: freed after the launch)
+    if row_scales:
+      flat = (torch.cat([g[1].reshape(-1) for g in row_scales]) if len(row_scales) > 1
+              else row_scales[0][1].reshape(-1))
+      wave = _Wave(flat)
+      self.stats["scale_copies"] += 1
+      pos = 0
+      for slots, scale_all in row_scales:
+        nscale = scale_all.shape[1]
+        for s in slots:
+          s.scale._wave, s.scale._host_at = wave, (pos, nscale)   # pylint: disable=protected-access
+          pos += nscale
+        wave.slots.extend(slots)
+      self._waves.append(wave)
 
-
-def _unpacker(q: PendingArray, packed: PendingArray, n: int, bits: int):
-  def resolve():
-    from . import ops
-    q.fill(ops.unpack_bits(packed.device_tensor, n, bits))
-  return resolve
+  def finish(self) -> None:
+    """Flush + wait for the scale copies + swap the placeholders of per-row scales."""
+    self.flush()
+    waves, self._waves = self._waves, []
+    for w in waves:
+      w.complete()
 
 
 _ACTIVE: Optional[RequantQueue] = None
@@ -230,7 +299,7 @@ def active() -> Optional[RequantQueue]:
 
 @contextlib.contextmanager
 def batching(budget_bytes: int = DEFAULT_BUDGET_BYTES, budget_tensors: int = DEFAULT_BUDGET_TENSORS):
-  """Defers fused requantization launches issued inside the block; flushes on exit."""
+  """Defers fused requantization launches issued inside the block; completes them on exit."""
   global _ACTIVE
   if _ACTIVE is not None:                     # nested use joins the outer queue
     yield _ACTIVE
@@ -242,6 +311,6 @@ def batching(budget_bytes: int = DEFAULT_BUDGET_BYTES, budget_tensors: int = DEF
   _ACTIVE = queue
   try:
     yield queue
-    queue.flush()
+    queue.finish()
   finally:
     _ACTIVE = None

@@ -59,7 +59,8 @@ def _perform_blockwise_quantization(ti: transformation_utils.TransformationInput
   q.detailsType = qtyping.QuantizationDetails.BlockwiseQuantization
   tensor = ti.subgraph.tensors[ti.tensor_id]
   details = qtyping.BlockwiseQuantizationT()
-  scales_f16 = uniform_quantize_tensor.round_to_bf16(
+  f16 = getattr(p.scale, "f16", None)     # written by the launch that quantized (requant_queue)
+  scales_f16 = np.asarray(f16) if f16 is not None else uniform_quantize_tensor.round_to_bf16(
       np.asarray(p.scale, dtype=np.float32)).astype(np.float16)
   name = tensor.name if isinstance(tensor.name, (bytes, bytearray)) else str(tensor.name).encode()
   details.scales = transformation_utils.add_new_constant_tensor(

@@ -39,7 +39,8 @@ typedef enum mi355q_status {
   MI355Q_BAD_ARG = -1,     /* null pointer, negative size, bad enum value */
   MI355Q_BAD_SHAPE = -2,   /* e.g. cols not divisible by block size */
   MI355Q_UNSUPPORTED = -3, /* valid request this build has no kernel for */
-  MI355Q_HIP_ERROR = -4    /* launch / runtime failure; see mi355q_last_error() */
+  MI355Q_HIP_ERROR = -4,   /* launch / runtime failure; see mi355q_last_error() */
+  MI355Q_RCCL_ERROR = -5   /* RCCL missing or a collective / communicator call failed */
 } mi355q_status;
 
 int32_t mi355q_version(void);
@@ -373,6 +374,41 @@ int32_t mi355q_dwr_scales_f32(const float* w, int64_t n, int64_t d, int64_t g, i
  * _validate_recovered_weights compares with its tolerance. */
 int32_t mi355q_dwr_max_error_f32(const float* w, const int8_t* q, const double* scale, int64_t total,
                                  int64_t g, double* max_out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-GPU exchange steps: one process per GPU, RCCL over xGMI. The
+ * reference is single-process; these define what the sharded calibration adds and must
+ * reproduce. `comm` is an opaque RCCL communicator (ncclComm_t) owned by the caller:
+ *   rank 0: mi355q_comm_unique_id(id)  ->  the host broadcasts the 128 bytes over its own
+ *   rendezvous  ->  every rank: mi355q_comm_init_rank(&comm, nranks, id, rank) with its GPU
+ *   current. Collectives enqueue on `stream` and return; all ranks must call them in the same
+ *   order. RCCL is bound at run time (the librccl.so.1 already in the process under
+ *   PyTorch-ROCm); without it these calls -- and only these -- return MI355Q_RCCL_ERROR.
+ * ------------------------------------------------------------------------ */
+#define MI355Q_UNIQUE_ID_BYTES 128
+int32_t mi355q_comm_unique_id(char* id_host /* [MI355Q_UNIQUE_ID_BYTES] */);
+int32_t mi355q_comm_init_rank(void** comm_out_host, int32_t nranks, const char* id_host, int32_t rank);
+int32_t mi355q_comm_info(void* comm, int32_t* nranks_host, int32_t* rank_host);
+int32_t mi355q_comm_destroy(void* comm);
+/* X1 -- per-sample activation statistics of every rank to every rank: out[r*n .. r*n+n) =
+ * rank r's local[0..n) (float (min, max) pairs, n floats per rank, equal on all ranks: shards
+ * are padded to the longest). The host then replays the order-dependent moving average
+ * (ref: utils/qsv_utils.py:43-68, calibrator.py:395-421) over all samples in dataset order. */
+int32_t mi355q_allgather_minmax(void* comm, const float* local, int64_t n, float* out, void* stream);
+/* X1 fast path -- global ranges when the update rule is min_max_update (ref:
+ * utils/qsv_utils.py:105-122; associative and commutative): in-place all-reduce(min) of mins[n]
+ * and all-reduce(max) of maxs[n], issued as one RCCL group. */
+int32_t mi355q_allreduce_minmax_f32(void* comm, float* mins, float* maxs, int64_t n, void* stream);
+/* In-place all-reduce(sum) building blocks (OSCAR's sample-weighted second moments, counts). */
+int32_t mi355q_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
+int32_t mi355q_allreduce_sum_f64(void* comm, double* buf, int64_t n, void* stream);
+/* X2 -- GPTQ Hessian over sample-sharded calibration: hessian (FLOAT64 [d, d], this rank's
+ * sample-weighted mean over its own samples, as chaining mi355q_gptq_hessian_merge_f64 yields) is
+ * scaled by weight = n_rank / N and all-reduced(sum) in place; every rank ends with the mean over
+ * all N samples, which is what chaining _gptq_merge_hessian over the whole dataset yields up to
+ * FP64 rounding (ref: utils/qsv_utils.py:71-102). One collective of d*d*8 bytes per distinct
+ * Hessian: 32 MiB at d = 2048, 2 GiB at d = 16384. A rank without samples passes zeros, weight 0. */
+int32_t mi355q_allreduce_hessian_f64(void* comm, double* hessian, int64_t d, double weight, void* stream);
 
 #ifdef __cplusplus
 } /* extern "C" */

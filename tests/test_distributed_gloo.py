@@ -230,6 +230,95 @@ def _worker_calibrate_model(rank, world, port, out):
   dist.destroy_process_group()
 
 
+def _worker_x2_exchange(rank, world, port, out):
+  """X2 at the exchange level: every rank holds the running mean of its own samples."""
+  dist = _setup(rank, world, port)
+  from mi355q import distributed as D
+  from oracle import aeq_oracle as O
+  xs = _hessian_samples()
+  shard = D.sample_shard(len(xs), rank, world)
+  local, totals = {}, {}
+  for name, d in (("a", 16), ("b", 24)):
+    q = None
+    for s in shard:
+      x = xs[s][..., :d]
+      q = O.gptq_and_moving_average_update(q, {"min": np.float32(0), "max": np.float32(1), "hessian": O.gptq_hessian(x),
+                                               "num_samples": x.shape[0]})
+    if q is not None:
+      local[name] = (q["hessian"], q["num_samples"])
+    totals[name] = (d, sum(x.shape[0] for x in xs))
+  # "c" was seen by rank 1 only (a rank without samples of a tensor contributes zeros)
+  totals["c"] = (8, 5)
+  if rank == 1:
+    local["c"] = (np.arange(64, dtype=np.float64).reshape(8, 8), 5)
+  before = {n: np.array(h, copy=True) for n, (h, _) in local.items()}
+  merged = D.merge_hessians_across_ranks(local, totals)
+  untouched = all(np.array_equal(before[n], local[n][0]) for n in local)     # the QSVs' own arrays are not written
+  out.put((rank, {n: np.asarray(h) for n, h in merged.items()}, untouched))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def _hessian_samples():
+  rng = np.random.default_rng(15)
+  return [rng.standard_normal((1 + i % 3, 6, 24)).astype(np.float32) * (1 + i) for i in range(7)]
+
+
+def _worker_calibrate_gptq(rank, world, port, out):
+  """calibrate_sharded with a GPTQ recipe on CPU: the Hessian statistics come from the oracle (the
+  product functions need a GPU; test process only), the sharded control flow is the product's."""
+  dist = _setup(rank, world, port)
+  import pickle
+  from mi355q import algorithm_manager as am, calibrator, distributed as D, recipe_manager
+  from mi355q.algorithms.uniform_quantize import gptq
+  from mi355q.utils import qsv_utils, tfl_flatbuffer_utils as fu
+  from oracle import aeq_oracle as O
+  base = _register_oracle_calibration()
+
+  def calibrate(tfl_op, graph_info, tensor_content_map, inputs_to_ignore=None, outputs_to_ignore=None,
+                valid_range=(-3e38, 3e38)):
+    res = base(tfl_op, graph_info, tensor_content_map, inputs_to_ignore, outputs_to_ignore, valid_range)
+    for name, qsv in res.items():
+      qsv["hessian"] = O.gptq_hessian(tensor_content_map[name])
+    return res
+  for op in am.get_supported_ops(am.AlgorithmName.GPTQ.value):
+    am.register_quantized_op(am.AlgorithmName.GPTQ.value, op, gptq.init_qsvs if hasattr(gptq, "init_qsvs") else None,
+                             calibration_func=calibrate, materialize_func=lambda *a, **k: [],
+                             update_qsv_func=qsv_utils.gptq_and_moving_average_update)
+  calibrator.Calibrator._stage_sample = lambda *a, **k: None
+  qsv_utils._gptq_merge_hessian = lambda a, b: (O.gptq_and_moving_average_update(
+      {"min": 0.0, "max": 0.0, **a}, {"min": 0.0, "max": 0.0, **b})["hessian"], a["num_samples"] + b["num_samples"])
+  sizes = []
+  real_gather = dist.all_gather_object
+
+  def counting_gather(parts, obj, group=None):
+    sizes.append(len(pickle.dumps(obj)))
+    return real_gather(parts, obj, group=group)
+  dist.all_gather_object = counting_gather
+  path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mi355q_tiny_fc_gptq_{port}_{rank}.tflite")
+  _tiny_fc(path)
+  data = {"serving_default": _calibration_samples()}
+  rcp = [dict(regex=".*", operation="FULLY_CONNECTED", algorithm_key="GPTQ", op_config=dict(
+      weight_tensor_config=dict(num_bits=4, symmetric=True, granularity="CHANNELWISE", dtype="INT"),
+      compute_precision="INTEGER", explicit_dequantize=False, skip_checks=False, min_weight_elements=0))]
+  got = D.calibrate_sharded(path, rcp, data)
+  rm = recipe_manager.RecipeManager()
+  rm.load_quantization_recipe(rcp)
+  single = calibrator.Calibrator(fu.read_model(path))
+  single.calibrate(data, rm)
+  want = single.get_model_qsvs()
+  os.remove(path)
+  rel = {n: float(np.max(np.abs(np.asarray(got[n]["hessian"]) - want[n]["hessian"])) / np.max(np.abs(want[n]["hessian"])))
+         for n in want if "hessian" in want[n]}
+  exact = all(np.array_equal(got[n][k], want[n][k]) for n in want for k in ("min", "max"))
+  counts = all(int(got[n]["num_samples"]) == int(want[n]["num_samples"]) for n in want if "num_samples" in want[n])
+  clean = all("hessian_dim" not in q for q in got.values())
+  out.put((rank, rel, exact and counts and clean and set(got) == set(want), max(sizes),
+           max(want[n]["hessian"].nbytes for n in rel)))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
 def _run(worker, world=2, timeout=300):
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
@@ -306,6 +395,36 @@ def test_hessian_allreduce_matches_sequential_merge():
   for rank, h, total in results:
     assert total == q["num_samples"]
     np.testing.assert_allclose(h, q["hessian"], rtol=1e-12, atol=1e-12)
+
+
+def test_x2_hessian_exchange_equals_sequential_merge_chain():
+  """merge_hessians_across_ranks (one weighted all-reduce per distinct Hessian) against the chain
+  of _gptq_merge_hessian over all samples in order (ref utils/qsv_utils.py:71-102)."""
+  from oracle import aeq_oracle as O
+  results = _run(_worker_x2_exchange)
+  xs = _hessian_samples()
+  for name, d in (("a", 16), ("b", 24)):
+    q = None
+    for x in xs:
+      q = O.gptq_and_moving_average_update(q, {"min": np.float32(0), "max": np.float32(1),
+                                               "hessian": O.gptq_hessian(x[..., :d]), "num_samples": x.shape[0]})
+    for rank, merged, untouched in results:
+      assert untouched
+      err = np.max(np.abs(merged[name] - q["hessian"])) / np.max(np.abs(q["hessian"]))
+      assert err <= 1e-14, (name, rank, err)
+  for rank, merged, _ in results:
+    assert np.array_equal(merged["c"], np.arange(64, dtype=np.float64).reshape(8, 8))   # weight 5/5 from one rank
+  assert all(np.array_equal(results[0][1][n], results[1][1][n]) for n in ("a", "b", "c"))
+
+
+def test_sample_sharded_gptq_calibration_reduces_hessians_instead_of_gathering_them():
+  """calibrate_sharded with a GPTQ recipe: min / max / num_samples equal the single-process result
+  exactly, the Hessian within FP64 rounding, and no d x d array enters the object gather."""
+  results = _run(_worker_calibrate_gptq)
+  for rank, rel, same, gathered_bytes, hessian_bytes in results:
+    assert same and rel and all(e <= 1e-14 for e in rel.values()), (rank, rel)
+    assert gathered_bytes < hessian_bytes * 9       # nine samples' Hessians would be at least this
+    assert gathered_bytes < 8192, gathered_bytes
 
 
 def test_tensor_sharded_quantize_gathers_everything_on_rank0():

@@ -102,14 +102,168 @@ def _worker_rccl_single(rank, world, port, out):
   ok &= bool(np.array_equal(D.gather_sample_stats(stats), stats))
   mm = D.allreduce_min_max(stats)
   ok &= bool(np.array_equal(mm[:, 0], stats[..., 0].min(0)) and np.array_equal(mm[:, 1], stats[..., 1].max(0)))
-  out.put((0, ok))
+  # ---- the C-ABI RCCL entry points themselves, on the communicator distributed.py creates
+  import ctypes
+  from mi355q import _ffi
+  L = _ffi.lib()
+  comm = D.rccl_comm()
+  ok &= comm is not None and D.rccl_comm() is comm
+  nr, rk = ctypes.c_int32(-1), ctypes.c_int32(-1)
+  _ffi.check(L.mi355q_comm_info(comm, ctypes.byref(nr), ctypes.byref(rk)))
+  ok &= (nr.value, rk.value) == (1, 0)
+  st = rt.stream_ptr()
+  a = torch.from_numpy(stats.reshape(-1).copy()).cuda()
+  b = torch.empty_like(a)
+  _ffi.check(L.mi355q_allgather_minmax(comm, rt.ptr(a), a.numel(), rt.ptr(b), st))
+  ok &= bool(torch.equal(a, b))
+  mn, mx = a.clone(), a.clone()
+  _ffi.check(L.mi355q_allreduce_minmax_f32(comm, rt.ptr(mn), rt.ptr(mx), a.numel(), st))
+  ok &= bool(torch.equal(mn, a) and torch.equal(mx, a))
+  f32 = a.clone()
+  _ffi.check(L.mi355q_allreduce_sum_f32(comm, rt.ptr(f32), f32.numel(), st))
+  f64 = torch.from_numpy(h).cuda()
+  _ffi.check(L.mi355q_allreduce_sum_f64(comm, rt.ptr(f64), f64.numel(), st))
+  ok &= bool(torch.equal(f32, a) and np.array_equal(f64.cpu().numpy(), h))
+  hh = torch.from_numpy(h).cuda()
+  _ffi.check(L.mi355q_allreduce_hessian_f64(comm, rt.ptr(hh), 64, 0.25, st))
+  ok &= bool(np.array_equal(hh.cpu().numpy(), h * 0.25))
+  ok &= L.mi355q_allreduce_hessian_f64(comm, rt.ptr(hh), 64, 1.5, st) == -1          # weight outside [0, 1]
+  ok &= L.mi355q_allreduce_sum_f32(None, rt.ptr(f32), 4, st) == -1                    # null communicator
+  # a second communicator from an explicit unique-id hand-over (what a non-torch rendezvous would do)
+  other = D.new_rccl_comm(0, 1, lambda uid: uid)
+  _ffi.check(L.mi355q_allreduce_sum_f32(other, rt.ptr(f32), f32.numel(), st))
+  torch.cuda.synchronize()
+  ok &= bool(torch.equal(f32, a))
+  _ffi.check(L.mi355q_comm_destroy(other))
+  merged = D.merge_hessians_across_ranks({"t": (rt.HbmArray(torch.from_numpy(h).cuda()), 3)}, {"t": (64, 3)})
+  ok &= bool(np.array_equal(np.asarray(merged["t"]), h))
+  D.destroy_rccl_comms()
+  out.put((0, bool(ok)))
   dist.barrier()
   dist.destroy_process_group()
 
 
 def test_collectives_over_rccl_world_of_one():
+  """torch.distributed is only the rendezvous: the data collectives are libmi355q's own RCCL entry
+  points (include/mi355q.h), exercised here on a world of one (the box has one GPU)."""
   (_, ok), = _run(_worker_rccl_single, world=1, timeout=600)
   assert ok
+
+
+def _gptq_recipe(bits=4):
+  return [dict(regex=".*", operation="FULLY_CONNECTED", algorithm_key="GPTQ", op_config=dict(
+      weight_tensor_config=dict(num_bits=bits, symmetric=True, granularity="CHANNELWISE", dtype="INT"),
+      compute_precision="INTEGER", explicit_dequantize=False, skip_checks=False, min_weight_elements=0))]
+
+
+def _fc_model(path, rows, d, seed=3):
+  import numpy as np
+  from mi355q import qtyping as q
+  from mi355q.utils import tflite_flatbuffer as fb
+  w = np.random.default_rng(seed).standard_normal((rows, d)).astype(np.float32) * np.float32(0.05)
+  model = q.ModelT(version=3, buffers=[q.BufferT(), q.BufferT(data=w.reshape(-1).view(np.uint8))],
+                   operatorCodes=[q.OperatorCodeT(builtinCode=9, deprecatedBuiltinCode=9)])
+  sg = q.SubGraphT(name=b"main", inputs=[0], outputs=[2],
+                   tensors=[q.TensorT(name=b"x", shape=[1, d], buffer=0), q.TensorT(name=b"w", shape=[rows, d], buffer=1),
+                            q.TensorT(name=b"y", shape=[1, rows], buffer=0)],
+                   operators=[q.OperatorT(inputs=[0, 1, -1], outputs=[2], builtinOptionsType=8,
+                                          builtinOptions=q.FullyConnectedOptionsT())])
+  model.subgraphs = [sg]
+  model.signatureDefs = [q.SignatureDefT(signatureKey=b"serving_default", subgraphIndex=0,
+                                         inputs=[q.TensorMapT(name=b"x", tensorIndex=0)],
+                                         outputs=[q.TensorMapT(name=b"y", tensorIndex=2)])]
+  open(path, "wb").write(fb.write_model(model))
+
+
+def _gptq_samples(d, rows, n=9):
+  import numpy as np
+  rng = np.random.default_rng(77)
+  return [{"x": (rng.standard_normal((2 + s % 3, 16, d)) * (1 + 0.1 * s)).astype(np.float32),
+           "y": rng.standard_normal((2 + s % 3, 16, rows)).astype(np.float32)} for s in range(n)]
+
+
+def _worker_calibrate_gptq(rank, world, port, out):
+  """X2 on the GPU (two gloo ranks sharing cuda:0): Hessians stay in HBM on the rank that made
+  them and are combined by one weighted all-reduce; nothing d x d is pickled."""
+  dist = _setup(rank, world, port)
+  import pickle
+  import numpy as np
+  from mi355q import calibrator, distributed as D, recipe_manager, runtime as rt
+  from mi355q.utils import tfl_flatbuffer_utils as fu
+  d, rows = 256, 64
+  path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mi355q_fc_gptq_{port}_{rank}.tflite")
+  _fc_model(path, rows, d)
+  data = {"serving_default": _gptq_samples(d, rows)}
+  sizes = []
+  real_gather = dist.all_gather_object
+
+  def counting_gather(parts, obj, group=None):
+    sizes.append(len(pickle.dumps(obj)))
+    return real_gather(parts, obj, group=group)
+  dist.all_gather_object = counting_gather
+  got = D.calibrate_sharded(path, _gptq_recipe(), data)
+  rm = recipe_manager.RecipeManager()
+  rm.load_quantization_recipe(_gptq_recipe())
+  single = calibrator.Calibrator(fu.read_model(path))
+  single.calibrate(data, rm)
+  want = single.get_model_qsvs()
+  os.remove(path)
+  ok = set(got) == set(want) and isinstance(got["x"]["hessian"], rt.HbmArray)
+  hw, hg = np.asarray(want["x"]["hessian"]), np.asarray(got["x"]["hessian"])
+  rel = float(np.max(np.abs(hg - hw)) / np.max(np.abs(hw)))
+  ok &= all(np.array_equal(np.asarray(got[n][k]), np.asarray(want[n][k])) for n in want for k in ("min", "max"))
+  ok &= int(got["x"]["num_samples"]) == int(want["x"]["num_samples"]) == sum(s["x"].shape[0] for s in data["serving_default"])
+  ok &= "hessian_dim" not in got["x"]
+  out.put((rank, bool(ok), rel, max(sizes), hw.nbytes))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_ranks_reduce_gptq_hessians_in_hbm():
+  results = _run(_worker_calibrate_gptq, timeout=600)
+  for rank, ok, rel, gathered_bytes, hessian_bytes in results:
+    assert ok, rank
+    assert rel <= 1e-14, rel                      # vs the sequential _gptq_merge_hessian chain
+    assert gathered_bytes < hessian_bytes // 8    # 9 samples' statistics, not one d x d array
+
+
+def test_quantize_sharded_tool_with_a_gptq_recipe(tmp_path):
+  """tools/quantize_sharded.py, two ranks (gloo transport, both on cuda:0), GPTQ recipe with
+  calibration samples: the file equals the one-rank file but for T2 (observed: identical)."""
+  import json
+  import subprocess
+  import numpy as np
+  from test_distributed_gloo import _free_port
+  d, rows = 256, 64
+  model = str(tmp_path / "fc.tflite")
+  for p in (os.path.join(ROOT, "ai-edge-quantizer_amd"), ROOT):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  _fc_model(model, rows, d)
+  rcp = str(tmp_path / "gptq.json")
+  json.dump(_gptq_recipe(), open(rcp, "w"))
+  samples = _gptq_samples(d, rows)
+  np.savez(str(tmp_path / "calib.npz"), **{f"{i}/{k}": v for i, s in enumerate(samples) for k, v in s.items()})
+  outs = []
+  for n in (1, 2):
+    dst = str(tmp_path / f"q{n}.tflite")
+    env = dict(os.environ, MI355Q_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "quantize_sharded.py"), model, rcp, dst,
+           str(tmp_path / "calib.npz")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    outs.append(open(dst, "rb").read())
+  assert len(outs[0]) == len(outs[1])
+  import parity_rates
+  a, b = np.frombuffer(outs[0], np.uint8), np.frombuffer(outs[1], np.uint8)
+  assert (a != b).mean() <= 1e-4                  # everything but (possibly) a few int4 nibbles
+  from mi355q.utils import tfl_flatbuffer_utils as fu
+  qa, qb = (np.asarray(fu.read_model(o).buffers[1].data) for o in outs)
+  def nib(v):
+    u = np.stack([v & 15, v >> 4], 1).reshape(-1).astype(np.int16)
+    return np.where(u > 7, u - 16, u)
+  parity_rates.check("quantize_sharded.py GPTQ int4: 2 ranks vs 1 rank", nib(qa), nib(qb), parity_rates.T2)
 
 
 def _worker_calibrate(rank, world, port, out):
