@@ -18,6 +18,8 @@
 // One wave owns one unit. The unit is staged once into LDS (one HBM read for all
 // 10 Newton iterations); selections are wave ballots, runs are found with scalar
 // bit scans, and short runs are summed from registers with v_readlane.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mi355q {
@@ -328,6 +330,408 @@ __global__ void octav_kernel(OctavArgs a) {
     guess = st.next;
   }
   if (lane == 0) publish_moving(a.moving, moved);
+}
+
+// ---- long contiguous units (1024 <= len <= 8192): one workgroup per unit, lanes own 16 elements ----
+//
+// Where the time went in octav_kernel on rows of 4096 weights (profiles/r01_octav_iterations...):
+// with the guess at 0 each of the two masks selects every other element at random, a row has
+// ~1000 runs per mask, and the running total `acc = acc + pairwise(run)` is a chain of ~2000
+// dependent additions per row that ONE wave walked 64 elements at a time, with a scalar bit scan,
+// DPP rounds and a ds_permute per batch (328 us for one iteration over 4096 rows), at one or two
+// waves per SIMD because a 16 KB row sits behind every wave.
+//
+// Here a 256-thread workgroup owns a row (staged once in LDS for all iterations) and the work is
+// split by what can be parallel:
+//   masks   every wave compares its 64-element batches; thread t keeps the 16 mask bits of "its"
+//           piece, elements [16 t, 16 t + 16). When the guess did not decrease (it never does after
+//           the first update on real weights) the new selection is a subset of the old one, so
+//           every thread just re-tests the set bits of its own old word: the cost follows the
+//           number of selected elements;
+//   runs    every thread walks the runs that START in its piece (bit scans on its own word; a run
+//           that reaches the end of the piece continues through the following words, read from
+//           LDS, up to NumPy's 8192-element chunk boundary) and sums each with NumPy's pairwise
+//           scheme from LDS: left to right below 8 elements, eight strided accumulators up to 128,
+//           runs longer than that (dense rows) by a whole wave. The sums land, in run order, in a
+//           list in LDS (a workgroup prefix sum over the per-thread run counts gives the slots);
+//   chain   acc = acc + R_j over the list: the only serial part, done by one wave (a different
+//           one from workgroup to workgroup, so the four SIMDs of a CU share that load). The
+//           positive and the negative mask's chains advance together as the two halves of packed
+//           FP32 additions (v_pk_add_f32); the list is read with broadcast 16-byte LDS loads,
+//           sixteen entries ahead of the additions.
+// The row is stored with one float of padding per 16 (thread-owned pieces start on distinct banks).
+constexpr int kRowsMinLen = 1024, kRowsMaxLen = kChunk;
+constexpr int kRowsThreads = 256;
+constexpr int kPiece = 16;
+
+__device__ __forceinline__ int pidx(int e) { return e + (e >> 4); }
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Wave-wide integer prefix sum on the DPP network (no LDS round trips): Hillis-Steele inside each
+// row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 of rows 0 / 2
+// into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add(int x) {
+  return x + __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xF, true);
+}
+
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  x = dpp_add<0x111, 0xF>(x);
+  x = dpp_add<0x112, 0xF>(x);
+  x = dpp_add<0x114, 0xF>(x);
+  x = dpp_add<0x118, 0xF>(x);
+  x = x + __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+  x = x + __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
+// NumPy's pairwise sum of row[e0 .. e0 + n) (padded addressing), computed by ONE lane.
+// n <= 128 (longer runs go to pairwise_wave below).
+__device__ __forceinline__ float pairwise_lane(const float* row, int e0, int n) {
+  if (n < 8) {
+    float res = 0.f;
+    for (int i = 0; i < n; ++i) res = res + row[pidx(e0 + i)];
+    return res;
+  }
+  float r[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = row[pidx(e0 + k)];
+  const int full = n & ~7;
+  for (int i = 8; i < full; i += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = r[k] + row[pidx(e0 + i + k)];
+  }
+  float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (int i = full; i < n; ++i) res = res + row[pidx(e0 + i)];
+  return res;
+}
+
+// The same for n > 128, by a whole wave (wave-uniform arguments): lanes 0..7 are the eight
+// accumulators of a leaf, the recursion splits as NumPy does.
+__device__ __forceinline__ float leaf_wave(const float* row, int e0, int m, int lane) {
+  const int full = m & ~7;
+  float r = 0.f;
+  if (lane < 8) {
+    r = row[pidx(e0 + lane)];
+    for (int i = 8; i < full; i += 8) r = r + row[pidx(e0 + i + lane)];
+  }
+  const float r0 = lane_bcast(r, 0), r1 = lane_bcast(r, 1), r2 = lane_bcast(r, 2),
+              r3 = lane_bcast(r, 3), r4 = lane_bcast(r, 4), r5 = lane_bcast(r, 5),
+              r6 = lane_bcast(r, 6), r7 = lane_bcast(r, 7);
+  float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (int i = full; i < m; ++i) res = res + row[pidx(e0 + i)];
+  return res;
+}
+
+template <int DEPTH>
+__device__ __noinline__ float pairwise_wave(const float* row, int e0, int n, int lane) {
+  if (n <= 128) return leaf_wave(row, e0, n, lane);   // (n >= 8 here: halves of n > 128 are >= 64)
+  if constexpr (DEPTH > 0) {
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const float left = pairwise_wave<DEPTH - 1>(row, e0, n2, lane);
+    const float right = pairwise_wave<DEPTH - 1>(row, e0 + n2, n - n2, lane);
+    return left + right;
+  } else {
+    return leaf_wave(row, e0, n, lane);  // unreachable for n <= 8192
+  }
+}
+
+struct RowsShared {      // small per-workgroup exchange area (in front of the row in LDS)
+  int wave_runs[2][2][4];   // [mask][slot][wave]: runs starting in that wave's pieces
+  int wave_count[2][4];     // selected elements per wave
+  int wave_changed[4];      // some word of the wave differs from the previous iteration's
+  float sum[2];             // the two chain totals
+};
+
+// One mask of one piece: `word` = the 16 selection bits of elements x[0..16) (element e0 = 16 pc),
+// `carry` = the element before the piece is selected too (same chunk). Writes the sums of the runs
+// that START in this piece to list[j0 ...][COMP] in order.
+//   * runs shorter than 8 that end inside the piece: a fixed 16-step pass over the registers --
+//     cur = cur + (selected ? x : +0.0), flushed to the list where a run ends (no data-dependent
+//     control flow; a step that ends no run stores to a per-thread dummy slot);
+//   * a run that reaches the piece's end continues through the following words (LDS); shorter
+//     than 8 in total: the left-to-right chain simply goes on over the row in LDS;
+//   * runs of 8 .. 128 elements: eight strided accumulators (pairwise_lane, from LDS);
+//   * longer runs (dense rows): reported back, summed by the whole wave afterwards.
+template <int COMP>
+__device__ __forceinline__ void piece_runs(const float (&x)[kPiece], unsigned word, unsigned carry, int pc,
+                                           int npieces, const unsigned short* words, const float* row,
+                                           v2f* list, float* dummy, int j0, int* long_e0, int* long_n,
+                                           int* long_j) {
+  // leading elements that continue a run started in an earlier piece are not this thread's business
+  const unsigned lead = carry ? ((word + 1u) & ~word) - 1u : 0u;   // the low run of ones (if bit 0 is set)
+  const unsigned w = word & ~lead & 0xFFFFu;
+  const unsigned ends = w & ~(w >> 1) & 0x7FFFu;   // runs ending inside the piece (bit 15 = open end)
+  float cur = 0.f;
+  int j = j0;
+#pragma unroll
+  for (int i = 0; i < kPiece; ++i) {
+    const int sel = static_cast<int>(w << (31 - i)) >> 31;      // 0 / -1
+    cur = cur + __int_as_float(__float_as_int(x[i]) & sel);
+    if (i < kPiece - 1) {
+      const int fin = static_cast<int>(ends << (31 - i)) >> 31;
+      float* dst = fin ? reinterpret_cast<float*>(list + j) + COMP : dummy;
+      *dst = cur;
+      j -= fin;
+      cur = __int_as_float(__float_as_int(cur) & ~fin);
+    }
+  }
+  // runs of 8+ elements that lie inside the piece (rare): redo them with the eight accumulators
+  unsigned m8 = w & (w >> 1); m8 &= m8 >> 2; m8 &= m8 >> 4;      // bit i: ones at i .. i+7
+  m8 &= ~(m8 << 1);                                              // ... and i is where they start
+  const unsigned starts = w & ~(w << 1);
+  while (m8 != 0) {
+    const int i = __builtin_ctz(m8);
+    m8 &= m8 - 1u;
+    const int n = __builtin_ctz(~(w >> i));
+    if (i + n < kPiece)    // (a run that reaches the end is handled below)
+      reinterpret_cast<float*>(list + j0 + __builtin_popcount(starts & ((1u << i) - 1u)))[COMP] =
+          pairwise_lane(row, kPiece * pc + i, n);
+  }
+  if (w >> (kPiece - 1)) {   // the last run is open: follow it
+    const unsigned zeros = ~w & 0xFFFFu;
+    const int i = zeros ? 32 - __builtin_clz(zeros) : 0;     // its first bit (0 when w is all ones)
+    int n = kPiece - i;
+    int q = pc + 1;
+    while (q < npieces && (q & (kChunk / kPiece - 1)) != 0) {
+      const unsigned nx = words[q];
+      if (nx == 0xFFFFu) { n += kPiece; ++q; continue; }
+      n += __builtin_ctz(~nx);
+      break;
+    }
+    const int e0 = kPiece * pc + i;
+    float res = cur;
+    if (n < 8) {
+      for (int k = kPiece - i; k < n; ++k) res = res + row[pidx(e0 + k)];
+    } else if (n <= 128) {
+      res = pairwise_lane(row, e0, n);
+    } else {
+      *long_e0 = e0; *long_n = n; *long_j = j;
+    }
+    reinterpret_cast<float*>(list + j)[COMP] = res;
+  }
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : 2) void octav_rows_kernel(OctavArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const long long unit = blockIdx.x;
+  const int len = a.len;
+  const int npieces = (len + kPiece - 1) / kPiece;
+  static_assert(sizeof(RowsShared) <= 128, "exchange area");
+  float* dummy = smem + 64 + tid;                          // (two exchange areas in front)
+  float* row = smem + 64 + kRowsThreads;
+  const int row_floats = (pidx(len) + 4) & ~3;
+  v2f* list = reinterpret_cast<v2f*>(row + row_floats);
+  const int cap = ((len / 2 + 1 + 31) & ~31) + 32;         // + the chain's read-ahead
+  unsigned short* words_pos = reinterpret_cast<unsigned short*>(list + cap);
+  unsigned short* words_neg = words_pos + ((npieces + 1) & ~1);
+
+  // ---- stage the unit: every thread keeps its pieces in registers for all iterations (one HBM
+  // read), the row also goes to LDS for the runs that leave a piece
+  const float qnan = __builtin_nanf("");
+  float x[SLOTS][kPiece];
+  float before[SLOTS];      // the element in front of each piece (same chunk), else NaN
+  {
+    const float* g = a.x + unit * len;
+    const bool al = (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int e0 = kPiece * (tid + kRowsThreads * s);
+      if (al && e0 + kPiece <= len) {
+        const float4* g4 = reinterpret_cast<const float4*>(g + e0);
+        const float4 v0 = g4[0], v1 = g4[1], v2 = g4[2], v3 = g4[3];
+        x[s][0] = v0.x; x[s][1] = v0.y; x[s][2] = v0.z; x[s][3] = v0.w;
+        x[s][4] = v1.x; x[s][5] = v1.y; x[s][6] = v1.z; x[s][7] = v1.w;
+        x[s][8] = v2.x; x[s][9] = v2.y; x[s][10] = v2.z; x[s][11] = v2.w;
+        x[s][12] = v3.x; x[s][13] = v3.y; x[s][14] = v3.z; x[s][15] = v3.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < kPiece; ++i) x[s][i] = e0 + i < len ? g[e0 + i] : qnan;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int e0 = kPiece * (tid + kRowsThreads * s);
+      const int p = pidx(e0);
+#pragma unroll
+      for (int i = 0; i < kPiece; ++i)
+        if (e0 + i < len) row[p + i] = x[s][i];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int pc = tid + kRowsThreads * s;
+    before[s] = (pc > 0 && pc < npieces && (pc & (kChunk / kPiece - 1)) != 0) ? row[pidx(kPiece * pc - 1)] : qnan;
+  }
+
+  unsigned wp[SLOTS], wn[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) wp[s] = wn[s] = 0u;
+  float guess = 1.0f;
+  float pos_sum = 0.f, neg_sum = 0.f;
+  int cp = 0, cn = 0;
+  unsigned long long moved = 0;
+  // the serial chain runs on one wave per workgroup: spread it over the SIMDs of the CU
+  // (workgroups u, u + 256, u + 512, ... tend to be co-resident)
+  const int chain_wave = static_cast<int>((unit + (unit >> 8)) & 3);
+  for (int it = 0; it < a.max_iter; ++it) {
+    const float hi = guess, lo = -guess;
+    // (two exchange areas, by iteration parity: an iteration whose masks did not change has only
+    // one barrier, so a fast wave may already publish the next iteration's counts while a slow one
+    // still reads this one's)
+    RowsShared* sh = reinterpret_cast<RowsShared*>(smem + 32 * (it & 1));
+    // ---- masks of the thread's own pieces, from registers
+    unsigned changed = 0;
+    unsigned sp[SLOTS], sn[SLOTS];   // run starts
+    int pre_p[SLOTS], pre_n[SLOTS];
+    int tp = 0, tn = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      unsigned np_ = 0, nn_ = 0;
+#pragma unroll
+      for (int i = 0; i < kPiece; ++i) {
+        np_ |= x[s][i] >= hi ? 1u << i : 0u;
+        nn_ |= x[s][i] <= lo ? 1u << i : 0u;
+      }
+      changed |= (np_ ^ wp[s]) | (nn_ ^ wn[s]);
+      wp[s] = np_; wn[s] = nn_;
+      const int pc = tid + kRowsThreads * s;
+      if (pc < npieces) {
+        words_pos[pc] = static_cast<unsigned short>(np_);
+        words_neg[pc] = static_cast<unsigned short>(nn_);
+      }
+      tp += __builtin_popcount(np_);
+      tn += __builtin_popcount(nn_);
+      const unsigned cpos = before[s] >= hi ? 1u : 0u, cneg = before[s] <= lo ? 1u : 0u;
+      sp[s] = np_ & ~((np_ << 1) | cpos) & 0xFFFFu;
+      sn[s] = nn_ & ~((nn_ << 1) | cneg) & 0xFFFFu;
+      const int ip = wave_incl_scan(__builtin_popcount(sp[s])), in = wave_incl_scan(__builtin_popcount(sn[s]));
+      pre_p[s] = ip - __builtin_popcount(sp[s]);
+      pre_n[s] = in - __builtin_popcount(sn[s]);
+      if (lane == kWave - 1) { sh->wave_runs[0][s][wave] = ip; sh->wave_runs[1][s][wave] = in; }
+    }
+    tp = wave_incl_scan(tp);
+    tn = wave_incl_scan(tn);
+    const bool wave_changed = __ballot(changed != 0) != 0;
+    if (lane == kWave - 1) {
+      sh->wave_count[0][wave] = tp; sh->wave_count[1][wave] = tn;
+      sh->wave_changed[wave] = wave_changed ? 1 : 0;
+    }
+    __syncthreads();
+    const bool any_changed = (sh->wave_changed[0] | sh->wave_changed[1] | sh->wave_changed[2] | sh->wave_changed[3]) != 0;
+    if (any_changed || it == 0) {
+      // (the same masks give the same sums and counts: late iterations mostly skip all of this)
+      cp = sh->wave_count[0][0] + sh->wave_count[0][1] + sh->wave_count[0][2] + sh->wave_count[0][3];
+      cn = sh->wave_count[1][0] + sh->wave_count[1][1] + sh->wave_count[1][2] + sh->wave_count[1][3];
+      int npos = 0, nneg = 0;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        int bp = npos, bn = nneg;   // runs of earlier slots, then of earlier waves of this slot
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c0 = sh->wave_runs[0][s][k], c1 = sh->wave_runs[1][s][k];
+          if (k < wave) { bp += c0; bn += c1; }
+          npos += c0; nneg += c1;
+        }
+        pre_p[s] += bp; pre_n[s] += bn;
+      }
+      // ---- run sums, in run order
+      int long_e0[2 * SLOTS], long_n[2 * SLOTS], long_j[2 * SLOTS];
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        const int pc = tid + kRowsThreads * s;
+        long_n[2 * s] = long_n[2 * s + 1] = 0;
+        long_e0[2 * s] = long_e0[2 * s + 1] = long_j[2 * s] = long_j[2 * s + 1] = 0;
+        if (pc < npieces) {
+          piece_runs<0>(x[s], wp[s], before[s] >= hi ? 1u : 0u, pc, npieces, words_pos, row, list, dummy,
+                        pre_p[s], &long_e0[2 * s], &long_n[2 * s], &long_j[2 * s]);
+          piece_runs<1>(x[s], wn[s], before[s] <= lo ? 1u : 0u, pc, npieces, words_neg, row, list, dummy,
+                        pre_n[s], &long_e0[2 * s + 1], &long_n[2 * s + 1], &long_j[2 * s + 1]);
+        }
+      }
+      // dense rows: runs longer than 128 elements, one at a time by the wave that found them
+#pragma unroll
+      for (int k = 0; k < 2 * SLOTS; ++k) {
+        unsigned long long pending = __ballot(long_n[k] > 0);
+        while (pending != 0) {
+          const int src = __builtin_ctzll(pending);
+          pending &= pending - 1ull;
+          const int e0 = __builtin_amdgcn_readlane(long_e0[k], src);
+          const int n = __builtin_amdgcn_readlane(long_n[k], src);
+          const int j = __builtin_amdgcn_readlane(long_j[k], src);
+          const float res = pairwise_wave<8>(row, e0, n, lane);
+          if (lane == 0) reinterpret_cast<float*>(list + j)[k & 1] = res;
+        }
+      }
+      const int kmax = (max(npos, nneg) + 31) & ~31;   // whole double blocks of 2 x 16 entries: no tail code in the chain
+      for (int j = npos + tid; j < kmax; j += kRowsThreads) reinterpret_cast<float*>(list + j)[0] = 0.f;
+      for (int j = nneg + tid; j < kmax; j += kRowsThreads) reinterpret_cast<float*>(list + j)[1] = 0.f;
+      __syncthreads();
+      // ---- the chain: acc = acc + R_j in run order, both masks at once (adding +0.0 padding is
+      // exact: a running total that started at +0.0 is never -0.0)
+      if (wave == chain_wave) {
+        v2f acc = {0.f, 0.f};
+        if (kmax > 0) {
+          // Software pipelined by hand: the eight 16-byte broadcast loads of the NEXT sixteen entries are
+          // issued, then the sixteen dependent packed additions of the current ones run while those
+          // loads are in flight (the scheduling barriers keep the compiler from sinking the loads
+          // back behind the additions; it still places the s_waitcnt itself). The list is
+          // over-allocated by one block: what the last read-ahead fetches is never added.
+          const float4* l4 = reinterpret_cast<const float4*>(list);
+          const int npair = kmax >> 5;
+          float4 qa[8], qb[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) qa[k] = l4[k];
+          for (int pr = 0; pr < npair; ++pr) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) qb[k] = l4[(2 * pr + 1) * 8 + k];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              acc = acc + v2f{qa[k].x, qa[k].y};
+              acc = acc + v2f{qa[k].z, qa[k].w};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) qa[k] = l4[(2 * pr + 2) * 8 + k];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              acc = acc + v2f{qb[k].x, qb[k].y};
+              acc = acc + v2f{qb[k].z, qb[k].w};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (lane == 0) { sh->sum[0] = acc.x; sh->sum[1] = acc.y; }
+      }
+      __syncthreads();   // totals visible; the list may be rewritten by the next iteration
+      pos_sum = sh->sum[0];
+      neg_sum = sh->sum[1];
+    }
+    const OctavStep st = octav_step(guess, pos_sum, neg_sum, cp, cn, len, a.s, a.count_is_f64);
+    if (tid == 0) a.hist[static_cast<long long>(it) * a.units + unit] = st.next;
+    if (!st.close) moved |= 1ull << it;
+    if (reached_fixed_point(guess, st.next)) {
+      if (tid == 0) repeat_iterate(a, it, unit, st.next);
+      break;
+    }
+    guess = st.next;
+  }
+  if (tid == 0) publish_moving(a.moving, moved);
+}
+
+size_t octav_rows_smem(int len) {
+  const int npieces = (len + kPiece - 1) / kPiece;
+  const size_t row_floats = static_cast<size_t>((len + (len >> 4) + 4) & ~3);
+  const size_t cap = static_cast<size_t>(((len / 2 + 1 + 31) & ~31) + 32);
+  return 256 + kRowsThreads * sizeof(float) + row_floats * sizeof(float) + cap * 2 * sizeof(float) +
+         static_cast<size_t>((npieces + 1) & ~1) * 2 * sizeof(unsigned short);
 }
 
 // ---- general [outer, channels, inner] view: unit c = the `outer` segments x[o, c, :] -----
@@ -706,6 +1110,30 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
   double p4 = 1.0;
   for (int i = 0; i < bits; ++i) p4 *= 0.25;
   const float s = static_cast<float>(p4 / static_cast<double>(exponent_divisor));
+  if (unit_len >= kRowsMinLen && unit_len <= kRowsMaxLen && !getenv("MI355Q_OCTAV_WAVE_KERNEL")) {
+    // rows of a weight matrix: lanes own 64-element batches of the LDS-resident row
+    OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close};
+    const size_t smem = octav_rows_smem(a.len);
+    const bool two = (a.len + kPiece - 1) / kPiece > kRowsThreads;
+    static bool raised[2] = {false, false};   // > 64 KB of dynamic LDS has to be asked for once
+    if (smem > 64 * 1024 && !raised[two]) {
+      const hipError_t e = two ? hipFuncSetAttribute(reinterpret_cast<const void*>(octav_rows_kernel<2>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                               : hipFuncSetAttribute(reinterpret_cast<const void*>(octav_rows_kernel<1>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+      raised[two] = true;
+    }
+    const dim3 grid(static_cast<unsigned>(units)), blk(kRowsThreads);
+    if (units > 0x7FFFFFFFLL) return fail(MI355Q_UNSUPPORTED, "too many units");
+    if (two) hipLaunchKernelGGL(octav_rows_kernel<2>, grid, blk, smem, st, a);
+    else hipLaunchKernelGGL(octav_rows_kernel<1>, grid, blk, smem, st, a);
+    MI355Q_CHECK_LAUNCH("octav rows launch");
+    hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
+                       hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
+    MI355Q_CHECK_LAUNCH("octav pick launch");
+    return MI355Q_OK;
+  }
   const UnitPlan p = plan_units(static_cast<int>(unit_len));
   OctavArgs a{x, units, static_cast<int>(unit_len), p.lds_stride, max_iter, count_is_f64, s, hist, not_close};
   const dim3 blk(p.waves * kWave);

@@ -343,7 +343,7 @@ def test_octav_masked_sums_with_designed_run_lengths(m, seed):
   elements are tiny, so the masks stay put over the iterations and every iteration exercises the
   same pattern; rows of several lengths, both signs."""
   rng = np.random.default_rng(1000 + seed)
-  lengths = [64, 100, 127, 128, 1000, 4096, 8192, 8192 + 37, 8192 + 64 + 7, 20000]
+  lengths = [64, 100, 127, 128, 1000, 1024, 1100, 2048, 4096, 5000, 8191, 8192, 8192 + 37, 8192 + 64 + 7, 20000]
   pool = np.concatenate([np.arange(1, 13), np.arange(55, 71), np.arange(120, 141), [300]])
   for n in lengths:
     rows = []
