@@ -68,6 +68,23 @@ def cpu_baseline(seconds: float):
                     f" host has {os.cpu_count()} cpus) in {dt:.2f}s"}
 
 
+def per_launch_ms(fn, iters: int):
+  """Duration of every single fn() launch (one HIP event pair each, on the launch stream):
+  sorted list of milliseconds. SURVEY 8d asks for median / p10 / p90, not only the mean."""
+  import torch
+  evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+  for a, b in evs:
+    a.record()
+    fn()
+    b.record()
+  torch.cuda.synchronize()
+  return sorted(a.elapsed_time(b) for a, b in evs)
+
+
+def pct(sorted_ms, q: float) -> float:
+  return sorted_ms[min(len(sorted_ms) - 1, int(q * len(sorted_ms)))]
+
+
 def event_time_ms(fn, iters: int) -> float:
   """Average duration of fn() measured with HIP events on the launch stream."""
   import torch
@@ -78,6 +95,185 @@ def event_time_ms(fn, iters: int) -> float:
   end.record()
   end.synchronize()
   return start.elapsed_time(end) / iters
+
+
+MFMA_F32_PEAK_TF, MFMA_F64_PEAK_TF = 157.3, 78.6   # dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def timed_ms(torch, fn, reps: int, warm: int = 2) -> float:
+  for _ in range(warm):
+    fn()
+  return event_time_ms(fn, reps)
+
+
+def more_extras(torch, ops, gen, xs) -> dict:
+  """The other BASELINE configurations at their own rooflines, the product path through the
+  public interface, and file in -> file out. All outside the timed region; a few seconds."""
+  import numpy as np
+  out = {}
+  # ---- C2 / C3 through the public interface: get_tensor_quant_params inside the batching
+  # context ParamsGenerator runs in (weights resident in HBM)
+  from mi355q import qtyping as q, requant_queue, runtime as rt
+  from mi355q.algorithms.uniform_quantize import naive_min_max_quantize as mm
+  api = {}
+  for label, pool, bits, gran, alg in (
+      ("c2_int8_channelwise_4096x4096", xs, 8, "CHANNELWISE", ALG_BYTES),
+      ("c3_int4_blockwise128_4096x11008",
+       [torch.randn((4096, 11008), generator=gen, device="cuda") * 0.02 for _ in range(8)], 4, "BLOCKWISE_128",
+       4096 * 11008 * 4 + 4096 * 11008 // 2 + 4096 * 11008 // 128 * 2)):
+    cfg = q.TensorQuantizationConfig(num_bits=bits, symmetric=True, granularity=q.QuantGranularity[gran])
+    info = q.OpInfo(op=q.OperatorT(), op_name=q.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
+                    op_quant_config=q.OpQuantizationConfig(weight_tensor_config=cfg))
+    res = [rt.HbmArray(t) for t in pool] * (64 // len(pool))
+    best = None
+    for _ in range(5):
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      with requant_queue.batching() as queue:
+        for r in res:
+          mm.get_tensor_quant_params(info, cfg, r)
+      torch.cuda.synchronize()
+      dt = (time.perf_counter() - t0) / len(res)
+      best = dt if best is None else min(best, dt)
+    api[label] = {"us_per_tensor": round(best * 1e6, 2), "launches": queue.stats["launches"],
+                  "tensors": queue.stats["tensors"], "weight_GBps": round(pool[0].numel() * 4 / best / 1e9, 1),
+                  "hbm_frac": round(alg / best / 1e9 / HBM_PEAK_GBS, 4)}
+    del res, pool
+  out["api_resident"] = dict(api, note="wall time per tensor of get_tensor_quant_params(resident weight) inside"
+                                       " requant_queue.batching(): Python + one batched launch per 64 tensors")
+  # ---- file in -> file out (PCIe, page cache and the flatbuffer writer included)
+  try:
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import file_bench
+    from mi355q import quantizer, recipe
+    with tempfile.TemporaryDirectory() as d:
+      src, dst = os.path.join(d, "in.tflite"), os.path.join(d, "out.tflite")
+      layers, rows, cols = 8, 4096, 11008
+      file_bench.build_model(src, layers, rows, cols)
+      best = None
+      for _ in range(3):
+        if os.path.exists(dst):
+          os.remove(dst)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        quantizer.Quantizer(src, recipe.dynamic_wi4b128_afp32()).quantize(serialize_to_path=dst)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+      wbytes = layers * rows * cols * 4
+      alg = layers * (rows * cols * 4 + rows * cols // 2 + rows * cols // 128 * 2)
+      out["file_to_file"] = {"workload": f"{layers} x FC {rows}x{cols} fp32 .tflite -> int4 blockwise-128 .tflite",
+                             "seconds": round(best, 4), "weight_GBps": round(wbytes / best / 1e9, 2),
+                             "hbm_frac": round(alg / best / 1e9 / HBM_PEAK_GBS, 5),
+                             "note": "host-bound: mmap'd file -> PCIe -> HBM -> PCIe -> mmap'd file"}
+  except Exception as e:  # noqa: BLE001 - an extra must never cost the headline
+    out["file_to_file"] = {"error": repr(e)[:200]}
+  # ---- host <-> device staging of one C2 buffer (SURVEY 8d: reported separately, never in `value`)
+  hostw = np.random.default_rng(0).standard_normal((ROWS, COLS), dtype=np.float32)
+  pinned = torch.from_numpy(hostw).pin_memory()
+  devw, q8 = torch.empty((ROWS, COLS), device="cuda"), torch.empty((ROWS, COLS), dtype=torch.int8, device="cuda")
+  hq = torch.empty((ROWS, COLS), dtype=torch.int8).pin_memory()
+
+  def wall(fn, reps=8):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+      fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+  out["pcie"] = {
+      "h2d_pageable_GBps": round(hostw.nbytes / wall(lambda: devw.copy_(torch.from_numpy(hostw))) / 1e9, 1),
+      "h2d_pinned_GBps": round(hostw.nbytes / wall(lambda: devw.copy_(pinned, non_blocking=True)) / 1e9, 1),
+      "d2h_pinned_int8_GBps": round(q8.numel() / wall(lambda: hq.copy_(q8, non_blocking=True)) / 1e9, 1),
+      "note": "one 4096x4096 buffer: 64 MiB FP32 up, 16 MiB int8 down"}
+  del pinned, devw, q8, hq
+  # ---- C4: activation min/max, 128 tensors of [1, 256, 4096] per launch
+  acts = [torch.randn((1, 256, 4096), generator=gen, device="cuda") * (1 + i / 8) for i in range(128)]
+  amm = ops.ActMinMaxBatch([a.reshape(-1) for a in acts])
+  ms = timed_ms(torch, amm.run, 50, 10)
+  nbytes = sum(a.numel() for a in acts) * 4
+  out["c4_act_minmax"] = {"ms_per_launch": round(ms, 5), "tensors_per_launch": len(acts),
+                          "roofline": {"bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                       "alg_bytes_per_launch": nbytes}}
+  del acts, amm
+  # ---- OCTAV / Hadamard on the C5 rotation shape (4096 x 4096, int4 channelwise)
+  w = xs[0] * 0.02
+  ms = timed_ms(torch, lambda: ops.octav_clip(w.view(-1), 4096, 4096, 4, 10, 3.0, True, True), 20, 3)
+  out["octav_clip_4096x4096_int4"] = {"ms": round(ms, 4), "hbm_frac_of_one_read": round(ROWS * COLS * 4 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                      "note": "bit-exact NumPy-order masked sums, 10 Newton iterations, sigma = 0.02"}
+  ms = timed_ms(torch, lambda: ops.hadamard_rotate(w, 4096), 50, 5)
+  out["hadamard_4096x4096"] = {"ms": round(ms, 5), "roofline": {"bound": "hbm", "achieved": round(2 * ROWS * COLS * 4 / ms / 1e6, 1),
+                                                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                               "frac": round(2 * ROWS * COLS * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)}}
+  # ---- C5: GPTQ at the Gemma-2B shapes (MFMA-bound; utilisation counters: profiles/r0*_gptq_mfma_util.txt)
+  c5 = {}
+  for d, tokens in ((2048, 65536), (16384, 16384)):
+    x = torch.randn((tokens, d), generator=gen, device="cuda")
+    reps = 10 if d == 2048 else 3
+    ms_h = timed_ms(torch, lambda: ops.gptq_xtx(x, 2.0 / 128), reps, 1)
+    h = ops.gptq_xtx(x, 2.0 / 128)
+    del x
+    ms_i = timed_ms(torch, lambda: ops.gptq_hinv(h, 0.01), reps, 1)
+    hinv, _ = ops.gptq_hinv(h, 0.01)
+    rows = 2048
+    wq = torch.randn((rows, d), generator=gen, device="cuda") * 0.02
+    sc = (wq.abs().amax(dim=1) / 7).contiguous()
+    ms_a = timed_ms(torch, lambda: ops.gptq_apply(wq, hinv, sc, None, 1, 0, 4, False, False, 8), reps, 1)
+    # the triangular product computes half of 2 n d^2; the inverse is d^3 (Cholesky + triangular inverse + product)
+    c5[f"d{d}"] = {
+        "hessian": {"ms": round(ms_h, 3), "tokens": tokens,
+                    "roofline": {"bound": "mfma", "achieved": round(tokens * d * d / ms_h / 1e9, 1), "peak": MFMA_F32_PEAK_TF,
+                                 "unit": "TFLOP/s", "frac": round(tokens * d * d / ms_h / 1e9 / MFMA_F32_PEAK_TF, 4),
+                                 "flops": "n d^2 (lower triangle of X^T X, FP32 MFMA)"}},
+        "hinv": {"ms": round(ms_i, 3),
+                 "roofline": {"bound": "mfma", "achieved": round(d ** 3 / ms_i / 1e9, 1), "peak": MFMA_F64_PEAK_TF,
+                              "unit": "TFLOP/s", "frac": round(d ** 3 / ms_i / 1e9 / MFMA_F64_PEAK_TF, 4),
+                              "flops": "d^3 (FP64 MFMA)"}},
+        "apply_2048_rows_int4": {"ms": round(ms_a, 3),
+                                 "roofline": {"bound": "mfma", "achieved": round(2 * rows * d * d / ms_a / 1e9, 1),
+                                              "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                              "frac": round(2 * rows * d * d / ms_a / 1e9 / MFMA_F32_PEAK_TF, 4),
+                                              "note": "latency-bound on the column-serial quantize -> divide -> update chain"}}}
+    del h, hinv, wq, sc
+  out["c5_gptq"] = c5
+  return out
+
+
+def collective_probe(torch, dist, rank, world, backend):
+  """N > 1 only, after the timed region: one all-gather of C4's per-sample statistics (128 KiB
+  per rank set) and one 16 MiB all-reduce (a d = 2048 Hessian in float32 terms) through
+  libmi355q's RCCL entry points, so a scaling run exercises xGMI and reports RCCL's own rank count."""
+  if backend != "nccl":
+    return {"transport": backend, "note": "RCCL needs one GPU per rank"}
+  import ctypes
+  from mi355q import _ffi, distributed as D, runtime as rt
+  L = _ffi.lib()
+  comm = D.rccl_comm()
+  nr, rk = ctypes.c_int32(0), ctypes.c_int32(0)
+  _ffi.check(L.mi355q_comm_info(comm, ctypes.byref(nr), ctypes.byref(rk)))
+  n_local = 512 // world * 32 * 2                      # C4: 512 samples x 32 tensors x (min, max) over the ranks
+  loc = torch.full((n_local,), float(rank), device="cuda")
+  allv = torch.empty((world * n_local,), device="cuda")
+  big = torch.ones((4 << 20,), device="cuda")
+
+  def gather():
+    _ffi.check(L.mi355q_allgather_minmax(comm, rt.ptr(loc), n_local, rt.ptr(allv), rt.stream_ptr()))
+
+  def reduce():
+    _ffi.check(L.mi355q_allreduce_sum_f32(comm, rt.ptr(big), big.numel(), rt.stream_ptr()))
+  res = {}
+  for name, fn, nbytes in (("allgather_minmax", gather, world * n_local * 4), ("allreduce_sum_f32_16MiB", reduce, 16 << 20)):
+    fn()
+    torch.cuda.synchronize()
+    dist.barrier()
+    ms = event_time_ms(fn, 10)
+    res[name] = {"ms": round(ms, 4), "bytes": nbytes}
+  ok = bool(torch.equal(allv.view(world, n_local)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)))
+  res.update(transport="rccl via libmi355q", rccl_ranks=nr.value, rccl_rank0=rk.value, allgather_correct=ok)
+  return res
 
 
 def main():
@@ -185,15 +381,24 @@ def main():
                                 "weight_GBps": round(POOL * ROWS * COLS * 4 / ms4 / 1e6, 1)}
     del b4
 
+  launch_sorted = per_launch_ms(batch.run, max(20, min(args.steps, 200)))
+
+  if args.extras and rank == 0 and world == 1:
+    extras.update(more_extras(torch, ops, gen, xs))
+  collectives = None
+  if world > 1:
+    collectives = collective_probe(torch, dist, rank, world, backend)
+
   if rank == 0:
     total_bytes = world * args.steps * POOL * ROWS * COLS * 4
-    traffic = None
+    traffic = traffic_source = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
       try:
-        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        rec = json.load(open(pmc))
+        traffic, traffic_source = rec.get("hbm_bytes_per_launch"), "recorded: " + rec.get("source", "profiles/")
       except Exception:  # noqa: BLE001
-        traffic = None
+        traffic = traffic_source = None
     line = {
         "metric": "weight-bytes quantized/sec (GB/s), 4096x4096 per-channel int8",
         "value": round(total_bytes / elapsed / 1e9, 2),
@@ -213,11 +418,21 @@ def main():
                    "sharding": f"tensor-buffers x{world} (no collective)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "kernel": "requant_rows_kernel<8,256,4,ieee-div,batched,nt>",
+                     # HBM bytes per launch from the rocprofv3 PMC passes recorded under profiles/
+                     # (FETCH_SIZE / WRITE_SIZE with the gfx950 corrections): a RECORDED figure of the
+                     # same kernel and launch shape, not a counter read during this run
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": "requant_rows_kernel<8,256,4,ieee-div,batched,nt>",
+                     "entry_point": "mi355q_requant_sym_f32_batched (what ParamsGenerator's batched"
+                                    " loop issues, mi355q/requant_queue.py)",
                      "alg_bytes_per_launch": POOL * ALG_BYTES,
-                     "launch_ms": round(kern_ms, 5)},
+                     "launch_ms": round(kern_ms, 5),
+                     "launch_ms_p10": round(pct(launch_sorted, 0.10), 5),
+                     "launch_ms_p50": round(pct(launch_sorted, 0.50), 5),
+                     "launch_ms_p90": round(pct(launch_sorted, 0.90), 5)},
         "cpu_baseline": cpu_baseline(args.cpu_seconds) if world == 1 else None,
         "extras": extras,
+        "collectives": collectives,
     }
     print(json.dumps(line), flush=True)
   if world > 1:
