@@ -57,16 +57,18 @@ __global__ __launch_bounds__(256) void fwht_kernel(const float* __restrict__ x, 
   }
 }
 
-// ---- 256 <= h <= 4096: radix-16 passes over a 4096-element tile ------------------------------
+// ---- h >= 256: radix-16 passes over a tile of 4096 / 8192 / 16384 elements --------------------
 // The radix-2 kernel above sends every element through LDS twice per stage (12 stages at
 // h = 4096: 24 LDS accesses per element for 2 HBM accesses) and is LDS-bound at ~2.6 TB/s. Here a
-// thread keeps 16 elements in registers and does four butterfly stages at once:
-//   pass 1  index bits {0,1,10,11}: straight from the coalesced float4 global loads
+// thread keeps 16 elements in registers and does up to four butterfly stages at once over a tile
+// of T = 2^LOG2T elements (T / 16 threads):
+//   pass 1  index bits {0, 1, LOG2T-2, LOG2T-1}: straight from the coalesced float4 global loads
 //   pass 2  index bits {2..5}      (LDS read + write)
-//   pass 3  index bits {6..9}      (LDS read, results stored to HBM as 256-byte wave rows)
-// i.e. 4 LDS accesses per element. Stages above log2(h) are skipped (those bits select the
-// vector inside the tile). The LDS index is XOR-swizzled (bits 2-4 ^= bits 6-8) so that pass 2,
-// whose lanes differ in bits {0,1,6..9}, still spreads over all 32 banks.
+//   pass 3  index bits {6..9}      (LDS read; for T = 4096 the results go to HBM as 256-byte rows)
+//   pass 4  index bits {10..LOG2T-3} (T = 8192: bit 10, T = 16384: bits 10 and 11; then HBM)
+// i.e. 4 (T = 4096) or 6 LDS accesses per element. Stages above log2(h) are skipped (those bits
+// select the vector inside the tile). The LDS index is XOR-swizzled (bits 2-4 ^= bits 6-8) so
+// that pass 2, whose lanes differ in bits {0,1,6..}, still spreads over all banks.
 constexpr int kTile = 4096;
 
 __device__ __forceinline__ int swz(int i) { return i ^ (((i >> 6) & 7) << 2); }
@@ -87,39 +89,42 @@ __device__ __forceinline__ void butterflies(float (&v)[16], int first_bit, int l
   }
 }
 
-__global__ __launch_bounds__(256) void fwht_tile_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                       long long total, int log2h, float r) {
-  __shared__ __attribute__((aligned(16))) float buf[kTile];
+template <int LOG2T>
+__global__ __launch_bounds__((1 << LOG2T) / 16) void fwht_tile_kernel(const float* __restrict__ x,
+                                                                      float* __restrict__ out,
+                                                                      long long total, int log2h, float r) {
+  constexpr int T = 1 << LOG2T, NT = T / 16;
+  __shared__ __attribute__((aligned(16))) float buf[T];
   const int t = threadIdx.x;
-  const long long base = static_cast<long long>(blockIdx.x) * kTile;
+  const long long base = static_cast<long long>(blockIdx.x) * T;
   const long long left = total - base;
-  const int valid = left < kTile ? static_cast<int>(left) : kTile;   // a multiple of h (and of 4)
+  const int valid = left < T ? static_cast<int>(left) : T;   // a multiple of h (and of 4)
   const float4* src = reinterpret_cast<const float4*>(x + base);
   float v[16];
-  // pass 1: register index k = c | (j << 2)  <->  tile index bits (0,1) and (10,11)
+  // pass 1: register index k = c | (j << 2)  <->  tile index bits (0,1) and (LOG2T-2, LOG2T-1)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int f4 = t + 256 * j;
+    const int f4 = t + NT * j;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (f4 * 4 < valid) q = src[f4];
     v[j * 4 + 0] = q.x * r; v[j * 4 + 1] = q.y * r; v[j * 4 + 2] = q.z * r; v[j * 4 + 3] = q.w * r;
   }
   butterflies<2>(v, 0, log2h);            // bits 0, 1 (always below log2h: h >= 256)
-  {                                       // bits 10, 11 = register bits 2, 3
+  {                                       // the two top bits = register bits 2, 3
     float hi[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) hi[k] = v[((k & 3) << 2) | (k >> 2)];   // transpose c <-> j
-    butterflies<2>(hi, 10, log2h);
+    butterflies<2>(hi, LOG2T - 2, log2h);
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[((k & 3) << 2) | (k >> 2)] = hi[k];
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int i = 4 * (t + 256 * j);
+    const int i = 4 * (t + NT * j);
     *reinterpret_cast<float4*>(&buf[swz(i)]) = make_float4(v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]);
   }
   __syncthreads();
-  // pass 2: bits 2..5 in registers; thread bits -> index bits {0,1} and {6..11}
+  // pass 2: bits 2..5 in registers; thread bits -> index bits {0,1} and {6..LOG2T-1}
   {
     const int fixed = (t & 3) | ((t >> 2) << 6);
 #pragma unroll
@@ -129,16 +134,46 @@ __global__ __launch_bounds__(256) void fwht_tile_kernel(const float* __restrict_
     for (int k = 0; k < 16; ++k) buf[swz(fixed | (k << 2))] = v[k];
   }
   __syncthreads();
-  // pass 3: bits 6..9 in registers; thread bits -> index bits {0..5} and {10,11}
+  // pass 3: bits 6..9 in registers; thread bits -> index bits {0..5} and {10..LOG2T-1}
   {
     const int fixed = (t & 63) | ((t >> 6) << 10);
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = buf[swz(fixed | (k << 6))];
     butterflies<4>(v, 6, log2h);
+    if constexpr (LOG2T == 12) {
+      float* dst = out + base;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int i = fixed | (k << 6);
+        if (i < valid) dst[i] = v[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) buf[swz(fixed | (k << 6))] = v[k];
+    }
+  }
+  if constexpr (LOG2T > 12) {
+    __syncthreads();
+    // pass 4: the remaining bits 10 .. LOG2T-3. Registers <-> index bits {LOG2T-4 .. LOG2T-1} (for
+    // T = 8192 that is {9, 10, 11, 12}: bit 9 only picks a second group), thread bits <-> the rest.
+    constexpr int kLow = LOG2T - 4;               // the threads cover index bits 0 .. kLow-1
+    const int fixed = t;                          // NT = 2^kLow threads
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = buf[swz(fixed | (k << kLow))];
+    {
+      // register bit (10 - kLow) is index bit 10
+      constexpr int shift = 10 - kLow;            // 1 for T = 8192, 0 for T = 16384
+      float w[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) w[k] = v[((k << shift) | (k >> (4 - shift))) & 15];   // rotate index bit 10 down to bit 0
+      butterflies<LOG2T - 12>(w, 10, log2h);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[((k << shift) | (k >> (4 - shift))) & 15] = w[k];
+    }
     float* dst = out + base;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int i = fixed | (k << 6);
+      const int i = fixed | (k << kLow);
       if (i < valid) dst[i] = v[k];
     }
   }
@@ -163,12 +198,17 @@ extern "C" int32_t mi355q_hadamard_rotate_f32(const float* x, int64_t n_vec, int
   // |H entry| of the reference: int8(1) / np.sqrt(h, dtype=float32)
   const float r = 1.0f / __builtin_sqrtf(static_cast<float>(h));
   const long long total = n_vec * static_cast<long long>(h);
-  if (h >= 256 && h <= kTile && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-      (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-    const long long tiles = (total + kTile - 1) / kTile;
+  if (h >= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int tile = h <= kTile ? kTile : h;   // 4096, 8192 or 16384 elements per workgroup
+    const long long tiles = (total + tile - 1) / tile;
     if (tiles > 0x7FFFFFFFLL) return fail(MI355Q_UNSUPPORTED, "too many vectors");
-    hipLaunchKernelGGL(fwht_tile_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, as_stream(stream),
-                       x, out, total, log2h, r);
+    const dim3 grid(static_cast<unsigned>(tiles));
+    if (tile == 4096)
+      hipLaunchKernelGGL(fwht_tile_kernel<12>, grid, dim3(256), 0, as_stream(stream), x, out, total, log2h, r);
+    else if (tile == 8192)
+      hipLaunchKernelGGL(fwht_tile_kernel<13>, grid, dim3(512), 0, as_stream(stream), x, out, total, log2h, r);
+    else
+      hipLaunchKernelGGL(fwht_tile_kernel<14>, grid, dim3(1024), 0, as_stream(stream), x, out, total, log2h, r);
     MI355Q_CHECK_LAUNCH("hadamard launch");
     return MI355Q_OK;
   }
