@@ -8,18 +8,14 @@
 //   group_terms    per (row, group) max of |w|*s with first-index argmax, then per group the
 //                  NumPy-order (8192-chunk, pairwise) sum over rows of the squared maxima
 //   winner_energy  the np.add.at accumulation of the winners' squares, per column, rows in order
-//   clip_bounds    per (row, group): stable descending sort of |w|*s carrying the masses, three
+//   clip_bounds    per (row, group): stable descending sort of |w|*s carrying the masses (LDS
+//                  bitonic tiles, 8192-element runs + merge passes beyond that), three
 //                  sequential running sums, the closed-form candidate of every segment, first
 //                  minimum
 //   quantize       clip(rint((w*s) / scale)) with FP64 product and quotient
 // Compiled with -ffp-contract=off: none of the FP64 expressions may be fused.
 #include <cstdlib>
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_segmented_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
 
@@ -357,23 +353,6 @@ __global__ __launch_bounds__(256) void winner_energy_kernel(const int32_t* __res
 }
 
 // ---------------------------------------------------------------- clip_bounds ---
-__global__ __launch_bounds__(256) void sort_keys_kernel(const float* __restrict__ w,
-                                                        const double* __restrict__ s,
-                                                        const double* __restrict__ m, int64_t total,
-                                                        int64_t d, double* __restrict__ keys,
-                                                        double* __restrict__ vals) {
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (e >= total) return;
-  const int64_t j = e % d;
-  keys[e] = s ? fabs(static_cast<double>(w[e])) * s[j] : fabs(static_cast<double>(w[e]));
-  vals[e] = m ? m[j] : 0.0;
-}
-
-struct SegmentStart {
-  uint32_t g;
-  __host__ __device__ uint32_t operator()(uint32_t i) const { return i * g; }
-};
-
 // Stable descending sort of every segment of g <= P (P a power of two, 32..8192) elements in
 // LDS: bitonic network on (key, position) pairs -- the position breaks ties, so the result is
 // the stable order. A 256-thread block sorts a tile of TILE / P consecutive segments; keys are
@@ -435,10 +414,15 @@ __device__ __forceinline__ void sort_levels(double* key, uint16_t* pos, int tile
   }
 }
 
+// Segments longer than the tile are sorted as runs: `runs_per_seg` > 1 makes unit u of the grid
+// the run u % runs_per_seg of segment u / runs_per_seg, i.e. elements [run * g, run * g + g) of
+// that `seg_len`-element segment, cut at its end (the last run of a segment is shorter);
+// merge_runs_kernel then merges neighbouring runs. With runs_per_seg == 1 a unit is a whole segment
+// of g == seg_len elements.
 __global__ __launch_bounds__(kSortThreadsMax) void sort_tile_kernel(
     const float* __restrict__ w, const double* __restrict__ s, const double* __restrict__ m,
     int64_t segments, int32_t g, int32_t P, int32_t tile, int64_t d, int32_t transposed,
-    double* __restrict__ keys_out, double* __restrict__ vals_out) {
+    int64_t seg_len, int32_t runs_per_seg, double* __restrict__ keys_out, double* __restrict__ vals_out) {
   extern __shared__ unsigned char lds_raw[];
   double* key = reinterpret_cast<double*>(lds_raw);
   uint16_t* pos = reinterpret_cast<uint16_t*>(key + lds_pad(tile) + 1);
@@ -449,10 +433,14 @@ __global__ __launch_bounds__(kSortThreadsMax) void sort_tile_kernel(
   for (int e = threadIdx.x; e < tile; e += blockDim.x) {
     const int sl = e / P, i = e - sl * P;
     double k = -1.0;                 // padding sorts behind every real magnitude
-    if (sl < segs_here && i < g) {
-      const int64_t ge = (seg0 + sl) * g + i;
-      k = fabs(static_cast<double>(w[ge]));
-      if (s) k = k * s[ge % d];
+    if (sl < segs_here) {
+      const int64_t unit = seg0 + sl, run = unit % runs_per_seg;
+      const int64_t off = run * g + i;                       // within the segment
+      if (i < g && off < seg_len) {
+        const int64_t ge = (unit / runs_per_seg) * seg_len + off;
+        k = fabs(static_cast<double>(w[ge]));
+        if (s) k = k * s[ge % d];
+      }
     }
     key[lds_pad(e)] = k;
     pos[lds_pad(e)] = static_cast<uint16_t>(i);
@@ -490,35 +478,42 @@ __global__ __launch_bounds__(kSortThreadsMax) void sort_tile_kernel(
       const int sl = e / P, i = e - sl * P;
       if (sl < segs_here && i < g) {
         const int at = lds_pad(e);
-        const int64_t seg = seg0 + sl;
-        keys_out[seg * g + i] = key[at];
-        if (m) vals_out[seg * g + i] = m[(seg * g + pos[at]) % d];
+        const int64_t unit = seg0 + sl, run = unit % runs_per_seg;
+        const int64_t first = (unit / runs_per_seg) * seg_len + run * g;   // the unit's first element
+        if (run * g + i < seg_len) {
+          keys_out[first + i] = key[at];
+          if (m) vals_out[first + i] = m[(first + pos[at]) % d];
+        }
       }
     }
   }
 }
 
-// Stable merge of the two sorted halves of every g-element segment (descending; on equal keys
-// the first half -- the lower original positions -- goes first): every element finds its rank by
-// a binary search in the other half.
-__global__ __launch_bounds__(256) void merge_halves_kernel(const double* __restrict__ keys,
-                                                           const double* __restrict__ vals,
-                                                           int64_t total, int64_t g,
-                                                           double* __restrict__ keys_out,
-                                                           double* __restrict__ vals_out) {
+// Stable merge of neighbouring sorted runs of `run` elements inside every g-element segment
+// (descending; on equal keys the left run -- the lower original positions -- goes first): every
+// element finds its rank by a binary search in the sibling run. The last run of a segment may be
+// shorter, a run without a sibling is copied. log2(runs) passes sort segments of any length.
+__global__ __launch_bounds__(256) void merge_runs_kernel(const double* __restrict__ keys,
+                                                         const double* __restrict__ vals,
+                                                         int64_t total, int64_t g, int64_t run,
+                                                         double* __restrict__ keys_out,
+                                                         double* __restrict__ vals_out) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (e >= total) return;
-  const int64_t h = g / 2, seg = e / g, i = e - seg * g;
+  const int64_t seg = e / g, off = e - seg * g;
+  const int64_t pair0 = off / (2 * run) * (2 * run);       // first element of the pair of runs
+  const int64_t mid = pair0 + run < g ? pair0 + run : g;   // end of the left run
+  const int64_t end = pair0 + 2 * run < g ? pair0 + 2 * run : g;
   const double k = keys[e];
-  const bool first = i < h;
-  const double* other = keys + seg * g + (first ? h : 0);
-  int64_t lo = 0, hi = h;                  // count of the other half's elements that go before k
+  const bool left = off < mid;
+  const double* other = keys + seg * g + (left ? mid : pair0);
+  int64_t lo = 0, hi = left ? end - mid : mid - pair0;     // count of the sibling's elements that go before k
   while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    const bool before = first ? other[mid] > k : other[mid] >= k;
-    if (before) lo = mid + 1; else hi = mid;
+    const int64_t m2 = (lo + hi) >> 1;
+    const bool before = left ? other[m2] > k : other[m2] >= k;
+    if (before) lo = m2 + 1; else hi = m2;
   }
-  const int64_t at = seg * g + (first ? i : i - h) + lo;
+  const int64_t at = seg * g + pair0 + (left ? off - pair0 : off - mid) + lo;
   keys_out[at] = k;
   if (vals) vals_out[at] = vals[e];
 }
@@ -835,19 +830,6 @@ extern "C" int32_t mi355q_oscar_winner_energy_f64(const int32_t* winner, const d
 }
 
 namespace {
-// Temporary storage of the library sort for `total` (key, value) pairs in `segments` segments.
-hipError_t sort_storage(size_t* bytes, int64_t total, int64_t segments, int64_t g) {
-  double* nil = nullptr;
-  if (segments == 1)
-    return rocprim::radix_sort_pairs_desc(nullptr, *bytes, nil, nil, nil, nil,
-                                          static_cast<size_t>(total), 0, 64, hipStream_t(0));
-  auto begin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0),
-                                                SegmentStart{static_cast<uint32_t>(g)});
-  return rocprim::segmented_radix_sort_pairs_desc(nullptr, *bytes, nil, nil, nil, nil,
-                                                  static_cast<size_t>(total),
-                                                  static_cast<unsigned>(segments), begin, begin + 1,
-                                                  0, 64, hipStream_t(0));
-}
 size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 }  // namespace
 
@@ -860,10 +842,8 @@ extern "C" int32_t mi355q_oscar_clip_workspace_bytes(int64_t n, int64_t d, int64
                 (long long)d, (long long)g);
   const int64_t total = n * d;
   if (total > 0xFFFFFFFFll - g) return fail(MI355Q_UNSUPPORTED, "oscar clip: more than 2^32 weights");
-  size_t tmp = 0;
-  hipError_t e = sort_storage(&tmp, total, total / g, g);
-  if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "oscar sort sizing: %s", hipGetErrorString(e));
-  *bytes_out = 4 * align256(static_cast<size_t>(total) * sizeof(double)) + align256(tmp);
+  // two (key, value) slabs: the run merges ping-pong between them
+  *bytes_out = 4 * align256(static_cast<size_t>(total) * sizeof(double));
   return MI355Q_OK;
 }
 
@@ -875,76 +855,61 @@ struct Sorted {
 };
 
 // Stable descending sort of every g-element segment of |w| * s (s == NULL: |w|) carrying m[column]
-// (m == NULL: nothing): the in-LDS tile sort for g <= 8192, the library radix sort otherwise.
+// (m == NULL: nothing): segments of up to 8192 elements are sorted whole in LDS (bitonic network on
+// (key, position) pairs); longer ones -- rows beyond 8192 columns, odd lengths, the whole tensor
+// for TENSORWISE -- as 8192-element runs in LDS followed by log2(runs) stable merge passes.
+constexpr int64_t kSortRun = 8192;
+
 int32_t sort_segments(const float* w, const double* s, const double* m, int64_t n, int64_t d,
                       int64_t g, bool allow_rank_major, void* workspace, size_t need, hipStream_t st,
                       Sorted* out) {
-  const int64_t total = n * d, segments = total / g;
+  (void)need;
+  const int64_t total = n * d;
   const size_t slab = align256(static_cast<size_t>(total) * sizeof(double));
   char* base = static_cast<char*>(workspace);
-  double* keys_in = reinterpret_cast<double*>(base);
-  double* vals_in = reinterpret_cast<double*>(base + slab);
-  double* keys_out = reinterpret_cast<double*>(base + 2 * slab);
-  double* vals_out = reinterpret_cast<double*>(base + 3 * slab);
-  void* tmp = base + 4 * slab;
-  size_t tmp_bytes = need - 4 * slab;
+  double* keys_a = reinterpret_cast<double*>(base);
+  double* vals_a = reinterpret_cast<double*>(base + slab);
+  double* keys_b = reinterpret_cast<double*>(base + 2 * slab);
+  double* vals_b = reinterpret_cast<double*>(base + 3 * slab);
   int64_t seg_stride = g, elem_stride = 1;
-  // MI355Q_OSCAR_LIBSORT: A/B switch to the library radix sort (tools/oscar_bench.py)
-  const bool two_runs = g > 8192 && g <= 16384 && g % 2 == 0;   // sort halves in LDS, then merge
-  if ((g <= 8192 || two_runs) && g >= 2 && !getenv("MI355Q_OSCAR_LIBSORT")) {
-    const int64_t g_full = g;
-    if (two_runs) {
-      g /= 2;
-      allow_rank_major = false;
-    }
-    const int64_t segments = total / g;
-    int32_t P = 32;
-    while (P < g) P <<= 1;
-    const int32_t tile = P > 4096 ? P : 4096;
-    const int32_t transposed = (P <= 256 && allow_rank_major) ? 1 : 0;
-    const size_t lds = (static_cast<size_t>(lds_pad(tile)) + 2) * (sizeof(double) + sizeof(uint16_t));
-    const int64_t tiles = (segments + tile / P - 1) / (tile / P);
-    if (lds > 64 * 1024) {
-      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tile_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          static_cast<int>(lds));
-      if (ea != hipSuccess) return fail(MI355Q_HIP_ERROR, "oscar sort LDS: %s", hipGetErrorString(ea));
-    }
-    const int threads = tile >= 8192 ? 1024 : 512;   // measured best of {256, 512, 1024} per tile size
-    hipLaunchKernelGGL(sort_tile_kernel, dim3(static_cast<unsigned>(tiles)), dim3(threads), lds, st,
-                       w, s, m, segments, static_cast<int32_t>(g), P, tile, d, transposed,
-                       two_runs ? keys_in : keys_out, two_runs ? vals_in : vals_out);
-    MI355Q_CHECK_LAUNCH("oscar_sort_tile");
-    if (two_runs) {
-      hipLaunchKernelGGL(merge_halves_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
-                         0, st, keys_in, m ? vals_in : nullptr, total, g_full, keys_out, vals_out);
-      MI355Q_CHECK_LAUNCH("oscar_merge_halves");
-      g = g_full;
-    }
-    if (transposed) {
-      seg_stride = 1;
-      elem_stride = segments;
-    }
-  } else {
-    hipLaunchKernelGGL(sort_keys_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
-                       0, st, w, s, m, total, d, keys_in, vals_in);
-    MI355Q_CHECK_LAUNCH("oscar_sort_keys");
-    hipError_t e;
-    if (segments == 1) {
-      e = rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
-                                         static_cast<size_t>(total), 0, 64, st);
-    } else {
-      auto begin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0),
-                                                    SegmentStart{static_cast<uint32_t>(g)});
-      e = rocprim::segmented_radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, keys_out, vals_in,
-                                                   vals_out, static_cast<size_t>(total),
-                                                   static_cast<unsigned>(segments), begin, begin + 1,
-                                                   0, 64, st);
-    }
-    if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "oscar sort: %s", hipGetErrorString(e));
+  const bool runs = g > kSortRun;
+  const int64_t unit_len = runs ? kSortRun : g;                       // what one LDS sort covers
+  const int64_t runs_per_seg = runs ? (g + kSortRun - 1) / kSortRun : 1;
+  const int64_t units = (total / g) * runs_per_seg;
+  if (runs) allow_rank_major = false;
+  int32_t P = 32;
+  while (P < unit_len) P <<= 1;
+  const int32_t tile = P > 4096 ? P : 4096;
+  const int32_t transposed = (P <= 256 && allow_rank_major) ? 1 : 0;
+  const size_t lds = (static_cast<size_t>(lds_pad(tile)) + 2) * (sizeof(double) + sizeof(uint16_t));
+  const int64_t tiles = (units + tile / P - 1) / (tile / P);
+  if (tiles > 0x7FFFFFFFLL) return fail(MI355Q_UNSUPPORTED, "oscar sort: too many segments");
+  if (lds > 64 * 1024) {
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tile_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(lds));
+    if (ea != hipSuccess) return fail(MI355Q_HIP_ERROR, "oscar sort LDS: %s", hipGetErrorString(ea));
   }
-  out->keys = keys_out;
-  out->vals = vals_out;
+  const int threads = tile >= 8192 ? 1024 : 512;   // measured best of {256, 512, 1024} per tile size
+  hipLaunchKernelGGL(sort_tile_kernel, dim3(static_cast<unsigned>(tiles)), dim3(threads), lds, st,
+                     w, s, m, units, static_cast<int32_t>(unit_len), P, tile, d, transposed, g,
+                     static_cast<int32_t>(runs_per_seg), keys_a, vals_a);
+  MI355Q_CHECK_LAUNCH("oscar_sort_tile");
+  const double *keys = keys_a, *vals = vals_a;
+  double *keys_o = keys_b, *vals_o = vals_b;
+  for (int64_t run = kSortRun; run < g; run *= 2) {
+    hipLaunchKernelGGL(merge_runs_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
+                       0, st, keys, m ? vals : nullptr, total, g, run, keys_o, vals_o);
+    MI355Q_CHECK_LAUNCH("oscar_merge_runs");
+    const double* tk = keys; keys = keys_o; keys_o = const_cast<double*>(tk);
+    const double* tv = vals; vals = vals_o; vals_o = const_cast<double*>(tv);
+  }
+  if (transposed) {
+    seg_stride = 1;
+    elem_stride = total / g;
+  }
+  out->keys = keys;
+  out->vals = vals;
   out->seg_stride = seg_stride;
   out->elem_stride = elem_stride;
   return MI355Q_OK;

@@ -81,13 +81,17 @@ def test_seeded_fake_quantized_weights_match_oracle(seed):
   assert np.array_equal(res.quantized_data, ref["quantized_data"])
 
 
-@pytest.mark.parametrize("rows,cols", [(2, 9000), (3, 16384), (2, 9001), (1, 20000)])
-def test_long_rows_take_the_merge_or_library_path(rows, cols):
+@pytest.mark.parametrize("rows,cols", [(2, 9000), (3, 16384), (2, 9001), (1, 20000), (2, 40001)])
+def test_long_rows_take_the_run_merge_path(rows, cols):
   rng = np.random.default_rng(rows * cols)
   q = rng.integers(-7, 8, size=(rows, cols)).astype(np.int8)
   w = q.astype(np.float32) * rng.uniform(1e-3, 0.1, (rows, 1)).astype(np.float32)
   res, ref = _call(w, 4, "CHANNELWISE"), O.dwr_quant_params(w, 4, "CHANNELWISE")
   assert np.array_equal(res.scale, ref["scale"]) and np.array_equal(res.quantized_data, ref["quantized_data"])
+  if rows * cols > 50000:      # ... and the whole tensor as one segment of several runs
+    w1 = q.astype(np.float32) * np.float32(0.03)
+    res, ref = _call(w1, 4, "TENSORWISE"), O.dwr_quant_params(w1, 4, "TENSORWISE")
+    assert np.array_equal(res.scale, ref["scale"]) and np.array_equal(res.quantized_data, ref["quantized_data"])
 
 
 def test_argument_errors():
