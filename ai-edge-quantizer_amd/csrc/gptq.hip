@@ -472,6 +472,129 @@ __global__ __launch_bounds__(256, kRowLanes == 16 ? 4 : 1) void gptq_block_kerne
   }
 }
 
+// ---- the same block with ONE LANE PER ROW (symmetric recipes, float scales: kPlain) -----------
+// With a row spread over 16 / 32 lanes every column step broadcasts the column's value through
+// v_readlane, every lane of the row repeats the quantization, and the step costs ~1000 cycles of
+// exposed latency (1.34 ms for 2048 x 2048). The chain itself is only quantize -> error -> divide ->
+// one multiply-subtract for the next column: with a whole row in one lane's registers (64 values,
+// statically indexed: the 64 steps are unrolled) nothing crosses lanes, Hinv's rows are wave-uniform
+// scalar loads (s_load) feeding the multiply as SGPR operands, and the updates of the columns
+// further right overlap the next steps' chains. A wave carries 64 rows; the arithmetic per element
+// is exactly the spread kernel's (same operations in the same order: identical integers).
+// The errors of the group's earlier blocks are applied beforehand by gptq_catchup_kernel (the
+// spread kernel's first phase as a kernel of its own: many workgroups, LDS tiles).
+template <int kRowLanes>
+__global__ __launch_bounds__(256) void gptq_catchup_kernel(ApplyArgs a) {
+  constexpr int kColsPerLane = NB / kRowLanes;
+  __shared__ __attribute__((aligned(16))) float h[NB][NB];
+  __shared__ float es[256 / kRowLanes][NB];
+  const int l = threadIdx.x % kRowLanes;
+  const int r = blockIdx.x * (256 / kRowLanes) + threadIdx.x / kRowLanes;
+  const bool live = r < a.rows;
+  const int rr = live ? r : a.rows - 1;
+  float* wrow = a.w + static_cast<long long>(rr) * a.d + a.c0;
+  float w[kColsPerLane];
+#pragma unroll
+  for (int k = 0; k < kColsPerLane; ++k) w[k] = wrow[l * kColsPerLane + k];
+  for (int pb = 0; pb < a.err_col; pb += NB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+      const int k = e / NB, c = e % NB;
+      h[k][c] = a.hinv[static_cast<long long>(a.c0 - a.err_col + pb + k) * a.d + a.c0 + c];
+    }
+    for (int e = threadIdx.x; e < (256 / kRowLanes) * NB; e += 256) {
+      const int rw = e / NB, k = e % NB;
+      const long long row = static_cast<long long>(blockIdx.x) * (256 / kRowLanes) + rw;
+      es[rw][k] = row < a.rows ? a.err[row * kErrLd + pb + k] : 0.f;
+    }
+    __syncthreads();
+    float sum[kColsPerLane];
+#pragma unroll
+    for (int k = 0; k < kColsPerLane; ++k) sum[k] = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < NB; ++k) {
+      const float ek = es[threadIdx.x / kRowLanes][k];
+      const float* hp = &h[k][l * kColsPerLane];
+#pragma unroll
+      for (int j = 0; j < kColsPerLane; ++j) sum[j] = sum[j] + ek * hp[j];
+    }
+#pragma unroll
+    for (int j = 0; j < kColsPerLane; ++j) w[j] = w[j] - sum[j];
+  }
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < kColsPerLane; ++k) wrow[l * kColsPerLane + k] = w[k];
+  }
+}
+
+__global__ __launch_bounds__(kWave) void gptq_rows_kernel(ApplyArgs a) {
+  __shared__ __attribute__((aligned(16))) float h[NB][NB];     // Hinv[c0:c0+64, c0:c0+64]
+  const int r = blockIdx.x * kWave + threadIdx.x;
+  const bool live = r < a.rows;
+  const int rr = live ? r : a.rows - 1;               // idle lanes shadow the last row, write nothing
+  {
+    const float* hblock = a.hinv + static_cast<long long>(a.c0) * a.d + a.c0;
+#pragma unroll
+    for (int k = 0; k < NB * NB / 4 / kWave; ++k) {    // 16 coalesced 16-byte loads per lane
+      const int e4 = k * kWave + threadIdx.x, row = e4 / (NB / 4), c4 = e4 % (NB / 4);
+      reinterpret_cast<float4*>(&h[row][0])[c4] =
+          *reinterpret_cast<const float4*>(hblock + static_cast<long long>(row) * a.d + 4 * c4);
+    }
+  }
+  const float* wrow = a.w + static_cast<long long>(rr) * a.d + a.c0;
+  float w[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(wrow + k);   // (d % 64 == 0, c0 % 64 == 0: aligned)
+    w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+  }
+  const float* sc = static_cast<const float*>(a.scale);
+  const long long si0 = a.scale_mode == 1 ? rr : (a.scale_mode == 2 ? static_cast<long long>(rr) * a.nblk + a.c0 / a.block_size : 0);
+  const long long si1 = a.scale_mode == 2 ? static_cast<long long>(rr) * a.nblk + (a.c0 + 32) / a.block_size : si0;
+  const float s_lo = sc[si0], s_hi = sc[si1];
+  unsigned* qrow = reinterpret_cast<unsigned*>(a.q + static_cast<long long>(rr) * a.d + a.c0);
+  float* erow = a.err + static_cast<long long>(rr) * kErrLd + a.err_col;
+  __syncthreads();
+  unsigned qword = 0;
+  float e4[4];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    // row i of the tile, columns i .. 63 (uniform addresses: LDS broadcasts); the reads are in
+    // flight while the head of this step's chain (divide, round, divide) runs
+    float hrow[NB];
+#pragma unroll
+    for (int k = (i & ~3); k < NB; k += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(&h[i][k]);
+      hrow[k] = v.x; hrow[k + 1] = v.y; hrow[k + 2] = v.z; hrow[k + 3] = v.w;
+    }
+    const float s = i < 32 ? s_lo : s_hi;
+    const float wi = w[i];
+    const float v = wi / s;
+    float q = __builtin_rintf(v);
+    q = fminf(fmaxf(q, a.lo), a.hi);
+    const int qi = (v != v) ? 0 : static_cast<int>(q);
+    const float dq = static_cast<float>(qi) * s;
+    float e = wi - dq;
+    e = e / hrow[i];
+    qword |= (static_cast<unsigned>(qi) & 0xFFu) << (8 * (i % 4));
+    e4[i % 4] = e;
+#pragma unroll
+    for (int k = i + 1; k < NB; ++k) {
+      const float p = e * hrow[k];     // product rounded, then subtracted (np.outer, then -=)
+      w[k] = w[k] - p;
+    }
+    if (i % 4 == 3) {
+      // Unconditional: idle lanes shadow the last row and store its (identical) values again. A
+      // branch here would cut the 64 steps into basic blocks, and the optimizer then sinks the
+      // updates of the far columns block by block towards their use -- every error and every
+      // Hinv value stays live and the kernel spills 700 registers.
+      qrow[i / 4] = qword;
+      *reinterpret_cast<float4*>(erow + i - 3) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+      qword = 0;
+    }
+  }
+}
+
 inline unsigned grid1d(long long n) {
   long long b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -820,6 +943,15 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
       const int rl = row_lanes_for(rows);
       const dim3 grid(static_cast<unsigned>((rows + (256 / rl) - 1) / (256 / rl)));
       const bool plain = a.nb == NB && zero_point == nullptr && !(scale_mode == 2 && block_size % 32 != 0);
+      if (plain && !scale_is_f64 && d % NB == 0 && !getenv("MI355Q_GPTQ_SPREAD")) {
+        // one lane per row: the column chain stays inside a lane (see gptq_rows_kernel)
+        if (a.err_col > 0) {
+          if (rl == 32) hipLaunchKernelGGL(gptq_catchup_kernel<32>, grid, dim3(256), 0, st, a);
+          else hipLaunchKernelGGL(gptq_catchup_kernel<16>, grid, dim3(256), 0, st, a);
+        }
+        hipLaunchKernelGGL(gptq_rows_kernel, dim3(static_cast<unsigned>((rows + kWave - 1) / kWave)), dim3(kWave), 0, st, a);
+        continue;
+      }
 #define MI355Q_BLOCK(ST, RL, PL) hipLaunchKernelGGL((gptq_block_kernel<ST, RL, PL>), grid, dim3(256), 0, st, a)
       if (scale_is_f64) {
         if (rl == 32) { if (plain) MI355Q_BLOCK(double, 32, true); else MI355Q_BLOCK(double, 32, false); }
