@@ -196,7 +196,9 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
         total += 0 if data is None else int(np.asarray(data).nbytes)
     return total
   owner = plan_tensor_shards([weight_bytes(it) for it in plan], world)
-  mine = {i: gen.materialize_op(it, qsvs) for i, (it, o) in enumerate(zip(plan, owner)) if o == rank}
+  from . import requant_queue
+  with requant_queue.batching():       # this rank's equally shaped weights leave in one launch per group
+    mine = {i: gen.materialize_op(it, qsvs) for i, (it, o) in enumerate(zip(plan, owner)) if o == rank}
   if world > 1:
     gathered = [None] * world if rank == 0 else None
     dist.gather_object(mine, gathered, dst=0, group=group)

@@ -334,6 +334,25 @@ def test_mse_row_sums_follow_numpy_order_for_every_row_length(m, cols):
   assert np.array_equal(np.asarray(p.quantized_data), ref["quantized_data"])
 
 
+@pytest.mark.parametrize("gran", ["CHANNELWISE", "BLOCKWISE_128"])
+def test_octav_row_with_nan_gets_nan_scale_and_zero_integers(m, gran):
+  """OCTAV's masked sums skip NaN (comparisons are false), so the clipping constant of a row that
+  holds a NaN stays finite while its max|x| is NaN: np.clip(NaN, -c, c) is NaN, the scale is NaN and
+  every integer of the row / block is 0 (ref uniform_quantize_tensor.py:529-563; fminf / fmaxf
+  would have returned the clip instead)."""
+  rng = np.random.default_rng(21)
+  w = rng.standard_normal((8, 4096), dtype=np.float32) * np.float32(0.05)
+  w[2, 100] = np.nan
+  w[5, 4095] = np.nan
+  cfg = m.qtyping.TensorQuantizationConfig(num_bits=4, symmetric=True, granularity=m.qtyping.QuantGranularity[gran])
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    ref = O.octav_quant_params(w, 4, gran)
+    p = m.octav.get_tensor_quant_params(op_info(m, "FULLY_CONNECTED", cfg), cfg, w)
+  assert np.isnan(ref["scale"]).sum() == 2 and np.array_equal(p.scale, ref["scale"], equal_nan=True)
+  assert np.array_equal(np.asarray(p.quantized_data), ref["quantized_data"])
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_octav_masked_sums_with_designed_run_lengths(m, seed):
   """Selected elements come in runs whose lengths are drawn from {1..12, 55..70, 120..140, 300}

@@ -64,15 +64,15 @@ def test_c3_shape_blockwise_scales_bound_every_block(m):
 
 
 def test_c4_parity_subset_16_samples_through_gather_and_replay(m):
-  """First 16 samples of the C4 workload shape (32 activation tensors of [1,256,4096]),
-  sentinels planted as in SURVEY 8d; world_size 1 path of the multi-GPU layer."""
+  """First 16 samples of the C4 workload (32 activation tensors of [1,256,4096], 4 MiB each, SURVEY
+  8d's parity subset), sentinels planted as there; world_size 1 path of the multi-GPU layer."""
   rng = np.random.default_rng(44)
   names = [f"act{i}" for i in range(32)]
   samples = []
   for s in range(16):
     d = {}
     for i, n in enumerate(names):
-      x = rng.standard_normal((1, 64, 4096), dtype=np.float32) * np.float32(1 + i / 8)
+      x = rng.standard_normal((1, 256, 4096), dtype=np.float32) * np.float32(1 + i / 8)
       if (s * 32 + i) % 97 == 0:
         x.reshape(-1)[:4] = [np.inf, -np.inf, 3.39e38, -3.39e38]
       d[n] = x
