@@ -292,8 +292,14 @@ def main():
   if backend != "nccl":
     local = local % torch.cuda.device_count()
   torch.cuda.set_device(local)
-  if world > 1:
+  # MI355Q_BENCH_FORCE_PROBE=1: run the N > 1 collective probe on a world of one as well (the only
+  # way to exercise it on a one-GPU box)
+  force_probe = os.environ.get("MI355Q_BENCH_FORCE_PROBE", "") == "1"
+  if world > 1 or force_probe:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     if backend == "nccl":
       dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
@@ -386,8 +392,24 @@ def main():
   if args.extras and rank == 0 and world == 1:
     extras.update(more_extras(torch, ops, gen, xs))
   collectives = None
-  if world > 1:
-    collectives = collective_probe(torch, dist, rank, world, backend)
+  probe_hung = False
+  if world > 1 or force_probe:
+    # The probe must never cost the headline: it runs in a helper thread with a deadline; a rank
+    # whose probe does not come back reports that, skips the final barrier and leaves.
+    import threading
+    box = {}
+
+    def run_probe():
+      try:
+        torch.cuda.set_device(local)
+        box["result"] = collective_probe(torch, dist, rank, world, backend)
+      except Exception as e:  # noqa: BLE001
+        box["result"] = {"error": repr(e)[:300]}
+    th = threading.Thread(target=run_probe, daemon=True)
+    th.start()
+    th.join(float(os.environ.get("MI355Q_BENCH_PROBE_SECONDS", "90")))
+    probe_hung = th.is_alive()
+    collectives = {"error": "collective probe did not finish in time"} if probe_hung else box.get("result")
 
   if rank == 0:
     total_bytes = world * args.steps * POOL * ROWS * COLS * 4
@@ -434,10 +456,21 @@ def main():
         "extras": extras,
         "collectives": collectives,
     }
+    try:        # whatever native libraries (RCCL's version banner ...) left in C stdio goes out first:
+      import ctypes   # the JSON line has to be the last line of stdout
+      ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+      pass
     print(json.dumps(line), flush=True)
-  if world > 1:
-    dist.barrier()
-    dist.destroy_process_group()
+  if world > 1 or force_probe:
+    sys.stdout.flush()
+    if probe_hung:
+      os._exit(0)          # a wedged collective cannot be cancelled; the line is out
+    # (no closing barrier: a rank whose peer left through the branch above must not wait for it)
+    try:
+      dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+      pass
 
 
 if __name__ == "__main__":
