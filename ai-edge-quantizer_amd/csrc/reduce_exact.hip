@@ -354,11 +354,10 @@ __global__ void octav_kernel(OctavArgs a) {
 //           scheme from LDS: left to right below 8 elements, eight strided accumulators up to 128,
 //           runs longer than that (dense rows) by a whole wave. The sums land, in run order, in a
 //           list in LDS (a workgroup prefix sum over the per-thread run counts gives the slots);
-//   chain   acc = acc + R_j over the list: the only serial part, done by one wave (a different
-//           one from workgroup to workgroup, so the four SIMDs of a CU share that load). The
-//           positive and the negative mask's chains advance together as the two halves of packed
-//           FP32 additions (v_pk_add_f32); the list is read with broadcast 16-byte LDS loads,
-//           sixteen entries ahead of the additions.
+//   chain   acc = acc + R_j over the list: the only serial part. The positive and the negative
+//           mask's chains run on two different waves at the same time (one wave issues one
+//           addition per four cycles however the operands arrive); the lists are read with
+//           broadcast 16-byte LDS loads, 32 entries ahead of the additions.
 // The row is stored with one float of padding per 16 (thread-owned pieces start on distinct banks).
 constexpr int kRowsMinLen = 1024, kRowsMaxLen = kChunk;
 constexpr int kRowsThreads = 256;
@@ -366,7 +365,6 @@ constexpr int kPiece = 16;
 
 __device__ __forceinline__ int pidx(int e) { return e + (e >> 4); }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Wave-wide integer prefix sum on the DPP network (no LDS round trips): Hillis-Steele inside each
 // row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 of rows 0 / 2
@@ -447,7 +445,7 @@ struct RowsShared {      // small per-workgroup exchange area (in front of the r
 
 // One mask of one piece: `word` = the 16 selection bits of elements x[0..16) (element e0 = 16 pc),
 // `carry` = the element before the piece is selected too (same chunk). Writes the sums of the runs
-// that START in this piece to list[j0 ...][COMP] in order.
+// that START in this piece to list[j0 ...] in order.
 //   * runs shorter than 8 that end inside the piece: a fixed 16-step pass over the registers --
 //     cur = cur + (selected ? x : +0.0), flushed to the list where a run ends (no data-dependent
 //     control flow; a step that ends no run stores to a per-thread dummy slot);
@@ -455,10 +453,9 @@ struct RowsShared {      // small per-workgroup exchange area (in front of the r
 //     than 8 in total: the left-to-right chain simply goes on over the row in LDS;
 //   * runs of 8 .. 128 elements: eight strided accumulators (pairwise_lane, from LDS);
 //   * longer runs (dense rows): reported back, summed by the whole wave afterwards.
-template <int COMP>
 __device__ __forceinline__ void piece_runs(const float (&x)[kPiece], unsigned word, unsigned carry, int pc,
                                            int npieces, const unsigned short* words, const float* row,
-                                           v2f* list, float* dummy, int j0, int* long_e0, int* long_n,
+                                           float* list, float* dummy, int j0, int* long_e0, int* long_n,
                                            int* long_j) {
   // leading elements that continue a run started in an earlier piece are not this thread's business
   const unsigned lead = carry ? ((word + 1u) & ~word) - 1u : 0u;   // the low run of ones (if bit 0 is set)
@@ -472,7 +469,7 @@ __device__ __forceinline__ void piece_runs(const float (&x)[kPiece], unsigned wo
     cur = cur + __int_as_float(__float_as_int(x[i]) & sel);
     if (i < kPiece - 1) {
       const int fin = static_cast<int>(ends << (31 - i)) >> 31;
-      float* dst = fin ? reinterpret_cast<float*>(list + j) + COMP : dummy;
+      float* dst = fin ? list + j : dummy;
       *dst = cur;
       j -= fin;
       cur = __int_as_float(__float_as_int(cur) & ~fin);
@@ -487,8 +484,7 @@ __device__ __forceinline__ void piece_runs(const float (&x)[kPiece], unsigned wo
     m8 &= m8 - 1u;
     const int n = __builtin_ctz(~(w >> i));
     if (i + n < kPiece)    // (a run that reaches the end is handled below)
-      reinterpret_cast<float*>(list + j0 + __builtin_popcount(starts & ((1u << i) - 1u)))[COMP] =
-          pairwise_lane(row, kPiece * pc + i, n);
+      list[j0 + __builtin_popcount(starts & ((1u << i) - 1u))] = pairwise_lane(row, kPiece * pc + i, n);
   }
   if (w >> (kPiece - 1)) {   // the last run is open: follow it
     const unsigned zeros = ~w & 0xFFFFu;
@@ -510,7 +506,44 @@ __device__ __forceinline__ void piece_runs(const float (&x)[kPiece], unsigned wo
     } else {
       *long_e0 = e0; *long_n = n; *long_j = j;
     }
-    reinterpret_cast<float*>(list + j)[COMP] = res;
+    list[j] = res;
+  }
+}
+
+// The same for a sparsely selected piece (late iterations select ~1 % of a row): a loop over
+// the runs that start here instead of the fixed pass over all 16 elements -- the cost follows the
+// number of runs (the caller takes this form when no lane of the wave has more than a few).
+__device__ __forceinline__ void piece_runs_sparse(unsigned word, unsigned carry, int pc, int npieces,
+                                                  const unsigned short* words, const float* row, float* list,
+                                                  int j0, int* long_e0, int* long_n, int* long_j) {
+  const unsigned lead = carry ? ((word + 1u) & ~word) - 1u : 0u;
+  const unsigned w = word & ~lead & 0xFFFFu;
+  unsigned st = w & ~(w << 1);
+  int j = j0;
+  while (st != 0) {
+    const int i = __builtin_ctz(st);
+    st &= st - 1u;
+    int n = __builtin_ctz(~(w >> i));            // bits above 15 - i read as "run ended"
+    if (i + n == kPiece) {                       // reaches the end of the piece: follow it
+      int q = pc + 1;
+      while (q < npieces && (q & (kChunk / kPiece - 1)) != 0) {
+        const unsigned nx = words[q];
+        if (nx == 0xFFFFu) { n += kPiece; ++q; continue; }
+        n += __builtin_ctz(~nx);
+        break;
+      }
+    }
+    const int e0 = kPiece * pc + i;
+    float res = 0.f;
+    if (n == 1) {
+      res = 0.f + row[pidx(e0)];
+    } else if (n <= 128) {
+      res = pairwise_lane(row, e0, n);
+    } else {
+      *long_e0 = e0; *long_n = n; *long_j = j;
+    }
+    list[j] = res;
+    ++j;
   }
 }
 
@@ -525,9 +558,10 @@ __global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : 2) void octav_rows_k
   float* dummy = smem + 64 + tid;                          // (two exchange areas in front)
   float* row = smem + 64 + kRowsThreads;
   const int row_floats = (pidx(len) + 4) & ~3;
-  v2f* list = reinterpret_cast<v2f*>(row + row_floats);
-  const int cap = ((len / 2 + 1 + 31) & ~31) + 32;         // + the chain's read-ahead
-  unsigned short* words_pos = reinterpret_cast<unsigned short*>(list + cap);
+  float* list_pos = row + row_floats;                       // run sums of the two masks, in run order
+  const int cap = ((len / 2 + 1 + 63) & ~63) + 64;         // + the chain's read-ahead
+  float* list_neg = list_pos + cap;
+  unsigned short* words_pos = reinterpret_cast<unsigned short*>(list_neg + cap);
   unsigned short* words_neg = words_pos + ((npieces + 1) & ~1);
 
   // ---- stage the unit: every thread keeps its pieces in registers for all iterations (one HBM
@@ -647,11 +681,23 @@ __global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : 2) void octav_rows_k
         const int pc = tid + kRowsThreads * s;
         long_n[2 * s] = long_n[2 * s + 1] = 0;
         long_e0[2 * s] = long_e0[2 * s + 1] = long_j[2 * s] = long_j[2 * s + 1] = 0;
+        // (wave-uniform choice per mask: the fixed 16-step pass costs ~240 instructions whatever
+        // is selected, the run loop ~30 per run of the busiest lane)
+        const bool sparse_p = __ballot(__builtin_popcount(sp[s]) > 3) == 0;
+        const bool sparse_n = __ballot(__builtin_popcount(sn[s]) > 3) == 0;
         if (pc < npieces) {
-          piece_runs<0>(x[s], wp[s], before[s] >= hi ? 1u : 0u, pc, npieces, words_pos, row, list, dummy,
-                        pre_p[s], &long_e0[2 * s], &long_n[2 * s], &long_j[2 * s]);
-          piece_runs<1>(x[s], wn[s], before[s] <= lo ? 1u : 0u, pc, npieces, words_neg, row, list, dummy,
-                        pre_n[s], &long_e0[2 * s + 1], &long_n[2 * s + 1], &long_j[2 * s + 1]);
+          if (sparse_p)
+            piece_runs_sparse(wp[s], before[s] >= hi ? 1u : 0u, pc, npieces, words_pos, row, list_pos,
+                              pre_p[s], &long_e0[2 * s], &long_n[2 * s], &long_j[2 * s]);
+          else
+            piece_runs(x[s], wp[s], before[s] >= hi ? 1u : 0u, pc, npieces, words_pos, row, list_pos, dummy,
+                       pre_p[s], &long_e0[2 * s], &long_n[2 * s], &long_j[2 * s]);
+          if (sparse_n)
+            piece_runs_sparse(wn[s], before[s] <= lo ? 1u : 0u, pc, npieces, words_neg, row, list_neg,
+                              pre_n[s], &long_e0[2 * s + 1], &long_n[2 * s + 1], &long_j[2 * s + 1]);
+          else
+            piece_runs(x[s], wn[s], before[s] <= lo ? 1u : 0u, pc, npieces, words_neg, row, list_neg, dummy,
+                       pre_n[s], &long_e0[2 * s + 1], &long_n[2 * s + 1], &long_j[2 * s + 1]);
         }
       }
       // dense rows: runs longer than 128 elements, one at a time by the wave that found them
@@ -665,50 +711,45 @@ __global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : 2) void octav_rows_k
           const int n = __builtin_amdgcn_readlane(long_n[k], src);
           const int j = __builtin_amdgcn_readlane(long_j[k], src);
           const float res = pairwise_wave<8>(row, e0, n, lane);
-          if (lane == 0) reinterpret_cast<float*>(list + j)[k & 1] = res;
+          if (lane == 0) ((k & 1) ? list_neg : list_pos)[j] = res;
         }
       }
-      const int kmax = (max(npos, nneg) + 31) & ~31;   // whole double blocks of 2 x 16 entries: no tail code in the chain
-      for (int j = npos + tid; j < kmax; j += kRowsThreads) reinterpret_cast<float*>(list + j)[0] = 0.f;
-      for (int j = nneg + tid; j < kmax; j += kRowsThreads) reinterpret_cast<float*>(list + j)[1] = 0.f;
+      // whole blocks of 64 entries: no tail code in the chains (adding +0.0 padding is exact: a
+      // running total that started at +0.0 is never -0.0)
+      const int kp = (npos + 63) & ~63, kn = (nneg + 63) & ~63;
+      for (int j = npos + tid; j < kp; j += kRowsThreads) list_pos[j] = 0.f;
+      for (int j = nneg + tid; j < kn; j += kRowsThreads) list_neg[j] = 0.f;
       __syncthreads();
-      // ---- the chain: acc = acc + R_j in run order, both masks at once (adding +0.0 padding is
-      // exact: a running total that started at +0.0 is never -0.0)
-      if (wave == chain_wave) {
-        v2f acc = {0.f, 0.f};
-        if (kmax > 0) {
-          // Software pipelined by hand: the eight 16-byte broadcast loads of the NEXT sixteen entries are
-          // issued, then the sixteen dependent packed additions of the current ones run while those
-          // loads are in flight (the scheduling barriers keep the compiler from sinking the loads
-          // back behind the additions; it still places the s_waitcnt itself). The list is
-          // over-allocated by one block: what the last read-ahead fetches is never added.
-          const float4* l4 = reinterpret_cast<const float4*>(list);
-          const int npair = kmax >> 5;
-          float4 qa[8], qb[8];
+      // ---- the chains: acc = acc + R_j in run order. A single wave issues one addition per four
+      // cycles however the operands arrive, so the two masks' chains run on two different waves
+      // (SIMDs) at the same time. Software pipelined by hand: the eight 16-byte broadcast loads of the
+      // NEXT 32 entries are issued, then the 32 dependent additions of the current ones run while those
+      // loads are in flight (the scheduling barriers keep the compiler from sinking the loads back
+      // behind the additions; it still places the s_waitcnt itself). The lists are over-allocated by
+      // one block: what the last read-ahead fetches is never added.
+      if (wave == chain_wave || wave == ((chain_wave + 1) & 3)) {
+        const bool neg = wave != chain_wave;
+        const float4* l4 = reinterpret_cast<const float4*>(neg ? list_neg : list_pos);
+        const int npair = (neg ? kn : kp) >> 6;
+        float acc = 0.f;
+        float4 qa[8], qb[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) qa[k] = l4[k];
-          for (int pr = 0; pr < npair; ++pr) {
+        for (int k = 0; k < 8; ++k) qa[k] = l4[k];
+        for (int pr = 0; pr < npair; ++pr) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) qb[k] = l4[(2 * pr + 1) * 8 + k];
-            __builtin_amdgcn_sched_barrier(0);
+          for (int k = 0; k < 8; ++k) qb[k] = l4[(2 * pr + 1) * 8 + k];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              acc = acc + v2f{qa[k].x, qa[k].y};
-              acc = acc + v2f{qa[k].z, qa[k].w};
-            }
-            __builtin_amdgcn_sched_barrier(0);
+          for (int k = 0; k < 8; ++k) { acc = acc + qa[k].x; acc = acc + qa[k].y; acc = acc + qa[k].z; acc = acc + qa[k].w; }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) qa[k] = l4[(2 * pr + 2) * 8 + k];
-            __builtin_amdgcn_sched_barrier(0);
+          for (int k = 0; k < 8; ++k) qa[k] = l4[(2 * pr + 2) * 8 + k];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              acc = acc + v2f{qb[k].x, qb[k].y};
-              acc = acc + v2f{qb[k].z, qb[k].w};
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          for (int k = 0; k < 8; ++k) { acc = acc + qb[k].x; acc = acc + qb[k].y; acc = acc + qb[k].z; acc = acc + qb[k].w; }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (lane == 0) { sh->sum[0] = acc.x; sh->sum[1] = acc.y; }
+        if (lane == 0) sh->sum[neg ? 1 : 0] = acc;
       }
       __syncthreads();   // totals visible; the list may be rewritten by the next iteration
       pos_sum = sh->sum[0];
@@ -729,7 +770,7 @@ __global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : 2) void octav_rows_k
 size_t octav_rows_smem(int len) {
   const int npieces = (len + kPiece - 1) / kPiece;
   const size_t row_floats = static_cast<size_t>((len + (len >> 4) + 4) & ~3);
-  const size_t cap = static_cast<size_t>(((len / 2 + 1 + 31) & ~31) + 32);
+  const size_t cap = static_cast<size_t>(((len / 2 + 1 + 63) & ~63) + 64);
   return 256 + kRowsThreads * sizeof(float) + row_floats * sizeof(float) + cap * 2 * sizeof(float) +
          static_cast<size_t>((npieces + 1) & ~1) * 2 * sizeof(unsigned short);
 }
