@@ -359,7 +359,7 @@ __global__ void octav_kernel(OctavArgs a) {
 //           addition per four cycles however the operands arrive); the lists are read with
 //           broadcast 16-byte LDS loads, 32 entries ahead of the additions.
 // The row is stored with one float of padding per 16 (thread-owned pieces start on distinct banks).
-constexpr int kRowsMinLen = 1024, kRowsMaxLen = kChunk;
+constexpr int kRowsMinLen = 1024, kRowsMaxLen = 2 * kChunk;   // up to 4 pieces per thread
 constexpr int kRowsThreads = 256;
 constexpr int kPiece = 16;
 
@@ -437,7 +437,7 @@ __device__ __noinline__ float pairwise_wave(const float* row, int e0, int n, int
 }
 
 struct RowsShared {      // small per-workgroup exchange area (in front of the row in LDS)
-  int wave_runs[2][2][4];   // [mask][slot][wave]: runs starting in that wave's pieces
+  int wave_runs[2][4][4];   // [mask][slot][wave]: runs starting in that wave's pieces
   int wave_count[2][4];     // selected elements per wave
   int wave_changed[4];      // some word of the wave differs from the previous iteration's
   float sum[2];             // the two chain totals
@@ -548,18 +548,18 @@ __device__ __forceinline__ void piece_runs_sparse(unsigned word, unsigned carry,
 }
 
 template <int SLOTS>
-__global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : 2) void octav_rows_kernel(OctavArgs a) {
+__global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)) void octav_rows_kernel(OctavArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const long long unit = blockIdx.x;
   const int len = a.len;
   const int npieces = (len + kPiece - 1) / kPiece;
-  static_assert(sizeof(RowsShared) <= 128, "exchange area");
-  float* dummy = smem + 64 + tid;                          // (two exchange areas in front)
-  float* row = smem + 64 + kRowsThreads;
+  static_assert(sizeof(RowsShared) <= 256, "exchange area");
+  float* dummy = smem + 128 + tid;                         // (two exchange areas in front)
+  float* row = smem + 128 + kRowsThreads;
   const int row_floats = (pidx(len) + 4) & ~3;
   float* list_pos = row + row_floats;                       // run sums of the two masks, in run order
-  const int cap = ((len / 2 + 1 + 63) & ~63) + 64;         // + the chain's read-ahead
+  const int cap = ((len / 2 + 2 + 63) & ~63) + 64;         // (+ one per 8192-chunk) + the chain's read-ahead
   float* list_neg = list_pos + cap;
   unsigned short* words_pos = reinterpret_cast<unsigned short*>(list_neg + cap);
   unsigned short* words_neg = words_pos + ((npieces + 1) & ~1);
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : 2) void octav_rows_k
     // (two exchange areas, by iteration parity: an iteration whose masks did not change has only
     // one barrier, so a fast wave may already publish the next iteration's counts while a slow one
     // still reads this one's)
-    RowsShared* sh = reinterpret_cast<RowsShared*>(smem + 32 * (it & 1));
+    RowsShared* sh = reinterpret_cast<RowsShared*>(smem + 64 * (it & 1));
     // ---- masks of the thread's own pieces, from registers
     unsigned changed = 0;
     unsigned sp[SLOTS], sn[SLOTS];   // run starts
@@ -770,8 +770,8 @@ __global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : 2) void octav_rows_k
 size_t octav_rows_smem(int len) {
   const int npieces = (len + kPiece - 1) / kPiece;
   const size_t row_floats = static_cast<size_t>((len + (len >> 4) + 4) & ~3);
-  const size_t cap = static_cast<size_t>(((len / 2 + 1 + 63) & ~63) + 64);
-  return 256 + kRowsThreads * sizeof(float) + row_floats * sizeof(float) + cap * 2 * sizeof(float) +
+  const size_t cap = static_cast<size_t>(((len / 2 + 2 + 63) & ~63) + 64);
+  return 512 + kRowsThreads * sizeof(float) + row_floats * sizeof(float) + cap * 2 * sizeof(float) +
          static_cast<size_t>((npieces + 1) & ~1) * 2 * sizeof(unsigned short);
 }
 
@@ -1155,20 +1155,25 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
     // rows of a weight matrix: lanes own 64-element batches of the LDS-resident row
     OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close};
     const size_t smem = octav_rows_smem(a.len);
-    const bool two = (a.len + kPiece - 1) / kPiece > kRowsThreads;
-    static bool raised[2] = {false, false};   // > 64 KB of dynamic LDS has to be asked for once
-    if (smem > 64 * 1024 && !raised[two]) {
-      const hipError_t e = two ? hipFuncSetAttribute(reinterpret_cast<const void*>(octav_rows_kernel<2>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                               : hipFuncSetAttribute(reinterpret_cast<const void*>(octav_rows_kernel<1>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int slots = ((a.len + kPiece - 1) / kPiece + kRowsThreads - 1) / kRowsThreads;   // 1 .. 4
+    static bool raised[5] = {false, false, false, false, false};   // > 64 KB of dynamic LDS has to be asked for once
+    if (smem > 64 * 1024 && !raised[slots]) {
+      const void* fn = slots == 1 ? reinterpret_cast<const void*>(octav_rows_kernel<1>)
+                     : slots == 2 ? reinterpret_cast<const void*>(octav_rows_kernel<2>)
+                     : slots == 3 ? reinterpret_cast<const void*>(octav_rows_kernel<3>)
+                                  : reinterpret_cast<const void*>(octav_rows_kernel<4>);
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-      raised[two] = true;
+      raised[slots] = true;
     }
     const dim3 grid(static_cast<unsigned>(units)), blk(kRowsThreads);
     if (units > 0x7FFFFFFFLL) return fail(MI355Q_UNSUPPORTED, "too many units");
-    if (two) hipLaunchKernelGGL(octav_rows_kernel<2>, grid, blk, smem, st, a);
-    else hipLaunchKernelGGL(octav_rows_kernel<1>, grid, blk, smem, st, a);
+    switch (slots) {
+      case 1: hipLaunchKernelGGL(octav_rows_kernel<1>, grid, blk, smem, st, a); break;
+      case 2: hipLaunchKernelGGL(octav_rows_kernel<2>, grid, blk, smem, st, a); break;
+      case 3: hipLaunchKernelGGL(octav_rows_kernel<3>, grid, blk, smem, st, a); break;
+      default: hipLaunchKernelGGL(octav_rows_kernel<4>, grid, blk, smem, st, a); break;
+    }
     MI355Q_CHECK_LAUNCH("octav rows launch");
     hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
                        hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
