@@ -360,7 +360,6 @@ __global__ void octav_kernel(OctavArgs a) {
 //           broadcast 16-byte LDS loads, 32 entries ahead of the additions.
 // The row is stored with one float of padding per 16 (thread-owned pieces start on distinct banks).
 constexpr int kRowsMinLen = 1024, kRowsMaxLen = 2 * kChunk;   // up to 4 pieces per thread
-constexpr int kRowsThreads = 256;
 constexpr int kPiece = 16;
 
 __device__ __forceinline__ int pidx(int e) { return e + (e >> 4); }
@@ -547,8 +546,11 @@ __device__ __forceinline__ void piece_runs_sparse(unsigned word, unsigned carry,
   }
 }
 
-template <int SLOTS>
-__global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)) void octav_rows_kernel(OctavArgs a) {
+// THREADS = 64 / 128 / 256: rows of up to 1024 / 2048 elements leave half or three quarters of a
+// 256-thread workgroup without a piece, so they get smaller workgroups (more rows per CU).
+template <int SLOTS, int THREADS>
+__global__ __launch_bounds__(THREADS, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)) void octav_rows_kernel(OctavArgs a) {
+  constexpr int kRowsThreads = THREADS, kWaves = THREADS / kWave;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const long long unit = blockIdx.x;
@@ -564,6 +566,7 @@ __global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)
   unsigned short* words_pos = reinterpret_cast<unsigned short*>(list_neg + cap);
   unsigned short* words_neg = words_pos + ((npieces + 1) & ~1);
 
+  for (int i = tid; i < 128; i += THREADS) smem[i] = 0.f;   // both exchange areas: waves this workgroup does not have count as 0
   // ---- stage the unit: every thread keeps its pieces in registers for all iterations (one HBM
   // read), the row also goes to LDS for the runs that leave a piece
   const float qnan = __builtin_nanf("");
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)
   unsigned long long moved = 0;
   // the serial chain runs on one wave per workgroup: spread it over the SIMDs of the CU
   // (workgroups u, u + 256, u + 512, ... tend to be co-resident)
-  const int chain_wave = static_cast<int>((unit + (unit >> 8)) & 3);
+  const int chain_wave = static_cast<int>((unit + (unit >> 8)) % kWaves);
   for (int it = 0; it < a.max_iter; ++it) {
     const float hi = guess, lo = -guess;
     // (two exchange areas, by iteration parity: an iteration whose masks did not change has only
@@ -727,8 +730,10 @@ __global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)
       // loads are in flight (the scheduling barriers keep the compiler from sinking the loads back
       // behind the additions; it still places the s_waitcnt itself). The lists are over-allocated by
       // one block: what the last read-ahead fetches is never added.
-      if (wave == chain_wave || wave == ((chain_wave + 1) & 3)) {
-        const bool neg = wave != chain_wave;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const bool neg = m == 1;
+        if (wave != (chain_wave + m) % kWaves) continue;   // (a one-wave workgroup runs both, one after the other)
         const float4* l4 = reinterpret_cast<const float4*>(neg ? list_neg : list_pos);
         const int npair = (neg ? kn : kp) >> 6;
         float acc = 0.f;
@@ -767,7 +772,13 @@ __global__ __launch_bounds__(kRowsThreads, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)
   if (tid == 0) publish_moving(a.moving, moved);
 }
 
+int octav_rows_threads(int len) {
+  const int npieces = (len + kPiece - 1) / kPiece;
+  return npieces <= 64 ? 64 : (npieces <= 128 ? 128 : 256);
+}
+
 size_t octav_rows_smem(int len) {
+  const int kRowsThreads = octav_rows_threads(len);
   const int npieces = (len + kPiece - 1) / kPiece;
   const size_t row_floats = static_cast<size_t>((len + (len >> 4) + 4) & ~3);
   const size_t cap = static_cast<size_t>(((len / 2 + 2 + 63) & ~63) + 64);
@@ -1155,25 +1166,24 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
     // rows of a weight matrix: lanes own 64-element batches of the LDS-resident row
     OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close};
     const size_t smem = octav_rows_smem(a.len);
-    const int slots = ((a.len + kPiece - 1) / kPiece + kRowsThreads - 1) / kRowsThreads;   // 1 .. 4
+    const int threads = octav_rows_threads(a.len);
+    const int slots = ((a.len + kPiece - 1) / kPiece + threads - 1) / threads;   // 1 .. 4 (> 1 only with 256 threads)
+    const void* fn = slots == 4 ? reinterpret_cast<const void*>(octav_rows_kernel<4, 256>)
+                   : slots == 3 ? reinterpret_cast<const void*>(octav_rows_kernel<3, 256>)
+                   : slots == 2 ? reinterpret_cast<const void*>(octav_rows_kernel<2, 256>)
+                   : threads == 256 ? reinterpret_cast<const void*>(octav_rows_kernel<1, 256>)
+                   : threads == 128 ? reinterpret_cast<const void*>(octav_rows_kernel<1, 128>)
+                                    : reinterpret_cast<const void*>(octav_rows_kernel<1, 64>);
     static bool raised[5] = {false, false, false, false, false};   // > 64 KB of dynamic LDS has to be asked for once
     if (smem > 64 * 1024 && !raised[slots]) {
-      const void* fn = slots == 1 ? reinterpret_cast<const void*>(octav_rows_kernel<1>)
-                     : slots == 2 ? reinterpret_cast<const void*>(octav_rows_kernel<2>)
-                     : slots == 3 ? reinterpret_cast<const void*>(octav_rows_kernel<3>)
-                                  : reinterpret_cast<const void*>(octav_rows_kernel<4>);
       const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "hipFuncSetAttribute: %s", hipGetErrorString(e));
       raised[slots] = true;
     }
-    const dim3 grid(static_cast<unsigned>(units)), blk(kRowsThreads);
     if (units > 0x7FFFFFFFLL) return fail(MI355Q_UNSUPPORTED, "too many units");
-    switch (slots) {
-      case 1: hipLaunchKernelGGL(octav_rows_kernel<1>, grid, blk, smem, st, a); break;
-      case 2: hipLaunchKernelGGL(octav_rows_kernel<2>, grid, blk, smem, st, a); break;
-      case 3: hipLaunchKernelGGL(octav_rows_kernel<3>, grid, blk, smem, st, a); break;
-      default: hipLaunchKernelGGL(octav_rows_kernel<4>, grid, blk, smem, st, a); break;
-    }
+    void* kargs[] = {&a};
+    if (hipLaunchKernel(fn, dim3(static_cast<unsigned>(units)), dim3(threads), kargs, smem, st) != hipSuccess)
+      return fail(MI355Q_HIP_ERROR, "octav rows launch failed");
     MI355Q_CHECK_LAUNCH("octav rows launch");
     hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
                        hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
