@@ -65,14 +65,20 @@ struct Tile<double> {
 // registers behind a second barrier - a K step is 64 MFMAs = 4096 cycles per wave, so the two
 // barriers cost ~2 %, and fragments are double-buffered in registers by hand so the single
 // resident wave per SIMD never waits on ds_read.
+#ifndef MI355Q_BIG_BK      // tuning hooks (tools/gemm_bench.py)
+#define MI355Q_BIG_BK 16
+#endif
+#ifndef MI355Q_BIG_DBUF
+#define MI355Q_BIG_DBUF 0
+#endif
 struct TileF64Big {
   static constexpr int MF = 16;
   static constexpr int KF = 4;
   static constexpr int TM = 4;
   static constexpr int BM = 128;
-  static constexpr int BK = 16;
+  static constexpr int BK = MI355Q_BIG_BK;
   static constexpr int VEC = 2;
-  static constexpr bool DBUF = false;
+  static constexpr bool DBUF = MI355Q_BIG_DBUF != 0;
   using Elem = double;
   using Acc = __attribute__((ext_vector_type(4))) double;
   using Vec = double2;

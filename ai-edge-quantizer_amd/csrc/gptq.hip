@@ -90,18 +90,14 @@ __global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __
 }
 
 // ---------------------------------------------------------- Cholesky ----
-// Unblocked lower Cholesky of the nb x nb diagonal block at (k,k) followed by the
-// inverse of that triangular factor. L_kk goes back into `a`; inv(L_kk) (zeros above
-// the diagonal, identity padding past nb) goes to `dinv` (NB x NB, row-major): the
-// panel solve and the triangular-inverse merge then are plain MFMA GEMMs.
-// info != 0 if a pivot is not positive.
-//
-// This kernel sits on the serial critical path (one workgroup per 64 columns), so it is
-// latency-tuned: the block lives in registers while it is factored (lane = row, wave w owns
-// columns 16w..16w+15; a 16-column panel is factored inside its wave with v_readlane
-// broadcasts and applied to the waves on its right as a rank-16 update: 4 barriers), and
-// the inverse is built by pairwise merging in LDS (levels s = 1, 2, ..., 32:
-// X21 = -X22 (L21 X11), 12 barriers in total) instead of 64 serial forward substitutions.
+// The 64-column step of the blocked factorization is a serial chain of small kernels
+// (diagonal block -> panel below it -> trailing update), so each link is latency-tuned and the
+// chain holds nothing that can run elsewhere:
+//   potf2_kernel        factors the nb x nb diagonal block in registers (one workgroup);
+//   trsm_panel_kernel   solves L21 L11^T = A21 in place, one wave per 64 rows, by forward
+//                       substitution against L11 held in LDS (no inverse of L11 is needed);
+//   diag_inverse_kernel inverts all diagonal blocks of the finished factor in one launch, off
+//                       the chain: the base level of the triangular inverse.
 __device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // c <= r
 
 __device__ __forceinline__ float lane_bcast32(float v, int src_lane) {
@@ -113,6 +109,223 @@ __device__ __forceinline__ double lane_bcast64(double v, int src_lane) {
   const int lo = __builtin_amdgcn_readlane(static_cast<int>(bits), src_lane);
   const int hi = __builtin_amdgcn_readlane(static_cast<int>(bits >> 32), src_lane);
   return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
+#if defined(MI355Q_POTF2_PROF)   // tools/kbench/potf2_bench.hip: phase stamps
+#define MI355Q_STAMP() do { long long now__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now__) : : "memory"); \
+    if (prof && threadIdx.x == 0) prof[stamp] = now__; ++stamp; } while (0)
+#define MI355Q_PROF_ARG , static_cast<long long*>(nullptr)
+#else
+#define MI355Q_STAMP() do { } while (0)
+#define MI355Q_PROF_ARG
+#endif
+
+// Unblocked lower Cholesky of the nb x nb diagonal block at (k, k), in place. info != 0 if a
+// pivot is not positive (LAPACK's convention: 1 + its index); `lt` (NB x NB) receives the
+// transposed factor, reciprocals on its diagonal, for the panel solve.
+//
+// Lane = row, wave w owns columns 16w..16w+15 of every row (a short block is padded with the
+// identity, which factors to itself: straight-line code). A 16-column panel is factored inside
+// its wave and applied to the waves on its right as a rank-16 update (4 barriers in all). Inside
+// the panel the factorization is root-free: column j stays unscaled (u), its multipliers are
+// m = u / p_j (hardware reciprocal + two Newton steps), and v_i -= u m_i. What this kernel's
+// time is made of is the chain from one pivot to the next and the cross-lane traffic around it
+// (a v_readlane pair and the use of its result cost ~30 cycles), so only the pivot and the next
+// column's multiplier travel by v_readlane; the other multipliers go through LDS (one write,
+// wave-uniform reads) and are used a column later. The 1/sqrt(p_j) scaling that turns u into L
+// is done for all 64 columns at once at the end.
+__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int d, int k, int nb, int* info,
+                                                   double* __restrict__ lt
+#if defined(MI355Q_POTF2_PROF)
+                                                   , long long* prof
+#endif
+                                                   ) {
+  __shared__ double PU[2][NB][17];                                  // the last two panels, unscaled: [row][column]
+  __shared__ __attribute__((aligned(16))) double PM[2][16][NB];     // their multipliers: [column][row]
+  __shared__ __attribute__((aligned(16))) double piv[NB], ys[NB];
+  __shared__ int bad[4];
+  const int t = threadIdx.x, r = t & 63, cq = t >> 6;
+#if defined(MI355Q_POTF2_PROF)
+  int stamp = 0;
+#endif
+  MI355Q_STAMP();
+  double v[16];
+  const double* row = a + static_cast<long long>(k + (r < nb ? r : 0)) * d + k;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = cq * 16 + i;
+    const double g = row[c < nb ? c : 0];           // clamped, not predicated: no branch per load
+    v[i] = (r < nb && c < nb) ? (c <= r ? g : 0.0) : (c == r ? 1.0 : 0.0);
+  }
+  MI355Q_STAMP();
+#pragma unroll
+  for (int jq = 0; jq < 4; ++jq) {
+    double (*pu)[17] = PU[jq & 1];
+    double (*pm)[NB] = PM[jq & 1];
+    if (cq == jq) {  // wave-uniform
+      int first_bad = NB;
+      double pv = 1.0;
+#pragma unroll
+      for (int ji = 0; ji < 16; ++ji) {
+        const int j = jq * 16 + ji;
+        const double u = v[ji];
+        const double p = lane_bcast64(u, j);
+        first_bad = (!(p > 0.0) && first_bad == NB) ? j : first_bad;
+        double rp = __builtin_amdgcn_rcp(p);
+        rp = __builtin_fma(rp, __builtin_fma(-p, rp, 1.0), rp);
+        rp = __builtin_fma(rp, __builtin_fma(-p, rp, 1.0), rp);
+        const double m = u * rp;
+        if (ji + 1 < 16) v[ji + 1] = __builtin_fma(-u, lane_bcast64(m, j + 1), v[ji + 1]);
+        pm[ji][r] = m;
+        pv = r == j ? u : pv;              // (a select, not a branch: the lane of row j keeps p_j)
+        __builtin_amdgcn_wave_barrier();   // same wave: the LDS unit keeps the order, the compiler must too
+#pragma unroll
+        for (int i = ji + 2; i < 16; ++i) v[i] = __builtin_fma(-u, pm[ji][jq * 16 + i], v[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pu[r][i] = v[i];
+      if ((r >> 4) == jq) piv[r] = pv;
+      if (r == 0) bad[jq] = first_bad;
+    }
+    __syncthreads();
+    if (cq > jq) {
+      double mine[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) mine[jj] = pu[r][jj];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = cq * 16 + i;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) v[i] = __builtin_fma(-mine[jj], pm[jj][c], v[i]);
+      }
+    }
+  }
+  MI355Q_STAMP();
+  // L = u / sqrt(p): 1/sqrt(p) by hardware estimate + two Newton steps, one pivot per thread
+  if (t < NB) {
+    const double p = piv[t];
+    double y = __builtin_amdgcn_rsq(p);
+    y = y * (1.5 - 0.5 * p * y * y);
+    y = y * (1.5 - 0.5 * p * y * y);
+    ys[t] = y;
+  }
+  __syncthreads();
+  double* out = a + static_cast<long long>(k + (r < nb ? r : 0)) * d + k;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = cq * 16 + i;
+    const double y = ys[c];
+    const double l = v[i] * y;                  // on the diagonal u = p: sqrt(p)
+    if (r < nb && c <= r) out[c] = l;
+    lt[c * NB + r] = c == r ? y : l;            // 1 / L_jj = 1 / sqrt(p_j)
+  }
+  if (t == 0) {
+    int j = NB;
+#pragma unroll
+    for (int q = 3; q >= 0; --q) j = bad[q] < NB ? bad[q] : j;
+    if (j < nb) atomicCAS(info, 0, k + j + 1);
+  }
+  MI355Q_STAMP();
+}
+
+// L21 := A21 inv(L11)^T in place for the m rows below the diagonal block: one wave per 64 rows,
+// lane = row, the row's 64 values in registers (128 of the 256 VGPRs an ALU operand can name).
+// potf2_kernel left L11 transposed (1 / L_jj on the diagonal) in `lt`, so that step j
+// (x_j /= L_jj, then x_i -= x_j L_ij for i > j) reads one contiguous LDS column with
+// wave-uniform (broadcast) addresses. Straight-line code over (column, 16-row chunk) items,
+// software pipelined by hand: the chunks of the next two items are in flight while this item's
+// FMAs issue. One wave issues one instruction every ~4.5 cycles whatever its kind, so the
+// solve costs (2016 FMAs + 1056 LDS reads + waits) x 4.5 cycles: ~17 k cycles per tile.
+typedef double Pair __attribute__((ext_vector_type(2)));
+
+// Item N of the solve: column J against rows 16 Q .. 16 Q + 15 (template recursion instead of
+// loops: every register index has to be a compile-time constant). The empty asm statements pin
+// the schedule: LDS reads cannot cross the first (its pointer operand makes the never-escaping
+// LDS array "memory"), and the FMAs of this item cannot sink below the second, which would keep
+// every chunk alive until its rows' own columns come up.
+// (Tried: the wave-uniform L values as scalar operands through s_load. The 16 KB of L11 do not
+// stay in the scalar cache next to 30 other waves' copies, s_waitcnt lgkmcnt(0) is the only wait
+// there is for scalar loads, and 32 SGPRs per item leave no room to request further ahead:
+// 31.6 k cycles per tile against 17 k through LDS.)
+template <int J, int Q, int N>
+__device__ __forceinline__ void trsm_item(double (&x)[NB], Pair (&buf)[3][8], const Pair* Lt) {
+  constexpr int NJ = (Q + 1 == 4) ? J + 1 : J;               // the next item
+  constexpr int NQ = (Q + 1 == 4) ? NJ / 16 : Q + 1;
+  constexpr int PJ = (NQ + 1 == 4) ? NJ + 1 : NJ;            // the one after it: its chunk is requested now
+  constexpr int PQ = (NQ + 1 == 4) ? PJ / 16 : NQ + 1;
+  if constexpr (NJ < NB && PJ < NB) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) buf[(N + 2) % 3][u] = Lt[(PJ * NB + PQ * 16) / 2 + u];
+  }
+  asm volatile("" : "+v"(x[J]) : "v"(Lt) : "memory");
+  const Pair* c = buf[N % 3];
+  if constexpr (Q == J / 16) x[J] *= (J & 1) ? c[(J % 16) / 2].y : c[(J % 16) / 2].x;
+#pragma unroll
+  for (int i = Q * 16; i < Q * 16 + 16; ++i) {
+    if (i > J) x[i] = __builtin_fma(-x[J], (i & 1) ? c[(i % 16) / 2].y : c[(i % 16) / 2].x, x[i]);
+  }
+  constexpr int B = Q * 16;
+  asm volatile("" : "+v"(x[B]), "+v"(x[B + 1]), "+v"(x[B + 2]), "+v"(x[B + 3]), "+v"(x[B + 4]), "+v"(x[B + 5]),
+               "+v"(x[B + 6]), "+v"(x[B + 7]), "+v"(x[B + 8]), "+v"(x[B + 9]), "+v"(x[B + 10]), "+v"(x[B + 11]),
+               "+v"(x[B + 12]), "+v"(x[B + 13]), "+v"(x[B + 14]), "+v"(x[B + 15]));
+  if constexpr (NJ < NB) trsm_item<NJ, NQ, N + 1>(x, buf, Lt);
+}
+
+__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ a, int d, int k, int nb, int m,
+                                                       const double* __restrict__ lt
+#if defined(MI355Q_POTF2_PROF)
+                                                       , long long* prof
+#endif
+                                                       ) {
+#if defined(MI355Q_POTF2_PROF)
+  int stamp = 8;
+  if (blockIdx.x != 0) prof = nullptr;
+#endif
+  MI355Q_STAMP();
+  __shared__ Pair Lt[NB * NB / 2];     // Lt[(j * NB + i) / 2] = (L11[i][j], L11[i + 1][j]), identity padded
+  __shared__ double X[NB * (NB + 1)];  // the 64 x 64 tile of A21 on its way between row-per-lane and coalesced
+  const int t = threadIdx.x;
+  const long long r0 = static_cast<long long>(blockIdx.x) * 64;      // first row of this tile (below the block)
+  const int rows = m - r0 < 64 ? static_cast<int>(m - r0) : 64;
+  double* tile = a + (static_cast<long long>(k + nb) + r0) * d + k;
+  // global -> LDS with lane = column (512 contiguous bytes per row), then LDS -> registers with lane = row
+  // (clamped addresses instead of predicated loads: a branch per load would serialize 64 round trips)
+  const int tc = t < nb ? t : nb - 1;
+  {
+    double g[NB];
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) g[rr] = tile[static_cast<long long>(rr < rows ? rr : rows - 1) * d + tc];
+    const Pair* src = reinterpret_cast<const Pair*>(lt);
+#pragma unroll 8
+    for (int e = t; e < NB * NB / 2; e += 64) Lt[e] = src[e];
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) asm volatile("" : "+v"(g[rr]));   // "used" whatever the row count: 64 loads in flight, no branches
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) X[rr * (NB + 1) + t] = (rr < rows && t < nb) ? g[rr] : 0.0;
+  }
+  __syncthreads();
+  MI355Q_STAMP();
+  double x[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) x[c] = X[t * (NB + 1) + c];
+  Pair buf[3][8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { buf[0][u] = Lt[u]; buf[1][u] = Lt[8 + u]; }   // items (0, 0) and (0, 1)
+  trsm_item<0, 0, 0>(x, buf, Lt);
+  MI355Q_STAMP();
+#pragma unroll
+  for (int c = 0; c < NB; ++c) X[t * (NB + 1) + c] = x[c];
+  __syncthreads();
+#pragma unroll 1
+  for (int r16 = 0; r16 < NB; r16 += 16) {
+    double g[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g[i] = X[(r16 + i) * (NB + 1) + t];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (r16 + i < rows && t < nb) tile[static_cast<long long>(r16 + i) * d + t] = g[i];
+  }
+  MI355Q_STAMP();
 }
 
 // One level of the in-LDS inverse: every pair of adjacent inverted S-blocks becomes one
@@ -148,123 +361,33 @@ __device__ __forceinline__ void merge_level(const double* __restrict__ Lp, doubl
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ a, int d, int k, int nb,
-                                                       double* __restrict__ dinv, int* info) {
+// Every diagonal NB-block of the finished factor := its inverse, in place (one workgroup per
+// block): pairwise merging in LDS, levels s = 1, 2, ..., 32 with X21 = -X22 (L21 X11).
+__global__ __launch_bounds__(256) void diag_inverse_kernel(double* __restrict__ a, int d) {
   __shared__ double Lp[NB * (NB + 1) / 2];   // packed lower triangles
   __shared__ double Xp[NB * (NB + 1) / 2];
   __shared__ double T[NB * NB / 4];          // per level: all pairs' s x s products (32 * s values)
-  __shared__ double P[2][NB][17];            // the last two factored 64 x 16 panels
-  const int t = threadIdx.x, r = t & 63, cq = t >> 6;   // wave cq owns columns 16*cq..+15 of every row
-#if defined(MI355Q_POTF2_PROF)   // tools/kbench/potf2_bench.hip: phase stamps behind the dinv block
-  long long* prof = reinterpret_cast<long long*>(dinv + NB * NB);
-  int stamp = 0;
-#define MI355Q_STAMP() do { if (t == 0) prof[stamp] = __builtin_readcyclecounter(); ++stamp; } while (0)
-#else
-#define MI355Q_STAMP() do { } while (0)
-#endif
-  MI355Q_STAMP();
-  double v[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = cq * 16 + i;
-    v[i] = (r < nb && c <= r) ? a[static_cast<long long>(k + r) * d + k + c] : 0.0;
-  }
-  MI355Q_STAMP();
-  // Left to right over the four 16-column panels. The owning wave factors its panel alone
-  // (lane = row, pivots and multipliers broadcast with v_readlane: no barrier inside a panel),
-  // publishes it, and the waves to its right apply it as one rank-16 update.
-#pragma unroll
-  for (int jq = 0; jq < 4; ++jq) {
-    double (*pan)[17] = P[jq & 1];
-    if (cq == jq) {  // wave-uniform
-#pragma unroll
-      for (int ji = 0; ji < 16; ++ji) {
-        const int j = jq * 16 + ji;
-        if (j < nb) {  // uniform
-          const double p = lane_bcast64(v[ji], j);
-          if (!(p > 0.0) && r == 0) atomicCAS(info, 0, k + j + 1);
-          // 1/sqrt(p): hardware estimate + two Newton steps, computed by every lane
-          double y = __builtin_amdgcn_rsq(p);
-          y = y * (1.5 - 0.5 * p * y * y);
-          y = y * (1.5 - 0.5 * p * y * y);
-          v[ji] = r == j ? p * y : v[ji] * y;
-#pragma unroll
-          for (int i = ji + 1; i < 16; ++i) v[i] -= v[ji] * lane_bcast64(v[ji], jq * 16 + i);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) pan[r][i] = v[i];
-    }
-    __syncthreads();
-    if (cq > jq) {
-      double mine[16];
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) mine[jj] = pan[r][jj];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int c = cq * 16 + i;
-#pragma unroll
-        for (int jj = 0; jj < 16; ++jj) v[i] -= mine[jj] * pan[c][jj];
-      }
-    }
-  }
-  MI355Q_STAMP();
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = cq * 16 + i;
-    if (c <= r) {
-      const double val = r < nb ? v[i] : (c == r ? 1.0 : 0.0);
-      Lp[tri(r, c)] = val;
-      if (r < nb) a[static_cast<long long>(k + r) * d + k + c] = val;
-    }
+  const int t = threadIdx.x, k = blockIdx.x * NB;
+  const int nb = d - k < NB ? d - k : NB;
+  for (int e = t; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    if (c <= r) Lp[tri(r, c)] = (r < nb) ? a[static_cast<long long>(k + r) * d + k + c] : (c == r ? 1.0 : 0.0);
   }
   __syncthreads();
   if (t < NB) Xp[tri(t, t)] = 1.0 / Lp[tri(t, t)];
   __syncthreads();
-  MI355Q_STAMP();
   merge_level<1>(Lp, Xp, T, t);
-  MI355Q_STAMP();
   merge_level<2>(Lp, Xp, T, t);
-  MI355Q_STAMP();
   merge_level<4>(Lp, Xp, T, t);
-  MI355Q_STAMP();
   merge_level<8>(Lp, Xp, T, t);
-  MI355Q_STAMP();
   merge_level<16>(Lp, Xp, T, t);
-  MI355Q_STAMP();
   merge_level<32>(Lp, Xp, T, t);
-  MI355Q_STAMP();
   for (int e = t; e < NB * NB; e += 256) {
-    const int rr = e / NB, cc = e % NB;
-    dinv[e] = cc <= rr ? Xp[tri(rr, cc)] : 0.0;
-  }
-  MI355Q_STAMP();
-#undef MI355Q_STAMP
-}
-
-// dst[i, 0:nb] (row stride ld_dst) = src[i, 0:nb] (row stride ld_src), i < m
-__global__ __launch_bounds__(256) void copy_panel_kernel(const double* __restrict__ src, long long ld_src,
-                                                        double* __restrict__ dst, long long ld_dst, int m,
-                                                        int nb) {
-  const long long n = static_cast<long long>(m) * nb;
-  const long long stride = static_cast<long long>(gridDim.x) * 256;
-  for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
-    const long long i = e / nb, j = e % nb;
-    dst[i * ld_dst + j] = src[i * ld_src + j];
-  }
-}
-
-// Every diagonal block of `a` := its inverse (lower part of dinv[block]).
-__global__ __launch_bounds__(256) void put_diag_inverses_kernel(double* __restrict__ a, int d,
-                                                               const double* __restrict__ dinv, int first) {
-  const int kb = first + blockIdx.x, k = kb * NB;
-  const int nb = d - k < NB ? d - k : NB;
-  const double* x = dinv + static_cast<long long>(kb) * NB * NB;
-  for (int e = threadIdx.x; e < NB * NB; e += 256) {
     const int r = e / NB, c = e % NB;
-    if (r < nb && c <= r) a[static_cast<long long>(k + r) * d + k + c] = x[e];
+    if (r < nb && c <= r) a[static_cast<long long>(k + r) * d + k + c] = Xp[tri(r, c)];
   }
 }
+#undef MI355Q_STAMP
 
 // out32 = sym(lower(src)) cast to float32 (both triangles written).
 __global__ __launch_bounds__(256) void symmetrize_cast_kernel(const double* __restrict__ src, int d,
@@ -728,10 +851,9 @@ extern "C" int32_t mi355q_shutdown(void) {
 }
 
 extern "C" size_t mi355q_gptq_hinv_workspace_bytes(int64_t d) {
-  // two d x d FP64 matrices + a d x NB panel + one NB x NB inverse per diagonal block + scalars
+  // two d x d FP64 matrices + one transposed NB x NB diagonal block + scalars
   if (d <= 0) return 0;
-  const size_t nblocks = static_cast<size_t>((d + NB - 1) / NB);
-  return (static_cast<size_t>(d) * d * 2 + static_cast<size_t>(d) * NB + nblocks * NB * NB + 8) * sizeof(double);
+  return (static_cast<size_t>(d) * d * 2 + NB * NB + 8) * sizeof(double);
 }
 
 extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, double damp_factor,
@@ -750,9 +872,8 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   const int nblocks = (d + NB - 1) / NB;
   double* a = static_cast<double*>(workspace);           // L, then L^-1 (lower, zeros above)
   double* out = a + static_cast<size_t>(d) * d;          // lower(H^-1) in FP64
-  double* panel = out + static_cast<size_t>(d) * d;      // d x NB temporary
-  double* dinv = panel + static_cast<size_t>(d) * NB;    // nblocks x (NB x NB): inv(L_kk)
-  double* scal = dinv + static_cast<size_t>(nblocks) * NB * NB;
+  double* lt = out + static_cast<size_t>(d) * d;         // NB x NB: the current diagonal block, transposed
+  double* scal = lt + NB * NB;
   if (hipMemsetAsync(info_out, 0, sizeof(int32_t), st) != hipSuccess)
     return fail(MI355Q_HIP_ERROR, "hipMemsetAsync failed");
   hipLaunchKernelGGL(diag_sum_kernel, dim3(1), dim3(256), 0, st, hessian, d, scal);
@@ -760,8 +881,8 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
                      hessian, d, scal, damp_factor, a);
   MI355Q_CHECK_LAUNCH("gptq damp launch");
   // ---- blocked right-looking Cholesky (lower), FP64, two levels. Per 64-column step:
-  //   diagonal block: factor + invert (one workgroup)
-  //   panel:    L21 = A21 * inv(L11)^T                      (MFMA GEMM)
+  //   diagonal block: factor (one workgroup)
+  //   panel:    L21 L11^T = A21, in place                   (forward substitution, one wave per 64 rows)
   //   trailing: A22 -= L21 * L21^T, lower triangle only     (MFMA GEMM)
   // A rank-64 update of the whole trailing matrix is memory-bound (it reads and writes
   // (d-k)^2/2 doubles for 64 flops each), so the 64-column steps only update the rest of their
@@ -781,20 +902,15 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
     const int ob = d - k0 < OB ? d - k0 : OB;
     for (int k = k0; k < k0 + ob; k += NB) {
       const int nb = k0 + ob - k < NB ? k0 + ob - k : NB;
-      double* inv11 = dinv + static_cast<size_t>(k / NB) * NB * NB;
-      hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, inv11, info_out);
+      hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, info_out, lt MI355Q_PROF_ARG);
       const int m = d - k - nb;            // rows below the diagonal block
       const int w = k0 + ob - k - nb;      // columns left in this outer block
       if (m > 0) {
-        double* a21 = a + static_cast<long long>(k + nb) * d + k;
-        double* a22 = a + static_cast<long long>(k + nb) * d + k + nb;
-        // panel(i,j) = sum_c A21[i][c] * inv11[j][c]
-        GemmArgs<double> gs{a21, d, 1, inv11, 1, NB, panel, NB, 1, m, nb, nb, 1.0, 0.0, 0, 0};
-        if (int32_t e = launch_gemm<double>(gs, st)) return e;
-        hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m) * nb)), dim3(256), 0, st,
-                           panel, static_cast<long long>(NB), a21, static_cast<long long>(d), m, nb);
+        hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + 63) / 64), dim3(64), 0, st, a, d, k, nb, m, lt MI355Q_PROF_ARG);
         if (w > 0) {
-          GemmArgs<double> gt{panel, NB, 1, panel, 1, NB, a22, d, 1, m, w, nb, -1.0, 1.0, 1, 0};
+          const double* l21 = a + static_cast<long long>(k + nb) * d + k;
+          double* a22 = a + static_cast<long long>(k + nb) * d + k + nb;
+          GemmArgs<double> gt{l21, d, 1, l21, 1, d, a22, d, 1, m, w, nb, -1.0, 1.0, 1, 0};
           if (int32_t e = launch_gemm<double>(gt, st)) return e;
         }
       }
@@ -852,7 +968,7 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   //   [ L21        L22^-1   ]      becomes one inverted block with  L21 <- -L22^-1 (L21 L11^-1).
   // All flops are in large triangular-operand GEMMs (two per pair); `out` is free until the
   // final product and holds the intermediate L21 L11^-1.
-  hipLaunchKernelGGL(put_diag_inverses_kernel, dim3(nblocks), dim3(256), 0, st, a, d, dinv, 0);
+  hipLaunchKernelGGL(diag_inverse_kernel, dim3(nblocks), dim3(256), 0, st, a, d);
   for (long long s = NB; s < d; s *= 2) {
     // the pairs of one level are independent and (but for a ragged last one) equally shaped:
     // the low levels, hundreds of one-tile GEMMs, go out as two batched launches per level
