@@ -650,26 +650,88 @@ __global__ __launch_bounds__(256) void gptq_catchup_kernel(ApplyArgs a) {
   }
 }
 
+// Four lanes per row (a DPP quad), 16 rows per wave: lane c4 of the quad owns columns 4k + c4 of
+// the block, k = 0..15, in registers. One wave issues an instruction every ~4.5 cycles whatever
+// its kind, and with a whole row per lane the 2 x (63 - i) multiply-subtracts of step i were 60 %
+// of the 7200 instructions of a block (18.9 us at 2048 rows, on 32 of 256 CUs). Spread over a
+// quad they are a quarter of that, four times as many waves work, and what crosses lanes -- the
+// step's error, once -- is one quad_perm DPP move. The arithmetic per element is unchanged.
+constexpr int kRowsPerWave = kWave / 4;
+
+template <int kLaneInQuad>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kLaneInQuad * 0x55, 0xF, 0xF, false));
+}
+
+template <int I>
+__device__ __forceinline__ void gptq_quad_step(const ApplyArgs& a, const float (*hp)[4][16], int c4, float s_lo, float s_hi,
+                                               float (&w)[16], float& mye, unsigned& myq, unsigned* qrow, float* erow) {
+  constexpr int KO = I >> 2, CO = I & 3;
+  // this lane's Hinv values of row I (columns 4k + c4, k >= KO) and the row's diagonal entry
+  float hv[16];
+#pragma unroll
+  for (int k = (KO & ~3); k < 16; k += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(&hp[I][c4][k]);
+    hv[k] = v.x; hv[k + 1] = v.y; hv[k + 2] = v.z; hv[k + 3] = v.w;
+  }
+  const float hii = hp[I][CO][KO];
+  // the chain: every lane runs it on its own column KO, the owner's result (c4 == CO) is the step's
+  const float s = I < 32 ? s_lo : s_hi;
+  const float wi = w[KO];
+  const float v = wi / s;
+  float q = __builtin_rintf(v);
+  q = fminf(fmaxf(q, a.lo), a.hi);
+  const int qi = (v != v) ? 0 : static_cast<int>(q);
+  const float dq = static_cast<float>(qi) * s;
+  float e_own = wi - dq;
+  e_own = e_own / hii;
+  const float e = quad_bcast<CO>(e_own);
+  myq = c4 == CO ? (static_cast<unsigned>(qi) & 0xFFu) << (8 * CO) : myq;
+  mye = c4 == CO ? e_own : mye;
+  if constexpr (CO < 3) {
+    const float p = e * hv[KO];          // product rounded, then subtracted (np.outer, then -=)
+    w[KO] = c4 > CO ? w[KO] - p : w[KO];
+  }
+#pragma unroll
+  for (int k = KO + 1; k < 16; ++k) {
+    const float p = e * hv[k];
+    w[k] = w[k] - p;
+  }
+  if constexpr (CO == 3) {
+    // Group KO is complete: its four bytes are gathered over the quad, every lane stores its own
+    // error. Unconditional (idle rows shadow the last row and store its values again): a branch
+    // here would cut the 64 steps into basic blocks, and the optimizer then sinks the updates of
+    // the far columns block by block towards their use.
+    unsigned word = myq;
+    word |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(word), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    word |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(word), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    qrow[KO] = word;
+    erow[4 * KO + c4] = mye;
+  }
+  if constexpr (I + 1 < NB) gptq_quad_step<I + 1>(a, hp, c4, s_lo, s_hi, w, mye, myq, qrow, erow);
+}
+
 __global__ __launch_bounds__(kWave) void gptq_rows_kernel(ApplyArgs a) {
-  __shared__ __attribute__((aligned(16))) float h[NB][NB];     // Hinv[c0:c0+64, c0:c0+64]
-  const int r = blockIdx.x * kWave + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float hp[NB][4][16];    // hp[i][c][k] = Hinv[c0 + i][c0 + 4 k + c]
+  __shared__ float wl[kRowsPerWave][NB + 4];                       // the rows' block on its way into the quad layout
+  const int lane = threadIdx.x, c4 = lane & 3, rl = lane >> 2;
+  const int r = blockIdx.x * kRowsPerWave + rl;
   const bool live = r < a.rows;
-  const int rr = live ? r : a.rows - 1;               // idle lanes shadow the last row, write nothing
+  const int rr = live ? r : a.rows - 1;               // idle lanes shadow the last row and store its values again
   {
     const float* hblock = a.hinv + static_cast<long long>(a.c0) * a.d + a.c0;
 #pragma unroll
     for (int k = 0; k < NB * NB / 4 / kWave; ++k) {    // 16 coalesced 16-byte loads per lane
-      const int e4 = k * kWave + threadIdx.x, row = e4 / (NB / 4), c4 = e4 % (NB / 4);
-      reinterpret_cast<float4*>(&h[row][0])[c4] =
-          *reinterpret_cast<const float4*>(hblock + static_cast<long long>(row) * a.d + 4 * c4);
+      const int e4 = k * kWave + lane, row = e4 / (NB / 4), kk = e4 % (NB / 4);
+      const float4 v = *reinterpret_cast<const float4*>(hblock + static_cast<long long>(row) * a.d + 4 * kk);
+      hp[row][0][kk] = v.x; hp[row][1][kk] = v.y; hp[row][2][kk] = v.z; hp[row][3][kk] = v.w;
     }
-  }
-  const float* wrow = a.w + static_cast<long long>(rr) * a.d + a.c0;
-  float w[NB];
+    const float* wrow = a.w + static_cast<long long>(rr) * a.d + a.c0 + 16 * c4;   // the quad reads its row's 256 bytes
 #pragma unroll
-  for (int k = 0; k < NB; k += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(wrow + k);   // (d % 64 == 0, c0 % 64 == 0: aligned)
-    w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow + 4 * k);
+      *reinterpret_cast<float4*>(&wl[rl][16 * c4 + 4 * k]) = v;
+    }
   }
   const float* sc = static_cast<const float*>(a.scale);
   const long long si0 = a.scale_mode == 1 ? rr : (a.scale_mode == 2 ? static_cast<long long>(rr) * a.nblk + a.c0 / a.block_size : 0);
@@ -678,44 +740,12 @@ __global__ __launch_bounds__(kWave) void gptq_rows_kernel(ApplyArgs a) {
   unsigned* qrow = reinterpret_cast<unsigned*>(a.q + static_cast<long long>(rr) * a.d + a.c0);
   float* erow = a.err + static_cast<long long>(rr) * kErrLd + a.err_col;
   __syncthreads();
-  unsigned qword = 0;
-  float e4[4];
+  float w[16];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    // row i of the tile, columns i .. 63 (uniform addresses: LDS broadcasts); the reads are in
-    // flight while the head of this step's chain (divide, round, divide) runs
-    float hrow[NB];
-#pragma unroll
-    for (int k = (i & ~3); k < NB; k += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(&h[i][k]);
-      hrow[k] = v.x; hrow[k + 1] = v.y; hrow[k + 2] = v.z; hrow[k + 3] = v.w;
-    }
-    const float s = i < 32 ? s_lo : s_hi;
-    const float wi = w[i];
-    const float v = wi / s;
-    float q = __builtin_rintf(v);
-    q = fminf(fmaxf(q, a.lo), a.hi);
-    const int qi = (v != v) ? 0 : static_cast<int>(q);
-    const float dq = static_cast<float>(qi) * s;
-    float e = wi - dq;
-    e = e / hrow[i];
-    qword |= (static_cast<unsigned>(qi) & 0xFFu) << (8 * (i % 4));
-    e4[i % 4] = e;
-#pragma unroll
-    for (int k = i + 1; k < NB; ++k) {
-      const float p = e * hrow[k];     // product rounded, then subtracted (np.outer, then -=)
-      w[k] = w[k] - p;
-    }
-    if (i % 4 == 3) {
-      // Unconditional: idle lanes shadow the last row and store its (identical) values again. A
-      // branch here would cut the 64 steps into basic blocks, and the optimizer then sinks the
-      // updates of the far columns block by block towards their use -- every error and every
-      // Hinv value stays live and the kernel spills 700 registers.
-      qrow[i / 4] = qword;
-      *reinterpret_cast<float4*>(erow + i - 3) = make_float4(e4[0], e4[1], e4[2], e4[3]);
-      qword = 0;
-    }
-  }
+  for (int k = 0; k < 16; ++k) w[k] = wl[rl][4 * k + c4];
+  float mye = 0.f;
+  unsigned myq = 0;
+  gptq_quad_step<0>(a, hp, c4, s_lo, s_hi, w, mye, myq, qrow, erow);
 }
 
 inline unsigned grid1d(long long n) {
@@ -1065,7 +1095,7 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
           if (rl == 32) hipLaunchKernelGGL(gptq_catchup_kernel<32>, grid, dim3(256), 0, st, a);
           else hipLaunchKernelGGL(gptq_catchup_kernel<16>, grid, dim3(256), 0, st, a);
         }
-        hipLaunchKernelGGL(gptq_rows_kernel, dim3(static_cast<unsigned>((rows + kWave - 1) / kWave)), dim3(kWave), 0, st, a);
+        hipLaunchKernelGGL(gptq_rows_kernel, dim3(static_cast<unsigned>((rows + kRowsPerWave - 1) / kRowsPerWave)), dim3(kWave), 0, st, a);
         continue;
       }
 #define MI355Q_BLOCK(ST, RL, PL) hipLaunchKernelGGL((gptq_block_kernel<ST, RL, PL>), grid, dim3(256), 0, st, a)
