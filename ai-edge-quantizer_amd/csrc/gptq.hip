@@ -595,61 +595,15 @@ __global__ __launch_bounds__(256, kRowLanes == 16 ? 4 : 1) void gptq_block_kerne
   }
 }
 
-// ---- the same block with ONE LANE PER ROW (symmetric recipes, float scales: kPlain) -----------
+// ---- the same block with the column chain inside a DPP QUAD (symmetric recipes, float scales) ----
 // With a row spread over 16 / 32 lanes every column step broadcasts the column's value through
 // v_readlane, every lane of the row repeats the quantization, and the step costs ~1000 cycles of
 // exposed latency (1.34 ms for 2048 x 2048). The chain itself is only quantize -> error -> divide ->
-// one multiply-subtract for the next column: with a whole row in one lane's registers (64 values,
-// statically indexed: the 64 steps are unrolled) nothing crosses lanes, Hinv's rows are wave-uniform
-// scalar loads (s_load) feeding the multiply as SGPR operands, and the updates of the columns
-// further right overlap the next steps' chains. A wave carries 64 rows; the arithmetic per element
-// is exactly the spread kernel's (same operations in the same order: identical integers).
-// The errors of the group's earlier blocks are applied beforehand by gptq_catchup_kernel (the
-// spread kernel's first phase as a kernel of its own: many workgroups, LDS tiles).
-template <int kRowLanes>
-__global__ __launch_bounds__(256) void gptq_catchup_kernel(ApplyArgs a) {
-  constexpr int kColsPerLane = NB / kRowLanes;
-  __shared__ __attribute__((aligned(16))) float h[NB][NB];
-  __shared__ float es[256 / kRowLanes][NB];
-  const int l = threadIdx.x % kRowLanes;
-  const int r = blockIdx.x * (256 / kRowLanes) + threadIdx.x / kRowLanes;
-  const bool live = r < a.rows;
-  const int rr = live ? r : a.rows - 1;
-  float* wrow = a.w + static_cast<long long>(rr) * a.d + a.c0;
-  float w[kColsPerLane];
-#pragma unroll
-  for (int k = 0; k < kColsPerLane; ++k) w[k] = wrow[l * kColsPerLane + k];
-  for (int pb = 0; pb < a.err_col; pb += NB) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
-      const int k = e / NB, c = e % NB;
-      h[k][c] = a.hinv[static_cast<long long>(a.c0 - a.err_col + pb + k) * a.d + a.c0 + c];
-    }
-    for (int e = threadIdx.x; e < (256 / kRowLanes) * NB; e += 256) {
-      const int rw = e / NB, k = e % NB;
-      const long long row = static_cast<long long>(blockIdx.x) * (256 / kRowLanes) + rw;
-      es[rw][k] = row < a.rows ? a.err[row * kErrLd + pb + k] : 0.f;
-    }
-    __syncthreads();
-    float sum[kColsPerLane];
-#pragma unroll
-    for (int k = 0; k < kColsPerLane; ++k) sum[k] = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < NB; ++k) {
-      const float ek = es[threadIdx.x / kRowLanes][k];
-      const float* hp = &h[k][l * kColsPerLane];
-#pragma unroll
-      for (int j = 0; j < kColsPerLane; ++j) sum[j] = sum[j] + ek * hp[j];
-    }
-#pragma unroll
-    for (int j = 0; j < kColsPerLane; ++j) w[j] = w[j] - sum[j];
-  }
-  if (live) {
-#pragma unroll
-    for (int k = 0; k < kColsPerLane; ++k) wrow[l * kColsPerLane + k] = w[k];
-  }
-}
-
+// one multiply-subtract for the next column. Round 2 first moved a whole row into one lane (64
+// statically indexed registers, nothing crosses lanes: 1.19 ms), then to the quad layout below.
+// The arithmetic per element is exactly the spread kernel's (same operations in the same order:
+// identical integers). The errors of the group's earlier blocks are applied by the same kernel
+// before the chain starts (the spread kernel's first phase; all four waves of the workgroup).
 // Four lanes per row (a DPP quad), 16 rows per wave: lane c4 of the quad owns columns 4k + c4 of
 // the block, k = 0..15, in registers. One wave issues an instruction every ~4.5 cycles whatever
 // its kind, and with a whole row per lane the 2 x (63 - i) multiply-subtracts of step i were 60 %
@@ -711,35 +665,65 @@ __device__ __forceinline__ void gptq_quad_step(const ApplyArgs& a, const float (
   if constexpr (I + 1 < NB) gptq_quad_step<I + 1>(a, hp, c4, s_lo, s_hi, w, mye, myq, qrow, erow);
 }
 
-__global__ __launch_bounds__(kWave) void gptq_rows_kernel(ApplyArgs a) {
-  __shared__ __attribute__((aligned(16))) float hp[NB][4][16];    // hp[i][c][k] = Hinv[c0 + i][c0 + 4 k + c]
-  __shared__ float wl[kRowsPerWave][NB + 4];                       // the rows' block on its way into the quad layout
-  const int lane = threadIdx.x, c4 = lane & 3, rl = lane >> 2;
-  const int r = blockIdx.x * kRowsPerWave + rl;
-  const bool live = r < a.rows;
-  const int rr = live ? r : a.rows - 1;               // idle lanes shadow the last row and store its values again
+__global__ __launch_bounds__(256) void gptq_rows_kernel(ApplyArgs a) {
+  // one buffer, two uses -- catch-up: h[k][c] = Hinv[g0 + pb + k][c0 + c]; chain: hp[i][c][k] = Hinv[c0 + i][c0 + 4 k + c]
+  __shared__ __attribute__((aligned(16))) float hbuf[NB * NB];
+  __shared__ __attribute__((aligned(16))) float es[kRowsPerWave][NB];
+  __shared__ __attribute__((aligned(16))) float wl[kRowsPerWave][NB + 4];   // the rows' block on its way into the quad layout
+  const int tid = threadIdx.x;
   {
+    // Catch-up, by the whole workgroup (16 lanes per row, 4 columns per lane): the errors of the
+    // group's earlier blocks reach this block's columns now,
+    //   W[rows, c0:c0+64] -= err[rows, 0:err_col] @ Hinv[g0:g0+err_col, c0:c0+64],
+    // one 64-deep sum per earlier block, subtracted in block order.
+    const int rw = tid >> 4, l = tid & 15;
+    const long long row = static_cast<long long>(blockIdx.x) * kRowsPerWave + rw;
+    const long long rrow = row < a.rows ? row : a.rows - 1;
+    const float4 w4 = *reinterpret_cast<const float4*>(a.w + rrow * a.d + a.c0 + 4 * l);
+    float w[4] = {w4.x, w4.y, w4.z, w4.w};
+    for (int pb = 0; pb < a.err_col; pb += NB) {
+      __syncthreads();
+      const float* hsrc = a.hinv + static_cast<long long>(a.c0 - a.err_col + pb) * a.d + a.c0;
+#pragma unroll
+      for (int k = 0; k < NB * NB / 4 / 256; ++k) {
+        const int e4 = k * 256 + tid, hr = e4 / (NB / 4), hc = e4 % (NB / 4);
+        reinterpret_cast<float4*>(hbuf)[e4] = *reinterpret_cast<const float4*>(hsrc + static_cast<long long>(hr) * a.d + 4 * hc);
+      }
+      *reinterpret_cast<float4*>(&es[rw][4 * l]) = *reinterpret_cast<const float4*>(a.err + rrow * kErrLd + pb + 4 * l);
+      __syncthreads();
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int k = 0; k < NB; ++k) {
+        const float ek = es[rw][k];
+        const float4 h4 = *reinterpret_cast<const float4*>(&hbuf[k * NB + 4 * l]);
+        sum[0] = sum[0] + ek * h4.x; sum[1] = sum[1] + ek * h4.y; sum[2] = sum[2] + ek * h4.z; sum[3] = sum[3] + ek * h4.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = w[j] - sum[j];
+    }
+    *reinterpret_cast<float4*>(&wl[rw][4 * l]) = make_float4(w[0], w[1], w[2], w[3]);
+    __syncthreads();
     const float* hblock = a.hinv + static_cast<long long>(a.c0) * a.d + a.c0;
+    float (*hp)[4][16] = reinterpret_cast<float (*)[4][16]>(hbuf);
 #pragma unroll
-    for (int k = 0; k < NB * NB / 4 / kWave; ++k) {    // 16 coalesced 16-byte loads per lane
-      const int e4 = k * kWave + lane, row = e4 / (NB / 4), kk = e4 % (NB / 4);
-      const float4 v = *reinterpret_cast<const float4*>(hblock + static_cast<long long>(row) * a.d + 4 * kk);
-      hp[row][0][kk] = v.x; hp[row][1][kk] = v.y; hp[row][2][kk] = v.z; hp[row][3][kk] = v.w;
+    for (int k = 0; k < NB * NB / 4 / 256; ++k) {
+      const int e4 = k * 256 + tid, hr = e4 / (NB / 4), kk = e4 % (NB / 4);
+      const float4 v = *reinterpret_cast<const float4*>(hblock + static_cast<long long>(hr) * a.d + 4 * kk);
+      hp[hr][0][kk] = v.x; hp[hr][1][kk] = v.y; hp[hr][2][kk] = v.z; hp[hr][3][kk] = v.w;
     }
-    const float* wrow = a.w + static_cast<long long>(rr) * a.d + a.c0 + 16 * c4;   // the quad reads its row's 256 bytes
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(wrow + 4 * k);
-      *reinterpret_cast<float4*>(&wl[rl][16 * c4 + 4 * k]) = v;
-    }
+    __syncthreads();
+    if (tid >= kWave) return;   // the chain is one wave's
   }
+  const float (*hp)[4][16] = reinterpret_cast<const float (*)[4][16]>(hbuf);
+  const int lane = tid, c4 = lane & 3, rl = lane >> 2;
+  const int r = blockIdx.x * kRowsPerWave + rl;
+  const int rr = r < a.rows ? r : a.rows - 1;         // idle lanes shadow the last row and store its values again
   const float* sc = static_cast<const float*>(a.scale);
   const long long si0 = a.scale_mode == 1 ? rr : (a.scale_mode == 2 ? static_cast<long long>(rr) * a.nblk + a.c0 / a.block_size : 0);
   const long long si1 = a.scale_mode == 2 ? static_cast<long long>(rr) * a.nblk + (a.c0 + 32) / a.block_size : si0;
   const float s_lo = sc[si0], s_hi = sc[si1];
   unsigned* qrow = reinterpret_cast<unsigned*>(a.q + static_cast<long long>(rr) * a.d + a.c0);
   float* erow = a.err + static_cast<long long>(rr) * kErrLd + a.err_col;
-  __syncthreads();
   float w[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) w[k] = wl[rl][4 * k + c4];
@@ -1091,11 +1075,7 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
       const bool plain = a.nb == NB && zero_point == nullptr && !(scale_mode == 2 && block_size % 32 != 0);
       if (plain && !scale_is_f64 && d % NB == 0 && !getenv("MI355Q_GPTQ_SPREAD")) {
         // one lane per row: the column chain stays inside a lane (see gptq_rows_kernel)
-        if (a.err_col > 0) {
-          if (rl == 32) hipLaunchKernelGGL(gptq_catchup_kernel<32>, grid, dim3(256), 0, st, a);
-          else hipLaunchKernelGGL(gptq_catchup_kernel<16>, grid, dim3(256), 0, st, a);
-        }
-        hipLaunchKernelGGL(gptq_rows_kernel, dim3(static_cast<unsigned>((rows + kRowsPerWave - 1) / kRowsPerWave)), dim3(kWave), 0, st, a);
+        hipLaunchKernelGGL(gptq_rows_kernel, dim3(static_cast<unsigned>((rows + kRowsPerWave - 1) / kRowsPerWave)), dim3(256), 0, st, a);
         continue;
       }
 #define MI355Q_BLOCK(ST, RL, PL) hipLaunchKernelGGL((gptq_block_kernel<ST, RL, PL>), grid, dim3(256), 0, st, a)
