@@ -65,6 +65,11 @@ struct Tile<double> {
 // registers behind a second barrier - a K step is 64 MFMAs = 4096 cycles per wave, so the two
 // barriers cost ~2 %, and fragments are double-buffered in registers by hand so the single
 // resident wave per SIMD never waits on ds_read.
+// (Round 2 re-measured the alternatives on the GPU -- two LDS buffers / one barrier per K step,
+// BK = 32, both: 8192^3 63.7 -> 58.2 / 56.3 / 48.7 TFLOP/s -- and an XCD-aware tile order that
+// walks 4 x 8 tile patches per XCD: the HBM fetch of the d = 16384 product fell from 83.5 to
+// 61.7 GB with no change in its 26.5 ms, and the rank-512 updates got slower (13.4 -> 16.7 ms).
+// The kernel is not bandwidth-bound; profiles/r02_hinv_phases.txt.)
 #ifndef MI355Q_BIG_BK      // tuning hooks (tools/gemm_bench.py)
 #define MI355Q_BIG_BK 16
 #endif
