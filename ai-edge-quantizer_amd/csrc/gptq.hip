@@ -619,7 +619,8 @@ __device__ __forceinline__ float quad_bcast(float v) {
 
 template <int I>
 __device__ __forceinline__ void gptq_quad_step(const ApplyArgs& a, const float (*hp)[4][16], int c4, float s_lo, float s_hi,
-                                               float (&w)[16], float& mye, unsigned& myq, unsigned* qrow, float* erow) {
+                                               float (&w)[16], float& mye, unsigned& myq, unsigned* qrow, float* erow,
+                                               float* es_row) {
   constexpr int KO = I >> 2, CO = I & 3;
   // this lane's Hinv values of row I (columns 4k + c4, k >= KO) and the row's diagonal entry
   float hv[16];
@@ -660,76 +661,85 @@ __device__ __forceinline__ void gptq_quad_step(const ApplyArgs& a, const float (
     word |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(word), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
     word |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(word), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
     qrow[KO] = word;
-    erow[4 * KO + c4] = mye;
+    erow[4 * KO + c4] = mye;       // for the update of the columns behind the group (one GEMM per group)
+    es_row[4 * KO + c4] = mye;     // for the group's later blocks, which this workgroup does next
   }
-  if constexpr (I + 1 < NB) gptq_quad_step<I + 1>(a, hp, c4, s_lo, s_hi, w, mye, myq, qrow, erow);
+  if constexpr (I + 1 < NB) gptq_quad_step<I + 1>(a, hp, c4, s_lo, s_hi, w, mye, myq, qrow, erow, es_row);
 }
 
+// One launch per GROUP of kLazyBlocks 64-column blocks (a.c0 = the group's first column, a.nb = its
+// number of blocks): rows are independent, so the workgroup that owns 16 rows takes them through
+// the group's blocks one after the other -- catch-up with the earlier blocks' errors (kept in
+// LDS), then the chain -- and nothing but the update of the columns behind the group needs a
+// kernel boundary (~5 us each on this stack; they were a quarter of the 2048 x 2048 time).
 __global__ __launch_bounds__(256) void gptq_rows_kernel(ApplyArgs a) {
   // one buffer, two uses -- catch-up: h[k][c] = Hinv[g0 + pb + k][c0 + c]; chain: hp[i][c][k] = Hinv[c0 + i][c0 + 4 k + c]
   __shared__ __attribute__((aligned(16))) float hbuf[NB * NB];
-  __shared__ __attribute__((aligned(16))) float es[kRowsPerWave][NB];
+  __shared__ __attribute__((aligned(16))) float es[kRowsPerWave][kErrLd];   // the group's errors so far
   __shared__ __attribute__((aligned(16))) float wl[kRowsPerWave][NB + 4];   // the rows' block on its way into the quad layout
   const int tid = threadIdx.x;
-  {
-    // Catch-up, by the whole workgroup (16 lanes per row, 4 columns per lane): the errors of the
-    // group's earlier blocks reach this block's columns now,
-    //   W[rows, c0:c0+64] -= err[rows, 0:err_col] @ Hinv[g0:g0+err_col, c0:c0+64],
-    // one 64-deep sum per earlier block, subtracted in block order.
-    const int rw = tid >> 4, l = tid & 15;
-    const long long row = static_cast<long long>(blockIdx.x) * kRowsPerWave + rw;
-    const long long rrow = row < a.rows ? row : a.rows - 1;
-    const float4 w4 = *reinterpret_cast<const float4*>(a.w + rrow * a.d + a.c0 + 4 * l);
-    float w[4] = {w4.x, w4.y, w4.z, w4.w};
-    for (int pb = 0; pb < a.err_col; pb += NB) {
-      __syncthreads();
-      const float* hsrc = a.hinv + static_cast<long long>(a.c0 - a.err_col + pb) * a.d + a.c0;
+  const int rw = tid >> 4, l = tid & 15;               // catch-up layout: 16 lanes per row, 4 columns per lane
+  const long long row = static_cast<long long>(blockIdx.x) * kRowsPerWave + rw;
+  const long long rrow = row < a.rows ? row : a.rows - 1;
+  const int lane = tid & 63, c4 = lane & 3, rl = lane >> 2;   // chain layout (wave 0): 4 lanes per row
+  const int r = blockIdx.x * kRowsPerWave + rl;
+  const int rr = r < a.rows ? r : a.rows - 1;          // idle lanes shadow the last row and store its values again
+  const float* sc = static_cast<const float*>(a.scale);
+  for (int blk = 0; blk < a.nb; ++blk) {
+    const int c0 = a.c0 + blk * NB, err_col = blk * NB;
+    {
+      // Catch-up, by the whole workgroup: the errors of the group's earlier blocks reach this
+      // block's columns now,
+      //   W[rows, c0:c0+64] -= err[rows, 0:err_col] @ Hinv[g0:g0+err_col, c0:c0+64],
+      // one 64-deep sum per earlier block, subtracted in block order.
+      const float4 w4 = *reinterpret_cast<const float4*>(a.w + rrow * a.d + c0 + 4 * l);
+      float w[4] = {w4.x, w4.y, w4.z, w4.w};
+      for (int pb = 0; pb < err_col; pb += NB) {
+        __syncthreads();
+        const float* hsrc = a.hinv + static_cast<long long>(a.c0 + pb) * a.d + c0;
+#pragma unroll
+        for (int k = 0; k < NB * NB / 4 / 256; ++k) {
+          const int e4 = k * 256 + tid, hr = e4 / (NB / 4), hc = e4 % (NB / 4);
+          reinterpret_cast<float4*>(hbuf)[e4] = *reinterpret_cast<const float4*>(hsrc + static_cast<long long>(hr) * a.d + 4 * hc);
+        }
+        __syncthreads();
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int k = 0; k < NB; ++k) {
+          const float ek = es[rw][pb + k];
+          const float4 h4 = *reinterpret_cast<const float4*>(&hbuf[k * NB + 4 * l]);
+          sum[0] = sum[0] + ek * h4.x; sum[1] = sum[1] + ek * h4.y; sum[2] = sum[2] + ek * h4.z; sum[3] = sum[3] + ek * h4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = w[j] - sum[j];
+      }
+      __syncthreads();                 // everyone is done with hbuf (and, for blk > 0, wave 0 with wl)
+      *reinterpret_cast<float4*>(&wl[rw][4 * l]) = make_float4(w[0], w[1], w[2], w[3]);
+      const float* hblock = a.hinv + static_cast<long long>(c0) * a.d + c0;
+      float (*hpw)[4][16] = reinterpret_cast<float (*)[4][16]>(hbuf);
 #pragma unroll
       for (int k = 0; k < NB * NB / 4 / 256; ++k) {
-        const int e4 = k * 256 + tid, hr = e4 / (NB / 4), hc = e4 % (NB / 4);
-        reinterpret_cast<float4*>(hbuf)[e4] = *reinterpret_cast<const float4*>(hsrc + static_cast<long long>(hr) * a.d + 4 * hc);
+        const int e4 = k * 256 + tid, hr = e4 / (NB / 4), kk = e4 % (NB / 4);
+        const float4 v = *reinterpret_cast<const float4*>(hblock + static_cast<long long>(hr) * a.d + 4 * kk);
+        hpw[hr][0][kk] = v.x; hpw[hr][1][kk] = v.y; hpw[hr][2][kk] = v.z; hpw[hr][3][kk] = v.w;
       }
-      *reinterpret_cast<float4*>(&es[rw][4 * l]) = *reinterpret_cast<const float4*>(a.err + rrow * kErrLd + pb + 4 * l);
       __syncthreads();
-      float sum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-      for (int k = 0; k < NB; ++k) {
-        const float ek = es[rw][k];
-        const float4 h4 = *reinterpret_cast<const float4*>(&hbuf[k * NB + 4 * l]);
-        sum[0] = sum[0] + ek * h4.x; sum[1] = sum[1] + ek * h4.y; sum[2] = sum[2] + ek * h4.z; sum[3] = sum[3] + ek * h4.w;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = w[j] - sum[j];
     }
-    *reinterpret_cast<float4*>(&wl[rw][4 * l]) = make_float4(w[0], w[1], w[2], w[3]);
-    __syncthreads();
-    const float* hblock = a.hinv + static_cast<long long>(a.c0) * a.d + a.c0;
-    float (*hp)[4][16] = reinterpret_cast<float (*)[4][16]>(hbuf);
+    if (tid < kWave) {                 // the chain is one wave's
+      const float (*hp)[4][16] = reinterpret_cast<const float (*)[4][16]>(hbuf);
+      const long long si0 = a.scale_mode == 1 ? rr : (a.scale_mode == 2 ? static_cast<long long>(rr) * a.nblk + c0 / a.block_size : 0);
+      const long long si1 = a.scale_mode == 2 ? static_cast<long long>(rr) * a.nblk + (c0 + 32) / a.block_size : si0;
+      const float s_lo = sc[si0], s_hi = sc[si1];
+      unsigned* qrow = reinterpret_cast<unsigned*>(a.q + static_cast<long long>(rr) * a.d + c0);
+      float* erow = a.err + static_cast<long long>(rr) * kErrLd + err_col;
+      float w[16];
 #pragma unroll
-    for (int k = 0; k < NB * NB / 4 / 256; ++k) {
-      const int e4 = k * 256 + tid, hr = e4 / (NB / 4), kk = e4 % (NB / 4);
-      const float4 v = *reinterpret_cast<const float4*>(hblock + static_cast<long long>(hr) * a.d + 4 * kk);
-      hp[hr][0][kk] = v.x; hp[hr][1][kk] = v.y; hp[hr][2][kk] = v.z; hp[hr][3][kk] = v.w;
+      for (int k = 0; k < 16; ++k) w[k] = wl[rl][4 * k + c4];
+      float mye = 0.f;
+      unsigned myq = 0;
+      gptq_quad_step<0>(a, hp, c4, s_lo, s_hi, w, mye, myq, qrow, erow, &es[rl][err_col]);
     }
-    __syncthreads();
-    if (tid >= kWave) return;   // the chain is one wave's
   }
-  const float (*hp)[4][16] = reinterpret_cast<const float (*)[4][16]>(hbuf);
-  const int lane = tid, c4 = lane & 3, rl = lane >> 2;
-  const int r = blockIdx.x * kRowsPerWave + rl;
-  const int rr = r < a.rows ? r : a.rows - 1;         // idle lanes shadow the last row and store its values again
-  const float* sc = static_cast<const float*>(a.scale);
-  const long long si0 = a.scale_mode == 1 ? rr : (a.scale_mode == 2 ? static_cast<long long>(rr) * a.nblk + a.c0 / a.block_size : 0);
-  const long long si1 = a.scale_mode == 2 ? static_cast<long long>(rr) * a.nblk + (a.c0 + 32) / a.block_size : si0;
-  const float s_lo = sc[si0], s_hi = sc[si1];
-  unsigned* qrow = reinterpret_cast<unsigned*>(a.q + static_cast<long long>(rr) * a.d + a.c0);
-  float* erow = a.err + static_cast<long long>(rr) * kErrLd + a.err_col;
-  float w[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) w[k] = wl[rl][4 * k + c4];
-  float mye = 0.f;
-  unsigned myq = 0;
-  gptq_quad_step<0>(a, hp, c4, s_lo, s_hi, w, mye, myq, qrow, erow);
 }
 
 inline unsigned grid1d(long long n) {
@@ -1066,18 +1076,23 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
   // products summed inside one GEMM before the subtraction instead of four subtractions.
   for (int g0 = 0; g0 < a.d; g0 += kErrLd) {
     const int g1 = a.d - g0 < kErrLd ? a.d : g0 + kErrLd;
-    for (int c0 = g0; c0 < g1; c0 += NB) {
+    // symmetric recipes with float scales: one launch takes every workgroup's rows through all of
+    // the group's blocks (see gptq_rows_kernel)
+    const bool plain_group = zero_point == nullptr && !(scale_mode == 2 && block_size % 32 != 0) && !scale_is_f64 &&
+                             d % NB == 0 && !getenv("MI355Q_GPTQ_SPREAD");
+    if (plain_group) {
+      a.c0 = g0;
+      a.nb = (g1 - g0) / NB;
+      a.err_col = 0;
+      hipLaunchKernelGGL(gptq_rows_kernel, dim3(static_cast<unsigned>((rows + kRowsPerWave - 1) / kRowsPerWave)), dim3(256), 0, st, a);
+    }
+    for (int c0 = g0; c0 < g1 && !plain_group; c0 += NB) {
       a.c0 = c0;
       a.nb = g1 - c0 < NB ? g1 - c0 : NB;
       a.err_col = c0 - g0;
       const int rl = row_lanes_for(rows);
       const dim3 grid(static_cast<unsigned>((rows + (256 / rl) - 1) / (256 / rl)));
       const bool plain = a.nb == NB && zero_point == nullptr && !(scale_mode == 2 && block_size % 32 != 0);
-      if (plain && !scale_is_f64 && d % NB == 0 && !getenv("MI355Q_GPTQ_SPREAD")) {
-        // one lane per row: the column chain stays inside a lane (see gptq_rows_kernel)
-        hipLaunchKernelGGL(gptq_rows_kernel, dim3(static_cast<unsigned>((rows + kRowsPerWave - 1) / kRowsPerWave)), dim3(256), 0, st, a);
-        continue;
-      }
 #define MI355Q_BLOCK(ST, RL, PL) hipLaunchKernelGGL((gptq_block_kernel<ST, RL, PL>), grid, dim3(256), 0, st, a)
       if (scale_is_f64) {
         if (rl == 32) { if (plain) MI355Q_BLOCK(double, 32, true); else MI355Q_BLOCK(double, 32, false); }
