@@ -23,6 +23,7 @@ struct GemmArgs {
                        // 3: B(k,j) == 0 for k < j (lower-triangular B): k >= j0
   int batch;           // > 1: grid.z independent problems of this shape; operand b starts
   long long sa, sb, sc;  //      batch strides (elements) after problem b - 1 (no split-K then)
+  float* c32;          // not null (beta == 0, no split-K): alpha * (A.B) is stored here as float32, same strides, C untouched
 };
 
 // Number of K slices launch_gemm would use for this shape (1 = no split) and the

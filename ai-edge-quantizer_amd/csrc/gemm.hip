@@ -289,9 +289,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<typename TL::Elem> g
           if (partial != nullptr) {  // raw partial sums; alpha / beta applied by the reducer
             partial[(static_cast<long long>(blockIdx.z) * g.M + i) * g.N + j] = acc[a][b][r];
           } else {
-            T* c = g.C + i * g.c_i + j * g.c_j;
             const T p = g.alpha * acc[a][b][r];  // P is rounded first, as sgemm-then-update does
-            *c = (g.beta == T(0)) ? p : g.beta * (*c) + p;
+            if (g.c32 != nullptr) {
+              g.c32[i * g.c_i + j * g.c_j] = static_cast<float>(p);
+            } else {
+              T* c = g.C + i * g.c_i + j * g.c_j;
+              *c = (g.beta == T(0)) ? p : g.beta * (*c) + p;
+            }
           }
         }
       }
@@ -481,9 +485,13 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs<typename TL::Elem>
           if (partial != nullptr) {
             partial[(static_cast<long long>(blockIdx.z) * g.M + i) * g.N + j] = acc[a][b][r];
           } else {
-            T* c = g.C + i * g.c_i + j * g.c_j;
             const T p = g.alpha * acc[a][b][r];
-            *c = (g.beta == T(0)) ? p : g.beta * (*c) + p;
+            if (g.c32 != nullptr) {
+              g.c32[i * g.c_i + j * g.c_j] = static_cast<float>(p);
+            } else {
+              T* c = g.C + i * g.c_i + j * g.c_j;
+              *c = (g.beta == T(0)) ? p : g.beta * (*c) + p;
+            }
           }
         }
       }

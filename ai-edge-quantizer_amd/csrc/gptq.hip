@@ -389,14 +389,22 @@ __global__ __launch_bounds__(256) void diag_inverse_kernel(double* __restrict__ 
 }
 #undef MI355Q_STAMP
 
-// out32 = sym(lower(src)) cast to float32 (both triangles written).
-__global__ __launch_bounds__(256) void symmetrize_cast_kernel(const double* __restrict__ src, int d,
-                                                             float* __restrict__ dst) {
-  const long long n = static_cast<long long>(d) * d;
-  const long long stride = static_cast<long long>(gridDim.x) * 256;
-  for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
-    const long long i = e / d, j = e % d;
-    dst[e] = static_cast<float>(j <= i ? src[e] : src[j * d + i]);
+// h[i][j] = h[j][i] for j > i: the upper triangle of a float32 matrix from its lower one, 32 x 32
+// tiles through LDS (coalesced both ways); one workgroup per tile strictly above the diagonal
+// plus the diagonal tiles.
+__global__ __launch_bounds__(256) void mirror_lower_f32_kernel(float* __restrict__ h, int d) {
+  __shared__ float tile[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;          // destination tile (bi, bj), bj >= bi
+  if (bj < bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bj * 32 + r, j = bi * 32 + tx;       // source: the mirror tile in the lower triangle
+    tile[r][tx] = (i < d && j < d) ? h[static_cast<long long>(i) * d + j] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    if (i < d && j < d && j > i) h[static_cast<long long>(i) * d + j] = tile[tx][r];
   }
 }
 
@@ -911,7 +919,7 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   // A rank-64 update of the whole trailing matrix is memory-bound (it reads and writes
   // (d-k)^2/2 doubles for 64 flops each), so the 64-column steps only update the rest of their
   // own 512-column outer block; the matrix behind it gets one rank-512 update per outer block.
-  constexpr int OB = 8 * NB;
+  static const int OB = [] { const char* e = getenv("MI355Q_CHOL_OB"); const int v = e ? atoi(e) : 0; return v >= 64 && v % 64 == 0 ? v : 8 * NB; }();
   std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
   if (d >= 4096) side_lock.lock();
   SideStream* side = d >= 4096 ? side_stream() : nullptr;
@@ -1024,11 +1032,15 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   }
   MI355Q_CHECK_LAUNCH("gptq trtri launch");
   // ---- H^-1 = L^-T L^-1 : out(i,j) = sum_k Linv[k][i] * Linv[k][j], k >= max(i,j); lower half
+  // (stored as float32 straight from the accumulators; the upper triangle is mirrored afterwards)
   GemmArgs<double> gp{a, 1, d, a, d, 1, out, d, 1, d, d, d, 1.0, 0.0, 1, 2};
+  gp.c32 = hinv_out;
   if (int32_t s = launch_gemm<double>(gp, st)) return s;
-  hipLaunchKernelGGL(symmetrize_cast_kernel, dim3(grid1d(static_cast<long long>(d) * d)), dim3(256), 0, st,
-                     out, d, hinv_out);
-  MI355Q_CHECK_LAUNCH("gptq symmetrize launch");
+  {
+    const unsigned nt = static_cast<unsigned>((d + 31) / 32);
+    hipLaunchKernelGGL(mirror_lower_f32_kernel, dim3(nt, nt), dim3(256), 0, st, hinv_out, d);
+  }
+  MI355Q_CHECK_LAUNCH("gptq mirror launch");
   return MI355Q_OK;
 }
 

@@ -50,6 +50,9 @@ def main():
       "full_8192": dict(M=8192, N=8192, K=8192, a=(n, 1), b=(n, 1), beta=0.0, lower=0, flops=2 * 8192**3),
       "rank64_lower_16384": dict(M=n, N=n, K=64, a=(n, 1), b=(1, n), beta=1.0, lower=1, flops=n * n * 64),
       "rank512_lower_16384": dict(M=n, N=n, K=512, a=(n, 1), b=(1, n), beta=1.0, lower=1, flops=n * n * 512),
+      # the same rank-512 update with B read from a transposed copy of the panel (j contiguous)
+      "rank512_lower_16384_Bt": dict(M=n, N=n, K=512, a=(n, 1), b=(n, 1), beta=1.0, lower=1, flops=n * n * 512),
+      "rank512_lower_16384_AtBt": dict(M=n, N=n, K=512, a=(1, n), b=(n, 1), beta=1.0, lower=1, flops=n * n * 512),
       "AtA_lower_16384_k8192": dict(M=n, N=n, K=8192, a=(1, n), b=(n, 1), beta=0.0, lower=1, flops=n * n * 8192),
   }
   res = {name: [[] for _ in libs] for name in shapes}

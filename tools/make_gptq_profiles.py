@@ -49,7 +49,7 @@ def phases(path):
   rows = rows[first:]
   last_potf2 = max(i for i, r in enumerate(rows) if "potf2_" in r[0])
   put = max(i for i, r in enumerate(rows) if "diag_inverse" in r[0])
-  sym = max(i for i, r in enumerate(rows) if "symmetrize" in r[0])
+  sym = max(i for i, r in enumerate(rows) if "mirror_lower_f32" in r[0])
   gemms = [i for i, r in enumerate(rows) if "gemm" in r[0]]
   prod = max(i for i in gemms if i < sym)
   def span(a, b):
@@ -59,7 +59,7 @@ def phases(path):
   for label, a, b in (("cholesky (two-level blocked, potf2 + GEMMs)", 0, put),
                       ("  of which potf2 + trsm_panel (the serial chain)", None, None),
                       ("triangular inverse (pairwise merge GEMMs)", put, prod),
-                      ("L^-T L^-1 product", prod, prod + 1), ("symmetrize + cast", sym, sym + 1)):
+                      ("L^-T L^-1 product", prod, prod + 1), ("mirror of the float32 lower triangle", sym, sym + 1)):
     if a is None:
       t = sum(r[3] for r in rows[:last_potf2 + 1] if "potf2_" in r[0] or "trsm_panel" in r[0])
       print(f"{t / 1e3:12.1f} {'':>12}  {label}")
