@@ -385,7 +385,8 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs<typename TL::Elem>
   if (g.lower_only == 2) {
     // triangular grid: block r of nt (nt + 1) / 2, the longest tile rows (most K work under the
     // k_modes) first; no empty blocks above the diagonal
-    const int r = static_cast<int>(gridDim.x) - 1 - static_cast<int>(blockIdx.x);
+    // (k_mode 2: K starts at the tile row's diagonal, the first rows are the long ones)
+    const int r = g.k_mode == 2 ? static_cast<int>(blockIdx.x) : static_cast<int>(gridDim.x) - 1 - static_cast<int>(blockIdx.x);
     bi = static_cast<int>((__builtin_sqrt(8.0 * r + 1.0) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= r) ++bi;
     while (bi * (bi + 1) / 2 > r) --bi;
