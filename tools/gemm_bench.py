@@ -50,6 +50,11 @@ def main():
       "full_8192": dict(M=8192, N=8192, K=8192, a=(n, 1), b=(n, 1), beta=0.0, lower=0, flops=2 * 8192**3),
       "rank64_lower_16384": dict(M=n, N=n, K=64, a=(n, 1), b=(1, n), beta=1.0, lower=1, flops=n * n * 64),
       "rank512_lower_16384": dict(M=n, N=n, K=512, a=(n, 1), b=(1, n), beta=1.0, lower=1, flops=n * n * 512),
+      # the trailing update of one 64-column Cholesky step at d = 2048 (first step of an outer block)
+      "chol_step_1984x448_k64": dict(M=1984, N=448, K=64, a=(n, 1), b=(1, n), beta=1.0, lower=1, flops=2 * 1984 * 448 * 64),
+      # one pair of a low triangular-inverse level and the d = 2048 product
+      "merge_1024_kmode0": dict(M=1024, N=1024, K=1024, a=(n, 1), b=(n, 1), beta=0.0, lower=0, flops=2 * 1024**3),
+      "AtA_lower_2048": dict(M=2048, N=2048, K=2048, a=(1, n), b=(n, 1), beta=0.0, lower=1, flops=2048**3),
       # the same rank-512 update with B read from a transposed copy of the panel (j contiguous)
       "rank512_lower_16384_Bt": dict(M=n, N=n, K=512, a=(n, 1), b=(n, 1), beta=1.0, lower=1, flops=n * n * 512),
       "rank512_lower_16384_AtBt": dict(M=n, N=n, K=512, a=(1, n), b=(n, 1), beta=1.0, lower=1, flops=n * n * 512),
