@@ -328,6 +328,117 @@ __global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ a, 
   MI355Q_STAMP();
 }
 
+// The panel solve and the trailing update of one 64-column step in ONE launch (whole tiles only).
+// A step's three kernels each cost 7-8 us before they do anything (launch, first loads, last
+// stores), which is most of what a step costs at d = 2048. Here the workgroup that owns trailing
+// tile (i, j) solves the two row tiles it needs itself -- wave 0 rows i, wave 1 rows j, both
+// against L11^T in LDS, with the same code as trsm_panel_kernel -- while its C tile is already on
+// the way, then multiplies them out of LDS (FP64 MFMA, 16 per wave) and subtracts. Row tile i is
+// solved by every workgroup of tile row i (up to 7 times); the chip is idle at this point of the
+// chain, and only the workgroups of tile column 0 write their L21 tile back.
+// s[i][0:64] = a[(k + 64 + i)][k : k + 64], i < m: the panel below a diagonal block, compact.
+__global__ __launch_bounds__(256) void copy_panel_kernel(const double* __restrict__ a, int d, int k, int m,
+                                                        double* __restrict__ s) {
+  const long long n = static_cast<long long>(m) * NB;
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride)
+    s[e] = a[(k + NB + e / NB) * d + k + e % NB];
+}
+
+__device__ __forceinline__ void trsm_tile_in_lds(double* __restrict__ X, const Pair* Lt, int lane) {
+  double x[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) x[c] = X[lane * (NB + 1) + c];
+  Pair buf[3][8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { buf[0][u] = Lt[u]; buf[1][u] = Lt[8 + u]; }   // items (0, 0) and (0, 1)
+  trsm_item<0, 0, 0>(x, buf, Lt);
+#pragma unroll
+  for (int c = 0; c < NB; ++c) X[lane * (NB + 1) + c] = x[c];
+}
+
+//
+// Row tile i is read by many workgroups and rewritten (solved) by one, so the unsolved panel cannot
+// be read from where L21 goes: it comes from `s_cur` (m x 64, compact), which the PREVIOUS step's
+// tile-column-0 workgroups filled with the columns they had just updated (`s_next` here; the first
+// step of an outer block copies it from `a`: copy_panel_kernel).
+__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, int d, int k,
+                                                       const double* __restrict__ lt,
+                                                       const double* __restrict__ s_cur, double* __restrict__ s_next) {
+  const int ti = blockIdx.x, tj = blockIdx.y;        // trailing tile (ti, tj): rows / columns k + 64 + 64 t ..
+  if (tj > ti) return;
+  __shared__ Pair Lt[NB * NB / 2];                   // Lt[(j * NB + i) / 2] = (L11[i][j], L11[i + 1][j])
+  __shared__ double Xi[NB * (NB + 1)], Xj[NB * (NB + 1)];   // A21 row tiles i and j, [row][column of the panel]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* rows_i = a + static_cast<long long>(k + NB + ti * NB) * d + k;
+  {
+    const Pair* src = reinterpret_cast<const Pair*>(lt);
+#pragma unroll
+    for (int it = 0; it < NB * NB / 2 / 256; ++it) Lt[tid + 256 * it] = src[tid + 256 * it];
+    const double* src_i = s_cur + static_cast<long long>(ti) * NB * NB;
+    const double* src_j = s_cur + static_cast<long long>(tj) * NB * NB;
+#pragma unroll
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+      Xi[rr * (NB + 1) + c] = src_i[e];
+      Xj[rr * (NB + 1) + c] = src_j[e];
+    }
+  }
+  // this thread's 16 elements of the C tile, in the MFMA accumulator layout; needed only at the end
+  const int wy = wave >> 1, wx = wave & 1;           // the wave's 32 x 32 quarter of the tile
+  double* ctile = a + static_cast<long long>(k + NB + ti * NB) * d + (k + NB + tj * NB);
+  double cold[2][2][4];
+#pragma unroll
+  for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cold[ma][mb][r] = ctile[static_cast<long long>(wy * 32 + ma * 16 + (lane >> 4) + 4 * r) * d + wx * 32 + mb * 16 + (lane & 15)];
+  __syncthreads();
+  if (wave == 0 || (wave == 1 && tj != ti)) trsm_tile_in_lds(wave == 0 ? Xi : Xj, Lt, lane);
+  __syncthreads();
+  const double* XJ = tj == ti ? Xi : Xj;
+  __attribute__((ext_vector_type(4))) double acc[2][2];
+#pragma unroll
+  for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) acc[ma][mb] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k0 = 0; k0 < NB; k0 += 4) {
+    double af[2], bf[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      af[t2] = Xi[(wy * 32 + t2 * 16 + (lane & 15)) * (NB + 1) + k0 + (lane >> 4)];
+      bf[t2] = XJ[(wx * 32 + t2 * 16 + (lane & 15)) * (NB + 1) + k0 + (lane >> 4)];
+    }
+#pragma unroll
+    for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+        acc[ma][mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ma], bf[mb], acc[ma][mb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wy * 32 + ma * 16 + (lane >> 4) + 4 * r, col = wx * 32 + mb * 16 + (lane & 15);
+        const double cnew = cold[ma][mb][r] - acc[ma][mb][r];
+        if (tj != ti || col <= row) ctile[static_cast<long long>(row) * d + col] = cnew;
+        // tile column 0 is the next step's panel (its tile 0 the next diagonal block: read from `a`)
+        if (tj == 0 && ti >= 1 && s_next != nullptr) s_next[static_cast<long long>(ti - 1) * NB * NB + row * NB + col] = cnew;
+      }
+  if (tj == 0) {   // L21 tile i goes back in place (coalesced: a row of the tile is 512 contiguous bytes)
+#pragma unroll
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+      rows_i[static_cast<long long>(rr) * d + c] = Xi[rr * (NB + 1) + c];
+    }
+  }
+}
+
 // One level of the in-LDS inverse: every pair of adjacent inverted S-blocks becomes one
 // inverted 2S-block. Fixed trip counts (terms outside the triangles are masked, the LDS index
 // clamped) so the S loads of a dot product are all in flight at once.
@@ -883,9 +994,9 @@ extern "C" int32_t mi355q_shutdown(void) {
 }
 
 extern "C" size_t mi355q_gptq_hinv_workspace_bytes(int64_t d) {
-  // two d x d FP64 matrices + one transposed NB x NB diagonal block + scalars
+  // two d x d FP64 matrices + one transposed NB x NB diagonal block + two d x NB panels + scalars
   if (d <= 0) return 0;
-  return (static_cast<size_t>(d) * d * 2 + NB * NB + 8) * sizeof(double);
+  return (static_cast<size_t>(d) * d * 2 + NB * NB + static_cast<size_t>(d) * NB * 2 + 8) * sizeof(double);
 }
 
 extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, double damp_factor,
@@ -905,7 +1016,8 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   double* a = static_cast<double*>(workspace);           // L, then L^-1 (lower, zeros above)
   double* out = a + static_cast<size_t>(d) * d;          // lower(H^-1) in FP64
   double* lt = out + static_cast<size_t>(d) * d;         // NB x NB: the current diagonal block, transposed
-  double* scal = lt + NB * NB;
+  double* spanel = lt + NB * NB;                         // 2 x (d x NB): the unsolved panels of the fused steps
+  double* scal = spanel + static_cast<size_t>(d) * NB * 2;
   if (hipMemsetAsync(info_out, 0, sizeof(int32_t), st) != hipSuccess)
     return fail(MI355Q_HIP_ERROR, "hipMemsetAsync failed");
   hipLaunchKernelGGL(diag_sum_kernel, dim3(1), dim3(256), 0, st, hessian, d, scal);
@@ -930,14 +1042,27 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
     SideStream*& side; bool& busy; hipStream_t st;
     ~JoinSide() { if (busy && side) (void)hipStreamWaitEvent(st, side->update_done, 0); }
   } join_side{side, side_busy, st};
+  double* step_panel[2] = {spanel, spanel + static_cast<size_t>(d) * NB};   // see chol_step_kernel
+  int step_parity = 0;
   for (int k0 = 0; k0 < d; k0 += OB) {
     const int ob = d - k0 < OB ? d - k0 : OB;
+    bool step_panel_ready = false;   // an outer block's first step reads its panel from `a`
     for (int k = k0; k < k0 + ob; k += NB) {
       const int nb = k0 + ob - k < NB ? k0 + ob - k : NB;
       hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, info_out, lt MI355Q_PROF_ARG);
       const int m = d - k - nb;            // rows below the diagonal block
       const int w = k0 + ob - k - nb;      // columns left in this outer block
-      if (m > 0) {
+      // small d (no look-ahead, the chip idle around the chain): panel solve + trailing update in one launch
+      static const bool fused_step = getenv("MI355Q_NO_FUSED_STEP") == nullptr;
+      if (m > 0 && w > 0 && nb == NB && m % NB == 0 && w % NB == 0 && fused_step && side == nullptr) {
+        if (!step_panel_ready)
+          hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m) * NB)), dim3(256), 0, st, a, d, k, m,
+                             step_panel[step_parity]);
+        hipLaunchKernelGGL(chol_step_kernel, dim3(m / NB, w / NB), dim3(256), 0, st, a, d, k, lt, step_panel[step_parity],
+                           step_panel[step_parity ^ 1]);
+        step_parity ^= 1;
+        step_panel_ready = true;     // the next step's panel (if it is fused too) is in step_panel[step_parity]
+      } else if (m > 0) {
         hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + 63) / 64), dim3(64), 0, st, a, d, k, nb, m, lt MI355Q_PROF_ARG);
         if (w > 0) {
           const double* l21 = a + static_cast<long long>(k + nb) * d + k;
