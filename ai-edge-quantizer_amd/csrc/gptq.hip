@@ -134,34 +134,22 @@ __device__ __forceinline__ double lane_bcast64(double v, int src_lane) {
 // column's multiplier travel by v_readlane; the other multipliers go through LDS (one write,
 // wave-uniform reads) and are used a column later. The 1/sqrt(p_j) scaling that turns u into L
 // is done for all 64 columns at once at the end.
-__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int d, int k, int nb, int* info,
-                                                   double* __restrict__ lt
-#if defined(MI355Q_POTF2_PROF)
-                                                   , long long* prof
-#endif
-                                                   ) {
-  __shared__ double PU[2][NB][17];                                  // the last two panels, unscaled: [row][column]
-  __shared__ __attribute__((aligned(16))) double PM[2][16][NB];     // their multipliers: [column][row]
-  __shared__ __attribute__((aligned(16))) double piv[NB], ys[NB];
-  __shared__ int bad[4];
-  const int t = threadIdx.x, r = t & 63, cq = t >> 6;
-#if defined(MI355Q_POTF2_PROF)
-  int stamp = 0;
-#endif
-  MI355Q_STAMP();
-  double v[16];
-  const double* row = a + static_cast<long long>(k + (r < nb ? r : 0)) * d + k;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = cq * 16 + i;
-    const double g = row[c < nb ? c : 0];           // clamped, not predicated: no branch per load
-    v[i] = (r < nb && c < nb) ? (c <= r ? g : 0.0) : (c == r ? 1.0 : 0.0);
-  }
-  MI355Q_STAMP();
+struct Potf2Shared {
+  double PU[2][NB][17];                                  // the last two panels, unscaled: [row][column]
+  __attribute__((aligned(16))) double PM[2][16][NB];     // their multipliers: [column][row]
+  __attribute__((aligned(16))) double piv[NB], ys[NB];
+  int bad[4];
+};
+
+// The factorization proper, by 256 threads: v = this thread's 16 values of the (identity padded)
+// block on entry, the unscaled columns u on exit; sh.ys[c] = 1 / sqrt(p_c), so L[r][c] = v * ys[c];
+// returns the index of the first non-positive pivot, NB if there is none (to every thread).
+__device__ __forceinline__ int potf2_core(double (&v)[16], Potf2Shared& sh, int t) {
+  const int r = t & 63, cq = t >> 6;
 #pragma unroll
   for (int jq = 0; jq < 4; ++jq) {
-    double (*pu)[17] = PU[jq & 1];
-    double (*pm)[NB] = PM[jq & 1];
+    double (*pu)[17] = sh.PU[jq & 1];
+    double (*pm)[NB] = sh.PM[jq & 1];
     if (cq == jq) {  // wave-uniform
       int first_bad = NB;
       double pv = 1.0;
@@ -184,8 +172,8 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int 
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) pu[r][i] = v[i];
-      if ((r >> 4) == jq) piv[r] = pv;
-      if (r == 0) bad[jq] = first_bad;
+      if ((r >> 4) == jq) sh.piv[r] = pv;
+      if (r == 0) sh.bad[jq] = first_bad;
     }
     __syncthreads();
     if (cq > jq) {
@@ -200,31 +188,54 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int 
       }
     }
   }
-  MI355Q_STAMP();
   // L = u / sqrt(p): 1/sqrt(p) by hardware estimate + two Newton steps, one pivot per thread
   if (t < NB) {
-    const double p = piv[t];
+    const double p = sh.piv[t];
     double y = __builtin_amdgcn_rsq(p);
     y = y * (1.5 - 0.5 * p * y * y);
     y = y * (1.5 - 0.5 * p * y * y);
-    ys[t] = y;
+    sh.ys[t] = y;
   }
   __syncthreads();
+  int j = NB;
+#pragma unroll
+  for (int q = 3; q >= 0; --q) j = sh.bad[q] < NB ? sh.bad[q] : j;
+  return j;
+}
+
+__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int d, int k, int nb, int* info,
+                                                   double* __restrict__ lt
+#if defined(MI355Q_POTF2_PROF)
+                                                   , long long* prof
+#endif
+                                                   ) {
+  __shared__ Potf2Shared sh;
+  const int t = threadIdx.x, r = t & 63, cq = t >> 6;
+#if defined(MI355Q_POTF2_PROF)
+  int stamp = 0;
+#endif
+  MI355Q_STAMP();
+  double v[16];
+  const double* row = a + static_cast<long long>(k + (r < nb ? r : 0)) * d + k;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = cq * 16 + i;
+    const double g = row[c < nb ? c : 0];           // clamped, not predicated: no branch per load
+    v[i] = (r < nb && c < nb) ? (c <= r ? g : 0.0) : (c == r ? 1.0 : 0.0);
+  }
+  MI355Q_STAMP();
+  const int first_bad = potf2_core(v, sh, t);
+  MI355Q_STAMP();
   double* out = a + static_cast<long long>(k + (r < nb ? r : 0)) * d + k;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = cq * 16 + i;
-    const double y = ys[c];
+    const double y = sh.ys[c];
     const double l = v[i] * y;                  // on the diagonal u = p: sqrt(p)
     if (r < nb && c <= r) out[c] = l;
     lt[c * NB + r] = c == r ? y : l;            // 1 / L_jj = 1 / sqrt(p_j)
   }
-  if (t == 0) {
-    int j = NB;
-#pragma unroll
-    for (int q = 3; q >= 0; --q) j = bad[q] < NB ? bad[q] : j;
-    if (j < nb) atomicCAS(info, 0, k + j + 1);
-  }
+  if (t == 0 && first_bad < nb) atomicCAS(info, 0, k + first_bad + 1);
   MI355Q_STAMP();
 }
 
@@ -328,21 +339,23 @@ __global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ a, 
   MI355Q_STAMP();
 }
 
-// The panel solve and the trailing update of one 64-column step in ONE launch (whole tiles only).
-// A step's three kernels each cost 7-8 us before they do anything (launch, first loads, last
-// stores), which is most of what a step costs at d = 2048. Here the workgroup that owns trailing
-// tile (i, j) solves the two row tiles it needs itself -- wave 0 rows i, wave 1 rows j, both
-// against L11^T in LDS, with the same code as trsm_panel_kernel -- while its C tile is already on
-// the way, then multiplies them out of LDS (FP64 MFMA, 16 per wave) and subtracts. Row tile i is
-// solved by every workgroup of tile row i (up to 7 times); the chip is idle at this point of the
-// chain, and only the workgroups of tile column 0 write their L21 tile back.
-// s[i][0:64] = a[(k + 64 + i)][k : k + 64], i < m: the panel below a diagonal block, compact.
-__global__ __launch_bounds__(256) void copy_panel_kernel(const double* __restrict__ a, int d, int k, int m,
+// A whole 64-column step -- diagonal block, panel solve, trailing update -- in ONE launch (whole
+// tiles only; small d). A step's three kernels each cost 7-8 us before they do anything (launch,
+// first loads, last stores), which is most of what a step costs at d = 2048. Here the workgroup
+// that owns trailing tile (i, j) factors the diagonal block itself (all four waves, potf2_core),
+// solves the two row tiles it needs itself -- wave 0 rows i, wave 1 rows j, against L11^T in LDS,
+// with the same code as trsm_panel_kernel -- while its C tile is already on the way, then
+// multiplies them out of LDS (FP64 MFMA, 16 per wave) and subtracts. The diagonal block is
+// factored by every workgroup and row tile i solved by every workgroup of tile row i (up to 7
+// times): the chip is idle at this point of the chain. Only workgroup (0, 0) writes L11 back, only
+// the workgroups of tile column 0 their L21 tile.
+// s[i][0:64] = a[k + i][k : k + 64], i < rows: a diagonal block and the panel below it, compact.
+__global__ __launch_bounds__(256) void copy_panel_kernel(const double* __restrict__ a, int d, int k, int rows,
                                                         double* __restrict__ s) {
-  const long long n = static_cast<long long>(m) * NB;
+  const long long n = static_cast<long long>(rows) * NB;
   const long long stride = static_cast<long long>(gridDim.x) * 256;
   for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride)
-    s[e] = a[(k + NB + e / NB) * d + k + e % NB];
+    s[e] = a[(k + e / NB) * d + k + e % NB];
 }
 
 __device__ __forceinline__ void trsm_tile_in_lds(double* __restrict__ X, const Pair* Lt, int lane) {
@@ -358,36 +371,33 @@ __device__ __forceinline__ void trsm_tile_in_lds(double* __restrict__ X, const P
 }
 
 //
-// Row tile i is read by many workgroups and rewritten (solved) by one, so the unsolved panel cannot
-// be read from where L21 goes: it comes from `s_cur` (m x 64, compact), which the PREVIOUS step's
-// tile-column-0 workgroups filled with the columns they had just updated (`s_next` here; the first
-// step of an outer block copies it from `a`: copy_panel_kernel).
-__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, int d, int k,
-                                                       const double* __restrict__ lt,
+// What a step reads is rewritten (factored, solved) by one workgroup while others still read it,
+// so it cannot be read from where L goes: the unsolved block column comes from `s_cur`
+// ((64 + m) x 64, compact; tile 0 = the diagonal block), which the PREVIOUS step's tile-column-0
+// workgroups filled with the columns they had just updated (`s_next` here; the first step of an
+// outer block copies it from `a`: copy_panel_kernel).
+__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, int d, int k, int* info,
                                                        const double* __restrict__ s_cur, double* __restrict__ s_next) {
   const int ti = blockIdx.x, tj = blockIdx.y;        // trailing tile (ti, tj): rows / columns k + 64 + 64 t ..
   if (tj > ti) return;
-  __shared__ Pair Lt[NB * NB / 2];                   // Lt[(j * NB + i) / 2] = (L11[i][j], L11[i + 1][j])
+  __shared__ Potf2Shared sh;
+  __shared__ Pair Lt[NB * NB / 2];                   // Lt[(j * NB + i) / 2] = (L11[i][j], L11[i + 1][j]), 1 / L_jj on the diagonal
   __shared__ double Xi[NB * (NB + 1)], Xj[NB * (NB + 1)];   // A21 row tiles i and j, [row][column of the panel]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* rows_i = a + static_cast<long long>(k + NB + ti * NB) * d + k;
+  // everything this workgroup reads is requested up front: the two row tiles, its C tile, the diagonal block
+  double gi[NB * NB / 256], gj[NB * NB / 256];
   {
-    const Pair* src = reinterpret_cast<const Pair*>(lt);
-#pragma unroll
-    for (int it = 0; it < NB * NB / 2 / 256; ++it) Lt[tid + 256 * it] = src[tid + 256 * it];
-    const double* src_i = s_cur + static_cast<long long>(ti) * NB * NB;
-    const double* src_j = s_cur + static_cast<long long>(tj) * NB * NB;
+    const double* src_i = s_cur + static_cast<long long>(ti + 1) * NB * NB;
+    const double* src_j = s_cur + static_cast<long long>(tj + 1) * NB * NB;
 #pragma unroll
     for (int it = 0; it < NB * NB / 256; ++it) {
-      const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
-      Xi[rr * (NB + 1) + c] = src_i[e];
-      Xj[rr * (NB + 1) + c] = src_j[e];
+      gi[it] = src_i[tid + 256 * it];
+      gj[it] = src_j[tid + 256 * it];
     }
   }
-  // this thread's 16 elements of the C tile, in the MFMA accumulator layout; needed only at the end
-  const int wy = wave >> 1, wx = wave & 1;           // the wave's 32 x 32 quarter of the tile
+  const int wy = wave >> 1, wx = wave & 1;           // the wave's 32 x 32 quarter of the C tile
   double* ctile = a + static_cast<long long>(k + NB + ti * NB) * d + (k + NB + tj * NB);
-  double cold[2][2][4];
+  double cold[2][2][4];                              // this thread's 16 elements of it, MFMA accumulator layout
 #pragma unroll
   for (int ma = 0; ma < 2; ++ma)
 #pragma unroll
@@ -395,6 +405,35 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, 
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         cold[ma][mb][r] = ctile[static_cast<long long>(wy * 32 + ma * 16 + (lane >> 4) + 4 * r) * d + wx * 32 + mb * 16 + (lane & 15)];
+  {
+    // the diagonal block: lane = row, wave = 16-column panel
+    const int r = lane, cq = wave;
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = cq * 16 + i;
+      const double g = s_cur[r * NB + c];
+      v[i] = c <= r ? g : 0.0;
+    }
+    const int first_bad = potf2_core(v, sh, tid);
+    double* ltd = reinterpret_cast<double*>(Lt);
+    double* out = a + static_cast<long long>(k + r) * d + k;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = cq * 16 + i;
+      const double y = sh.ys[c];
+      const double l = v[i] * y;                  // on the diagonal u = p: sqrt(p)
+      ltd[c * NB + r] = c == r ? y : l;
+      if (ti == 0 && tj == 0 && c <= r) out[c] = l;
+    }
+    if (ti == 0 && tj == 0 && tid == 0 && first_bad < NB) atomicCAS(info, 0, k + first_bad + 1);
+  }
+#pragma unroll
+  for (int it = 0; it < NB * NB / 256; ++it) {
+    const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+    Xi[rr * (NB + 1) + c] = gi[it];
+    Xj[rr * (NB + 1) + c] = gj[it];
+  }
   __syncthreads();
   if (wave == 0 || (wave == 1 && tj != ti)) trsm_tile_in_lds(wave == 0 ? Xi : Xj, Lt, lane);
   __syncthreads();
@@ -427,10 +466,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, 
         const int row = wy * 32 + ma * 16 + (lane >> 4) + 4 * r, col = wx * 32 + mb * 16 + (lane & 15);
         const double cnew = cold[ma][mb][r] - acc[ma][mb][r];
         if (tj != ti || col <= row) ctile[static_cast<long long>(row) * d + col] = cnew;
-        // tile column 0 is the next step's panel (its tile 0 the next diagonal block: read from `a`)
-        if (tj == 0 && ti >= 1 && s_next != nullptr) s_next[static_cast<long long>(ti - 1) * NB * NB + row * NB + col] = cnew;
+        // tile column 0 is the next step's block column (its tile 0 the next diagonal block)
+        if (tj == 0 && s_next != nullptr) s_next[static_cast<long long>(ti) * NB * NB + row * NB + col] = cnew;
       }
   if (tj == 0) {   // L21 tile i goes back in place (coalesced: a row of the tile is 512 contiguous bytes)
+    double* rows_i = a + static_cast<long long>(k + NB + ti * NB) * d + k;
 #pragma unroll
     for (int it = 0; it < NB * NB / 256; ++it) {
       const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
@@ -1049,20 +1089,22 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
     bool step_panel_ready = false;   // an outer block's first step reads its panel from `a`
     for (int k = k0; k < k0 + ob; k += NB) {
       const int nb = k0 + ob - k < NB ? k0 + ob - k : NB;
-      hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, info_out, lt MI355Q_PROF_ARG);
       const int m = d - k - nb;            // rows below the diagonal block
       const int w = k0 + ob - k - nb;      // columns left in this outer block
-      // small d (no look-ahead, the chip idle around the chain): panel solve + trailing update in one launch
+      // small d (no look-ahead, the chip idle around the chain): the whole step in one launch
       static const bool fused_step = getenv("MI355Q_NO_FUSED_STEP") == nullptr;
       if (m > 0 && w > 0 && nb == NB && m % NB == 0 && w % NB == 0 && fused_step && side == nullptr) {
         if (!step_panel_ready)
-          hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m) * NB)), dim3(256), 0, st, a, d, k, m,
-                             step_panel[step_parity]);
-        hipLaunchKernelGGL(chol_step_kernel, dim3(m / NB, w / NB), dim3(256), 0, st, a, d, k, lt, step_panel[step_parity],
-                           step_panel[step_parity ^ 1]);
+          hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m + NB) * NB)), dim3(256), 0, st, a, d, k,
+                             m + NB, step_panel[step_parity]);
+        hipLaunchKernelGGL(chol_step_kernel, dim3(m / NB, w / NB), dim3(256), 0, st, a, d, k, info_out,
+                           step_panel[step_parity], step_panel[step_parity ^ 1]);
         step_parity ^= 1;
-        step_panel_ready = true;     // the next step's panel (if it is fused too) is in step_panel[step_parity]
-      } else if (m > 0) {
+        step_panel_ready = true;     // the next step's block column (if it is fused too) is in step_panel[step_parity]
+        continue;
+      }
+      hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, info_out, lt MI355Q_PROF_ARG);
+      if (m > 0) {
         hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + 63) / 64), dim3(64), 0, st, a, d, k, nb, m, lt MI355Q_PROF_ARG);
         if (w > 0) {
           const double* l21 = a + static_cast<long long>(k + nb) * d + k;
