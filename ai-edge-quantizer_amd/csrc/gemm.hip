@@ -52,9 +52,33 @@ struct Tile<double> {
   static constexpr int KF = 4;
   static constexpr int TM = 2;
   static constexpr int BM = 64;   // 2 waves x 2 tiles x 16
-  static constexpr int BK = 16;
+#ifndef MI355Q_F64_BK        // tuning hooks (tools/gemm_bench.py)
+#define MI355Q_F64_BK 16
+#endif
+#ifndef MI355Q_F64_DBUF
+#define MI355Q_F64_DBUF 1
+#endif
+  static constexpr int BK = MI355Q_F64_BK;
   static constexpr int VEC = 2;
-  static constexpr bool DBUF = true;
+  static constexpr bool DBUF = MI355Q_F64_DBUF != 0;
+  using Elem = double;
+  using Acc = __attribute__((ext_vector_type(4))) double;
+  using Vec = double2;
+};
+// The merge products of a small triangular inverse (d = 2048: two batched launches per level, at
+// most one 64 x 64 tile per CU) are chains of K / BK steps that each wait ~1.2 us for their
+// operands -- the 16 MFMAs of a BK = 16 step take 0.43 us -- so for those the step is twice as
+// deep (a K = 1024 product 99 -> 71 us). Not for the product L^-T L^-1, whose 528 tiles share CUs
+// and lose more occupancy than they gain (0.41 -> 0.44 ms); BK = 64 and a four-stage register
+// ring measured the same or worse on both.
+struct TileF64K32 {
+  static constexpr int MF = 16;
+  static constexpr int KF = 4;
+  static constexpr int TM = 2;
+  static constexpr int BM = 64;
+  static constexpr int BK = 32;
+  static constexpr int VEC = 2;
+  static constexpr bool DBUF = false;
   using Elem = double;
   using Acc = __attribute__((ext_vector_type(4))) double;
   using Vec = double2;
@@ -663,6 +687,12 @@ int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_
         (!g.lower_only || tiles128 >= MI355Q_BIG_MIN_TRI_TILES))
       return launch_with<TileF64Big>(g, st, nullptr, 0, a_mode, b_mode);
 #endif
+  }
+  if constexpr (sizeof(T) == 8) {
+    const long long tiles64 = static_cast<long long>((g.M + 63) / 64) * ((g.N + 63) / 64) * (g.batch > 1 ? g.batch : 1);
+    if ((g.k_mode == 1 || g.k_mode == 3) && tiles64 <= 512 && g.M % 64 == 0 && g.N % 64 == 0 && g.K % 32 == 0 &&
+        g.K >= 128 && a_mode != kGeneric && b_mode != kGeneric)
+      return launch_with<TileF64K32>(g, st, nullptr, 0, a_mode, b_mode);
   }
   return launch_with<Tile<T>>(g, st, splitk_ws, splitk_ws_bytes, a_mode, b_mode);
 }
