@@ -134,57 +134,65 @@ __device__ __forceinline__ double lane_bcast64(double v, int src_lane) {
 // column's multiplier travel by v_readlane; the other multipliers go through LDS (one write,
 // wave-uniform reads) and are used a column later. The 1/sqrt(p_j) scaling that turns u into L
 // is done for all 64 columns at once at the end.
+#ifndef MI355Q_POTF2_PW     // columns per wave (tuning hook: 16 -> 4 waves, 8 -> 8 waves)
+#define MI355Q_POTF2_PW 16
+#endif
+constexpr int kPW = MI355Q_POTF2_PW, kPotf2Waves = NB / kPW, kPotf2Threads = 64 * kPotf2Waves;
+
 struct Potf2Shared {
-  double PU[2][NB][17];                                  // the last two panels, unscaled: [row][column]
-  __attribute__((aligned(16))) double PM[2][16][NB];     // their multipliers: [column][row]
+  double PU[2][NB][kPW + 1];                              // the last two panels, unscaled: [row][column]
+  __attribute__((aligned(16))) double PM[2][kPW][NB];     // their multipliers: [column][row]
   __attribute__((aligned(16))) double piv[NB], ys[NB];
-  int bad[4];
+  int bad[kPotf2Waves];
 };
 
-// The factorization proper, by 256 threads: v = this thread's 16 values of the (identity padded)
-// block on entry, the unscaled columns u on exit; sh.ys[c] = 1 / sqrt(p_c), so L[r][c] = v * ys[c];
-// returns the index of the first non-positive pivot, NB if there is none (to every thread).
-__device__ __forceinline__ int potf2_core(double (&v)[16], Potf2Shared& sh, int t) {
+// The factorization proper, by kPotf2Threads threads: v = this thread's kPW values of the
+// (identity padded) block on entry, the unscaled columns u on exit; sh.ys[c] = 1 / sqrt(p_c), so
+// L[r][c] = v * ys[c]; returns the index of the first non-positive pivot, NB if there is none (to
+// every thread).
+__device__ __forceinline__ int potf2_core(double (&v)[kPW], Potf2Shared& sh, int t) {
   const int r = t & 63, cq = t >> 6;
 #pragma unroll
-  for (int jq = 0; jq < 4; ++jq) {
-    double (*pu)[17] = sh.PU[jq & 1];
+  for (int jq = 0; jq < kPotf2Waves; ++jq) {
+    double (*pu)[kPW + 1] = sh.PU[jq & 1];
     double (*pm)[NB] = sh.PM[jq & 1];
     if (cq == jq) {  // wave-uniform
-      int first_bad = NB;
-      double pv = 1.0;
+      // (every instruction of this loop costs the chain ~8 cycles x 64 columns: the pivot test and
+      // the pivots themselves are taken from the finished panel below, not tracked per column)
 #pragma unroll
-      for (int ji = 0; ji < 16; ++ji) {
-        const int j = jq * 16 + ji;
+      for (int ji = 0; ji < kPW; ++ji) {
+        const int j = jq * kPW + ji;
         const double u = v[ji];
         const double p = lane_bcast64(u, j);
-        first_bad = (!(p > 0.0) && first_bad == NB) ? j : first_bad;
-        double rp = __builtin_amdgcn_rcp(p);
-        rp = __builtin_fma(rp, __builtin_fma(-p, rp, 1.0), rp);
+        double rp = __builtin_amdgcn_rcp(p);                      // ~2^-40 relative (measured): one Newton step
         rp = __builtin_fma(rp, __builtin_fma(-p, rp, 1.0), rp);
         const double m = u * rp;
-        if (ji + 1 < 16) v[ji + 1] = __builtin_fma(-u, lane_bcast64(m, j + 1), v[ji + 1]);
+        if (ji + 1 < kPW) v[ji + 1] = __builtin_fma(-u, lane_bcast64(m, j + 1), v[ji + 1]);
         pm[ji][r] = m;
-        pv = r == j ? u : pv;              // (a select, not a branch: the lane of row j keeps p_j)
         __builtin_amdgcn_wave_barrier();   // same wave: the LDS unit keeps the order, the compiler must too
 #pragma unroll
-        for (int i = ji + 2; i < 16; ++i) v[i] = __builtin_fma(-u, pm[ji][jq * 16 + i], v[i]);
+        for (int i = ji + 2; i < kPW; ++i) v[i] = __builtin_fma(-u, pm[ji][jq * kPW + i], v[i]);
       }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pu[r][i] = v[i];
-      if ((r >> 4) == jq) sh.piv[r] = pv;
-      if (r == 0) sh.bad[jq] = first_bad;
+      for (int i = 0; i < kPW; ++i) pu[r][i] = v[i];
+      __builtin_amdgcn_wave_barrier();
+      // the panel's pivots sit on its diagonal: u_j of row j is p_j
+      const bool mine = r / kPW == jq;
+      const double pv = pu[r][r % kPW];
+      if (mine) sh.piv[r] = pv;
+      const unsigned long long nonpos = __ballot(mine && !(pv > 0.0));
+      if (r == 0) sh.bad[jq] = nonpos ? __builtin_ctzll(nonpos) : NB;
     }
     __syncthreads();
     if (cq > jq) {
-      double mine[16];
+      double mine[kPW];
 #pragma unroll
-      for (int jj = 0; jj < 16; ++jj) mine[jj] = pu[r][jj];
+      for (int jj = 0; jj < kPW; ++jj) mine[jj] = pu[r][jj];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int c = cq * 16 + i;
+      for (int i = 0; i < kPW; ++i) {
+        const int c = cq * kPW + i;
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) v[i] = __builtin_fma(-mine[jj], pm[jj][c], v[i]);
+        for (int jj = 0; jj < kPW; ++jj) v[i] = __builtin_fma(-mine[jj], pm[jj][c], v[i]);
       }
     }
   }
@@ -193,17 +201,17 @@ __device__ __forceinline__ int potf2_core(double (&v)[16], Potf2Shared& sh, int 
     const double p = sh.piv[t];
     double y = __builtin_amdgcn_rsq(p);
     y = y * (1.5 - 0.5 * p * y * y);
-    y = y * (1.5 - 0.5 * p * y * y);
+    y = y * (1.5 - 0.5 * p * y * y);   // (off the chain: kept at two steps)
     sh.ys[t] = y;
   }
   __syncthreads();
   int j = NB;
 #pragma unroll
-  for (int q = 3; q >= 0; --q) j = sh.bad[q] < NB ? sh.bad[q] : j;
+  for (int q = kPotf2Waves - 1; q >= 0; --q) j = sh.bad[q] < NB ? sh.bad[q] : j;
   return j;
 }
 
-__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int d, int k, int nb, int* info,
+__global__ __launch_bounds__(kPotf2Threads) void potf2_kernel(double* __restrict__ a, int d, int k, int nb, int* info,
                                                    double* __restrict__ lt
 #if defined(MI355Q_POTF2_PROF)
                                                    , long long* prof
@@ -215,11 +223,11 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int 
   int stamp = 0;
 #endif
   MI355Q_STAMP();
-  double v[16];
+  double v[kPW];
   const double* row = a + static_cast<long long>(k + (r < nb ? r : 0)) * d + k;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = cq * 16 + i;
+  for (int i = 0; i < kPW; ++i) {
+    const int c = cq * kPW + i;
     const double g = row[c < nb ? c : 0];           // clamped, not predicated: no branch per load
     v[i] = (r < nb && c < nb) ? (c <= r ? g : 0.0) : (c == r ? 1.0 : 0.0);
   }
@@ -228,8 +236,8 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ a, int 
   MI355Q_STAMP();
   double* out = a + static_cast<long long>(k + (r < nb ? r : 0)) * d + k;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = cq * 16 + i;
+  for (int i = 0; i < kPW; ++i) {
+    const int c = cq * kPW + i;
     const double y = sh.ys[c];
     const double l = v[i] * y;                  // on the diagonal u = p: sqrt(p)
     if (r < nb && c <= r) out[c] = l;
@@ -376,6 +384,7 @@ __device__ __forceinline__ void trsm_tile_in_lds(double* __restrict__ X, const P
 // ((64 + m) x 64, compact; tile 0 = the diagonal block), which the PREVIOUS step's tile-column-0
 // workgroups filled with the columns they had just updated (`s_next` here; the first step of an
 // outer block copies it from `a`: copy_panel_kernel).
+#if MI355Q_POTF2_PW == 16
 __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, int d, int k, int* info,
                                                        const double* __restrict__ s_cur, double* __restrict__ s_next) {
   const int ti = blockIdx.x, tj = blockIdx.y;        // trailing tile (ti, tj): rows / columns k + 64 + 64 t ..
@@ -478,6 +487,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, 
     }
   }
 }
+
+#endif
 
 // One level of the in-LDS inverse: every pair of adjacent inverted S-blocks becomes one
 // inverted 2S-block. Fixed trip counts (terms outside the triangles are masked, the LDS index
@@ -1093,6 +1104,7 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
       const int w = k0 + ob - k - nb;      // columns left in this outer block
       // small d (no look-ahead, the chip idle around the chain): the whole step in one launch
       static const bool fused_step = getenv("MI355Q_NO_FUSED_STEP") == nullptr;
+#if MI355Q_POTF2_PW == 16
       if (m > 0 && w > 0 && nb == NB && m % NB == 0 && w % NB == 0 && fused_step && side == nullptr) {
         if (!step_panel_ready)
           hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m + NB) * NB)), dim3(256), 0, st, a, d, k,
@@ -1103,7 +1115,8 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
         step_panel_ready = true;     // the next step's block column (if it is fused too) is in step_panel[step_parity]
         continue;
       }
-      hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, st, a, d, k, nb, info_out, lt MI355Q_PROF_ARG);
+#endif
+      hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(kPotf2Threads), 0, st, a, d, k, nb, info_out, lt MI355Q_PROF_ARG);
       if (m > 0) {
         hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + 63) / 64), dim3(64), 0, st, a, d, k, nb, m, lt MI355Q_PROF_ARG);
         if (w > 0) {

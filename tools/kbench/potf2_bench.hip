@@ -28,7 +28,7 @@ int main() {
   for (int it = 0; it < 200; ++it) {
     hipMemcpy(a, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(mi355q::potf2_kernel, dim3(1), dim3(256), 0, 0, a, d, 0, nb, info, lt, prof);
+    hipLaunchKernelGGL(mi355q::potf2_kernel, dim3(1), dim3(mi355q::kPotf2Threads), 0, 0, a, d, 0, nb, info, lt, prof);
     hipEventRecord(e1);
     hipLaunchKernelGGL(mi355q::trsm_panel_kernel, dim3((m + 63) / 64), dim3(64), 0, 0, a, d, 0, nb, m, lt, prof);
     hipEventRecord(e2);
