@@ -135,7 +135,7 @@ __device__ __forceinline__ double lane_bcast64(double v, int src_lane) {
 // wave-uniform reads) and are used a column later. The 1/sqrt(p_j) scaling that turns u into L
 // is done for all 64 columns at once at the end.
 #ifndef MI355Q_POTF2_PW     // columns per wave (tuning hook: 16 -> 4 waves, 8 -> 8 waves)
-#define MI355Q_POTF2_PW 16
+#define MI355Q_POTF2_PW 8
 #endif
 constexpr int kPW = MI355Q_POTF2_PW, kPotf2Waves = NB / kPW, kPotf2Threads = 64 * kPotf2Waves;
 
@@ -384,9 +384,10 @@ __device__ __forceinline__ void trsm_tile_in_lds(double* __restrict__ X, const P
 // ((64 + m) x 64, compact; tile 0 = the diagonal block), which the PREVIOUS step's tile-column-0
 // workgroups filled with the columns they had just updated (`s_next` here; the first step of an
 // outer block copies it from `a`: copy_panel_kernel).
-#if MI355Q_POTF2_PW == 16
-__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, int d, int k, int* info,
-                                                       const double* __restrict__ s_cur, double* __restrict__ s_next) {
+__global__ __launch_bounds__(kPotf2Threads) void chol_step_kernel(double* __restrict__ a, int d, int k, int* info,
+                                                                 const double* __restrict__ s_cur, double* __restrict__ s_next) {
+  constexpr int T = kPotf2Threads, W = kPotf2Waves;
+  constexpr int SC = NB / (W / 2), MB = SC / 16;     // a wave's part of the C tile: 32 rows x SC columns, 2 x MB MFMA tiles
   const int ti = blockIdx.x, tj = blockIdx.y;        // trailing tile (ti, tj): rows / columns k + 64 + 64 t ..
   if (tj > ti) return;
   __shared__ Potf2Shared sh;
@@ -394,33 +395,33 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, 
   __shared__ double Xi[NB * (NB + 1)], Xj[NB * (NB + 1)];   // A21 row tiles i and j, [row][column of the panel]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // everything this workgroup reads is requested up front: the two row tiles, its C tile, the diagonal block
-  double gi[NB * NB / 256], gj[NB * NB / 256];
+  double gi[NB * NB / T], gj[NB * NB / T];
   {
     const double* src_i = s_cur + static_cast<long long>(ti + 1) * NB * NB;
     const double* src_j = s_cur + static_cast<long long>(tj + 1) * NB * NB;
 #pragma unroll
-    for (int it = 0; it < NB * NB / 256; ++it) {
-      gi[it] = src_i[tid + 256 * it];
-      gj[it] = src_j[tid + 256 * it];
+    for (int it = 0; it < NB * NB / T; ++it) {
+      gi[it] = src_i[tid + T * it];
+      gj[it] = src_j[tid + T * it];
     }
   }
-  const int wy = wave >> 1, wx = wave & 1;           // the wave's 32 x 32 quarter of the C tile
+  const int wy = wave / (W / 2), wx = wave % (W / 2);
   double* ctile = a + static_cast<long long>(k + NB + ti * NB) * d + (k + NB + tj * NB);
-  double cold[2][2][4];                              // this thread's 16 elements of it, MFMA accumulator layout
+  double cold[2][MB][4];                             // this thread's elements of it, MFMA accumulator layout
 #pragma unroll
   for (int ma = 0; ma < 2; ++ma)
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        cold[ma][mb][r] = ctile[static_cast<long long>(wy * 32 + ma * 16 + (lane >> 4) + 4 * r) * d + wx * 32 + mb * 16 + (lane & 15)];
+        cold[ma][mb][r] = ctile[static_cast<long long>(wy * 32 + ma * 16 + (lane >> 4) + 4 * r) * d + wx * SC + mb * 16 + (lane & 15)];
   {
-    // the diagonal block: lane = row, wave = 16-column panel
+    // the diagonal block: lane = row, wave = kPW-column panel
     const int r = lane, cq = wave;
-    double v[16];
+    double v[kPW];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = cq * 16 + i;
+    for (int i = 0; i < kPW; ++i) {
+      const int c = cq * kPW + i;
       const double g = s_cur[r * NB + c];
       v[i] = c <= r ? g : 0.0;
     }
@@ -428,8 +429,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, 
     double* ltd = reinterpret_cast<double*>(Lt);
     double* out = a + static_cast<long long>(k + r) * d + k;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = cq * 16 + i;
+    for (int i = 0; i < kPW; ++i) {
+      const int c = cq * kPW + i;
       const double y = sh.ys[c];
       const double l = v[i] * y;                  // on the diagonal u = p: sqrt(p)
       ltd[c * NB + r] = c == r ? y : l;
@@ -438,8 +439,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, 
     if (ti == 0 && tj == 0 && tid == 0 && first_bad < NB) atomicCAS(info, 0, k + first_bad + 1);
   }
 #pragma unroll
-  for (int it = 0; it < NB * NB / 256; ++it) {
-    const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+  for (int it = 0; it < NB * NB / T; ++it) {
+    const int e = tid + T * it, rr = e >> 6, c = e & 63;
     Xi[rr * (NB + 1) + c] = gi[it];
     Xj[rr * (NB + 1) + c] = gj[it];
   }
@@ -447,32 +448,31 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, 
   if (wave == 0 || (wave == 1 && tj != ti)) trsm_tile_in_lds(wave == 0 ? Xi : Xj, Lt, lane);
   __syncthreads();
   const double* XJ = tj == ti ? Xi : Xj;
-  __attribute__((ext_vector_type(4))) double acc[2][2];
+  __attribute__((ext_vector_type(4))) double acc[2][MB];
 #pragma unroll
   for (int ma = 0; ma < 2; ++ma)
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) acc[ma][mb] = {0.0, 0.0, 0.0, 0.0};
+    for (int mb = 0; mb < MB; ++mb) acc[ma][mb] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k0 = 0; k0 < NB; k0 += 4) {
-    double af[2], bf[2];
+    double af[2], bf[MB];
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-      af[t2] = Xi[(wy * 32 + t2 * 16 + (lane & 15)) * (NB + 1) + k0 + (lane >> 4)];
-      bf[t2] = XJ[(wx * 32 + t2 * 16 + (lane & 15)) * (NB + 1) + k0 + (lane >> 4)];
-    }
+    for (int t2 = 0; t2 < 2; ++t2) af[t2] = Xi[(wy * 32 + t2 * 16 + (lane & 15)) * (NB + 1) + k0 + (lane >> 4)];
+#pragma unroll
+    for (int t2 = 0; t2 < MB; ++t2) bf[t2] = XJ[(wx * SC + t2 * 16 + (lane & 15)) * (NB + 1) + k0 + (lane >> 4)];
 #pragma unroll
     for (int ma = 0; ma < 2; ++ma)
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
         acc[ma][mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ma], bf[mb], acc[ma][mb], 0, 0, 0);
   }
 #pragma unroll
   for (int ma = 0; ma < 2; ++ma)
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = wy * 32 + ma * 16 + (lane >> 4) + 4 * r, col = wx * 32 + mb * 16 + (lane & 15);
+        const int row = wy * 32 + ma * 16 + (lane >> 4) + 4 * r, col = wx * SC + mb * 16 + (lane & 15);
         const double cnew = cold[ma][mb][r] - acc[ma][mb][r];
         if (tj != ti || col <= row) ctile[static_cast<long long>(row) * d + col] = cnew;
         // tile column 0 is the next step's block column (its tile 0 the next diagonal block)
@@ -481,14 +481,12 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ a, 
   if (tj == 0) {   // L21 tile i goes back in place (coalesced: a row of the tile is 512 contiguous bytes)
     double* rows_i = a + static_cast<long long>(k + NB + ti * NB) * d + k;
 #pragma unroll
-    for (int it = 0; it < NB * NB / 256; ++it) {
-      const int e = tid + 256 * it, rr = e >> 6, c = e & 63;
+    for (int it = 0; it < NB * NB / T; ++it) {
+      const int e = tid + T * it, rr = e >> 6, c = e & 63;
       rows_i[static_cast<long long>(rr) * d + c] = Xi[rr * (NB + 1) + c];
     }
   }
 }
-
-#endif
 
 // One level of the in-LDS inverse: every pair of adjacent inverted S-blocks becomes one
 // inverted 2S-block. Fixed trip counts (terms outside the triangles are masked, the LDS index
@@ -1104,18 +1102,16 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
       const int w = k0 + ob - k - nb;      // columns left in this outer block
       // small d (no look-ahead, the chip idle around the chain): the whole step in one launch
       static const bool fused_step = getenv("MI355Q_NO_FUSED_STEP") == nullptr;
-#if MI355Q_POTF2_PW == 16
       if (m > 0 && w > 0 && nb == NB && m % NB == 0 && w % NB == 0 && fused_step && side == nullptr) {
         if (!step_panel_ready)
           hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m + NB) * NB)), dim3(256), 0, st, a, d, k,
                              m + NB, step_panel[step_parity]);
-        hipLaunchKernelGGL(chol_step_kernel, dim3(m / NB, w / NB), dim3(256), 0, st, a, d, k, info_out,
+        hipLaunchKernelGGL(chol_step_kernel, dim3(m / NB, w / NB), dim3(kPotf2Threads), 0, st, a, d, k, info_out,
                            step_panel[step_parity], step_panel[step_parity ^ 1]);
         step_parity ^= 1;
         step_panel_ready = true;     // the next step's block column (if it is fused too) is in step_panel[step_parity]
         continue;
       }
-#endif
       hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(kPotf2Threads), 0, st, a, d, k, nb, info_out, lt MI355Q_PROF_ARG);
       if (m > 0) {
         hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + 63) / 64), dim3(64), 0, st, a, d, k, nb, m, lt MI355Q_PROF_ARG);
