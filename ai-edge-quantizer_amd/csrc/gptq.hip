@@ -357,6 +357,54 @@ __global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ a, 
 // factored by every workgroup and row tile i solved by every workgroup of tile row i (up to 7
 // times): the chip is idle at this point of the chain. Only workgroup (0, 0) writes L11 back, only
 // the workgroups of tile column 0 their L21 tile.
+// The panel solve of the step kernel: FOUR LANES PER ROW (a DPP quad, lane c of the quad owns
+// columns 4k + c), 16 rows per wave, so that the eight waves of the workgroup solve its two row
+// tiles together: a lane's 2016 FMAs become ~560, and x_j crosses the quad as two DPP moves.
+// LtQ[(j * 4 + c) * 16 + k] = L11[4k + c][j] (1 / L_jj in the diagonal's slot): a lane's values of
+// column j are contiguous. One column ahead in flight, schedule pinned as in trsm_item.
+template <int CO>
+__device__ __forceinline__ double quad_bcast64(double v) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits), CO * 0x55, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits >> 32), CO * 0x55, 0xF, 0xF, false);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
+template <int J>
+__device__ __forceinline__ void trsm_quad_item(double (&x)[16], Pair (&buf)[2][8], const Pair* LtQ, int c4) {
+  constexpr int KO = J >> 2, CO = J & 3;
+  if constexpr (J + 1 < NB) {
+    constexpr int NKO = (J + 1) >> 2;
+#pragma unroll
+    for (int u = NKO / 2; u < 8; ++u) buf[(J + 1) & 1][u] = LtQ[((J + 1) * 4 + c4) * 8 + u];
+  }
+  asm volatile("" : "+v"(x[KO]) : "v"(LtQ) : "memory");
+  const Pair* c = buf[J & 1];
+  const double lko = (KO & 1) ? c[KO / 2].y : c[KO / 2].x;   // the owner's: 1 / L_JJ; lanes right of it: L[4 KO + c4][J]
+  const double own = x[KO] * lko;
+  const double xj = quad_bcast64<CO>(own);
+  x[KO] = c4 == CO ? own : (c4 > CO ? __builtin_fma(-xj, lko, x[KO]) : x[KO]);
+#pragma unroll
+  for (int k = KO + 1; k < 16; ++k) x[k] = __builtin_fma(-xj, (k & 1) ? c[k / 2].y : c[k / 2].x, x[k]);
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+               "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+  if constexpr (J + 1 < NB) trsm_quad_item<J + 1>(x, buf, LtQ, c4);
+}
+
+// rows 16 * part .. + 15 of the tile X ([row][column], row stride NB + 1), by one wave
+__device__ __forceinline__ void trsm_quad_in_lds(double* __restrict__ X, const Pair* LtQ, int part, int lane) {
+  const int c4 = lane & 3, row = part * 16 + (lane >> 2);
+  double x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = X[row * (NB + 1) + 4 * k + c4];
+  Pair buf[2][8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) buf[0][u] = LtQ[c4 * 8 + u];
+  trsm_quad_item<0>(x, buf, LtQ, c4);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) X[row * (NB + 1) + 4 * k + c4] = x[k];
+}
+
 // s[i][0:64] = a[k + i][k : k + 64], i < rows: a diagonal block and the panel below it, compact.
 __global__ __launch_bounds__(256) void copy_panel_kernel(const double* __restrict__ a, int d, int k, int rows,
                                                         double* __restrict__ s) {
@@ -433,7 +481,8 @@ __global__ __launch_bounds__(kPotf2Threads) void chol_step_kernel(double* __rest
       const int c = cq * kPW + i;
       const double y = sh.ys[c];
       const double l = v[i] * y;                  // on the diagonal u = p: sqrt(p)
-      ltd[c * NB + r] = c == r ? y : l;
+      if constexpr (W == 8) ltd[(c * 4 + (r & 3)) * 16 + (r >> 2)] = c == r ? y : l;   // trsm_quad_item's layout
+      else ltd[c * NB + r] = c == r ? y : l;
       if (ti == 0 && tj == 0 && c <= r) out[c] = l;
     }
     if (ti == 0 && tj == 0 && tid == 0 && first_bad < NB) atomicCAS(info, 0, k + first_bad + 1);
@@ -445,7 +494,11 @@ __global__ __launch_bounds__(kPotf2Threads) void chol_step_kernel(double* __rest
     Xj[rr * (NB + 1) + c] = gj[it];
   }
   __syncthreads();
-  if (wave == 0 || (wave == 1 && tj != ti)) trsm_tile_in_lds(wave == 0 ? Xi : Xj, Lt, lane);
+  if constexpr (W == 8) {
+    if (wave < 4 || tj != ti) trsm_quad_in_lds(wave < 4 ? Xi : Xj, Lt, wave & 3, lane);
+  } else {
+    if (wave == 0 || (wave == 1 && tj != ti)) trsm_tile_in_lds(wave == 0 ? Xi : Xj, Lt, lane);
+  }
   __syncthreads();
   const double* XJ = tj == ti ? Xi : Xj;
   __attribute__((ext_vector_type(4))) double acc[2][MB];
