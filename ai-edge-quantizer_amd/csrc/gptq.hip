@@ -432,8 +432,11 @@ __device__ __forceinline__ void trsm_tile_in_lds(double* __restrict__ X, const P
 // ((64 + m) x 64, compact; tile 0 = the diagonal block), which the PREVIOUS step's tile-column-0
 // workgroups filled with the columns they had just updated (`s_next` here; the first step of an
 // outer block copies it from `a`: copy_panel_kernel).
+// update == 0: the last step of an outer block (nothing left to update inside it): grid (m / 64, 1),
+// diagonal block and panel solve only.
 __global__ __launch_bounds__(kPotf2Threads) void chol_step_kernel(double* __restrict__ a, int d, int k, int* info,
-                                                                 const double* __restrict__ s_cur, double* __restrict__ s_next) {
+                                                                 const double* __restrict__ s_cur, double* __restrict__ s_next,
+                                                                 int update) {
   constexpr int T = kPotf2Threads, W = kPotf2Waves;
   constexpr int SC = NB / (W / 2), MB = SC / 16;     // a wave's part of the C tile: 32 rows x SC columns, 2 x MB MFMA tiles
   const int ti = blockIdx.x, tj = blockIdx.y;        // trailing tile (ti, tj): rows / columns k + 64 + 64 t ..
@@ -455,14 +458,16 @@ __global__ __launch_bounds__(kPotf2Threads) void chol_step_kernel(double* __rest
   }
   const int wy = wave / (W / 2), wx = wave % (W / 2);
   double* ctile = a + static_cast<long long>(k + NB + ti * NB) * d + (k + NB + tj * NB);
-  double cold[2][MB][4];                             // this thread's elements of it, MFMA accumulator layout
+  double cold[2][MB][4] = {};                        // this thread's elements of it, MFMA accumulator layout
+  if (update) {
 #pragma unroll
-  for (int ma = 0; ma < 2; ++ma)
+    for (int ma = 0; ma < 2; ++ma)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        cold[ma][mb][r] = ctile[static_cast<long long>(wy * 32 + ma * 16 + (lane >> 4) + 4 * r) * d + wx * SC + mb * 16 + (lane & 15)];
+        for (int r = 0; r < 4; ++r)
+          cold[ma][mb][r] = ctile[static_cast<long long>(wy * 32 + ma * 16 + (lane >> 4) + 4 * r) * d + wx * SC + mb * 16 + (lane & 15)];
+  }
   {
     // the diagonal block: lane = row, wave = kPW-column panel
     const int r = lane, cq = wave;
@@ -495,11 +500,12 @@ __global__ __launch_bounds__(kPotf2Threads) void chol_step_kernel(double* __rest
   }
   __syncthreads();
   if constexpr (W == 8) {
-    if (wave < 4 || tj != ti) trsm_quad_in_lds(wave < 4 ? Xi : Xj, Lt, wave & 3, lane);
+    if (wave < 4 || (tj != ti && update)) trsm_quad_in_lds(wave < 4 ? Xi : Xj, Lt, wave & 3, lane);
   } else {
-    if (wave == 0 || (wave == 1 && tj != ti)) trsm_tile_in_lds(wave == 0 ? Xi : Xj, Lt, lane);
+    if (wave == 0 || (wave == 1 && tj != ti && update)) trsm_tile_in_lds(wave == 0 ? Xi : Xj, Lt, lane);
   }
   __syncthreads();
+  if (update) {
   const double* XJ = tj == ti ? Xi : Xj;
   __attribute__((ext_vector_type(4))) double acc[2][MB];
 #pragma unroll
@@ -531,6 +537,7 @@ __global__ __launch_bounds__(kPotf2Threads) void chol_step_kernel(double* __rest
         // tile column 0 is the next step's block column (its tile 0 the next diagonal block)
         if (tj == 0 && s_next != nullptr) s_next[static_cast<long long>(ti) * NB * NB + row * NB + col] = cnew;
       }
+  }
   if (tj == 0) {   // L21 tile i goes back in place (coalesced: a row of the tile is 512 contiguous bytes)
     double* rows_i = a + static_cast<long long>(k + NB + ti * NB) * d + k;
 #pragma unroll
@@ -1155,12 +1162,12 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
       const int w = k0 + ob - k - nb;      // columns left in this outer block
       // small d (no look-ahead, the chip idle around the chain): the whole step in one launch
       static const bool fused_step = getenv("MI355Q_NO_FUSED_STEP") == nullptr;
-      if (m > 0 && w > 0 && nb == NB && m % NB == 0 && w % NB == 0 && fused_step && side == nullptr) {
+      if (m > 0 && nb == NB && m % NB == 0 && w % NB == 0 && fused_step && side == nullptr && (w > 0 || step_panel_ready)) {
         if (!step_panel_ready)
           hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m + NB) * NB)), dim3(256), 0, st, a, d, k,
                              m + NB, step_panel[step_parity]);
-        hipLaunchKernelGGL(chol_step_kernel, dim3(m / NB, w / NB), dim3(kPotf2Threads), 0, st, a, d, k, info_out,
-                           step_panel[step_parity], step_panel[step_parity ^ 1]);
+        hipLaunchKernelGGL(chol_step_kernel, dim3(m / NB, w > 0 ? w / NB : 1), dim3(kPotf2Threads), 0, st, a, d, k, info_out,
+                           step_panel[step_parity], step_panel[step_parity ^ 1], w > 0 ? 1 : 0);
         step_parity ^= 1;
         step_panel_ready = true;     // the next step's block column (if it is fused too) is in step_panel[step_parity]
         continue;
