@@ -1162,7 +1162,11 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
       const int w = k0 + ob - k - nb;      // columns left in this outer block
       // small d (no look-ahead, the chip idle around the chain): the whole step in one launch
       static const bool fused_step = getenv("MI355Q_NO_FUSED_STEP") == nullptr;
-      if (m > 0 && nb == NB && m % NB == 0 && w % NB == 0 && fused_step && side == nullptr && (w > 0 || step_panel_ready)) {
+      // (with look-ahead, i.e. d >= 4096, only for the last 2048 rows: above that the workgroups' redundant
+      // factor + solve work competes with the side stream's update for CUs -- 92 vs 87 ms at d = 16384 everywhere)
+      static const int fused_max_m = [] { const char* e = getenv("MI355Q_FUSED_MAX_M"); return e ? atoi(e) : 2048; }();
+      if (m > 0 && nb == NB && m % NB == 0 && w % NB == 0 && fused_step && (side == nullptr || m <= fused_max_m) &&
+          (w > 0 || step_panel_ready)) {
         if (!step_panel_ready)
           hipLaunchKernelGGL(copy_panel_kernel, dim3(grid1d(static_cast<long long>(m + NB) * NB)), dim3(256), 0, st, a, d, k,
                              m + NB, step_panel[step_parity]);

@@ -47,7 +47,7 @@ def phases(path):
   rows = c.execute("select name, start, end, duration from kernels order by start").fetchall()
   first = max(i for i, r in enumerate(rows) if "copy_damped_lower" in r[0])
   rows = rows[first:]
-  last_potf2 = max(i for i, r in enumerate(rows) if "potf2_" in r[0])
+  last_potf2 = max(i for i, r in enumerate(rows) if "potf2_" in r[0] or "chol_step" in r[0])
   put = max(i for i, r in enumerate(rows) if "diag_inverse" in r[0])
   sym = max(i for i, r in enumerate(rows) if "mirror_lower_f32" in r[0])
   gemms = [i for i, r in enumerate(rows) if "gemm" in r[0]]
@@ -57,11 +57,11 @@ def phases(path):
     return sum(r[3] for r in sel), (sel[-1][2] - sel[0][1]) if sel else 0
   print("# phases of one mi355q_gptq_hinv_f64 call (kernel time / wall span, microseconds)")
   for label, a, b in (("cholesky (two-level blocked, potf2 + GEMMs)", 0, put),
-                      ("  of which potf2 + trsm_panel (the serial chain)", None, None),
+                      ("  of which chol_step / potf2 + trsm_panel (the serial chain)", None, None),
                       ("triangular inverse (pairwise merge GEMMs)", put, prod),
                       ("L^-T L^-1 product", prod, prod + 1), ("mirror of the float32 lower triangle", sym, sym + 1)):
     if a is None:
-      t = sum(r[3] for r in rows[:last_potf2 + 1] if "potf2_" in r[0] or "trsm_panel" in r[0])
+      t = sum(r[3] for r in rows[:last_potf2 + 1] if "potf2_" in r[0] or "trsm_panel" in r[0] or "chol_step" in r[0])
       print(f"{t / 1e3:12.1f} {'':>12}  {label}")
       continue
     k, w = span(a, b)
