@@ -583,11 +583,22 @@ int gemm_pick_splitk(int M, int N, int K, bool lower_only) {
     tiles = nt * (nt + 1) / 2;
   }
   if (tiles >= 1024 || K < 4096) return 1;
-  int s = static_cast<int>((1024 + tiles - 1) / tiles);
-  const int max_s = K / 1024;  // >= 1024 of K per slice
-  if (s > max_s) s = max_s;
-  if (s > 16) s = 16;
-  return s < 1 ? 1 : s;
+  // 1024 workgroups run at a time (4 per CU: 97-113 VGPRs, 33 KB of LDS), so tiles x slices should
+  // fill whole rounds of 1024: 136 tiles x 8 slices = 1088 was one full round and one at 6 %
+  // (the d = 2048 Hessian at 72 of ~130 TFLOP/s). The fewest slices that fill their rounds to
+  // within 5 % of the best filling win (every slice is another partial matrix to write and add).
+  int max_s = K / 1024;        // >= 1024 of K per slice
+  if (max_s > 16) max_s = 16;
+  if (max_s < 1) max_s = 1;
+  auto fill = [&](int s) {
+    const long long wg = tiles * s, rounds = (wg + 1023) / 1024;
+    return static_cast<double>(wg) / static_cast<double>(rounds * 1024);
+  };
+  double best_fill = 0.0;
+  for (int s = 1; s <= max_s; ++s) best_fill = fill(s) > best_fill ? fill(s) : best_fill;
+  for (int s = 1; s <= max_s; ++s)
+    if (fill(s) >= best_fill - 0.05) return s;
+  return 1;
 }
 
 template <typename TL>
