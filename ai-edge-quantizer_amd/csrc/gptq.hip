@@ -1320,6 +1320,10 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
   a.nblk = scale_mode == 2 ? static_cast<int>(d / block_size) : 1;
   a.lo = static_cast<float>(narrow ? qmin + 1 : qmin); a.hi = static_cast<float>(qmax);
   a.zp_via_f64 = zp_via_f64; a.diff_bits = diff_bits; a.err = err; a.q = q_out;
+  // (Tried: look-ahead -- only the next group's 256 columns updated on this stream, the rest on the
+  // library's side stream underneath the next chain, two alternating error buffers. The chain's
+  // workgroups then wait for CUs the update holds: 0.77 -> 0.91 ms at 2048 x 2048, 11.0 -> 11.1 ms
+  // at [2048, 16384]. Dropped.)
   // Lazy batch updates: a block's error reaches the later blocks of its own group of kLazyBlocks
   // inside their block kernels (they are quantized next), the columns beyond the group once per
   // group, as one K = 256 product instead of four K = 64 ones -- a quarter of the passes over the

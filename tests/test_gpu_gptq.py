@@ -186,6 +186,64 @@ def test_hessian_inverse_lookahead_with_delayed_side_stream(m):
   assert worst <= 1e-6, worst
 
 
+_STEP_KERNEL_VS_CHAIN = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/ai-edge-quantizer_amd")
+import __graft_entry__ as g
+g.build()
+from mi355q import ops
+for d in (576, 1536, 2048, 3072):
+  gen = torch.Generator(device="cuda").manual_seed(d)
+  x = torch.randn((2 * d, d), generator=gen, device="cuda", dtype=torch.float64)
+  h = ((x.T @ x) / (2 * d)).contiguous()
+  hinv, info = ops.gptq_hinv(h, 0.01)
+  assert int(info.item()) == 0
+  torch.save(hinv.cpu(), sys.argv[2] + f"/hinv_{d}.pt")
+"""
+
+
+def test_hessian_inverse_step_kernel(m, tmp_path):
+  """d < 4096: a 64-column Cholesky step is one launch (chol_step_kernel: every workgroup factors
+  the diagonal block and solves the row tiles it needs itself). Checked against the exact FP64
+  inverse, for run-to-run determinism, for a non-positive pivot deep inside the factorization, and
+  against the unfused chain (MI355Q_NO_FUSED_STEP=1 in a child process): the two orders of the
+  same FP64 operations agree far below the float32 output's resolution."""
+  import os
+  import subprocess
+  import sys
+  import torch
+  for d in (576, 1536, 2048, 3072):
+    gen = torch.Generator(device="cuda").manual_seed(d)
+    x = torch.randn((2 * d, d), generator=gen, device="cuda", dtype=torch.float64)
+    h = ((x.T @ x) / (2 * d)).contiguous()
+    damped = h + torch.diag(torch.full((d,), 0.01 * float(torch.diagonal(h).mean()), device="cuda", dtype=torch.float64))
+    exact = torch.linalg.inv(damped)
+    hinv, info = m.ops.gptq_hinv(h, 0.01)
+    assert int(info.item()) == 0
+    assert float((hinv.double() - exact).abs().max() / exact.abs().max()) <= 3e-7
+    assert torch.equal(hinv, hinv.T)
+    again, _ = m.ops.gptq_hinv(h, 0.01)
+    assert torch.equal(hinv, again)
+    torch.save(hinv.cpu(), str(tmp_path / f"fused_{d}.pt"))
+  # column 700 makes the 700th pivot negative: LAPACK's info convention, through the step kernel
+  d = 1024
+  gen = torch.Generator(device="cuda").manual_seed(3)
+  x = torch.randn((2 * d, d), generator=gen, device="cuda", dtype=torch.float64)
+  h = ((x.T @ x) / (2 * d)).contiguous()
+  h[700, 700] = -5.0
+  _, info = m.ops.gptq_hinv(h, 0.0)
+  assert int(info.item()) == 701
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, MI355Q_NO_FUSED_STEP="1")
+  out = subprocess.run([sys.executable, "-c", _STEP_KERNEL_VS_CHAIN, root, str(tmp_path)], env=env, capture_output=True,
+                       text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  for d in (576, 1536, 2048, 3072):
+    fused = torch.load(str(tmp_path / f"fused_{d}.pt"))
+    chain = torch.load(str(tmp_path / f"hinv_{d}.pt"))
+    assert float((fused.double() - chain.double()).abs().max() / chain.double().abs().max()) <= 1e-7
+
+
 def _apply_with_reference_hinv(m, arrays, name, c):
   w, scale, zp = arrays[f"{name}/w"], arrays[f"{name}/scale"], arrays[f"{name}/zero_point"]
   rows, d = w.shape
