@@ -116,10 +116,10 @@ def serialize_model(model: Any, serialize_to_path: Optional[tfl_flatbuffer_utils
       f.truncate(total)
       return mmap.mmap(f.fileno(), total)
 
-  out = tflite_flatbuffer.serialize_with_external_buffers(model, _MIN_EXTERNAL_BUFFER_BYTES, sink)
-  if isinstance(out, mmap.mmap):
-    out.flush()
-  return out
+  # (no msync: a shared mapping is coherent with the page cache, so readers see the bytes at once,
+  # and they reach the disk when the kernel writes them back -- what a plain write() gives too;
+  # the synchronous flush cost 19 ms of a 147 ms file -> file run)
+  return tflite_flatbuffer.serialize_with_external_buffers(model, _MIN_EXTERNAL_BUFFER_BYTES, sink)
 
 
 class ModelModifier:
