@@ -455,7 +455,7 @@ struct RowsShared {      // small per-workgroup exchange area (in front of the r
 __device__ __forceinline__ void piece_runs(const float (&x)[kPiece], unsigned word, unsigned carry, int pc,
                                            int npieces, const unsigned short* words, const float* row,
                                            float* list, float* dummy, int j0, int* long_e0, int* long_n,
-                                           int* long_j) {
+                                           int* long_j, int qmask = kChunk / kPiece - 1) {
   // leading elements that continue a run started in an earlier piece are not this thread's business
   const unsigned lead = carry ? ((word + 1u) & ~word) - 1u : 0u;   // the low run of ones (if bit 0 is set)
   const unsigned w = word & ~lead & 0xFFFFu;
@@ -490,7 +490,7 @@ __device__ __forceinline__ void piece_runs(const float (&x)[kPiece], unsigned wo
     const int i = zeros ? 32 - __builtin_clz(zeros) : 0;     // its first bit (0 when w is all ones)
     int n = kPiece - i;
     int q = pc + 1;
-    while (q < npieces && (q & (kChunk / kPiece - 1)) != 0) {
+    while (q < npieces && (q & qmask) != 0) {   // (a run ends where NumPy's chunk -- or the unit -- does)
       const unsigned nx = words[q];
       if (nx == 0xFFFFu) { n += kPiece; ++q; continue; }
       n += __builtin_ctz(~nx);
@@ -514,7 +514,8 @@ __device__ __forceinline__ void piece_runs(const float (&x)[kPiece], unsigned wo
 // number of runs (the caller takes this form when no lane of the wave has more than a few).
 __device__ __forceinline__ void piece_runs_sparse(unsigned word, unsigned carry, int pc, int npieces,
                                                   const unsigned short* words, const float* row, float* list,
-                                                  int j0, int* long_e0, int* long_n, int* long_j) {
+                                                  int j0, int* long_e0, int* long_n, int* long_j,
+                                                  int qmask = kChunk / kPiece - 1) {
   const unsigned lead = carry ? ((word + 1u) & ~word) - 1u : 0u;
   const unsigned w = word & ~lead & 0xFFFFu;
   unsigned st = w & ~(w << 1);
@@ -525,7 +526,7 @@ __device__ __forceinline__ void piece_runs_sparse(unsigned word, unsigned carry,
     int n = __builtin_ctz(~(w >> i));            // bits above 15 - i read as "run ended"
     if (i + n == kPiece) {                       // reaches the end of the piece: follow it
       int q = pc + 1;
-      while (q < npieces && (q & (kChunk / kPiece - 1)) != 0) {
+      while (q < npieces && (q & qmask) != 0) {
         const unsigned nx = words[q];
         if (nx == 0xFFFFu) { n += kPiece; ++q; continue; }
         n += __builtin_ctz(~nx);
@@ -770,6 +771,175 @@ __global__ __launch_bounds__(THREADS, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)) voi
     guess = st.next;
   }
   if (tid == 0) publish_moving(a.moving, moved);
+}
+
+// ---- short units (blockwise recipes: 32 .. 512 elements): a workgroup takes kGroupLen contiguous
+// elements = 8 .. 128 whole units through the same machinery ----------------------------------
+// One wave per 128-element unit (octav_kernel) spends ~400 cycles per unit, mask and iteration on
+// ballots, scalar bit scans and lane broadcasts with most lanes idle: 0.43 ms for 4096 x 4096 in
+// blocks of 128. Here thread t owns piece t (16 elements in registers) of the group, a unit is
+// ppu = unit_len / 16 consecutive pieces, and everything that is per row in octav_rows_kernel is
+// per unit: the guess (LDS, one float per unit), where a run may continue (not past the unit's last
+// piece), the slice of the run-sum list a chain walks, the selected-element counts (differences of
+// the wave's inclusive scan at the unit's ends: units never straddle waves). Thread u < units runs
+// unit u's two short chains and its Newton update; the group leaves the loop when every unit has
+// reached a fixed point.
+constexpr int kGroupLen = 4096, kGroupThreads = kGroupLen / kPiece;
+
+struct GroupsShared {          // per iteration parity, like RowsShared
+  int wave_runs[2][4];         // [mask][wave]: runs starting in that wave's pieces
+  int wave_changed[4];
+};
+
+__global__ __launch_bounds__(kGroupThreads, 2) void octav_groups_kernel(OctavArgs a, int ulen) {
+  constexpr int kWaves = kGroupThreads / kWave;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int ppu = ulen / kPiece, qmask = ppu - 1, upg = kGroupLen / ulen;   // pieces per unit (a power of two), units per group
+  const long long unit0 = static_cast<long long>(blockIdx.x) * upg;
+  constexpr int npieces = kGroupThreads;
+  float* dummy = smem + 128 + tid;
+  float* row = smem + 128 + kGroupThreads;
+  constexpr int row_floats = (kGroupLen + (kGroupLen >> 4) + 4) & ~3;
+  float* list_pos = row + row_floats;
+  constexpr int cap = ((kGroupLen / 2 + 2 + 63) & ~63) + 64;
+  float* list_neg = list_pos + cap;
+  unsigned short* words_pos = reinterpret_cast<unsigned short*>(list_neg + cap);
+  unsigned short* words_neg = words_pos + npieces;
+  int* run_pre = reinterpret_cast<int*>(words_neg + npieces);   // [2][threads]: index of the thread's first run in the list
+  int* cnt_incl = run_pre + 2 * kGroupThreads;                   // [2][threads]: selected elements up to and including the thread's piece (per wave)
+  float* ug = reinterpret_cast<float*>(cnt_incl + 2 * kGroupThreads);   // [upg]: the units' current guesses
+  int* totals = reinterpret_cast<int*>(ug + kGroupThreads);      // [2]: runs in the whole group
+
+  for (int i = tid; i < 128; i += kGroupThreads) smem[i] = 0.f;
+  if (tid < upg) ug[tid] = 1.0f;
+  const float qnan = __builtin_nanf("");
+  float x[kPiece];
+  {
+    const float4* g4 = reinterpret_cast<const float4*>(a.x + unit0 * ulen + kPiece * tid);   // (16-byte aligned: see the dispatch)
+    const float4 v0 = g4[0], v1 = g4[1], v2 = g4[2], v3 = g4[3];
+    x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w;
+    x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+    x[8] = v2.x; x[9] = v2.y; x[10] = v2.z; x[11] = v2.w;
+    x[12] = v3.x; x[13] = v3.y; x[14] = v3.z; x[15] = v3.w;
+    const int p = pidx(kPiece * tid);
+#pragma unroll
+    for (int i = 0; i < kPiece; ++i) row[p + i] = x[i];
+  }
+  __syncthreads();
+  const float before = (tid & qmask) != 0 ? row[pidx(kPiece * tid - 1)] : qnan;   // the element in front of the piece, same unit
+  const int my_unit = tid / ppu;
+
+  unsigned wp = 0u, wn = 0u;
+  // thread u < upg carries unit u's state
+  float pos_sum = 0.f, neg_sum = 0.f;
+  int cp = 0, cn = 0;
+  unsigned long long moved = 0;
+  bool done = tid >= upg;
+  for (int it = 0; it < a.max_iter; ++it) {
+    const float hi = ug[my_unit], lo = -hi;
+    GroupsShared* sh = reinterpret_cast<GroupsShared*>(smem + 64 * (it & 1));
+    unsigned np_ = 0, nn_ = 0;
+#pragma unroll
+    for (int i = 0; i < kPiece; ++i) {
+      np_ |= x[i] >= hi ? 1u << i : 0u;
+      nn_ |= x[i] <= lo ? 1u << i : 0u;
+    }
+    const unsigned changed = (np_ ^ wp) | (nn_ ^ wn);
+    wp = np_; wn = nn_;
+    words_pos[tid] = static_cast<unsigned short>(np_);
+    words_neg[tid] = static_cast<unsigned short>(nn_);
+    const unsigned cpos = before >= hi ? 1u : 0u, cneg = before <= lo ? 1u : 0u;
+    const unsigned sp = np_ & ~((np_ << 1) | cpos) & 0xFFFFu, sn = nn_ & ~((nn_ << 1) | cneg) & 0xFFFFu;   // run starts
+    const int ip = wave_incl_scan(__builtin_popcount(sp)), in = wave_incl_scan(__builtin_popcount(sn));
+    int pre_p = ip - __builtin_popcount(sp), pre_n = in - __builtin_popcount(sn);
+    cnt_incl[tid] = wave_incl_scan(__builtin_popcount(np_));
+    cnt_incl[kGroupThreads + tid] = wave_incl_scan(__builtin_popcount(nn_));
+    const bool wave_changed = __ballot(changed != 0) != 0;
+    if (lane == kWave - 1) {
+      sh->wave_runs[0][wave] = ip; sh->wave_runs[1][wave] = in;
+      sh->wave_changed[wave] = wave_changed ? 1 : 0;
+    }
+    __syncthreads();
+    const bool any_changed = (sh->wave_changed[0] | sh->wave_changed[1] | sh->wave_changed[2] | sh->wave_changed[3]) != 0;
+    if (any_changed || it == 0) {
+      int npos = 0, nneg = 0;
+#pragma unroll
+      for (int k = 0; k < kWaves; ++k) {
+        const int c0 = sh->wave_runs[0][k], c1 = sh->wave_runs[1][k];
+        if (k < wave) { pre_p += c0; pre_n += c1; }
+        npos += c0; nneg += c1;
+      }
+      run_pre[tid] = pre_p;
+      run_pre[kGroupThreads + tid] = pre_n;
+      if (tid == 0) { totals[0] = npos; totals[1] = nneg; }
+      int long_e0[2] = {0, 0}, long_n[2] = {0, 0}, long_j[2] = {0, 0};
+      const bool sparse_p = __ballot(__builtin_popcount(sp) > 3) == 0;
+      const bool sparse_n = __ballot(__builtin_popcount(sn) > 3) == 0;
+      if (sparse_p)
+        piece_runs_sparse(wp, cpos, tid, npieces, words_pos, row, list_pos, pre_p, &long_e0[0], &long_n[0], &long_j[0], qmask);
+      else
+        piece_runs(x, wp, cpos, tid, npieces, words_pos, row, list_pos, dummy, pre_p, &long_e0[0], &long_n[0], &long_j[0], qmask);
+      if (sparse_n)
+        piece_runs_sparse(wn, cneg, tid, npieces, words_neg, row, list_neg, pre_n, &long_e0[1], &long_n[1], &long_j[1], qmask);
+      else
+        piece_runs(x, wn, cneg, tid, npieces, words_neg, row, list_neg, dummy, pre_n, &long_e0[1], &long_n[1], &long_j[1], qmask);
+      // units of more than 128 elements only: runs longer than 128, one at a time by the wave that found them
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        unsigned long long pending = __ballot(long_n[k] > 0);
+        while (pending != 0) {
+          const int src = __builtin_ctzll(pending);
+          pending &= pending - 1ull;
+          const int e0 = __builtin_amdgcn_readlane(long_e0[k], src);
+          const int n = __builtin_amdgcn_readlane(long_n[k], src);
+          const int j = __builtin_amdgcn_readlane(long_j[k], src);
+          const float res = pairwise_wave<8>(row, e0, n, lane);
+          if (lane == 0) (k ? list_neg : list_pos)[j] = res;
+        }
+      }
+      __syncthreads();
+      if (!done) {
+        // ---- unit tid: acc = acc + R_j over its slice of each list, its counts
+        const int first = tid * ppu, last = first + ppu - 1;
+        const bool at_wave_start = (first & (kWave - 1)) == 0;
+        {
+          const int j0 = run_pre[first], j1 = tid + 1 < upg ? run_pre[first + ppu] : totals[0];
+          float acc = 0.f;
+          for (int j = j0; j < j1; ++j) acc = acc + list_pos[j];
+          pos_sum = acc;
+          cp = cnt_incl[last] - (at_wave_start ? 0 : cnt_incl[first - 1]);
+        }
+        {
+          const int j0 = run_pre[kGroupThreads + first], j1 = tid + 1 < upg ? run_pre[kGroupThreads + first + ppu] : totals[1];
+          float acc = 0.f;
+          for (int j = j0; j < j1; ++j) acc = acc + list_neg[j];
+          neg_sum = acc;
+          cn = cnt_incl[kGroupThreads + last] - (at_wave_start ? 0 : cnt_incl[kGroupThreads + first - 1]);
+        }
+      }
+    }
+    if (!done) {
+      const float guess = ug[tid];
+      const OctavStep st = octav_step(guess, pos_sum, neg_sum, cp, cn, ulen, a.s, a.count_is_f64);
+      a.hist[static_cast<long long>(it) * a.units + unit0 + tid] = st.next;
+      if (!st.close) moved |= 1ull << it;
+      if (reached_fixed_point(guess, st.next)) {
+        repeat_iterate(a, it, unit0 + tid, st.next);
+        done = true;
+      }
+      ug[tid] = st.next;
+    }
+    if (__syncthreads_and(done ? 1 : 0)) break;   // (also: guesses visible, lists free for the next iteration)
+  }
+  if (tid < upg) publish_moving(a.moving, moved);
+}
+
+size_t octav_groups_smem() {
+  const size_t row_floats = static_cast<size_t>((kGroupLen + (kGroupLen >> 4) + 4) & ~3);
+  const size_t cap = static_cast<size_t>(((kGroupLen / 2 + 2 + 63) & ~63) + 64);
+  return 512 + kGroupThreads * sizeof(float) + row_floats * sizeof(float) + cap * 2 * sizeof(float) +
+         2 * kGroupThreads * sizeof(unsigned short) + 4 * kGroupThreads * sizeof(int) + kGroupThreads * sizeof(float) + 16;
 }
 
 int octav_rows_threads(int len) {
@@ -1185,6 +1355,20 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
     if (hipLaunchKernel(fn, dim3(static_cast<unsigned>(units)), dim3(threads), kargs, smem, st) != hipSuccess)
       return fail(MI355Q_HIP_ERROR, "octav rows launch failed");
     MI355Q_CHECK_LAUNCH("octav rows launch");
+    hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
+                       hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
+    MI355Q_CHECK_LAUNCH("octav pick launch");
+    return MI355Q_OK;
+  }
+  if (unit_len >= 2 * kPiece && unit_len <= 512 && (unit_len & (unit_len - 1)) == 0 &&
+      (units * unit_len) % kGroupLen == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      units * unit_len / kGroupLen <= 0x7FFFFFFFLL && !getenv("MI355Q_OCTAV_WAVE_KERNEL")) {
+    // blockwise units: 4096 contiguous elements (8 .. 128 whole units) per workgroup
+    OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close};
+    const size_t smem = octav_groups_smem();
+    hipLaunchKernelGGL(octav_groups_kernel, dim3(static_cast<unsigned>(units * unit_len / kGroupLen)), dim3(kGroupThreads), smem,
+                       st, a, static_cast<int>(unit_len));
+    MI355Q_CHECK_LAUNCH("octav groups launch");
     hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
                        hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
     MI355Q_CHECK_LAUNCH("octav pick launch");

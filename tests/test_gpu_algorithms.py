@@ -387,3 +387,56 @@ def test_octav_masked_sums_with_designed_run_lengths(m, seed):
       got = m.octav._guess_clipping_with_octav(w, bits, (1,), 10, 3.0)
       ref = O.octav_clip(w, bits, (1,), 10, 3.0)
       assert np.array_equal(got, ref), (n, bits)
+
+
+@pytest.mark.parametrize("block", [32, 64, 128, 256, 512])
+def test_octav_blockwise_groups_kernel_bit_exact(m, block):
+  """Blockwise units of 32 .. 512 elements go through octav_groups_kernel (4096 contiguous elements =
+  8 .. 128 whole units per workgroup, csrc/reduce_exact.hip) when the tensor is a whole number of
+  groups. Designed content: runs of selected elements of every length up to the block size, ending
+  at / crossing piece (16) and block boundaries -- where a run must stop --, all-selected blocks
+  (runs longer than 128 in blocks of 256 / 512), all-small blocks, single outliers at a block's
+  first and last element, NaN / inf, and plain weight-like data; blocks differ, so their guesses
+  move independently and reach their fixed points in different iterations."""
+  rng = np.random.default_rng(500 + block)
+  rows, cols = 24, 2048                                # 49 152 elements = 12 groups
+  w = (rng.standard_normal((rows, cols)) * 0.02).astype(np.float32)
+  flat = w.reshape(-1, block)
+  nb = flat.shape[0]
+  for u in range(0, nb, 3):                            # every third block gets a designed pattern
+    sel = np.zeros(block, bool)
+    i, on = 0, bool(rng.integers(2))
+    while i < block:
+      run = int(rng.integers(1, min(block, 150) + 1)) if on else int(rng.integers(1, 9))
+      sel[i:i + run] = on
+      i += run
+      on = not on
+    sign = np.where(rng.integers(0, 2, block) > 0, 1.0, -1.0)
+    flat[u] = np.where(sel, rng.uniform(1.0, 2.0, block), rng.uniform(1e-4, 2e-4, block)).astype(np.float32) * sign
+  flat[1] = np.abs(flat[1]) + 1.5                      # every element selected, one sign
+  flat[4] = -np.abs(flat[4]) - 0.5
+  flat[7] = 1e-5
+  flat[10, 0] = 3.0
+  flat[13, block - 1] = -3.0
+  flat[16, :17 % block] = 2.0                          # a run over the first piece boundary
+  flat[19, block - 9:] = 2.5                           # ... up to the block's end (the next block starts small)
+  flat[22, 5] = np.inf
+  flat[25, 9] = np.nan
+  w = flat.reshape(rows, cols)
+  data = w.reshape(rows, cols // block, block)
+  for bits in (4, 8):
+    with warnings.catch_warnings():
+      warnings.simplefilter("ignore")
+      ref = O.octav_clip(data, bits, 2, 10, 3.0)
+      got = m.octav._guess_clipping_with_octav(data, bits, 2, 10, 3.0)
+      ref_all = O.octav_clip(data, bits, 2, 10, 3.0, early_stop=False)
+      got_all = m.octav._guess_clipping_with_octav(data, bits, 2, 10, 3.0, early_stop=False)
+    assert got.shape == ref.shape and np.array_equal(got, ref, equal_nan=True), bits
+    assert np.array_equal(got_all, ref_all, equal_nan=True), bits
+  # a tensor that is not a whole number of groups takes the one-wave-per-unit kernel: same numbers
+  odd = w[:5, :cols - block].copy()
+  data = odd.reshape(5, (cols - block) // block, block)
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    assert np.array_equal(m.octav._guess_clipping_with_octav(data, 4, 2, 10, 3.0), O.octav_clip(data, 4, 2, 10, 3.0),
+                          equal_nan=True)
