@@ -204,6 +204,9 @@ def more_extras(torch, ops, gen, xs) -> dict:
   ms = timed_ms(torch, lambda: ops.octav_clip(w.view(-1), 4096, 4096, 4, 10, 3.0, True, True), 20, 3)
   out["octav_clip_4096x4096_int4"] = {"ms": round(ms, 4), "hbm_frac_of_one_read": round(ROWS * COLS * 4 / ms / 1e6 / HBM_PEAK_GBS, 4),
                                       "note": "bit-exact NumPy-order masked sums, 10 Newton iterations, sigma = 0.02"}
+  ms = timed_ms(torch, lambda: ops.octav_clip(w.view(-1), 4096 * 32, 128, 4, 10, 3.0, True, True), 20, 3)
+  out["octav_clip_4096x4096_int4_blockwise128"] = {"ms": round(ms, 4),
+                                                   "hbm_frac_of_one_read": round(ROWS * COLS * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)}
   ms = timed_ms(torch, lambda: ops.hadamard_rotate(w, 4096), 50, 5)
   out["hadamard_4096x4096"] = {"ms": round(ms, 5), "roofline": {"bound": "hbm", "achieved": round(2 * ROWS * COLS * 4 / ms / 1e6, 1),
                                                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
