@@ -875,10 +875,21 @@ __device__ __forceinline__ void gptq_quad_step(const ApplyArgs& a, const float (
     const float p = e * hv[KO];          // product rounded, then subtracted (np.outer, then -=)
     w[KO] = c4 > CO ? w[KO] - p : w[KO];
   }
+  // (pairs: v_pk_mul_f32 + v_pk_add_f32 do two columns per instruction, with the same two
+  // roundings per column; a wave issues an instruction every ~4.5 cycles whatever it does)
+  typedef float Pair32 __attribute__((ext_vector_type(2)));
+  constexpr int K1 = KO + 1, KP = K1 + (K1 & 1);
+  if constexpr ((K1 & 1) != 0 && K1 < 16) {
+    const float p = e * hv[K1];
+    w[K1] = w[K1] - p;
+  }
 #pragma unroll
-  for (int k = KO + 1; k < 16; ++k) {
-    const float p = e * hv[k];
-    w[k] = w[k] - p;
+  for (int k = KP; k < 16; k += 2) {
+    const Pair32 hh = {hv[k], hv[k + 1]};
+    Pair32 ww = {w[k], w[k + 1]};
+    const Pair32 pp = hh * e;
+    ww = ww - pp;
+    w[k] = ww.x; w[k + 1] = ww.y;
   }
   if constexpr (CO == 3) {
     // Group KO is complete: its four bytes are gathered over the quad, every lane stores its own
