@@ -942,15 +942,18 @@ __global__ __launch_bounds__(256) void gptq_rows_kernel(ApplyArgs a) {
           reinterpret_cast<float4*>(hbuf)[e4] = *reinterpret_cast<const float4*>(hsrc + static_cast<long long>(hr) * a.d + 4 * hc);
         }
         __syncthreads();
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+        typedef float Pair32 __attribute__((ext_vector_type(2)));   // packed FP32: two columns per instruction
+        Pair32 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll 8
         for (int k = 0; k < NB; ++k) {
           const float ek = es[rw][pb + k];
           const float4 h4 = *reinterpret_cast<const float4*>(&hbuf[k * NB + 4 * l]);
-          sum[0] = sum[0] + ek * h4.x; sum[1] = sum[1] + ek * h4.y; sum[2] = sum[2] + ek * h4.z; sum[3] = sum[3] + ek * h4.w;
+          const Pair32 h01 = {h4.x, h4.y}, h23 = {h4.z, h4.w};
+          const Pair32 p01 = h01 * ek, p23 = h23 * ek;
+          s01 = s01 + p01;
+          s23 = s23 + p23;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = w[j] - sum[j];
+        w[0] = w[0] - s01.x; w[1] = w[1] - s01.y; w[2] = w[2] - s23.x; w[3] = w[3] - s23.y;
       }
       __syncthreads();                 // everyone is done with hbuf (and, for blk > 0, wave 0 with wl)
       *reinterpret_cast<float4*>(&wl[rw][4 * l]) = make_float4(w[0], w[1], w[2], w[3]);
