@@ -700,8 +700,9 @@ int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_
 #endif
   }
   if constexpr (sizeof(T) == 8) {
+    static const long long kK32MaxTiles = [] { const char* e = getenv("MI355Q_K32_MAX_TILES"); return e ? atoll(e) : 512LL; }();
     const long long tiles64 = static_cast<long long>((g.M + 63) / 64) * ((g.N + 63) / 64) * (g.batch > 1 ? g.batch : 1);
-    if ((g.k_mode == 1 || g.k_mode == 3 || (g.k_mode == 0 && g.lower_only != 0)) && tiles64 <= 512 && g.M % 64 == 0 && g.N % 64 == 0 && g.K % 32 == 0 &&
+    if ((g.k_mode == 1 || g.k_mode == 3 || (g.k_mode == 0 && g.lower_only != 0)) && tiles64 <= kK32MaxTiles && g.M % 64 == 0 && g.N % 64 == 0 && g.K % 32 == 0 &&
         g.K >= 128 && a_mode != kGeneric && b_mode != kGeneric)
       return launch_with<TileF64K32>(g, st, nullptr, 0, a_mode, b_mode);
   }
