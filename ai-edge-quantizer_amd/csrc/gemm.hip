@@ -71,6 +71,35 @@ struct Tile<double> {
 // deep (a K = 1024 product 99 -> 71 us). Not for the product L^-T L^-1, whose 528 tiles share CUs
 // and lose more occupancy than they gain (0.41 -> 0.44 ms); BK = 64 and a four-stage register
 // ring measured the same or worse on both.
+// The same idea in FP32 for GPTQ's update of the columns behind a group: [rows, <= d] += err[rows, 256] x
+// Hinv[256, <= d] is at most 224 tiles of 128 x 128 with K = 256, i.e. sixteen BK = 16 steps of ~3 us
+// (operand latency; their 32 MFMAs per wave take 0.85) = 52 us whatever the width. Four steps of 64.
+struct TileF32K64 {
+  static constexpr int MF = 32;
+  static constexpr int KF = 2;
+  static constexpr int TM = 2;
+  static constexpr int BM = 128;
+  static constexpr int BK = 64;
+  static constexpr int VEC = 4;
+  static constexpr bool DBUF = false;   // 2 x 33 KB of LDS
+  using Elem = float;
+  using Acc = __attribute__((ext_vector_type(16))) float;
+  using Vec = float4;
+};
+// ... and when even those 128 x 128 tiles are fewer than the CUs (every group but the first few of a
+// d = 2048 layer), a quarter of the tile: its 512 MFMAs per wave (13.7 us at K = 256) become 128.
+struct TileF32Small {
+  static constexpr int MF = 32;
+  static constexpr int KF = 2;
+  static constexpr int TM = 1;
+  static constexpr int BM = 64;
+  static constexpr int BK = 64;
+  static constexpr int VEC = 4;
+  static constexpr bool DBUF = false;
+  using Elem = float;
+  using Acc = __attribute__((ext_vector_type(16))) float;
+  using Vec = float4;
+};
 struct TileF64K32 {
   static constexpr int MF = 16;
   static constexpr int KF = 4;
@@ -705,6 +734,16 @@ int32_t launch_gemm(const GemmArgs<T>& g, hipStream_t st, void* splitk_ws, size_
     if ((g.k_mode == 1 || g.k_mode == 3 || (g.k_mode == 0 && g.lower_only != 0)) && tiles64 <= kK32MaxTiles && g.M % 64 == 0 && g.N % 64 == 0 && g.K % 32 == 0 &&
         g.K >= 128 && a_mode != kGeneric && b_mode != kGeneric)
       return launch_with<TileF64K32>(g, st, nullptr, 0, a_mode, b_mode);
+  }
+  if constexpr (sizeof(T) == 4) {
+    const long long tiles128 = static_cast<long long>((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.batch > 1 ? g.batch : 1);
+    static const bool f32_k64 = getenv("MI355Q_NO_F32_K64") == nullptr;
+    const bool short_k = f32_k64 && g.k_mode == 0 && !g.lower_only && g.K % 64 == 0 && g.K >= 128 && g.K <= 1024 &&
+                         a_mode != kGeneric && b_mode != kGeneric;
+    if (short_k && tiles128 <= 256 && g.M % 64 == 0 && g.N % 64 == 0)
+      return launch_with<TileF32Small>(g, st, nullptr, 0, a_mode, b_mode);
+    if (short_k && tiles128 <= 512 && g.M % 128 == 0 && g.N % 128 == 0)
+      return launch_with<TileF32K64>(g, st, nullptr, 0, a_mode, b_mode);
   }
   return launch_with<Tile<T>>(g, st, splitk_ws, splitk_ws_bytes, a_mode, b_mode);
 }
