@@ -43,6 +43,10 @@ from . import runtime as rt
 DEFAULT_BUDGET_BYTES = int(os.environ.get("MI355Q_BATCH_BYTES", 48 << 30))
 # ... and the number of pending tensors: the GPU starts on a wave while the host walks on
 DEFAULT_BUDGET_TENSORS = int(os.environ.get("MI355Q_BATCH_TENSORS", 64))
+# A shape group that has collected this many tensors leaves at once (the batched kernel is at its
+# roofline fraction with 16 buffers per launch): the GPU works on them while Python enqueues the next
+# ones, instead of idling until the whole model has been walked.
+GROUP_LAUNCH_TENSORS = int(os.environ.get("MI355Q_GROUP_LAUNCH_TENSORS", 16))
 
 _I8, _U8, _F32, _F16 = np.dtype(np.int8), np.dtype(np.uint8), np.dtype(np.float32), np.dtype(np.float16)
 
@@ -128,10 +132,10 @@ class PendingArray(rt.HbmArray):
 
 
 class _Slot:
-  __slots__ = ("x", "scale", "out", "params")
+  __slots__ = ("x", "scale", "out", "params", "key")
 
-  def __init__(self, x, scale, out):
-    self.x, self.scale, self.out = x, scale, out
+  def __init__(self, x, scale, out, key=None):
+    self.x, self.scale, self.out, self.key = x, scale, out, key
     self.params = None
 
 
@@ -200,8 +204,8 @@ class RequantQueue:
     else:
       q = out = PendingArray(shape, _I8, self)
       sub_byte = False
-    slot = _Slot(x, scale, out)
     key = (rows, cols, block, num_bits, sub_byte)
+    slot = _Slot(x, scale, out, key)
     group = self._groups.get(key)
     if group is None:
       group = self._groups[key] = []
@@ -216,6 +220,14 @@ class RequantQueue:
     slot.params = params
     if self._pending >= self.budget_tensors or self._pending_bytes >= self.budget_bytes:
       self.flush()
+      return
+    group = self._groups.get(slot.key)
+    if group is not None and len(group) >= GROUP_LAUNCH_TENSORS:
+      del self._groups[slot.key]
+      rows, cols = slot.key[0], slot.key[1]
+      self._pending -= len(group)
+      self._pending_bytes -= len(group) * rows * cols * 4
+      self._launch({slot.key: group})
 
   # -------------------------------------------------------------------------------- flush
   def flush(self) -> None:
@@ -226,6 +238,9 @@ class RequantQueue:
     groups, self._groups = self._groups, {}
     self._pending_bytes = self._pending = 0
     self.stats["flushes"] += 1
+    self._launch(groups)
+
+  def _launch(self, groups) -> None:
     L = _ffi.lib()
     dev = rt.device()
     stream = rt.stream_ptr()
