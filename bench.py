@@ -140,7 +140,7 @@ def more_extras(torch, ops, gen, xs) -> dict:
                   "hbm_frac": round(alg / best / 1e9 / HBM_PEAK_GBS, 4)}
     del res, pool
   out["api_resident"] = dict(api, note="wall time per tensor of get_tensor_quant_params(resident weight) inside"
-                                       " requant_queue.batching(): Python + one batched launch per 64 tensors")
+                                       " requant_queue.batching(): Python + one batched launch per 16 tensors of a shape")
   # ---- file in -> file out (PCIe, page cache and the flatbuffer writer included)
   try:
     import tempfile
