@@ -99,9 +99,9 @@ def get_activation_min_max(tensor_content: np.ndarray,
   if tensor_content.size == 0:
     raise ValueError("zero-size array to reduction operation minimum which has no identity")
   rec = rt.staged(tensor_content)        # reduced already with the rest of this sample?
-  if rec is not None and (rec["lo"], rec["hi"]) == (valid_float_range_min, valid_float_range_max):
+  if rec is not None and rec["lo"] == valid_float_range_min and rec["hi"] == valid_float_range_max:
     mn, mx = rec["minmax"]
-    return {"min": np.reshape(mn, shape), "max": np.reshape(mx, shape)}
+    return {"min": mn.reshape(shape), "max": mx.reshape(shape)}
   is_int = np.issubdtype(tensor_content.dtype, np.integer)
   # The kernel reads float32; other dtypes are accepted when the conversion is exact
   # (integers below 2^24, float64 holding float32 values) so min / max are unchanged.
@@ -124,7 +124,7 @@ def collect_activation_tensor_statistics(tensor_idx: int, graph_info: qtyping.Gr
                                          valid_float_range_max: float | None = None):
   """(name, content, qsv{min,max,num_samples}) or None for constants (ref :1416-1456)."""
   tensor = graph_info.subgraph_tensors[tensor_idx]
-  if tfl_flatbuffer_utils.get_tensor_data(tensor, graph_info.buffers) is not None:
+  if graph_info.buffers[tensor.buffer].data is not None:   # a constant (get_tensor_data's test)
     return None
   name = tfl_flatbuffer_utils.get_tensor_name(tensor)
   content = tensor_content_map[name]

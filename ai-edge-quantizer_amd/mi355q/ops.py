@@ -222,8 +222,10 @@ class ActMinMaxBatch:
     n = len(self.tensors)
     self.out = rt.empty((n, 2), torch.float32)
     if n:
-      self._tab = rt.ptr_table(self.tensors)
-      self._numel = torch.tensor([t.numel() for t in self.tensors], dtype=torch.int64).to(rt.device())
+      # pointer and length tables travel in one copy
+      both = torch.tensor([[t.data_ptr() for t in self.tensors],
+                           [t.numel() for t in self.tensors]], dtype=torch.int64).to(rt.device())
+      self._tab, self._numel = both[0], both[1]
       self._nbytes = _ffi.lib().mi355q_act_minmax_workspace_bytes(n)
       self._ws = rt.empty((self._nbytes,), torch.uint8)
 

@@ -22,6 +22,7 @@ def main():
   ap.add_argument("--samples", type=int, default=32)
   ap.add_argument("--tensors", type=int, default=32)
   ap.add_argument("--resident", action="store_true", help="samples are device tensors")
+  ap.add_argument("--profile", action="store_true", help="cProfile the timed loop (slower)")
   a = ap.parse_args()
   import __graft_entry__ as g
   g.build()
@@ -53,10 +54,18 @@ def main():
   cal.calibrate({"serving_default": pool[:2]}, rm)                # warm-up
   cal.reset_model_qsvs()
   torch.cuda.synchronize()
+  if a.profile:
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
   t0 = time.perf_counter()
   cal.calibrate({"serving_default": (pool[i % 4] for i in range(a.samples))}, rm)
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
+  if a.profile:
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
   nbytes = a.samples * a.tensors * seq * width * 4
   print(json.dumps(dict(workload=f"C4: static_wi8_ai8 calibration, {a.samples} samples x {a.tensors} x [1,{seq},{width}] f32"
                                  + (" (resident in HBM)" if a.resident else ""),
