@@ -141,6 +141,11 @@ def get_tensor_quant_params(
   """ref :219-300."""
   cfg = tensor_quant_config
   act_qsv = tensor_qsv.get("activation_tensor_qsv") if tensor_qsv else None
+  if (act_qsv is not None and "hessian" in act_qsv and isinstance(tensor_content, np.ndarray)
+      and tensor_content.dtype == np.float32 and tensor_content.ndim == 2):
+    # one upload serves both the min / max below and the update (a Gemma-2B layer is 440 MB)
+    rt.require_gpu()
+    tensor_content = rt.HbmArray(rt.to_device(tensor_content))
   if tensor_qsv is None or "min" not in tensor_qsv:
     if tensor_content is None:
       raise ValueError(

@@ -71,6 +71,7 @@ def main():
   ap.add_argument("--dir", default="/tmp")
   ap.add_argument("--resident", action="store_true",
                   help="samples are device tensors (activations produced on this GPU never visit the host)")
+  ap.add_argument("--profile", action="store_true", help="cProfile of the quantize + write phase")
   a = ap.parse_args()
   import __graft_entry__ as g
   g.build()
@@ -97,9 +98,17 @@ def main():
   qsvs = qz.calibrate({"serving_default": data})
   torch.cuda.synchronize()
   t1 = time.perf_counter()
+  if a.profile:
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
   qz.quantize(calibration_result=qsvs, serialize_to_path=dst)
   torch.cuda.synchronize()
   t2 = time.perf_counter()
+  if a.profile:
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(25)
   weight_bytes = a.layers * 4 * (2 * D * D + 2 * DKV * D + 3 * DFF * D)
   print(json.dumps(dict(workload=f"C5: GPTQ int4, {a.layers} Gemma-2B-shaped layer(s), {a.tokens} calibration tokens"
                                  + (" (samples resident in HBM)" if a.resident else ""),
