@@ -435,12 +435,15 @@ __device__ __noinline__ float pairwise_wave(const float* row, int e0, int n, int
   }
 }
 
+template <int W>
 struct RowsShared {      // small per-workgroup exchange area (in front of the row in LDS)
-  int wave_runs[2][4][4];   // [mask][slot][wave]: runs starting in that wave's pieces
-  int wave_count[2][4];     // selected elements per wave
-  int wave_changed[4];      // some word of the wave differs from the previous iteration's
+  int wave_runs[2][4][W];   // [mask][slot][wave]: runs starting in that wave's pieces
+  int wave_count[2][W];     // selected elements per wave
+  int wave_changed[W];      // some word of the wave differs from the previous iteration's
   float sum[2];             // the two chain totals
 };
+// floats per exchange area (there are two, by iteration parity)
+constexpr int rows_xchg_floats(int threads) { return threads <= 256 ? 64 : 192; }
 
 // One mask of one piece: `word` = the 16 selection bits of elements x[0..16) (element e0 = 16 pc),
 // `carry` = the element before the piece is selected too (same chunk). Writes the sums of the runs
@@ -549,17 +552,23 @@ __device__ __forceinline__ void piece_runs_sparse(unsigned word, unsigned carry,
 
 // THREADS = 64 / 128 / 256: rows of up to 1024 / 2048 elements leave half or three quarters of a
 // 256-thread workgroup without a piece, so they get smaller workgroups (more rows per CU).
+// THREADS = 512 / 1024 (one piece per thread) for rows of up to 8192 / 16384 elements: with 256
+// threads and two to four pieces each, such a row (70 - 140 KB of LDS) left its CU with one wave
+// per SIMD walking four pieces one after the other.
 template <int SLOTS, int THREADS>
-__global__ __launch_bounds__(THREADS, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)) void octav_rows_kernel(OctavArgs a) {
+__global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1))) void octav_rows_kernel(OctavArgs a) {
   constexpr int kRowsThreads = THREADS, kWaves = THREADS / kWave;
+  constexpr int kWavesAlloc = kWaves < 4 ? 4 : kWaves;      // (entries of absent waves stay 0)
+  constexpr int kX = rows_xchg_floats(THREADS);
+  using Shared = RowsShared<kWavesAlloc>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const long long unit = blockIdx.x;
   const int len = a.len;
   const int npieces = (len + kPiece - 1) / kPiece;
-  static_assert(sizeof(RowsShared) <= 256, "exchange area");
-  float* dummy = smem + 128 + tid;                         // (two exchange areas in front)
-  float* row = smem + 128 + kRowsThreads;
+  static_assert(sizeof(Shared) <= kX * sizeof(float), "exchange area");
+  float* dummy = smem + 2 * kX + tid;                      // (two exchange areas in front)
+  float* row = smem + 2 * kX + kRowsThreads;
   const int row_floats = (pidx(len) + 4) & ~3;
   float* list_pos = row + row_floats;                       // run sums of the two masks, in run order
   const int cap = ((len / 2 + 2 + 63) & ~63) + 64;         // (+ one per 8192-chunk) + the chain's read-ahead
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(THREADS, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)) voi
   unsigned short* words_pos = reinterpret_cast<unsigned short*>(list_neg + cap);
   unsigned short* words_neg = words_pos + ((npieces + 1) & ~1);
 
-  for (int i = tid; i < 128; i += THREADS) smem[i] = 0.f;   // both exchange areas: waves this workgroup does not have count as 0
+  for (int i = tid; i < 2 * kX; i += THREADS) smem[i] = 0.f;   // both exchange areas: waves this workgroup does not have count as 0
   // ---- stage the unit: every thread keeps its pieces in registers for all iterations (one HBM
   // read), the row also goes to LDS for the runs that leave a piece
   const float qnan = __builtin_nanf("");
@@ -622,7 +631,7 @@ __global__ __launch_bounds__(THREADS, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)) voi
     // (two exchange areas, by iteration parity: an iteration whose masks did not change has only
     // one barrier, so a fast wave may already publish the next iteration's counts while a slow one
     // still reads this one's)
-    RowsShared* sh = reinterpret_cast<RowsShared*>(smem + 64 * (it & 1));
+    Shared* sh = reinterpret_cast<Shared*>(smem + kX * (it & 1));
     // ---- masks of the thread's own pieces, from registers
     unsigned changed = 0;
     unsigned sp[SLOTS], sn[SLOTS];   // run starts
@@ -661,22 +670,47 @@ __global__ __launch_bounds__(THREADS, SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1)) voi
       sh->wave_changed[wave] = wave_changed ? 1 : 0;
     }
     __syncthreads();
-    const bool any_changed = (sh->wave_changed[0] | sh->wave_changed[1] | sh->wave_changed[2] | sh->wave_changed[3]) != 0;
+    bool any_changed;
+    if constexpr (kWavesAlloc > 4) {
+      any_changed = __ballot(lane < kWavesAlloc && sh->wave_changed[lane] != 0) != 0;
+    } else {
+      any_changed = (sh->wave_changed[0] | sh->wave_changed[1] | sh->wave_changed[2] | sh->wave_changed[3]) != 0;
+    }
     if (any_changed || it == 0) {
       // (the same masks give the same sums and counts: late iterations mostly skip all of this)
-      cp = sh->wave_count[0][0] + sh->wave_count[0][1] + sh->wave_count[0][2] + sh->wave_count[0][3];
-      cn = sh->wave_count[1][0] + sh->wave_count[1][1] + sh->wave_count[1][2] + sh->wave_count[1][3];
       int npos = 0, nneg = 0;
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        int bp = npos, bn = nneg;   // runs of earlier slots, then of earlier waves of this slot
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c0 = sh->wave_runs[0][s][k], c1 = sh->wave_runs[1][s][k];
-          if (k < wave) { bp += c0; bn += c1; }
-          npos += c0; nneg += c1;
+      if constexpr (kWavesAlloc > 4) {
+        // many waves, one slot: lane k holds wave k's figures, one scan per figure on the DPP network
+        static_assert(SLOTS == 1, "wide workgroups own one piece per thread");
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        const bool in = lane < kWavesAlloc;
+        const int ip = wave_incl_scan(in ? sh->wave_runs[0][0][lane] : 0);
+        const int inn = wave_incl_scan(in ? sh->wave_runs[1][0][lane] : 0);
+        const int icp = wave_incl_scan(in ? sh->wave_count[0][lane] : 0);
+        const int icn = wave_incl_scan(in ? sh->wave_count[1][lane] : 0);
+        npos = __builtin_amdgcn_readlane(ip, kWavesAlloc - 1);
+        nneg = __builtin_amdgcn_readlane(inn, kWavesAlloc - 1);
+        cp = __builtin_amdgcn_readlane(icp, kWavesAlloc - 1);
+        cn = __builtin_amdgcn_readlane(icn, kWavesAlloc - 1);
+        if (uw > 0) {
+          pre_p[0] += __builtin_amdgcn_readlane(ip, uw - 1);
+          pre_n[0] += __builtin_amdgcn_readlane(inn, uw - 1);
         }
-        pre_p[s] += bp; pre_n[s] += bn;
+      } else {
+        cp = cn = 0;
+#pragma unroll
+        for (int k = 0; k < kWavesAlloc; ++k) { cp += sh->wave_count[0][k]; cn += sh->wave_count[1][k]; }
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+          int bp = npos, bn = nneg;   // runs of earlier slots, then of earlier waves of this slot
+#pragma unroll
+          for (int k = 0; k < kWavesAlloc; ++k) {
+            const int c0 = sh->wave_runs[0][s][k], c1 = sh->wave_runs[1][s][k];
+            if (k < wave) { bp += c0; bn += c1; }
+            npos += c0; nneg += c1;
+          }
+          pre_p[s] += bp; pre_n[s] += bn;
+        }
       }
       // ---- run sums, in run order
       int long_e0[2 * SLOTS], long_n[2 * SLOTS], long_j[2 * SLOTS];
@@ -944,6 +978,7 @@ size_t octav_groups_smem() {
 
 int octav_rows_threads(int len) {
   const int npieces = (len + kPiece - 1) / kPiece;
+  if (npieces > 256 && !getenv("MI355Q_OCTAV_NARROW_ROWS")) return npieces <= 512 ? 512 : 1024;
   return npieces <= 64 ? 64 : (npieces <= 128 ? 128 : 256);
 }
 
@@ -952,7 +987,7 @@ size_t octav_rows_smem(int len) {
   const int npieces = (len + kPiece - 1) / kPiece;
   const size_t row_floats = static_cast<size_t>((len + (len >> 4) + 4) & ~3);
   const size_t cap = static_cast<size_t>(((len / 2 + 2 + 63) & ~63) + 64);
-  return 512 + kRowsThreads * sizeof(float) + row_floats * sizeof(float) + cap * 2 * sizeof(float) +
+  return 2 * rows_xchg_floats(kRowsThreads) * sizeof(float) + kRowsThreads * sizeof(float) + row_floats * sizeof(float) + cap * 2 * sizeof(float) +
          static_cast<size_t>((npieces + 1) & ~1) * 2 * sizeof(unsigned short);
 }
 
@@ -1338,17 +1373,20 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
     const size_t smem = octav_rows_smem(a.len);
     const int threads = octav_rows_threads(a.len);
     const int slots = ((a.len + kPiece - 1) / kPiece + threads - 1) / threads;   // 1 .. 4 (> 1 only with 256 threads)
-    const void* fn = slots == 4 ? reinterpret_cast<const void*>(octav_rows_kernel<4, 256>)
+    const int variant = threads == 1024 ? 6 : threads == 512 ? 5 : slots;   // (slots 2 .. 4: MI355Q_OCTAV_NARROW_ROWS)
+    const void* fn = variant == 6 ? reinterpret_cast<const void*>(octav_rows_kernel<1, 1024>)
+                   : variant == 5 ? reinterpret_cast<const void*>(octav_rows_kernel<1, 512>)
+                   : slots == 4 ? reinterpret_cast<const void*>(octav_rows_kernel<4, 256>)
                    : slots == 3 ? reinterpret_cast<const void*>(octav_rows_kernel<3, 256>)
                    : slots == 2 ? reinterpret_cast<const void*>(octav_rows_kernel<2, 256>)
                    : threads == 256 ? reinterpret_cast<const void*>(octav_rows_kernel<1, 256>)
                    : threads == 128 ? reinterpret_cast<const void*>(octav_rows_kernel<1, 128>)
                                     : reinterpret_cast<const void*>(octav_rows_kernel<1, 64>);
-    static bool raised[5] = {false, false, false, false, false};   // > 64 KB of dynamic LDS has to be asked for once
-    if (smem > 64 * 1024 && !raised[slots]) {
+    static bool raised[7] = {false, false, false, false, false, false, false};   // > 64 KB of dynamic LDS has to be asked for once
+    if (smem > 64 * 1024 && !raised[variant]) {
       const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-      raised[slots] = true;
+      raised[variant] = true;
     }
     if (units > 0x7FFFFFFFLL) return fail(MI355Q_UNSUPPORTED, "too many units");
     void* kargs[] = {&a};

@@ -136,7 +136,7 @@ def test_octav_dense_and_degenerate_rows_bit_exact(m):
     ref = O.octav_clip(w, bits, (1,), 10, 3.0)
     got = m.octav._guess_clipping_with_octav(w, bits, (1,), 10, 3.0)
     assert np.array_equal(got, ref)
-  for n in (9000, 20000):  # rows longer than NumPy's 8192-element buffer
+  for n in (9000, 11008, 16384, 20000):  # rows longer than NumPy's 8192-element buffer
     w = np.abs(rng.standard_normal((3, n))).astype(np.float32)
     assert np.array_equal(m.octav._guess_clipping_with_octav(w, 4, (1,), 10, 3.0),
                           O.octav_clip(w, 4, (1,), 10, 3.0))
@@ -362,7 +362,8 @@ def test_octav_masked_sums_with_designed_run_lengths(m, seed):
   elements are tiny, so the masks stay put over the iterations and every iteration exercises the
   same pattern; rows of several lengths, both signs."""
   rng = np.random.default_rng(1000 + seed)
-  lengths = [64, 100, 127, 128, 1000, 1024, 1100, 2048, 4096, 5000, 8191, 8192, 8192 + 37, 8192 + 64 + 7, 20000]
+  lengths = [64, 100, 127, 128, 1000, 1024, 1100, 2048, 4096, 5000, 8191, 8192, 8192 + 37, 8192 + 64 + 7, 11008,
+             16000, 16383, 16384, 20000]
   pool = np.concatenate([np.arange(1, 13), np.arange(55, 71), np.arange(120, 141), [300]])
   for n in lengths:
     rows = []
