@@ -65,7 +65,10 @@ def get_tensor_quant_params(
   scale_d = ops.mse_scale_nd(xd, outer, units, inner, _MSE_QUANT_MULS[cfg.num_bits])
   q = ops.quantize(xd, outer, units, inner, scale_d, None, cfg.num_bits, cfg.num_bits >= 8,
                    zp_via_f64=True)
-  scale = rt.to_numpy(scale_d).reshape(out_shape)
+  # a large weight's results stay in HBM (the integers for the model writer, the scales so that
+  # the call does not wait for its own kernels); NumPy consumers get host copies on demand
+  scale = (rt.HbmArray(scale_d.reshape(out_shape)) if tensor_content.nbytes >= rt.KEEP_IN_HBM_BYTES
+           else rt.to_numpy(scale_d).reshape(out_shape))
   return qtyping.UniformQuantParams(
       scale=scale, zero_point=np.zeros(scale.shape, np.int32), num_bits=cfg.num_bits,
       symmetric=cfg.symmetric, quantized_dimension=quantized_dim, block_size=0,
