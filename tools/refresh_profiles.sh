@@ -41,5 +41,27 @@ python tools/make_gptq_profiles.py /tmp/prof_pmc > "$OUT/gptq_mfma_util.txt" 2>&
 rm -rf /tmp/prof_fetch
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_fetch -o p -- python "$R/tools/hinv_profile.py" 16384 > "$OUT/fetch.log" 2>&1)
 python tools/pmc_big_kernels.py /tmp/prof_fetch > "$OUT/hinv16384_fetch.txt" 2>&1
+{
+  echo "# tools/octav_iter_bench.py on one MI355X: OCTAV clip search (int4, channelwise), total time (two kernels + memset, wall clock"
+  echo "# over 20 calls) vs number of Newton iterations; all 10 run in production (the reference's early stop is global)."
+  echo "# octav_rows_kernel<SLOTS, THREADS>: workgroup per row, 16-element pieces in registers (one per thread; 512 / 1024 threads for rows"
+  echo "# beyond 4096 elements), run sums listed in LDS (fixed 16-step pass, or a run loop for sparsely selected pieces), the two masks'"
+  echo "# serial chains on two waves; unchanged masks reuse the sums."
+  echo "# --- 4096 x 4096, sigma = 0.02 (typical weights: the first guess 1.0 selects nothing, the second (0.0) half of every mask)"
+  timeout 200 python tools/octav_iter_bench.py 4096 4096 0.02 2>&1 | grep max_iter
+  echo "# --- 4096 x 4096, sigma = 1.0"
+  timeout 200 python tools/octav_iter_bench.py 4096 4096 1.0 2>&1 | grep max_iter
+  echo "# --- other shapes, sigma = 0.02, all ten iterations"
+  for s in "2048 2048" "16384 2048" "2048 8192" "4096 8192" "4096 11008" "2048 16384"; do
+    echo "# rows cols = $s"; timeout 200 python tools/octav_iter_bench.py $s 0.02 2>&1 | grep "max_iter=10"
+  done
+  echo "# tools/octav_block_bench.py (blockwise units, octav_groups_kernel)"
+  timeout 200 python tools/octav_block_bench.py 2>&1 | grep -v amdgpu.ids
+  echo "# tools/api_resident_bench.py (get_tensor_quant_params on HBM-resident weights; batched = inside requant_queue.batching())"
+  timeout 300 python tools/api_resident_bench.py 2>&1 | grep workload
+} > "$OUT/octav_iterations_and_api_resident.txt" 2>&1
+for a in "" "--resident"; do timeout 300 python tools/c4_bench.py --samples 128 $a 2>&1 | tail -1; done > "$OUT/c4_c5_public.txt"
+for a in "" "--resident"; do timeout 600 python tools/c5_bench.py --samples 4 $a 2>&1 | tail -1; done >> "$OUT/c4_c5_public.txt"
+timeout 300 python tools/file_bench.py 2>&1 | tail -1 >> "$OUT/c4_c5_public.txt"
 ls -la "$OUT"
 cat "$OUT/gpu_tests_tail.txt"
