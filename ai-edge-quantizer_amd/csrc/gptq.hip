@@ -996,10 +996,18 @@ inline unsigned grid1d(long long n) {
 
 using namespace mi355q;
 
+namespace mi355q {
+// xtx_bf16x3.hip: the product on the bf16 matrix cores (three-way split of every float32)
+bool xtx_bf16x3_usable(int64_t n, int64_t d);
+size_t xtx_bf16x3_workspace_bytes(int64_t n, int64_t d);
+int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspace, hipStream_t st);
+}  // namespace mi355q
+
 extern "C" size_t mi355q_gptq_xtx_workspace_bytes(int64_t n, int64_t d) {
   if (d <= 0 || d > 0x7FFFFFFF || n > 0x7FFFFFFF) return 0;
-  return static_cast<size_t>(d) * d * sizeof(float) +
-         gemm_splitk_workspace_bytes<float>(static_cast<int>(d), static_cast<int>(d), static_cast<int>(n < 0 ? 0 : n), true);
+  const size_t fp32 = gemm_splitk_workspace_bytes<float>(static_cast<int>(d), static_cast<int>(d), static_cast<int>(n < 0 ? 0 : n), true);
+  const size_t split = xtx_bf16x3_usable(n, d) ? xtx_bf16x3_workspace_bytes(n, d) : 0;
+  return static_cast<size_t>(d) * d * sizeof(float) + (split > fp32 ? split : fp32);
 }
 
 extern "C" int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, double alpha,
@@ -1019,9 +1027,13 @@ extern "C" int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, dou
   // P = X^T X : A(i,k) = X[k][i], B(k,j) = X[k][j]; long K is split over gridDim.z. P is
   // symmetric and P[i][j], P[j][i] are the same k-ordered sum of the same (commuting) products,
   // so only the lower triangle is computed (triangular launch grid: half the flops) and mirrored.
-  GemmArgs<float> g{x, 1, d, x, d, 1, p, d, 1, static_cast<int>(d), static_cast<int>(d),
-                    static_cast<int>(n), 1.0f, 0.0f, 1, 0};
-  if (int32_t s = launch_gemm<float>(g, st, split_ws, need - static_cast<size_t>(d) * d * sizeof(float))) return s;
+  if (xtx_bf16x3_usable(n, d)) {
+    if (int32_t s = xtx_bf16x3(x, n, d, p, split_ws, st)) return s;
+  } else {
+    GemmArgs<float> g{x, 1, d, x, d, 1, p, d, 1, static_cast<int>(d), static_cast<int>(d),
+                      static_cast<int>(n), 1.0f, 0.0f, 1, 0};
+    if (int32_t s = launch_gemm<float>(g, st, split_ws, need - static_cast<size_t>(d) * d * sizeof(float))) return s;
+  }
   const unsigned t32 = static_cast<unsigned>((d + 31) / 32);
   hipLaunchKernelGGL(mirror_scale_to_f64_kernel, dim3(t32, t32), dim3(256), 0, st, p, static_cast<int>(d),
                      alpha, hessian_out);

@@ -1,0 +1,274 @@
+// GPTQ Hessian X^T X on the bf16 matrix cores with float32-class accuracy (gfx950).
+//
+//   ref: algorithms/uniform_quantize/gptq.py:100-107  (2.0 / num_samples) * x.T.dot(x), float32 sgemm
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 matrix rate (157 vs 2500 TFLOP/s), the FP32
+// product holds the socket at its power limit (profiles/r02_gptq_mfma_util.txt), and the d = 16384
+// Hessian of a Gemma down_proj (65 536 tokens: 17.6 TFLOP on the triangle) is the largest single
+// cost of a GPTQ layer. Every float32 is the exact sum of three bfloat16 numbers
+// (x = x1 + x2 + x3, 8 significant bits each; the residuals x - x1 and x - x1 - x2 are exact in
+// float32), and a product of two bfloat16 numbers is exact in float32, so
+//   x * y = x1 y1 + (x1 y2 + x2 y1) + (x1 y3 + x2 y2 + x3 y1) + O(2^-25 |x y|)
+// with every kept term exact: six v_mfma_f32_32x32x16_bf16 products accumulated in float32 give
+// the float32 dot product to within the rounding noise of its own accumulation (what is dropped
+// is below half an ulp of x y). Like the sgemm it replaces, the result depends on the order of the
+// float32 additions (tolerance class T2). Non-finite activations become NaN (inf * 0 in a cross
+// term) instead of +-inf; the damped Cholesky refuses both.
+//
+// Two kernels per slab of <= 16384 tokens:
+//   split   X [n, d] float32 -> P[k tile of 32 tokens][plane 0..2][row i < d][64 bytes]: the 32
+//           tokens of row i as four 16-byte chunks, chunk c stored at c ^ ((i >> 2) & 3). A 128-row
+//           operand tile of one plane and k tile is 8 KB of contiguous memory in exactly the image
+//           LDS needs, so it is staged by global_load_lds (no registers, no ds_write), and the
+//           swizzle makes every 16-lane group of the ds_read_b128 fragment reads touch all 64 banks.
+//   xtx     lower-triangular grid of 128 x 128 output tiles (8 x 8 patches of tiles per XCD so that
+//           what shares an L2 shares its operand panels); per k tile the three planes of both
+//           operand tiles (48 KB) go to LDS and every wave issues 2 x 24 MFMAs on its 64 x 64
+//           quadrant -- six products per pair of fragments, so the L2 -> LDS traffic per MFMA is half
+//           that of a plain bf16 GEMM with this tile. Small terms are added first.
+#include "common.h"
+
+namespace mi355q {
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+
+constexpr int kTile = 128;                  // output tile edge
+constexpr int kBK = 16;                     // tokens per k tile (one MFMA K step)
+constexpr int kRowB = 2 * kBK;              // bytes of one row of one plane in one k tile
+constexpr int kPlaneTileB = kTile * kRowB;  // 8 KB
+constexpr int kOperandB = 3 * kPlaneTileB;  // 24 KB
+constexpr int kSuper = 8;                   // tiles per side of an XCD patch
+constexpr int kSlabTokens = 16384;
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float x) {
+  unsigned b = __float_as_uint(x);
+  if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (b >> 16) | 0x40u;   // NaN stays NaN
+  const unsigned r = (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+  return ((r & 0x7F80u) == 0x7F80u && (b & 0x7F800000u) != 0x7F800000u) ? b >> 16 : r;   // never round a finite value to inf
+}
+
+// grid (d / 64, pairs of k tiles), 256 threads; tokens [k0, k_end) of x, zero beyond
+__global__ __launch_bounds__(256) void xtx_split_kernel(const float* __restrict__ x, int d, long long k0,
+                                                       long long k_end, int kt_total, unsigned char* __restrict__ planes) {
+  __shared__ float tile[32][65];
+  const int i0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 32; r += 4) {
+    const long long k = k0 + static_cast<long long>(blockIdx.y) * 32 + r;
+    tile[r][tx] = k < k_end ? x[k * d + i0 + tx] : 0.f;
+  }
+  __syncthreads();
+  const int ii = threadIdx.x >> 2, c = threadIdx.x & 3, i = i0 + ii;
+  const int kt = 2 * blockIdx.y + (c >> 1);
+  if (kt >= kt_total) return;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = tile[8 * c + j][ii];
+  const int cs = (c & 1) ^ ((i >> 3) & 1);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool finite = (__float_as_uint(v[j]) & 0x7F800000u) != 0x7F800000u;
+      const unsigned bits = bf16_rne_bits(v[j]);
+      w[j >> 1] |= bits << (16 * (j & 1));
+      v[j] = finite ? v[j] - __uint_as_float(bits << 16) : 0.f;   // exact
+    }
+    unsigned char* dst = planes + ((static_cast<long long>(kt) * 3 + p) * d + i) * kRowB + cs * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+struct XtxArgs {
+  const unsigned char* planes;   // [k tile][3][d][64 B]
+  int d, tiles;                  // tiles = d / 128
+  int kt_total, kt_per_split;
+  float* c;                      // [d, d] float32 (lower-triangular tiles), or partials [split][d][d]
+  int accumulate;                // c += product (direct mode)
+  int partial;                   // write split z's product to c + z d d
+  int patches;                   // 1: 8 x 8 patches of tiles dealt to XCDs; 0: plain triangular list
+};
+
+__global__ __launch_bounds__(256) void xtx_bf16x3_kernel(XtxArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  int ti, tj;
+  if (a.patches) {
+    const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
+    const int sup = (local / (kSuper * kSuper)) * 8 + xcd, within = local % (kSuper * kSuper);
+    int si = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(sup) + 1.0f) - 1.0f) * 0.5f);
+    while ((si + 1) * (si + 2) / 2 <= sup) ++si;
+    while (si * (si + 1) / 2 > sup) --si;
+    const int sj = sup - si * (si + 1) / 2;
+    ti = si * kSuper + within / kSuper;
+    tj = sj * kSuper + within % kSuper;
+    if (ti >= a.tiles || tj > ti) return;
+  } else {
+    const int b = blockIdx.x;
+    ti = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(b) + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    tj = b - ti * (ti + 1) / 2;
+  }
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 1, wc = wave & 1;                 // this wave's 64 x 64 quadrant
+  const int kt0 = blockIdx.y * a.kt_per_split;
+  const int kt1 = min(a.kt_total, kt0 + a.kt_per_split);
+
+  f32x16 acc[2][2], lo[2][2];   // x1 y1 and the five cross terms: the small ones do not round against the large sum
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = 0.f;
+
+  // fragment addresses: row = quadrant + 32 i + (lane & 31); chunk (lane >> 5) ^ ((row >> 3) & 1)
+  const int frow = lane & 31;
+  const int fch = ((lane >> 5) ^ ((frow >> 3) & 1)) * 16;
+  const int offA = (wr * 64 + frow) * kRowB + fch, offB = kOperandB + (wc * 64 + frow) * kRowB + fch;
+
+  const long long row_stride = static_cast<long long>(a.d) * kRowB;   // one plane of one k tile
+  const unsigned char* gA = a.planes + static_cast<long long>(ti) * kPlaneTileB + lane * 16;
+  const unsigned char* gB = a.planes + static_cast<long long>(tj) * kPlaneTileB + lane * 16;
+
+  // 24 wave-wide 1 KB pieces per k tile: operand (A, B) x plane x 4 pieces of 32 rows; wave w takes w, w + 4, ...
+  auto stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int piece = q * 4 + wave;                 // 0 .. 23
+      const int op = piece / 12, r = piece % 12, p = r >> 2, seg = r & 3;
+      const unsigned char* src = (op ? gB : gA) + (static_cast<long long>(kt) * 3 + p) * row_stride + seg * 1024;
+      unsigned char* dst = lds + buf * (2 * kOperandB) + op * kOperandB + p * kPlaneTileB + seg * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  if (kt0 < kt1) stage(kt0, 0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // this k tile has landed; every wave is done with the other buffer
+    if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
+    const unsigned char* img = lds + buf * (2 * kOperandB);
+    bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fa[i][p] = *reinterpret_cast<const bf16x8*>(img + offA + p * kPlaneTileB + i * 32 * kRowB);
+        fb[i][p] = *reinterpret_cast<const bf16x8*>(img + offB + p * kPlaneTileB + i * 32 * kRowB);
+      }
+    // the five cross terms (x1 y3 + x2 y2 + x3 y1) + (x1 y2 + x2 y1) and x1 y1 have accumulators of their own
+#define MI355Q_TERM(ACC, PA, PB)                                                                \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], ACC[i][j], 0, 0, 0)
+    MI355Q_TERM(lo, 0, 2);
+    MI355Q_TERM(lo, 1, 1);
+    MI355Q_TERM(lo, 2, 0);
+    MI355Q_TERM(lo, 0, 1);
+    MI355Q_TERM(lo, 1, 0);
+    MI355Q_TERM(acc, 0, 0);
+#undef MI355Q_TERM
+  }
+
+  // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* c = a.c + (a.partial ? static_cast<long long>(blockIdx.y) * a.d * a.d : 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = ti * kTile + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = tj * kTile + wc * 64 + j * 32 + (lane & 31);
+        float* dst = c + static_cast<long long>(row) * a.d + col;
+        const float v = acc[i][j][r] + lo[i][j][r];
+        *dst = a.accumulate ? *dst + v : v;
+      }
+}
+
+// c (+)= partial[0] + partial[1] + ... (slices added in order) over the lower-triangular tiles
+__global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict__ partial, int splits, int d,
+                                                        int accumulate, float* __restrict__ c) {
+  const long long n = static_cast<long long>(d) * d;
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
+    const long long i = e / d, j = e % d;
+    if (j / kTile > i / kTile) continue;
+    float s = partial[e];
+    for (int z = 1; z < splits; ++z) s = s + partial[z * n + e];
+    c[e] = accumulate ? c[e] + s : s;
+  }
+}
+
+int xtx_splits(int64_t d, int64_t kt) {
+  const int64_t tiles = (d / kTile) * (d / kTile + 1) / 2;
+  if (tiles >= 512) return 1;
+  int64_t s = (768 + tiles - 1) / tiles;
+  if (s > 16) s = 16;
+  if (s > kt / 64) s = kt / 64;        // >= 1024 tokens per split
+  return s < 1 ? 1 : static_cast<int>(s);
+}
+
+}  // namespace
+
+bool xtx_bf16x3_usable(int64_t n, int64_t d) {
+  return d % kTile == 0 && d >= 256 && n >= 1024 && getenv("MI355Q_XTX_FP32_MFMA") == nullptr;
+}
+
+size_t xtx_bf16x3_workspace_bytes(int64_t n, int64_t d) {
+  const int64_t ks = n < kSlabTokens ? n : kSlabTokens;
+  const int64_t kt = (ks + kBK - 1) / kBK;
+  const int splits = xtx_splits(d, kt);
+  return 1024 + static_cast<size_t>(kt) * 3 * d * kRowB +
+         (splits > 1 ? static_cast<size_t>(splits) * d * d * sizeof(float) : 0);
+}
+
+// p (float32 [d, d], lower-triangular 128 x 128 tiles valid) = X^T X for X float32 [n, d].
+int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspace, hipStream_t st) {
+  unsigned char* planes = reinterpret_cast<unsigned char*>(
+      (reinterpret_cast<uintptr_t>(workspace) + 1023) & ~static_cast<uintptr_t>(1023));
+  const int tiles = static_cast<int>(d / kTile);
+  const int64_t ks_max = n < kSlabTokens ? n : kSlabTokens;
+  const int64_t kt_max = (ks_max + kBK - 1) / kBK;
+  float* partial = reinterpret_cast<float*>(planes + static_cast<size_t>(kt_max) * 3 * d * kRowB);
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(xtx_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            4 * kOperandB) != hipSuccess)
+      return fail(MI355Q_HIP_ERROR, "hipFuncSetAttribute failed");
+    raised = true;
+  }
+  for (int64_t k0 = 0; k0 < n; k0 += kSlabTokens) {
+    const int64_t ks = n - k0 < kSlabTokens ? n - k0 : kSlabTokens;
+    const int kt = static_cast<int>((ks + kBK - 1) / kBK);
+    hipLaunchKernelGGL(xtx_split_kernel, dim3(static_cast<unsigned>(d / 64), static_cast<unsigned>((kt + 1) / 2)), dim3(256), 0, st,
+                       x, static_cast<int>(d), static_cast<long long>(k0), static_cast<long long>(k0 + ks), kt, planes);
+    const int splits = xtx_splits(d, kt);
+    XtxArgs a{};
+    a.planes = planes; a.d = static_cast<int>(d); a.tiles = tiles; a.kt_total = kt;
+    a.kt_per_split = (kt + splits - 1) / splits;
+    a.partial = splits > 1 ? 1 : 0;
+    a.c = splits > 1 ? partial : p;
+    a.accumulate = (splits == 1 && k0 > 0) ? 1 : 0;
+    a.patches = tiles >= 4 * kSuper ? 1 : 0;
+    unsigned gx;
+    if (a.patches) {
+      const int sside = (tiles + kSuper - 1) / kSuper, nsup = sside * (sside + 1) / 2;
+      gx = static_cast<unsigned>((nsup + 7) / 8 * 8 * kSuper * kSuper);
+    } else {
+      gx = static_cast<unsigned>(tiles * (tiles + 1) / 2);
+    }
+    hipLaunchKernelGGL(xtx_bf16x3_kernel, dim3(gx, static_cast<unsigned>(splits)), dim3(256), 4 * kOperandB, st, a);
+    if (splits > 1)
+      hipLaunchKernelGGL(xtx_reduce_kernel, dim3(2048), dim3(256), 0, st, partial, splits, static_cast<int>(d),
+                         k0 > 0 ? 1 : 0, p);
+  }
+  MI355Q_CHECK_LAUNCH("xtx bf16x3 launch");
+  return MI355Q_OK;
+}
+
+}  // namespace mi355q
