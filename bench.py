@@ -98,6 +98,7 @@ def event_time_ms(fn, iters: int) -> float:
 
 
 MFMA_F32_PEAK_TF, MFMA_F64_PEAK_TF = 157.3, 78.6   # dense MFMA peaks (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0
 
 
 def timed_ms(torch, fn, reps: int, warm: int = 2) -> float:
@@ -228,9 +229,12 @@ def more_extras(torch, ops, gen, xs) -> dict:
     # the triangular product computes half of 2 n d^2; the inverse is d^3 (Cholesky + triangular inverse + product)
     c5[f"d{d}"] = {
         "hessian": {"ms": round(ms_h, 3), "tokens": tokens,
-                    "roofline": {"bound": "mfma", "achieved": round(tokens * d * d / ms_h / 1e9, 1), "peak": MFMA_F32_PEAK_TF,
-                                 "unit": "TFLOP/s", "frac": round(tokens * d * d / ms_h / 1e9 / MFMA_F32_PEAK_TF, 4),
-                                 "flops": "n d^2 (lower triangle of X^T X, FP32 MFMA)"}},
+                    "roofline": {"bound": "mfma", "achieved": round(6 * tokens * d * d / ms_h / 1e9, 1), "peak": MFMA_BF16_PEAK_TF,
+                                 "unit": "TFLOP/s", "frac": round(6 * tokens * d * d / ms_h / 1e9 / MFMA_BF16_PEAK_TF, 4),
+                                 "flops": "6 n d^2: lower triangle of X^T X, every float32 product as six bf16 MFMA products"
+                                          " (exact three-way split of both operands, xtx_bf16x3.hip)",
+                                 "float32_product_TFLOPs": round(tokens * d * d / ms_h / 1e9, 1),
+                                 "mfma_f32_peak": MFMA_F32_PEAK_TF}},
         "hinv": {"ms": round(ms_i, 3),
                  "roofline": {"bound": "mfma", "achieved": round(d ** 3 / ms_i / 1e9, 1), "peak": MFMA_F64_PEAK_TF,
                               "unit": "TFLOP/s", "frac": round(d ** 3 / ms_i / 1e9 / MFMA_F64_PEAK_TF, 4),

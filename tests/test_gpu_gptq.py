@@ -244,6 +244,65 @@ def test_hessian_inverse_step_kernel(m, tmp_path):
     assert float((fused.double() - chain.double()).abs().max() / chain.double().abs().max()) <= 1e-7
 
 
+_XTX_FP32_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/ai-edge-quantizer_amd")
+import __graft_entry__ as g
+g.build()
+from mi355q import ops
+for d, n in ((256, 1024), (384, 1500), (2048, 20000)):
+  x = torch.load(sys.argv[2] + f"/x_{d}_{n}.pt").cuda()
+  torch.save(ops.gptq_xtx(x, 2.0 / n).cpu(), sys.argv[2] + f"/fp32_{d}_{n}.pt")
+"""
+
+
+def test_hessian_bf16_split_product(m, tmp_path):
+  """d a multiple of 128 and >= 1024 tokens: X^T X runs on the bf16 matrix cores, every float32
+  split exactly into three bfloat16 (xtx_bf16x3.hip). Checked against the FP64 product (the bound
+  of the FP32-MFMA path, 2e-6 of the largest entry; the observed error is recorded), for exact
+  symmetry and run-to-run determinism, over ragged token counts, a second slab that accumulates
+  (20 000 tokens) and split-K partials, with entries across 30 binades and non-zero means; against
+  the FP32-MFMA product of the same build (MI355Q_XTX_FP32_MFMA=1 in a child process); and a
+  non-finite activation must poison the Hessian (the damped Cholesky then refuses it)."""
+  import os
+  import subprocess
+  import sys
+  import torch
+  shapes = ((256, 1024), (384, 1500), (2048, 20000))
+  got = {}
+  for d, n in shapes:
+    gen = torch.Generator(device="cuda").manual_seed(7 * d + n)
+    x = torch.randn((n, d), generator=gen, device="cuda")
+    x = x * torch.exp2(torch.randint(-15, 15, (1, d), generator=gen, device="cuda").float()) + 0.25
+    torch.save(x.cpu(), str(tmp_path / f"x_{d}_{n}.pt"))
+    h = m.ops.gptq_xtx(x, 2.0 / n)
+    ref = (x.double().T @ x.double()) * (2.0 / n)
+    # entries span 60 binades: the error is measured against the scale of each entry's own sum
+    mag = (x.double().abs().T @ x.double().abs()) * (2.0 / n)
+    err = float(((h - ref).abs() / mag).max())
+    parity_rates.note(f"hessian bf16 split d={d} {n} tokens vs FP64 product (per-entry scale)", "max_rel_error", err, 2e-6)
+    assert err <= 2e-6, (d, n, err)
+    assert torch.equal(h, h.T)
+    assert torch.equal(h, m.ops.gptq_xtx(x, 2.0 / n))
+    got[(d, n)] = h.cpu()
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, MI355Q_XTX_FP32_MFMA="1")
+  out = subprocess.run([sys.executable, "-c", _XTX_FP32_CHILD, root, str(tmp_path)], env=env, capture_output=True,
+                       text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  for d, n in shapes:
+    fp32 = torch.load(str(tmp_path / f"fp32_{d}_{n}.pt"))
+    x = torch.load(str(tmp_path / f"x_{d}_{n}.pt")).double()
+    mag = (x.abs().T @ x.abs()) * (2.0 / n)
+    assert float(((got[(d, n)] - fp32).abs() / mag).max()) <= 4e-6
+  x = torch.randn((1024, 256), device="cuda")
+  x[100, 7] = float("inf")
+  h = m.ops.gptq_xtx(x, 2.0 / 1024)
+  assert not bool(torch.isfinite(h[7]).all())
+  _, info = m.ops.gptq_hinv(h, 0.01)
+  assert int(info.item()) != 0
+
+
 def _apply_with_reference_hinv(m, arrays, name, c):
   w, scale, zp = arrays[f"{name}/w"], arrays[f"{name}/scale"], arrays[f"{name}/zero_point"]
   rows, d = w.shape

@@ -31,13 +31,14 @@ def mfma(path):
   print(f"{'dur_us':>10} {'TFLOP/s':>8} {'MfmaUtil%':>9} {'GHz':>5}  kernel")
   groups = {}
   for d in per.values():
-    if "gemm" not in d["name"] and "Cijk" not in d["name"]:
+    if "gemm" not in d["name"] and "Cijk" not in d["name"] and "xtx_bf16x3_kernel" not in d["name"]:
       continue
     groups.setdefault(d["name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:64], []).append(d)
   for name, ds in sorted(groups.items()):
     for d in sorted(ds, key=lambda x: -x["dur"])[:6]:
       gui = d.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
-      flops = (d.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) + d.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)) * 512
+      flops = (d.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) + d.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) +
+               d.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)) * 512
       util = 100.0 * d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024) if gui else 0.0
       print(f"{d['dur'] / 1e3:10.1f} {flops / d['dur'] / 1e3:8.2f} {util:9.1f} {gui / d['dur']:5.2f}  {name}")
 

@@ -110,9 +110,9 @@ def main():
     flops = 2.0 * ntok * d * d            # of the full product; only the tiles on / below the
     nt = d // 128                          # diagonal are computed (symmetric result, mirrored)
     done = flops * (nt + 1) / (2 * nt)
-    emit(op="gptq_hessian xtx (f32 MFMA, lower triangle + mirror)", d=d, tokens=ntok, ms=round(ms, 3),
-         TFLOPs_executed=round(done / ms / 1e9, 2), TFLOPs_of_full_product=round(flops / ms / 1e9, 2),
-         mfma_f32_peak=157.3)
+    emit(op="gptq_hessian xtx (bf16 MFMA x 6 on the exact three-way split, lower triangle + mirror)", d=d, tokens=ntok,
+         ms=round(ms, 3), float32_product_TFLOPs_executed=round(done / ms / 1e9, 2),
+         bf16_mfma_TFLOPs_executed=round(6 * done / ms / 1e9, 1), mfma_bf16_peak=2500.0, mfma_f32_peak=157.3)
     h = ops.gptq_xtx(x, 2.0 / 128)
     del x
     ms = timed(lambda: ops.gptq_hinv(h), 3 if d == 2048 else 1, warm=1)

@@ -35,7 +35,7 @@ trace hinv16384 python "$R/tools/hinv_profile.py" 16384
   timeout 60 tools/kbench/lat_bench
 } > "$OUT/hinv_phases.txt" 2>&1
 rm -rf /tmp/prof_pmc
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 \
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_BF16 \
     -d /tmp/prof_pmc -o p -- python "$R/tools/path_bench.py" --big > "$OUT/pmc.log" 2>&1)
 python tools/make_gptq_profiles.py /tmp/prof_pmc > "$OUT/gptq_mfma_util.txt" 2>&1
 rm -rf /tmp/prof_fetch
