@@ -258,8 +258,15 @@ int32_t mi355q_gemm_f64(const double* A, int64_t a_i, int64_t a_k, const double*
  * FP32 on the MFMA units, alpha = 2 / num_samples applied in FLOAT64 exactly as
  * `(2.0 / num_samples) * x.T.dot(x)` promotes in the reference.
  * ref: algorithms/uniform_quantize/gptq.py:100-107
- * workspace: mi355q_gptq_xtx_workspace_bytes(n, d) bytes (X^T X in FP32 plus the
- * split-K partial sums used when d is small and n is long).
+ * When d is a multiple of 128 and n >= 1024 the float32 products are formed on the
+ * bf16 matrix cores: each float32 is split exactly into three bfloat16 and six
+ * exact bf16 products per pair are accumulated in FP32 (what is dropped is below
+ * half an ulp of each product; csrc/xtx_bf16x3.hip). MI355Q_XTX_FP32_MFMA=1 in the
+ * environment selects the FP32-MFMA product for those shapes too. Either way the
+ * result is an FP32-accumulated sgemm whose addition order is the kernel's own
+ * (tolerance class T2), symmetric bit for bit, and deterministic run to run.
+ * workspace: mi355q_gptq_xtx_workspace_bytes(n, d) bytes (X^T X in FP32, plus the
+ * bfloat16 planes of one slab of <= 16384 tokens or the split-K partial sums).
  * ------------------------------------------------------------------------ */
 size_t mi355q_gptq_xtx_workspace_bytes(int64_t n, int64_t d);
 int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, double alpha,
