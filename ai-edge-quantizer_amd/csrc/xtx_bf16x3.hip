@@ -41,6 +41,7 @@ constexpr int kPlaneTileB = kTile * kRowB;  // 8 KB
 constexpr int kOperandB = 3 * kPlaneTileB;  // 24 KB
 constexpr int kSuper = 8;                   // tiles per side of an XCD patch
 constexpr int kSlabTokens = 16384;
+constexpr int kFold = 32;                   // k tiles per first-level accumulation chain
 
 __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
   unsigned b = __float_as_uint(x);
@@ -117,13 +118,15 @@ __global__ __launch_bounds__(256) void xtx_bf16x3_kernel(XtxArgs a) {
   const int kt0 = blockIdx.y * a.kt_per_split;
   const int kt1 = min(a.kt_total, kt0 + a.kt_per_split);
 
-  f32x16 acc[2][2], lo[2][2];   // x1 y1 and the five cross terms: the small ones do not round against the large sum
+  // x1 y1, the five cross terms (the small ones do not round against the large sum), and the sum of the
+  // x1 y1 accumulators folded away every kFold k tiles: chains of 32 + 32 additions instead of 1024
+  f32x16 acc[2][2], lo[2][2], top[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = top[i][j][r] = 0.f;
 
   // fragment addresses: row = quadrant + 32 i + (lane & 31); chunk (lane >> 5) ^ ((row >> 3) & 1)
   const int frow = lane & 31;
@@ -172,6 +175,17 @@ __global__ __launch_bounds__(256) void xtx_bf16x3_kernel(XtxArgs a) {
     MI355Q_TERM(lo, 1, 0);
     MI355Q_TERM(acc, 0, 0);
 #undef MI355Q_TERM
+    if (((kt - kt0) & (kFold - 1)) == kFold - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            top[i][j][r] = top[i][j][r] + acc[i][j][r];
+            acc[i][j][r] = 0.f;
+          }
+    }
   }
 
   // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(256) void xtx_bf16x3_kernel(XtxArgs a) {
         const int row = ti * kTile + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int col = tj * kTile + wc * 64 + j * 32 + (lane & 31);
         float* dst = c + static_cast<long long>(row) * a.d + col;
-        const float v = acc[i][j][r] + lo[i][j][r];
+        const float v = (top[i][j][r] + acc[i][j][r]) + lo[i][j][r];
         *dst = a.accumulate ? *dst + v : v;
       }
 }

@@ -65,7 +65,7 @@ def test_hessian_d16384_against_oracle_columns_and_fp64(m, big):
   sub = x[..., torch.from_numpy(cols).cuda()].cpu().numpy()          # [32, 512, 384]
   ref = O.gptq_hessian(sub)                                          # NumPy sgemm, (2/32) x^T x
   got = h[torch.from_numpy(cols).cuda()][:, torch.from_numpy(cols).cuda()].cpu().numpy()
-  parity_rates.check_rel("hessian d=16384 16384 tokens vs oracle (384 columns)", got, ref, 1e-5)
+  parity_rates.check_rel("hessian d=16384 16384 tokens vs oracle (384 columns)", got, ref, 2e-6)
   x2 = x.reshape(-1, D_BIG)
   exact = torch.zeros((D_BIG, D_BIG), dtype=torch.float64, device="cuda")
   for k0 in range(0, x2.shape[0], 4096):                             # FP64 checker in K slabs
@@ -73,7 +73,7 @@ def test_hessian_d16384_against_oracle_columns_and_fp64(m, big):
     exact.addmm_(xs.T, xs)
   exact *= 2.0 / 32
   err = float((h - exact).abs().max() / exact.abs().max())
-  parity_rates.note("hessian d=16384 16384 tokens vs FP64 product", "max_rel_error", err, 1e-5)   # FP32 sums of 16384 products: observed 3.9e-6
+  parity_rates.note("hessian d=16384 16384 tokens vs FP64 product", "max_rel_error", err, 2e-6)   # bf16 split, two-level FP32 sums: observed 2e-7 (FP32 MFMA: 3.9e-6)
 
 
 def _damped(torch, h):
