@@ -254,13 +254,6 @@ int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspa
   const int64_t ks_max = n < kSlabTokens ? n : kSlabTokens;
   const int64_t kt_max = (ks_max + kBK - 1) / kBK;
   float* partial = reinterpret_cast<float*>(planes + static_cast<size_t>(kt_max) * 3 * d * kRowB);
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(xtx_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            4 * kOperandB) != hipSuccess)
-      return fail(MI355Q_HIP_ERROR, "hipFuncSetAttribute failed");
-    raised = true;
-  }
   for (int64_t k0 = 0; k0 < n; k0 += kSlabTokens) {
     const int64_t ks = n - k0 < kSlabTokens ? n - k0 : kSlabTokens;
     const int kt = static_cast<int>((ks + kBK - 1) / kBK);
