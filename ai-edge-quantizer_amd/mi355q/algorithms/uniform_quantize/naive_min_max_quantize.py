@@ -120,6 +120,35 @@ def scale_shape_for(tensor_content: np.ndarray, granularity, quantized_dim) -> t
   return tuple(d if i == quantized_dim else 1 for i, d in enumerate(shape))
 
 
+_QUEUED_PLANS: dict = {}
+
+
+def _queued_plan(op_info, cfg, tensor_content):
+  """(layout, quantized_dim, block_size, scale shape, packs in kernel, zero points) of a weight
+  that goes to the requant queue, or None when it does not (no fused layout, too small)."""
+  if tensor_content is None:
+    return None
+  op_name = op_info.op_name
+  adj = op_info.op.builtinOptions.adjY if op_name == qtyping.TFLOperationName.BATCH_MATMUL else None
+  key = (op_name, adj, cfg.granularity, cfg.num_bits, tensor_content.shape, tensor_content.dtype)
+  plan = _QUEUED_PLANS.get(key, _QUEUED_PLANS)
+  if plan is _QUEUED_PLANS:
+    quantized_dim = common_utils.get_weight_quantized_dim(op_info, tensor_content, cfg.granularity)
+    layout = fused_weight_layout(tensor_content, cfg.granularity, quantized_dim)
+    plan = None
+    if layout is not None and batchable(layout, tensor_content):
+      scale_shape = scale_shape_for(tensor_content, cfg.granularity, quantized_dim)
+      zero_point = np.zeros(scale_shape, np.int8)
+      zero_point.flags.writeable = False          # shared by every tensor of this shape
+      plan = (layout, quantized_dim,
+              uniform_quantize_tensor.extract_block_size_from_granularity(cfg.granularity), scale_shape,
+              packs_in_kernel(layout, cfg.num_bits), zero_point)
+    if len(_QUEUED_PLANS) > 4096:
+      _QUEUED_PLANS.clear()
+    _QUEUED_PLANS[key] = plan
+  return plan
+
+
 def get_tensor_quant_params(
     op_info: qtyping.OpInfo, tensor_quant_config: qtyping.TensorQuantizationConfig,
     tensor_content: Optional[np.ndarray] = None, tensor_qsv: Optional[dict[str, Any]] = None,
@@ -132,26 +161,30 @@ def get_tensor_quant_params(
         f"{op_info.op_name}(index: {op_info.subgraph_op_index}) not found in"
         " tensor_name_to_qsv. Check if the correct calibration results are passed into the"
         " ParamsGenerator.")
-  quantized_dim = common_utils.get_weight_quantized_dim(op_info, tensor_content, cfg.granularity)
-  block_size = uniform_quantize_tensor.extract_block_size_from_granularity(cfg.granularity)
-
   # ---- fused single-pass path (weights; min/max collected on the spot) ----
   weight_cfg = op_info.op_quant_config.weight_tensor_config
   if (not have_qsv and cfg.symmetric and cfg.num_bits in (2, 4, 8) and weight_cfg is not None
       and weight_cfg.granularity == cfg.granularity):
-    layout = fused_weight_layout(tensor_content, cfg.granularity, quantized_dim)
     queue = requant_queue.active()
-    if layout is not None and queue is not None and batchable(layout, tensor_content):
-      # inside ParamsGenerator's loop: enqueue, equally shaped weights leave in one launch
-      scale, q, slot = queue.submit(
-          tensor_content, layout, cfg.num_bits,
-          scale_shape_for(tensor_content, cfg.granularity, quantized_dim), packs_in_kernel(layout, cfg.num_bits))
-      params = qtyping.UniformQuantParams(
-          scale=scale, zero_point=np.zeros(scale.shape, np.int8), num_bits=cfg.num_bits,
-          symmetric=True, quantized_dimension=quantized_dim, block_size=block_size,
-          quantized_data=q)
-      queue.attach(slot, params)
-      return params
+    if queue is not None:
+      # inside ParamsGenerator's loop: enqueue, equally shaped weights leave in one launch. What the
+      # call derives from (op, granularity, bits, shape) alone is looked up, not recomputed: the
+      # host side of a queued tensor has to stay below the 14 us the kernel takes for it
+      plan = _queued_plan(op_info, cfg, tensor_content)
+      if plan is not None:
+        layout, quantized_dim, block_size, scale_shape, packs, zero_point = plan
+        scale, q, slot = queue.submit(tensor_content, layout, cfg.num_bits, scale_shape, packs)
+        params = qtyping.UniformQuantParams(
+            scale=scale, zero_point=zero_point, num_bits=cfg.num_bits,
+            symmetric=True, quantized_dimension=quantized_dim, block_size=block_size,
+            quantized_data=q)
+        queue.attach(slot, params)
+        return params
+  quantized_dim = common_utils.get_weight_quantized_dim(op_info, tensor_content, cfg.granularity)
+  block_size = uniform_quantize_tensor.extract_block_size_from_granularity(cfg.granularity)
+  if (not have_qsv and cfg.symmetric and cfg.num_bits in (2, 4, 8) and weight_cfg is not None
+      and weight_cfg.granularity == cfg.granularity):
+    layout = fused_weight_layout(tensor_content, cfg.granularity, quantized_dim)
     if layout is not None:
       scale, q = fused_symmetric_requant(tensor_content, layout, cfg.num_bits)
       scale = scale.reshape(scale_shape_for(tensor_content, cfg.granularity, quantized_dim))

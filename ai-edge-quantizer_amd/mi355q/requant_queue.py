@@ -56,19 +56,21 @@ class PendingArray(rt.HbmArray):
   arrive when its wave has been issued (`source` = (group tensor, row)) or when its packed
   sibling has been unpacked."""
 
+  # (class-level defaults: three of these are made per queued tensor, and only what differs is set)
+  _source = None        # (tensor [n, ...], index) once the wave is out
+  _wave = None          # _Wave whose pinned copy carries the host values (scales)
+  _host_at = None       # (offset, count) into the wave's host block
+  _unpack = None        # (packed sibling, element count, bits)
+  _tensor = None
+  _host = None
+  packed = None
+  f16 = None
+
   def __init__(self, shape, dtype, queue):  # pylint: disable=super-init-not-called
     self._shape = shape
     self._dtype = dtype
     self._queue = queue
-    self._source = None        # (tensor [n, ...], index) once the wave is out
-    self._wave = None          # _Wave whose pinned copy carries the host values (scales)
-    self._host_at = None       # (offset, count) into the wave's host block
-    self._unpack = None        # (packed sibling, element count, bits)
-    self._tensor = None
-    self._host = None
     self.cache = {}
-    self.packed = None
-    self.f16 = None
 
   @property
   def device_tensor(self) -> torch.Tensor:

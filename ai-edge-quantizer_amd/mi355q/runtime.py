@@ -52,6 +52,9 @@ def to_device(a, dtype=None) -> torch.Tensor:
   return t.to(device(), non_blocking=True)
 
 
+_NP_DTYPE: dict = {}     # torch dtype -> NumPy dtype
+
+
 class HbmArray:
   """A result that lives in HBM and reaches the host only if somebody asks for it.
 
@@ -93,7 +96,11 @@ class HbmArray:
 
   @property
   def dtype(self):
-    return np.dtype(str(self.device_tensor.dtype).replace("torch.", ""))
+    t = self.device_tensor.dtype
+    d = _NP_DTYPE.get(t)
+    if d is None:
+      d = _NP_DTYPE[t] = np.dtype(str(t).replace("torch.", ""))
+    return d
 
   @property
   def size(self) -> int:

@@ -19,4 +19,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter(); run(); torch.cuda.synchroniz
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): run()
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(30)
