@@ -89,6 +89,25 @@ __global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __
   }
 }
 
+// The same for columns [c0, c1) only (grid: x over the columns, y over groups of 8 rows): with a
+// look-ahead factorization the first outer block's columns are copied on the caller's stream and
+// everything behind them on the side stream, underneath the first block's chain of small kernels.
+__global__ __launch_bounds__(256) void copy_damped_lower_cols_kernel(const double* __restrict__ h, int d,
+                                                                    const double* __restrict__ diag_sum, double damp,
+                                                                    double* __restrict__ a, int c0, int c1) {
+  const double add = damp * (diag_sum[0] / static_cast<double>(d));
+  const int j = c0 + static_cast<int>(blockIdx.x) * 256 + static_cast<int>(threadIdx.x);
+  if (j >= c1) return;
+  const int i_end = min(d, (static_cast<int>(blockIdx.y) + 1) * 8);
+  for (int i = static_cast<int>(blockIdx.y) * 8; i < i_end; ++i) {
+    const long long e = static_cast<long long>(i) * d + j;
+    double v = 0.0;
+    if (j < i) v = h[e];
+    if (j == i) { v = h[e]; v = ((v != 0.0) ? v : 1.0) + add; }
+    a[e] = v;
+  }
+}
+
 // ---------------------------------------------------------- Cholesky ----
 // The 64-column step of the blocked factorization is a serial chain of small kernels
 // (diagonal block -> panel below it -> trailing update), so each link is latency-tuned and the
@@ -1156,8 +1175,6 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   if (hipMemsetAsync(info_out, 0, sizeof(int32_t), st) != hipSuccess)
     return fail(MI355Q_HIP_ERROR, "hipMemsetAsync failed");
   hipLaunchKernelGGL(diag_sum_kernel, dim3(1), dim3(256), 0, st, hessian, d, scal);
-  hipLaunchKernelGGL(copy_damped_lower_kernel, dim3(grid1d(static_cast<long long>(d) * d)), dim3(256), 0, st,
-                     hessian, d, scal, damp_factor, a);
   MI355Q_CHECK_LAUNCH("gptq damp launch");
   // ---- blocked right-looking Cholesky (lower), FP64, two levels. Per 64-column step:
   //   diagonal block: factor (one workgroup)
@@ -1177,6 +1194,24 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
     SideStream*& side; bool& busy; hipStream_t st;
     ~JoinSide() { if (busy && side) (void)hipStreamWaitEvent(st, side->update_done, 0); }
   } join_side{side, side_busy, st};
+  if (side != nullptr && d > 2 * OB && getenv("MI355Q_NO_SPLIT_COPY") == nullptr) {
+    // the first outer block's columns now; the other 2 GB (d = 16384: 0.75 ms) on the side stream,
+    // underneath the first block's chain. update_done doubles as "copied": the first update behind
+    // outer block 0 waits for it like for any earlier side-stream update.
+    if (hipEventRecord(side->panel_done, st) != hipSuccess || hipStreamWaitEvent(side->stream, side->panel_done, 0) != hipSuccess)
+      return fail(MI355Q_HIP_ERROR, "look-ahead: copy hand-over failed");
+    hipLaunchKernelGGL(copy_damped_lower_cols_kernel, dim3((OB + 255) / 256, (d + 7) / 8), dim3(256), 0, st, hessian, d, scal,
+                       damp_factor, a, 0, OB);
+    hipLaunchKernelGGL(copy_damped_lower_cols_kernel, dim3((d - OB + 255) / 256, (d + 7) / 8), dim3(256), 0, side->stream,
+                       hessian, d, scal, damp_factor, a, OB, d);
+    if (hipEventRecord(side->update_done, side->stream) != hipSuccess)
+      return fail(MI355Q_HIP_ERROR, "look-ahead: record failed");
+    side_busy = true;
+  } else {
+    hipLaunchKernelGGL(copy_damped_lower_kernel, dim3(grid1d(static_cast<long long>(d) * d)), dim3(256), 0, st,
+                       hessian, d, scal, damp_factor, a);
+  }
+  MI355Q_CHECK_LAUNCH("gptq damp launch");
   double* step_panel[2] = {spanel, spanel + static_cast<size_t>(d) * NB};   // see chol_step_kernel
   int step_parity = 0;
   for (int k0 = 0; k0 < d; k0 += OB) {
