@@ -73,7 +73,11 @@ __global__ __launch_bounds__(256) void diag_sum_kernel(const double* __restrict_
   if (threadIdx.x == 0) out[0] = part[0];
 }
 
-// a = lower(h) with the damped diagonal; strictly upper part zeroed.
+// a = lower(h) with the damped diagonal; the band of kZeroBand elements above the diagonal zeroed.
+// Nothing reads `a` further up: every kernel touches the upper triangle only inside tiles (<= 128
+// wide, at offsets that are multiples of 64) that straddle the diagonal; a third of the copy's
+// traffic was zeros nobody looked at (tests/test_gpu_gptq.py poisons the workspace to prove it).
+constexpr int kZeroBand = 256;
 __global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __restrict__ h, int d,
                                                                const double* __restrict__ diag_sum,
                                                                double damp, double* __restrict__ a) {
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __
     double v = 0.0;
     if (j < i) v = h[e];
     if (j == i) { v = h[e]; v = ((v != 0.0) ? v : 1.0) + add; }
-    a[e] = v;
+    if (j - i < kZeroBand) a[e] = v;
   }
 }
 
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void copy_damped_lower_cols_kernel(const doubl
     double v = 0.0;
     if (j < i) v = h[e];
     if (j == i) { v = h[e]; v = ((v != 0.0) ? v : 1.0) + add; }
-    a[e] = v;
+    if (j - i < kZeroBand) a[e] = v;
   }
 }
 

@@ -315,6 +315,52 @@ def test_hessian_bf16_split_product(m, tmp_path):
   assert int(info.item()) != 0
 
 
+def test_workspaces_and_outputs_are_written_before_they_are_read(m, monkeypatch):
+  """The GPTQ entry points take caller-owned workspaces and outputs that they may not assume
+  anything about: with every byte of them set to 0xFF beforehand (NaN as float32 / float64)
+  the Hessian, its inverse (fused steps, look-ahead with the split copy, ragged d) and the weight
+  update return exactly what they return on zero-filled memory."""
+  torch = m.torch
+  from mi355q import runtime as rt
+  real_empty = rt.empty
+
+  def run_all():
+    out = []
+    for n, d in ((1500, 384), (700, 320), (3000, 2048)):
+      gen = torch.Generator(device="cuda").manual_seed(n + d)
+      x = torch.randn((n, d), generator=gen, device="cuda")
+      h = m.ops.gptq_xtx(x, 2.0 / n)
+      hinv, info = m.ops.gptq_hinv(h, 0.01)
+      out += [h.clone(), hinv.clone(), info.clone()]
+    for d in (576, 4608):
+      gen = torch.Generator(device="cuda").manual_seed(d)
+      x = torch.randn((2 * d, d), generator=gen, device="cuda", dtype=torch.float64)
+      hinv, info = m.ops.gptq_hinv(((x.T @ x) / (2 * d)).contiguous(), 0.01)
+      out += [hinv.clone(), info.clone()]
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((4096, 2048), generator=gen, device="cuda")
+    hinv, _ = m.ops.gptq_hinv(m.ops.gptq_xtx(x, 2.0 / 4096), 0.01)
+    w = torch.randn((256, 2048), generator=gen, device="cuda") * 0.02
+    scale = (w.abs().amax(dim=1) / 7.0).contiguous()
+    out.append(m.ops.gptq_apply(w, hinv, scale, None, 1, 0, 4, False, False, 8).clone())
+    return out
+
+  monkeypatch.setattr(rt, "empty", lambda shape, dtype: torch.zeros(shape, dtype=dtype, device=rt.device()))
+  clean = run_all()
+
+  def poisoned(shape, dtype):
+    t = real_empty(shape, dtype)
+    t.view(torch.uint8).fill_(0xFF)
+    return t
+  monkeypatch.setattr(rt, "empty", poisoned)
+  dirty = run_all()
+  assert len(clean) == len(dirty)
+  for a, b in zip(clean, dirty):
+    assert torch.equal(a, b)
+    if a.is_floating_point():
+      assert bool(torch.isfinite(a).all())
+
+
 def _apply_with_reference_hinv(m, arrays, name, c):
   w, scale, zp = arrays[f"{name}/w"], arrays[f"{name}/scale"], arrays[f"{name}/zero_point"]
   rows, d = w.shape
