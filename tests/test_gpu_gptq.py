@@ -315,6 +315,36 @@ def test_hessian_bf16_split_product(m, tmp_path):
   assert int(info.item()) != 0
 
 
+@pytest.mark.parametrize("kind", ["grid", "wide_range", "tiny", "integers", "constant"])
+def test_hessian_bf16_split_structured_inputs(m, kind):
+  """Inputs whose rounding errors are not random: values on a coarse grid (activations that were
+  quantized before), columns spread over 80 binades inside one tensor, magnitudes near the bottom of
+  the float32 range (the third bfloat16 piece runs into subnormals), small integers (every product
+  and every partial sum exact: the Hessian must be exact), and one constant."""
+  torch = m.torch
+  n, d = 4096, 512
+  gen = torch.Generator(device="cuda").manual_seed({"grid": 1, "wide_range": 2, "tiny": 3, "integers": 4, "constant": 5}[kind])
+  if kind == "grid":
+    x = torch.round(torch.randn((n, d), generator=gen, device="cuda") * 8.0) / 8.0 + 0.375
+  elif kind == "wide_range":
+    x = torch.randn((n, d), generator=gen, device="cuda") * torch.exp2(torch.randint(-40, 40, (1, d), generator=gen, device="cuda").float())
+  elif kind == "tiny":
+    x = torch.randn((n, d), generator=gen, device="cuda") * 1e-18
+  elif kind == "integers":
+    x = torch.randint(-7, 8, (n, d), generator=gen, device="cuda").float()
+  else:
+    x = torch.full((n, d), 0.1, device="cuda")
+  h = m.ops.gptq_xtx(x, 2.0 / n)
+  ref = (x.double().T @ x.double()) * (2.0 / n)
+  assert torch.equal(h, h.T)
+  if kind == "integers":
+    assert torch.equal(h, ref)
+    return
+  mag = (x.double().abs().T @ x.double().abs()) * (2.0 / n)
+  err = float(((h - ref).abs() / mag.clamp_min(1e-300)).max())
+  parity_rates.note(f"hessian bf16 split, {kind} inputs, vs FP64 product (per-entry scale)", "max_rel_error", err, 1e-6)
+
+
 def test_workspaces_and_outputs_are_written_before_they_are_read(m, monkeypatch):
   """The GPTQ entry points take caller-owned workspaces and outputs that they may not assume
   anything about: with every byte of them set to 0xFF beforehand (NaN as float32 / float64)
