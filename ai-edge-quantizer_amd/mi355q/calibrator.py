@@ -121,14 +121,22 @@ class Calibrator:
     key = (signature_key, id(model_recipe_manager))
     plan = None if self._plans is None else self._plans.get(key)
     if plan is None:
-      from .algorithms.uniform_quantize import common_quantize
-      ops_ = list(self._scan_ops_to_calibrate(signature_key, model_recipe_manager))
+      from .algorithms.uniform_quantize import common_quantize, naive_min_max_quantize
       names: dict[str, None] = {}
-      for sg, graph_info, op, _, _ in ops_:
+      ops_ = []
+      for sg, graph_info, op, op_key, alg in self._scan_ops_to_calibrate(signature_key, model_recipe_manager):
+        calibrate = algorithm_manager.get_quantization_func(alg, op_key, qtyping.QuantizeMode.CALIBRATE)
+        mine = []
         for tid in common_quantize.get_tensor_indices_requiring_calibration(op, graph_info):
           tensor = sg.tensors[tid]
           if self._flatbuffer_model.buffers[tensor.buffer].data is None:
-            names[tfl_flatbuffer_utils.get_tensor_name(tensor)] = None
+            name = tfl_flatbuffer_utils.get_tensor_name(tensor)
+            names[name] = None
+            mine.append(name)
+        # the stock per-op function (min / max of every runtime tensor of the op) is a function of
+        # these names alone: the walk takes them from here instead of deriving them per sample
+        stock = mine if calibrate is naive_min_max_quantize.min_max_calibrate else None
+        ops_.append((sg, graph_info, op, op_key, alg, calibrate, stock))
       plan = {"ops": ops_, "runtime_tensors": list(names)}
       if self._plans is not None:
         self._plans[key] = plan
@@ -183,10 +191,22 @@ class Calibrator:
         for i, (a, d) in enumerate(zip(arrays, dev))})
 
   def _walk(self, signature_key, model_recipe_manager) -> None:
+    from .algorithms.uniform_quantize import common_quantize
     updated: set[str] = set()
-    for _, graph_info, op, op_key, alg in self._ops_to_calibrate(signature_key, model_recipe_manager):
-      calibrate = algorithm_manager.get_quantization_func(alg, op_key, qtyping.QuantizeMode.CALIBRATE)
-      op_qsvs = calibrate(op, graph_info, self._tensor_content_map)
+    for _, graph_info, op, op_key, alg, calibrate, stock in self._ops_to_calibrate(signature_key, model_recipe_manager):
+      if stock is None:
+        op_qsvs = calibrate(op, graph_info, self._tensor_content_map)
+      else:
+        # min_max_calibrate with its default valid_range, minus what a tensor seen earlier in this
+        # sample (the previous op's output) would compute again only to be ignored below
+        op_qsvs = {}
+        for name in stock:
+          if name in updated:
+            continue
+          content = self._tensor_content_map[name]
+          qsv = common_quantize.get_activation_min_max(content, -3e38, 3e38)
+          qsv["num_samples"] = np.array(content.shape[0] if content.ndim > 0 else 1)
+          op_qsvs[name] = qsv
       if self._recording is not None:
         # sample-sharded calibration: keep this sample's statistics as events; another process
         # replays all samples' events in dataset order (distributed.calibrate_sharded)
