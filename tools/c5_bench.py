@@ -72,6 +72,7 @@ def main():
   ap.add_argument("--resident", action="store_true",
                   help="samples are device tensors (activations produced on this GPU never visit the host)")
   ap.add_argument("--profile", action="store_true", help="cProfile of the quantize + write phase")
+  ap.add_argument("--profile-calibrate", action="store_true", help="cProfile of the calibration phase")
   a = ap.parse_args()
   import __graft_entry__ as g
   g.build()
@@ -94,10 +95,18 @@ def main():
   if a.resident:
     data = [{k: torch.from_numpy(v).cuda() for k, v in m.items()} for m in data]
   torch.cuda.synchronize()
+  if a.profile_calibrate:
+    import cProfile
+    import pstats
+    prc = cProfile.Profile()
+    prc.enable()
   t0 = time.perf_counter()
   qsvs = qz.calibrate({"serving_default": data})
   torch.cuda.synchronize()
   t1 = time.perf_counter()
+  if a.profile_calibrate:
+    prc.disable()
+    pstats.Stats(prc).sort_stats("tottime").print_stats(18)
   if a.profile:
     import cProfile
     import pstats
