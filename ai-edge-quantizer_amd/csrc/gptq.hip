@@ -1024,6 +1024,12 @@ namespace mi355q {
 bool xtx_bf16x3_usable(int64_t n, int64_t d);
 size_t xtx_bf16x3_workspace_bytes(int64_t n, int64_t d);
 int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspace, hipStream_t st);
+// ... and the same split for the update behind a group of columns of the OBS apply
+bool upd_bf16x3_usable(int64_t rows, int64_t d);
+size_t upd_bf16x3_workspace_bytes(int64_t rows, int64_t d, int64_t kk_max);
+int32_t upd_bf16x3_prepare(const float* hinv, int64_t d, void* workspace, hipStream_t st);
+int32_t upd_bf16x3(const float* err, int64_t ld, int64_t rows, int64_t d, int64_t g0, int64_t kk, int64_t g1, float* w,
+                   void* workspace, hipStream_t st);
 }  // namespace mi355q
 
 extern "C" size_t mi355q_gptq_xtx_workspace_bytes(int64_t n, int64_t d) {
@@ -1351,7 +1357,8 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
 
 extern "C" size_t mi355q_gptq_apply_workspace_bytes(int64_t rows, int64_t d) {
   if (rows <= 0 || d <= 0) return 0;
-  return (static_cast<size_t>(rows) * d + static_cast<size_t>(rows) * kErrLd) * sizeof(float);
+  return (static_cast<size_t>(rows) * d + static_cast<size_t>(rows) * kErrLd) * sizeof(float) +
+         (upd_bf16x3_usable(rows, d) ? upd_bf16x3_workspace_bytes(rows, d, kErrLd) : 0);
 }
 
 extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d, const float* hinv,
@@ -1378,6 +1385,12 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
   float* err = wc + rows * d;
   if (hipMemcpyAsync(wc, w, static_cast<size_t>(rows) * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
     return fail(MI355Q_HIP_ERROR, "hipMemcpyAsync failed");
+  // wide layers: the update behind a group runs on the bf16 matrix cores (exact three-way split of
+  // the errors and of Hinv, xtx_bf16x3.hip); Hinv's planes are made once here
+  const bool split_upd = upd_bf16x3_usable(rows, d);
+  void* upd_ws = err + rows * kErrLd;
+  if (split_upd)
+    if (int32_t s = upd_bf16x3_prepare(hinv, d, upd_ws, st)) return s;
   const double qmax = static_cast<double>((1 << (bits - 1)) - 1), qmin = -static_cast<double>(1 << (bits - 1));
   ApplyArgs a{};
   a.w = wc; a.rows = static_cast<int>(rows); a.d = static_cast<int>(d); a.hinv = hinv; a.scale = scale;
@@ -1426,9 +1439,13 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
     }
     if (g1 < a.d) {
       // W[:, g1:] -= err[:, group] @ Hinv[g0:g1, g1:]
-      GemmArgs<float> g{err, kErrLd, 1, hinv + static_cast<long long>(g0) * d + g1, d, 1, wc + g1, d, 1,
-                        a.rows, a.d - g1, g1 - g0, -1.0f, 1.0f, 0, 0};
-      if (int32_t s = launch_gemm<float>(g, st)) return s;
+      if (split_upd && (g1 - g0) % 16 == 0 && g1 % 128 == 0) {
+        if (int32_t s = upd_bf16x3(err, kErrLd, rows, d, g0, g1 - g0, g1, wc, upd_ws, st)) return s;
+      } else {
+        GemmArgs<float> g{err, kErrLd, 1, hinv + static_cast<long long>(g0) * d + g1, d, 1, wc + g1, d, 1,
+                          a.rows, a.d - g1, g1 - g0, -1.0f, 1.0f, 0, 0};
+        if (int32_t s = launch_gemm<float>(g, st)) return s;
+      }
     }
   }
   MI355Q_CHECK_LAUNCH("gptq apply launch");

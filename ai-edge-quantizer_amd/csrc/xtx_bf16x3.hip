@@ -209,6 +209,125 @@ __global__ __launch_bounds__(256) void xtx_bf16x3_kernel(XtxArgs a) {
       }
 }
 
+// ---- the same exact split for GPTQ's update behind a group of columns (gptq.hip):
+//   W[:, g1:] -= E @ Hinv[g0:g1, g1:],  E = the group's errors [rows, kk] float32 (kk <= 256).
+// Hinv's planes are made once per call by xtx_split_kernel (x = Hinv: "token" = row k of Hinv,
+// "feature" = column j), E's per group by upd_split_err_kernel; upd_bf16x3_kernel is the product
+// kernel above with a rectangular grid, 16 k tiles and a read-modify-write epilogue.
+// grid (rows / 8), 256 threads: thread -> (row, chunk of 8 k); e[row][k] with leading dimension ld
+__global__ __launch_bounds__(256) void upd_split_err_kernel(const float* __restrict__ e, int rows, int ld, int kk,
+                                                           unsigned char* __restrict__ planes) {
+  const int chunks = kk / 8;                       // per row
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int row = idx / chunks, ch = idx % chunks;
+  if (row >= rows) return;
+  const float4 lo4 = *reinterpret_cast<const float4*>(e + static_cast<long long>(row) * ld + ch * 8);
+  const float4 hi4 = *reinterpret_cast<const float4*>(e + static_cast<long long>(row) * ld + ch * 8 + 4);
+  float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+  const int kt = ch >> 1, cs = (ch & 1) ^ ((row >> 3) & 1);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool finite = (__float_as_uint(v[j]) & 0x7F800000u) != 0x7F800000u;
+      const unsigned bits = bf16_rne_bits(v[j]);
+      w[j >> 1] |= bits << (16 * (j & 1));
+      v[j] = finite ? v[j] - __uint_as_float(bits << 16) : 0.f;
+    }
+    unsigned char* dst = planes + ((static_cast<long long>(kt) * 3 + p) * rows + row) * kRowB + cs * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+struct UpdArgs {
+  const unsigned char* eplanes;   // [k tile][3][rows][32 B]
+  const unsigned char* hplanes;   // [k tile of Hinv rows][3][d][32 B]
+  int rows, d;
+  int kt_count;                   // k tiles of the group
+  int h_kt0;                      // first k tile of the group in Hinv (g0 / 16)
+  int col0;                       // first output column (g1)
+  float* w;                       // [rows, d]
+};
+
+// grid (column tiles, row tiles)
+__global__ __launch_bounds__(256) void upd_bf16x3_kernel(UpdArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[2][2], lo[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = 0.f;
+  const int frow = lane & 31;
+  const int fch = ((lane >> 5) ^ ((frow >> 3) & 1)) * 16;
+  const int offA = (wr * 64 + frow) * kRowB + fch, offB = kOperandB + (wc * 64 + frow) * kRowB + fch;
+  const long long strideA = static_cast<long long>(a.rows) * kRowB, strideB = static_cast<long long>(a.d) * kRowB;
+  const unsigned char* gA = a.eplanes + static_cast<long long>(ti) * kPlaneTileB + lane * 16;
+  const unsigned char* gB = a.hplanes + (static_cast<long long>(a.col0) + static_cast<long long>(tj) * kTile) * kRowB + lane * 16;
+  auto stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int piece = q * 4 + wave;
+      const int op = piece / 12, r = piece % 12, p = r >> 2, seg = r & 3;
+      const unsigned char* src = op ? gB + (static_cast<long long>(a.h_kt0 + kt) * 3 + p) * strideB + seg * 1024
+                                    : gA + (static_cast<long long>(kt) * 3 + p) * strideA + seg * 1024;
+      unsigned char* dst = lds + buf * (2 * kOperandB) + op * kOperandB + p * kPlaneTileB + seg * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  for (int kt = 0; kt < a.kt_count; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < a.kt_count) stage(kt + 1, buf ^ 1);
+    const unsigned char* img = lds + buf * (2 * kOperandB);
+    bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fa[i][p] = *reinterpret_cast<const bf16x8*>(img + offA + p * kPlaneTileB + i * 32 * kRowB);
+        fb[i][p] = *reinterpret_cast<const bf16x8*>(img + offB + p * kPlaneTileB + i * 32 * kRowB);
+      }
+#define MI355Q_TERM(ACC, PA, PB)                                                                \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], ACC[i][j], 0, 0, 0)
+    MI355Q_TERM(lo, 0, 2);
+    MI355Q_TERM(lo, 1, 1);
+    MI355Q_TERM(lo, 2, 0);
+    MI355Q_TERM(lo, 0, 1);
+    MI355Q_TERM(lo, 1, 0);
+    MI355Q_TERM(acc, 0, 0);
+#undef MI355Q_TERM
+  }
+  // read-modify-write of the tile in two phases (all 64 loads of a lane in flight, then the stores:
+  // one at a time, every store waited for its own load)
+  float* base = a.w + static_cast<long long>(ti * kTile + wr * 64 + 4 * (lane >> 5)) * a.d + a.col0 + tj * kTile + wc * 64 + (lane & 31);
+  float old[2][2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        old[i][j][r] = __builtin_nontemporal_load(base + static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __builtin_nontemporal_store(old[i][j][r] - (acc[i][j][r] + lo[i][j][r]),
+                                    base + static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32);
+}
+
 // c (+)= partial[0] + partial[1] + ... (slices added in order) over the lower-triangular tiles
 __global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict__ partial, int splits, int d,
                                                         int accumulate, float* __restrict__ c) {
@@ -280,6 +399,44 @@ int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspa
                          k0 > 0 ? 1 : 0, p);
   }
   MI355Q_CHECK_LAUNCH("xtx bf16x3 launch");
+  return MI355Q_OK;
+}
+
+// ---- GPTQ update behind a group (see upd_bf16x3_kernel) ----
+bool upd_bf16x3_usable(int64_t rows, int64_t d) {
+  return rows % kTile == 0 && d % kTile == 0 && (d >= 4096 || (d >= 1024 && rows >= 8192)) && getenv("MI355Q_UPD_FP32_MFMA") == nullptr;
+}
+
+size_t upd_bf16x3_workspace_bytes(int64_t rows, int64_t d, int64_t kk_max) {
+  return 2048 + static_cast<size_t>(d / kBK) * 3 * d * kRowB + static_cast<size_t>(kk_max / kBK) * 3 * rows * kRowB;
+}
+
+static unsigned char* upd_hplanes(void* workspace) {
+  return reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(workspace) + 1023) & ~static_cast<uintptr_t>(1023));
+}
+
+// once per call: the planes of Hinv [d, d]
+int32_t upd_bf16x3_prepare(const float* hinv, int64_t d, void* workspace, hipStream_t st) {
+  const int kt = static_cast<int>(d / kBK);
+  hipLaunchKernelGGL(xtx_split_kernel, dim3(static_cast<unsigned>(d / 64), static_cast<unsigned>((kt + 1) / 2)), dim3(256), 0, st,
+                     hinv, static_cast<int>(d), 0LL, static_cast<long long>(d), kt, upd_hplanes(workspace));
+  MI355Q_CHECK_LAUNCH("gptq update planes launch");
+  return MI355Q_OK;
+}
+
+// w[:, g1:] -= err[:, 0:kk] @ hinv[g0:g0+kk, g1:]   (kk a multiple of 16, g0 of 16, g1 and d - g1 of 128)
+int32_t upd_bf16x3(const float* err, int64_t ld, int64_t rows, int64_t d, int64_t g0, int64_t kk, int64_t g1, float* w,
+                   void* workspace, hipStream_t st) {
+  unsigned char* hplanes = upd_hplanes(workspace);
+  unsigned char* eplanes = hplanes + static_cast<size_t>(d / kBK) * 3 * d * kRowB;
+  const int chunks = static_cast<int>(kk / 8);
+  hipLaunchKernelGGL(upd_split_err_kernel, dim3(static_cast<unsigned>((rows * chunks + 255) / 256)), dim3(256), 0, st, err,
+                     static_cast<int>(rows), static_cast<int>(ld), static_cast<int>(kk), eplanes);
+  UpdArgs a{eplanes, hplanes, static_cast<int>(rows), static_cast<int>(d), static_cast<int>(kk / kBK),
+            static_cast<int>(g0 / kBK), static_cast<int>(g1), w};
+  hipLaunchKernelGGL(upd_bf16x3_kernel, dim3(static_cast<unsigned>((d - g1) / kTile), static_cast<unsigned>(rows / kTile)),
+                     dim3(256), 4 * kOperandB, st, a);
+  MI355Q_CHECK_LAUNCH("gptq update launch");
   return MI355Q_OK;
 }
 

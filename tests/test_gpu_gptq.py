@@ -373,6 +373,13 @@ def test_workspaces_and_outputs_are_written_before_they_are_read(m, monkeypatch)
     w = torch.randn((256, 2048), generator=gen, device="cuda") * 0.02
     scale = (w.abs().amax(dim=1) / 7.0).contiguous()
     out.append(m.ops.gptq_apply(w, hinv, scale, None, 1, 0, 4, False, False, 8).clone())
+    # d >= 4096 and 128-row multiples: the update behind a group on the bf16 matrix cores (its planes
+    # of Hinv and of the errors live in the workspace too)
+    x = torch.randn((8192, 4096), generator=gen, device="cuda")
+    hinv, _ = m.ops.gptq_hinv(m.ops.gptq_xtx(x, 2.0 / 8192), 0.01)
+    w = torch.randn((128, 4096), generator=gen, device="cuda") * 0.02
+    scale = (w.abs().amax(dim=1) / 7.0).contiguous()
+    out.append(m.ops.gptq_apply(w, hinv, scale, None, 1, 0, 4, False, False, 8).clone())
     return out
 
   monkeypatch.setattr(rt, "empty", lambda shape, dtype: torch.zeros(shape, dtype=dtype, device=rt.device()))
