@@ -302,7 +302,10 @@ int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d, double damp_facto
  * of the block (rank-1, FP32, product rounded before the subtraction as NumPy's
  * np.outer does) and then to all later columns with MFMA GEMMs (lazy batch
  * updates: the later blocks of a group of four catch up inside their own
- * kernel, the columns beyond the group get one K = 256 product per group).
+ * kernel, the columns beyond the group get one K = 256 product per group; for
+ * rows and d multiples of 128 with d >= 4096 or rows >= 8192 that product runs on
+ * the bf16 matrix cores on the exact three-way split of its float32 operands,
+ * csrc/xtx_bf16x3.hip -- MI355Q_UPD_FP32_MFMA=1 keeps the FP32 MFMA product).
  * ref: algorithms/uniform_quantize/gptq.py:131-216 (_apply_gptq, blocksize 64)
  *   w [rows, d] float32 (not modified); hinv float32 [d, d]
  *   scale_mode 0: scale[1] (TENSORWISE); 1: scale[rows] (CHANNELWISE);
