@@ -243,7 +243,10 @@ def more_extras(torch, ops, gen, xs) -> dict:
                                  "roofline": {"bound": "mfma", "achieved": round(2 * rows * d * d / ms_a / 1e9, 1),
                                               "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                               "frac": round(2 * rows * d * d / ms_a / 1e9 / MFMA_F32_PEAK_TF, 4),
-                                              "note": "latency-bound on the column-serial quantize -> divide -> update chain"}}}
+                                              "note": ("latency-bound on the column-serial quantize -> divide -> update chain"
+                                                       + ("; 'achieved' counts float32 products: at this width the update behind a group of"
+                                                          " columns runs as six bf16 MFMA products per float32 product (xtx_bf16x3.hip), so the"
+                                                          " FP32-MFMA peak is a yardstick here, not the bound" if d >= 4096 else ""))}}}
     del h, hinv, wq, sc
   out["c5_gptq"] = c5
   return out
