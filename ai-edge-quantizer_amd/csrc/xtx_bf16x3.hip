@@ -328,6 +328,101 @@ __global__ __launch_bounds__(256) void upd_bf16x3_kernel(UpdArgs a) {
                                     base + static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32);
 }
 
+// Two column tiles per workgroup: the E fragments are read once for both, a k tile carries 48 MFMAs
+// per wave between two barriers instead of 24, and the prologue is paid once per 128 x 256 outputs.
+// All six terms go to one accumulator per tile (16 k tiles: the cross terms' rounding against the
+// x1 y1 sums is far below the float32 update's own).
+__global__ __launch_bounds__(256) void upd2_bf16x3_kernel(UpdArgs a, int ntj) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  constexpr int kImage = 3 * kOperandB;            // A, B0, B1
+  const int ti = blockIdx.y, tj0 = 2 * blockIdx.x;
+  const bool two = tj0 + 1 < ntj;
+  const int tj1 = two ? tj0 + 1 : tj0;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][i][j][r] = 0.f;
+  const int frow = lane & 31;
+  const int fch = ((lane >> 5) ^ ((frow >> 3) & 1)) * 16;
+  const int offA = (wr * 64 + frow) * kRowB + fch, offB = kOperandB + (wc * 64 + frow) * kRowB + fch;
+  const long long strideA = static_cast<long long>(a.rows) * kRowB, strideB = static_cast<long long>(a.d) * kRowB;
+  const unsigned char* gA = a.eplanes + static_cast<long long>(ti) * kPlaneTileB + lane * 16;
+  const unsigned char* gB0 = a.hplanes + (static_cast<long long>(a.col0) + static_cast<long long>(tj0) * kTile) * kRowB + lane * 16;
+  const unsigned char* gB1 = a.hplanes + (static_cast<long long>(a.col0) + static_cast<long long>(tj1) * kTile) * kRowB + lane * 16;
+  auto stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int piece = q * 4 + wave;                 // 0 .. 35
+      const int op = piece / 12, r = piece % 12, p = r >> 2, seg = r & 3;
+      const unsigned char* src = op == 0 ? gA + (static_cast<long long>(kt) * 3 + p) * strideA + seg * 1024
+                                         : (op == 1 ? gB0 : gB1) + (static_cast<long long>(a.h_kt0 + kt) * 3 + p) * strideB + seg * 1024;
+      unsigned char* dst = lds + buf * kImage + op * kOperandB + p * kPlaneTileB + seg * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  for (int kt = 0; kt < a.kt_count; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < a.kt_count) stage(kt + 1, buf ^ 1);
+    const unsigned char* img = lds + buf * kImage;
+    bf16x8 fa[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fa[i][p] = *reinterpret_cast<const bf16x8*>(img + offA + p * kPlaneTileB + i * 32 * kRowB);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      bf16x8 fb[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          fb[i][p] = *reinterpret_cast<const bf16x8*>(img + b * kOperandB + offB + p * kPlaneTileB + i * 32 * kRowB);
+#define MI355Q_TERM(PA, PB)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+      acc[b][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[b][i][j], 0, 0, 0)
+      MI355Q_TERM(0, 2);
+      MI355Q_TERM(1, 1);
+      MI355Q_TERM(2, 0);
+      MI355Q_TERM(0, 1);
+      MI355Q_TERM(1, 0);
+      MI355Q_TERM(0, 0);
+#undef MI355Q_TERM
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    if (b == 1 && !two) break;
+    float* base = a.w + static_cast<long long>(ti * kTile + wr * 64 + 4 * (lane >> 5)) * a.d + a.col0 +
+                  (b ? tj1 : tj0) * kTile + wc * 64 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {      // 32 loads of a lane in flight, then their stores
+      float old[2][16];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          old[j][r] = __builtin_nontemporal_load(base + static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __builtin_nontemporal_store(old[j][r] - acc[b][i][j][r],
+                                      base + static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32);
+    }
+  }
+}
+
 // c (+)= partial[0] + partial[1] + ... (slices added in order) over the lower-triangular tiles
 __global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict__ partial, int splits, int d,
                                                         int accumulate, float* __restrict__ c) {
@@ -434,8 +529,22 @@ int32_t upd_bf16x3(const float* err, int64_t ld, int64_t rows, int64_t d, int64_
                      static_cast<int>(rows), static_cast<int>(ld), static_cast<int>(kk), eplanes);
   UpdArgs a{eplanes, hplanes, static_cast<int>(rows), static_cast<int>(d), static_cast<int>(kk / kBK),
             static_cast<int>(g0 / kBK), static_cast<int>(g1), w};
-  hipLaunchKernelGGL(upd_bf16x3_kernel, dim3(static_cast<unsigned>((d - g1) / kTile), static_cast<unsigned>(rows / kTile)),
-                     dim3(256), 4 * kOperandB, st, a);
+  const int ntj = static_cast<int>((d - g1) / kTile);
+  static const bool two_tiles = getenv("MI355Q_UPD_ONE_TILE") == nullptr;
+  if (two_tiles && ntj >= 8) {
+    static bool raised = false;     // 72 KB of dynamic LDS has to be asked for once
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(upd2_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              6 * kOperandB) != hipSuccess)
+        return fail(MI355Q_HIP_ERROR, "hipFuncSetAttribute failed");
+      raised = true;
+    }
+    hipLaunchKernelGGL(upd2_bf16x3_kernel, dim3(static_cast<unsigned>((ntj + 1) / 2), static_cast<unsigned>(rows / kTile)),
+                       dim3(256), 6 * kOperandB, st, a, ntj);
+  } else {
+    hipLaunchKernelGGL(upd_bf16x3_kernel, dim3(static_cast<unsigned>(ntj), static_cast<unsigned>(rows / kTile)),
+                       dim3(256), 4 * kOperandB, st, a);
+  }
   MI355Q_CHECK_LAUNCH("gptq update launch");
   return MI355Q_OK;
 }

@@ -178,6 +178,26 @@ def test_apply_gate_proj_16384x2048_rows_against_oracle(m):
                        q[idx].cpu().numpy(), ref, 3e-3 if bits == 8 else parity_rates.T2)
 
 
+def test_apply_split_update_with_an_odd_number_of_column_tiles(m):
+  """d = 4224 = 33 tiles of 128 columns: the update behind a group runs on the bf16 matrix cores
+  (d >= 4096) two column tiles per workgroup, and behind every other group the last workgroup of
+  a row has a single tile left. 16 rows against the oracle with the same Hinv."""
+  torch = m.torch
+  d = 4224
+  x = _activations(torch, 16, 640, d, 5500)
+  hinv, info = m.ops.gptq_hinv(m.ops.gptq_xtx(x.reshape(-1, d), 2.0 / 16), 0.01)
+  assert int(info.item()) == 0
+  gen = torch.Generator(device="cuda").manual_seed(5501)
+  w = torch.randn((128, d), generator=gen, device="cuda") * 0.02
+  scale = _channelwise_scale(torch, w, 4)
+  q = m.ops.gptq_apply(w, hinv, scale, None, 1, 0, 4, False, False, 8)
+  rows = np.r_[0:8, 120:128]
+  idx = torch.from_numpy(rows).cuda()
+  ref = _oracle_rows(w[idx].cpu().numpy(), scale[idx].cpu().numpy(), hinv.cpu().numpy(), 4)
+  parity_rates.check("gptq apply [128,4224] int4 channelwise, 16 rows vs oracle (same Hinv)",
+                     q[idx].cpu().numpy(), ref, parity_rates.T2)
+
+
 def test_down_proj_through_get_tensor_quant_params(m, big):
   """The public entry point at the C5 shape: Hessian handed over as the HBM resident the
   calibrator produces, result rows against the oracle fed the same inverse."""
