@@ -195,18 +195,25 @@ __global__ __launch_bounds__(256) void xtx_bf16x3_kernel(XtxArgs a) {
 
   // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   float* c = a.c + (a.partial ? static_cast<long long>(blockIdx.y) * a.d * a.d : 0);
+  float* base = c + static_cast<long long>(ti * kTile + wr * 64 + 4 * (lane >> 5)) * a.d + tj * kTile + wc * 64 + (lane & 31);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    // (a later slab adds to the product so far: the 32 loads of a lane go out together, then the
+    // stores -- one at a time, every store waited for its own load)
+    float old[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        old[j][r] = a.accumulate ? base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] : 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = ti * kTile + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int col = tj * kTile + wc * 64 + j * 32 + (lane & 31);
-        float* dst = c + static_cast<long long>(row) * a.d + col;
         const float v = (top[i][j][r] + acc[i][j][r]) + lo[i][j][r];
-        *dst = a.accumulate ? *dst + v : v;
+        base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] = a.accumulate ? old[j][r] + v : v;
       }
+  }
 }
 
 // ---- the same exact split for GPTQ's update behind a group of columns (gptq.hip):
