@@ -40,6 +40,12 @@ struct Rccl {
 
 Rccl g_rccl;
 std::once_flag g_rccl_once;
+char g_rccl_why[256] = "unknown";    // why binding failed, captured when it happened (dlerror() is one-shot)
+
+void keep_why(const char* what) {
+  const char* e = dlerror();
+  snprintf(g_rccl_why, sizeof(g_rccl_why), "%s: %s", what, e ? e : "unknown");
+}
 
 template <typename F>
 bool bind(void* h, const char* name, F* out) {
@@ -52,7 +58,7 @@ const Rccl* rccl() {
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);   // the copy PyTorch-ROCm brought
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) return;
+    if (!h) { keep_why("dlopen(librccl.so.1)"); return; }
     Rccl& r = g_rccl;
     r.handle = h;
     r.ok = bind(h, "ncclGetUniqueId", &r.GetUniqueId) && bind(h, "ncclCommInitRank", &r.CommInitRank) &&
@@ -60,11 +66,12 @@ const Rccl* rccl() {
            bind(h, "ncclCommUserRank", &r.CommUserRank) && bind(h, "ncclAllReduce", &r.AllReduce) &&
            bind(h, "ncclAllGather", &r.AllGather) && bind(h, "ncclGroupStart", &r.GroupStart) &&
            bind(h, "ncclGroupEnd", &r.GroupEnd) && bind(h, "ncclGetErrorString", &r.GetErrorString);
+    if (!r.ok) keep_why("dlsym");
   });
   return g_rccl.ok ? &g_rccl : nullptr;
 }
 
-int32_t no_rccl() { return fail(MI355Q_RCCL_ERROR, "librccl.so.1 could not be loaded: %s", dlerror()); }
+int32_t no_rccl() { return fail(MI355Q_RCCL_ERROR, "librccl.so.1 could not be bound (%s)", g_rccl_why); }
 
 #define MI355Q_RCCL(call, what)                                                             \
   do {                                                                                      \

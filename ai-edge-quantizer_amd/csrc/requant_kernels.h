@@ -69,6 +69,7 @@ __device__ __forceinline__ float make_scale(uint32_t absmax_bits, const float* c
   if ((absmax_bits & 0x7FFFFFFFu) > 0x7F800000u) bound = u2f(absmax_bits);  // NaN
   if (clip != nullptr) {
     float pos = clip[g], neg = -clip[g];
+    const bool clip_nan = pos != pos;   // np.minimum / np.maximum with the f16 cap keep a NaN clip NaN
     if constexpr (BLOCKWISE) {
       // f16 scale range cap (ref :529-550): +65280*(2^bits-1), -65280*2^bits
       pos = fminf(pos, 65280.0f * static_cast<float>((1 << BITS) - 1));
@@ -77,7 +78,7 @@ __device__ __forceinline__ float make_scale(uint32_t absmax_bits, const float* c
     // np.clip(bound, neg, pos) = minimum(maximum(bound, neg), pos), both NaN-propagating:
     // a NaN bound stays NaN (fminf / fmaxf would return the other operand), a NaN clip makes it NaN
     if (bound == bound) bound = fminf(fmaxf(bound, neg), pos);
-    if (pos != pos) bound = pos;
+    if (clip_nan) bound = clip[g];
   }
   float s = bound / QRange<BITS>::qmax;
   if constexpr (BLOCKWISE) s = round_scale_blockwise(s, half_bits);

@@ -539,13 +539,11 @@ int32_t upd_bf16x3(const float* err, int64_t ld, int64_t rows, int64_t d, int64_
   const int ntj = static_cast<int>((d - g1) / kTile);
   static const bool two_tiles = getenv("MI355Q_UPD_ONE_TILE") == nullptr;
   if (two_tiles && ntj >= 8) {
-    static bool raised = false;     // 72 KB of dynamic LDS has to be asked for once
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(upd2_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              6 * kOperandB) != hipSuccess)
-        return fail(MI355Q_HIP_ERROR, "hipFuncSetAttribute failed");
-      raised = true;
-    }
+    // 72 KB of dynamic LDS has to be asked for; the attribute belongs to the current device and a
+    // process may drive several, so it is set on every call (a host-side table write)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(upd2_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            6 * kOperandB) != hipSuccess)
+      return fail(MI355Q_HIP_ERROR, "hipFuncSetAttribute failed");
     hipLaunchKernelGGL(upd2_bf16x3_kernel, dim3(static_cast<unsigned>((ntj + 1) / 2), static_cast<unsigned>(rows / kTile)),
                        dim3(256), 6 * kOperandB, st, a, ntj);
   } else {

@@ -1,27 +1,52 @@
 """GPTQ (Hessian-aware weight quantization), GPU backed.
 
-Mirror of ref: algorithms/uniform_quantize/gptq.py. calibrate() builds
-H = (2/num_samples) X^T X with the FP32 MFMA GEMM, _prepare_hessian_inverse runs
-the blocked FP64 Cholesky / inverse on the GPU and _apply_gptq the column-serial
-OBS update (mi355q_gptq_*). QSVs stay NumPy dictionaries at this interface, as in
-the reference; the min/max up-front scales are computed exactly as there.
+Mirror of ref: algorithms/uniform_quantize/gptq.py. calibrate() collects H = (2/num_samples) X^T X
+on the matrix cores, _prepare_hessian_inverse runs the blocked Cholesky / inverse on the GPU and
+_apply_gptq the column-serial OBS update (mi355q_gptq_*). QSVs stay dictionaries at this
+interface, as in the reference; the min/max up-front scales are computed exactly as there.
+
+What is organised differently from the reference (same values):
+  * a Hessian lives in HBM as a `HessianAccumulator`: the sample-weighted mean the reference's
+    merge rule chains per sample (utils/qsv_utils.py:71-102) equals (2/N) X^T X over all tokens seen,
+    so the tokens of successive samples are collected in a slab and multiplied 16384 at a time;
+  * inside `Calibrator` only tensors some GPTQ op will read a Hessian from get one (the reference
+    computes one for every runtime tensor of the op, outputs included, that nothing ever reads);
+  * inside `ParamsGenerator`'s batching block the ops that share a Hessian (q / k / v, gate / up)
+    are applied as ONE row-concatenated update, the up-front scales are computed on the device and
+    the factorization's `info` is checked once per block instead of per tensor.
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 from collections.abc import Mapping, MutableMapping, Sequence
-from typing import Any
+from typing import Any, Optional
 
 import numpy as np
 
 from ... import ops
 from ... import qtyping
+from ... import requant_queue
 from ... import runtime as rt
 from ..utils import common_utils
 from . import common_quantize
 from . import uniform_quantize_tensor
 
 ALGORITHM_KEY = "GPTQ"
+
+# Names of the runtime tensors whose Hessian some op will read (set by Calibrator for the duration
+# of a walk); None = every tensor, as the reference does.
+_HESSIAN_READERS: Optional[set] = None
+
+
+@contextlib.contextmanager
+def hessians_only_for(names: Optional[set]):
+  global _HESSIAN_READERS
+  saved, _HESSIAN_READERS = _HESSIAN_READERS, names
+  try:
+    yield
+  finally:
+    _HESSIAN_READERS = saved
 
 
 def calibrate(tfl_op, graph_info: qtyping.GraphInfo,
@@ -39,27 +64,141 @@ def calibrate(tfl_op, graph_info: qtyping.GraphInfo,
     if res is None:
       continue
     name, content, qsv = res
-    qsv["hessian"] = hessian_of(content, qsv["num_samples"])
+    if _HESSIAN_READERS is None or name in _HESSIAN_READERS:
+      qsv["hessian"] = hessian_of(content, qsv["num_samples"])
     out[name] = qsv
   return out
+
+
+class HessianAccumulator(rt.HbmArray):
+  """float64 [d, d] = the sample-weighted mean of (2/n_i) X_i^T X_i over the samples added so far.
+
+  The mean over samples i of H_i weighted by n_i is (2/N) sum_i X_i^T X_i, N = sum n_i: tokens that
+  have not been multiplied yet wait in a float32 slab and leave SLAB_TOKENS at a time through
+  mi355q_gptq_xtx_f32 (the bf16-split product needs >= 1024 tokens to run at all, and one product
+  of 16384 tokens costs a tenth of 32 products of 512); the slab's Hessian then joins the running
+  mean through mi355q_gptq_hessian_merge_f64, the reference's rule at slab granularity. Reading
+  the array (device_tensor, np.asarray, ...) multiplies what is pending first."""
+  SLAB_TOKENS = 16384
+
+  def __init__(self, d: int):  # pylint: disable=super-init-not-called
+    self.d = int(d)
+    self._mean = None             # float64 [d, d] over _n_done samples
+    self._n_done = 0.0
+    self._slab = None             # float32 [capacity, d]
+    self._fill = 0
+    self._n_pending = 0.0
+    self._host = None
+    self.cache = {}
+    self.packed = None
+
+  @classmethod
+  def of(cls, x2d, num_samples: float) -> "HessianAccumulator":
+    acc = cls(x2d.shape[1])
+    acc.add(x2d, num_samples)
+    return acc
+
+  def add(self, x2d, num_samples: float) -> None:
+    """x2d: float32 device tensor [tokens, d] (copied: the caller's buffer may change)."""
+    import torch
+    t = int(x2d.shape[0])
+    self._host = None
+    self.cache.clear()
+    if t >= self.SLAB_TOKENS:        # a slab's worth on its own: multiplied where it lies
+      self.flush()
+      self._join(ops.gptq_xtx(x2d.contiguous(), 2.0 / float(num_samples)), float(num_samples))
+      return
+    if self._slab is not None and self._fill + t > self._slab.shape[0] and self._fill:
+      if self._slab.shape[0] < self.SLAB_TOKENS and self._fill + t <= self.SLAB_TOKENS:
+        grown = torch.empty((self.SLAB_TOKENS, self.d), dtype=torch.float32, device=x2d.device)
+        grown[:self._fill].copy_(self._slab[:self._fill])
+        self._slab = grown
+      else:
+        self.flush()
+    if self._slab is None or self._slab.shape[0] < t:
+      self._slab = torch.empty((t, self.d), dtype=torch.float32, device=x2d.device)
+    self._slab[self._fill:self._fill + t].copy_(x2d)
+    self._fill += t
+    self._n_pending += float(num_samples)
+
+  def _join(self, h, n: float) -> None:
+    """running mean <- weighted mean with Hessian h of n samples (ref utils/qsv_utils.py:71-88)."""
+    if self._mean is None:
+      self._mean, self._n_done = h, n
+    else:
+      self._mean = ops.gptq_hessian_merge(self._mean, self._n_done, h, n)
+      self._n_done += n
+
+  def absorb(self, other: "HessianAccumulator") -> None:
+    """self <- the mean over both sets of samples."""
+    if other._fill:   # pylint: disable=protected-access
+      self.add(other._slab[:other._fill], other._n_pending)   # pylint: disable=protected-access
+    if other._mean is not None:   # pylint: disable=protected-access
+      self.flush()
+      self._join(other._mean, other._n_done)   # pylint: disable=protected-access
+      self._host = None
+      self.cache.clear()
+
+  def flush(self) -> None:
+    if not self._fill:
+      return
+    self._join(ops.gptq_xtx(self._slab[:self._fill], 2.0 / self._n_pending), self._n_pending)
+    self._fill, self._n_pending = 0, 0.0
+
+  def finalize(self) -> None:
+    """Multiplies what is pending and gives the slab's HBM back."""
+    self.flush()
+    self._slab = None
+
+  @property
+  def device_tensor(self):
+    self.flush()
+    return self._mean
+
+  @device_tensor.setter
+  def device_tensor(self, value) -> None:
+    self._mean, self._fill, self._n_pending = value, 0, 0.0
+
+  @property
+  def shape(self):
+    return (self.d, self.d)
+
+  @property
+  def ndim(self) -> int:
+    return 2
+
+  @property
+  def dtype(self):
+    return np.dtype(np.float64)
+
+  @property
+  def size(self) -> int:
+    return self.d * self.d
+
+  @property
+  def nbytes(self) -> int:
+    return self.d * self.d * 8
+
+  def __repr__(self):
+    return f"HessianAccumulator(d={self.d}, samples={self._n_done + self._n_pending:g}, pending_tokens={self._fill})"
 
 
 def hessian_of(tensor_content: np.ndarray, num_samples):
   """(2.0 / num_samples) * x.T.dot(x), x = content.reshape(-1, last) (ref :100-107).
 
-  float32 content: X^T X on the FP32 MFMA units, scaled into float64 (NumPy's
-  promotion of `2.0 / np.array(n)`). float64 content (the reference's own test
-  feeds 1e39): the FP64 MFMA GEMM.
+  float32 content: X^T X on the matrix cores, scaled into float64 (NumPy's promotion of
+  `2.0 / np.array(n)`), resident in HBM. float64 content (the reference's own test feeds 1e39):
+  the FP64 MFMA GEMM.
   """
   alpha = 2.0 / np.asarray(num_samples)
   rt.require_gpu()
   rec = rt.staged(tensor_content)        # the calibrator put this sample's activations in HBM
   if rec is not None and tensor_content.dtype == np.float32:
     xd = rec["dev"].reshape(-1, tensor_content.shape[-1])
-    return rt.HbmArray(ops.gptq_xtx(xd, float(alpha)))
+    return HessianAccumulator.of(xd, float(np.asarray(num_samples)))
   x = np.ascontiguousarray(tensor_content.reshape([-1, tensor_content.shape[-1]]))
   if x.dtype == np.float32:   # stays in HBM: merged per sample and consumed by the GPU again
-    return rt.HbmArray(ops.gptq_xtx(rt.to_device(x), float(alpha)))
+    return HessianAccumulator.of(rt.to_device(x), float(np.asarray(num_samples)))
   if x.dtype == np.float64:
     xd = rt.to_device(x)
     return alpha * rt.to_numpy(ops.gemm(xd, xd, trans_a=True))
@@ -69,9 +208,13 @@ def hessian_of(tensor_content: np.ndarray, num_samples):
 def _prepare_hessian_inverse(hessian: np.ndarray, damp_factor: float = 0.01) -> np.ndarray:
   """Damped inverse through Cholesky; float32 result (ref :111-128)."""
   hinv, info = _device_hessian_inverse(hessian, damp_factor)
-  if int(info.item()) != 0:
-    raise np.linalg.LinAlgError("Matrix is not positive definite")
+  _check_info(info)
   return rt.to_numpy(hinv)
+
+
+def _check_info(info) -> None:
+  if int(info.max().item() if info.numel() > 1 else info.item()) != 0:
+    raise np.linalg.LinAlgError("Matrix is not positive definite")
 
 
 def _device_hessian_inverse(hessian, damp_factor: float = 0.01):
@@ -91,6 +234,16 @@ def torch_f64():
   return torch.float64
 
 
+def _scale_mode(scale_size: int, rows: int, d: int, blockwise: bool, block_size: int):
+  if blockwise:
+    return 2, block_size
+  if scale_size == 1:
+    return 0, 0
+  if scale_size == rows:
+    return 1, 0
+  raise NotImplementedError(f"scale of {scale_size} values for a [{rows}, {d}] weight")
+
+
 def _apply_gptq(tensor_content: np.ndarray, quant_params: qtyping.UniformQuantParams,
                 activation_tensor_qsv: Mapping[str, Any],
                 tensor_quant_config: qtyping.TensorQuantizationConfig,
@@ -107,14 +260,7 @@ def _apply_gptq(tensor_content: np.ndarray, quant_params: qtyping.UniformQuantPa
   hinv, info = _device_hessian_inverse(activation_tensor_qsv["hessian"], 0.01)
   scale, zp = quant_params.scale, quant_params.zero_point
   blockwise = uniform_quantize_tensor.is_blockwise(tensor_quant_config.granularity)
-  if blockwise:
-    mode, bs = 2, quant_params.block_size
-  elif scale.size == 1:
-    mode, bs = 0, 0
-  elif scale.size == rows:
-    mode, bs = 1, 0
-  else:
-    raise NotImplementedError(f"scale shape {scale.shape} for a [{rows}, {d}] weight")
+  mode, bs = _scale_mode(scale.size, rows, d, blockwise, quant_params.block_size)
   if not np.issubdtype(zp.dtype, np.signedinteger):
     raise ValueError(f"zero_points need to be {np.signedinteger}. But the actual type is"
                      f" {zp.dtype}.")
@@ -128,10 +274,139 @@ def _apply_gptq(tensor_content: np.ndarray, quant_params: qtyping.UniformQuantPa
   diff_bits = min(32, np.result_type(np.int8, zp.dtype).itemsize * 8)
   q = ops.gptq_apply(rt.to_device(tensor_content), hinv, s_dev, z_dev, mode, bs,
                      quant_params.num_bits, narrow, zp.dtype.itemsize >= 4, diff_bits)
-  if int(info.item()) != 0:
-    raise np.linalg.LinAlgError("Matrix is not positive definite")
+  _check_info(info)
   return dataclasses.replace(quant_params, quantized_data=rt.quantized_result(
       q, quant_params.num_bits, tensor_content.nbytes, tensor_content.shape))
+
+
+# ------------------------------------------------------------------ queued applies ---
+class _Pending(requant_queue.PendingArray):
+  """Placeholder whose device tensor the apply queue sets when its group has been issued."""
+
+  @property
+  def device_tensor(self):
+    if self._tensor is None:
+      self._queue.flush()
+    return self._tensor
+
+  @device_tensor.setter
+  def device_tensor(self, value) -> None:
+    self._tensor = value
+
+  @property
+  def resolved(self) -> bool:
+    return self._tensor is not None
+
+  def numpy(self) -> np.ndarray:
+    if self._host is None:
+      self._host = self.device_tensor.cpu().numpy()
+    return self._host
+
+
+class _ApplyQueue:
+  """GPTQ weights met inside `requant_queue.batching()`: symmetric channel- / blockwise targets.
+
+  submit(): the weight goes to HBM, its up-front min/max scales are made by the fused launch that
+  serves the min/max algorithm (mi355q_requant_sym_f32 with only the scale output: the same
+  arithmetic as init_tensor_min_max + tensor_zp_scale_from_min_max, bit for bit), and the caller
+  gets placeholders. Weights that read the same Hessian with the same target wait for each other;
+  when a different Hessian arrives (or the block exits) they leave as ONE row-concatenated
+  mi355q_gptq_apply_f32 -- rows are independent (ref :131-216), the column-serial chain is paid
+  once. `info` of every inverse used is checked when the block exits."""
+
+  def __init__(self, host_queue):
+    self._key = None
+    self._entries: list = []
+    self._hinv = None
+    self._infos: list = []
+    self._scales: list = []          # (placeholder, params) of per-row scales to hand over as ndarrays
+    self.stats = host_queue.stats
+    self.stats.setdefault("gptq_tensors", 0)
+    self.stats.setdefault("gptq_applies", 0)
+
+  def submit(self, w_dev, hessian, cfg, block_size: int, shape):
+    import torch
+    rows, d = shape
+    bits = cfg.num_bits
+    res = ops.requant_sym(w_dev, block_size, bits, want_q=False)
+    scale_dev = res["scale"]
+    key = (id(hessian), bits, block_size)
+    if key != self._key:
+      self.flush()
+      self._key = key
+      self._hinv, info = _device_hessian_inverse(hessian, 0.01)
+      self._infos.append(info)
+    scale = _Pending(((rows, d // block_size) if block_size else (rows, 1)), np.dtype(np.float32), self)
+    scale.device_tensor = scale_dev.reshape(scale.shape)
+    if bits in (2, 4):
+      packed = _Pending((rows * d * bits // 8,), np.dtype(np.uint8), self)
+      q = _Pending((rows, d), np.dtype(np.int8), self)
+      q.packed = packed
+    else:
+      q, packed = _Pending((rows, d), np.dtype(np.int8), self), None
+    self._entries.append((w_dev, scale_dev.reshape(-1), q, packed, bits, block_size))
+    self.stats["gptq_tensors"] += 1
+    del torch
+    return scale, q
+
+  def flush(self) -> None:
+    if not self._entries:
+      return
+    import torch
+    entries, self._entries = self._entries, []
+    _, _, _, _, bits, bs = entries[0]
+    if len(entries) == 1:
+      w, s = entries[0][0], entries[0][1]
+    else:
+      w = torch.cat([e[0] for e in entries], dim=0)
+      s = torch.cat([e[1] for e in entries])
+    mode = 2 if bs else 1
+    q_all = ops.gptq_apply(w, self._hinv, s, None, mode, bs, bits, bits >= 8, False, 8)
+    self.stats["gptq_applies"] += 1
+    packed_all = ops.pack_bits(q_all, bits) if bits in (2, 4) else None
+    row0 = 0
+    d = w.shape[1]
+    for w_e, _, q, packed, _, _ in entries:
+      rows = w_e.shape[0]
+      q.device_tensor = q_all[row0:row0 + rows]
+      if packed is not None:
+        per = 8 // bits
+        packed.device_tensor = packed_all[row0 * d // per:(row0 + rows) * d // per]
+      row0 += rows
+
+  def attach(self, scale, params) -> None:
+    if params.block_size == 0:
+      self._scales.append((scale, params))
+
+  def complete(self) -> None:
+    """Block exit: last applies out, one copy for all per-row scales, one look at the infos."""
+    import torch
+    self.flush()
+    self._key = self._hinv = None
+    if self._scales:
+      flat = torch.cat([s.device_tensor.reshape(-1) for s, _ in self._scales]).cpu().numpy()
+      pos = 0
+      for s, params in self._scales:
+        n = s.size
+        s._host = flat[pos:pos + n].reshape(s.shape)   # pylint: disable=protected-access
+        pos += n
+        if params.scale is s:
+          object.__setattr__(params, "scale", s._host)   # pylint: disable=protected-access
+      self._scales = []
+    if self._infos:
+      infos, self._infos = self._infos, []
+      _check_info(torch.cat([i.reshape(-1) for i in infos]))
+
+
+def _apply_queue() -> Optional[_ApplyQueue]:
+  host = requant_queue.active()
+  if host is None:
+    return None
+  q = getattr(host, "gptq", None)
+  if q is None:
+    q = host.gptq = _ApplyQueue(host)
+    host.defer(q.complete)
+  return q
 
 
 def get_tensor_quant_params(
@@ -141,11 +416,31 @@ def get_tensor_quant_params(
   """ref :219-300."""
   cfg = tensor_quant_config
   act_qsv = tensor_qsv.get("activation_tensor_qsv") if tensor_qsv else None
-  if (act_qsv is not None and "hessian" in act_qsv and isinstance(tensor_content, np.ndarray)
+  has_hessian = act_qsv is not None and "hessian" in act_qsv
+  if (has_hessian and isinstance(tensor_content, (np.ndarray, rt.HbmArray))
       and tensor_content.dtype == np.float32 and tensor_content.ndim == 2):
     # one upload serves both the min / max below and the update (a Gemma-2B layer is 440 MB)
     rt.require_gpu()
-    tensor_content = rt.HbmArray(rt.to_device(tensor_content))
+    if not isinstance(tensor_content, rt.HbmArray):
+      tensor_content = rt.HbmArray(rt.to_device(tensor_content))
+    queue = _apply_queue()
+    block_size = uniform_quantize_tensor.extract_block_size_from_granularity(cfg.granularity)
+    rows, d = tensor_content.shape
+    if (queue is not None and cfg.symmetric and cfg.num_bits in (2, 4, 8)
+        and (tensor_qsv is None or "min" not in tensor_qsv)
+        and (block_size or cfg.granularity == qtyping.QuantGranularity.CHANNELWISE)
+        and (not block_size or (d % block_size == 0 and block_size % 4 == 0))
+        and common_utils.get_weight_quantized_dim(op_info, tensor_content, cfg.granularity) == (1 if block_size else 0)):
+      w_dev = tensor_content.device_tensor
+      if not w_dev.is_contiguous():
+        w_dev = w_dev.contiguous()
+      scale, q = queue.submit(w_dev, act_qsv["hessian"], cfg, block_size, (rows, d))
+      zp = np.zeros(scale.shape, dtype=np.int8)       # symmetric: zeros cast to the quantized type (ref a2)
+      params = qtyping.UniformQuantParams(
+          scale=scale, zero_point=zp, num_bits=cfg.num_bits, symmetric=True,
+          quantized_dimension=1 if block_size else 0, block_size=block_size, quantized_data=q)
+      queue.attach(scale, params)
+      return params
   if tensor_qsv is None or "min" not in tensor_qsv:
     if tensor_content is None:
       raise ValueError(
@@ -167,6 +462,6 @@ def get_tensor_quant_params(
       quantized_dimension=common_utils.get_weight_quantized_dim(op_info, tensor_content,
                                                                cfg.granularity),
       block_size=uniform_quantize_tensor.extract_block_size_from_granularity(cfg.granularity))
-  if tensor_content is None or act_qsv is None or "hessian" not in act_qsv:
+  if tensor_content is None or not has_hessian:
     return params
   return _apply_gptq(tensor_content, params, act_qsv, cfg)

@@ -43,7 +43,14 @@ class _QsvEncoder(json.JSONEncoder):
 
 class Calibrator:
   def __init__(self, float_tflite: Any, tensor_provider: Optional[TensorProvider] = None,
-               qsv_update_func: Any = _MISSING):
+               qsv_update_func: Any = _MISSING, hessians: str = "consumed"):
+    """hessians="consumed": a GPTQ Hessian (d x d per tensor, the dominant cost of calibration) is
+    collected only for tensors some GPTQ op reads one from -- the first input of the op, ref
+    algorithms/utils/common_utils.py:182-216; "all": for every runtime tensor of every GPTQ op,
+    outputs included, as ref algorithms/uniform_quantize/gptq.py:84-107 does (nothing reads them)."""
+    if hessians not in ("consumed", "all"):
+      raise ValueError("hessians must be 'consumed' or 'all'")
+    self._hessians = hessians
     self._flatbuffer_model = (float_tflite if hasattr(float_tflite, "subgraphs")
                               else tfl_flatbuffer_utils.read_model(float_tflite))
     self._tensor_provider = tensor_provider
@@ -97,10 +104,22 @@ class Calibrator:
     contents = {k: rt.resident_sample(v) for k, v in contents.items()}
     self._tensor_content_map.update(contents)
     self._stage_sample(signature_key, contents, model_recipe_manager)
+    from .algorithms.uniform_quantize import gptq
+    readers = (self._plan(signature_key, model_recipe_manager)["hessian_readers"]
+               if self._hessians == "consumed" else None)
     try:
-      self._walk(signature_key, model_recipe_manager)
+      with gptq.hessians_only_for(readers):
+        self._walk(signature_key, model_recipe_manager)
     finally:
       rt.clear_calibration_step()
+
+  def finalize_statistics(self) -> None:
+    """Statistics that still hold unprocessed samples in HBM (GPTQ Hessians collect tokens in a
+    slab) are brought up to date and their staging memory is returned."""
+    for qsv in self._model_qsvs.values():
+      h = qsv.get("hessian") if isinstance(qsv, dict) else None
+      if hasattr(h, "finalize"):
+        h.finalize()
 
   @contextlib.contextmanager
   def plan_once(self):
@@ -124,7 +143,10 @@ class Calibrator:
       from .algorithms.uniform_quantize import common_quantize, naive_min_max_quantize
       names: dict[str, None] = {}
       ops_ = []
+      readers: set[str] = set()
       for sg, graph_info, op, op_key, alg in self._scan_ops_to_calibrate(signature_key, model_recipe_manager):
+        if alg == algorithm_manager.AlgorithmName.GPTQ and not isinstance(op, qtyping.IOOperator) and len(op.inputs):
+          readers.add(tfl_flatbuffer_utils.get_tensor_name(sg.tensors[op.inputs[0]]))
         calibrate = algorithm_manager.get_quantization_func(alg, op_key, qtyping.QuantizeMode.CALIBRATE)
         mine = []
         for tid in common_quantize.get_tensor_indices_requiring_calibration(op, graph_info):
@@ -137,7 +159,7 @@ class Calibrator:
         # these names alone: the walk takes them from here instead of deriving them per sample
         stock = mine if calibrate is naive_min_max_quantize.min_max_calibrate else None
         ops_.append((sg, graph_info, op, op_key, alg, calibrate, stock))
-      plan = {"ops": ops_, "runtime_tensors": list(names)}
+      plan = {"ops": ops_, "runtime_tensors": list(names), "hessian_readers": readers}
       if self._plans is not None:
         self._plans[key] = plan
     return plan
@@ -259,6 +281,7 @@ class Calibrator:
         for data in dataset:
           self._metadata["num_samples_calibrated"] += 1
           self._calibrate_step(signature_key, data, model_recipe_manager)
+    self.finalize_statistics()
 
   def get_model_qsvs(self) -> dict[str, qtyping.QSV]:
     return self._model_qsvs

@@ -71,7 +71,11 @@ def _comm_device(group=None) -> torch.device:
 
 
 # --------------------------------------------------- RCCL via the C ABI ---
-_COMMS: dict[Any, ctypes.c_void_p] = {}
+# (group object or None for the default group, communicator): identity of the group object is
+# checked, not its id() -- Python reuses ids of destroyed groups, and a stale communicator would
+# talk to the wrong peers
+_COMMS: list[tuple[Any, ctypes.c_void_p]] = []
+_ATEXIT = [False]
 
 
 def rccl_comm(group=None) -> Optional[ctypes.c_void_p]:
@@ -79,12 +83,16 @@ def rccl_comm(group=None) -> Optional[ctypes.c_void_p]:
   of the group cannot have one: no process group, or a host transport ("gloo")."""
   if not dist.is_available() or not dist.is_initialized() or dist.get_backend(group) != "nccl":
     return None
-  key = "default" if group is None else id(group)
-  comm = _COMMS.get(key)
-  if comm is None:
-    comm = new_rccl_comm(dist.get_rank(group), dist.get_world_size(group),
-                         lambda uid: _broadcast_bytes(uid, group))
-    _COMMS[key] = comm
+  for g, comm in _COMMS:
+    if g is group:
+      return comm
+  comm = new_rccl_comm(dist.get_rank(group), dist.get_world_size(group),
+                       lambda uid: _broadcast_bytes(uid, group))
+  _COMMS.append((group, comm))     # the entry keeps `group` alive, so its identity stays unique
+  if not _ATEXIT[0]:
+    import atexit
+    atexit.register(destroy_rccl_comms)
+    _ATEXIT[0] = True
   return comm
 
 
@@ -114,10 +122,12 @@ def new_rccl_comm(rank: int, world: int, broadcast: Callable[[Optional[bytes]], 
 
 
 def destroy_rccl_comms() -> None:
+  """Destroys every cached communicator (also registered with atexit; call it before
+  dist.destroy_process_group() when groups are torn down and re-created in one process)."""
   from . import _ffi
-  for comm in _COMMS.values():
+  comms, _COMMS[:] = list(_COMMS), []
+  for _, comm in comms:
     _ffi.check(_ffi.lib().mi355q_comm_destroy(comm))
-  _COMMS.clear()
 
 
 # ------------------------------------------------- weight requantization ---
@@ -161,54 +171,179 @@ def quantize_sharded(tensors: dict[str, np.ndarray],
   return merged
 
 
+# Seconds on one MI355X, fitted to the measured kernels (profiles/r03_c5_model.txt, bench.py
+# extras.c5_gptq): what an op costs decides where it runs, not how many bytes it has -- under GPTQ
+# a [2048, 16384] weight (128 MiB) costs ~50x a [16384, 2048] one (also 128 MiB) because its
+# Hessian is 16384 x 16384.
+COST_MODEL = {
+    # damped Hessian inverse (mi355q_gptq_hinv_f64): d^3 flop at the rate the blocked factorization
+    # sustains + one serial step per 64 columns
+    "hinv_flops_per_s": float(os.environ.get("MI355Q_COST_HINV_FLOPS", 55e12)),
+    "hinv_step_s": 40e-6,
+    # OBS apply (mi355q_gptq_apply_f32): one dependent quantize -> divide -> update step per
+    # column + 2 rows d^2 flop of lazy updates (bf16 split path for wide / tall layers)
+    "apply_column_s": 0.2e-6,
+    "apply_flops_per_s": 123e12,
+    "apply_flops_per_s_wide": 222e12,
+    # one pass over the FP32 weight (min/max + quantize, HBM bound)
+    "stream_bytes_per_s": 4.0e12,
+    # per-element cost of the scale searches relative to one pass
+    "passes": {"min_max_uniform_quantize": 1.0, "MSE": 2.0, "OCTAV": 14.0, "HADAMARD_ROTATION": 16.0,
+               "DECOMPOSED_HADAMARD_ROTATION": 16.0, "OSCAR": 100.0, "GPTQ": 1.0, "float_casting": 1.0,
+               "dequantized_weight_recovery": 30.0},
+    "launch_s": 20e-6,
+}
+
+
+def hinv_seconds(d: int) -> float:
+  c = COST_MODEL
+  return d ** 3 / c["hinv_flops_per_s"] + (d / 64.0) * c["hinv_step_s"]
+
+
+def gptq_apply_seconds(rows: int, d: int) -> float:
+  c = COST_MODEL
+  rate = c["apply_flops_per_s_wide"] if (d >= 4096 or rows >= 8192) else c["apply_flops_per_s"]
+  return d * c["apply_column_s"] + 2.0 * rows * d * d / rate
+
+
+def op_cost(item: tuple, model_qsvs: Optional[dict] = None) -> tuple[float, Optional[tuple], float]:
+  """(seconds of the op itself, key of what it shares with other ops, seconds of that shared part).
+
+  GPTQ ops that read the same input activation share its Hessian and therefore its damped inverse
+  (ref algorithms/uniform_quantize/gptq.py:243-300: `tensor_qsv["activation_tensor_qsv"]["hessian"]`
+  is the QSV of op.inputs[0], common_utils.py:182-216): key = ("hessian", activation name), shared
+  cost = one inverse. Everything else stands alone."""
+  graph_info, op, _, op_key, alg, _ = item
+  alg = str(getattr(alg, "value", alg))
+  if alg == "no_quantize" or op_key is None:
+    return 0.0, None, 0.0
+  c = COST_MODEL
+  shapes = []
+  for tid in op.inputs:
+    if tid == -1:
+      continue
+    t = graph_info.subgraph_tensors[tid]
+    data = graph_info.buffers[t.buffer].data
+    if data is not None and len(data):
+      shapes.append((tuple(int(v) for v in (t.shape if t.shape is not None else ())), len(data)))
+  if not shapes:
+    return 0.0, None, 0.0
+  nbytes = sum(n for _, n in shapes)
+  stream = c["launch_s"] + c["passes"].get(alg, 1.0) * nbytes / c["stream_bytes_per_s"]
+  if alg == "GPTQ" and str(getattr(op_key, "value", op_key)) == "FULLY_CONNECTED" and len(op.inputs) > 1:
+    from .utils import tfl_flatbuffer_utils
+    w_shape = next((shp for shp, _ in shapes if len(shp) == 2), None)
+    act = graph_info.subgraph_tensors[op.inputs[0]]
+    act_name = tfl_flatbuffer_utils.get_tensor_name(act)
+    has_h = model_qsvs is None or "hessian" in (model_qsvs.get(act_name) or {})
+    if w_shape is not None and has_h and graph_info.buffers[act.buffer].data is None:
+      rows, d = w_shape
+      return stream + gptq_apply_seconds(rows, d), ("hessian", act_name), hinv_seconds(d)
+  return stream, None, 0.0
+
+
+def plan_op_shards(costs: Sequence[tuple[float, Optional[tuple], float]], world_size: int) -> list[int]:
+  """Owner rank of every op: ops with the same sharing key travel together (their shared part is
+  paid once in the whole job), units are placed longest first on the least loaded rank
+  (deterministic: ties -> lower op index / lower rank, so every rank derives the same plan
+  without communication)."""
+  units: dict[Any, list] = {}
+  for i, (work, key, shared) in enumerate(costs):
+    u = units.setdefault(("solo", i) if key is None else key, [0.0, 0.0, []])
+    u[0] += float(work)
+    u[1] = max(u[1], float(shared))
+    u[2].append(i)
+  order = sorted(units.values(), key=lambda u: (-(u[0] + u[1]), u[2][0]))
+  load = [0.0] * world_size
+  owner = [0] * len(costs)
+  for work, shared, members in order:
+    r = min(range(world_size), key=lambda k: (load[k], k))
+    load[r] += work + shared
+    for i in members:
+      owner[i] = r
+  return owner
+
+
+def plan_loads(costs: Sequence[tuple[float, Optional[tuple], float]], owner: Sequence[int],
+               world_size: int) -> list[float]:
+  """Modelled seconds per rank under `owner` (a shared part counts once per rank that needs it)."""
+  load = [0.0] * world_size
+  paid: set = set()
+  for (work, key, shared), r in zip(costs, owner):
+    load[r] += work
+    if key is not None and (r, key) not in paid:
+      paid.add((r, key))
+      load[r] += shared
+  return load
+
+
+def plan_model_shards(float_model, recipe, world_size: int, calibration_result: Optional[dict] = None):
+  """(ParamsGenerator, op plan, owner rank per op, modelled costs) of quantizing `float_model`
+  (a path, bytes or a parsed model) on `world_size` ranks -- no arithmetic, same answer on
+  every rank."""
+  from . import params_generator, quantizer
+  qz = float_model if isinstance(float_model, quantizer.Quantizer) else quantizer.Quantizer(float_model, recipe)
+  gen = params_generator.ParamsGenerator(qz.float_model)
+  plan = gen.plan_ops(qz._recipe_manager)  # pylint: disable=protected-access
+  costs = [op_cost(it, calibration_result) for it in plan]
+  return qz, gen, plan, plan_op_shards(costs, world_size), costs
+
+
+def hessian_owners(plan: Sequence[tuple], owner: Sequence[int], costs) -> dict[str, int]:
+  """Activation tensor name -> the one rank whose ops read its GPTQ Hessian."""
+  out: dict[str, int] = {}
+  for (_, key, _), r in zip(costs, owner):
+    if key is not None and key[0] == "hessian":
+      out[key[1]] = r
+  return out
+
+
 def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dict] = None,
                            serialize_to_path=None, group=None):
   """`Quantizer(float_model, recipe).quantize(...)` with the ops' weight work spread over the
   ranks of `group` (BASELINE configs 3 and 5: tensor-buffers sharded over 8 GPUs).
 
-  Every rank maps the model file and resolves the recipe (no arithmetic), ops are assigned to
-  ranks by the bytes of their constant operands (plan_tensor_shards: deterministic, no
-  communication), each rank materializes its ops on its own GPU, and rank 0 gathers the per-op
-  results, merges them in op order, applies the transformations and serializes. Returns the
-  serialized model on rank 0 and None elsewhere. The only collective is the final gather of the
-  (already quantized, 4-8x smaller) results.
+  Every rank maps the model file and resolves the recipe (no arithmetic); ops are assigned to
+  ranks by modelled cost (op_cost: a GPTQ op costs its OBS update plus -- once per distinct
+  Hessian -- the d^3 inverse; other ops cost their passes over the weight bytes) with the ops that
+  share a Hessian kept on one rank, so every inverse is computed once in the whole job
+  (plan_op_shards: deterministic, no communication). Each rank materializes its ops on its own
+  GPU, and rank 0 gathers the per-op results, merges them in op order, applies the
+  transformations and serializes. Returns the serialized model on rank 0 and None elsewhere.
+  The only exchange is the final gather of the (already quantized, 4-8x smaller) results.
   """
-  from . import model_modifier, params_generator, quantizer
+  from . import model_modifier, requant_queue
   rank, world = _world(group)
-  qz = quantizer.Quantizer(float_model, recipe)
+  qz, gen, plan, owner, _ = plan_model_shards(float_model, recipe, world, calibration_result)
   rm = qz._recipe_manager  # pylint: disable=protected-access
   if rm.need_calibration() and not calibration_result:
     raise RuntimeError(
         "Model quantization statistics values (QSVs) are required for the input recipe. This"
         " can be obtained by running calibration on sample dataset.")
   qsvs = calibration_result if calibration_result is not None else {}
-  gen = params_generator.ParamsGenerator(qz.float_model)
-  plan = gen.plan_ops(rm)
-
-  def weight_bytes(item) -> int:
-    graph_info, op = item[0], item[1]
-    if item[4] == "no_quantize":
-      return 0
-    total = 0
-    for tid in op.inputs:
-      if tid != -1:
-        data = graph_info.buffers[graph_info.subgraph_tensors[tid].buffer].data
-        total += 0 if data is None else int(np.asarray(data).nbytes)
-    return total
-  owner = plan_tensor_shards([weight_bytes(it) for it in plan], world)
-  from . import requant_queue
   with requant_queue.batching():       # this rank's equally shaped weights leave in one launch per group
     mine = {i: gen.materialize_op(it, qsvs) for i, (it, o) in enumerate(zip(plan, owner)) if o == rank}
+  gen.release_derived(qsvs)
   if world > 1:
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(mine, gathered, dst=0, group=group)
-    if rank != 0:
+    mine = _gather_results(mine, group)
+    if mine is None:
       return None
-    mine = {}
-    for part in gathered:
-      mine.update(part)
   params = gen.finish(mine[i] for i in range(len(plan)))
   return model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path)
+
+
+def _gather_results(mine: dict, group=None) -> Optional[dict]:
+  """Per-op results of every rank -> rank 0 ({op index: results}); None on the other ranks."""
+  rank, world = _world(group)
+  gathered = [None] * world if rank == 0 else None
+  dst = 0 if group is None else dist.get_global_rank(group, 0)
+  dist.gather_object(mine, gathered, dst=dst, group=group)
+  if rank != 0:
+    return None
+  merged: dict = {}
+  for part in gathered:
+    merged.update(part)
+  return merged
 
 
 # ------------------------------------------------ activation calibration ---
@@ -249,7 +384,7 @@ def _ema_and_count_update(qsv, new_qsv):
 
 
 def calibrate_sharded(float_model, recipe, calibration_data, previous_calibration_result=None,
-                      tensor_provider=None, group=None) -> dict:
+                      tensor_provider=None, group=None, hessians: str = "consumed") -> dict:
   """`Quantizer(float_model, recipe).calibrate(calibration_data)` with every signature's samples
   sharded contiguously over the ranks of `group` (BASELINE config 4: 512 samples over 8 GPUs;
   config 5: GPTQ Hessians).
@@ -269,7 +404,7 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
   rm = qz._recipe_manager  # pylint: disable=protected-access
   if not rm.need_calibration():
     return {}
-  local = calibrator.Calibrator(qz.float_model, tensor_provider=tensor_provider)
+  local = calibrator.Calibrator(qz.float_model, tensor_provider=tensor_provider, hessians=hessians)
   mine = []                                    # (signature index, sample index, events)
   running: dict[str, list] = {}                # tensor name -> [Hessian mean over my samples, count]
   with local.plan_once():
@@ -463,7 +598,9 @@ def allreduce_hessian(weighted_sum, num_samples: int, group=None):
     _sum_f64_across_ranks(n, group, comm)
   total = int(round(float(n.item())))
   h = t / total if total else t
-  return (h.cpu().numpy() if is_np else h), total
+  if is_np:          # the caller's dtype comes back (a float32 OSCAR mu2 stays float32, as the
+    return h.cpu().numpy().astype(np.asarray(weighted_sum).dtype, copy=False), total   # one-process merge)
+  return h.to(weighted_sum.dtype), total
 
 
 allreduce_second_moment = allreduce_hessian   # OSCAR mu2: same sample-weighted mean
@@ -486,6 +623,9 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
   comm = rccl_comm(group) if world > 1 else None
   out: dict[str, Any] = {}
   on_gpu = torch.cuda.is_available()
+  for h, _ in local.values():
+    if hasattr(h, "finalize"):       # tokens still waiting in a slab are multiplied now
+      h.finalize()
   if on_gpu:
     from . import _ffi
     from . import runtime as rt

@@ -211,11 +211,15 @@ class ParamsGenerator:
     with requant_queue.batching() as queue:
       per_op = [self.materialize_op(item, model_qsvs) for item in self.plan_ops(model_recipe_manager)]
     self.batch_stats = dict(queue.stats)
-    # derived device results cached on the statistics (the damped Hessian inverse, one d x d float32
-    # per GPTQ Hessian, shared by the ops that read the same activation) have served their last
-    # consumer: give the HBM back instead of keeping it for as long as the QSVs live
-    for qsv in model_qsvs.values():
+    self.release_derived(model_qsvs)
+    return self.finish(per_op)
+
+  @staticmethod
+  def release_derived(model_qsvs) -> None:
+    """Derived device results cached on the statistics (the damped Hessian inverse, one d x d
+    float32 per GPTQ Hessian, shared by the ops that read the same activation) have served their
+    last consumer: give the HBM back instead of keeping it for as long as the QSVs live."""
+    for qsv in (model_qsvs or {}).values():
       h = qsv.get("hessian") if isinstance(qsv, dict) else None
       if hasattr(h, "cache"):
         h.cache.clear()
-    return self.finish(per_op)

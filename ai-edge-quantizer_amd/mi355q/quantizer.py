@@ -130,13 +130,14 @@ class Quantizer:
                                            weight_granularity, algorithm_key)
 
   def calibrate(self, calibration_data: dict, previous_calibration_result: Optional[dict] = None,
-                tensor_provider: Optional[Any] = None) -> dict[str, qtyping.QSV]:
+                tensor_provider: Optional[Any] = None, hessians: str = "consumed") -> dict[str, qtyping.QSV]:
     """Model QSVs from per-sample tensor contents (ref :369-413). The reference runs the float
     model in the LiteRT interpreter to obtain those tensors; here each sample is the
-    {tensor name: ndarray} map itself, or `tensor_provider(signature_key, sample)` returns it."""
+    {tensor name: ndarray} map itself, or `tensor_provider(signature_key, sample)` returns it.
+    `hessians`: see Calibrator ("all" = a GPTQ Hessian for every runtime tensor, as the reference)."""
     if not self.need_calibration:
       return {}
-    calib = calibrator.Calibrator(self.float_model, tensor_provider=tensor_provider)
+    calib = calibrator.Calibrator(self.float_model, tensor_provider=tensor_provider, hessians=hessians)
     if previous_calibration_result is not None:
       calib.load_model_qsvs(previous_calibration_result)
     calib.calibrate(calibration_data, self._recipe_manager)

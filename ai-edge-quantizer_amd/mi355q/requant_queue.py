@@ -30,6 +30,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
+import threading
 from typing import Optional
 
 import numpy as np
@@ -179,7 +180,13 @@ class RequantQueue:
     self._pending_bytes = 0
     self._pending = 0
     self._waves: list[_Wave] = []
+    self._deferred: list = []           # other algorithms' own queues: completed with this one
     self.stats = {"tensors": 0, "launches": 0, "flushes": 0, "scale_copies": 0}
+
+  def defer(self, complete) -> None:
+    """`complete()` runs when the block exits (before the waits): an algorithm that queues work of
+    its own inside `batching()` (GPTQ's applies that share a Hessian inverse) finishes there."""
+    self._deferred.append(complete)
 
   # ------------------------------------------------------------------------------- submit
   def submit(self, tensor_content, layout, num_bits: int, scale_shape, packable: bool):
@@ -298,36 +305,41 @@ class RequantQueue:
 
   def finish(self) -> None:
     """Flush + wait for the scale copies + swap the placeholders of per-row scales."""
+    deferred, self._deferred = self._deferred, []
+    for complete in deferred:
+      complete()
     self.flush()
     waves, self._waves = self._waves, []
     for w in waves:
       w.complete()
 
 
-_ACTIVE: Optional[RequantQueue] = None
+# the queue of the thread that opened `batching()`: another thread's calls neither join it nor
+# have their launches issued on its stream
+_LOCAL = threading.local()
 # False: `batching()` is a no-op and every tensor is quantized by its own launch (the behaviour
 # the batched path is tested against; also MI355Q_NO_BATCH=1)
 ENABLED = os.environ.get("MI355Q_NO_BATCH", "") in ("", "0")
 
 
 def active() -> Optional[RequantQueue]:
-  return _ACTIVE
+  return getattr(_LOCAL, "queue", None)
 
 
 @contextlib.contextmanager
 def batching(budget_bytes: int = DEFAULT_BUDGET_BYTES, budget_tensors: int = DEFAULT_BUDGET_TENSORS):
   """Defers fused requantization launches issued inside the block; completes them on exit."""
-  global _ACTIVE
-  if _ACTIVE is not None:                     # nested use joins the outer queue
-    yield _ACTIVE
+  outer = active()
+  if outer is not None:                       # nested use joins the outer queue
+    yield outer
     return
   queue = RequantQueue(budget_bytes, budget_tensors)
   if not ENABLED:
     yield queue
     return
-  _ACTIVE = queue
+  _LOCAL.queue = queue
   try:
     yield queue
     queue.finish()
   finally:
-    _ACTIVE = None
+    _LOCAL.queue = None

@@ -167,30 +167,88 @@ class LiteRTLMFile:
     return total
 
 
-def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path,
-                      overwrite: bool = False) -> int:
-  """Quantizes every TFLite section that has a recipe and re-packs the container.
+def _pick(table: Optional[Mapping], sid: int, model_type: Optional[str]) -> Any:
+  """Entry of a per-model table: by section index, by model type, else "default"."""
+  if table is None:
+    return None
+  for key in (sid, model_type, "default"):
+    if key is not None and key in table:
+      return table[key]
+  return None
 
-  `recipe` is one recipe (list) applied to every model, or a mapping model_type -> recipe with
-  an optional "default" entry (ref aeq.py:61-181). Returns the size of the written file.
-  """
-  from .. import quantizer   # deferred: quantizer imports this package's utils
-  if os.path.exists(output_path) and not overwrite:
-    raise ValueError(f"The model {output_path} already exists. Specify overwrite=True to replace it.")
-  recipes = recipe if isinstance(recipe, Mapping) else {"default": recipe}
-  src = LiteRTLMFile(litertlm_path)
-  replaced: dict[int, Any] = {}
+
+def _recipes(recipe: Any) -> Mapping:
+  return recipe if isinstance(recipe, Mapping) else {"default": recipe}
+
+
+def _tflite_sections(src: "LiteRTLMFile", recipes: Mapping):
+  """(section index, model type, recipe) of every TFLite section that has a recipe."""
   for sid, section in enumerate(src.sections):
     if section.dataType != AnySectionDataType.TFLiteModel:
       continue
     model_type = src.get_model_type(sid)
     if model_type is None:
       continue
-    model_recipe = recipes.get(model_type, recipes.get("default"))
-    if model_recipe is None:
+    model_recipe = _pick(recipes, sid, model_type)
+    if model_recipe is not None:
+      yield sid, model_type, model_recipe
+
+
+def calibrate_litertlm(litertlm_path: Path, recipe: Any, calibration_data: Mapping,
+                       previous_calibration_results: Optional[Mapping] = None,
+                       tensor_provider: Optional[Any] = None, group: Any = None) -> dict[int, dict]:
+  """Model QSVs of every TFLite section whose recipe needs calibration: {section index: QSVs}.
+
+  `calibration_data` maps a section (index, model type or "default") to that model's
+  {signature key: samples}; a sample is the {tensor name: content} map of one run of the float
+  model (see Calibrator). With a process group the samples of every signature are sharded over
+  the ranks (distributed.calibrate_sharded: per-sample statistics gathered and replayed in
+  dataset order, GPTQ Hessians all-reduced); every rank returns the same QSVs.
+  """
+  from .. import distributed
+  src = LiteRTLMFile(litertlm_path)
+  out: dict[int, dict] = {}
+  for sid, model_type, model_recipe in _tflite_sections(src, _recipes(recipe)):
+    data = _pick(calibration_data, sid, model_type)
+    if data is None:
       continue
-    result = quantizer.Quantizer(src.get_section_buffer(sid), model_recipe).quantize()
-    replaced[sid] = result.quantized_model
-  if not replaced:
+    qsvs = distributed.calibrate_sharded(
+        src.get_section_buffer(sid), model_recipe, data,
+        previous_calibration_result=_pick(previous_calibration_results, sid, model_type),
+        tensor_provider=tensor_provider, group=group)
+    if qsvs:
+      out[sid] = qsvs
+  return out
+
+
+def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path, overwrite: bool = False,
+                      calibration_results: Optional[Mapping] = None, group: Any = None) -> Optional[int]:
+  """Quantizes every TFLite section that has a recipe and re-packs the container.
+
+  `recipe` is one recipe (list) applied to every model, or a mapping model_type -> recipe with
+  an optional "default" entry (ref aeq.py:61-181). `calibration_results` maps a section (index,
+  model type or "default") to the model QSVs its recipe needs (static recipes, GPTQ, OSCAR:
+  what Quantizer.calibrate / calibrate_litertlm returned) -- the reference's loop passes none
+  and therefore cannot run such recipes on a container. With a process group (`group`, or an
+  initialised default group) the ops of every model are spread over the ranks by cost and by
+  shared statistics (distributed.quantize_model_sharded); rank 0 writes the file and returns
+  its size, the other ranks return None.
+  """
+  from .. import distributed
+  if os.path.exists(output_path) and not overwrite:
+    raise ValueError(f"The model {output_path} already exists. Specify overwrite=True to replace it.")
+  src = LiteRTLMFile(litertlm_path)
+  replaced: dict[int, Any] = {}
+  quantized_any = False
+  for sid, model_type, model_recipe in _tflite_sections(src, _recipes(recipe)):
+    result = distributed.quantize_model_sharded(
+        src.get_section_buffer(sid), model_recipe,
+        calibration_result=_pick(calibration_results, sid, model_type), group=group)
+    quantized_any = True
+    if result is not None:
+      replaced[sid] = result
+  if not quantized_any:
     raise ValueError("No models were quantized, not creating output file.")
+  if not replaced:          # a rank other than the group's first: nothing to write
+    return None
   return src.serialize(output_path, replaced)

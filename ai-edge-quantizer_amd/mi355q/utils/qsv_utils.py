@@ -41,6 +41,11 @@ def _gptq_merge_hessian(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> tuple[Any, in
   if total == 0:
     return new_qsv["hessian"], 0
   h0, h1 = qsv["hessian"], new_qsv["hessian"]
+  if hasattr(h0, "absorb") and hasattr(h1, "absorb"):
+    # both still collect tokens in HBM (gptq.HessianAccumulator): the weighted mean of the two is
+    # the accumulator over both sets of samples; h1 is this sample's own, made for this merge
+    h0.absorb(h1)
+    return h0, total
   if not (hasattr(h0, "dtype") and hasattr(h1, "dtype")):
     h0, h1 = np.asarray(h0), np.asarray(h1)
   if h0.dtype == np.float64 and h1.dtype == np.float64 and h0.ndim == 2 and h0.shape == h1.shape \
@@ -84,5 +89,9 @@ def gptq_and_moving_average_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qt
   if not qsv:
     return new_qsv
   out = moving_average_update(qsv, new_qsv)
+  if "hessian" not in qsv and "hessian" not in new_qsv:
+    # a tensor no op reads a Hessian from (Calibrator(hessians="consumed")): min / max / count only
+    out["num_samples"] = qsv["num_samples"] + new_qsv["num_samples"]
+    return out
   out["hessian"], out["num_samples"] = _gptq_merge_hessian(qsv, new_qsv)
   return out

@@ -578,8 +578,14 @@ def gptq_hessian(x: np.ndarray) -> np.ndarray:
   return (2.0 / n) * x2.T.dot(x2)
 
 
-def gptq_hessian_inverse(hessian: np.ndarray, damp_factor: float = 0.01) -> np.ndarray:
-  """damp -> Cholesky -> triangular inverse -> L^-T L^-1. ref: gptq.py:111-128."""
+def gptq_hessian_inverse(hessian: np.ndarray, damp_factor: float = 0.01,
+                         product: str = "einsum") -> np.ndarray:
+  """damp -> Cholesky -> triangular inverse -> L^-T L^-1. ref: gptq.py:111-128.
+
+  product="matmul" forms the final product with sgemm instead of the reference's two-operand
+  einsum (NumPy's own loops, no BLAS: 2.3 s at d = 2048, hours at d = 16384). Same float32
+  products, another addition order -- for checks at sizes the einsum cannot reach, and as one of
+  the reference-side reorderings the T2 noise floor is measured with."""
   import scipy.linalg
   hessian = np.array(hessian, copy=True)
   d0 = np.diag(hessian)
@@ -592,12 +598,14 @@ def gptq_hessian_inverse(hessian: np.ndarray, damp_factor: float = 0.01) -> np.n
   # casts a float64 factor to float32 first, so L^-1 and H^-1 are float32.
   linv, err = scipy.linalg.lapack.strtri(l, lower=True, overwrite_c=True)
   assert err == 0
+  if product == "matmul":
+    return np.matmul(linv.T, linv)
   return np.einsum("ji,jk->ik", linv, linv)
 
 
 def gptq_apply(w: np.ndarray, scale, zp, num_bits: int, symmetric: bool,
                hessian: np.ndarray, granularity: str, block_size: int = 0,
-               blocksize: int = 64, hinv=None) -> np.ndarray:
+               blocksize: int = 64, hinv=None, product: str = "einsum") -> np.ndarray:
   """Blocked OBS update + column-serial quantization. ref: gptq.py:131-216.
 
   `scale`/`zp` are the up-front min/max parameters (shape [rows,1] channelwise,
@@ -608,7 +616,7 @@ def gptq_apply(w: np.ndarray, scale, zp, num_bits: int, symmetric: bool,
   qdt = int_dtype(num_bits, True)
   qw = np.zeros(fw.shape, dtype=qdt)
   if hinv is None:
-    hinv = gptq_hessian_inverse(hessian)
+    hinv = gptq_hessian_inverse(hessian, product=product)
   ncols = hinv.shape[0]
   blockwise = is_blockwise(granularity)
   cw = str(granularity).endswith(CHANNELWISE)
