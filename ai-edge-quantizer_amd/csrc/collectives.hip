@@ -32,6 +32,7 @@ struct Rccl {
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -64,7 +65,7 @@ const Rccl* rccl() {
     r.ok = bind(h, "ncclGetUniqueId", &r.GetUniqueId) && bind(h, "ncclCommInitRank", &r.CommInitRank) &&
            bind(h, "ncclCommDestroy", &r.CommDestroy) && bind(h, "ncclCommCount", &r.CommCount) &&
            bind(h, "ncclCommUserRank", &r.CommUserRank) && bind(h, "ncclAllReduce", &r.AllReduce) &&
-           bind(h, "ncclAllGather", &r.AllGather) && bind(h, "ncclGroupStart", &r.GroupStart) &&
+           bind(h, "ncclAllGather", &r.AllGather) && bind(h, "ncclReduce", &r.Reduce) && bind(h, "ncclGroupStart", &r.GroupStart) &&
            bind(h, "ncclGroupEnd", &r.GroupEnd) && bind(h, "ncclGetErrorString", &r.GetErrorString);
     if (!r.ok) keep_why("dlsym");
   });
@@ -83,6 +84,39 @@ int32_t no_rccl() { return fail(MI355Q_RCCL_ERROR, "librccl.so.1 could not be bo
 __global__ __launch_bounds__(256) void scale_f64_kernel(double* __restrict__ x, long long n, double a) {
   const long long stride = static_cast<long long>(gridDim.x) * 256;
   for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) x[i] *= a;
+}
+
+// The Hessian is symmetric: only its lower triangle travels. Row i of the packed form starts at
+// i (i + 1) / 2. pack: packed = weight * lower(h); unpack: h = packed mirrored to both triangles.
+__global__ __launch_bounds__(256) void pack_lower_f64_kernel(const double* __restrict__ h, long long d, double weight,
+                                                            double* __restrict__ packed) {
+  const long long i = blockIdx.y;
+  const long long row = i * (i + 1) / 2;
+  for (long long j = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; j <= i; j += static_cast<long long>(gridDim.x) * 256)
+    packed[row + j] = h[i * d + j] * weight;
+}
+
+__global__ __launch_bounds__(256) void unpack_lower_f64_kernel(const double* __restrict__ packed, long long d,
+                                                              double* __restrict__ h) {
+  __shared__ double tile[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const bool upper = bj > bi;
+  const int si = upper ? bj : bi, sj = upper ? bi : bj;         // source tile (lower triangle)
+  for (int r = ty; r < 32; r += 8) {
+    const long long i = si * 32LL + r, j = sj * 32LL + tx;
+    double v = 0.0;
+    if (i < d && j < d) {
+      const long long a = i >= j ? i : j, b = i >= j ? j : i;
+      v = packed[a * (a + 1) / 2 + b];
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const long long i = bi * 32LL + r, j = bj * 32LL + tx;
+    if (i < d && j < d) h[i * d + j] = upper ? tile[tx][r] : tile[r][tx];
+  }
 }
 
 inline ncclComm_t as_comm(void* c) { return reinterpret_cast<ncclComm_t>(c); }
@@ -194,6 +228,46 @@ extern "C" int32_t mi355q_allreduce_minmax_f32(void* comm, float* mins, float* m
   MI355Q_RCCL(R->GroupEnd(), "ncclGroupEnd");
   MI355Q_RCCL(a, "ncclAllReduce(min)");
   MI355Q_RCCL(b, "ncclAllReduce(max)");
+  return MI355Q_OK;
+}
+
+extern "C" size_t mi355q_hessian_exchange_workspace_bytes(int64_t d) {
+  if (d <= 0) return 0;
+  return static_cast<size_t>(d) * static_cast<size_t>(d + 1) / 2 * sizeof(double);
+}
+
+extern "C" int32_t mi355q_reduce_hessian_f64(void* comm, double* hessian, int64_t d, double weight, int32_t root,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (!comm) return fail(MI355Q_BAD_ARG, "null communicator");
+  if (d < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (d == 0) return MI355Q_OK;
+  if (d > 0x7FFFFFFF) return fail(MI355Q_UNSUPPORTED, "dimension too large");
+  if (!hessian) return fail(MI355Q_BAD_ARG, "null pointer");
+  if (!(weight >= 0.0 && weight <= 1.0)) return fail(MI355Q_BAD_ARG, "weight must be n_rank / N in [0, 1]");
+  const size_t need = mi355q_hessian_exchange_workspace_bytes(d);
+  if (!workspace || workspace_bytes < need) return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  const Rccl* R = rccl();
+  if (!R) return no_rccl();
+  int nranks = 0, me = 0;
+  MI355Q_RCCL(R->CommCount(as_comm(comm), &nranks), "ncclCommCount");
+  MI355Q_RCCL(R->CommUserRank(as_comm(comm), &me), "ncclCommUserRank");
+  if (root >= nranks) return fail(MI355Q_BAD_ARG, "root %d of %d ranks", root, nranks);
+  double* packed = static_cast<double*>(workspace);
+  const size_t n = static_cast<size_t>(d) * static_cast<size_t>(d + 1) / 2;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(pack_lower_f64_kernel, dim3(static_cast<unsigned>((d + 2047) / 2048 < 1 ? 1 : (d + 2047) / 2048), static_cast<unsigned>(d)),
+                     dim3(256), 0, st, hessian, static_cast<long long>(d), weight, packed);
+  MI355Q_CHECK_LAUNCH("hessian pack launch");
+  if (root < 0)
+    MI355Q_RCCL(R->AllReduce(packed, packed, n, ncclFloat64, ncclSum, as_comm(comm), st), "ncclAllReduce(hessian)");
+  else
+    MI355Q_RCCL(R->Reduce(packed, packed, n, ncclFloat64, ncclSum, root, as_comm(comm), st), "ncclReduce(hessian)");
+  if (root < 0 || root == me) {
+    const unsigned t32 = static_cast<unsigned>((d + 31) / 32);
+    hipLaunchKernelGGL(unpack_lower_f64_kernel, dim3(t32, t32), dim3(256), 0, st, packed, static_cast<long long>(d), hessian);
+    MI355Q_CHECK_LAUNCH("hessian unpack launch");
+  }
   return MI355Q_OK;
 }
 

@@ -1023,20 +1023,42 @@ namespace mi355q {
 // xtx_bf16x3.hip: the product on the bf16 matrix cores (three-way split of every float32)
 bool xtx_bf16x3_usable(int64_t n, int64_t d);
 size_t xtx_bf16x3_workspace_bytes(int64_t n, int64_t d);
-int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspace, hipStream_t st);
+int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspace, hipStream_t st, bool accumulate_first);
 // ... and the same split for the update behind a group of columns of the OBS apply
 bool upd_bf16x3_usable(int64_t rows, int64_t d);
 size_t upd_bf16x3_workspace_bytes(int64_t rows, int64_t d, int64_t kk_max);
 int32_t upd_bf16x3_prepare(const float* hinv, int64_t d, void* workspace, hipStream_t st);
 int32_t upd_bf16x3(const float* err, int64_t ld, int64_t rows, int64_t d, int64_t g0, int64_t kk, int64_t g1, float* w,
                    void* workspace, hipStream_t st);
+// ... and for the single-precision steps of the Hessian inverse (triangular inverse, L^-T L^-1)
+size_t hinv_split_scratch_bytes(int64_t d);
+int32_t trtri_level_bf16x3(double* a, int64_t d, int64_t s, int64_t items, void* scratch, hipStream_t st);
+int32_t ltl_bf16x3(const double* linv, int64_t d, float* hinv, void* scratch, hipStream_t st);
 }  // namespace mi355q
+
+namespace {
+size_t xtx_scratch_bytes(int64_t n, int64_t d) {
+  const size_t fp32 = gemm_splitk_workspace_bytes<float>(static_cast<int>(d), static_cast<int>(d), static_cast<int>(n < 0 ? 0 : n), true);
+  const size_t split = xtx_bf16x3_usable(n, d) ? xtx_bf16x3_workspace_bytes(n, d) : 0;
+  return split > fp32 ? split : fp32;
+}
+
+// product (+)= X^T X on the lower-triangular tiles
+int32_t xtx_product(const float* x, int64_t n, int64_t d, float* p, bool accumulate, void* scratch, size_t scratch_bytes,
+                    hipStream_t st) {
+  // P = X^T X : A(i,k) = X[k][i], B(k,j) = X[k][j]; long K is split over gridDim.z. P is
+  // symmetric and P[i][j], P[j][i] are the same k-ordered sum of the same (commuting) products,
+  // so only the lower triangle is computed (triangular launch grid: half the flops) and mirrored.
+  if (xtx_bf16x3_usable(n, d)) return xtx_bf16x3(x, n, d, p, scratch, st, accumulate);
+  GemmArgs<float> g{x, 1, d, x, d, 1, p, d, 1, static_cast<int>(d), static_cast<int>(d),
+                    static_cast<int>(n), 1.0f, accumulate ? 1.0f : 0.0f, 1, 0};
+  return launch_gemm<float>(g, st, scratch, scratch_bytes);
+}
+}  // namespace
 
 extern "C" size_t mi355q_gptq_xtx_workspace_bytes(int64_t n, int64_t d) {
   if (d <= 0 || d > 0x7FFFFFFF || n > 0x7FFFFFFF) return 0;
-  const size_t fp32 = gemm_splitk_workspace_bytes<float>(static_cast<int>(d), static_cast<int>(d), static_cast<int>(n < 0 ? 0 : n), true);
-  const size_t split = xtx_bf16x3_usable(n, d) ? xtx_bf16x3_workspace_bytes(n, d) : 0;
-  return static_cast<size_t>(d) * d * sizeof(float) + (split > fp32 ? split : fp32);
+  return static_cast<size_t>(d) * d * sizeof(float) + xtx_scratch_bytes(n, d);
 }
 
 extern "C" int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, double alpha,
@@ -1052,20 +1074,43 @@ extern "C" int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, dou
     return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
   hipStream_t st = as_stream(stream);
   float* p = static_cast<float*>(workspace);
-  float* split_ws = p + d * d;
-  // P = X^T X : A(i,k) = X[k][i], B(k,j) = X[k][j]; long K is split over gridDim.z. P is
-  // symmetric and P[i][j], P[j][i] are the same k-ordered sum of the same (commuting) products,
-  // so only the lower triangle is computed (triangular launch grid: half the flops) and mirrored.
-  if (xtx_bf16x3_usable(n, d)) {
-    if (int32_t s = xtx_bf16x3(x, n, d, p, split_ws, st)) return s;
-  } else {
-    GemmArgs<float> g{x, 1, d, x, d, 1, p, d, 1, static_cast<int>(d), static_cast<int>(d),
-                      static_cast<int>(n), 1.0f, 0.0f, 1, 0};
-    if (int32_t s = launch_gemm<float>(g, st, split_ws, need - static_cast<size_t>(d) * d * sizeof(float))) return s;
-  }
+  if (int32_t s = xtx_product(x, n, d, p, false, p + d * d, need - static_cast<size_t>(d) * d * sizeof(float), st)) return s;
   const unsigned t32 = static_cast<unsigned>((d + 31) / 32);
   hipLaunchKernelGGL(mirror_scale_to_f64_kernel, dim3(t32, t32), dim3(256), 0, st, p, static_cast<int>(d),
                      alpha, hessian_out);
+  MI355Q_CHECK_LAUNCH("hessian scale launch");
+  return MI355Q_OK;
+}
+
+extern "C" size_t mi355q_gptq_xtx_accum_workspace_bytes(int64_t n, int64_t d) {
+  if (d <= 0 || d > 0x7FFFFFFF || n > 0x7FFFFFFF) return 0;
+  return xtx_scratch_bytes(n, d);
+}
+
+extern "C" int32_t mi355q_gptq_xtx_accum_f32(const float* x, int64_t n, int64_t d, float* product,
+                                             int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+  clear_error();
+  if (n < 0 || d < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (d == 0) return MI355Q_OK;
+  if (d > 0x7FFFFFFF || n > 0x7FFFFFFF) return fail(MI355Q_UNSUPPORTED, "dimension too large");
+  if (!x || !product) return fail(MI355Q_BAD_ARG, "null pointer");
+  const size_t need = mi355q_gptq_xtx_accum_workspace_bytes(n, d);
+  if (need && (!workspace || workspace_bytes < need))
+    return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  return xtx_product(x, n, d, product, accumulate != 0, workspace, workspace_bytes, as_stream(stream));
+}
+
+extern "C" int32_t mi355q_gptq_xtx_finish_f64(const float* product, int64_t d, double alpha,
+                                              double* hessian_out, void* stream) {
+  clear_error();
+  if (d < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (d == 0) return MI355Q_OK;
+  if (d > 0x7FFFFFFF) return fail(MI355Q_UNSUPPORTED, "dimension too large");
+  if (!product || !hessian_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  const unsigned t32 = static_cast<unsigned>((d + 31) / 32);
+  hipLaunchKernelGGL(mirror_scale_to_f64_kernel, dim3(t32, t32), dim3(256), 0, as_stream(stream), product,
+                     static_cast<int>(d), alpha, hessian_out);
   MI355Q_CHECK_LAUNCH("hessian scale launch");
   return MI355Q_OK;
 }
@@ -1312,12 +1357,25 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   // All flops are in large triangular-operand GEMMs (two per pair); `out` is free until the
   // final product and holds the intermediate L21 L11^-1.
   hipLaunchKernelGGL(diag_inverse_kernel, dim3(nblocks), dim3(256), 0, st, a, d);
+  // The reference runs everything from here on in single precision (scipy's strtri on the float32
+  // cast of the factor, a float32 einsum for the product, ref gptq.py:121-128). For d >= 4096 the
+  // large merge levels and the product therefore run on the bf16 matrix cores with float32-class
+  // accuracy (exact three-way split of every operand rounded to float32, csrc/xtx_bf16x3.hip);
+  // the factorization above stays FP64 like the reference's np.linalg.cholesky of the float64
+  // Hessian. MI355Q_HINV_FP64=1 keeps FP64 MFMA throughout. `out` (free until the product) is the scratch.
+  static const bool split_ok = getenv("MI355Q_HINV_FP64") == nullptr;
+  static const long long split_min_s = [] { const char* e = getenv("MI355Q_HINV_SPLIT_MIN_S"); const long long v = e ? atoll(e) : 0; return v >= 128 ? v : 1024LL; }();
+  const bool split = split_ok && d >= 4096 && d % 128 == 0 && d <= 16384 &&
+                     hinv_split_scratch_bytes(d) + 4096 <= static_cast<size_t>(d) * d * sizeof(double);
   for (long long s = NB; s < d; s *= 2) {
     // the pairs of one level are independent and (but for a ragged last one) equally shaped:
     // the low levels, hundreds of one-tile GEMMs, go out as two batched launches per level
     long long first = 0;
     const long long full = (d - s) / (2 * s) + ((d - s) % (2 * s) >= s ? 1 : 0);   // pairs with n2 == s
-    if (full >= 2 && s <= 2048) {
+    if (split && s >= split_min_s && full >= 1) {
+      if (int32_t e = trtri_level_bf16x3(a, d, s, full, out, st)) return e;
+      first = full * 2 * s;
+    } else if (full >= 2 && s <= 2048) {
       const int n = static_cast<int>(s);
       const long long hop = 2 * s * (static_cast<long long>(d) + 1);
       GemmArgs<double> g1{a + s * d, d, 1, a, d, 1, out, n, 1, n, n, n, 1.0, 0.0, 0, 3,
@@ -1344,9 +1402,13 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   MI355Q_CHECK_LAUNCH("gptq trtri launch");
   // ---- H^-1 = L^-T L^-1 : out(i,j) = sum_k Linv[k][i] * Linv[k][j], k >= max(i,j); lower half
   // (stored as float32 straight from the accumulators; the upper triangle is mirrored afterwards)
-  GemmArgs<double> gp{a, 1, d, a, d, 1, out, d, 1, d, d, d, 1.0, 0.0, 1, 2};
-  gp.c32 = hinv_out;
-  if (int32_t s = launch_gemm<double>(gp, st)) return s;
+  if (split) {
+    if (int32_t s = ltl_bf16x3(a, d, hinv_out, out, st)) return s;
+  } else {
+    GemmArgs<double> gp{a, 1, d, a, d, 1, out, d, 1, d, d, d, 1.0, 0.0, 1, 2};
+    gp.c32 = hinv_out;
+    if (int32_t s = launch_gemm<double>(gp, st)) return s;
+  }
   {
     const unsigned nt = static_cast<unsigned>((d + 31) / 32);
     hipLaunchKernelGGL(mirror_lower_f32_kernel, dim3(nt, nt), dim3(256), 0, st, hinv_out, d);

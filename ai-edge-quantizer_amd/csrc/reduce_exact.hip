@@ -239,6 +239,7 @@ struct OctavArgs {
   float s;          // float32(4^-bits / divisor)
   float* hist;      // [max_iter][units] guesses
   unsigned long long* moving;  // bit `it` set: some unit's guess still moved in iteration `it`
+  int sparse;       // octav_rows_kernel: late iterations re-test a list of candidates instead of the row
 };
 
 struct OctavStep {
@@ -441,9 +442,109 @@ struct RowsShared {      // small per-workgroup exchange area (in front of the r
   int wave_count[2][W];     // selected elements per wave
   int wave_changed[W];      // some word of the wave differs from the previous iteration's
   float sum[2];             // the two chain totals
+  float wave_amax[W];       // largest |x| of the wave's pieces (written once, area 0)
+  int sparse_ok;            // sparse iterations: the scanning wave's verdict, its two counts (sums in `sum`)
+  int sparse_count[2];
+  int sparse_kept[2];       // ... and what is left of the candidate lists
 };
 // floats per exchange area (there are two, by iteration parity)
-constexpr int rows_xchg_floats(int threads) { return threads <= 256 ? 64 : 192; }
+constexpr int rows_xchg_floats(int threads) { return threads <= 256 ? 64 : 256; }
+
+// acc = (..((acc + R0) + R1)..) over the lanes set in `ends`, in lane order (R = that lane's `partial`).
+// Few ends: a scalar loop over the set bits. Otherwise the run totals are compacted to lanes 0..k-1
+// (one ds_permute; the other lanes park theirs above k), then every lane repeats x = left
+// neighbour's x + R (lane 0's neighbour is acc): lane j is final after j + 1 rounds and stays
+// final, so k rounds (rounded up to the unroll) leave the total in lane k - 1.
+__device__ __forceinline__ float chain_ends(float acc, float partial, unsigned long long ends, int lane) {
+  const int k = __builtin_popcountll(ends);
+  if (k <= 3) {
+    while (ends != 0) {
+      acc = acc + lane_bcast(partial, __builtin_ctzll(ends));
+      ends &= ends - 1ull;
+    }
+    return acc;
+  }
+  const bool is_end = ((ends >> lane) & 1ull) != 0;
+  const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(ends >> 32),
+                                             __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(ends), 0));
+  const int dest = is_end ? rank : k + lane - rank;
+  const float r = __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(partial)));
+  float x = r;
+  for (int t = 0; t < k; t += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float left = __int_as_float(__builtin_amdgcn_update_dpp(
+          __float_as_int(acc), __float_as_int(x), 0x138, 0xF, 0xF, false));
+      x = left + r;
+    }
+  }
+  return lane_bcast(x, k - 1);
+}
+
+// One mask of a sparsely selected row, by ONE wave. `cv` / `cp` list the n elements that passed an
+// earlier, lower guess (values and positions in the row, ascending): while the guess keeps
+// growing, what it selects is a subset of them, so an iteration costs what it selects instead of a
+// pass over the row. A run is a stretch of selected candidates at consecutive positions inside
+// one 8192-chunk; lane l holds candidate base + l and its successor, so the link "my successor
+// continues my run" needs no neighbour exchange. Runs shorter than 8 are summed left to right
+// from +0.0 (NumPy's n < 8 loop) by rounds of "left neighbour's partial sum + mine", the run
+// totals join the running total in order (chain_ends). A run of 8 or more candidates needs the
+// eight-accumulator scheme: the caller is told (false) and repeats the iteration the dense way.
+template <bool NEG>
+__device__ __forceinline__ bool sparse_mask_sum(float* cv, unsigned short* cp, int n, float thr, float keep, int lane,
+                                                float* sum_out, int* count_out, int* kept_out) {
+  float acc = 0.f;
+  int count = 0;
+  int kept = 0;                 // the list shrinks as the guess grows: candidates beyond `keep` move to the front
+  bool carry_link = false;      // lane 0 continues the run the previous batch ended with
+  float carry_partial = 0.f;
+  int carry_len = 0;
+  for (int base = 0; base < n; base += kWave) {
+    const int i = base + lane;
+    const bool in = i < n, in1 = i + 1 < n;
+    const float v = in ? cv[i] : 0.f, vn = in1 ? cv[i + 1] : 0.f;
+    const int p = in ? static_cast<int>(cp[i]) : -1, pn = in1 ? static_cast<int>(cp[i + 1]) : -3;
+    const bool sel = in && (NEG ? v <= thr : v >= thr);
+    const bool seln = in1 && (NEG ? vn <= thr : vn >= thr);
+    const bool linkn = sel && seln && pn == p + 1 && (pn & (kChunk - 1)) != 0;
+    const unsigned long long S = __ballot(sel), Ln = __ballot(linkn);
+    count += __builtin_popcountll(S);
+    {
+      // (in place: everything this batch reads is in registers, and what is kept lands at or below
+      // the batch's own start)
+      const bool stay = in && (NEG ? v <= keep : v >= keep);
+      const unsigned long long K = __ballot(stay);
+      const int at = kept + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(K >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(K), 0));
+      if (stay) { cv[at] = v; cp[at] = static_cast<unsigned short>(p); }
+      kept += __builtin_popcountll(K);
+    }
+    const unsigned long long L = (Ln << 1) | (carry_link ? 1ull : 0ull);   // bit l: lane l continues lane l - 1's run
+    unsigned long long c7 = L & (L << 1);
+    c7 &= c7 << 2;
+    c7 &= c7 << 3;                                                         // seven links in a row: a run of 8
+    const int lead = carry_link ? __builtin_ctzll(~L) : 0;                 // elements of the carried run in this batch
+    if (c7 != 0 || carry_len + lead >= 8) return false;
+    float partial = sel ? v : 0.f;
+    if (lane == 0 && carry_link) partial = carry_partial + v;
+    const bool cont = lane != 0 && ((L >> lane) & 1ull) != 0;
+    for (unsigned long long c = L & ~1ull; c != 0; c &= c << 1) {
+      const float left = wave_shr1(partial);
+      if (cont) partial = left + v;
+    }
+    const unsigned long long ends = S & ~Ln;
+    if (ends != 0) acc = chain_ends(acc, partial, ends, lane);
+    carry_link = (Ln >> 63) != 0;
+    if (carry_link) {     // the open run started in this batch (fewer than seven links end at lane 63)
+      carry_partial = lane_bcast(partial, 63);
+      carry_len = __builtin_clzll(~L) + 1;
+    }
+  }
+  *sum_out = acc;
+  *count_out = count;
+  *kept_out = kept;
+  return true;
+}
 
 // One mask of one piece: `word` = the 16 selection bits of elements x[0..16) (element e0 = 16 pc),
 // `carry` = the element before the piece is selected too (same chunk). Writes the sums of the runs
@@ -577,6 +678,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
   unsigned short* words_neg = words_pos + ((npieces + 1) & ~1);
 
   for (int i = tid; i < 2 * kX; i += THREADS) smem[i] = 0.f;   // both exchange areas: waves this workgroup does not have count as 0
+  __syncthreads();
   // ---- stage the unit: every thread keeps its pieces in registers for all iterations (one HBM
   // read), the row also goes to LDS for the runs that leave a piece
   const float qnan = __builtin_nanf("");
@@ -609,7 +711,21 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
         if (e0 + i < len) row[p + i] = x[s][i];
     }
   }
+  {
+    // largest |x| of the row (NaN ignored: a NaN is never selected): a guess above it selects nothing
+    float am = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+      for (int i = 0; i < kPiece; ++i) am = fmaxf(am, fabsf(x[s][i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
+    if (lane == 0) reinterpret_cast<Shared*>(smem)->wave_amax[wave] = am;
+  }
   __syncthreads();
+  float row_amax = 0.f;
+#pragma unroll
+  for (int k = 0; k < kWavesAlloc; ++k) row_amax = fmaxf(row_amax, reinterpret_cast<Shared*>(smem)->wave_amax[k]);
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int pc = tid + kRowsThreads * s;
@@ -626,12 +742,65 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
   // the serial chain runs on one wave per workgroup: spread it over the SIMDs of the CU
   // (workgroups u, u + 256, u + 512, ... tend to be co-resident)
   const int chain_wave = static_cast<int>((unit + (unit >> 8)) % kWaves);
+  // sparse iterations (see sparse_mask_sum): candidate lists live where the run lists are
+  constexpr bool kCanSparse = SLOTS == 1;
+  const bool allow_sparse = a.sparse != 0;
+  const int cand_cap = len / 8 < 64 ? 64 : len / 8;                  // per mask
+  float* cand_v[2] = {list_pos, list_neg};
+  unsigned short* cand_p[2] = {reinterpret_cast<unsigned short*>(list_pos + cand_cap),
+                               reinterpret_cast<unsigned short*>(list_neg + cand_cap)};
+  bool sparse = false, force = true;
+  float cand_guess = 0.f;
+  int ncand[2] = {0, 0};
+  int nit = 0;      // iterations that exchanged something (the exchange areas alternate with it)
+  int scan_p = 0, scan_n = 0;   // the last dense iteration's inclusive scans of selected elements inside the wave
   for (int it = 0; it < a.max_iter; ++it) {
     const float hi = guess, lo = -guess;
-    // (two exchange areas, by iteration parity: an iteration whose masks did not change has only
+    bool have_sums = false;
+    if (guess > row_amax) {
+      // nothing reaches the guess (the reference's first guess 1.0 on ordinary weights): empty masks
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) wp[s] = wn[s] = 0u;
+      pos_sum = neg_sum = 0.f;
+      cp = cn = 0;
+      force = true;
+      have_sums = true;
+    } else if (kCanSparse && sparse) {
+      Shared* shs = reinterpret_cast<Shared*>(smem + kX * (nit & 1));
+      ++nit;
+      // candidates a little below the guess stay listed: an iterate that settles may step back by an ulp
+      const float keep = hi * 0.998046875f;     // 1 - 2^-9
+      if (wave == chain_wave) {
+        float sp_ = 0.f, sn_ = 0.f;
+        int kp_ = 0, kn_ = 0, lp_ = 0, ln_ = 0;
+        const bool ok = sparse_mask_sum<false>(cand_v[0], cand_p[0], ncand[0], hi, keep, lane, &sp_, &kp_, &lp_) &&
+                        sparse_mask_sum<true>(cand_v[1], cand_p[1], ncand[1], lo, -keep, lane, &sn_, &kn_, &ln_);
+        if (lane == 0) {
+          shs->sparse_ok = ok ? 1 : 0;
+          shs->sum[0] = sp_; shs->sum[1] = sn_;
+          shs->sparse_count[0] = kp_; shs->sparse_count[1] = kn_;
+          shs->sparse_kept[0] = lp_; shs->sparse_kept[1] = ln_;
+        }
+      }
+      __syncthreads();
+      if (shs->sparse_ok) {
+        pos_sum = shs->sum[0]; neg_sum = shs->sum[1];
+        cp = shs->sparse_count[0]; cn = shs->sparse_count[1];
+        ncand[0] = shs->sparse_kept[0]; ncand[1] = shs->sparse_kept[1];
+        cand_guess = keep;
+        have_sums = true;
+      } else {
+        sparse = false;    // a run of 8+ among the candidates: this iteration again, the dense way
+        force = true;
+        __syncthreads();   // (everybody has read the verdict before the lists are rewritten)
+      }
+    }
+    if (!have_sums) {
+    // (two exchange areas, alternating: an iteration whose masks did not change has only
     // one barrier, so a fast wave may already publish the next iteration's counts while a slow one
     // still reads this one's)
-    Shared* sh = reinterpret_cast<Shared*>(smem + kX * (it & 1));
+    Shared* sh = reinterpret_cast<Shared*>(smem + kX * (nit & 1));
+    ++nit;
     // ---- masks of the thread's own pieces, from registers
     unsigned changed = 0;
     unsigned sp[SLOTS], sn[SLOTS];   // run starts
@@ -664,6 +833,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
     }
     tp = wave_incl_scan(tp);
     tn = wave_incl_scan(tn);
+    scan_p = tp; scan_n = tn;
     const bool wave_changed = __ballot(changed != 0) != 0;
     if (lane == kWave - 1) {
       sh->wave_count[0][wave] = tp; sh->wave_count[1][wave] = tn;
@@ -676,7 +846,8 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
     } else {
       any_changed = (sh->wave_changed[0] | sh->wave_changed[1] | sh->wave_changed[2] | sh->wave_changed[3]) != 0;
     }
-    if (any_changed || it == 0) {
+    if (any_changed || force) {
+      force = false;
       // (the same masks give the same sums and counts: late iterations mostly skip all of this)
       int npos = 0, nneg = 0;
       if constexpr (kWavesAlloc > 4) {
@@ -752,25 +923,24 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
           if (lane == 0) ((k & 1) ? list_neg : list_pos)[j] = res;
         }
       }
-      // whole blocks of 64 entries: no tail code in the chains (adding +0.0 padding is exact: a
-      // running total that started at +0.0 is never -0.0)
+      // whole blocks of 64 entries, both lists padded to the longer one: no tail code in the chain
+      // (adding +0.0 padding is exact: a running total that started at +0.0 is never -0.0)
       const int kp = (npos + 63) & ~63, kn = (nneg + 63) & ~63;
-      for (int j = npos + tid; j < kp; j += kRowsThreads) list_pos[j] = 0.f;
-      for (int j = nneg + tid; j < kn; j += kRowsThreads) list_neg[j] = 0.f;
+      const int kmax = kp > kn ? kp : kn;
+      for (int j = npos + tid; j < kmax; j += kRowsThreads) list_pos[j] = 0.f;
+      for (int j = nneg + tid; j < kmax; j += kRowsThreads) list_neg[j] = 0.f;
       __syncthreads();
-      // ---- the chains: acc = acc + R_j in run order. A single wave issues one addition per four
-      // cycles however the operands arrive, so the two masks' chains run on two different waves
-      // (SIMDs) at the same time. Software pipelined by hand: the eight 16-byte broadcast loads of the
-      // NEXT 32 entries are issued, then the 32 dependent additions of the current ones run while those
-      // loads are in flight (the scheduling barriers keep the compiler from sinking the loads back
-      // behind the additions; it still places the s_waitcnt itself). The lists are over-allocated by
-      // one block: what the last read-ahead fetches is never added.
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const bool neg = m == 1;
-        if (wave != (chain_wave + m) % kWaves) continue;   // (a one-wave workgroup runs both, one after the other)
-        const float4* l4 = reinterpret_cast<const float4*>(neg ? list_neg : list_pos);
-        const int npair = (neg ? kn : kp) >> 6;
+      // ---- the chains: acc = acc + R_j in run order. A wave issues one dependent addition per four
+      // cycles however many lanes take part, so ONE wave walks both lists at once: even lanes the
+      // positive mask's, odd lanes the negative's (per-lane LDS addresses, two distinct ones per
+      // load). Software pipelined by hand: the eight 16-byte loads of the NEXT 32 entries are issued,
+      // then the 32 dependent additions of the current ones run while those loads are in flight
+      // (the scheduling barriers keep the compiler from sinking the loads back behind the additions;
+      // it still places the s_waitcnt itself). The lists are over-allocated by one block: what the
+      // last read-ahead fetches is never added.
+      if (wave == chain_wave) {
+        const float4* l4 = reinterpret_cast<const float4*>((lane & 1) ? list_neg : list_pos);
+        const int npair = kmax >> 6;
         float acc = 0.f;
         float4 qa[8], qb[8];
 #pragma unroll
@@ -789,18 +959,42 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
           for (int k = 0; k < 8; ++k) { acc = acc + qb[k].x; acc = acc + qb[k].y; acc = acc + qb[k].z; acc = acc + qb[k].w; }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (lane == 0) sh->sum[neg ? 1 : 0] = acc;
+        if (lane < 2) sh->sum[lane] = acc;
       }
       __syncthreads();   // totals visible; the list may be rewritten by the next iteration
       pos_sum = sh->sum[0];
       neg_sum = sh->sum[1];
     }
+    }  // dense body
     const OctavStep st = octav_step(guess, pos_sum, neg_sum, cp, cn, len, a.s, a.count_is_f64);
     if (tid == 0) a.hist[static_cast<long long>(it) * a.units + unit] = st.next;
     if (!st.close) moved |= 1ull << it;
     if (reached_fixed_point(guess, st.next)) {
       if (tid == 0) repeat_iterate(a, it, unit, st.next);
       break;
+    }
+    if constexpr (kCanSparse) {
+      if (sparse) {
+        if (!(st.next >= cand_guess)) { sparse = false; force = true; }   // the guess fell below what the candidates passed
+      } else if (allow_sparse && !have_sums && it + 1 < a.max_iter && guess > 0.f && st.next >= guess && cp <= cand_cap && cn <= cand_cap) {
+        // few elements selected and the guess growing: list them (value, position; in row order) and let
+        // one wave re-test the list from now on. tp / tn are this iteration's inclusive scans of the
+        // per-thread counts inside the wave, the exchange area has the waves' totals.
+        const Shared* shc = reinterpret_cast<const Shared*>(smem + kX * ((nit - 1) & 1));
+        int bp = scan_p - __builtin_popcount(wp[0]), bn = scan_n - __builtin_popcount(wn[0]);
+        for (int k = 0; k < wave; ++k) { bp += shc->wave_count[0][k]; bn += shc->wave_count[1][k]; }
+        __syncthreads();        // (the chain wave is done with the run lists)
+        const int e0 = kPiece * tid;
+#pragma unroll
+        for (int i = 0; i < kPiece; ++i) {
+          if ((wp[0] >> i) & 1u) { cand_v[0][bp] = x[0][i]; cand_p[0][bp] = static_cast<unsigned short>(e0 + i); ++bp; }
+          if ((wn[0] >> i) & 1u) { cand_v[1][bn] = x[0][i]; cand_p[1][bn] = static_cast<unsigned short>(e0 + i); ++bn; }
+        }
+        ncand[0] = cp; ncand[1] = cn;
+        cand_guess = guess;
+        sparse = true;
+        __syncthreads();
+      }
     }
     guess = st.next;
   }
@@ -1369,9 +1563,14 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
   const float s = static_cast<float>(p4 / static_cast<double>(exponent_divisor));
   if (unit_len >= kRowsMinLen && unit_len <= kRowsMaxLen && !getenv("MI355Q_OCTAV_WAVE_KERNEL")) {
     // rows of a weight matrix: lanes own 64-element batches of the LDS-resident row
-    OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close};
+    // candidate lists for the late iterations (MI355Q_OCTAV_SPARSE: 0 never, 2 always; default: rows of up to
+    // 4096 elements -- a longer row has its CU to itself, and one wave re-testing the list while fifteen
+    // wait measured slower than all of them rebuilding the masks: 4096 x 11008 1.47 against 1.01 ms)
+    static const int sparse_mode = [] { const char* e = getenv("MI355Q_OCTAV_SPARSE"); return e ? atoi(e) : 1; }();
+    const int threads = octav_rows_threads(static_cast<int>(unit_len));
+    OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close,
+                sparse_mode == 2 || (sparse_mode == 1 && threads <= 256) ? 1 : 0};
     const size_t smem = octav_rows_smem(a.len);
-    const int threads = octav_rows_threads(a.len);
     const int slots = ((a.len + kPiece - 1) / kPiece + threads - 1) / threads;   // 1 .. 4 (> 1 only with 256 threads)
     const int variant = threads == 1024 ? 6 : threads == 512 ? 5 : slots;   // (slots 2 .. 4: MI355Q_OCTAV_NARROW_ROWS)
     const void* fn = variant == 6 ? reinterpret_cast<const void*>(octav_rows_kernel<1, 1024>)
@@ -1382,11 +1581,10 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
                    : threads == 256 ? reinterpret_cast<const void*>(octav_rows_kernel<1, 256>)
                    : threads == 128 ? reinterpret_cast<const void*>(octav_rows_kernel<1, 128>)
                                     : reinterpret_cast<const void*>(octav_rows_kernel<1, 64>);
-    static bool raised[7] = {false, false, false, false, false, false, false};   // > 64 KB of dynamic LDS has to be asked for once
-    if (smem > 64 * 1024 && !raised[variant]) {
+    (void)variant;
+    if (smem > 64 * 1024) {   // > 64 KB of dynamic LDS has to be asked for (per device: set on every call)
       const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return fail(MI355Q_HIP_ERROR, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-      raised[variant] = true;
     }
     if (units > 0x7FFFFFFFLL) return fail(MI355Q_UNSUPPORTED, "too many units");
     void* kargs[] = {&a};

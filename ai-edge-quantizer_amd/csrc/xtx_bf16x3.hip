@@ -12,8 +12,8 @@
 // with every kept term exact: six v_mfma_f32_32x32x16_bf16 products accumulated in float32 give
 // the float32 dot product to within the rounding noise of its own accumulation (what is dropped
 // is below half an ulp of x y). Like the sgemm it replaces, the result depends on the order of the
-// float32 additions (tolerance class T2). Non-finite activations become NaN (inf * 0 in a cross
-// term) instead of +-inf; the damped Cholesky refuses both.
+// float32 additions (tolerance class T2). An infinite activation gives +-inf where x.T.dot(x) does
+// (the x1 y1 sum decides; the NaN of an inf * 0 cross term is dropped); the damped Cholesky refuses it.
 //
 // Two kernels per slab of <= 16384 tokens:
 //   split   X [n, d] float32 -> P[k tile of 16 tokens][plane 0..2][row i < d][32 bytes]: the 16
@@ -96,6 +96,7 @@ struct XtxArgs {
   int accumulate;                // c += product (direct mode)
   int partial;                   // write split z's product to c + z d d
   int patches;                   // 1: 8 x 8 patches of tiles dealt to XCDs; 0: plain triangular list
+  int tri;                       // X is lower triangular (X[k][i] == 0 for k < i): tile row ti starts at k = 128 ti
 };
 
 __global__ __launch_bounds__(256) void xtx_bf16x3_kernel(XtxArgs a) {
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(256) void xtx_bf16x3_kernel(XtxArgs a) {
   }
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wave >> 1, wc = wave & 1;                 // this wave's 64 x 64 quadrant
-  const int kt0 = blockIdx.y * a.kt_per_split;
-  const int kt1 = min(a.kt_total, kt0 + a.kt_per_split);
+  const int kt0 = a.tri ? ti * (kTile / kBK) : blockIdx.y * a.kt_per_split;
+  const int kt1 = a.tri ? a.kt_total : min(a.kt_total, kt0 + a.kt_per_split);
 
   // x1 y1, the five cross terms (the small ones do not round against the large sum), and the sum of the
   // x1 y1 accumulators folded away every kFold k tiles: chains of 32 + 32 additions instead of 1024
@@ -210,7 +211,10 @@ __global__ __launch_bounds__(256) void xtx_bf16x3_kernel(XtxArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = (top[i][j][r] + acc[i][j][r]) + lo[i][j][r];
+        // (an infinite x1 y1 sum is the product's value: the cross terms of a non-finite operand are
+        // inf * 0 = NaN whenever the other side's residual planes are zero, where x.T.dot(x) has +-inf)
+        const float big = top[i][j][r] + acc[i][j][r];
+        const float v = __builtin_isinf(big) ? big : big + lo[i][j][r];
         base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] = a.accumulate ? old[j][r] + v : v;
       }
   }
@@ -430,6 +434,187 @@ __global__ __launch_bounds__(256) void upd2_bf16x3_kernel(UpdArgs a, int ntj) {
   }
 }
 
+// ---- the same split for the GEMMs of the Hessian inverse (gptq.hip): operands are FP64 blocks of
+// the factor; every element is rounded to float32 first (the reference runs these steps in single
+// precision: scipy's strtri and a float32 einsum, ref gptq.py:121-128), then split exactly.
+//
+// B-type operand: element (k, j) = src[k * ld + j] -> planes[kt][p][row0 + j]; grid (cols / 64, pairs of
+// k tiles, items); with `lower` blocks that only hold elements above the diagonal (k < j) are skipped
+// (they are never read: the products start at the diagonal).
+template <typename T>
+__global__ __launch_bounds__(256) void split_cols_kernel(const T* __restrict__ src, long long ld, long long item_stride,
+                                                        int kk, int kt_total, int rows_per_item, int plane_rows,
+                                                        int lower, unsigned char* __restrict__ planes) {
+  __shared__ float tile[32][65];
+  const int i0 = blockIdx.x * 64;
+  const int kb = blockIdx.y * 32;
+  if (lower && kb + 31 < (i0 / kTile) * kTile) return;   // (the products start at the 128-aligned diagonal tile)
+  const T* x = src + static_cast<long long>(blockIdx.z) * item_stride;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 32; r += 4) {
+    const int k = kb + r;
+    tile[r][tx] = k < kk ? static_cast<float>(x[static_cast<long long>(k) * ld + i0 + tx]) : 0.f;
+  }
+  __syncthreads();
+  const int ii = threadIdx.x >> 2, c = threadIdx.x & 3, i = i0 + ii;
+  const int kt = 2 * blockIdx.y + (c >> 1);
+  if (kt >= kt_total) return;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = tile[8 * c + j][ii];
+  const int prow = blockIdx.z * rows_per_item + i;
+  const int cs = (c & 1) ^ ((prow >> 3) & 1);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool finite = (__float_as_uint(v[j]) & 0x7F800000u) != 0x7F800000u;
+      const unsigned bits = bf16_rne_bits(v[j]);
+      w[j >> 1] |= bits << (16 * (j & 1));
+      v[j] = finite ? v[j] - __uint_as_float(bits << 16) : 0.f;   // exact
+    }
+    unsigned char* dst = planes + ((static_cast<long long>(kt) * 3 + p) * plane_rows + prow) * kRowB + cs * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// A-type operand: element (r, k) = src[r * ld + k] -> planes[kt][p][row0 + r]; thread -> (row, chunk of 8 k)
+template <typename T>
+__global__ __launch_bounds__(256) void split_rows_kernel(const T* __restrict__ src, long long ld, long long item_stride,
+                                                        int rows, int kk, int plane_rows, unsigned char* __restrict__ planes) {
+  const int chunks = kk / 8;
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const int row = static_cast<int>(idx / chunks), ch = static_cast<int>(idx % chunks);
+  if (row >= rows) return;
+  const T* e = src + static_cast<long long>(blockIdx.z) * item_stride + static_cast<long long>(row) * ld + ch * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = static_cast<float>(e[j]);
+  const int prow = blockIdx.z * rows + row;
+  const int kt = ch >> 1, cs = (ch & 1) ^ ((prow >> 3) & 1);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool finite = (__float_as_uint(v[j]) & 0x7F800000u) != 0x7F800000u;
+      const unsigned bits = bf16_rne_bits(v[j]);
+      w[j >> 1] |= bits << (16 * (j & 1));
+      v[j] = finite ? v[j] - __uint_as_float(bits << 16) : 0.f;
+    }
+    unsigned char* dst = planes + ((static_cast<long long>(kt) * 3 + p) * plane_rows + prow) * kRowB + cs * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+struct Gemm3Args {
+  const unsigned char* aplanes;   // [k tile][3][a_rows][32 B]: item z owns rows [z m, (z + 1) m)
+  const unsigned char* bplanes;   // [k tile][3][b_rows][32 B]: item z owns rows [z n, (z + 1) n)
+  int a_rows, b_rows;
+  int m_tiles, n_tiles;           // output tiles of one item
+  int kt_total;
+  int k_mode;                     // 0: all k; 1: A lower triangular (k < 128 (ti + 1)); 3: B lower triangular (k >= 128 tj)
+  void* c;                        // item z at c + z c_item (elements), row stride ldc
+  long long ldc, c_item;
+  float alpha;
+  int out_f64;
+};
+
+// C = alpha A B, one 128 x 128 tile per workgroup; the product kernel above with two plane sets, a
+// k range per tile and a plain store. grid (tiles of an item, items).
+__global__ __launch_bounds__(256) void gemm3_bf16x3_kernel(Gemm3Args a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  int ti, tj;
+  {
+    const int b = blockIdx.x;
+    if (a.k_mode == 3) { tj = b / a.m_tiles; ti = b % a.m_tiles; }                       // long columns first
+    else if (a.k_mode == 1) { ti = a.m_tiles - 1 - b / a.n_tiles; tj = b % a.n_tiles; }  // long rows first
+    else { ti = b / a.n_tiles; tj = b % a.n_tiles; }
+  }
+  const int z = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int kt0 = a.k_mode == 3 ? tj * (kTile / kBK) : 0;
+  const int kt1 = a.k_mode == 1 ? min(a.kt_total, (ti + 1) * (kTile / kBK)) : a.kt_total;
+  f32x16 acc[2][2], lo[2][2], top[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = top[i][j][r] = 0.f;
+  const int frow = lane & 31;
+  const int fch = ((lane >> 5) ^ ((frow >> 3) & 1)) * 16;
+  const int offA = (wr * 64 + frow) * kRowB + fch, offB = kOperandB + (wc * 64 + frow) * kRowB + fch;
+  const long long strideA = static_cast<long long>(a.a_rows) * kRowB, strideB = static_cast<long long>(a.b_rows) * kRowB;
+  const unsigned char* gA = a.aplanes + (static_cast<long long>(z) * a.m_tiles + ti) * kPlaneTileB + lane * 16;
+  const unsigned char* gB = a.bplanes + (static_cast<long long>(z) * a.n_tiles + tj) * kPlaneTileB + lane * 16;
+  auto stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int piece = q * 4 + wave;
+      const int op = piece / 12, r = piece % 12, p = r >> 2, seg = r & 3;
+      const unsigned char* src = op ? gB + (static_cast<long long>(kt) * 3 + p) * strideB + seg * 1024
+                                    : gA + (static_cast<long long>(kt) * 3 + p) * strideA + seg * 1024;
+      unsigned char* dst = lds + buf * (2 * kOperandB) + op * kOperandB + p * kPlaneTileB + seg * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  if (kt0 < kt1) stage(kt0, 0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
+    const unsigned char* img = lds + buf * (2 * kOperandB);
+    bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fa[i][p] = *reinterpret_cast<const bf16x8*>(img + offA + p * kPlaneTileB + i * 32 * kRowB);
+        fb[i][p] = *reinterpret_cast<const bf16x8*>(img + offB + p * kPlaneTileB + i * 32 * kRowB);
+      }
+#define MI355Q_TERM(ACC, PA, PB)                                                                \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], ACC[i][j], 0, 0, 0)
+    MI355Q_TERM(lo, 0, 2);
+    MI355Q_TERM(lo, 1, 1);
+    MI355Q_TERM(lo, 2, 0);
+    MI355Q_TERM(lo, 0, 1);
+    MI355Q_TERM(lo, 1, 0);
+    MI355Q_TERM(acc, 0, 0);
+#undef MI355Q_TERM
+    if (((kt - kt0) & (kFold - 1)) == kFold - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            top[i][j][r] = top[i][j][r] + acc[i][j][r];
+            acc[i][j][r] = 0.f;
+          }
+    }
+  }
+  const long long row0 = static_cast<long long>(ti) * kTile + wr * 64 + 4 * (lane >> 5);
+  const long long col0 = static_cast<long long>(tj) * kTile + wc * 64 + (lane & 31);
+  const long long base = static_cast<long long>(z) * a.c_item + row0 * a.ldc + col0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = a.alpha * ((top[i][j][r] + acc[i][j][r]) + lo[i][j][r]);
+        const long long at = base + static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.ldc + j * 32;
+        if (a.out_f64) static_cast<double*>(a.c)[at] = static_cast<double>(v);
+        else static_cast<float*>(a.c)[at] = v;
+      }
+}
+
 // c (+)= partial[0] + partial[1] + ... (slices added in order) over the lower-triangular tiles
 __global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict__ partial, int splits, int d,
                                                         int accumulate, float* __restrict__ c) {
@@ -467,8 +652,9 @@ size_t xtx_bf16x3_workspace_bytes(int64_t n, int64_t d) {
          (splits > 1 ? static_cast<size_t>(splits) * d * d * sizeof(float) : 0);
 }
 
-// p (float32 [d, d], lower-triangular 128 x 128 tiles valid) = X^T X for X float32 [n, d].
-int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspace, hipStream_t st) {
+// p (float32 [d, d], lower-triangular 128 x 128 tiles valid) = X^T X for X float32 [n, d]
+// (accumulate_first: p += X^T X, the product of earlier calls).
+int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspace, hipStream_t st, bool accumulate_first) {
   unsigned char* planes = reinterpret_cast<unsigned char*>(
       (reinterpret_cast<uintptr_t>(workspace) + 1023) & ~static_cast<uintptr_t>(1023));
   const int tiles = static_cast<int>(d / kTile);
@@ -486,7 +672,7 @@ int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspa
     a.kt_per_split = (kt + splits - 1) / splits;
     a.partial = splits > 1 ? 1 : 0;
     a.c = splits > 1 ? partial : p;
-    a.accumulate = (splits == 1 && k0 > 0) ? 1 : 0;
+    a.accumulate = (splits == 1 && (k0 > 0 || accumulate_first)) ? 1 : 0;
     a.patches = tiles >= 4 * kSuper ? 1 : 0;
     unsigned gx;
     if (a.patches) {
@@ -498,9 +684,67 @@ int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspa
     hipLaunchKernelGGL(xtx_bf16x3_kernel, dim3(gx, static_cast<unsigned>(splits)), dim3(256), 4 * kOperandB, st, a);
     if (splits > 1)
       hipLaunchKernelGGL(xtx_reduce_kernel, dim3(2048), dim3(256), 0, st, partial, splits, static_cast<int>(d),
-                         k0 > 0 ? 1 : 0, p);
+                         (k0 > 0 || accumulate_first) ? 1 : 0, p);
   }
   MI355Q_CHECK_LAUNCH("xtx bf16x3 launch");
+  return MI355Q_OK;
+}
+
+// ---- Hessian inverse on the split (gptq.hip) ----
+// One merge level of the triangular inverse: for `items` pairs of adjacent inverted s x s blocks
+// (pair z at a + z hop, hop = 2 s (d + 1)):  L21 <- -L22^-1 (L21 L11^-1).  scratch: 4 d s bytes... see hinv_split_scratch_bytes.
+size_t hinv_split_scratch_bytes(int64_t d) { return static_cast<size_t>(d) * d * 6; }
+
+int32_t trtri_level_bf16x3(double* a, int64_t d, int64_t s, int64_t items, void* scratch, hipStream_t st) {
+  const long long hop = 2 * s * (d + 1);
+  const int kt = static_cast<int>(s / kBK);
+  const int rows = static_cast<int>(items * s);            // plane rows of every operand set
+  unsigned char* base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(scratch) + 1023) & ~static_cast<uintptr_t>(1023));
+  float* tmat = reinterpret_cast<float*>(base);                               // items x [s, s] float32
+  unsigned char* pa = base + static_cast<size_t>(items) * s * s * sizeof(float);
+  pa = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(pa) + 1023) & ~static_cast<uintptr_t>(1023));
+  unsigned char* pb = pa + static_cast<size_t>(kt) * 3 * rows * kRowB;
+  const unsigned tiles = static_cast<unsigned>(s / kTile);
+  // T = L21 L11^-1 (B lower triangular: k >= column)
+  hipLaunchKernelGGL((split_rows_kernel<double>), dim3(static_cast<unsigned>((s * (s / 8) + 255) / 256), 1, static_cast<unsigned>(items)),
+                     dim3(256), 0, st, a + s * d, static_cast<long long>(d), hop, static_cast<int>(s), static_cast<int>(s), rows, pa);
+  hipLaunchKernelGGL((split_cols_kernel<double>), dim3(static_cast<unsigned>(s / 64), static_cast<unsigned>((kt + 1) / 2), static_cast<unsigned>(items)),
+                     dim3(256), 0, st, a, static_cast<long long>(d), hop, static_cast<int>(s), kt, static_cast<int>(s), rows, 1, pb);
+  Gemm3Args g1{pa, pb, rows, rows, static_cast<int>(tiles), static_cast<int>(tiles), kt, 3, tmat, s, s * s, 1.0f, 0};
+  hipLaunchKernelGGL(gemm3_bf16x3_kernel, dim3(tiles * tiles, static_cast<unsigned>(items)), dim3(256), 4 * kOperandB, st, g1);
+  // L21 = -L22^-1 T (A lower triangular: k <= row)
+  hipLaunchKernelGGL((split_rows_kernel<double>), dim3(static_cast<unsigned>((s * (s / 8) + 255) / 256), 1, static_cast<unsigned>(items)),
+                     dim3(256), 0, st, a + s * d + s, static_cast<long long>(d), hop, static_cast<int>(s), static_cast<int>(s), rows, pa);
+  hipLaunchKernelGGL((split_cols_kernel<float>), dim3(static_cast<unsigned>(s / 64), static_cast<unsigned>((kt + 1) / 2), static_cast<unsigned>(items)),
+                     dim3(256), 0, st, tmat, static_cast<long long>(s), static_cast<long long>(s * s), static_cast<int>(s), kt,
+                     static_cast<int>(s), rows, 0, pb);
+  Gemm3Args g2{pa, pb, rows, rows, static_cast<int>(tiles), static_cast<int>(tiles), kt, 1, a + s * d, d, hop, -1.0f, 1};
+  hipLaunchKernelGGL(gemm3_bf16x3_kernel, dim3(tiles * tiles, static_cast<unsigned>(items)), dim3(256), 4 * kOperandB, st, g2);
+  MI355Q_CHECK_LAUNCH("trtri level (bf16 split) launch");
+  return MI355Q_OK;
+}
+
+// hinv (float32 [d, d], lower-triangular tiles) = Linv^T Linv for the lower-triangular FP64 Linv [d, d]
+// (d a multiple of 128, <= 16384: one slab).
+int32_t ltl_bf16x3(const double* linv, int64_t d, float* hinv, void* scratch, hipStream_t st) {
+  unsigned char* planes = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(scratch) + 1023) & ~static_cast<uintptr_t>(1023));
+  const int kt = static_cast<int>(d / kBK);
+  hipLaunchKernelGGL((split_cols_kernel<double>), dim3(static_cast<unsigned>(d / 64), static_cast<unsigned>((kt + 1) / 2), 1), dim3(256), 0, st,
+                     linv, static_cast<long long>(d), 0LL, static_cast<int>(d), kt, static_cast<int>(d), static_cast<int>(d), 1, planes);
+  const int tiles = static_cast<int>(d / kTile);
+  XtxArgs a{};
+  a.planes = planes; a.d = static_cast<int>(d); a.tiles = tiles; a.kt_total = kt; a.kt_per_split = kt;
+  a.c = hinv; a.accumulate = 0; a.partial = 0; a.tri = 1;
+  a.patches = tiles >= 4 * kSuper ? 1 : 0;
+  unsigned gx;
+  if (a.patches) {
+    const int sside = (tiles + kSuper - 1) / kSuper, nsup = sside * (sside + 1) / 2;
+    gx = static_cast<unsigned>((nsup + 7) / 8 * 8 * kSuper * kSuper);
+  } else {
+    gx = static_cast<unsigned>(tiles * (tiles + 1) / 2);
+  }
+  hipLaunchKernelGGL(xtx_bf16x3_kernel, dim3(gx, 1), dim3(256), 4 * kOperandB, st, a);
+  MI355Q_CHECK_LAUNCH("hinv product (bf16 split) launch");
   return MI355Q_OK;
 }
 

@@ -54,6 +54,9 @@ PROTOTYPES = {
                                 c_i64, c_i64, c_i64, c_f64, c_f64, c_i32, c_ptr]),
     "mi355q_gptq_xtx_workspace_bytes": (c_size, [c_i64, c_i64]),
     "mi355q_gptq_xtx_f32": (c_i32, [c_ptr, c_i64, c_i64, c_f64, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_gptq_xtx_accum_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "mi355q_gptq_xtx_accum_f32": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_i32, c_ptr, c_size, c_ptr]),
+    "mi355q_gptq_xtx_finish_f64": (c_i32, [c_ptr, c_i64, c_f64, c_ptr, c_ptr]),
     "mi355q_gptq_hessian_merge_f64": (c_i32, [c_ptr, c_f64, c_ptr, c_f64, c_i64, c_ptr, c_ptr]),
     "mi355q_gptq_hinv_workspace_bytes": (c_size, [c_i64]),
     "mi355q_shutdown": (c_i32, []),
@@ -82,6 +85,8 @@ PROTOTYPES = {
     "mi355q_allreduce_sum_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr]),
     "mi355q_allreduce_sum_f64": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr]),
     "mi355q_allreduce_hessian_f64": (c_i32, [c_ptr, c_ptr, c_i64, c_f64, c_ptr]),
+    "mi355q_hessian_exchange_workspace_bytes": (c_size, [c_i64]),
+    "mi355q_reduce_hessian_f64": (c_i32, [c_ptr, c_ptr, c_i64, c_f64, c_i32, c_ptr, c_size, c_ptr]),
 }
 
 STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "BAD_SHAPE", -3: "UNSUPPORTED", -4: "HIP_ERROR",

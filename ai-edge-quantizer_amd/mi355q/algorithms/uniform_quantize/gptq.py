@@ -75,19 +75,25 @@ class HessianAccumulator(rt.HbmArray):
 
   The mean over samples i of H_i weighted by n_i is (2/N) sum_i X_i^T X_i, N = sum n_i: tokens that
   have not been multiplied yet wait in a float32 slab and leave SLAB_TOKENS at a time through
-  mi355q_gptq_xtx_f32 (the bf16-split product needs >= 1024 tokens to run at all, and one product
-  of 16384 tokens costs a tenth of 32 products of 512); the slab's Hessian then joins the running
-  mean through mi355q_gptq_hessian_merge_f64, the reference's rule at slab granularity. Reading
-  the array (device_tensor, np.asarray, ...) multiplies what is pending first."""
+  mi355q_gptq_xtx_accum_f32 into ONE float32 product (the bf16-split product needs >= 1024
+  tokens to run at all, and one product of 16384 tokens costs a tenth of 32 products of 512;
+  slabs add to the product in float32 like the K loop's own steps). The product becomes the
+  float64 Hessian -- (2/N) product, mi355q_gptq_xtx_finish_f64 -- when somebody reads the array
+  (device_tensor, np.asarray, ...) and is given back by finalize(). A Hessian that arrives as a
+  finished float64 array (resumed calibration, another process's share) joins through
+  mi355q_gptq_hessian_merge_f64, the reference's rule (utils/qsv_utils.py:71-88)."""
   SLAB_TOKENS = 16384
 
   def __init__(self, d: int):  # pylint: disable=super-init-not-called
     self.d = int(d)
-    self._mean = None             # float64 [d, d] over _n_done samples
+    self._mean = None             # float64 [d, d] over _n_done samples (only what joined as float64)
     self._n_done = 0.0
+    self._prod = None             # float32 [d, d]: sum of X^T X over _n_prod samples
+    self._n_prod = 0.0
     self._slab = None             # float32 [capacity, d]
     self._fill = 0
     self._n_pending = 0.0
+    self._value = None            # the float64 statistic, while nothing changed since it was formed
     self._host = None
     self.cache = {}
     self.packed = None
@@ -98,15 +104,19 @@ class HessianAccumulator(rt.HbmArray):
     acc.add(x2d, num_samples)
     return acc
 
+  def _touched(self) -> None:
+    self._value = self._host = None
+    self.cache.clear()
+
   def add(self, x2d, num_samples: float) -> None:
     """x2d: float32 device tensor [tokens, d] (copied: the caller's buffer may change)."""
     import torch
     t = int(x2d.shape[0])
-    self._host = None
-    self.cache.clear()
+    self._touched()
     if t >= self.SLAB_TOKENS:        # a slab's worth on its own: multiplied where it lies
       self.flush()
-      self._join(ops.gptq_xtx(x2d.contiguous(), 2.0 / float(num_samples)), float(num_samples))
+      self._prod = ops.gptq_xtx_accum(x2d.contiguous(), self._prod)
+      self._n_prod += float(num_samples)
       return
     if self._slab is not None and self._fill + t > self._slab.shape[0] and self._fill:
       if self._slab.shape[0] < self.SLAB_TOKENS and self._fill + t <= self.SLAB_TOKENS:
@@ -122,7 +132,7 @@ class HessianAccumulator(rt.HbmArray):
     self._n_pending += float(num_samples)
 
   def _join(self, h, n: float) -> None:
-    """running mean <- weighted mean with Hessian h of n samples (ref utils/qsv_utils.py:71-88)."""
+    """float64 mean <- weighted mean with Hessian h of n samples (ref utils/qsv_utils.py:71-88)."""
     if self._mean is None:
       self._mean, self._n_done = h, n
     else:
@@ -131,33 +141,48 @@ class HessianAccumulator(rt.HbmArray):
 
   def absorb(self, other: "HessianAccumulator") -> None:
     """self <- the mean over both sets of samples."""
+    self._touched()
     if other._fill:   # pylint: disable=protected-access
       self.add(other._slab[:other._fill], other._n_pending)   # pylint: disable=protected-access
-    if other._mean is not None:   # pylint: disable=protected-access
+    if other._prod is not None:   # pylint: disable=protected-access
       self.flush()
+      if self._prod is None:
+        self._prod, self._n_prod = other._prod.clone(), other._n_prod   # pylint: disable=protected-access
+      else:
+        self._prod += other._prod   # pylint: disable=protected-access
+        self._n_prod += other._n_prod   # pylint: disable=protected-access
+    if other._mean is not None:   # pylint: disable=protected-access
       self._join(other._mean, other._n_done)   # pylint: disable=protected-access
-      self._host = None
-      self.cache.clear()
 
   def flush(self) -> None:
     if not self._fill:
       return
-    self._join(ops.gptq_xtx(self._slab[:self._fill], 2.0 / self._n_pending), self._n_pending)
+    self._prod = ops.gptq_xtx_accum(self._slab[:self._fill], self._prod)
+    self._n_prod += self._n_pending
     self._fill, self._n_pending = 0, 0.0
 
   def finalize(self) -> None:
-    """Multiplies what is pending and gives the slab's HBM back."""
-    self.flush()
-    self._slab = None
+    """Forms the float64 statistic and gives slab and product back."""
+    value = self.device_tensor
+    self._mean, self._n_done = value, self._n_done + self._n_prod
+    self._prod, self._n_prod, self._slab = None, 0.0, None
+    self._value = value
 
   @property
   def device_tensor(self):
-    self.flush()
-    return self._mean
+    if self._value is None:
+      self.flush()
+      if self._prod is None:
+        self._value = self._mean
+      else:
+        h = ops.gptq_xtx_finish(self._prod, 2.0 / self._n_prod)
+        self._value = h if self._mean is None else ops.gptq_hessian_merge(self._mean, self._n_done, h, self._n_prod)
+    return self._value
 
   @device_tensor.setter
   def device_tensor(self, value) -> None:
-    self._mean, self._fill, self._n_pending = value, 0, 0.0
+    self._mean, self._prod, self._n_prod, self._fill, self._n_pending = value, None, 0.0, 0, 0.0
+    self._value = value
 
   @property
   def shape(self):
@@ -180,7 +205,8 @@ class HessianAccumulator(rt.HbmArray):
     return self.d * self.d * 8
 
   def __repr__(self):
-    return f"HessianAccumulator(d={self.d}, samples={self._n_done + self._n_pending:g}, pending_tokens={self._fill})"
+    return (f"HessianAccumulator(d={self.d}, samples={self._n_done + self._n_prod + self._n_pending:g},"
+            f" pending_tokens={self._fill})")
 
 
 def hessian_of(tensor_content: np.ndarray, num_samples):

@@ -120,6 +120,7 @@ class Calibrator:
       h = qsv.get("hessian") if isinstance(qsv, dict) else None
       if hasattr(h, "finalize"):
         h.finalize()
+    ops.release_scratch()
 
   @contextlib.contextmanager
   def plan_once(self):

@@ -178,7 +178,7 @@ def quantize_sharded(tensors: dict[str, np.ndarray],
 COST_MODEL = {
     # damped Hessian inverse (mi355q_gptq_hinv_f64): d^3 flop at the rate the blocked factorization
     # sustains + one serial step per 64 columns
-    "hinv_flops_per_s": float(os.environ.get("MI355Q_COST_HINV_FLOPS", 55e12)),
+    "hinv_flops_per_s": float(os.environ.get("MI355Q_COST_HINV_FLOPS", 97e12)),
     "hinv_step_s": 40e-6,
     # OBS apply (mi355q_gptq_apply_f32): one dependent quantize -> divide -> update step per
     # column + 2 rows d^2 flop of lazy updates (bf16 split path for wide / tall layers)
@@ -299,7 +299,7 @@ def hessian_owners(plan: Sequence[tuple], owner: Sequence[int], costs) -> dict[s
 
 
 def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dict] = None,
-                           serialize_to_path=None, group=None):
+                           serialize_to_path=None, group=None, planned=None):
   """`Quantizer(float_model, recipe).quantize(...)` with the ops' weight work spread over the
   ranks of `group` (BASELINE configs 3 and 5: tensor-buffers sharded over 8 GPUs).
 
@@ -314,7 +314,9 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
   """
   from . import model_modifier, requant_queue
   rank, world = _world(group)
-  qz, gen, plan, owner, _ = plan_model_shards(float_model, recipe, world, calibration_result)
+  # (`planned`: the plan_model_shards() result a caller already derived -- calibrate_and_quantize_sharded
+  # plans before calibration, when no rank's statistics can make its plan differ from the others')
+  qz, gen, plan, owner, _ = planned if planned is not None else plan_model_shards(float_model, recipe, world, calibration_result)
   rm = qz._recipe_manager  # pylint: disable=protected-access
   if rm.need_calibration() and not calibration_result:
     raise RuntimeError(
@@ -344,6 +346,40 @@ def _gather_results(mine: dict, group=None) -> Optional[dict]:
   for part in gathered:
     merged.update(part)
   return merged
+
+
+def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serialize_to_path=None, group=None,
+                                   tensor_provider=None, stats: Optional[dict] = None):
+  """BASELINE config 5 in one call: `Quantizer.calibrate` + `Quantizer.quantize` over a process group.
+
+  The op plan comes first (a function of model, recipe and world size: the same on every rank), so
+  calibration knows which rank will read which GPTQ Hessian: samples are sharded over the ranks
+  (calibrate_sharded), every rank multiplies the tokens of its own samples, and each Hessian is
+  reduced -- packed lower triangle, one ncclReduce -- to the one rank that owns the ops reading it
+  instead of being all-reduced to all. Then every rank materializes its ops (quantize_model_sharded)
+  and rank 0 writes the file. Returns the serialized model on rank 0, None elsewhere. `stats`, when
+  given, receives wall seconds per phase."""
+  import time
+  rank, world = _world(group)
+  t0 = time.perf_counter()
+  planned = plan_model_shards(float_model, recipe, world)
+  qz, _, plan, owner, costs = planned
+  owners = hessian_owners(plan, owner, costs) if world > 1 else None
+  qsvs = None
+  if qz._recipe_manager.need_calibration():  # pylint: disable=protected-access
+    qsvs = calibrate_sharded(qz.float_model, recipe, calibration_data, tensor_provider=tensor_provider, group=group,
+                             hessian_owners=owners)
+  if torch.cuda.is_available():
+    torch.cuda.synchronize()
+  t1 = time.perf_counter()
+  out = quantize_model_sharded(qz.float_model, recipe, calibration_result=qsvs, serialize_to_path=serialize_to_path,
+                               group=group, planned=planned)
+  if torch.cuda.is_available():
+    torch.cuda.synchronize()
+  if stats is not None:
+    stats["calibrate_s"] = stats.get("calibrate_s", 0.0) + (t1 - t0)
+    stats["quantize_and_write_s"] = stats.get("quantize_and_write_s", 0.0) + (time.perf_counter() - t1)
+  return out
 
 
 # ------------------------------------------------ activation calibration ---
@@ -384,7 +420,8 @@ def _ema_and_count_update(qsv, new_qsv):
 
 
 def calibrate_sharded(float_model, recipe, calibration_data, previous_calibration_result=None,
-                      tensor_provider=None, group=None, hessians: str = "consumed") -> dict:
+                      tensor_provider=None, group=None, hessians: str = "consumed",
+                      hessian_owners: Optional[dict[str, int]] = None) -> dict:
   """`Quantizer(float_model, recipe).calibrate(calibration_data)` with every signature's samples
   sharded contiguously over the ranks of `group` (BASELINE config 4: 512 samples over 8 GPUs;
   config 5: GPTQ Hessians).
@@ -396,7 +433,9 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
   bit for bit. GPTQ Hessians (d x d float64 per activation) never enter the gather: every rank
   keeps the running mean over its own samples in HBM and the ranks combine them with one
   all-reduce(sum) per distinct Hessian (merge_hessians_across_ranks, X2), exact up to FP64
-  rounding. Returns the model QSVs on every rank.
+  rounding. Returns the model QSVs on every rank. With `hessian_owners` (tensor name -> rank, see
+  calibrate_and_quantize_sharded) a Hessian is reduced to that one rank only and the other ranks'
+  QSVs carry no "hessian" entry for it.
   """
   from . import calibrator, quantizer
   rank, world = _world(group)
@@ -431,8 +470,12 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
         entry = totals.setdefault(name, [qsv["hessian_dim"], 0])
         entry[1] += qsv["num_samples"]
   merged = merge_hessians_across_ranks({n: (h, c) for n, (h, c) in running.items()},
-                                       {n: (d, c) for n, (d, c) in totals.items()}, group)
+                                       {n: (d, c) for n, (d, c) in totals.items()}, group, hessian_owners)
   qsvs = final.get_model_qsvs()
+  for name in totals:
+    if name not in merged:          # reduced to another rank: this one never reads it
+      qsvs[name].pop("hessian_dim", None)
+      qsvs[name].pop("hessian", None)
   for name, h in merged.items():
     qsv = qsvs[name]
     qsv.pop("hessian_dim", None)
@@ -607,17 +650,20 @@ allreduce_second_moment = allreduce_hessian   # OSCAR mu2: same sample-weighted 
 
 
 def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dict[str, tuple[int, float]],
-                                group=None) -> dict[str, Any]:
+                                group=None, owners: Optional[dict[str, int]] = None) -> dict[str, Any]:
   """X2: the sample-weighted mean of every GPTQ Hessian over all ranks.
 
   local[name] = (H_rank, n_rank): this rank's running mean over its own samples (the chain of
   _gptq_merge_hessian, ref utils/qsv_utils.py:71-102) and their sample count; names this rank
   saw no sample of are simply absent. totals[name] = (d, N): Hessian order and the sample count
   over all ranks (known to every rank from the gathered per-sample records, so no collective is
-  spent on counts). Per distinct Hessian, in sorted-name order on every rank: H_rank *= n_rank/N,
-  one in-place all-reduce(sum) of d*d float64 (32 MiB at d = 2048, 2 GiB at d = 16384) --
-  mi355q_allreduce_hessian_f64 over RCCL when ranks own GPUs; nothing d x d is ever pickled.
-  Returns {name: H} (runtime.HbmArray when the data lives in HBM).
+  spent on counts). Per distinct Hessian, in sorted-name order on every rank: the packed lower
+  triangle of H_rank * n_rank / N (the matrix is symmetric: d (d + 1) / 2 float64, 1 GiB at
+  d = 16384 instead of 2) goes through one collective -- mi355q_reduce_hessian_f64 over RCCL when
+  ranks own GPUs; nothing d x d is ever pickled. `owners` (tensor name -> rank, from
+  hessian_owners(): the one rank whose ops read that Hessian) turns the all-reduce into a reduce to
+  that rank, half the ring traffic again; without it every rank ends with every mean.
+  Returns {name: H} (runtime.HbmArray when the data lives in HBM) for the Hessians this rank holds.
   """
   rank, world = _world(group)
   comm = rccl_comm(group) if world > 1 else None
@@ -627,28 +673,42 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
     if hasattr(h, "finalize"):       # tokens still waiting in a slab are multiplied now
       h.finalize()
   if on_gpu:
-    from . import _ffi
+    from . import _ffi, ops
     from . import runtime as rt
+    ops.release_scratch()
+  scratch = None
   for name in sorted(totals):
     d, total = totals[name]
     h, n_rank = local.get(name, (None, 0.0))
+    root = -1 if owners is None else int(owners.get(name, -1))
+    mine = root < 0 or root == rank
     if world == 1:
       out[name] = h
       continue
     weight = float(n_rank) / float(total) if total else 0.0
     if on_gpu:
-      t = (torch.zeros((d, d), dtype=torch.float64, device=rt.device()) if h is None
-           else rt.on_device(h, torch.float64).clone())       # the QSV's own Hessian stays as it is
+      if h is None:
+        t = torch.zeros((d, d), dtype=torch.float64, device=rt.device())
+      else:                        # the rank that keeps the result works on a copy: the QSV's own Hessian stays as it is
+        t = rt.on_device(h, torch.float64)
+        t = t.clone() if mine else t
       if comm is not None:
-        _ffi.check(_ffi.lib().mi355q_allreduce_hessian_f64(comm, rt.ptr(t), d, weight, rt.stream_ptr()))
+        L = _ffi.lib()
+        need = L.mi355q_hessian_exchange_workspace_bytes(d)
+        if scratch is None or scratch.numel() < need:
+          scratch = rt.empty((need,), torch.uint8)
+        _ffi.check(L.mi355q_reduce_hessian_f64(comm, rt.ptr(t), d, weight, root, rt.ptr(scratch), scratch.numel(),
+                                               rt.stream_ptr()))
       else:                                                     # test transport: ranks share a GPU
         host = (t * weight).cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         t = host.to(rt.device())
-      out[name] = rt.HbmArray(t)
+      if mine:
+        out[name] = rt.HbmArray(t)
     else:
       t = torch.zeros((d, d), dtype=torch.float64) if h is None else torch.from_numpy(np.array(h, dtype=np.float64))
       t *= weight
       dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-      out[name] = t.numpy()
+      if mine:
+        out[name] = t.numpy()
   return out

@@ -362,6 +362,45 @@ def gptq_xtx(x: torch.Tensor, alpha: float) -> torch.Tensor:
   return h
 
 
+_XTX_SCRATCH: dict = {}      # (device index, d) -> uint8 scratch for products of <= 16384-token slabs
+
+
+def gptq_xtx_accum(x: torch.Tensor, product: torch.Tensor | None) -> torch.Tensor:
+  """product (float32 [d, d], lower-triangular part valid) (+)= x^T x for float32 x [n, d];
+  None starts a new product. The scratch (bfloat16 planes of a slab / split-K partials, up to
+  1.5 GiB at d = 16384) is kept per device and width: calibration calls this once per slab and
+  Hessian, back to back on one stream."""
+  rt.require_gpu()
+  x = _f32(x)
+  n, d = x.shape
+  L = _ffi.lib()
+  nbytes = L.mi355q_gptq_xtx_accum_workspace_bytes(n, d)
+  key = (x.device.index, d)
+  ws = _XTX_SCRATCH.get(key)
+  if ws is None or ws.numel() < nbytes:
+    ws = _XTX_SCRATCH[key] = rt.empty((max(nbytes, L.mi355q_gptq_xtx_accum_workspace_bytes(16384, d), 1),), torch.uint8)
+  fresh = product is None
+  if fresh:
+    product = rt.empty((d, d), torch.float32)
+  _ffi.check(L.mi355q_gptq_xtx_accum_f32(rt.ptr(x), n, d, rt.ptr(product), 0 if fresh else 1, rt.ptr(ws),
+                                         ws.numel(), rt.stream_ptr()))
+  return product
+
+
+def gptq_xtx_finish(product: torch.Tensor, alpha: float) -> torch.Tensor:
+  """float64 [d, d] = alpha * product, both triangles (ref gptq.py:100-107's scaling)."""
+  rt.require_gpu()
+  d = product.shape[0]
+  h = rt.empty((d, d), torch.float64)
+  _ffi.check(_ffi.lib().mi355q_gptq_xtx_finish_f64(rt.ptr(product), d, float(alpha), rt.ptr(h), rt.stream_ptr()))
+  return h
+
+
+def release_scratch() -> None:
+  """Gives the cached product scratch back (ParamsGenerator / Calibrator call this when done)."""
+  _XTX_SCRATCH.clear()
+
+
 def gptq_hessian_merge(h_cur: torch.Tensor, n_cur: float, h_new: torch.Tensor, n_new: float):
   """(h_cur*n_cur + h_new*n_new)/(n_cur+n_new), float64. ref: qsv_utils.py:71-88."""
   rt.require_gpu()

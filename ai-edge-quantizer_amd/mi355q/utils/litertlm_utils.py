@@ -222,17 +222,22 @@ def calibrate_litertlm(litertlm_path: Path, recipe: Any, calibration_data: Mappi
 
 
 def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path, overwrite: bool = False,
-                      calibration_results: Optional[Mapping] = None, group: Any = None) -> Optional[int]:
+                      calibration_results: Optional[Mapping] = None, group: Any = None,
+                      calibration_data: Optional[Mapping] = None, tensor_provider: Optional[Any] = None,
+                      stats: Optional[dict] = None) -> Optional[int]:
   """Quantizes every TFLite section that has a recipe and re-packs the container.
 
   `recipe` is one recipe (list) applied to every model, or a mapping model_type -> recipe with
   an optional "default" entry (ref aeq.py:61-181). `calibration_results` maps a section (index,
   model type or "default") to the model QSVs its recipe needs (static recipes, GPTQ, OSCAR:
   what Quantizer.calibrate / calibrate_litertlm returned) -- the reference's loop passes none
-  and therefore cannot run such recipes on a container. With a process group (`group`, or an
+  and therefore cannot run such recipes on a container. `calibration_data` (same keys; a model's
+  {signature key: samples}, see calibrate_litertlm) instead has the statistics collected here, in
+  the same call (distributed.calibrate_and_quantize_sharded: with several ranks every GPTQ Hessian
+  is reduced straight to the rank that will read it). With a process group (`group`, or an
   initialised default group) the ops of every model are spread over the ranks by cost and by
   shared statistics (distributed.quantize_model_sharded); rank 0 writes the file and returns
-  its size, the other ranks return None.
+  its size, the other ranks return None. `stats` receives wall seconds per phase.
   """
   from .. import distributed
   if os.path.exists(output_path) and not overwrite:
@@ -241,9 +246,14 @@ def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path, overw
   replaced: dict[int, Any] = {}
   quantized_any = False
   for sid, model_type, model_recipe in _tflite_sections(src, _recipes(recipe)):
-    result = distributed.quantize_model_sharded(
-        src.get_section_buffer(sid), model_recipe,
-        calibration_result=_pick(calibration_results, sid, model_type), group=group)
+    data = _pick(calibration_data, sid, model_type)
+    if data is not None:
+      result = distributed.calibrate_and_quantize_sharded(
+          src.get_section_buffer(sid), model_recipe, data, group=group, tensor_provider=tensor_provider, stats=stats)
+    else:
+      result = distributed.quantize_model_sharded(
+          src.get_section_buffer(sid), model_recipe,
+          calibration_result=_pick(calibration_results, sid, model_type), group=group)
     quantized_any = True
     if result is not None:
       replaced[sid] = result
@@ -251,4 +261,9 @@ def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path, overw
     raise ValueError("No models were quantized, not creating output file.")
   if not replaced:          # a rank other than the group's first: nothing to write
     return None
-  return src.serialize(output_path, replaced)
+  import time
+  t0 = time.perf_counter()
+  n = src.serialize(output_path, replaced)
+  if stats is not None:
+    stats["repack_s"] = stats.get("repack_s", 0.0) + (time.perf_counter() - t0)
+  return n

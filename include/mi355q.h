@@ -273,6 +273,21 @@ int32_t mi355q_gptq_xtx_f32(const float* x, int64_t n, int64_t d, double alpha,
                             double* hessian_out, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* K8 in two steps, for statistics collected over many calibration samples: the sample-weighted
+ * mean of (2 / n_i) X_i^T X_i over samples i (what chaining _gptq_merge_hessian yields, ref
+ * utils/qsv_utils.py:71-102) is (2 / N) sum_i X_i^T X_i with N = sum n_i, so the float32 product
+ * itself is accumulated -- product (float32 [d, d], lower-triangular part valid) (+)= X^T X, the
+ * addition in float32 like the K loop's own -- and scaled into FLOAT64 once at the end:
+ * hessian_out = alpha * product, mirrored to both triangles. accumulate == 0 starts a product.
+ * workspace: mi355q_gptq_xtx_accum_workspace_bytes(n, d) (the bfloat16 planes of one slab of
+ * <= 16384 tokens or the split-K partial sums; no room for the product, which is the caller's). */
+size_t mi355q_gptq_xtx_accum_workspace_bytes(int64_t n, int64_t d);
+int32_t mi355q_gptq_xtx_accum_f32(const float* x, int64_t n, int64_t d, float* product,
+                                  int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+int32_t mi355q_gptq_xtx_finish_f64(const float* product, int64_t d, double alpha,
+                                   double* hessian_out, void* stream);
+
 /* Sample-weighted running mean of two Hessians, FLOAT64:
  * h_out = (h_cur*n_cur + h_new*n_new) / (n_cur + n_new); h_out may alias an input.
  * ref: utils/qsv_utils.py:71-88 (_gptq_merge_hessian) */
@@ -419,6 +434,17 @@ int32_t mi355q_allreduce_sum_f64(void* comm, double* buf, int64_t n, void* strea
  * FP64 rounding (ref: utils/qsv_utils.py:71-102). One collective of d*d*8 bytes per distinct
  * Hessian: 32 MiB at d = 2048, 2 GiB at d = 16384. A rank without samples passes zeros, weight 0. */
 int32_t mi355q_allreduce_hessian_f64(void* comm, double* hessian, int64_t d, double weight, void* stream);
+/* X2 at half the bytes, and to the one rank that needs it: the Hessian is symmetric, so only its
+ * packed lower triangle (d (d + 1) / 2 doubles: 1 GiB at d = 16384) travels -- packed = weight *
+ * lower(hessian) in `workspace`, one all-reduce(sum) (root < 0: every rank ends with the mean) or one
+ * reduce(sum) to `root` (under GPTQ exactly one rank reads a given Hessian: the owner of the ops
+ * whose input it belongs to; a ring reduce moves half of what a ring all-reduce does), then the
+ * receiving ranks unpack to both triangles in place. On the other ranks `hessian` is left as it was.
+ * The sum is the same FP64 sum of the same weighted entries as in mi355q_allreduce_hessian_f64.
+ * workspace: mi355q_hessian_exchange_workspace_bytes(d) bytes. */
+size_t mi355q_hessian_exchange_workspace_bytes(int64_t d);
+int32_t mi355q_reduce_hessian_f64(void* comm, double* hessian, int64_t d, double weight, int32_t root,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 } /* extern "C" */

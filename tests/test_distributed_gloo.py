@@ -259,6 +259,28 @@ def _worker_x2_exchange(rank, world, port, out):
   dist.destroy_process_group()
 
 
+def _worker_x2_owners(rank, world, port, out):
+  """X2 with owners: every Hessian is reduced to the one rank that will read it."""
+  dist = _setup(rank, world, port)
+  from mi355q import distributed as D
+  from oracle import aeq_oracle as O
+  xs = _hessian_samples()
+  shard = D.sample_shard(len(xs), rank, world)
+  local, totals = {}, {}
+  for name, d in (("a", 16), ("b", 24)):
+    q = None
+    for s in shard:
+      x = xs[s][..., :d]
+      q = O.gptq_and_moving_average_update(q, {"min": np.float32(0), "max": np.float32(1), "hessian": O.gptq_hessian(x),
+                                               "num_samples": x.shape[0]})
+    local[name] = (q["hessian"], q["num_samples"])
+    totals[name] = (d, sum(x.shape[0] for x in xs))
+  merged = D.merge_hessians_across_ranks(local, totals, owners={"a": 1, "b": 0})
+  out.put((rank, {n: np.asarray(h) for n, h in merged.items()}))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
 def _hessian_samples():
   rng = np.random.default_rng(15)
   return [rng.standard_normal((1 + i % 3, 6, 24)).astype(np.float32) * (1 + i) for i in range(7)]
@@ -415,6 +437,70 @@ def test_x2_hessian_exchange_equals_sequential_merge_chain():
   for rank, merged, _ in results:
     assert np.array_equal(merged["c"], np.arange(64, dtype=np.float64).reshape(8, 8))   # weight 5/5 from one rank
   assert all(np.array_equal(results[0][1][n], results[1][1][n]) for n in ("a", "b", "c"))
+
+
+def test_x2_reduce_to_owner_keeps_each_hessian_on_the_rank_that_reads_it():
+  from oracle import aeq_oracle as O
+  results = dict(_run(_worker_x2_owners))
+  assert set(results[0]) == {"b"} and set(results[1]) == {"a"}
+  xs = _hessian_samples()
+  for name, d, owner in (("a", 16, 1), ("b", 24, 0)):
+    q = None
+    for x in xs:
+      q = O.gptq_and_moving_average_update(q, {"min": np.float32(0), "max": np.float32(1),
+                                               "hessian": O.gptq_hessian(x[..., :d]), "num_samples": x.shape[0]})
+    got = results[owner][name]
+    assert np.max(np.abs(got - q["hessian"])) / np.max(np.abs(q["hessian"])) <= 1e-14
+
+
+def _c5_plan(world, variant="gptq", layers=18):
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  for p in (os.path.join(ROOT, "ai-edge-quantizer_amd"), ROOT):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  import c5_model as C
+  from mi355q import distributed as D
+  model = C.build_model(layers, weights="virtual")       # shapes and byte counts only
+  _, _, plan, owner, costs = D.plan_model_shards(model, C.recipe(variant), world)
+  return D, plan, owner, costs
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_c5_plan_keeps_a_hessians_ops_together_and_balances_cost(world):
+  """The sharding plan of the 18-layer Gemma-2B-shaped model under GPTQ (ref
+  gptq.py:243-300 for what is shared): ops that read one activation sit on one rank, so every
+  inverse is computed once in the whole job; the load is balanced by modelled seconds, not bytes."""
+  D, plan, owner, costs = _c5_plan(world)
+  by_key = {}
+  for (_, key, _), r in zip(costs, owner):
+    if key is not None:
+      by_key.setdefault(key, set()).add(r)
+  assert len(by_key) == 18 * 4 and all(len(r) == 1 for r in by_key.values())
+  owners = D.hessian_owners(plan, owner, costs)
+  assert len(owners) == 18 * 4
+  loads = D.plan_loads(costs, owner, world)
+  mean = sum(loads) / world
+  # 18 indivisible d = 16384 units (one inverse + one apply each, ~64 ms) dominate: the best any plan
+  # can do is ceil(18 / world) of them on the busiest rank
+  units = {}
+  for w, key, shared in costs:
+    if key is not None:
+      units[key] = units.get(key, shared) + w
+  heavy = max(units.values())
+  bound = -(-18 // world) * heavy
+  assert max(loads) <= max(1.15 * mean, bound * 1.02), (loads, mean, bound)
+  # by bytes the two kinds of 128 MiB weights would be interchangeable; by cost they are not
+  down = [c for c, it in zip(costs, plan) if it[3] is not None and c[2] > 0.01]
+  assert len(down) == 18
+
+
+def test_c5_plan_is_deterministic_and_mixed_recipe_has_no_heavy_units():
+  a = _c5_plan(8)[2]
+  b = _c5_plan(8)[2]
+  assert a == b
+  D, plan, owner, costs = _c5_plan(8, "mixed")
+  loads = D.plan_loads(costs, owner, 8)
+  assert max(loads) <= 1.15 * (sum(loads) / 8)
 
 
 def test_sample_sharded_gptq_calibration_reduces_hessians_instead_of_gathering_them():

@@ -128,6 +128,17 @@ def _worker_rccl_single(rank, world, port, out):
   _ffi.check(L.mi355q_allreduce_hessian_f64(comm, rt.ptr(hh), 64, 0.25, st))
   ok &= bool(np.array_equal(hh.cpu().numpy(), h * 0.25))
   ok &= L.mi355q_allreduce_hessian_f64(comm, rt.ptr(hh), 64, 1.5, st) == -1          # weight outside [0, 1]
+  # the packed-triangle form: all-reduce (root -1) and reduce to a root; 67 is not a multiple of the tile
+  sym = rng.standard_normal((67, 67)); sym = sym + sym.T
+  need = L.mi355q_hessian_exchange_workspace_bytes(67)
+  ok &= need == 67 * 68 // 2 * 8
+  ws = torch.empty((need,), dtype=torch.uint8, device="cuda")
+  for root in (-1, 0):
+    hs = torch.from_numpy(sym).cuda()
+    _ffi.check(L.mi355q_reduce_hessian_f64(comm, rt.ptr(hs), 67, 0.5, root, rt.ptr(ws), need, st))
+    ok &= bool(np.array_equal(hs.cpu().numpy(), sym * 0.5))
+  ok &= L.mi355q_reduce_hessian_f64(comm, rt.ptr(hs), 67, 0.5, 1, rt.ptr(ws), need, st) == -1      # no rank 1
+  ok &= L.mi355q_reduce_hessian_f64(comm, rt.ptr(hs), 67, 0.5, 0, rt.ptr(ws), need - 8, st) == -1  # workspace too small
   ok &= L.mi355q_allreduce_sum_f32(None, rt.ptr(f32), 4, st) == -1                    # null communicator
   # a second communicator from an explicit unique-id hand-over (what a non-torch rendezvous would do)
   other = D.new_rccl_comm(0, 1, lambda uid: uid)
@@ -223,8 +234,64 @@ def test_two_ranks_reduce_gptq_hessians_in_hbm():
   results = _run(_worker_calibrate_gptq, timeout=600)
   for rank, ok, rel, gathered_bytes, hessian_bytes in results:
     assert ok, rank
-    assert rel <= 1e-14, rel                      # vs the sequential _gptq_merge_hessian chain
+    # vs the one-process calibration: every process multiplies the tokens of its own samples in one
+    # float32-accumulated product (gptq.HessianAccumulator), so two ranks add two such products in FP64
+    # where one process forms a single one -- float32 accumulation noise, far inside T2's 2e-6 (the
+    # FP64 all-reduce itself equals the sequential merge chain to 1e-14: tests/test_distributed_gloo.py)
+    assert rel <= 1e-6, rel
     assert gathered_bytes < hessian_bytes // 8    # 9 samples' statistics, not one d x d array
+
+
+def _worker_c5_fused(rank, world, port, out):
+  """calibrate_and_quantize_sharded on a small Gemma-shaped model (two gloo ranks on cuda:0)."""
+  dist = _setup(rank, world, port)
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  import torch
+  import c5_model as C
+  from mi355q import distributed as D, model_modifier, ops, quantizer
+  shapes = (256, 128, 512)
+  path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mi355q_c5_small_{port}.tflite")
+  if rank == 0:
+    model_modifier.serialize_model(C.build_model(2, *shapes), path)
+  dist.barrier()
+  samples = C.calibration_set(torch, 2, 8, 160, *shapes)          # 8 samples of [1, 160, d] per input
+  data = {"serving_default": samples}
+  rcp = C.recipe("gptq")
+  calls = {"hinv": 0}
+  real = ops.gptq_hinv
+
+  def counting(*a, **k):
+    calls["hinv"] += 1
+    return real(*a, **k)
+  ops.gptq_hinv = counting
+  sharded = D.calibrate_and_quantize_sharded(path, rcp, data)
+  mine = calls["hinv"]
+  ops.gptq_hinv = real
+  single = None
+  if rank == 0:
+    qz = quantizer.Quantizer(path, rcp)
+    single = bytes(qz.quantize(calibration_result=qz.calibrate(data)).quantized_model)
+  dist.barrier()
+  if rank == 0:
+    os.remove(path)
+  out.put((rank, mine, None if sharded is None else bytes(sharded), single))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_ranks_calibrate_and_quantize_in_one_call_one_inverse_per_hessian():
+  """BASELINE config 5's call on two ranks: every distinct Hessian (2 layers x 4 inputs) is inverted
+  exactly once in the whole job, on the rank that owns the ops reading it, and the file rank 0
+  writes is the single-process file but for T2 (the Hessian of two ranks' token products; observed
+  identical bytes)."""
+  import numpy as np
+  (r0, n0, sharded, single), (r1, n1, other, _) = sorted(_run(_worker_c5_fused, timeout=600))
+  assert other is None and sharded is not None
+  assert n0 + n1 == 8 and n0 > 0 and n1 > 0, (n0, n1)
+  assert len(sharded) == len(single)
+  diff = np.frombuffer(sharded, np.uint8) != np.frombuffer(single, np.uint8)
+  parity_rates.note("C5 small model, two ranks vs one: differing bytes of the written file", "byte_mismatch_fraction",
+                    float(diff.mean()), 1e-4)
 
 
 def test_quantize_sharded_tool_with_a_gptq_recipe(tmp_path):

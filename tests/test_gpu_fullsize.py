@@ -103,8 +103,25 @@ def test_hadamard_octav_4096_against_oracle(m):
     ref = O.hadamard_quant_params(w, 4, "CHANNELWISE")
   p = m.had.get_tensor_quant_params(info, cfg, w)
   assert p.hadamard.hadamard_size == 4096
-  np.testing.assert_allclose(p.scale, ref["scale"], rtol=2e-6)
+  np.testing.assert_allclose(p.scale, ref["scale"], rtol=1e-6)
   parity_rates.check("hadamard(h=4096)+octav int4 512x4096 vs oracle", p.quantized_data, ref["quantized_data"], parity_rates.T2)
+
+
+@pytest.mark.parametrize("rows,cols,h", [(256, 2048, 2048), (64, 16384, 16384)])
+def test_hadamard_octav_gemma_shapes_against_oracle(m, rows, cols, h):
+  """The C5 Hadamard shapes: h = 2048 (q / k / v / o / gate / up rows of a Gemma-2B layer) and
+  h = 16384 (down_proj rows): rotation + OCTAV + int4 against the oracle's sgemm rotation
+  (ref hadamard_rotation.py:137-203). T2: scales 1e-6 rel, integers +-1 on <= 1e-5."""
+  w = np.random.default_rng(57 + h).standard_normal((rows, cols), dtype=np.float32) * np.float32(0.02)
+  info, cfg = info_cfg(m, 4, "CHANNELWISE")
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    ref = O.hadamard_quant_params(w, 4, "CHANNELWISE")
+  p = m.had.get_tensor_quant_params(info, cfg, w)
+  assert p.hadamard.hadamard_size == h
+  np.testing.assert_allclose(p.scale, ref["scale"], rtol=1e-6)
+  parity_rates.check(f"hadamard(h={h})+octav int4 {rows}x{cols} vs oracle", p.quantized_data, ref["quantized_data"],
+                     parity_rates.T2)
 
 
 def test_octav_4096_rows_bit_exact(m):

@@ -345,6 +345,26 @@ def test_hessian_bf16_split_structured_inputs(m, kind):
   parity_rates.note(f"hessian bf16 split, {kind} inputs, vs FP64 product (per-entry scale)", "max_rel_error", err, 1e-6)
 
 
+@pytest.mark.parametrize("n,d", [(2048, 256), (300, 192)])
+def test_hessian_with_infinite_activations_against_oracle(m, n, d):
+  """An inf among the activations (ref gptq.py:100-107 computes x.T.dot(x) whatever x holds): row and
+  column of that channel are +-inf exactly where NumPy's sgemm has them, every other entry is the
+  ordinary product. (2048, 256) takes the bf16 split, (300, 192) the FP32-MFMA product."""
+  rng = np.random.default_rng(n)
+  x = rng.standard_normal((1, n, d), dtype=np.float32)
+  x[0, 17, 5] = np.inf
+  x[0, 40, 9] = -np.inf
+  with np.errstate(invalid="ignore", over="ignore"):
+    ref = O.gptq_hessian(x)
+  got = np.asarray(m.gptq.hessian_of(x, np.array(1)))
+  assert np.array_equal(np.isposinf(got), np.isposinf(ref))
+  assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+  assert np.array_equal(np.isnan(got), np.isnan(ref))            # inf - inf where both channels meet
+  fin = np.isfinite(ref)
+  assert fin.sum() == (d - 2) ** 2
+  assert np.max(np.abs(got[fin] - ref[fin])) <= 2e-6 * np.abs(ref[fin]).max()
+
+
 def test_workspaces_and_outputs_are_written_before_they_are_read(m, monkeypatch):
   """The GPTQ entry points take caller-owned workspaces and outputs that they may not assume
   anything about: with every byte of them set to 0xFF beforehand (NaN as float32 / float64)

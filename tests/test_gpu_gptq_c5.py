@@ -94,7 +94,10 @@ def test_hessian_inverse_error_level_small_shapes(m, d, tokens):
   assert int(info.item()) == 0
   exact = torch.linalg.inv(_damped(torch, h))
   err = float((hinv.double() - exact).abs().max() / exact.abs().max())
-  parity_rates.note(f"hinv d={d} vs exact FP64 inverse", "max_rel_error", err, 3e-7)    # observed 3.3e-8 / 1.9e-8
+  # d = 2048: FP64 MFMA throughout (3.3e-8); d >= 4096: the single-precision steps of the reference
+  # (strtri, the L^-T L^-1 einsum: ref gptq.py:121-128) run on the bf16 split with float32-class accuracy --
+  # the bound is the level the reference's own float32 steps reach (6.8e-7)
+  parity_rates.note(f"hinv d={d} vs exact FP64 inverse", "max_rel_error", err, 3e-7 if d < 4096 else 7e-7)
 
 
 def test_hessian_inverse_d16384(m, big):
@@ -110,7 +113,7 @@ def test_hessian_inverse_d16384(m, big):
   parity_rates.note("hinv d=16384 residual max|Hinv.Hd - I|", "max_abs_residual", r, 5e-6)        # observed 5.1e-7
   exact = torch.linalg.inv(damped)
   err = float((hinv.double() - exact).abs().max() / exact.abs().max())
-  parity_rates.note("hinv d=16384 vs exact FP64 inverse", "max_rel_error", err, 3e-7)   # observed 2.7e-8 (FP32 rounding of the result)
+  parity_rates.note("hinv d=16384 vs exact FP64 inverse", "max_rel_error", err, 7e-7)   # observed 1.2e-7 on the bf16 split (FP64 throughout: 2.7e-8); the reference's float32 steps: 6.8e-7
   again, _ = m.ops.gptq_hinv(h, 0.01)
   assert torch.equal(hinv, again)          # same launches in the same order: bit-identical
 
@@ -124,6 +127,55 @@ def _oracle_rows(w_rows, scale_rows, hinv_host, bits, gran="CHANNELWISE", block=
   scale = scale_rows.reshape(w_rows.shape[0], -1).astype(np.float32)
   zp = np.zeros(scale.shape, np.int8)
   return O.gptq_apply(w_rows, scale, zp, bits, True, None, gran, block_size=block, hinv=hinv_host)
+
+
+def _oracle_rows_split_matmul(w_rows, scale_rows, hinv_host, bits):
+  """O.gptq_apply (channelwise, symmetric) with ONE difference: the update of the columns behind a
+  64-column block (ref gptq.py:213-214, `W[:, rest] -= err @ Hinv[blk, rest]`) is formed as two
+  K = 32 products added together -- the same float32 products in another addition order."""
+  fw = np.array(w_rows, copy=True)
+  scale = scale_rows.reshape(-1, 1).astype(np.float32)
+  zp = np.zeros(scale.shape, np.int8)
+  qw = np.zeros(fw.shape, np.int8)
+  d = hinv_host.shape[0]
+  for b0 in range(0, d, 64):
+    b1 = min(b0 + 64, d)
+    wb = fw[:, b0:b1]
+    eb = np.zeros_like(wb)
+    for i in range(b1 - b0):
+      c = b0 + i
+      col = wb[:, i]
+      qc = O.uniform_quantize(np.expand_dims(col, -1), scale, zp, bits, True, quantized_dim=0).reshape(-1, 1)
+      dq = O.uniform_dequantize(qc, scale, zp, quantized_dim=0).reshape(-1)
+      qw[:, c] = qc.reshape(-1)
+      np.subtract(col, dq, out=eb[:, i])
+      eb[:, i] /= hinv_host[c, c]
+      if i < b1 - b0 - 1:
+        wb[:, i + 1:] -= np.outer(eb[:, i], hinv_host[c, c + 1:b1])
+    half = (b1 - b0) // 2
+    fw[:, b1:] -= np.matmul(eb[:, :half], hinv_host[b0:b0 + half, b1:]) + np.matmul(eb[:, half:], hinv_host[b0 + half:b1, b1:])
+  return qw
+
+
+def test_apply_down_proj_2048x16384_int8_rows_against_oracle(m, big):
+  """int8 at the down_proj shape (scales 18 x finer than int4's): GPU vs oracle with the same
+  inverse, beside the oracle's own reproducibility under another block-update summation order."""
+  torch = m.torch
+  gen = torch.Generator(device="cuda").manual_seed(5210)
+  w = torch.randn((2048, D_BIG), generator=gen, device="cuda") * 0.02
+  scale = _channelwise_scale(torch, w, 8)
+  q = m.ops.gptq_apply(w, big["hinv"], scale, None, 1, 0, 8, True, False, 8)
+  hinv_host = big["hinv"].cpu().numpy()
+  rows = np.r_[0:8, 2040:2048]
+  idx = torch.from_numpy(rows).cuda()
+  wr, sr = w[idx].cpu().numpy(), scale[idx].cpu().numpy()
+  ref = _oracle_rows(wr, sr, hinv_host, 8)
+  ref_b = _oracle_rows_split_matmul(wr, sr, hinv_host, 8)
+  floor = float((ref != ref_b).mean())
+  parity_rates.note("reference noise floor: oracle gptq apply [2048,16384] int8, 16 rows, block update summed in two halves",
+                    "int_mismatch_fraction", floor, 1.0)
+  parity_rates.check("gptq apply [2048,16384] int8 channelwise, 16 rows vs oracle (same Hinv)",
+                     q[idx].cpu().numpy(), ref, max(parity_rates.T2, 2 * floor))
 
 
 def test_apply_down_proj_2048x16384_rows_against_oracle(m, big):
@@ -171,11 +223,19 @@ def test_apply_gate_proj_16384x2048_rows_against_oracle(m):
       scale = _channelwise_scale(torch, w, bits)
       q = m.ops.gptq_apply(w, hinv, scale, None, 1, 0, bits, bits >= 8, False, 8)
       ref = _oracle_rows(w[idx].cpu().numpy(), scale[idx].cpu().numpy(), hinv_host, bits)
-    # observed (profiles/r02_parity_rates.txt): int4 0, int8 3.3e-4 (scales 18 x finer: a last-ulp
-    # difference of the K = 256 update crosses a rounding boundary 18 x as often, and every
-    # flipped integer perturbs the rest of its row)
-    parity_rates.check(f"gptq apply [16384,2048] int{bits} {gran}, 128 rows vs oracle (same Hinv)",
-                       q[idx].cpu().numpy(), ref, 3e-3 if bits == 8 else parity_rates.T2)
+    if bits == 8:
+      # int8: the reference's own reproducibility first -- the same oracle with the update behind a
+      # block summed in two halves (what a BLAS with another K blocking does with gptq.py:213-214's
+      # matmul): the rate at which THAT flips integers is the floor for any implementation
+      ref_b = _oracle_rows_split_matmul(w[idx].cpu().numpy(), scale[idx].cpu().numpy(), hinv_host, bits)
+      floor = float((ref != ref_b).mean())
+      parity_rates.note("reference noise floor: oracle gptq apply [16384,2048] int8, 128 rows, block update summed in two halves",
+                        "int_mismatch_fraction", floor, 1.0)
+      parity_rates.check(f"gptq apply [16384,2048] int{bits} {gran}, 128 rows vs oracle (same Hinv)",
+                         q[idx].cpu().numpy(), ref, max(parity_rates.T2, 2 * floor))
+    else:
+      parity_rates.check(f"gptq apply [16384,2048] int{bits} {gran}, 128 rows vs oracle (same Hinv)",
+                         q[idx].cpu().numpy(), ref, parity_rates.T2)
 
 
 def test_apply_split_update_with_an_odd_number_of_column_tiles(m):
@@ -216,4 +276,4 @@ def test_down_proj_through_get_tensor_quant_params(m, big):
   rows = np.r_[0:8, 248:256]
   ref = _oracle_rows(w[rows], ref_scale[rows], hinv_host, 4)
   parity_rates.check("gptq.get_tensor_quant_params [256,16384] int4, 16 rows vs oracle (same Hinv)",
-                     np.asarray(p.quantized_data)[rows], ref, 3e-4)       # observed 3.4e-5 (9 of 262144)
+                     np.asarray(p.quantized_data)[rows], ref, parity_rates.T2)

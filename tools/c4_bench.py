@@ -17,6 +17,27 @@ sys.path.insert(0, os.path.join(ROOT, "ai-edge-quantizer_amd"))
 sys.path.insert(0, ROOT)
 
 
+def build_model(tensors=32, width=4096, seq=256):
+  """A chain of FullyConnected ops with `tensors` activation tensors of [1, seq, width]."""
+  from mi355q import qtyping as q
+  rng = np.random.default_rng(4)
+  model = q.ModelT(version=3)
+  model.buffers = [q.BufferT()]
+  sg = q.SubGraphT(name=b"main", tensors=[], operators=[], inputs=[0], outputs=[tensors - 1])
+  w = rng.standard_normal((width, width), dtype=np.float32) * np.float32(0.02)
+  for i in range(tensors):
+    sg.tensors.append(q.TensorT(name=f"act{i}".encode(), shape=[1, seq, width], buffer=0))
+  for i in range(tensors - 1):
+    model.buffers.append(q.BufferT(data=w.reshape(-1).view(np.uint8)))
+    sg.tensors.append(q.TensorT(name=f"w{i}".encode(), shape=[width, width], buffer=len(model.buffers) - 1))
+    sg.operators.append(q.OperatorT(inputs=[i, len(sg.tensors) - 1, -1], outputs=[i + 1], opcodeIndex=0,
+                                    builtinOptionsType=8, builtinOptions=q.FullyConnectedOptionsT(keepNumDims=True)))
+  model.operatorCodes = [q.OperatorCodeT(builtinCode=int(q.BuiltinOperator.FULLY_CONNECTED), deprecatedBuiltinCode=9)]
+  model.subgraphs = [sg]
+  model.signatureDefs = [q.SignatureDefT(signatureKey=b"serving_default", subgraphIndex=0)]
+  return model
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--samples", type=int, default=32)
@@ -30,20 +51,7 @@ def main():
   from mi355q import calibrator, qtyping as q, recipe, recipe_manager
   rng = np.random.default_rng(4)
   width, seq = 4096, 256
-  model = q.ModelT(version=3)
-  model.buffers = [q.BufferT()]
-  sg = q.SubGraphT(name=b"main", tensors=[], operators=[], inputs=[0], outputs=[a.tensors - 1])
-  w = rng.standard_normal((width, width), dtype=np.float32) * np.float32(0.02)
-  for i in range(a.tensors):
-    sg.tensors.append(q.TensorT(name=f"act{i}".encode(), shape=[1, seq, width], buffer=0))
-  for i in range(a.tensors - 1):
-    model.buffers.append(q.BufferT(data=w.reshape(-1).view(np.uint8)))
-    sg.tensors.append(q.TensorT(name=f"w{i}".encode(), shape=[width, width], buffer=len(model.buffers) - 1))
-    sg.operators.append(q.OperatorT(inputs=[i, len(sg.tensors) - 1, -1], outputs=[i + 1], opcodeIndex=0,
-                                    builtinOptionsType=8, builtinOptions=q.FullyConnectedOptionsT(keepNumDims=True)))
-  model.operatorCodes = [q.OperatorCodeT(builtinCode=int(q.BuiltinOperator.FULLY_CONNECTED), deprecatedBuiltinCode=9)]
-  model.subgraphs = [sg]
-  model.signatureDefs = [q.SignatureDefT(signatureKey=b"serving_default", subgraphIndex=0)]
+  model = build_model(a.tensors, width, seq)
   rm = recipe_manager.RecipeManager()
   rm.load_quantization_recipe(recipe.static_wi8_ai8())
   pool = [{f"act{i}": rng.standard_normal((1, seq, width), dtype=np.float32) * np.float32(1 + i / 8)

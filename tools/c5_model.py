@@ -192,31 +192,46 @@ class GpuPhases:
     return [round(e0.elapsed_time(e1), 3) for f, e0, e1 in self.events if f == family]
 
 
+def prepare(layers=18, shapes=(D, DKV, DFF), workdir="/tmp"):
+  """Writes the float container (rank 0; untimed) and returns its path on every rank."""
+  import torch
+  import torch.distributed as dist
+  from mi355q import distributed as Dm
+  rank, world = Dm._world()   # pylint: disable=protected-access
+  d, dkv, dff = shapes
+  src = os.path.join(workdir, f"c5_{layers}l_{d}_{dff}.litertlm")
+  if rank == 0 and not os.path.exists(src):
+    write_litertlm(build_model(layers, d, dkv, dff, weights=device_weights(torch)), src)
+  if world > 1:
+    dist.barrier()
+  return src
+
+
 def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="/tmp", bits=4,
-        shapes=(D, DKV, DFF), keep=False, phases=True, out_tokens=None):
-  """Builds the container (untimed), then times open -> calibrate -> quantize -> write. Returns a dict
-  (rank 0) or None. Works under torchrun: samples and ops are sharded over the ranks."""
+        shapes=(D, DKV, DFF), keep=False, phases=True, out_tokens=None, src=None):
+  """One call -- litertlm_utils.quantize_litertlm(container, recipe, out, calibration_data=...) -- timed
+  from opening the container to the written file. Returns a dict (rank 0) or None. Works under
+  torchrun: samples and ops are sharded over the ranks, Hessians reduced to their owners."""
   import torch
   import torch.distributed as dist
   from mi355q import distributed as Dm, ops
   from mi355q.utils import litertlm_utils
   rank, world = Dm._world()   # pylint: disable=protected-access
   d, dkv, dff = shapes
-  src = os.path.join(workdir, f"c5_{layers}l_{d}_{dff}.litertlm")
-  dst = os.path.join(workdir, f"c5_{layers}l_{d}_{dff}_{variant}_q.litertlm")
   t_build = time.perf_counter()
-  if rank == 0:
-    write_litertlm(build_model(layers, d, dkv, dff, weights=device_weights(torch)), src)
-  if world > 1:
-    dist.barrier()
+  own_src = src is None
+  if own_src:
+    src = prepare(layers, shapes, workdir)
   t_build = time.perf_counter() - t_build
+  dst = os.path.join(workdir, f"c5_{layers}l_{d}_{dff}_{variant}_q.litertlm")
   rcp = recipe(variant, bits)
   need_cal = variant != "hadamard"
   data = None
   if need_cal:
     mine = Dm.sample_shard(sequences // batch, rank, world)
-    full = calibration_set(torch, layers, sequences, tokens, d, dkv, dff, batch, out_tokens) if world == 1 else None
-    if world > 1:      # every rank generates only its own share (the shard calibrate_sharded will walk)
+    if world == 1:
+      full = calibration_set(torch, layers, sequences, tokens, d, dkv, dff, batch, out_tokens)
+    else:      # every rank generates only its own share (the shard calibrate_sharded will walk)
       full = [None] * (sequences // batch)
       part = calibration_set(torch, layers, len(mine) * batch, tokens, d, dkv, dff, batch, out_tokens)
       for k, s in zip(mine, part):
@@ -225,16 +240,14 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()
+  if os.path.exists(dst) and rank == 0:
+    os.remove(dst)
   timer = GpuPhases(torch, ops) if phases else None
   if timer:
     timer.__enter__()
+  stats = {}
   t0 = time.perf_counter()
-  qsvs = litertlm_utils.calibrate_litertlm(src, rcp, data) if need_cal else None
-  torch.cuda.synchronize()
-  t1 = time.perf_counter()
-  if os.path.exists(dst) and rank == 0:
-    os.remove(dst)
-  n_out = litertlm_utils.quantize_litertlm(src, rcp, dst, overwrite=True, calibration_results=qsvs)
+  n_out = litertlm_utils.quantize_litertlm(src, rcp, dst, overwrite=True, calibration_data=data, stats=stats)
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()
@@ -243,28 +256,30 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
   trace = {f: timer.calls(f) for f in (os.environ.get("MI355Q_C5_TRACE", "").split(",")) if f} if timer else None
   if timer:
     timer.__exit__()
+  del data
   if rank != 0:
     return None
   per = projections(d, dkv, dff)
   weight_bytes = layers * 4 * sum(r * c for _, r, c, _ in per)
-  _, _, plan, owner, costs = Dm.plan_model_shards(litertlm_utils.LiteRTLMFile(src).get_section_buffer(0), rcp, world,
-                                                  qsvs.get(0) if qsvs else None)
+  _, _, plan, owner, costs = Dm.plan_model_shards(litertlm_utils.LiteRTLMFile(src).get_section_buffer(0), rcp, world)
   loads = Dm.plan_loads(costs, owner, world)
   out = dict(
       workload=f"C5 {variant}: {layers} Gemma-2B-shaped layers (d={d}, kv={dkv}, ff={dff}) in a .litertlm,"
-               f" {sequences} x {tokens} calibration tokens resident in HBM, int{bits} channelwise",
-      ranks=world, seconds=round(t2 - t0, 3), calibrate_s=round(t1 - t0, 3), quantize_and_write_s=round(t2 - t1, 3),
+               f" {sequences} x {tokens} calibration tokens resident in HBM, int{bits} channelwise, one"
+               " quantize_litertlm(calibration_data=...) call",
+      ranks=world, seconds=round(t2 - t0, 3), calibrate_s=round(stats.get("calibrate_s", 0.0), 3),
+      quantize_and_write_s=round(stats.get("quantize_and_write_s", 0.0), 3), repack_s=round(stats.get("repack_s", 0.0), 3),
       s_per_layer=round((t2 - t0) / layers, 4), weight_bytes=weight_bytes,
       weight_GBps=round(weight_bytes / (t2 - t0) / 1e9, 2), out_bytes=n_out, build_s=round(t_build, 2),
-      gpu_busy_s=busy, gpu_busy_total_s=None if busy is None else round(sum(busy.values()), 3),
+      gpu_busy_s_rank0=busy, gpu_busy_total_s=None if busy is None else round(sum(busy.values()), 3),
       gpu_busy_frac=None if busy is None else round(sum(busy.values()) / (t2 - t0), 3),
       trace=trace or None,
       plan=dict(modelled_s_per_rank=[round(v, 4) for v in loads],
                 makespan_over_mean=round(max(loads) / (sum(loads) / world), 3) if sum(loads) else None))
-  if not keep:
-    for f in (src, dst):
-      if os.path.exists(f):
-        os.remove(f)
+  if os.path.exists(dst) and not keep:
+    os.remove(dst)
+  if own_src and not keep and os.path.exists(src):
+    os.remove(src)
   return out
 
 
