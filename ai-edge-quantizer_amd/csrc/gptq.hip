@@ -57,11 +57,14 @@ __global__ __launch_bounds__(256) void hessian_merge_kernel(const double* __rest
 
 // ---------------------------------------------------- damping + copy ----
 // sum of where(diag, diag, 1.0) -> out[0]
-__global__ __launch_bounds__(256) void diag_sum_kernel(const double* __restrict__ h, int d, double* out) {
+// (S = double: the Hessian itself, alpha = 1; S = float: the float32 product X^T X it is alpha times of --
+// alpha * double(p) is exactly what mi355q_gptq_xtx_finish_f64 would have stored)
+template <typename S>
+__global__ __launch_bounds__(256) void diag_sum_kernel(const S* __restrict__ h, double alpha, int d, double* out) {
   __shared__ double part[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < d; i += 256) {
-    const double v = h[static_cast<long long>(i) * d + i];
+    const double v = alpha * static_cast<double>(h[static_cast<long long>(i) * d + i]);
     s += (v != 0.0) ? v : 1.0;
   }
   part[threadIdx.x] = s;
@@ -78,7 +81,8 @@ __global__ __launch_bounds__(256) void diag_sum_kernel(const double* __restrict_
 // wide, at offsets that are multiples of 64) that straddle the diagonal; a third of the copy's
 // traffic was zeros nobody looked at (tests/test_gpu_gptq.py poisons the workspace to prove it).
 constexpr int kZeroBand = 256;
-__global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __restrict__ h, int d,
+template <typename S>
+__global__ __launch_bounds__(256) void copy_damped_lower_kernel(const S* __restrict__ h, double alpha, int d,
                                                                const double* __restrict__ diag_sum,
                                                                double damp, double* __restrict__ a) {
   const double add = damp * (diag_sum[0] / static_cast<double>(d));
@@ -87,8 +91,8 @@ __global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __
   for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
     const int i = static_cast<int>(e / d), j = static_cast<int>(e % d);
     double v = 0.0;
-    if (j < i) v = h[e];
-    if (j == i) { v = h[e]; v = ((v != 0.0) ? v : 1.0) + add; }
+    if (j < i) v = alpha * static_cast<double>(h[e]);
+    if (j == i) { v = alpha * static_cast<double>(h[e]); v = ((v != 0.0) ? v : 1.0) + add; }
     if (j - i < kZeroBand) a[e] = v;
   }
 }
@@ -96,7 +100,8 @@ __global__ __launch_bounds__(256) void copy_damped_lower_kernel(const double* __
 // The same for columns [c0, c1) only (grid: x over the columns, y over groups of 8 rows): with a
 // look-ahead factorization the first outer block's columns are copied on the caller's stream and
 // everything behind them on the side stream, underneath the first block's chain of small kernels.
-__global__ __launch_bounds__(256) void copy_damped_lower_cols_kernel(const double* __restrict__ h, int d,
+template <typename S>
+__global__ __launch_bounds__(256) void copy_damped_lower_cols_kernel(const S* __restrict__ h, double alpha, int d,
                                                                     const double* __restrict__ diag_sum, double damp,
                                                                     double* __restrict__ a, int c0, int c1) {
   const double add = damp * (diag_sum[0] / static_cast<double>(d));
@@ -106,8 +111,8 @@ __global__ __launch_bounds__(256) void copy_damped_lower_cols_kernel(const doubl
   for (int i = static_cast<int>(blockIdx.y) * 8; i < i_end; ++i) {
     const long long e = static_cast<long long>(i) * d + j;
     double v = 0.0;
-    if (j < i) v = h[e];
-    if (j == i) { v = h[e]; v = ((v != 0.0) ? v : 1.0) + add; }
+    if (j < i) v = alpha * static_cast<double>(h[e]);
+    if (j == i) { v = alpha * static_cast<double>(h[e]); v = ((v != 0.0) ? v : 1.0) + add; }
     if (j - i < kZeroBand) a[e] = v;
   }
 }
@@ -1187,8 +1192,11 @@ SideStream* side_stream() {
 }
 }  // namespace
 
+namespace { void release_hinv_pools(); }
+
 extern "C" int32_t mi355q_shutdown(void) {
   clear_error();
+  release_hinv_pools();
   std::lock_guard<std::mutex> lock(g_side_mutex);
   for (SideStream& s : g_side) {
     if (s.stream) {
@@ -1208,14 +1216,15 @@ extern "C" size_t mi355q_gptq_hinv_workspace_bytes(int64_t d) {
   return (static_cast<size_t>(d) * d * 2 + NB * NB + static_cast<size_t>(d) * NB * 2 + 8) * sizeof(double);
 }
 
-extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, double damp_factor,
-                                        float* hinv_out, int32_t* info_out, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
+namespace {
+// hessian (FLOAT64 [d, d]) or, when it is null, alpha * product (product FLOAT32 [d, d], lower triangle valid)
+int32_t hinv_impl(const double* hessian, const float* product, double alpha, int64_t d64, double damp_factor,
+                  float* hinv_out, int32_t* info_out, void* workspace, size_t workspace_bytes, void* stream) {
   clear_error();
   if (d64 < 0) return fail(MI355Q_BAD_ARG, "negative shape");
   if (d64 == 0) return MI355Q_OK;
   if (d64 > 46000) return fail(MI355Q_UNSUPPORTED, "d too large");
-  if (!hessian || !hinv_out || !info_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  if ((!hessian && !product) || !hinv_out || !info_out) return fail(MI355Q_BAD_ARG, "null pointer");
   const size_t need = mi355q_gptq_hinv_workspace_bytes(d64);
   if (!workspace || workspace_bytes < need)
     return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
@@ -1229,7 +1238,8 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   double* scal = spanel + static_cast<size_t>(d) * NB * 2;
   if (hipMemsetAsync(info_out, 0, sizeof(int32_t), st) != hipSuccess)
     return fail(MI355Q_HIP_ERROR, "hipMemsetAsync failed");
-  hipLaunchKernelGGL(diag_sum_kernel, dim3(1), dim3(256), 0, st, hessian, d, scal);
+  if (hessian) hipLaunchKernelGGL((diag_sum_kernel<double>), dim3(1), dim3(256), 0, st, hessian, 1.0, d, scal);
+  else hipLaunchKernelGGL((diag_sum_kernel<float>), dim3(1), dim3(256), 0, st, product, alpha, d, scal);
   MI355Q_CHECK_LAUNCH("gptq damp launch");
   // ---- blocked right-looking Cholesky (lower), FP64, two levels. Per 64-column step:
   //   diagonal block: factor (one workgroup)
@@ -1255,16 +1265,27 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
     // outer block 0 waits for it like for any earlier side-stream update.
     if (hipEventRecord(side->panel_done, st) != hipSuccess || hipStreamWaitEvent(side->stream, side->panel_done, 0) != hipSuccess)
       return fail(MI355Q_HIP_ERROR, "look-ahead: copy hand-over failed");
-    hipLaunchKernelGGL(copy_damped_lower_cols_kernel, dim3((OB + 255) / 256, (d + 7) / 8), dim3(256), 0, st, hessian, d, scal,
-                       damp_factor, a, 0, OB);
-    hipLaunchKernelGGL(copy_damped_lower_cols_kernel, dim3((d - OB + 255) / 256, (d + 7) / 8), dim3(256), 0, side->stream,
-                       hessian, d, scal, damp_factor, a, OB, d);
+    if (hessian) {
+      hipLaunchKernelGGL((copy_damped_lower_cols_kernel<double>), dim3((OB + 255) / 256, (d + 7) / 8), dim3(256), 0, st, hessian, 1.0,
+                         d, scal, damp_factor, a, 0, OB);
+      hipLaunchKernelGGL((copy_damped_lower_cols_kernel<double>), dim3((d - OB + 255) / 256, (d + 7) / 8), dim3(256), 0, side->stream,
+                         hessian, 1.0, d, scal, damp_factor, a, OB, d);
+    } else {
+      hipLaunchKernelGGL((copy_damped_lower_cols_kernel<float>), dim3((OB + 255) / 256, (d + 7) / 8), dim3(256), 0, st, product, alpha,
+                         d, scal, damp_factor, a, 0, OB);
+      hipLaunchKernelGGL((copy_damped_lower_cols_kernel<float>), dim3((d - OB + 255) / 256, (d + 7) / 8), dim3(256), 0, side->stream,
+                         product, alpha, d, scal, damp_factor, a, OB, d);
+    }
     if (hipEventRecord(side->update_done, side->stream) != hipSuccess)
       return fail(MI355Q_HIP_ERROR, "look-ahead: record failed");
     side_busy = true;
   } else {
-    hipLaunchKernelGGL(copy_damped_lower_kernel, dim3(grid1d(static_cast<long long>(d) * d)), dim3(256), 0, st,
-                       hessian, d, scal, damp_factor, a);
+    if (hessian)
+      hipLaunchKernelGGL((copy_damped_lower_kernel<double>), dim3(grid1d(static_cast<long long>(d) * d)), dim3(256), 0, st,
+                         hessian, 1.0, d, scal, damp_factor, a);
+    else
+      hipLaunchKernelGGL((copy_damped_lower_kernel<float>), dim3(grid1d(static_cast<long long>(d) * d)), dim3(256), 0, st,
+                         product, alpha, d, scal, damp_factor, a);
   }
   MI355Q_CHECK_LAUNCH("gptq damp launch");
   double* step_panel[2] = {spanel, spanel + static_cast<size_t>(d) * NB};   // see chol_step_kernel
@@ -1415,6 +1436,120 @@ extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d64, doub
   }
   MI355Q_CHECK_LAUNCH("gptq mirror launch");
   return MI355Q_OK;
+}
+}  // namespace
+
+extern "C" int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d, double damp_factor, float* hinv_out,
+                                        int32_t* info_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!hessian) { clear_error(); return d == 0 ? MI355Q_OK : fail(d < 0 ? MI355Q_BAD_ARG : MI355Q_BAD_ARG, d < 0 ? "negative shape" : "null pointer"); }
+  return hinv_impl(hessian, nullptr, 1.0, d, damp_factor, hinv_out, info_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t mi355q_gptq_hinv_from_product_f32(const float* product, int64_t d, double alpha, double damp_factor,
+                                                     float* hinv_out, int32_t* info_out, void* workspace,
+                                                     size_t workspace_bytes, void* stream) {
+  if (!product) { clear_error(); return d == 0 ? MI355Q_OK : fail(MI355Q_BAD_ARG, d < 0 ? "negative shape" : "null pointer"); }
+  return hinv_impl(nullptr, product, alpha, d, damp_factor, hinv_out, info_out, workspace, workspace_bytes, stream);
+}
+
+// ---- several independent inverses at once ---------------------------------------------------
+// A d = 2048 inverse is a chain of ~32 dependent step kernels of ~28 us, each a few hundred
+// workgroups at most: 250 CUs idle through it, and a Gemma-2B has 54 such Hessians. The chains of
+// different Hessians share nothing, so they go out on a small pool of streams (per device, made on
+// first use, released by mi355q_shutdown) and interleave on the chip; each lane of the pool has its
+// own slice of the workspace, instances on one lane follow each other. Every instance runs the
+// launches of mi355q_gptq_hinv_f64 unchanged: bit-identical results.
+namespace {
+constexpr int kHinvLanes = 8;
+struct HinvPool {
+  hipStream_t lane[kHinvLanes] = {};
+  hipEvent_t fork = nullptr, done[kHinvLanes] = {};
+  bool tried = false, ok = false;
+};
+HinvPool g_hinv_pool[64];
+std::mutex g_hinv_pool_mutex;
+
+HinvPool* hinv_pool() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  HinvPool& p = g_hinv_pool[dev];
+  if (!p.tried) {
+    p.tried = true;
+    bool ok = getenv("MI355Q_HINV_NO_LANES") == nullptr && hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < kHinvLanes; ++i)
+      ok = hipStreamCreateWithFlags(&p.lane[i], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    p.ok = ok;
+  }
+  return p.ok ? &p : nullptr;
+}
+
+size_t hinv_lane_bytes(int64_t d) { return (mi355q_gptq_hinv_workspace_bytes(d) + 255) & ~static_cast<size_t>(255); }
+int hinv_lanes_for(int32_t count, int64_t d) { return d >= 4096 || count < 2 ? 1 : (count < kHinvLanes ? count : kHinvLanes); }
+}  // namespace
+
+namespace {
+void release_hinv_pools() {
+  std::lock_guard<std::mutex> lock(g_hinv_pool_mutex);
+  for (HinvPool& p : g_hinv_pool) {
+    if (p.ok) {
+      for (int i = 0; i < kHinvLanes; ++i) {
+        (void)hipStreamSynchronize(p.lane[i]);
+        (void)hipStreamDestroy(p.lane[i]);
+        (void)hipEventDestroy(p.done[i]);
+      }
+      (void)hipEventDestroy(p.fork);
+    }
+    p = HinvPool();
+  }
+}
+}  // namespace
+
+extern "C" size_t mi355q_gptq_hinv_batched_workspace_bytes(int32_t count, int64_t d) {
+  if (count <= 0 || d <= 0) return 0;
+  return hinv_lane_bytes(d) * static_cast<size_t>(hinv_lanes_for(count, d));
+}
+
+extern "C" int32_t mi355q_gptq_hinv_f64_batched(const double* const* hessians_host, int32_t count, int64_t d,
+                                                double damp_factor, float* const* hinv_out_host, int32_t* info_out,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (count < 0 || d < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (count == 0 || d == 0) return MI355Q_OK;
+  if (!hessians_host || !hinv_out_host || !info_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  const size_t need = mi355q_gptq_hinv_batched_workspace_bytes(count, d);
+  if (!workspace || workspace_bytes < need) return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  const size_t per = hinv_lane_bytes(d);
+  int lanes = hinv_lanes_for(count, d);
+  std::unique_lock<std::mutex> lock(g_hinv_pool_mutex, std::defer_lock);
+  HinvPool* pool = nullptr;
+  if (lanes > 1) {
+    lock.lock();
+    pool = hinv_pool();
+    if (!pool) lanes = 1;
+  }
+  hipStream_t st = as_stream(stream);
+  if (lanes == 1) {
+    for (int32_t i = 0; i < count; ++i)
+      if (int32_t e = mi355q_gptq_hinv_f64(hessians_host[i], d, damp_factor, hinv_out_host[i], info_out + i, workspace, per, stream))
+        return e;
+    return MI355Q_OK;
+  }
+  if (hipEventRecord(pool->fork, st) != hipSuccess) return fail(MI355Q_HIP_ERROR, "hinv lanes: record failed");
+  for (int l = 0; l < lanes; ++l)
+    if (hipStreamWaitEvent(pool->lane[l], pool->fork, 0) != hipSuccess) return fail(MI355Q_HIP_ERROR, "hinv lanes: wait failed");
+  int32_t status = MI355Q_OK;
+  for (int32_t i = 0; i < count && status == MI355Q_OK; ++i) {
+    const int l = i % lanes;
+    status = mi355q_gptq_hinv_f64(hessians_host[i], d, damp_factor, hinv_out_host[i], info_out + i,
+                                  static_cast<unsigned char*>(workspace) + static_cast<size_t>(l) * per, per, pool->lane[l]);
+  }
+  // whatever happened, the caller's stream waits for every lane: the workspace is the caller's
+  for (int l = 0; l < lanes; ++l)
+    if (hipEventRecord(pool->done[l], pool->lane[l]) != hipSuccess || hipStreamWaitEvent(st, pool->done[l], 0) != hipSuccess)
+      return fail(MI355Q_HIP_ERROR, "hinv lanes: join failed");
+  return status;
 }
 
 extern "C" size_t mi355q_gptq_apply_workspace_bytes(int64_t rows, int64_t d) {

@@ -239,7 +239,21 @@ struct OctavArgs {
   float s;          // float32(4^-bits / divisor)
   float* hist;      // [max_iter][units] guesses
   unsigned long long* moving;  // bit `it` set: some unit's guess still moved in iteration `it`
-  int sparse;       // octav_rows_kernel: late iterations re-test a list of candidates instead of the row
+  // octav_rows_kernel -> octav_tail_kernel hand-over (null: the rows kernel runs every iteration itself)
+  struct TailState* tail;      // [units]
+  float* tail_values;          // [units][2][tail_cap]: the candidates' values, positive mask first
+  unsigned short* tail_pos;    // [units][2][tail_cap]: their positions in the row
+  int tail_cap;
+};
+
+// What a row's workgroup leaves for the wave that finishes the row (octav_tail_kernel).
+struct TailState {
+  int next_it;          // first iteration the tail runs; 0: the rows kernel finished the row itself
+  int n[2];             // candidates per mask
+  float guess;          // the iterate to continue from
+  float cand_guess;     // every listed candidate satisfies |x| >= cand_guess
+  unsigned moved_lo, moved_hi;   // iterations (bit mask) in which the guess still moved so far
+  int pad;
 };
 
 struct OctavStep {
@@ -443,9 +457,6 @@ struct RowsShared {      // small per-workgroup exchange area (in front of the r
   int wave_changed[W];      // some word of the wave differs from the previous iteration's
   float sum[2];             // the two chain totals
   float wave_amax[W];       // largest |x| of the wave's pieces (written once, area 0)
-  int sparse_ok;            // sparse iterations: the scanning wave's verdict, its two counts (sums in `sum`)
-  int sparse_count[2];
-  int sparse_kept[2];       // ... and what is left of the candidate lists
 };
 // floats per exchange area (there are two, by iteration parity)
 constexpr int rows_xchg_floats(int threads) { return threads <= 256 ? 64 : 256; }
@@ -742,16 +753,11 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
   // the serial chain runs on one wave per workgroup: spread it over the SIMDs of the CU
   // (workgroups u, u + 256, u + 512, ... tend to be co-resident)
   const int chain_wave = static_cast<int>((unit + (unit >> 8)) % kWaves);
-  // sparse iterations (see sparse_mask_sum): candidate lists live where the run lists are
-  constexpr bool kCanSparse = SLOTS == 1;
-  const bool allow_sparse = a.sparse != 0;
-  const int cand_cap = len / 8 < 64 ? 64 : len / 8;                  // per mask
-  float* cand_v[2] = {list_pos, list_neg};
-  unsigned short* cand_p[2] = {reinterpret_cast<unsigned short*>(list_pos + cand_cap),
-                               reinterpret_cast<unsigned short*>(list_neg + cand_cap)};
-  bool sparse = false, force = true;
-  float cand_guess = 0.f;
-  int ncand[2] = {0, 0};
+  // late iterations select a few per cent of a row: the candidates are listed once and a single wave
+  // per row (octav_tail_kernel: no row in LDS, no barriers, dozens of rows per CU) finishes the row
+  constexpr bool kCanHandOver = SLOTS == 1;
+  const int cand_cap = a.tail_cap;
+  bool force = true, handed_over = false;
   int nit = 0;      // iterations that exchanged something (the exchange areas alternate with it)
   int scan_p = 0, scan_n = 0;   // the last dense iteration's inclusive scans of selected elements inside the wave
   for (int it = 0; it < a.max_iter; ++it) {
@@ -765,35 +771,6 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
       cp = cn = 0;
       force = true;
       have_sums = true;
-    } else if (kCanSparse && sparse) {
-      Shared* shs = reinterpret_cast<Shared*>(smem + kX * (nit & 1));
-      ++nit;
-      // candidates a little below the guess stay listed: an iterate that settles may step back by an ulp
-      const float keep = hi * 0.998046875f;     // 1 - 2^-9
-      if (wave == chain_wave) {
-        float sp_ = 0.f, sn_ = 0.f;
-        int kp_ = 0, kn_ = 0, lp_ = 0, ln_ = 0;
-        const bool ok = sparse_mask_sum<false>(cand_v[0], cand_p[0], ncand[0], hi, keep, lane, &sp_, &kp_, &lp_) &&
-                        sparse_mask_sum<true>(cand_v[1], cand_p[1], ncand[1], lo, -keep, lane, &sn_, &kn_, &ln_);
-        if (lane == 0) {
-          shs->sparse_ok = ok ? 1 : 0;
-          shs->sum[0] = sp_; shs->sum[1] = sn_;
-          shs->sparse_count[0] = kp_; shs->sparse_count[1] = kn_;
-          shs->sparse_kept[0] = lp_; shs->sparse_kept[1] = ln_;
-        }
-      }
-      __syncthreads();
-      if (shs->sparse_ok) {
-        pos_sum = shs->sum[0]; neg_sum = shs->sum[1];
-        cp = shs->sparse_count[0]; cn = shs->sparse_count[1];
-        ncand[0] = shs->sparse_kept[0]; ncand[1] = shs->sparse_kept[1];
-        cand_guess = keep;
-        have_sums = true;
-      } else {
-        sparse = false;    // a run of 8+ among the candidates: this iteration again, the dense way
-        force = true;
-        __syncthreads();   // (everybody has read the verdict before the lists are rewritten)
-      }
     }
     if (!have_sums) {
     // (two exchange areas, alternating: an iteration whose masks did not change has only
@@ -973,32 +950,107 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
       if (tid == 0) repeat_iterate(a, it, unit, st.next);
       break;
     }
-    if constexpr (kCanSparse) {
-      if (sparse) {
-        if (!(st.next >= cand_guess)) { sparse = false; force = true; }   // the guess fell below what the candidates passed
-      } else if (allow_sparse && !have_sums && it + 1 < a.max_iter && guess > 0.f && st.next >= guess && cp <= cand_cap && cn <= cand_cap) {
-        // few elements selected and the guess growing: list them (value, position; in row order) and let
-        // one wave re-test the list from now on. tp / tn are this iteration's inclusive scans of the
-        // per-thread counts inside the wave, the exchange area has the waves' totals.
+    if constexpr (kCanHandOver) {
+      if (a.tail != nullptr && !have_sums && it + 2 < a.max_iter && guess > 0.f && st.next >= guess && cp <= cand_cap && cn <= cand_cap) {
+        // few elements selected and the guess growing: every later selection is a subset of this one.
+        // List it (value, position; row order) for the tail. scan_p / scan_n are this iteration's
+        // inclusive scans of the per-thread counts inside the wave, the exchange area has the waves' totals.
         const Shared* shc = reinterpret_cast<const Shared*>(smem + kX * ((nit - 1) & 1));
         int bp = scan_p - __builtin_popcount(wp[0]), bn = scan_n - __builtin_popcount(wn[0]);
         for (int k = 0; k < wave; ++k) { bp += shc->wave_count[0][k]; bn += shc->wave_count[1][k]; }
-        __syncthreads();        // (the chain wave is done with the run lists)
+        float* vp = a.tail_values + (static_cast<long long>(unit) * 2) * cand_cap;
+        float* vn = vp + cand_cap;
+        unsigned short* pp = a.tail_pos + (static_cast<long long>(unit) * 2) * cand_cap;
+        unsigned short* pn = pp + cand_cap;
         const int e0 = kPiece * tid;
 #pragma unroll
         for (int i = 0; i < kPiece; ++i) {
-          if ((wp[0] >> i) & 1u) { cand_v[0][bp] = x[0][i]; cand_p[0][bp] = static_cast<unsigned short>(e0 + i); ++bp; }
-          if ((wn[0] >> i) & 1u) { cand_v[1][bn] = x[0][i]; cand_p[1][bn] = static_cast<unsigned short>(e0 + i); ++bn; }
+          if ((wp[0] >> i) & 1u) { vp[bp] = x[0][i]; pp[bp] = static_cast<unsigned short>(e0 + i); ++bp; }
+          if ((wn[0] >> i) & 1u) { vn[bn] = x[0][i]; pn[bn] = static_cast<unsigned short>(e0 + i); ++bn; }
         }
-        ncand[0] = cp; ncand[1] = cn;
-        cand_guess = guess;
-        sparse = true;
-        __syncthreads();
+        if (tid == 0) {
+          TailState ts;
+          ts.next_it = it + 1; ts.n[0] = cp; ts.n[1] = cn; ts.guess = st.next; ts.cand_guess = guess;
+          ts.moved_lo = static_cast<unsigned>(moved); ts.moved_hi = static_cast<unsigned>(moved >> 32); ts.pad = 0;
+          a.tail[unit] = ts;
+        }
+        handed_over = true;
+        break;
       }
     }
     guess = st.next;
   }
-  if (tid == 0) publish_moving(a.moving, moved);
+  if (tid == 0 && !handed_over) {
+    publish_moving(a.moving, moved);
+    if (a.tail != nullptr) a.tail[unit].next_it = 0;
+  }
+}
+
+// The rest of a row's iterations on ONE wave: the candidates the row's workgroup listed are staged in
+// LDS (a few KB) and re-tested against every new guess (sparse_mask_sum; the lists shrink as the
+// guess grows). Should an iterate step below what the candidates passed, or a run of 8+ candidates
+// show up, the wave falls back to scanning the row itself from global memory (the generic one-wave
+// scheme of octav_kernel) for the iterations that are left -- correct whatever the data does.
+__global__ __launch_bounds__(kWave) void octav_tail_kernel(OctavArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const long long unit = blockIdx.x;
+  const int lane = threadIdx.x;
+  const TailState ts = a.tail[unit];
+  if (ts.next_it <= 0 || ts.next_it >= a.max_iter) return;
+  const int cap = a.tail_cap, len = a.len;
+  float* cv[2] = {smem, smem + cap};
+  unsigned short* cp[2] = {reinterpret_cast<unsigned short*>(smem + 2 * cap), reinterpret_cast<unsigned short*>(smem + 2 * cap) + cap};
+  int n[2] = {ts.n[0], ts.n[1]};
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const float* gv = a.tail_values + (unit * 2 + m) * cap;
+    const unsigned short* gp = a.tail_pos + (unit * 2 + m) * cap;
+    for (int i = lane; i < n[m]; i += kWave) { cv[m][i] = gv[i]; cp[m][i] = gp[i]; }
+  }
+  const float* u = a.x + unit * len;
+  const float qnan = __builtin_nanf("");
+  float guess = ts.guess, cand_guess = ts.cand_guess;
+  unsigned long long moved = static_cast<unsigned long long>(ts.moved_lo) | (static_cast<unsigned long long>(ts.moved_hi) << 32);
+  bool lists_ok = true;
+  for (int it = ts.next_it; it < a.max_iter; ++it) {
+    const float hi = guess, lo = -guess;
+    float pos_sum = 0.f, neg_sum = 0.f;
+    int cpos = 0, cneg = 0;
+    bool have = false;
+    if (lists_ok && guess >= cand_guess) {
+      // candidates a little below the guess stay listed: an iterate that settles may step back by an ulp
+      const float keep = hi * 0.998046875f;     // 1 - 2^-9
+      int l0 = 0, l1 = 0;
+      have = sparse_mask_sum<false>(cv[0], cp[0], n[0], hi, keep, lane, &pos_sum, &cpos, &l0) &&
+             sparse_mask_sum<true>(cv[1], cp[1], n[1], lo, -keep, lane, &neg_sum, &cneg, &l1);
+      if (have) { n[0] = l0; n[1] = l1; cand_guess = keep; }
+    }
+    if (!have) {
+      lists_ok = false;          // (a failed pass leaves its list half compacted)
+      RunSum pos, neg;
+      for (int base = 0; base < len; base += kWave) {
+        const int i = base + lane;
+        const float v = i < len ? u[i] : qnan;
+        const unsigned long long mp = __ballot(v >= hi), mn = __ballot(v <= lo);
+        if ((mp | mn) == 0 && (pos.pend_len | neg.pend_len) == 0) continue;
+        pos.feed(mp, base, v, u, lane);
+        neg.feed(mn, base, v, u, lane);
+      }
+      pos.flush(u, lane);
+      neg.flush(u, lane);
+      pos_sum = pos.acc; neg_sum = neg.acc;
+      cpos = static_cast<int>(pos.count); cneg = static_cast<int>(neg.count);
+    }
+    const OctavStep st = octav_step(guess, pos_sum, neg_sum, cpos, cneg, len, a.s, a.count_is_f64);
+    if (lane == 0) a.hist[static_cast<long long>(it) * a.units + unit] = st.next;
+    if (!st.close) moved |= 1ull << it;
+    if (reached_fixed_point(guess, st.next)) {
+      if (lane == 0) repeat_iterate(a, it, unit, st.next);
+      break;
+    }
+    guess = st.next;
+  }
+  if (lane == 0) publish_moving(a.moving, moved);
 }
 
 // ---- short units (blockwise recipes: 32 .. 512 elements): a workgroup takes kGroupLen contiguous
@@ -1169,6 +1221,9 @@ size_t octav_groups_smem() {
   return 512 + kGroupThreads * sizeof(float) + row_floats * sizeof(float) + cap * 2 * sizeof(float) +
          2 * kGroupThreads * sizeof(unsigned short) + 4 * kGroupThreads * sizeof(int) + kGroupThreads * sizeof(float) + 16;
 }
+
+// candidates per mask a row may hand to its tail (an eighth of the row, a multiple of 64)
+int octav_tail_cap(int len) { const int c = ((len / 8) + 63) & ~63; return c < 64 ? 64 : c; }
 
 int octav_rows_threads(int len) {
   const int npieces = (len + kPiece - 1) / kPiece;
@@ -1536,6 +1591,13 @@ extern "C" size_t mi355q_octav_workspace_bytes(int64_t units, int32_t max_iter) 
   return static_cast<size_t>(units) * max_iter * sizeof(float) + 64 * sizeof(int);
 }
 
+extern "C" size_t mi355q_octav_rows_workspace_bytes(int64_t units, int64_t unit_len, int32_t max_iter) {
+  const size_t base = mi355q_octav_workspace_bytes(units, max_iter);
+  if (base == 0 || unit_len < kRowsMinLen || unit_len > kRowsMaxLen) return base;
+  const size_t cap = static_cast<size_t>(octav_tail_cap(static_cast<int>(unit_len)));
+  return ((base + 63) & ~static_cast<size_t>(63)) + static_cast<size_t>(units) * (sizeof(TailState) + 2 * cap * (sizeof(float) + sizeof(unsigned short)));
+}
+
 extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t unit_len,
                                          int32_t bits, int32_t max_iter, float exponent_divisor,
                                          int32_t early_stop, int32_t count_is_f64, float* clip_out,
@@ -1563,13 +1625,19 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
   const float s = static_cast<float>(p4 / static_cast<double>(exponent_divisor));
   if (unit_len >= kRowsMinLen && unit_len <= kRowsMaxLen && !getenv("MI355Q_OCTAV_WAVE_KERNEL")) {
     // rows of a weight matrix: lanes own 64-element batches of the LDS-resident row
-    // candidate lists for the late iterations (MI355Q_OCTAV_SPARSE: 0 never, 2 always; default: rows of up to
-    // 4096 elements -- a longer row has its CU to itself, and one wave re-testing the list while fifteen
-    // wait measured slower than all of them rebuilding the masks: 4096 x 11008 1.47 against 1.01 ms)
-    static const int sparse_mode = [] { const char* e = getenv("MI355Q_OCTAV_SPARSE"); return e ? atoi(e) : 1; }();
+    // late iterations on a one-wave tail kernel (octav_tail_kernel) when the caller's workspace has room for
+    // the hand-over (mi355q_octav_rows_workspace_bytes); MI355Q_OCTAV_TAIL=0 keeps every iteration in the rows kernel
+    static const bool tail_on = [] { const char* e = getenv("MI355Q_OCTAV_TAIL"); return e == nullptr || atoi(e) != 0; }();
     const int threads = octav_rows_threads(static_cast<int>(unit_len));
-    OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close,
-                sparse_mode == 2 || (sparse_mode == 1 && threads <= 256) ? 1 : 0};
+    OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close, nullptr, nullptr, nullptr, 0};
+    a.tail_cap = octav_tail_cap(a.len);
+    const int slots_ = ((a.len + kPiece - 1) / kPiece + threads - 1) / threads;
+    if (tail_on && slots_ == 1 && workspace_bytes >= mi355q_octav_rows_workspace_bytes(units, unit_len, max_iter)) {
+      unsigned char* tb = reinterpret_cast<unsigned char*>(workspace) + ((need + 63) & ~static_cast<size_t>(63));
+      a.tail = reinterpret_cast<TailState*>(tb);
+      a.tail_values = reinterpret_cast<float*>(tb + static_cast<size_t>(units) * sizeof(TailState));
+      a.tail_pos = reinterpret_cast<unsigned short*>(a.tail_values + static_cast<size_t>(units) * 2 * a.tail_cap);
+    }
     const size_t smem = octav_rows_smem(a.len);
     const int slots = ((a.len + kPiece - 1) / kPiece + threads - 1) / threads;   // 1 .. 4 (> 1 only with 256 threads)
     const int variant = threads == 1024 ? 6 : threads == 512 ? 5 : slots;   // (slots 2 .. 4: MI355Q_OCTAV_NARROW_ROWS)
@@ -1591,6 +1659,10 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
     if (hipLaunchKernel(fn, dim3(static_cast<unsigned>(units)), dim3(threads), kargs, smem, st) != hipSuccess)
       return fail(MI355Q_HIP_ERROR, "octav rows launch failed");
     MI355Q_CHECK_LAUNCH("octav rows launch");
+    if (a.tail != nullptr) {
+      hipLaunchKernelGGL(octav_tail_kernel, dim3(static_cast<unsigned>(units)), dim3(kWave), static_cast<size_t>(a.tail_cap) * 12, st, a);
+      MI355Q_CHECK_LAUNCH("octav tail launch");
+    }
     hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
                        hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
     MI355Q_CHECK_LAUNCH("octav pick launch");

@@ -41,6 +41,7 @@ PROTOTYPES = {
     "mi355q_act_minmax_f32": (c_i32, [c_ptr, c_ptr, c_i32, c_f32, c_f32, c_i32, c_ptr, c_ptr,
                                       c_size, c_ptr]),
     "mi355q_octav_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "mi355q_octav_rows_workspace_bytes": (c_size, [c_i64, c_i64, c_i32]),
     "mi355q_octav_clip_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_f32, c_i32, c_i32,
                                       c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_octav_clip_nd_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_i32, c_f32, c_i32,
@@ -61,6 +62,9 @@ PROTOTYPES = {
     "mi355q_gptq_hinv_workspace_bytes": (c_size, [c_i64]),
     "mi355q_shutdown": (c_i32, []),
     "mi355q_gptq_hinv_f64": (c_i32, [c_ptr, c_i64, c_f64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_gptq_hinv_from_product_f32": (c_i32, [c_ptr, c_i64, c_f64, c_f64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_gptq_hinv_batched_workspace_bytes": (c_size, [c_i32, c_i64]),
+    "mi355q_gptq_hinv_f64_batched": (c_i32, [c_ptr, c_i32, c_i64, c_f64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_gptq_apply_workspace_bytes": (c_size, [c_i64, c_i64]),
     "mi355q_gptq_apply_f32": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32,
                                       c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_size, c_ptr]),

@@ -82,7 +82,9 @@ class HessianAccumulator(rt.HbmArray):
   (device_tensor, np.asarray, ...) and is given back by finalize(). A Hessian that arrives as a
   finished float64 array (resumed calibration, another process's share) joins through
   mi355q_gptq_hessian_merge_f64, the reference's rule (utils/qsv_utils.py:71-88)."""
-  SLAB_TOKENS = 16384
+  SLAB_TOKENS = 4096         # (a slab's product adds to the float32 product with one read-modify-write of
+                             # the triangle: 0.3 ms at d = 16384 against 6 ms of multiplying; 16384-token slabs
+                             # cost four times the staging memory for nothing)
 
   def __init__(self, d: int):  # pylint: disable=super-init-not-called
     self.d = int(d)
@@ -162,11 +164,19 @@ class HessianAccumulator(rt.HbmArray):
     self._fill, self._n_pending = 0, 0.0
 
   def finalize(self) -> None:
-    """Forms the float64 statistic and gives slab and product back."""
-    value = self.device_tensor
-    self._mean, self._n_done = value, self._n_done + self._n_prod
-    self._prod, self._n_prod, self._slab = None, 0.0, None
-    self._value = value
+    """Multiplies what is pending and gives the slab back. The statistic stays in its float32
+    product form: the damped inverse is taken straight from it (product_form), and the float64
+    array is only made if somebody reads it."""
+    self.flush()
+    self._slab = None
+
+  def product_form(self):
+    """(product float32 [d, d], alpha) with hessian = alpha * product, or None when float64
+    Hessians have joined the statistic (it then only exists as the float64 array)."""
+    self.flush()
+    if self._mean is None and self._prod is not None:
+      return self._prod, 2.0 / self._n_prod
+    return None
 
   @property
   def device_tensor(self):
@@ -250,9 +260,43 @@ def _device_hessian_inverse(hessian, damp_factor: float = 0.01):
   if isinstance(hessian, rt.HbmArray):
     key = ("hinv", float(damp_factor))
     if key not in hessian.cache:
-      hessian.cache[key] = ops.gptq_hinv(rt.on_device(hessian, torch_f64()), damp_factor)
+      form = hessian.product_form() if isinstance(hessian, HessianAccumulator) else None
+      # (a statistic still in product form is inverted from there: no 2 GiB float64 copy at d = 16384)
+      hessian.cache[key] = (ops.gptq_hinv_from_product(form[0], form[1], damp_factor) if form is not None
+                            else ops.gptq_hinv(rt.on_device(hessian, torch_f64()), damp_factor))
     return hessian.cache[key]
   return ops.gptq_hinv(rt.to_device(np.ascontiguousarray(hessian, dtype=np.float64)), damp_factor)
+
+
+def prefetch_hessian_inverses(plan_items, model_qsvs, damp_factor: float = 0.01) -> int:
+  """Inverts, in one batched call per order, every Hessian the GPTQ ops among `plan_items`
+  (ParamsGenerator.plan_ops tuples) will read and that has no cached inverse yet. A model has
+  one Hessian per distinct FULLY_CONNECTED input and most are small (54 of order 2048 in a
+  Gemma-2B): alone each is a latency-bound chain of kernels, together they fill the chip
+  (mi355q_gptq_hinv_f64_batched). Returns how many were inverted here."""
+  from ...utils import tfl_flatbuffer_utils
+  todo: dict[int, list] = {}
+  seen: set[int] = set()
+  for graph_info, op, _, op_key, alg, _ in plan_items:
+    if str(getattr(alg, "value", alg)) != ALGORITHM_KEY or op_key is None or not len(op.inputs):
+      continue
+    name = tfl_flatbuffer_utils.get_tensor_name(graph_info.subgraph_tensors[op.inputs[0]])
+    qsv = model_qsvs.get(name) if model_qsvs else None
+    h = qsv.get("hessian") if isinstance(qsv, dict) else None
+    if not isinstance(h, rt.HbmArray) or id(h) in seen or ("hinv", float(damp_factor)) in h.cache:
+      continue
+    seen.add(id(h))
+    if h.shape[0] < 4096:          # larger ones fill the chip on their own (and need 4 GiB of scratch each)
+      todo.setdefault(h.shape[0], []).append(h)
+  count = 0
+  for hs in todo.values():
+    if len(hs) < 2:
+      continue
+    rt.require_gpu()
+    for h, res in zip(hs, ops.gptq_hinv_batched([rt.on_device(h, torch_f64()) for h in hs], damp_factor)):
+      h.cache[("hinv", float(damp_factor))] = res
+      count += 1
+  return count
 
 
 def torch_f64():

@@ -323,6 +323,7 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
         "Model quantization statistics values (QSVs) are required for the input recipe. This"
         " can be obtained by running calibration on sample dataset.")
   qsvs = calibration_result if calibration_result is not None else {}
+  gen.prefetch([it for it, o in zip(plan, owner) if o == rank], qsvs)
   with requant_queue.batching():       # this rank's equally shaped weights leave in one launch per group
     mine = {i: gen.materialize_op(it, qsvs) for i, (it, o) in enumerate(zip(plan, owner)) if o == rank}
   gen.release_derived(qsvs)

@@ -262,7 +262,7 @@ def octav_clip(x: torch.Tensor, units: int, unit_len: int, bits: int, max_iter: 
   clip = rt.empty((units,), torch.float32)
   iters = rt.empty((1,), torch.int32)
   L = _ffi.lib()
-  nbytes = L.mi355q_octav_workspace_bytes(units, max_iter)
+  nbytes = L.mi355q_octav_rows_workspace_bytes(units, unit_len, max_iter)
   ws = rt.empty((max(nbytes, 1),), torch.uint8)
   _ffi.check(L.mi355q_octav_clip_f32(
       rt.ptr(x), units, unit_len, bits, max_iter, np.float32(exponent_divisor),
@@ -426,6 +426,45 @@ def gptq_hinv(hessian: torch.Tensor, damp_factor: float = 0.01):
   _ffi.check(L.mi355q_gptq_hinv_f64(rt.ptr(hessian), d, float(damp_factor), rt.ptr(hinv),
                                     rt.ptr(info), rt.ptr(ws), nbytes, rt.stream_ptr()))
   return hinv, info
+
+
+def gptq_hinv_from_product(product: torch.Tensor, alpha: float, damp_factor: float = 0.01):
+  """K9 on hessian = alpha * product (float32 X^T X, lower triangle valid) without materializing the
+  float64 Hessian; same (hinv, info) as gptq_hinv(gptq_xtx_finish(product, alpha))."""
+  rt.require_gpu()
+  d = product.shape[0]
+  hinv = rt.empty((d, d), torch.float32)
+  info = rt.empty((1,), torch.int32)
+  L = _ffi.lib()
+  nbytes = L.mi355q_gptq_hinv_workspace_bytes(d)
+  ws = rt.empty((max(nbytes, 1),), torch.uint8)
+  _ffi.check(L.mi355q_gptq_hinv_from_product_f32(rt.ptr(_f32(product)), d, float(alpha), float(damp_factor), rt.ptr(hinv),
+                                                 rt.ptr(info), rt.ptr(ws), nbytes, rt.stream_ptr()))
+  return hinv, info
+
+
+def gptq_hinv_batched(hessians, damp_factor: float = 0.01):
+  """K9 for several Hessians of one order: [(hinv float32 [d, d], info int32[1]), ...], the same
+  bits as gptq_hinv on each (for d < 4096 the independent chains interleave on a stream pool)."""
+  import ctypes
+  rt.require_gpu()
+  hs = [h.contiguous() if h.dtype == torch.float64 else h.to(torch.float64).contiguous() for h in hessians]
+  if not hs:
+    return []
+  d = hs[0].shape[0]
+  if any(tuple(h.shape) != (d, d) for h in hs):
+    raise ValueError("all Hessians of a batch must have one order")
+  n = len(hs)
+  hinv = rt.empty((n, d, d), torch.float32)
+  info = rt.empty((n,), torch.int32)
+  L = _ffi.lib()
+  nbytes = L.mi355q_gptq_hinv_batched_workspace_bytes(n, d)
+  ws = rt.empty((max(nbytes, 1),), torch.uint8)
+  src = (ctypes.c_void_p * n)(*[h.data_ptr() for h in hs])
+  dst = (ctypes.c_void_p * n)(*[hinv[i].data_ptr() for i in range(n)])
+  _ffi.check(L.mi355q_gptq_hinv_f64_batched(src, n, d, float(damp_factor), dst, rt.ptr(info), rt.ptr(ws), nbytes,
+                                            rt.stream_ptr()))
+  return [(hinv[i], info[i:i + 1]) for i in range(n)]
 
 
 def gptq_apply(w: torch.Tensor, hinv: torch.Tensor, scale: torch.Tensor,

@@ -208,11 +208,21 @@ class ParamsGenerator:
     # The op loop only enqueues the fused min/max weight requantizations; equally shaped weights
     # leave in one batched launch per group when the queue flushes (requant_queue), at the latest
     # before the shared-constant checks of finish() compare parameters by value.
+    plan = self.plan_ops(model_recipe_manager)
+    self.prefetch(plan, model_qsvs)
     with requant_queue.batching() as queue:
-      per_op = [self.materialize_op(item, model_qsvs) for item in self.plan_ops(model_recipe_manager)]
+      per_op = [self.materialize_op(item, model_qsvs) for item in plan]
     self.batch_stats = dict(queue.stats)
     self.release_derived(model_qsvs)
     return self.finish(per_op)
+
+  @staticmethod
+  def prefetch(plan_items, model_qsvs) -> None:
+    """Work that is cheaper done for all of `plan_items` at once than op by op: the damped inverses of
+    the small GPTQ Hessians (batched on the device)."""
+    if model_qsvs and any(isinstance(q, dict) and "hessian" in q for q in model_qsvs.values()):
+      from .algorithms.uniform_quantize import gptq
+      gptq.prefetch_hessian_inverses(plan_items, model_qsvs)
 
   @staticmethod
   def release_derived(model_qsvs) -> None:

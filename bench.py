@@ -314,9 +314,10 @@ def sharded_configs(torch, dist, rank, world, workdir):
                                           "note": "samples resident in HBM; statistics all-gathered, replayed in dataset order"}
   del pool, data, model
   # ---- C5
-  c5src = c5_model.prepare(18, workdir=workdir)
+  c5dir = c5_model.scratch_dir(20 << 30, workdir)
+  c5src = c5_model.prepare(18, workdir=c5dir)
   for variant in ("gptq", "mixed"):
-    res = c5_model.run(18, 128, 512, variant, workdir=workdir, src=c5src, phases=(world == 1))
+    res = c5_model.run(18, 128, 512, variant, workdir=c5dir, src=c5src, phases=(world == 1))
     if rank == 0:
       res.pop("trace", None)
       out[f"c5_{variant}"] = res

@@ -201,6 +201,12 @@ int32_t mi355q_act_minmax_f32(const float* const* x_ptrs, const int64_t* numel,
  *   workspace : mi355q_octav_workspace_bytes(units, max_iter) bytes
  * ------------------------------------------------------------------------ */
 size_t mi355q_octav_workspace_bytes(int64_t units, int32_t max_iter);
+/* The same plus, for units of 1024 .. 16384 elements (weight rows), room for the hand-over of a
+ * row's late iterations to a one-wave tail kernel (the few per cent of a row a converging guess still
+ * selects are listed once and re-tested instead of the row): a caller that passes this much gets
+ * that path, one that passes mi355q_octav_workspace_bytes() gets every iteration from the row's own
+ * workgroup -- same bits either way. */
+size_t mi355q_octav_rows_workspace_bytes(int64_t units, int64_t unit_len, int32_t max_iter);
 int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t unit_len, int32_t bits,
                               int32_t max_iter, float exponent_divisor, int32_t early_stop,
                               int32_t count_is_f64, float* clip_out, int32_t* iters_out,
@@ -310,6 +316,26 @@ int32_t mi355q_shutdown(void);
 int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d, double damp_factor, float* hinv_out,
                              int32_t* info_out, void* workspace, size_t workspace_bytes,
                              void* stream);
+
+/* The same inverse of hessian = alpha * product, taken straight from the float32 product X^T X that
+ * mi355q_gptq_xtx_accum_f32 collected (lower triangle valid): alpha * double(product) is formed where
+ * the damped copy reads it, so the 2 GiB float64 Hessian of a d = 16384 layer is never materialized
+ * (mi355q_gptq_xtx_finish_f64 makes it only when a caller reads the statistic). Bit-identical to
+ * mi355q_gptq_hinv_f64 on the finished Hessian. Same workspace. */
+int32_t mi355q_gptq_hinv_from_product_f32(const float* product, int64_t d, double alpha, double damp_factor,
+                                          float* hinv_out, int32_t* info_out, void* workspace,
+                                          size_t workspace_bytes, void* stream);
+
+/* `count` independent inverses of equally sized Hessians in one call (a model has one per distinct
+ * FULLY_CONNECTED input: 54 of order 2048 in a Gemma-2B): for d < 4096, where one inverse is a chain
+ * of small dependent kernels that leaves the chip idle, the chains interleave on a per-device pool
+ * of streams; results are bit-identical to `count` calls of mi355q_gptq_hinv_f64. The two pointer
+ * tables are HOST arrays of device pointers; info_out is device int32[count].
+ * workspace: mi355q_gptq_hinv_batched_workspace_bytes(count, d). */
+size_t mi355q_gptq_hinv_batched_workspace_bytes(int32_t count, int64_t d);
+int32_t mi355q_gptq_hinv_f64_batched(const double* const* hessians_host, int32_t count, int64_t d,
+                                     double damp_factor, float* const* hinv_out_host, int32_t* info_out,
+                                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * K10 -- GPTQ weight update + quantization: for each 64-column block, quantize

@@ -49,12 +49,18 @@ def c5():
   import c5_model as C
   from mi355q import ops
   from mi355q.utils import litertlm_utils
-  calls = {"hinv": 0, "apply": 0}
-  orig_hinv, orig_apply = ops.gptq_hinv, ops.gptq_apply
+  calls = {"hinv": 0, "apply": 0, "batched_calls": 0}
+  orig_hinv, orig_apply, orig_batched = ops.gptq_hinv, ops.gptq_apply, ops.gptq_hinv_batched
 
   def hinv(*a, **k):
     calls["hinv"] += 1
     return orig_hinv(*a, **k)
+
+  def batched(hs, *a, **k):
+    calls["hinv"] += len(hs)
+    calls["batched_calls"] += 1
+    return orig_batched(hs, *a, **k)
+  ops.gptq_hinv_batched = batched
 
   def apply(*a, **k):
     calls["apply"] += 1
@@ -77,7 +83,7 @@ def c5():
     qsvs = litertlm_utils.calibrate_litertlm(src, rcp, {0: {"serving_default": samples}})
     n = litertlm_utils.quantize_litertlm(src, rcp, dst, calibration_results=qsvs)
   finally:
-    ops.gptq_hinv, ops.gptq_apply = orig_hinv, orig_apply
+    ops.gptq_hinv, ops.gptq_apply, ops.gptq_hinv_batched = orig_hinv, orig_apply, orig_batched
   out = litertlm_utils.LiteRTLMFile(dst)
   qmodel = out.read_model(0)
   yield dict(C=C, torch=torch, ops=ops, weights=weights, samples=samples, qsvs=qsvs[0], qmodel=qmodel,
@@ -103,6 +109,7 @@ def test_container_written_and_work_shared(c5):
   assert c5["out_bytes"] > LAYERS * per_layer // 2                      # packed nibbles + metadata
   assert c5["out_bytes"] < LAYERS * per_layer // 2 + (8 << 20)
   assert c5["calls"]["hinv"] == 4 * LAYERS                              # attn_in, o_in, mlp_in, down_in
+  assert c5["calls"]["batched_calls"] == 1                              # the 3 x LAYERS of order 2048: one batched call
   assert c5["calls"]["apply"] == 4 * LAYERS                             # q+k+v, o, gate+up, down
   for name, qsv in c5["qsvs"].items():
     assert ("hessian" in qsv) == (not name.endswith("/y")), name       # only where an op reads one

@@ -5,6 +5,7 @@ import sys
 
 import pytest
 
+import parity_rates
 from test_distributed_gloo import ROOT, _run, _setup
 
 pytestmark = pytest.mark.gpu
@@ -258,15 +259,19 @@ def _worker_c5_fused(rank, world, port, out):
   data = {"serving_default": samples}
   rcp = C.recipe("gptq")
   calls = {"hinv": 0}
-  real = ops.gptq_hinv
+  real, real_batched = ops.gptq_hinv, ops.gptq_hinv_batched
 
   def counting(*a, **k):
     calls["hinv"] += 1
     return real(*a, **k)
-  ops.gptq_hinv = counting
+
+  def counting_batched(hs, *a, **k):
+    calls["hinv"] += len(hs)
+    return real_batched(hs, *a, **k)
+  ops.gptq_hinv, ops.gptq_hinv_batched = counting, counting_batched
   sharded = D.calibrate_and_quantize_sharded(path, rcp, data)
   mine = calls["hinv"]
-  ops.gptq_hinv = real
+  ops.gptq_hinv, ops.gptq_hinv_batched = real, real_batched
   single = None
   if rank == 0:
     qz = quantizer.Quantizer(path, rcp)

@@ -365,6 +365,58 @@ def test_hessian_with_infinite_activations_against_oracle(m, n, d):
   assert np.max(np.abs(got[fin] - ref[fin])) <= 2e-6 * np.abs(ref[fin]).max()
 
 
+@pytest.mark.parametrize("n,d", [(5000, 2048), (900, 320), (4500, 4224)])
+def test_inverse_from_the_float32_product_equals_inverse_of_the_finished_hessian(m, n, d):
+  """mi355q_gptq_hinv_from_product_f32 (what a HessianAccumulator is inverted through: the float64
+  Hessian is never materialized) against mi355q_gptq_xtx_finish_f64 + mi355q_gptq_hinv_f64."""
+  torch = m.torch
+  gen = torch.Generator(device="cuda").manual_seed(n + d)
+  x = torch.randn((n, d), generator=gen, device="cuda")
+  x[:, 3] = 0.0
+  prod = m.ops.gptq_xtx_accum(x[: n // 2], None)
+  prod = m.ops.gptq_xtx_accum(x[n // 2:], prod)
+  alpha = 2.0 / 7
+  h = m.ops.gptq_xtx_finish(prod, alpha)
+  assert torch.equal(h, h.T)
+  whole = m.ops.gptq_xtx(x, alpha)
+  assert float((h - whole).abs().max() / whole.abs().max()) <= 1e-6      # two slabs added in float32
+  want, winfo = m.ops.gptq_hinv(h, 0.01)
+  got, ginfo = m.ops.gptq_hinv_from_product(prod, alpha, 0.01)
+  assert int(winfo.item()) == int(ginfo.item()) == 0
+  assert torch.equal(got, want)
+  acc = m.gptq.HessianAccumulator.of(x[: n // 2], 3.0)
+  acc.add(x[n // 2:], 4.0)
+  acc.finalize()
+  a_hinv, a_info = m.gptq._device_hessian_inverse(acc)
+  assert acc._value is None and acc._prod is not None                    # inverted from the product form
+  assert int(a_info.item()) == 0 and float((a_hinv - want).abs().max() / want.abs().max()) <= 1e-5
+  assert np.asarray(acc).dtype == np.float64                              # ... and still readable as the float64 statistic
+
+
+@pytest.mark.parametrize("d,count", [(2048, 11), (320, 3), (4224, 2)])
+def test_batched_inverses_equal_single_calls_bit_for_bit(m, d, count):
+  """mi355q_gptq_hinv_f64_batched: the chains of independent Hessians interleave on a stream pool
+  (d < 4096) or follow each other (d >= 4096); each instance runs the single call's launches."""
+  torch = m.torch
+  hs = []
+  for i in range(count):
+    gen = torch.Generator(device="cuda").manual_seed(900 + 7 * i + d)
+    x = torch.randn((d + 64 * (i + 1), d), generator=gen, device="cuda") * (1.0 + 0.25 * i)
+    hs.append(m.ops.gptq_xtx(x, 2.0 / (i + 1)))
+  hs[1][5, :] = 0.0
+  hs[1][:, 5] = 0.0                               # a dead channel in one of them
+  bad = hs[-1].clone()
+  bad[3, 3] = -1e6                                # ... and one that is not positive definite
+  hs.append(bad)
+  got = m.ops.gptq_hinv_batched(hs, 0.01)
+  for h, (hinv, info) in zip(hs, got):
+    want, winfo = m.ops.gptq_hinv(h, 0.01)
+    assert int(info.item()) == int(winfo.item())
+    if int(winfo.item()) == 0:
+      assert torch.equal(hinv, want)
+  assert int(got[-1][1].item()) != 0 and all(int(i.item()) == 0 for _, i in got[:-1])
+
+
 def test_workspaces_and_outputs_are_written_before_they_are_read(m, monkeypatch):
   """The GPTQ entry points take caller-owned workspaces and outputs that they may not assume
   anything about: with every byte of them set to 0xFF beforehand (NaN as float32 / float64)

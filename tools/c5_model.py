@@ -153,7 +153,8 @@ def calibration_set(torch, layers, sequences, tokens, d=D, dkv=DKV, dff=DFF, bat
 class GpuPhases:
   """GPU-busy milliseconds per kernel family: HIP events around every mi355q.ops call of a family
   (no synchronisation is added; the events are read after the run)."""
-  FAMILIES = {"gptq_xtx": "hessian", "gptq_hessian_merge": "hessian_merge", "gptq_hinv": "hinv",
+  FAMILIES = {"gptq_xtx": "hessian", "gptq_xtx_accum": "hessian", "gptq_xtx_finish": "hessian_finish",
+              "gptq_hessian_merge": "hessian_merge", "gptq_hinv": "hinv", "gptq_hinv_batched": "hinv",
               "gptq_apply": "apply", "act_minmax": "act_minmax", "requant_sym": "scales",
               "hadamard_rotate": "hadamard", "octav_clip": "octav", "pack_bits": "pack", "minmax": "scales"}
 
@@ -190,6 +191,20 @@ class GpuPhases:
     """Milliseconds of every call of one family, in call order."""
     self.torch.cuda.synchronize()
     return [round(e0.elapsed_time(e1), 3) for f, e0, e1 in self.events if f == family]
+
+
+def scratch_dir(need_bytes, fallback=None):
+  """Where the float container and the result go: a memory-backed directory when it has room (the float
+  file is written right before it is read: on a disk-backed file system its 16 GB of dirty pages are still
+  being written back while the run reads them, which throttles the reader, not the quantizer)."""
+  import shutil
+  for d in ("/dev/shm",):
+    try:
+      if os.path.isdir(d) and shutil.disk_usage(d).free > need_bytes:
+        return d
+    except OSError:
+      pass
+  return fallback or os.environ.get("TMPDIR", "/tmp")
 
 
 def prepare(layers=18, shapes=(D, DKV, DFF), workdir="/tmp"):
@@ -246,9 +261,18 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
   if timer:
     timer.__enter__()
   stats = {}
+  prof = None
+  if os.environ.get("MI355Q_C5_PROFILE") and rank == 0:      # where the host's time goes (slows the run down)
+    import cProfile
+    prof = cProfile.Profile()
+    prof.enable()
   t0 = time.perf_counter()
   n_out = litertlm_utils.quantize_litertlm(src, rcp, dst, overwrite=True, calibration_data=data, stats=stats)
   torch.cuda.synchronize()
+  if prof is not None:
+    import pstats
+    prof.disable()
+    pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(32)
   if world > 1:
     dist.barrier()
   t2 = time.perf_counter()
@@ -291,7 +315,7 @@ def main():
   ap.add_argument("--batch", type=int, default=1, help="sequences per calibration sample (the sample's leading dim)")
   ap.add_argument("--variant", default="gptq", choices=("gptq", "mixed", "hadamard"))
   ap.add_argument("--bits", type=int, default=4)
-  ap.add_argument("--dir", default=os.environ.get("TMPDIR", "/tmp"))
+  ap.add_argument("--dir", default=None, help="default: /dev/shm when it has room, else $TMPDIR")
   ap.add_argument("--keep", action="store_true")
   ap.add_argument("--no-phases", action="store_true")
   a = ap.parse_args()
@@ -299,7 +323,8 @@ def main():
   g.build()
   from mi355q import distributed as Dm
   rank, world = Dm.init()
-  res = run(a.layers, a.sequences, a.tokens, a.variant, a.batch, a.dir, a.bits, keep=a.keep, phases=not a.no_phases)
+  workdir = a.dir or scratch_dir(a.layers * 1000 * (1 << 20))
+  res = run(a.layers, a.sequences, a.tokens, a.variant, a.batch, workdir, a.bits, keep=a.keep, phases=not a.no_phases)
   if rank == 0:
     print(json.dumps(res), flush=True)
   if world > 1:
