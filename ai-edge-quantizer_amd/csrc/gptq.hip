@@ -1635,13 +1635,25 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
 #undef MI355Q_BLOCK
     }
     if (g1 < a.d) {
-      // W[:, g1:] -= err[:, group] @ Hinv[g0:g1, g1:]
-      if (split_upd && (g1 - g0) % 16 == 0 && g1 % 128 == 0) {
-        if (int32_t s = upd_bf16x3(err, kErrLd, rows, d, g0, g1 - g0, g1, wc, upd_ws, st)) return s;
-      } else {
-        GemmArgs<float> g{err, kErrLd, 1, hinv + static_cast<long long>(g0) * d + g1, d, 1, wc + g1, d, 1,
-                          a.rows, a.d - g1, g1 - g0, -1.0f, 1.0f, 0, 0};
-        if (int32_t s = launch_gemm<float>(g, st)) return s;
+      // W[:, g1:] -= err[:, group] @ Hinv[g0:g1, g1:]. One K = 256 product rounds the far columns once
+      // where the reference's per-block `W[:, rest] -= err_blk @ Hinv[blk, rest]` (gptq.py:213-214) rounds
+      // them four times. At 4 bits that never moved an integer (0 of 393 216 against the oracle); on an
+      // 8-bit grid, 18 x finer, it did -- 2.4e-4 of them at [16384, 2048], where re-ordering the sums INSIDE
+      // the oracle's block products moves none -- so 8-bit targets take the reference's sequence: one
+      // product and one subtraction per 64-column block (a quarter of the speed-up of the lazy update).
+      static const int far_env = [] { const char* e = getenv("MI355Q_GPTQ_FAR_PER_BLOCK"); return e ? atoi(e) : -1; }();
+      const bool per_block = far_env >= 0 ? far_env != 0 : bits >= 8;
+      const int step = per_block ? NB : g1 - g0;
+      for (int b0 = g0; b0 < g1; b0 += step) {
+        const int kk = g1 - b0 < step ? g1 - b0 : step;
+        const float* eb = err + (b0 - g0);
+        if (split_upd && kk % 16 == 0 && g1 % 128 == 0) {
+          if (int32_t s = upd_bf16x3(eb, kErrLd, rows, d, b0, kk, g1, wc, upd_ws, st)) return s;
+        } else {
+          GemmArgs<float> g{eb, kErrLd, 1, hinv + static_cast<long long>(b0) * d + g1, d, 1, wc + g1, d, 1,
+                            a.rows, a.d - g1, kk, -1.0f, 1.0f, 0, 0};
+          if (int32_t s = launch_gemm<float>(g, st)) return s;
+        }
       }
     }
   }

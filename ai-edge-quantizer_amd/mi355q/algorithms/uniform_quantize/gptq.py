@@ -82,12 +82,14 @@ class HessianAccumulator(rt.HbmArray):
   (device_tensor, np.asarray, ...) and is given back by finalize(). A Hessian that arrives as a
   finished float64 array (resumed calibration, another process's share) joins through
   mi355q_gptq_hessian_merge_f64, the reference's rule (utils/qsv_utils.py:71-88)."""
-  SLAB_TOKENS = 4096         # (a slab's product adds to the float32 product with one read-modify-write of
-                             # the triangle: 0.3 ms at d = 16384 against 6 ms of multiplying; 16384-token slabs
-                             # cost four times the staging memory for nothing)
+  SLAB_TOKENS = 16384        # tokens per product for narrow Hessians; wide ones: SLAB_BYTES of staging
+  SLAB_BYTES = 256 << 20     # (d = 16384: 4096 tokens -- a slab's product joins the float32 product with one
+                             # read-modify-write of the triangle, 0.3 ms against 6 ms of multiplying, and a
+                             # 16384-token slab would be 1 GiB of staging per Hessian)
 
   def __init__(self, d: int):  # pylint: disable=super-init-not-called
     self.d = int(d)
+    self.SLAB_TOKENS = max(4096, min(HessianAccumulator.SLAB_TOKENS, (self.SLAB_BYTES // (4 * self.d)) // 1024 * 1024))
     self._mean = None             # float64 [d, d] over _n_done samples (only what joined as float64)
     self._n_done = 0.0
     self._prod = None             # float32 [d, d]: sum of X^T X over _n_prod samples
@@ -491,9 +493,12 @@ def get_tensor_quant_params(
       and tensor_content.dtype == np.float32 and tensor_content.ndim == 2):
     # one upload serves both the min / max below and the update (a Gemma-2B layer is 440 MB)
     rt.require_gpu()
-    if not isinstance(tensor_content, rt.HbmArray):
-      tensor_content = rt.HbmArray(rt.to_device(tensor_content))
     queue = _apply_queue()
+    if not isinstance(tensor_content, rt.HbmArray):
+      # (inside the model-level loop the GPU is busy with the previous ops' inverses and updates:
+      # the upload must not wait for them, see runtime.upload_overlapped)
+      big = queue is not None and tensor_content.nbytes >= (1 << 20)
+      tensor_content = rt.HbmArray(rt.upload_overlapped(tensor_content) if big else rt.to_device(tensor_content))
     block_size = uniform_quantize_tensor.extract_block_size_from_granularity(cfg.granularity)
     rows, d = tensor_content.shape
     if (queue is not None and cfg.symmetric and cfg.num_bits in (2, 4, 8)

@@ -93,8 +93,13 @@ class Calibrator:
       updated.add(name)
     return updated
 
-  def _calibrate_step(self, signature_key: Optional[str], data: Any,
-                      model_recipe_manager: recipe_manager.RecipeManager) -> None:
+  def _prepare_step(self, signature_key: Optional[str], data: Any,
+                    model_recipe_manager: recipe_manager.RecipeManager) -> dict:
+    """First half of a calibration step: the sample's activations go to HBM and their (min, max)
+    reduction is launched; nothing waits for the GPU. Steps are prepared ONE AHEAD of the walk
+    (calibrate / record_steps), so the small copy that brings a sample's statistics back is
+    queued in front of the previous sample's Hessian products instead of behind them, and the host
+    walks sample k while the GPU still multiplies sample k - 1."""
     contents = self._tensor_provider(signature_key, data) if self._tensor_provider else data
     if not isinstance(contents, Mapping):
       raise TypeError("a calibration sample must be a {tensor name: ndarray} map (or pass a"
@@ -102,8 +107,20 @@ class Calibrator:
     # activations that already live in HBM (torch tensors on the device, e.g. the outputs of a
     # float run on this GPU) stay there: statistics are taken where they are
     contents = {k: rt.resident_sample(v) for k, v in contents.items()}
-    self._tensor_content_map.update(contents)
-    self._stage_sample(signature_key, contents, model_recipe_manager)
+    return {"contents": contents, "stage": self._stage_sample(signature_key, contents, model_recipe_manager)}
+
+  def _finish_step(self, signature_key: Optional[str], prepared: dict,
+                   model_recipe_manager: recipe_manager.RecipeManager) -> None:
+    """Second half: the statistics are on the host now; the ops are walked."""
+    self._tensor_content_map.update(prepared["contents"])
+    stage = prepared["stage"]
+    if stage is not None:
+      arrays, dev, pinned, event, lo, hi = stage
+      event.synchronize()
+      mm = pinned.numpy().astype(np.float32, copy=True)
+      rt.stage_calibration_step({
+          id(a): {"host": a, "dev": d, "lo": lo, "hi": hi, "minmax": (mm[i, 0], mm[i, 1])}
+          for i, (a, d) in enumerate(zip(arrays, dev))})
     from .algorithms.uniform_quantize import gptq
     readers = (self._plan(signature_key, model_recipe_manager)["hessian_readers"]
                if self._hessians == "consumed" else None)
@@ -112,6 +129,22 @@ class Calibrator:
         self._walk(signature_key, model_recipe_manager)
     finally:
       rt.clear_calibration_step()
+
+  def _calibrate_step(self, signature_key: Optional[str], data: Any,
+                      model_recipe_manager: recipe_manager.RecipeManager) -> None:
+    self._finish_step(signature_key, self._prepare_step(signature_key, data, model_recipe_manager),
+                      model_recipe_manager)
+
+  def _steps_one_ahead(self, signature_key, dataset, model_recipe_manager):
+    """Prepared steps of `dataset`, each yielded after the NEXT one has been prepared."""
+    waiting = None
+    for data in dataset:
+      nxt = self._prepare_step(signature_key, data, model_recipe_manager)
+      if waiting is not None:
+        yield waiting
+      waiting = nxt
+    if waiting is not None:
+      yield waiting
 
   def finalize_statistics(self) -> None:
     """Statistics that still hold unprocessed samples in HBM (GPTQ Hessians collect tokens in a
@@ -193,25 +226,31 @@ class Calibrator:
         yield sg, graph_info, op, op_key, alg
         todo.extend(tfl_flatbuffer_utils.get_op_side_effect_subgraphs(op))
 
-  def _stage_sample(self, signature_key, contents, model_recipe_manager) -> None:
+  def _stage_sample(self, signature_key, contents, model_recipe_manager):
     """Every float32 activation the walk will read goes to HBM once and gets its (min, max)
-    from one batched launch (the per-op calibration functions then find it staged)."""
+    from one batched launch (the per-op calibration functions then find it staged). Returns
+    (arrays, device tensors, pinned result, event, lo, hi) -- the result is on its way -- or None."""
+    import torch
     lo, hi = -3e38, 3e38                      # the calibration functions' default valid_range
     wanted: dict[int, np.ndarray] = {}
     for name in self._plan(signature_key, model_recipe_manager)["runtime_tensors"]:
-      arr = self._tensor_content_map.get(name)
+      arr = contents.get(name)
+      if arr is None:
+        arr = self._tensor_content_map.get(name)
       if isinstance(arr, (np.ndarray, rt.HbmArray)) and arr.dtype == np.float32 and arr.size:
         wanted[id(arr)] = arr
     if not wanted:
-      return
+      return None
     rt.require_gpu()
     arrays = list(wanted.values())
     dev = [a.device_tensor.contiguous().reshape(-1) if isinstance(a, rt.HbmArray)
            else rt.to_device(np.ascontiguousarray(a).reshape(-1)) for a in arrays]
-    mm = rt.to_numpy(ops.act_minmax(dev, lo, hi)).astype(np.float32)
-    rt.stage_calibration_step({
-        id(a): {"host": a, "dev": d, "lo": lo, "hi": hi, "minmax": (mm[i, 0], mm[i, 1])}
-        for i, (a, d) in enumerate(zip(arrays, dev))})
+    mm = ops.act_minmax(dev, lo, hi)
+    pinned = torch.empty(tuple(mm.shape), dtype=mm.dtype, pin_memory=True)
+    pinned.copy_(mm, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record()
+    return arrays, dev, pinned, event, lo, hi
 
   def _walk(self, signature_key, model_recipe_manager) -> None:
     from .algorithms.uniform_quantize import common_quantize
@@ -241,6 +280,18 @@ class Calibrator:
       update = (self._qsv_update_func if self._is_custom_qsv_update_func
                 else algorithm_manager.get_update_qsv_func(alg, op_key))
       updated |= self._update_qsvs(op_qsvs, updated, update)
+
+  def record_steps(self, signature_key: Optional[str], dataset: Iterable[Any],
+                   model_recipe_manager: recipe_manager.RecipeManager):
+    """record_step over a sequence of samples, the next one's statistics already on their way
+    while this one is walked (yields one event list per sample, in order)."""
+    for prepared in self._steps_one_ahead(signature_key, dataset, model_recipe_manager):
+      self._recording = []
+      try:
+        self._finish_step(signature_key, prepared, model_recipe_manager)
+        yield self._recording
+      finally:
+        self._recording = None
 
   def record_step(self, signature_key: Optional[str], data: Any,
                   model_recipe_manager: recipe_manager.RecipeManager) -> list[tuple]:
@@ -279,9 +330,12 @@ class Calibrator:
     del cache_output   # model outputs are the caller's: nothing is executed here
     with self.plan_once():
       for signature_key, dataset in calibration_dataset.items():
-        for data in dataset:
-          self._metadata["num_samples_calibrated"] += 1
-          self._calibrate_step(signature_key, data, model_recipe_manager)
+        def counted(samples):        # (a sample counts when it is taken up, before its step can fail: ref :325-330)
+          for data in samples:
+            self._metadata["num_samples_calibrated"] += 1
+            yield data
+        for prepared in self._steps_one_ahead(signature_key, counted(dataset), model_recipe_manager):
+          self._finish_step(signature_key, prepared, model_recipe_manager)
     self.finalize_statistics()
 
   def get_model_qsvs(self) -> dict[str, qtyping.QSV]:

@@ -450,8 +450,8 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
   with local.plan_once():
     for sig_idx, (signature_key, dataset) in enumerate(calibration_data.items()):
       samples = dataset if hasattr(dataset, "__len__") and hasattr(dataset, "__getitem__") else list(dataset)
-      for k in sample_shard(len(samples), rank, world):
-        events = local.record_step(signature_key, samples[k], rm)
+      shard = sample_shard(len(samples), rank, world)
+      for k, events in zip(shard, local.record_steps(signature_key, (samples[j] for j in shard), rm)):
         mine.append((sig_idx, k, _set_hessians_aside(events, running)))
   if world > 1:
     parts = [None] * world

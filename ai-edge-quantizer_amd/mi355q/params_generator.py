@@ -233,3 +233,5 @@ class ParamsGenerator:
       h = qsv.get("hessian") if isinstance(qsv, dict) else None
       if hasattr(h, "cache"):
         h.cache.clear()
+    from . import runtime as rt
+    rt.release_upload_staging()

@@ -52,6 +52,118 @@ def to_device(a, dtype=None) -> torch.Tensor:
   return t.to(device(), non_blocking=True)
 
 
+# ---- uploads that do not wait for the compute queue ---------------------------------------------
+_UPLOAD_SLOT_BYTES = 256 << 20
+_UPLOAD_READERS = 8
+_UPLOAD: dict = {}         # device index -> {"stream", "slots": [(pinned, event)], "next"}
+_FILE_MAPPINGS: list = []  # (base address, length, path) of model files mapped by tfl_flatbuffer_utils
+_FILE_FDS: dict = {}
+_READ_POOL: list = []
+
+
+def register_file_mapping(mapping, path) -> None:
+  """Remembers where a model file is mapped, so that a weight that is a view of the mapping can also
+  be fetched with pread() from the file itself (upload_overlapped)."""
+  try:
+    base = np.frombuffer(mapping, dtype=np.uint8).ctypes.data
+  except (ValueError, TypeError):
+    return
+  _FILE_MAPPINGS[:] = [m for m in _FILE_MAPPINGS if m[0] != base][-15:]
+  _FILE_MAPPINGS.append((base, len(mapping), str(path)))
+
+
+def _file_range_of(arr: np.ndarray):
+  addr = arr.ctypes.data
+  for base, length, path in reversed(_FILE_MAPPINGS):
+    if base <= addr and addr + arr.nbytes <= base + length:
+      return path, addr - base
+  return None
+
+
+def upload_overlapped(a: np.ndarray) -> torch.Tensor:
+  """A weight that is a view of a mapped model file -> device tensor, without waiting for the compute
+  already queued on the current stream.
+
+  to_device's pageable copy is ordered behind everything queued on the current stream and blocks
+  the calling thread until it ran: under GPTQ, where every FULLY_CONNECTED queues tens of
+  milliseconds of inverse and update, the op walk then advances in lock step with the GPU and the
+  model's 8 GB of weights cross PCIe while nothing computes. Here the bytes are read from the
+  FILE (pread() on a few reader threads: a kernel copy out of the page cache, no page-table
+  population of the mapping; 43 GB/s against 18 for the mapped pageable copy on a 6 GB file,
+  tools/h2d_big_probe.py) into one of two pinned slots and travel on a copy stream of their own;
+  the current stream waits for them only where it first uses the tensor. The tensor is allocated
+  on the copy stream (the block it lands in cannot still be read by compute queued earlier) and
+  recorded on the current one. Arrays that are not views of a registered mapping take to_device."""
+  import concurrent.futures
+  import os
+  where = _file_range_of(a) if isinstance(a, np.ndarray) and a.flags.c_contiguous else None
+  if where is None:
+    return to_device(a)
+  path, offset = where
+  fd = _FILE_FDS.get(path)
+  if fd is None:
+    fd = _FILE_FDS[path] = os.open(path, os.O_RDONLY)
+  if not _READ_POOL:
+    _READ_POOL.append(concurrent.futures.ThreadPoolExecutor(max_workers=_UPLOAD_READERS, thread_name_prefix="mi355q-read"))
+  pool = _READ_POOL[0]
+  dev = device()
+  st = _UPLOAD.get(dev.index)
+  if st is None:
+    st = _UPLOAD[dev.index] = {"stream": torch.cuda.Stream(device=dev), "slots": [], "next": 0}
+  copy_stream = st["stream"]
+  n = a.nbytes
+  with torch.cuda.stream(copy_stream):
+    out = torch.empty((n,), dtype=torch.uint8, device=dev)
+
+  def read(view, at):
+    got = 0
+    while got < len(view):
+      k = os.preadv(fd, [view[got:]], at + got)
+      if k <= 0:
+        raise OSError(f"short read from {path}")
+      got += k
+  for off in range(0, n, _UPLOAD_SLOT_BYTES):
+    size = min(_UPLOAD_SLOT_BYTES, n - off)
+    k = st["next"] % 2
+    st["next"] += 1
+    if len(st["slots"]) <= k:
+      st["slots"].append((torch.empty((_UPLOAD_SLOT_BYTES,), dtype=torch.uint8).pin_memory(), torch.cuda.Event()))
+    pinned, event = st["slots"][k]
+    event.synchronize()                        # the slot's previous transfer has left it
+    view = memoryview(pinned.numpy())
+    part = max(4 << 20, -(-size // _UPLOAD_READERS) + 4095 & ~4095)
+    jobs = [pool.submit(read, view[p:min(size, p + part)], offset + off + p) for p in range(0, size, part)]
+    for j in jobs:
+      j.result()
+    with torch.cuda.stream(copy_stream):
+      out[off:off + size].copy_(pinned[:size], non_blocking=True)
+      event.record(copy_stream)
+  done = torch.cuda.Event()
+  done.record(copy_stream)
+  cur = torch.cuda.current_stream()
+  cur.wait_event(done)
+  out.record_stream(cur)
+  t = torch.from_numpy(np.empty(0, a.dtype)).dtype
+  return out.view(t).reshape(a.shape)
+
+
+def release_upload_staging() -> None:
+  """Gives the pinned staging slots (512 MB of page-locked host memory per device), the reader
+  threads and the file descriptors back."""
+  import os
+  for st in _UPLOAD.values():
+    st["stream"].synchronize()
+  _UPLOAD.clear()
+  for fd in _FILE_FDS.values():
+    try:
+      os.close(fd)
+    except OSError:
+      pass
+  _FILE_FDS.clear()
+  while _READ_POOL:
+    _READ_POOL.pop().shutdown(wait=True)
+
+
 _NP_DTYPE: dict = {}     # torch dtype -> NumPy dtype
 
 

@@ -114,6 +114,20 @@ def _sylvester_hadamard(size: int) -> np.ndarray:
   return h / np.sqrt(size)
 
 
+_HADAMARD_F32: dict[int, np.ndarray] = {}
+
+
+def _sylvester_hadamard_f32(size: int) -> np.ndarray:
+  """The float32 constant the rotation op multiplies by, built once per size (a model inserts one per
+  rotated FULLY_CONNECTED: 126 of order 2048 in an 18-layer decoder; read-only, shared by the writers)."""
+  m = _HADAMARD_F32.get(size)
+  if m is None:
+    m = _sylvester_hadamard(size).astype(np.float32)
+    m.setflags(write=False)
+    _HADAMARD_F32[size] = m
+  return m
+
+
 def insert_decomposed_hadamard_rotation(ti: _Input) -> qtyping.TransformationInfo:
   """x -> RESHAPE(-1, h) -> FULLY_CONNECTED with H_h / sqrt(h) -> RESHAPE(x.shape), feeding the
   FULLY_CONNECTED consumers (or everything after an EMBEDDING_LOOKUP producer) whose weights
@@ -139,7 +153,7 @@ def insert_decomposed_hadamard_rotation(ti: _Input) -> qtyping.TransformationInf
   reshape_code = transformation_utils.add_op_code(qtyping.BuiltinOperator.RESHAPE, model.operatorCodes, "RESHAPE")
   pre = qtyping.OperatorT(opcodeIndex=reshape_code, inputs=[ti.tensor_id, pre_shape], outputs=[pre_out])
   matrix = transformation_utils.add_new_constant_tensor(
-      name + b"_hadamard_matrix", _sylvester_hadamard(h).astype(np.float32), f32, sg, model,
+      name + b"_hadamard_matrix", _sylvester_hadamard_f32(h), f32, sg, model,
       allow_tensor_sharing=True)
   rotated = transformation_utils.add_new_activation_tensor(name + b"_rotated", flat, f32, sg)
   fc_code = transformation_utils.add_op_code(qtyping.BuiltinOperator.FULLY_CONNECTED, model.operatorCodes,

@@ -105,7 +105,13 @@ def get_model_content(tflite_path: Path) -> memoryview:
   with open(tflite_path, "rb") as f:
     if os.fstat(f.fileno()).st_size == 0:
       raise ValueError(f"{tflite_path} is empty")
-    return memoryview(mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ))
+    mapping = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+  try:
+    from .. import runtime          # (weights that are views of this mapping can be read from the file)
+    runtime.register_file_mapping(mapping, os.path.abspath(tflite_path))
+  except Exception:  # noqa: BLE001 - host-only tools import this module without a GPU runtime
+    pass
+  return memoryview(mapping)
 
 
 def get_model_buffer(tflite_path: Path) -> bytearray:

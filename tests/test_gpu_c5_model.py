@@ -61,6 +61,12 @@ def c5():
     calls["batched_calls"] += 1
     return orig_batched(hs, *a, **k)
   ops.gptq_hinv_batched = batched
+  orig_prod = ops.gptq_hinv_from_product
+
+  def from_product(*a, **k):
+    calls["hinv"] += 1
+    return orig_prod(*a, **k)
+  ops.gptq_hinv_from_product = from_product
 
   def apply(*a, **k):
     calls["apply"] += 1
@@ -84,6 +90,7 @@ def c5():
     n = litertlm_utils.quantize_litertlm(src, rcp, dst, calibration_results=qsvs)
   finally:
     ops.gptq_hinv, ops.gptq_apply, ops.gptq_hinv_batched = orig_hinv, orig_apply, orig_batched
+    ops.gptq_hinv_from_product = orig_prod
   out = litertlm_utils.LiteRTLMFile(dst)
   qmodel = out.read_model(0)
   yield dict(C=C, torch=torch, ops=ops, weights=weights, samples=samples, qsvs=qsvs[0], qmodel=qmodel,
@@ -155,14 +162,23 @@ def test_full_chain_d2048_against_the_oracles_own_chain(c5):
   got_h = np.asarray(c5["qsvs"]["l0/attn_in"]["hessian"])
   parity_rates.check_rel("C5 model l0/attn_in Hessian (16 samples merged) vs oracle x.T.dot(x)", got_h, hess, 2e-6)
   hinv = O.gptq_hessian_inverse(hess)
+  # the reference's own reproducibility (see the d = 16384 test): the Hessian summed in two halves
+  x2 = x.reshape(-1, x.shape[-1])
+  half = x2.shape[0] // 2
+  hinv_b = O.gptq_hessian_inverse((2.0 / np.array(x.shape[0])) * (x2[:half].T.dot(x2[:half]) + x2[half:].T.dot(x2[half:])))
   for name, rows in (("q", 2048), ("k", 256), ("v", 256)):
     w = c5["weights"][f"l0/{name}/w"]
     q, _, _ = _quantized(c5["qmodel"], f"l0/{name}/w")
     sel = np.r_[0:32, rows - 32:rows]
     ref_scale = O.min_max_quant_params(w, 4, True, "CHANNELWISE")["scale"]
-    ref = O.gptq_apply(w[sel], ref_scale[sel], np.zeros((len(sel), 1), np.int8), 4, True, None, "CHANNELWISE", hinv=hinv)
+    zp = np.zeros((len(sel), 1), np.int8)
+    ref = O.gptq_apply(w[sel], ref_scale[sel], zp, 4, True, None, "CHANNELWISE", hinv=hinv)
+    ref_b = O.gptq_apply(w[sel], ref_scale[sel], zp, 4, True, None, "CHANNELWISE", hinv=hinv_b)
+    floor = float((ref != ref_b).mean())
+    parity_rates.note(f"reference noise floor: oracle FULL CHAIN l0/{name} [64,2048] int4 with the Hessian summed in another order",
+                      "int_mismatch_fraction", floor, 1.0)
     parity_rates.check(f"C5 model l0/{name} [{rows},2048] int4, 64 rows vs oracle FULL CHAIN (einsum)",
-                       q[sel], ref, parity_rates.T2)
+                       q[sel], ref, max(parity_rates.T2, 4 * floor, 2e-4))
 
 
 def test_full_chain_d16384_against_the_oracles_own_chain(c5):

@@ -379,7 +379,7 @@ def test_inverse_from_the_float32_product_equals_inverse_of_the_finished_hessian
   h = m.ops.gptq_xtx_finish(prod, alpha)
   assert torch.equal(h, h.T)
   whole = m.ops.gptq_xtx(x, alpha)
-  assert float((h - whole).abs().max() / whole.abs().max()) <= 1e-6      # two slabs added in float32
+  assert float((h - whole).abs().max() / whole.abs().max()) <= 4e-6      # two slabs added in float32 (FP32-MFMA path: one K chain per slab)
   want, winfo = m.ops.gptq_hinv(h, 0.01)
   got, ginfo = m.ops.gptq_hinv_from_product(prod, alpha, 0.01)
   assert int(winfo.item()) == int(ginfo.item()) == 0

@@ -155,6 +155,7 @@ class GpuPhases:
   (no synchronisation is added; the events are read after the run)."""
   FAMILIES = {"gptq_xtx": "hessian", "gptq_xtx_accum": "hessian", "gptq_xtx_finish": "hessian_finish",
               "gptq_hessian_merge": "hessian_merge", "gptq_hinv": "hinv", "gptq_hinv_batched": "hinv",
+              "gptq_hinv_from_product": "hinv",
               "gptq_apply": "apply", "act_minmax": "act_minmax", "requant_sym": "scales",
               "hadamard_rotate": "hadamard", "octav_clip": "octav", "pack_bits": "pack", "minmax": "scales"}
 

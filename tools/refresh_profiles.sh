@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-end refresh of the measured artefacts, run ON THE GPU BOX from the repo root:
-#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02'
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'
 # Everything lands under gpurun_out/<round>/; copy what is to be judged into profiles/.
 set -u
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$ROUND
 mkdir -p "$OUT"
@@ -46,7 +46,9 @@ python tools/pmc_big_kernels.py /tmp/prof_fetch > "$OUT/hinv16384_fetch.txt" 2>&
   echo "# over 20 calls) vs number of Newton iterations; all 10 run in production (the reference's early stop is global)."
   echo "# octav_rows_kernel<SLOTS, THREADS>: workgroup per row, 16-element pieces in registers (one per thread; 512 / 1024 threads for rows"
   echo "# beyond 4096 elements), run sums listed in LDS (fixed 16-step pass, or a run loop for sparsely selected pieces), the two masks'"
-  echo "# serial chains on two waves; unchanged masks reuse the sums."
+  echo "# serial chains on the lanes of ONE wave; unchanged masks reuse the sums; a guess above the row's largest |x| selects nothing"
+  echo "# without touching the masks; once few elements are selected and the guess grows, the candidates are listed and a one-wave"
+  echo "# tail kernel (octav_tail_kernel) finishes the row."
   echo "# --- 4096 x 4096, sigma = 0.02 (typical weights: the first guess 1.0 selects nothing, the second (0.0) half of every mask)"
   timeout 200 python tools/octav_iter_bench.py 4096 4096 0.02 2>&1 | grep max_iter
   echo "# --- 4096 x 4096, sigma = 1.0"
@@ -60,6 +62,18 @@ python tools/pmc_big_kernels.py /tmp/prof_fetch > "$OUT/hinv16384_fetch.txt" 2>&
   echo "# tools/api_resident_bench.py (get_tensor_quant_params on HBM-resident weights; batched = inside requant_queue.batching())"
   timeout 300 python tools/api_resident_bench.py 2>&1 | grep workload
 } > "$OUT/octav_iterations_and_api_resident.txt" 2>&1
+{
+  echo "# tools/c5_model.py: BASELINE config 5 as one quantize_litertlm(calibration_data=...) call, 18 Gemma-2B-shaped layers, one GPU"
+  for v in gptq mixed hadamard; do timeout 600 python tools/c5_model.py --layers 18 --variant $v 2>&1 | tail -1; done
+  echo "# tools/hinv_batched_bench.py: d = 2048 inverses, one call each vs mi355q_gptq_hinv_f64_batched"
+  timeout 200 python tools/hinv_batched_bench.py 2048 54 2>&1 | tail -1
+  echo "# tools/hinv_accuracy.py: time and error vs the exact FP64 inverse (bf16 split for the float32 steps, then FP64 throughout)"
+  timeout 300 python tools/hinv_accuracy.py 4096 8192 16384 2>&1 | grep mode
+  MI355Q_HINV_FP64=1 timeout 300 python tools/hinv_accuracy.py 4096 16384 2>&1 | grep mode
+  echo "# tools/gptq_apply_bench.py"
+  timeout 200 python tools/gptq_apply_bench.py 2>&1 | grep op
+} > "$OUT/c5_model.txt" 2>&1
+bash tools/pmc_traffic_refresh.sh "$ROUND" > "$OUT/pmc_traffic.log" 2>&1
 for a in "" "--resident"; do timeout 300 python tools/c4_bench.py --samples 128 $a 2>&1 | tail -1; done > "$OUT/c4_c5_public.txt"
 for a in "" "--resident"; do timeout 600 python tools/c5_bench.py --samples 4 $a 2>&1 | tail -1; done >> "$OUT/c4_c5_public.txt"
 timeout 300 python tools/file_bench.py 2>&1 | tail -1 >> "$OUT/c4_c5_public.txt"
