@@ -299,7 +299,7 @@ def hessian_owners(plan: Sequence[tuple], owner: Sequence[int], costs) -> dict[s
 
 
 def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dict] = None,
-                           serialize_to_path=None, group=None, planned=None):
+                           serialize_to_path=None, group=None, planned=None, sink=None):
   """`Quantizer(float_model, recipe).quantize(...)` with the ops' weight work spread over the
   ranks of `group` (BASELINE configs 3 and 5: tensor-buffers sharded over 8 GPUs).
 
@@ -332,7 +332,7 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
     if mine is None:
       return None
   params = gen.finish(mine[i] for i in range(len(plan)))
-  return model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path)
+  return model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path, sink=sink)
 
 
 def _gather_results(mine: dict, group=None) -> Optional[dict]:
@@ -350,7 +350,7 @@ def _gather_results(mine: dict, group=None) -> Optional[dict]:
 
 
 def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serialize_to_path=None, group=None,
-                                   tensor_provider=None, stats: Optional[dict] = None):
+                                   tensor_provider=None, stats: Optional[dict] = None, sink=None):
   """BASELINE config 5 in one call: `Quantizer.calibrate` + `Quantizer.quantize` over a process group.
 
   The op plan comes first (a function of model, recipe and world size: the same on every rank), so
@@ -374,7 +374,7 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
     torch.cuda.synchronize()
   t1 = time.perf_counter()
   out = quantize_model_sharded(qz.float_model, recipe, calibration_result=qsvs, serialize_to_path=serialize_to_path,
-                               group=group, planned=planned)
+                               group=group, planned=planned, sink=sink)
   if torch.cuda.is_available():
     torch.cuda.synchronize()
   if stats is not None:

@@ -98,8 +98,9 @@ def _large_buffer_bytes(model: Any) -> int:
   return total
 
 
-def serialize_model(model: Any, serialize_to_path: Optional[tfl_flatbuffer_utils.Path] = None):
-  """ref :184-199 (layout choice), :290-391 (the two serializers)."""
+def serialize_model(model: Any, serialize_to_path: Optional[tfl_flatbuffer_utils.Path] = None, sink=None):
+  """ref :184-199 (layout choice), :290-391 (the two serializers). `sink(total_bytes)` -> a writable
+  buffer to build a large model into (e.g. its place inside a container file's mapping)."""
   if _large_buffer_bytes(model) < _INLINE_LIMIT_BYTES:
     for b in model.buffers or []:
       if hasattr(b.data, "copy_into"):        # device resident: the inline writer wants bytes
@@ -109,7 +110,11 @@ def serialize_model(model: Any, serialize_to_path: Optional[tfl_flatbuffer_utils
       tfl_flatbuffer_utils.set_file_contents(serialize_to_path, out)
     return out
 
+  caller_sink = sink
+
   def sink(total: int):
+    if caller_sink is not None:
+      return caller_sink(total)
     if not serialize_to_path:
       return None
     with open(serialize_to_path, "w+b") as f:
@@ -128,7 +133,7 @@ class ModelModifier:
 
   def modify_model(self, params: dict[str, qtyping.TensorTransformationParams],
                    serialize_to_path: Optional[tfl_flatbuffer_utils.Path] = None,
-                   enable_progress_bar: Optional[bool] = None):
+                   enable_progress_bar: Optional[bool] = None, sink=None):
     del enable_progress_bar
     quantized = copy_with_views(self._model)
     insts = apply_transformations(quantized, params)
@@ -137,4 +142,4 @@ class ModelModifier:
     if _inserted_before_output(insts, _T.ADD_QUANTIZE):
       _repoint_signature_outputs(quantized, "_quantized")
     self.quantized_model_object = quantized
-    return serialize_model(quantized, serialize_to_path)
+    return serialize_model(quantized, serialize_to_path, sink)

@@ -234,4 +234,4 @@ class ParamsGenerator:
       if hasattr(h, "cache"):
         h.cache.clear()
     from . import runtime as rt
-    rt.release_upload_staging()
+    rt.release_upload_files()

@@ -53,7 +53,7 @@ def to_device(a, dtype=None) -> torch.Tensor:
 
 
 # ---- uploads that do not wait for the compute queue ---------------------------------------------
-_UPLOAD_SLOT_BYTES = 256 << 20
+_UPLOAD_SLOT_BYTES = 64 << 20     # (page-locking memory costs ~0.3 ms per MiB: two small slots, kept for the process)
 _UPLOAD_READERS = 8
 _UPLOAD: dict = {}         # device index -> {"stream", "slots": [(pinned, event)], "next"}
 _FILE_MAPPINGS: list = []  # (base address, length, path) of model files mapped by tfl_flatbuffer_utils
@@ -90,7 +90,7 @@ def upload_overlapped(a: np.ndarray) -> torch.Tensor:
   model's 8 GB of weights cross PCIe while nothing computes. Here the bytes are read from the
   FILE (pread() on a few reader threads: a kernel copy out of the page cache, no page-table
   population of the mapping; 43 GB/s against 18 for the mapped pageable copy on a 6 GB file,
-  tools/h2d_big_probe.py) into one of two pinned slots and travel on a copy stream of their own;
+  tools/h2d_big_probe.py) into one of two pinned 64 MiB slots and travel on a copy stream of their own;
   the current stream waits for them only where it first uses the tensor. The tensor is allocated
   on the copy stream (the block it lands in cannot still be read by compute queued earlier) and
   recorded on the current one. Arrays that are not views of a registered mapping take to_device."""
@@ -147,8 +147,21 @@ def upload_overlapped(a: np.ndarray) -> torch.Tensor:
   return out.view(t).reshape(a.shape)
 
 
+def release_upload_files() -> None:
+  """Closes the model files opened for pread (after the transfers that read them have left)."""
+  import os
+  for st in _UPLOAD.values():
+    st["stream"].synchronize()
+  for fd in _FILE_FDS.values():
+    try:
+      os.close(fd)
+    except OSError:
+      pass
+  _FILE_FDS.clear()
+
+
 def release_upload_staging() -> None:
-  """Gives the pinned staging slots (512 MB of page-locked host memory per device), the reader
+  """Gives the pinned staging slots (128 MB of page-locked host memory per device), the reader
   threads and the file descriptors back."""
   import os
   for st in _UPLOAD.values():
@@ -259,8 +272,65 @@ class HbmArray:
     return f"HbmArray(shape={self.shape}, dtype={self.dtype})"
 
   def __reduce__(self):
-    # crosses process boundaries (gather of sharded results) as host data
+    # crosses process boundaries (gather of sharded results) as host data. A sub-byte quantized
+    # weight travels as the packed bytes the model file stores -- a third of what the int8
+    # containers plus the packed bytes would be; the containers are unpacked on arrival only if read.
+    if self.packed is not None and self.dtype == np.int8 and self.size:
+      bits = self.packed.size * 8 // self.size
+      if bits in (2, 4):
+        return (PackedCarrier, (np.asarray(self.packed), self.shape, bits))
     return (_host_carrier, (self.numpy(), None if self.packed is None else np.asarray(self.packed)))
+
+
+class PackedCarrier:
+  """What the HbmArray of an int4 / int2 quantized weight unpickles to on another rank: the packed
+  bytes (`.packed`, what transformations/quantize_tensor stores) and, on demand, the sign-extended
+  int8 containers (ref transformations/transformation_utils.py:293-353 read backwards)."""
+  __array_priority__ = 100.0
+
+  def __init__(self, packed: np.ndarray, shape, bits: int):
+    self.packed = packed
+    self._shape = tuple(int(v) for v in shape)
+    self._bits = int(bits)
+    self._values = None
+
+  shape = property(lambda self: self._shape)
+  ndim = property(lambda self: len(self._shape))
+  dtype = property(lambda self: np.dtype(np.int8))
+  size = property(lambda self: int(np.prod(self._shape, dtype=np.int64)))
+  nbytes = property(lambda self: self.size)
+
+  def numpy(self) -> np.ndarray:
+    if self._values is None:
+      per = 8 // self._bits
+      b = np.asarray(self.packed, dtype=np.uint8)
+      parts = [(b >> (self._bits * k)) & ((1 << self._bits) - 1) for k in range(per)]
+      v = np.stack(parts, axis=-1).reshape(-1)[:self.size].astype(np.int8)
+      half = 1 << (self._bits - 1)
+      self._values = np.where(v >= half, v - (1 << self._bits), v).astype(np.int8).reshape(self._shape)
+    return self._values
+
+  def __array__(self, dtype=None, copy=None):
+    a = self.numpy()
+    return a if dtype is None else a.astype(dtype, copy=False)
+
+  def __len__(self) -> int:
+    return self._shape[0]
+
+  def __getitem__(self, idx):
+    return self.numpy()[idx]
+
+  def reshape(self, *shape):
+    return self.numpy().reshape(*shape)
+
+  def tolist(self):
+    return self.numpy().tolist()
+
+  def __reduce__(self):
+    return (PackedCarrier, (self.packed, self._shape, self._bits))
+
+  def __repr__(self):
+    return f"PackedCarrier(shape={self._shape}, int{self._bits})"
 
 
 KEEP_IN_HBM_BYTES = 4 << 20     # quantized weights of float tensors this large stay in HBM

@@ -134,16 +134,13 @@ class LiteRTLMFile:
       return None
     return tfl_flatbuffer_utils.read_model(self.get_section_buffer(section_id))
 
-  def serialize(self, path: Path, section_data_overrides: Mapping[int, Any]) -> int:
-    """Writes the file again with some sections replaced; returns the number of bytes written.
-    Sections keep their order and start at BLOCK_SIZE-aligned offsets (ref :176-283)."""
-    if not self._sections:
-      raise ValueError("LiteRT-LM file has no sections")
+  def _layout(self, new_lengths: Mapping[int, int]):
+    """(header bytes with patched offsets, section offsets, section lengths, total) when the
+    sections in `new_lengths` get those lengths (ref :176-283: order kept, BLOCK_SIZE alignment)."""
     offsets = [min(s.beginOffset for s in self._sections)]
     lengths = []
     for sid, s in enumerate(self._sections):
-      data = section_data_overrides.get(sid)
-      n = len(data) if data is not None and len(data) else s.endOffset - s.beginOffset
+      n = new_lengths.get(sid) or s.endOffset - s.beginOffset
       lengths.append(n)
       offsets.append((offsets[-1] + n + BLOCK_SIZE - 1) & ~(BLOCK_SIZE - 1))
     header = bytearray(self._buf[:self._header_end])
@@ -152,7 +149,32 @@ class LiteRTLMFile:
         raise ValueError("section record without stored offsets cannot be re-addressed in place")
       struct.pack_into("<Q", header, HEADER_BEGIN_BYTE_OFFSET + begin_at, offsets[sid])
       struct.pack_into("<Q", header, HEADER_BEGIN_BYTE_OFFSET + end_at, offsets[sid] + lengths[sid])
-    total = offsets[-2] + lengths[-1]
+    return header, offsets, lengths, offsets[-2] + lengths[-1]
+
+  def open_with_section(self, path: Path, section_id: int, section_bytes: int):
+    """Creates the output file for a container whose section `section_id` will be `section_bytes`
+    long, writes the header and every other section, and returns (mapping, writable view of the
+    section's place, total size): the new section is then built in place (a quantized model is
+    serialized once, into the file, instead of into memory and from there into the file)."""
+    if not self._sections:
+      raise ValueError("LiteRT-LM file has no sections")
+    header, offsets, lengths, total = self._layout({section_id: section_bytes})
+    with open(path, "w+b") as f:
+      f.truncate(total)
+      out = mmap.mmap(f.fileno(), total)
+    out[:len(header)] = header
+    for sid in range(len(self._sections)):
+      if sid != section_id:
+        out[offsets[sid]:offsets[sid] + lengths[sid]] = memoryview(self.get_section_buffer(sid)).cast("B")
+    return out, memoryview(out)[offsets[section_id]:offsets[section_id] + section_bytes], total
+
+  def serialize(self, path: Path, section_data_overrides: Mapping[int, Any]) -> int:
+    """Writes the file again with some sections replaced; returns the number of bytes written.
+    Sections keep their order and start at BLOCK_SIZE-aligned offsets (ref :176-283)."""
+    if not self._sections:
+      raise ValueError("LiteRT-LM file has no sections")
+    new_lengths = {sid: len(d) for sid, d in section_data_overrides.items() if d is not None and len(d)}
+    header, offsets, lengths, total = self._layout(new_lengths)
     with open(path, "w+b") as f:
       f.truncate(total)
       out = mmap.mmap(f.fileno(), total)
@@ -242,26 +264,41 @@ def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path, overw
   from .. import distributed
   if os.path.exists(output_path) and not overwrite:
     raise ValueError(f"The model {output_path} already exists. Specify overwrite=True to replace it.")
+  import time
   src = LiteRTLMFile(litertlm_path)
+  todo = list(_tflite_sections(src, _recipes(recipe)))
+  if not todo:
+    raise ValueError("No models were quantized, not creating output file.")
   replaced: dict[int, Any] = {}
-  quantized_any = False
-  for sid, model_type, model_recipe in _tflite_sections(src, _recipes(recipe)):
+  built_in_place: dict = {}
+  for sid, model_type, model_recipe in todo:
+    sink = None
+    if len(todo) == 1:
+      # the only section that changes: once its size is known the container is laid out and the
+      # model is serialized straight into its place in the output file
+      def sink(total, sid=sid):
+        t0 = time.perf_counter()
+        mapping, place, size = src.open_with_section(output_path, sid, total)
+        built_in_place.update(mapping=mapping, size=size)
+        if stats is not None:
+          stats["repack_s"] = stats.get("repack_s", 0.0) + (time.perf_counter() - t0)
+        return place
     data = _pick(calibration_data, sid, model_type)
     if data is not None:
       result = distributed.calibrate_and_quantize_sharded(
-          src.get_section_buffer(sid), model_recipe, data, group=group, tensor_provider=tensor_provider, stats=stats)
+          src.get_section_buffer(sid), model_recipe, data, group=group, tensor_provider=tensor_provider, stats=stats,
+          sink=sink)
     else:
       result = distributed.quantize_model_sharded(
           src.get_section_buffer(sid), model_recipe,
-          calibration_result=_pick(calibration_results, sid, model_type), group=group)
-    quantized_any = True
+          calibration_result=_pick(calibration_results, sid, model_type), group=group, sink=sink)
     if result is not None:
       replaced[sid] = result
-  if not quantized_any:
-    raise ValueError("No models were quantized, not creating output file.")
+  if built_in_place:
+    # (no msync: a shared mapping is coherent with the page cache, readers see the bytes at once)
+    return built_in_place["size"]
   if not replaced:          # a rank other than the group's first: nothing to write
     return None
-  import time
   t0 = time.perf_counter()
   n = src.serialize(output_path, replaced)
   if stats is not None:
