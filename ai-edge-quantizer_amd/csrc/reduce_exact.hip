@@ -958,27 +958,19 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
         const Shared* shc = reinterpret_cast<const Shared*>(smem + kX * ((nit - 1) & 1));
         int bp = scan_p - __builtin_popcount(wp[0]), bn = scan_n - __builtin_popcount(wn[0]);
         for (int k = 0; k < wave; ++k) { bp += shc->wave_count[0][k]; bn += shc->wave_count[1][k]; }
-        // (through LDS, where the run lists were: a thread's own few candidates are scattered 4- and 2-byte
-        // stores, the copy out is whole lines -- the scattered form fetched and wrote back four times the row)
-        float* lv[2] = {list_pos, list_neg};
-        unsigned short* lp[2] = {reinterpret_cast<unsigned short*>(list_pos + cand_cap),
-                                 reinterpret_cast<unsigned short*>(list_neg + cand_cap)};
-        __syncthreads();        // the chain wave is done with the run lists
+        // (each thread stores the few candidates of its own piece straight to global memory. Staging them
+        // in LDS and copying whole lines out was measured: the partial-line stores here cost 4 x the row in
+        // HBM traffic (profiles/r03_pmc_traffic.txt) but the kernel is bound by instruction issue, and the
+        // two extra barriers + copy loops made it 10 % slower: 200 against 182 us at 4096 x 4096)
+        float* vp = a.tail_values + (static_cast<long long>(unit) * 2) * cand_cap;
+        float* vn = vp + cand_cap;
+        unsigned short* pp = a.tail_pos + (static_cast<long long>(unit) * 2) * cand_cap;
+        unsigned short* pn = pp + cand_cap;
         const int e0 = kPiece * tid;
 #pragma unroll
         for (int i = 0; i < kPiece; ++i) {
-          if ((wp[0] >> i) & 1u) { lv[0][bp] = x[0][i]; lp[0][bp] = static_cast<unsigned short>(e0 + i); ++bp; }
-          if ((wn[0] >> i) & 1u) { lv[1][bn] = x[0][i]; lp[1][bn] = static_cast<unsigned short>(e0 + i); ++bn; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int n = m ? cn : cp;
-          float* gv = a.tail_values + (static_cast<long long>(unit) * 2 + m) * cand_cap;
-          unsigned* gp = reinterpret_cast<unsigned*>(a.tail_pos + (static_cast<long long>(unit) * 2 + m) * cand_cap);
-          const unsigned* lpw = reinterpret_cast<const unsigned*>(lp[m]);
-          for (int i = tid; i < n; i += THREADS) gv[i] = lv[m][i];
-          for (int i = tid; i < (n + 1) / 2; i += THREADS) gp[i] = lpw[i];
+          if ((wp[0] >> i) & 1u) { vp[bp] = x[0][i]; pp[bp] = static_cast<unsigned short>(e0 + i); ++bp; }
+          if ((wn[0] >> i) & 1u) { vn[bn] = x[0][i]; pn[bn] = static_cast<unsigned short>(e0 + i); ++bn; }
         }
         if (tid == 0) {
           TailState ts;
