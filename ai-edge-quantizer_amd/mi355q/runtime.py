@@ -53,7 +53,8 @@ def to_device(a, dtype=None) -> torch.Tensor:
 
 
 # ---- uploads that do not wait for the compute queue ---------------------------------------------
-_UPLOAD_SLOT_BYTES = 64 << 20     # (page-locking memory costs ~0.3 ms per MiB: two small slots, kept for the process)
+_UPLOAD_SLOT_BYTES = 32 << 20     # (page-locking memory costs ~1 ms per MiB here: two small slots, kept for the process)
+_UPLOAD_MIN_FILE_BYTES = 2 << 30  # ... and only for models large enough to earn the 70 ms back
 _UPLOAD_READERS = 8
 _UPLOAD: dict = {}         # device index -> {"stream", "slots": [(pinned, event)], "next"}
 _FILE_MAPPINGS: list = []  # (base address, length, path) of model files mapped by tfl_flatbuffer_utils
@@ -76,7 +77,7 @@ def _file_range_of(arr: np.ndarray):
   addr = arr.ctypes.data
   for base, length, path in reversed(_FILE_MAPPINGS):
     if base <= addr and addr + arr.nbytes <= base + length:
-      return path, addr - base
+      return (path, addr - base) if length >= _UPLOAD_MIN_FILE_BYTES else None
   return None
 
 
@@ -90,10 +91,10 @@ def upload_overlapped(a: np.ndarray) -> torch.Tensor:
   model's 8 GB of weights cross PCIe while nothing computes. Here the bytes are read from the
   FILE (pread() on a few reader threads: a kernel copy out of the page cache, no page-table
   population of the mapping; 43 GB/s against 18 for the mapped pageable copy on a 6 GB file,
-  tools/h2d_big_probe.py) into one of two pinned 64 MiB slots and travel on a copy stream of their own;
+  tools/h2d_big_probe.py) into one of two pinned 32 MiB slots and travel on a copy stream of their own;
   the current stream waits for them only where it first uses the tensor. The tensor is allocated
   on the copy stream (the block it lands in cannot still be read by compute queued earlier) and
-  recorded on the current one. Arrays that are not views of a registered mapping take to_device."""
+  recorded on the current one. Arrays that are not views of a registered mapping of at least 2 GiB take to_device."""
   import concurrent.futures
   import os
   where = _file_range_of(a) if isinstance(a, np.ndarray) and a.flags.c_contiguous else None
@@ -161,7 +162,7 @@ def release_upload_files() -> None:
 
 
 def release_upload_staging() -> None:
-  """Gives the pinned staging slots (128 MB of page-locked host memory per device), the reader
+  """Gives the pinned staging slots (64 MB of page-locked host memory per device), the reader
   threads and the file descriptors back."""
   import os
   for st in _UPLOAD.values():
