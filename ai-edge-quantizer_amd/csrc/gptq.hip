@@ -13,6 +13,9 @@
 // done in FP64 and cast to FP32 at the end (tolerance class T2).
 #include <cstdlib>
 #include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "gemm.h"
 
@@ -1029,6 +1032,10 @@ namespace mi355q {
 bool xtx_bf16x3_usable(int64_t n, int64_t d);
 size_t xtx_bf16x3_workspace_bytes(int64_t n, int64_t d);
 int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspace, hipStream_t st, bool accumulate_first);
+// xtx_f16x2.hip: the same product from a two-way float16 split (half the MFMA work; the default)
+bool xtx_f16x2_usable(int64_t n, int64_t d);
+size_t xtx_f16x2_workspace_bytes(int64_t n, int64_t d);
+int32_t xtx_f16x2(const float* x, int64_t n, int64_t d, float* p, void* workspace, hipStream_t st, bool accumulate_first);
 // ... and the same split for the update behind a group of columns of the OBS apply
 bool upd_bf16x3_usable(int64_t rows, int64_t d);
 size_t upd_bf16x3_workspace_bytes(int64_t rows, int64_t d, int64_t kk_max);
@@ -1044,7 +1051,8 @@ int32_t ltl_bf16x3(const double* linv, int64_t d, float* hinv, void* scratch, hi
 namespace {
 size_t xtx_scratch_bytes(int64_t n, int64_t d) {
   const size_t fp32 = gemm_splitk_workspace_bytes<float>(static_cast<int>(d), static_cast<int>(d), static_cast<int>(n < 0 ? 0 : n), true);
-  const size_t split = xtx_bf16x3_usable(n, d) ? xtx_bf16x3_workspace_bytes(n, d) : 0;
+  size_t split = xtx_bf16x3_usable(n, d) ? xtx_bf16x3_workspace_bytes(n, d) : 0;
+  if (xtx_f16x2_usable(n, d) && xtx_f16x2_workspace_bytes(n, d) > split) split = xtx_f16x2_workspace_bytes(n, d);
   return split > fp32 ? split : fp32;
 }
 
@@ -1054,6 +1062,7 @@ int32_t xtx_product(const float* x, int64_t n, int64_t d, float* p, bool accumul
   // P = X^T X : A(i,k) = X[k][i], B(k,j) = X[k][j]; long K is split over gridDim.z. P is
   // symmetric and P[i][j], P[j][i] are the same k-ordered sum of the same (commuting) products,
   // so only the lower triangle is computed (triangular launch grid: half the flops) and mirrored.
+  if (xtx_f16x2_usable(n, d)) return xtx_f16x2(x, n, d, p, scratch, st, accumulate);
   if (xtx_bf16x3_usable(n, d)) return xtx_bf16x3(x, n, d, p, scratch, st, accumulate);
   GemmArgs<float> g{x, 1, d, x, d, 1, p, d, 1, static_cast<int>(d), static_cast<int>(d),
                     static_cast<int>(n), 1.0f, accumulate ? 1.0f : 0.0f, 1, 0};
@@ -1539,11 +1548,33 @@ extern "C" int32_t mi355q_gptq_hinv_f64_batched(const double* const* hessians_ho
   if (hipEventRecord(pool->fork, st) != hipSuccess) return fail(MI355Q_HIP_ERROR, "hinv lanes: record failed");
   for (int l = 0; l < lanes; ++l)
     if (hipStreamWaitEvent(pool->lane[l], pool->fork, 0) != hipSuccess) return fail(MI355Q_HIP_ERROR, "hinv lanes: wait failed");
+  // One inverse is ~130 launches of a few microseconds of host time each: a single thread enqueuing 54
+  // chains is the bottleneck long before the chip is (39 ms of enqueue for 54 x 0.73 ms). Every lane
+  // therefore gets a thread of its own for the duration of the call.
   int32_t status = MI355Q_OK;
-  for (int32_t i = 0; i < count && status == MI355Q_OK; ++i) {
-    const int l = i % lanes;
-    status = mi355q_gptq_hinv_f64(hessians_host[i], d, damp_factor, hinv_out_host[i], info_out + i,
-                                  static_cast<unsigned char*>(workspace) + static_cast<size_t>(l) * per, per, pool->lane[l]);
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::vector<int32_t> lane_status(static_cast<size_t>(lanes), MI355Q_OK);
+    std::vector<std::string> lane_error(static_cast<size_t>(lanes));
+    std::vector<std::thread> workers;
+    for (int l = 0; l < lanes; ++l)
+      workers.emplace_back([&, l] {
+        (void)hipSetDevice(dev);
+        for (int32_t i = l; i < count; i += lanes) {
+          const int32_t e = mi355q_gptq_hinv_f64(hessians_host[i], d, damp_factor, hinv_out_host[i], info_out + i,
+                                                static_cast<unsigned char*>(workspace) + static_cast<size_t>(l) * per, per, pool->lane[l]);
+          if (e != MI355Q_OK) {
+            lane_status[static_cast<size_t>(l)] = e;
+            lane_error[static_cast<size_t>(l)] = mi355q_last_error();
+            break;
+          }
+        }
+      });
+    for (std::thread& w : workers) w.join();
+    for (int l = 0; l < lanes; ++l)
+      if (lane_status[static_cast<size_t>(l)] != MI355Q_OK && status == MI355Q_OK)
+        status = fail(static_cast<mi355q_status>(lane_status[static_cast<size_t>(l)]), "%s", lane_error[static_cast<size_t>(l)].c_str());
   }
   // whatever happened, the caller's stream waits for every lane: the workspace is the caller's
   for (int l = 0; l < lanes; ++l)

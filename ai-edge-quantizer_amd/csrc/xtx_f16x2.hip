@@ -1,0 +1,626 @@
+// GPTQ Hessian X^T X on the f16 matrix cores from a two-way split of every float32 (gfx950).
+//
+//   ref: algorithms/uniform_quantize/gptq.py:100-107  (2.0 / num_samples) * x.T.dot(x), float32 sgemm
+//
+// xtx_bf16x3.hip spends six bf16 products on every pair of operands and holds the socket at its
+// power limit (1.0-1.15 PFLOP/s of MFMA work at 1.5-1.7 GHz, profiles/r03_gptq_mfma_util.txt): the
+// Hessians of a Gemma-2B layer are 57 % of the GPU time of a whole GPTQ run. The way to make that
+// product faster is to need fewer MFMAs for it. A float16 carries 11 significant bits where a
+// bfloat16 carries 8, so TWO pieces hold 22 of a float32's 24 bits:
+//   x~ = x 2^e(column)            (a power of two per column: the column's largest |x| lands in
+//                                  [2^14, 2^15), inside float16's range whatever the activations' scale)
+//   h1 = f16(x~),  h2 = f16(x~ - h1)          (x~ - h1 is exact in float32)
+//   x~ y~ = h1 g1 + (h1 g2 + h2 g1) + O(2^-22 |x~ y~|)
+// and a product of two float16 numbers is exact in float32: three v_mfma_f32_32x32x16_f16 products
+// accumulated in float32 -- half the MFMA work and two thirds of the operand traffic of the
+// three-way split -- and the result is scaled back by 2^-(e_i + e_j) (exact) in the epilogue.
+// What is dropped is the tail of each operand below 2^-23 of itself (round to nearest, so the
+// errors of the terms of a sum do not line up) or, for elements more than 2^17 below their column's
+// largest, below 2^-39 of that largest: 2^-22 of sum |x||y| per entry at the very worst, a few 1e-8
+// of it observed -- the accumulation order of the float32 sgemm this replaces moves its result
+// by more (4e-6 for the FP32 MFMA product, tests/test_gpu_gptq.py). Tolerance class T2.
+// MI355Q_XTX_BF16X3=1 selects the three-way split instead.
+//
+// Per slab of <= 16384 tokens:
+//   colmax  the largest finite |x| of every column (atomicMax on the bit patterns)
+//   split   X [n, d] float32 -> P[k tile of 16 tokens][plane 0..1][row i < d][32 bytes], the image
+//           xtx_bf16x3.hip describes (4 KB per 128-row operand tile, plane and k tile; 16-byte chunks
+//           swapped where (i >> 3) & 1), and the exponents e_i
+//   xtx     lower-triangular grid of 128 x 128 output tiles in 8 x 8 patches per XCD; per PAIR of k
+//           tiles (32 tokens) both planes of both operand tiles (32 KB, a ring of three) go to LDS
+//           by global_load_lds and every wave issues 24 MFMAs on its 64 x 64 quadrant from 16
+//           fragment reads. h1 g1 has accumulators of its own, folded into a third set every 32 k
+//           tiles as in the three-way kernel.
+// An infinite activation gives +-inf where x.T.dot(x) does (the h1 g1 sum decides; the NaN of an
+// inf * 0 cross term is dropped); the damped Cholesky refuses it.
+#include "common.h"
+
+namespace mi355q {
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+
+constexpr int kTile = 128;                  // output tile edge
+constexpr int kBK = 16;                     // tokens per k tile (one MFMA K step)
+constexpr int kRowB = 2 * kBK;              // bytes of one row of one plane in one k tile
+constexpr int kPlaneTileB = kTile * kRowB;  // 4 KB
+constexpr int kOperandB = 2 * kPlaneTileB;  // 8 KB: both planes of one operand tile, one k tile
+constexpr int kStageB = 4 * kOperandB;      // 32 KB: two k tiles of both operands
+constexpr int kSuper = 8;                   // tiles per side of an XCD patch
+constexpr int kSlabTokens = 16384;
+constexpr int kFold = 32;                   // k tiles per first-level accumulation chain
+
+// grid (d / 64, chunks of 512 tokens), 256 threads: column maxima of the finite |x| as bit patterns
+__global__ __launch_bounds__(256) void xtx2_colmax_kernel(const float* __restrict__ x, int d, long long k0, long long k_end,
+                                                         unsigned* __restrict__ cmax) {
+  __shared__ unsigned part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long kb = k0 + static_cast<long long>(blockIdx.y) * 512;
+  const long long ke = kb + 512 < k_end ? kb + 512 : k_end;
+  const float* col = x + blockIdx.x * 64 + tx;
+  unsigned m = 0u;
+  for (long long k = kb + ty; k < ke; k += 4) {
+    const unsigned b = __float_as_uint(col[k * d]) & 0x7FFFFFFFu;
+    if (b < 0x7F800000u && b > m) m = b;
+  }
+  part[ty][tx] = m;
+  __syncthreads();
+  if (ty == 0) {
+    m = max(max(part[0][tx], part[1][tx]), max(part[2][tx], part[3][tx]));
+    if (m) atomicMax(cmax + blockIdx.x * 64 + tx, m);
+  }
+}
+
+// the power of two that brings a column whose largest finite |x| has these bits into [2^14, 2^15)
+__device__ __forceinline__ int column_exponent(unsigned max_bits) {
+  const int biased = static_cast<int>(max_bits >> 23);
+  return max_bits == 0u ? 0 : 14 - ((biased ? biased : 1) - 127);
+}
+
+// grid (d / 64, pairs of k tiles), 256 threads; tokens [k0, k_end) of x, zero beyond
+__global__ __launch_bounds__(256) void xtx2_split_kernel(const float* __restrict__ x, int d, long long k0, long long k_end,
+                                                        int kt_total, const unsigned* __restrict__ cmax,
+                                                        int* __restrict__ exps, unsigned char* __restrict__ planes) {
+  __shared__ float tile[32][65];
+  const int i0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 32; r += 4) {
+    const long long k = k0 + static_cast<long long>(blockIdx.y) * 32 + r;
+    tile[r][tx] = k < k_end ? x[k * d + i0 + tx] : 0.f;
+  }
+  __syncthreads();
+  const int ii = threadIdx.x >> 2, c = threadIdx.x & 3, i = i0 + ii;
+  const int kt = 2 * blockIdx.y + (c >> 1);
+  if (kt >= kt_total) return;
+  const int e = column_exponent(cmax[i]);
+  if (blockIdx.y == 0 && c == 0) exps[i] = e;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = __builtin_ldexpf(tile[8 * c + j][ii], e);   // exact (finite x~ < 2^15)
+  const int cs = (c & 1) ^ ((i >> 3) & 1);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool finite = (__float_as_uint(v[j]) & 0x7F800000u) != 0x7F800000u;
+      const _Float16 h = static_cast<_Float16>(v[j]);                 // round to nearest even
+      w[j >> 1] |= static_cast<unsigned>(__builtin_bit_cast(unsigned short, h)) << (16 * (j & 1));
+      v[j] = finite ? v[j] - static_cast<float>(h) : 0.f;             // exact
+    }
+    unsigned char* dst = planes + ((static_cast<long long>(kt) * 2 + p) * d + i) * kRowB + cs * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+struct Xtx2Args {
+  const unsigned char* planes;   // [k tile][2][d][32 B]
+  const int* exps;               // [d]
+  int d, tiles;                  // tiles = d / 128
+  int kt_total, kt_per_split;    // both even
+  float* c;                      // [d, d] float32 (lower-triangular tiles), or partials [split][d][d]
+  int accumulate;                // c += product (direct mode)
+  int partial;                   // write split z's product to c + z d d
+  int patches;                   // 1: 8 x 8 patches of tiles dealt to XCDs; 0: plain triangular list
+  int probe;                     // timing probes only: 1 = no MFMAs, 2 = no staging
+};
+
+template <int DEPTH>
+__global__ __launch_bounds__(256) void xtx_f16x2_kernel(Xtx2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  int ti, tj;
+  if (a.patches) {
+    const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
+    const int sup = (local / (kSuper * kSuper)) * 8 + xcd, within = local % (kSuper * kSuper);
+    int si = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(sup) + 1.0f) - 1.0f) * 0.5f);
+    while ((si + 1) * (si + 2) / 2 <= sup) ++si;
+    while (si * (si + 1) / 2 > sup) --si;
+    const int sj = sup - si * (si + 1) / 2;
+    ti = si * kSuper + within / kSuper;
+    tj = sj * kSuper + within % kSuper;
+    if (ti >= a.tiles || tj > ti) return;
+  } else {
+    const int b = blockIdx.x;
+    ti = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(b) + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    tj = b - ti * (ti + 1) / 2;
+  }
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 1, wc = wave & 1;                 // this wave's 64 x 64 quadrant
+  const int kt0 = blockIdx.y * a.kt_per_split;
+  const int kt1 = min(a.kt_total, kt0 + a.kt_per_split);
+
+  f32x16 acc[2][2], lo[2][2], top[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = top[i][j][r] = 0.f;
+
+  // fragment addresses: row = quadrant + 32 i + (lane & 31); chunk (lane >> 5) ^ ((row >> 3) & 1)
+  const int frow = lane & 31;
+  const int fch = ((lane >> 5) ^ ((frow >> 3) & 1)) * 16;
+  const int offA = (wr * 64 + frow) * kRowB + fch, offB = kOperandB + (wc * 64 + frow) * kRowB + fch;
+
+  const long long row_stride = static_cast<long long>(a.d) * kRowB;   // one plane of one k tile
+  const unsigned char* gA = a.planes + static_cast<long long>(ti) * kPlaneTileB + lane * 16;
+  const unsigned char* gB = a.planes + static_cast<long long>(tj) * kPlaneTileB + lane * 16;
+
+  // 32 wave-wide 1 KB pieces per pair of k tiles: k tile x operand (A, B) x plane x 4 pieces of 32 rows
+  auto stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int piece = q * 4 + wave;                 // 0 .. 31
+      const int kk = piece >> 4, op = (piece >> 3) & 1, p = (piece >> 2) & 1, seg = piece & 3;
+      const unsigned char* src = (op ? gB : gA) + (static_cast<long long>(kt + kk) * 2 + p) * row_stride + seg * 1024;
+      unsigned char* dst = lds + buf * kStageB + kk * (2 * kOperandB) + op * kOperandB + p * kPlaneTileB + seg * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  // a ring of DEPTH stage buffers: DEPTH - 1 stages are in flight while one is multiplied (an L2 hit under
+  // this load takes longer than the 768 MFMA cycles of one stage; vmcnt counts the 8 loads per stage and wave)
+  const int nst = (kt1 - kt0) / 2;
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s)
+    if ((s < nst || (DEPTH == 3 && (a.probe & 4))) && nst > 0 && !(a.probe & 2) && !(DEPTH == 2 && (a.probe & 8))) stage(min(kt0 + 2 * s, kt1 - 2), s);
+  if (DEPTH == 2 && (a.probe & 8)) {
+    // ---- staging through registers: global_load_dwordx4 a stage ahead, ds_write_b128 behind the MFMAs
+    const unsigned char* lA = gA + wave * 1024;
+    const unsigned char* lB = gB + wave * 1024;
+    uint4 hold[8];
+    auto fetch = [&](int kt) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int kk = q >> 2, op = (q >> 1) & 1, pl = q & 1;
+        hold[q] = *reinterpret_cast<const uint4*>((op ? lB : lA) + (static_cast<long long>(kt + kk) * 2 + pl) * row_stride);
+      }
+    };
+    auto park = [&](int b) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int kk = q >> 2, op = (q >> 1) & 1, pl = q & 1;
+        *reinterpret_cast<uint4*>(lds + b * kStageB + kk * (2 * kOperandB) + op * kOperandB + pl * kPlaneTileB + wave * 1024 + lane * 16) = hold[q];
+      }
+    };
+    if (nst > 0) { fetch(kt0); park(0); }
+    if (nst > 1) fetch(kt0 + 2);
+    for (int s = 0; s < nst; ++s) {
+      __syncthreads();
+      const unsigned char* img0 = lds + (s & 1) * kStageB;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const unsigned char* img = img0 + kk * (2 * kOperandB);
+        f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            fa[i][pl] = *reinterpret_cast<const f16x8*>(img + offA + pl * kPlaneTileB + i * 32 * kRowB);
+            fb[i][pl] = *reinterpret_cast<const f16x8*>(img + offB + pl * kPlaneTileB + i * 32 * kRowB);
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], lo[i][j], 0, 0, 0);
+            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], lo[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+          }
+      }
+      if (s + 1 < nst) park((s + 1) & 1);
+      if (s + 2 < nst) fetch(kt0 + 2 * (s + 2));
+      if ((s & (kFold / 2 - 1)) == kFold / 2 - 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              top[i][j][r] = top[i][j][r] + acc[i][j][r];
+              acc[i][j][r] = 0.f;
+            }
+      }
+    }
+  } else
+  if (DEPTH == 3 && (a.probe & 4)) {
+    // ---- the staging spread over the MFMAs of the stage: one piece behind every third MFMA, so that the
+    // memory pipeline is fed while the matrix cores run (all eight pieces at the top of the stage block the
+    // wave's issue for as long as the L2 is busy: staging and multiplying then take turns, the sum of both).
+    // Past the last stage the loads go on (the last stage again, into a buffer nobody reads): vmcnt(8) always.
+    int bufi = 0, filli = DEPTH - 1;
+    for (int s = 0; s < nst; ++s) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __syncthreads();
+      const int ktn = min(kt0 + 2 * (s + DEPTH - 1), kt1 - 2);
+      const unsigned char* nA = gA + static_cast<long long>(ktn) * 2 * row_stride + wave * 1024;
+      const unsigned char* nB = gB + static_cast<long long>(ktn) * 2 * row_stride + wave * 1024;
+      unsigned char* dstb = lds + filli * kStageB + wave * 1024;
+      auto piece = [&](int q) {      // q -> k tile of the pair, operand, plane; the wave is the 32-row segment
+        const int kk = q >> 2, op = (q >> 1) & 1, pl = q & 1;
+        const unsigned char* src = (op ? nB : nA) + (kk * 2 + pl) * row_stride;
+        unsigned char* dst = dstb + kk * (2 * kOperandB) + op * kOperandB + pl * kPlaneTileB;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      };
+      const unsigned char* img = lds + bufi * kStageB;
+      f16x8 fa[2][2][2], fb[2][2][2];     // [k tile of the pair][32-row block][plane]
+      auto frags = [&](int kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            fa[kk][i][pl] = *reinterpret_cast<const f16x8*>(img + kk * (2 * kOperandB) + offA + pl * kPlaneTileB + i * 32 * kRowB);
+            fb[kk][i][pl] = *reinterpret_cast<const f16x8*>(img + kk * (2 * kOperandB) + offB + pl * kPlaneTileB + i * 32 * kRowB);
+          }
+      };
+      frags(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 24; ++m) {
+        const int kk = m / 12, mm = m % 12, term = mm >> 2, i = (mm >> 1) & 1, j = mm & 1;
+        if (term == 0) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][0], fb[kk][j][1], lo[i][j], 0, 0, 0);
+        else if (term == 1) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][1], fb[kk][j][0], lo[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][0], fb[kk][j][0], acc[i][j], 0, 0, 0);
+        if (m % 3 == 2) {
+          piece(m / 3);
+          if (m == 2) frags(1);      // the second k tile's fragments land behind the first one's MFMAs
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      bufi = bufi + 1 == DEPTH ? 0 : bufi + 1;
+      filli = filli + 1 == DEPTH ? 0 : filli + 1;
+      if ((s & (kFold / 2 - 1)) == kFold / 2 - 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              top[i][j][r] = top[i][j][r] + acc[i][j][r];
+              acc[i][j][r] = 0.f;
+            }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+  int buf = 0, fill = DEPTH - 1;
+  for (int s = 0; s < nst; ++s) {
+    const int behind = nst - 1 - s;          // stages after this one
+    if (DEPTH >= 4 && behind >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (DEPTH >= 3 && behind >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // this stage has landed; every wave is done with the buffer refilled next
+    if (s + DEPTH - 1 < nst && !(a.probe & 2)) stage(kt0 + 2 * (s + DEPTH - 1), fill);
+    fill = fill + 1 == DEPTH ? 0 : fill + 1;
+    if (!(a.probe & 1))
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const unsigned char* img = lds + buf * kStageB + kk * (2 * kOperandB);
+      f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          fa[i][p] = *reinterpret_cast<const f16x8*>(img + offA + p * kPlaneTileB + i * 32 * kRowB);
+          fb[i][p] = *reinterpret_cast<const f16x8*>(img + offB + p * kPlaneTileB + i * 32 * kRowB);
+        }
+#define MI355Q_TERM(ACC, PA, PB)                                                                \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA], fb[j][PB], ACC[i][j], 0, 0, 0)
+      MI355Q_TERM(lo, 0, 1);
+      MI355Q_TERM(lo, 1, 0);
+      MI355Q_TERM(acc, 0, 0);
+#undef MI355Q_TERM
+    }
+    buf = buf + 1 == DEPTH ? 0 : buf + 1;
+    if ((s & (kFold / 2 - 1)) == kFold / 2 - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            top[i][j][r] = top[i][j][r] + acc[i][j][r];
+            acc[i][j][r] = 0.f;
+          }
+    }
+  }
+
+  }
+
+  // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* c = a.c + (a.partial ? static_cast<long long>(blockIdx.y) * a.d * a.d : 0);
+  const int row0 = ti * kTile + wr * 64 + 4 * (lane >> 5), col0 = tj * kTile + wc * 64 + (lane & 31);
+  float* base = c + static_cast<long long>(row0) * a.d + col0;
+  const int ec[2] = {a.exps[col0], a.exps[col0 + 32]};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    // (a later slab adds to the product so far: the 32 loads of a lane go out together, then the stores)
+    float old[2][16];
+    int er[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) er[r] = a.exps[row0 + i * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        old[j][r] = a.accumulate ? base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // (an infinite h1 g1 sum is the product's value: the cross terms of a non-finite operand are
+        // inf * 0 = NaN whenever the other side's residual plane is zero, where x.T.dot(x) has +-inf)
+        const float big = top[i][j][r] + acc[i][j][r];
+        const float s = __builtin_isinf(big) ? big : big + lo[i][j][r];
+        const float v = __builtin_ldexpf(s, -(er[r] + ec[j]));       // back to the columns' own scales
+        base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] = a.accumulate ? old[j][r] + v : v;
+      }
+  }
+}
+
+// The same product with the staging taken off the multiplying waves. An LDS-DMA piece costs the wave that
+// issues it 60-185 cycles of issue time (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"): eight pieces per
+// stage and wave are as long as the stage's 24 MFMAs (768 cycles), and the single-role kernel above sits at
+// 38 % MFMA utilisation with 29 % of its wave cycles parked on vmcnt / the barrier. Here a workgroup is 8 waves:
+// waves 0-3 only multiply (one per SIMD, 64 x 64 quadrants as above), waves 4-7 only stage (one per SIMD beside
+// a multiplying wave; 8 pieces per stage each, a ring of DEPTH stages). One barrier per stage joins them:
+// behind it stage s has landed (the staging waves waited for their own pieces) and stage s - 1 is free again.
+template <int DEPTH>
+__global__ __launch_bounds__(512) void xtx_f16x2_pc_kernel(Xtx2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  int ti, tj;
+  if (a.patches) {
+    const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
+    const int sup = (local / (kSuper * kSuper)) * 8 + xcd, within = local % (kSuper * kSuper);
+    int si = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(sup) + 1.0f) - 1.0f) * 0.5f);
+    while ((si + 1) * (si + 2) / 2 <= sup) ++si;
+    while (si * (si + 1) / 2 > sup) --si;
+    const int sj = sup - si * (si + 1) / 2;
+    ti = si * kSuper + within / kSuper;
+    tj = sj * kSuper + within % kSuper;
+    if (ti >= a.tiles || tj > ti) return;
+  } else {
+    const int b = blockIdx.x;
+    ti = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(b) + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    tj = b - ti * (ti + 1) / 2;
+  }
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6) ^ ((a.probe & 16) ? 4 : 0);   // probe 16: the first four waves stage
+  const int kt0 = blockIdx.y * a.kt_per_split;
+  const int kt1 = min(a.kt_total, kt0 + a.kt_per_split);
+  const int nst = kt1 > kt0 ? (kt1 - kt0) / 2 : 0;
+
+  if (wave >= 4) {
+    // ---- staging waves: 32 wave-wide 1 KB pieces per stage (k tile x operand x plane x 4 pieces of 32 rows)
+    const int pw = wave - 4;
+    if (a.probe & 32) __builtin_amdgcn_s_setprio(3);
+    const long long row_stride = static_cast<long long>(a.d) * kRowB;   // one plane of one k tile
+    const unsigned char* gA = a.planes + static_cast<long long>(ti) * kPlaneTileB + lane * 16;
+    const unsigned char* gB = a.planes + static_cast<long long>(tj) * kPlaneTileB + lane * 16;
+    auto stage = [&](int kt, int buf) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int piece = q * 4 + pw;                 // 0 .. 31
+        const int kk = piece >> 4, op = (piece >> 3) & 1, p = (piece >> 2) & 1, seg = piece & 3;
+        const unsigned char* src = (op ? gB : gA) + (static_cast<long long>(kt + kk) * 2 + p) * row_stride + seg * 1024;
+        unsigned char* dst = lds + buf * kStageB + kk * (2 * kOperandB) + op * kOperandB + p * kPlaneTileB + seg * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s)
+      if (s < nst) stage(kt0 + 2 * s, s);
+    int fill = DEPTH - 1;
+    for (int s = 0; s < nst; ++s) {
+      const int behind = nst - 1 - s;          // stages issued after this one (at most DEPTH - 2 of them are in flight)
+      if (DEPTH >= 4 && behind >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (DEPTH >= 3 && behind >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + DEPTH - 1 < nst) stage(kt0 + 2 * (s + DEPTH - 1), fill);
+      fill = fill + 1 == DEPTH ? 0 : fill + 1;
+    }
+    return;
+  }
+
+  // ---- multiplying waves
+  const int wr = wave >> 1, wc = wave & 1;                 // this wave's 64 x 64 quadrant
+  f32x16 acc[2][2], lo[2][2], top[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = top[i][j][r] = 0.f;
+  const int frow = lane & 31;
+  const int fch = ((lane >> 5) ^ ((frow >> 3) & 1)) * 16;
+  const int offA = (wr * 64 + frow) * kRowB + fch, offB = kOperandB + (wc * 64 + frow) * kRowB + fch;
+  int buf = 0;
+  for (int s = 0; s < nst; ++s) {
+    __syncthreads();          // stage s has landed
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const unsigned char* img = lds + buf * kStageB + kk * (2 * kOperandB);
+      f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          fa[i][p] = *reinterpret_cast<const f16x8*>(img + offA + p * kPlaneTileB + i * 32 * kRowB);
+          fb[i][p] = *reinterpret_cast<const f16x8*>(img + offB + p * kPlaneTileB + i * 32 * kRowB);
+        }
+#define MI355Q_TERM(ACC, PA, PB)                                                                \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA], fb[j][PB], ACC[i][j], 0, 0, 0)
+      MI355Q_TERM(lo, 0, 1);
+      MI355Q_TERM(lo, 1, 0);
+      MI355Q_TERM(acc, 0, 0);
+#undef MI355Q_TERM
+    }
+    buf = buf + 1 == DEPTH ? 0 : buf + 1;
+    if ((s & (kFold / 2 - 1)) == kFold / 2 - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            top[i][j][r] = top[i][j][r] + acc[i][j][r];
+            acc[i][j][r] = 0.f;
+          }
+    }
+  }
+
+  float* c = a.c + (a.partial ? static_cast<long long>(blockIdx.y) * a.d * a.d : 0);
+  const int row0 = ti * kTile + wr * 64 + 4 * (lane >> 5), col0 = tj * kTile + wc * 64 + (lane & 31);
+  float* base = c + static_cast<long long>(row0) * a.d + col0;
+  const int ec[2] = {a.exps[col0], a.exps[col0 + 32]};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float old[16];
+      int er[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        er[r] = a.exps[row0 + i * 32 + (r & 3) + 8 * (r >> 2)];
+        old[r] = a.accumulate ? base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float big = top[i][j][r] + acc[i][j][r];
+        const float sum = __builtin_isinf(big) ? big : big + lo[i][j][r];
+        const float v = __builtin_ldexpf(sum, -(er[r] + ec[j]));
+        base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] = a.accumulate ? old[r] + v : v;
+      }
+    }
+  }
+}
+
+// c (+)= partial[0] + partial[1] + ... (slices added in order) over the lower-triangular tiles
+__global__ __launch_bounds__(256) void xtx2_reduce_kernel(const float* __restrict__ partial, int splits, int d,
+                                                         int accumulate, float* __restrict__ c) {
+  const long long n = static_cast<long long>(d) * d;
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
+    const long long i = e / d, j = e % d;
+    if (j / kTile > i / kTile) continue;
+    float s = partial[e];
+    for (int z = 1; z < splits; ++z) s = s + partial[z * n + e];
+    c[e] = accumulate ? c[e] + s : s;
+  }
+}
+
+// split-K slices for narrow layers (few output tiles): every slice a whole number of PAIRS of k tiles
+int xtx2_splits(int64_t d, int64_t kt) {
+  const int64_t tiles = (d / kTile) * (d / kTile + 1) / 2;
+  if (tiles >= 512) return 1;
+  int64_t s = (768 + tiles - 1) / tiles;
+  if (s > 16) s = 16;
+  if (s > kt / 64) s = kt / 64;        // >= 1024 tokens per split
+  return s < 1 ? 1 : static_cast<int>(s);
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+bool xtx_f16x2_usable(int64_t n, int64_t d) {
+  return d % kTile == 0 && d >= 256 && n >= 1024 && getenv("MI355Q_XTX_FP32_MFMA") == nullptr &&
+         getenv("MI355Q_XTX_BF16X3") == nullptr;
+}
+
+size_t xtx_f16x2_workspace_bytes(int64_t n, int64_t d) {
+  const int64_t ks = n < kSlabTokens ? n : kSlabTokens;
+  const int64_t kt = (ks + 2 * kBK - 1) / (2 * kBK) * 2;
+  const int splits = xtx2_splits(d, kt);
+  return 1024 + align_up(static_cast<size_t>(d) * 8, 1024) + static_cast<size_t>(kt) * 2 * d * kRowB +
+         (splits > 1 ? static_cast<size_t>(splits) * d * d * sizeof(float) : 0);
+}
+
+// p (float32 [d, d], lower-triangular 128 x 128 tiles valid) = X^T X for X float32 [n, d]
+// (accumulate_first: p += X^T X, the product of earlier calls).
+int32_t xtx_f16x2(const float* x, int64_t n, int64_t d, float* p, void* workspace, hipStream_t st, bool accumulate_first) {
+  unsigned char* ws = reinterpret_cast<unsigned char*>(
+      (reinterpret_cast<uintptr_t>(workspace) + 1023) & ~static_cast<uintptr_t>(1023));
+  unsigned* cmax = reinterpret_cast<unsigned*>(ws);
+  int* exps = reinterpret_cast<int*>(ws) + d;
+  unsigned char* planes = ws + align_up(static_cast<size_t>(d) * 8, 1024);
+  const int tiles = static_cast<int>(d / kTile);
+  const int64_t ks_max = n < kSlabTokens ? n : kSlabTokens;
+  const int64_t kt_max = (ks_max + 2 * kBK - 1) / (2 * kBK) * 2;
+  float* partial = reinterpret_cast<float*>(planes + static_cast<size_t>(kt_max) * 2 * d * kRowB);
+  for (int64_t k0 = 0; k0 < n; k0 += kSlabTokens) {
+    const int64_t ks = n - k0 < kSlabTokens ? n - k0 : kSlabTokens;
+    const int kt = static_cast<int>((ks + 2 * kBK - 1) / (2 * kBK) * 2);       // an even number: the kernel works on pairs
+    if (hipError_t e = hipMemsetAsync(cmax, 0, static_cast<size_t>(d) * sizeof(unsigned), st))
+      return fail(MI355Q_HIP_ERROR, "xtx column maxima memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(xtx2_colmax_kernel, dim3(static_cast<unsigned>(d / 64), static_cast<unsigned>((ks + 511) / 512)), dim3(256), 0, st,
+                       x, static_cast<int>(d), static_cast<long long>(k0), static_cast<long long>(k0 + ks), cmax);
+    hipLaunchKernelGGL(xtx2_split_kernel, dim3(static_cast<unsigned>(d / 64), static_cast<unsigned>(kt / 2)), dim3(256), 0, st,
+                       x, static_cast<int>(d), static_cast<long long>(k0), static_cast<long long>(k0 + ks), kt, cmax, exps, planes);
+    const int splits = xtx2_splits(d, kt);
+    Xtx2Args a{};
+    a.planes = planes; a.exps = exps; a.d = static_cast<int>(d); a.tiles = tiles; a.kt_total = kt;
+    a.kt_per_split = ((kt / 2 + splits - 1) / splits) * 2;
+    a.partial = splits > 1 ? 1 : 0;
+    a.c = splits > 1 ? partial : p;
+    a.accumulate = (splits == 1 && (k0 > 0 || accumulate_first)) ? 1 : 0;
+    a.patches = tiles >= 4 * kSuper ? 1 : 0;
+    { const char* e = getenv("MI355Q_XTX_PROBE"); a.probe = e ? atoi(e) : 0; }
+    unsigned gx;
+    if (a.patches) {
+      const int sside = (tiles + kSuper - 1) / kSuper, nsup = sside * (sside + 1) / 2;
+      gx = static_cast<unsigned>((nsup + 7) / 8 * 8 * kSuper * kSuper);
+    } else {
+      gx = static_cast<unsigned>(tiles * (tiles + 1) / 2);
+    }
+    static const int depth = [] { const char* e = getenv("MI355Q_XTX_DEPTH"); const int v = e ? atoi(e) : 2; return v < 2 ? 2 : v > 4 ? 4 : v; }();
+    static const bool two_roles = getenv("MI355Q_XTX_TWO_ROLES") != nullptr;
+    auto launch = [&](auto kernel, int stages, int threads) -> hipError_t {
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, stages * kStageB))
+        return e;
+      hipLaunchKernelGGL(kernel, dim3(gx, static_cast<unsigned>(splits)), dim3(threads), static_cast<size_t>(stages) * kStageB, st, a);
+      return hipSuccess;
+    };
+    hipError_t le;
+    if (two_roles) le = depth <= 3 ? launch(xtx_f16x2_pc_kernel<3>, 3, 512) : launch(xtx_f16x2_pc_kernel<4>, 4, 512);
+    else le = depth == 2 ? launch(xtx_f16x2_kernel<2>, 2, 256) : depth == 3 ? launch(xtx_f16x2_kernel<3>, 3, 256) : launch(xtx_f16x2_kernel<4>, 4, 256);
+    if (le != hipSuccess) return fail(MI355Q_HIP_ERROR, "xtx f16x2 LDS attribute: %s", hipGetErrorString(le));
+    if (splits > 1)
+      hipLaunchKernelGGL(xtx2_reduce_kernel, dim3(2048), dim3(256), 0, st, partial, splits, static_cast<int>(d),
+                         (k0 > 0 || accumulate_first) ? 1 : 0, p);
+  }
+  MI355Q_CHECK_LAUNCH("xtx f16x2 launch");
+  return MI355Q_OK;
+}
+
+}  // namespace mi355q
