@@ -27,10 +27,17 @@
 //           xtx_bf16x3.hip describes (4 KB per 128-row operand tile, plane and k tile; 16-byte chunks
 //           swapped where (i >> 3) & 1), and the exponents e_i
 //   xtx     lower-triangular grid of 128 x 128 output tiles in 8 x 8 patches per XCD; per PAIR of k
-//           tiles (32 tokens) both planes of both operand tiles (32 KB, a ring of three) go to LDS
+//           tiles (32 tokens) both planes of both operand tiles (32 KB, double-buffered) go to LDS
 //           by global_load_lds and every wave issues 24 MFMAs on its 64 x 64 quadrant from 16
 //           fragment reads. h1 g1 has accumulators of its own, folded into a third set every 32 k
 //           tiles as in the three-way kernel.
+// What bounds it (profiles/r03_xtx_f16x2.txt): the staging alone (32 KB per stage and workgroup, 20 TB/s out of
+// the L2s chip-wide) and the MFMAs alone (1.9 PFLOP/s) each take about half of the kernel's time, and
+// their times ADD whatever the arrangement -- a deeper ring, the pieces spread between the MFMAs, staging
+// waves of their own beside the multiplying ones, two workgroups per CU -- with the matrix cores at
+// 38 % and no wave waiting for data: the sum of both energies at the socket's power limit. Fewer MFMAs (this
+// split) and fewer staged bytes per MFMA (a larger tile: 256 x 128 is what three accumulator sets leave
+// room for, a quarter less) are what is left.
 // An infinite activation gives +-inf where x.T.dot(x) does (the h1 g1 sum decides; the NaN of an
 // inf * 0 cross term is dropped); the damped Cholesky refuses it.
 #include "common.h"
@@ -123,7 +130,7 @@ struct Xtx2Args {
   int accumulate;                // c += product (direct mode)
   int partial;                   // write split z's product to c + z d d
   int patches;                   // 1: 8 x 8 patches of tiles dealt to XCDs; 0: plain triangular list
-  int probe;                     // timing probes only: 1 = no MFMAs, 2 = no staging
+  int probe;                     // MI355Q_XTX_PROBE, timing probes only (wrong results): 1 no MFMAs and fragment reads, 2 no staging, 64 no fragment reads
 };
 
 template <int DEPTH>
@@ -181,132 +188,12 @@ __global__ __launch_bounds__(256) void xtx_f16x2_kernel(Xtx2Args a) {
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
-  // a ring of DEPTH stage buffers: DEPTH - 1 stages are in flight while one is multiplied (an L2 hit under
-  // this load takes longer than the 768 MFMA cycles of one stage; vmcnt counts the 8 loads per stage and wave)
+  // a ring of DEPTH stage buffers: DEPTH - 1 stages are in flight while one is multiplied (vmcnt counts the
+  // 8 loads per stage and wave)
   const int nst = (kt1 - kt0) / 2;
 #pragma unroll
   for (int s = 0; s < DEPTH - 1; ++s)
-    if ((s < nst || (DEPTH == 3 && (a.probe & 4))) && nst > 0 && !(a.probe & 2) && !(DEPTH == 2 && (a.probe & 8))) stage(min(kt0 + 2 * s, kt1 - 2), s);
-  if (DEPTH == 2 && (a.probe & 8)) {
-    // ---- staging through registers: global_load_dwordx4 a stage ahead, ds_write_b128 behind the MFMAs
-    const unsigned char* lA = gA + wave * 1024;
-    const unsigned char* lB = gB + wave * 1024;
-    uint4 hold[8];
-    auto fetch = [&](int kt) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int kk = q >> 2, op = (q >> 1) & 1, pl = q & 1;
-        hold[q] = *reinterpret_cast<const uint4*>((op ? lB : lA) + (static_cast<long long>(kt + kk) * 2 + pl) * row_stride);
-      }
-    };
-    auto park = [&](int b) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int kk = q >> 2, op = (q >> 1) & 1, pl = q & 1;
-        *reinterpret_cast<uint4*>(lds + b * kStageB + kk * (2 * kOperandB) + op * kOperandB + pl * kPlaneTileB + wave * 1024 + lane * 16) = hold[q];
-      }
-    };
-    if (nst > 0) { fetch(kt0); park(0); }
-    if (nst > 1) fetch(kt0 + 2);
-    for (int s = 0; s < nst; ++s) {
-      __syncthreads();
-      const unsigned char* img0 = lds + (s & 1) * kStageB;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const unsigned char* img = img0 + kk * (2 * kOperandB);
-        f16x8 fa[2][2], fb[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
-            fa[i][pl] = *reinterpret_cast<const f16x8*>(img + offA + pl * kPlaneTileB + i * 32 * kRowB);
-            fb[i][pl] = *reinterpret_cast<const f16x8*>(img + offB + pl * kPlaneTileB + i * 32 * kRowB);
-          }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], lo[i][j], 0, 0, 0);
-            lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], lo[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-          }
-      }
-      if (s + 1 < nst) park((s + 1) & 1);
-      if (s + 2 < nst) fetch(kt0 + 2 * (s + 2));
-      if ((s & (kFold / 2 - 1)) == kFold / 2 - 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              top[i][j][r] = top[i][j][r] + acc[i][j][r];
-              acc[i][j][r] = 0.f;
-            }
-      }
-    }
-  } else
-  if (DEPTH == 3 && (a.probe & 4)) {
-    // ---- the staging spread over the MFMAs of the stage: one piece behind every third MFMA, so that the
-    // memory pipeline is fed while the matrix cores run (all eight pieces at the top of the stage block the
-    // wave's issue for as long as the L2 is busy: staging and multiplying then take turns, the sum of both).
-    // Past the last stage the loads go on (the last stage again, into a buffer nobody reads): vmcnt(8) always.
-    int bufi = 0, filli = DEPTH - 1;
-    for (int s = 0; s < nst; ++s) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      __syncthreads();
-      const int ktn = min(kt0 + 2 * (s + DEPTH - 1), kt1 - 2);
-      const unsigned char* nA = gA + static_cast<long long>(ktn) * 2 * row_stride + wave * 1024;
-      const unsigned char* nB = gB + static_cast<long long>(ktn) * 2 * row_stride + wave * 1024;
-      unsigned char* dstb = lds + filli * kStageB + wave * 1024;
-      auto piece = [&](int q) {      // q -> k tile of the pair, operand, plane; the wave is the 32-row segment
-        const int kk = q >> 2, op = (q >> 1) & 1, pl = q & 1;
-        const unsigned char* src = (op ? nB : nA) + (kk * 2 + pl) * row_stride;
-        unsigned char* dst = dstb + kk * (2 * kOperandB) + op * kOperandB + pl * kPlaneTileB;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      };
-      const unsigned char* img = lds + bufi * kStageB;
-      f16x8 fa[2][2][2], fb[2][2][2];     // [k tile of the pair][32-row block][plane]
-      auto frags = [&](int kk) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
-            fa[kk][i][pl] = *reinterpret_cast<const f16x8*>(img + kk * (2 * kOperandB) + offA + pl * kPlaneTileB + i * 32 * kRowB);
-            fb[kk][i][pl] = *reinterpret_cast<const f16x8*>(img + kk * (2 * kOperandB) + offB + pl * kPlaneTileB + i * 32 * kRowB);
-          }
-      };
-      frags(0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < 24; ++m) {
-        const int kk = m / 12, mm = m % 12, term = mm >> 2, i = (mm >> 1) & 1, j = mm & 1;
-        if (term == 0) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][0], fb[kk][j][1], lo[i][j], 0, 0, 0);
-        else if (term == 1) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][1], fb[kk][j][0], lo[i][j], 0, 0, 0);
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][0], fb[kk][j][0], acc[i][j], 0, 0, 0);
-        if (m % 3 == 2) {
-          piece(m / 3);
-          if (m == 2) frags(1);      // the second k tile's fragments land behind the first one's MFMAs
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      bufi = bufi + 1 == DEPTH ? 0 : bufi + 1;
-      filli = filli + 1 == DEPTH ? 0 : filli + 1;
-      if ((s & (kFold / 2 - 1)) == kFold / 2 - 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              top[i][j][r] = top[i][j][r] + acc[i][j][r];
-              acc[i][j][r] = 0.f;
-            }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
+    if (s < nst && !(a.probe & 2)) stage(kt0 + 2 * s, s);
   int buf = 0, fill = DEPTH - 1;
   for (int s = 0; s < nst; ++s) {
     const int behind = nst - 1 - s;          // stages after this one
@@ -321,6 +208,15 @@ __global__ __launch_bounds__(256) void xtx_f16x2_kernel(Xtx2Args a) {
     for (int kk = 0; kk < 2; ++kk) {
       const unsigned char* img = lds + buf * kStageB + kk * (2 * kOperandB);
       f16x8 fa[2][2], fb[2][2];
+      if (a.probe & 64) {          // probe: no fragment reads (whatever the registers hold)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            asm volatile("" : "=v"(fa[i][p]));
+            asm volatile("" : "=v"(fb[i][p]));
+          }
+      } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -328,6 +224,7 @@ __global__ __launch_bounds__(256) void xtx_f16x2_kernel(Xtx2Args a) {
           fa[i][p] = *reinterpret_cast<const f16x8*>(img + offA + p * kPlaneTileB + i * 32 * kRowB);
           fb[i][p] = *reinterpret_cast<const f16x8*>(img + offB + p * kPlaneTileB + i * 32 * kRowB);
         }
+      }
 #define MI355Q_TERM(ACC, PA, PB)                                                                \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
       ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA], fb[j][PB], ACC[i][j], 0, 0, 0)
@@ -348,8 +245,6 @@ __global__ __launch_bounds__(256) void xtx_f16x2_kernel(Xtx2Args a) {
             acc[i][j][r] = 0.f;
           }
     }
-  }
-
   }
 
   // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -380,148 +275,6 @@ __global__ __launch_bounds__(256) void xtx_f16x2_kernel(Xtx2Args a) {
         const float v = __builtin_ldexpf(s, -(er[r] + ec[j]));       // back to the columns' own scales
         base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] = a.accumulate ? old[j][r] + v : v;
       }
-  }
-}
-
-// The same product with the staging taken off the multiplying waves. An LDS-DMA piece costs the wave that
-// issues it 60-185 cycles of issue time (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"): eight pieces per
-// stage and wave are as long as the stage's 24 MFMAs (768 cycles), and the single-role kernel above sits at
-// 38 % MFMA utilisation with 29 % of its wave cycles parked on vmcnt / the barrier. Here a workgroup is 8 waves:
-// waves 0-3 only multiply (one per SIMD, 64 x 64 quadrants as above), waves 4-7 only stage (one per SIMD beside
-// a multiplying wave; 8 pieces per stage each, a ring of DEPTH stages). One barrier per stage joins them:
-// behind it stage s has landed (the staging waves waited for their own pieces) and stage s - 1 is free again.
-template <int DEPTH>
-__global__ __launch_bounds__(512) void xtx_f16x2_pc_kernel(Xtx2Args a) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-  int ti, tj;
-  if (a.patches) {
-    const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
-    const int sup = (local / (kSuper * kSuper)) * 8 + xcd, within = local % (kSuper * kSuper);
-    int si = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(sup) + 1.0f) - 1.0f) * 0.5f);
-    while ((si + 1) * (si + 2) / 2 <= sup) ++si;
-    while (si * (si + 1) / 2 > sup) --si;
-    const int sj = sup - si * (si + 1) / 2;
-    ti = si * kSuper + within / kSuper;
-    tj = sj * kSuper + within % kSuper;
-    if (ti >= a.tiles || tj > ti) return;
-  } else {
-    const int b = blockIdx.x;
-    ti = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(b) + 1.0f) - 1.0f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-    while (ti * (ti + 1) / 2 > b) --ti;
-    tj = b - ti * (ti + 1) / 2;
-  }
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6) ^ ((a.probe & 16) ? 4 : 0);   // probe 16: the first four waves stage
-  const int kt0 = blockIdx.y * a.kt_per_split;
-  const int kt1 = min(a.kt_total, kt0 + a.kt_per_split);
-  const int nst = kt1 > kt0 ? (kt1 - kt0) / 2 : 0;
-
-  if (wave >= 4) {
-    // ---- staging waves: 32 wave-wide 1 KB pieces per stage (k tile x operand x plane x 4 pieces of 32 rows)
-    const int pw = wave - 4;
-    if (a.probe & 32) __builtin_amdgcn_s_setprio(3);
-    const long long row_stride = static_cast<long long>(a.d) * kRowB;   // one plane of one k tile
-    const unsigned char* gA = a.planes + static_cast<long long>(ti) * kPlaneTileB + lane * 16;
-    const unsigned char* gB = a.planes + static_cast<long long>(tj) * kPlaneTileB + lane * 16;
-    auto stage = [&](int kt, int buf) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int piece = q * 4 + pw;                 // 0 .. 31
-        const int kk = piece >> 4, op = (piece >> 3) & 1, p = (piece >> 2) & 1, seg = piece & 3;
-        const unsigned char* src = (op ? gB : gA) + (static_cast<long long>(kt + kk) * 2 + p) * row_stride + seg * 1024;
-        unsigned char* dst = lds + buf * kStageB + kk * (2 * kOperandB) + op * kOperandB + p * kPlaneTileB + seg * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      }
-    };
-#pragma unroll
-    for (int s = 0; s < DEPTH - 1; ++s)
-      if (s < nst) stage(kt0 + 2 * s, s);
-    int fill = DEPTH - 1;
-    for (int s = 0; s < nst; ++s) {
-      const int behind = nst - 1 - s;          // stages issued after this one (at most DEPTH - 2 of them are in flight)
-      if (DEPTH >= 4 && behind >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (DEPTH >= 3 && behind >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (s + DEPTH - 1 < nst) stage(kt0 + 2 * (s + DEPTH - 1), fill);
-      fill = fill + 1 == DEPTH ? 0 : fill + 1;
-    }
-    return;
-  }
-
-  // ---- multiplying waves
-  const int wr = wave >> 1, wc = wave & 1;                 // this wave's 64 x 64 quadrant
-  f32x16 acc[2][2], lo[2][2], top[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = top[i][j][r] = 0.f;
-  const int frow = lane & 31;
-  const int fch = ((lane >> 5) ^ ((frow >> 3) & 1)) * 16;
-  const int offA = (wr * 64 + frow) * kRowB + fch, offB = kOperandB + (wc * 64 + frow) * kRowB + fch;
-  int buf = 0;
-  for (int s = 0; s < nst; ++s) {
-    __syncthreads();          // stage s has landed
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const unsigned char* img = lds + buf * kStageB + kk * (2 * kOperandB);
-      f16x8 fa[2][2], fb[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          fa[i][p] = *reinterpret_cast<const f16x8*>(img + offA + p * kPlaneTileB + i * 32 * kRowB);
-          fb[i][p] = *reinterpret_cast<const f16x8*>(img + offB + p * kPlaneTileB + i * 32 * kRowB);
-        }
-#define MI355Q_TERM(ACC, PA, PB)                                                                \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
-      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA], fb[j][PB], ACC[i][j], 0, 0, 0)
-      MI355Q_TERM(lo, 0, 1);
-      MI355Q_TERM(lo, 1, 0);
-      MI355Q_TERM(acc, 0, 0);
-#undef MI355Q_TERM
-    }
-    buf = buf + 1 == DEPTH ? 0 : buf + 1;
-    if ((s & (kFold / 2 - 1)) == kFold / 2 - 1) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            top[i][j][r] = top[i][j][r] + acc[i][j][r];
-            acc[i][j][r] = 0.f;
-          }
-    }
-  }
-
-  float* c = a.c + (a.partial ? static_cast<long long>(blockIdx.y) * a.d * a.d : 0);
-  const int row0 = ti * kTile + wr * 64 + 4 * (lane >> 5), col0 = tj * kTile + wc * 64 + (lane & 31);
-  float* base = c + static_cast<long long>(row0) * a.d + col0;
-  const int ec[2] = {a.exps[col0], a.exps[col0 + 32]};
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float old[16];
-      int er[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        er[r] = a.exps[row0 + i * 32 + (r & 3) + 8 * (r >> 2)];
-        old[r] = a.accumulate ? base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float big = top[i][j][r] + acc[i][j][r];
-        const float sum = __builtin_isinf(big) ? big : big + lo[i][j][r];
-        const float v = __builtin_ldexpf(sum, -(er[r] + ec[j]));
-        base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] = a.accumulate ? old[r] + v : v;
-      }
-    }
   }
 }
 
@@ -603,17 +356,15 @@ int32_t xtx_f16x2(const float* x, int64_t n, int64_t d, float* p, void* workspac
     } else {
       gx = static_cast<unsigned>(tiles * (tiles + 1) / 2);
     }
+    // (a ring of 3 or 4 stages is no faster than 2: the kernel is not waiting for loads, see profiles/r03_xtx_f16x2.txt)
     static const int depth = [] { const char* e = getenv("MI355Q_XTX_DEPTH"); const int v = e ? atoi(e) : 2; return v < 2 ? 2 : v > 4 ? 4 : v; }();
-    static const bool two_roles = getenv("MI355Q_XTX_TWO_ROLES") != nullptr;
-    auto launch = [&](auto kernel, int stages, int threads) -> hipError_t {
+    auto launch = [&](auto kernel, int stages) -> hipError_t {
       if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, stages * kStageB))
         return e;
-      hipLaunchKernelGGL(kernel, dim3(gx, static_cast<unsigned>(splits)), dim3(threads), static_cast<size_t>(stages) * kStageB, st, a);
+      hipLaunchKernelGGL(kernel, dim3(gx, static_cast<unsigned>(splits)), dim3(256), static_cast<size_t>(stages) * kStageB, st, a);
       return hipSuccess;
     };
-    hipError_t le;
-    if (two_roles) le = depth <= 3 ? launch(xtx_f16x2_pc_kernel<3>, 3, 512) : launch(xtx_f16x2_pc_kernel<4>, 4, 512);
-    else le = depth == 2 ? launch(xtx_f16x2_kernel<2>, 2, 256) : depth == 3 ? launch(xtx_f16x2_kernel<3>, 3, 256) : launch(xtx_f16x2_kernel<4>, 4, 256);
+    const hipError_t le = depth == 2 ? launch(xtx_f16x2_kernel<2>, 2) : depth == 3 ? launch(xtx_f16x2_kernel<3>, 3) : launch(xtx_f16x2_kernel<4>, 4);
     if (le != hipSuccess) return fail(MI355Q_HIP_ERROR, "xtx f16x2 LDS attribute: %s", hipGetErrorString(le));
     if (splits > 1)
       hipLaunchKernelGGL(xtx2_reduce_kernel, dim3(2048), dim3(256), 0, st, partial, splits, static_cast<int>(d),

@@ -11,6 +11,7 @@ shapes = list(zip(args[0::2], args[1::2])) or [(2048, 65536), (16384, 16384), (1
 for d, n in shapes:
   gen = torch.Generator(device="cuda").manual_seed(d + n)
   x = torch.randn((n, d), generator=gen, device="cuda") * torch.exp2(torch.randint(-6, 6, (1, d), generator=gen, device="cuda").float()) + 0.1
+  if os.environ.get("XTX_BENCH_ZERO"): x.zero_()   # (power probe: no data toggling in the matrix cores)
   strip = slice(d // 2, d // 2 + 128)
   ref = x.double().T @ x[:, strip].double()
   mag = x.double().abs().T @ x[:, strip].double().abs()
