@@ -1202,10 +1202,12 @@ SideStream* side_stream() {
 }  // namespace
 
 namespace { void release_hinv_pools(); }
+namespace mi355q { void release_file_io(); }   // file_io.hip
 
 extern "C" int32_t mi355q_shutdown(void) {
   clear_error();
   release_hinv_pools();
+  release_file_io();
   std::lock_guard<std::mutex> lock(g_side_mutex);
   for (SideStream& s : g_side) {
     if (s.stream) {

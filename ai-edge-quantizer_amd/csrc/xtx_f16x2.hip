@@ -133,8 +133,10 @@ struct Xtx2Args {
   int probe;                     // MI355Q_XTX_PROBE, timing probes only (wrong results): 1 no MFMAs and fragment reads, 2 no staging, 64 no fragment reads
 };
 
+// (two workgroups per CU -- at most 256 registers per lane, 64 KB of LDS each: the 64 workgroups of an XCD's
+// 8 x 8 patch are then resident together and every operand panel of the patch comes into that L2 once)
 template <int DEPTH>
-__global__ __launch_bounds__(256) void xtx_f16x2_kernel(Xtx2Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 ? 2 : 1, DEPTH == 2 ? 2 : 1))) void xtx_f16x2_kernel(Xtx2Args a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   int ti, tj;
   if (a.patches) {

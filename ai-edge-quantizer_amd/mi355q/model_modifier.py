@@ -13,11 +13,13 @@ multiply op insertion is outside this build's scope and raises NotImplementedErr
 from __future__ import annotations
 
 import mmap
+import os
 from typing import Any, Optional
 
 import numpy as np
 
 from . import qtyping
+from . import runtime
 from . import transformation_instruction_generator
 from . import transformation_performer
 from .utils import tfl_flatbuffer_utils
@@ -111,20 +113,34 @@ def serialize_model(model: Any, serialize_to_path: Optional[tfl_flatbuffer_utils
     return out
 
   caller_sink = sink
+  opened: list = []
 
   def sink(total: int):
     if caller_sink is not None:
       return caller_sink(total)
     if not serialize_to_path:
       return None
-    with open(serialize_to_path, "w+b") as f:
-      f.truncate(total)
-      return mmap.mmap(f.fileno(), total)
+    # (no O_TRUNC: dropping an old file's pages from the page cache costs as much as writing them --
+    # 13 ms for 186 MB -- and the new bytes overwrite them anyway; the length is set below)
+    fd = os.open(serialize_to_path, os.O_RDWR | os.O_CREAT, 0o644)
+    if os.fstat(fd).st_size != total:
+      os.ftruncate(fd, total)
+    mapping = mmap.mmap(fd, total)
+    runtime.register_output_mapping(mapping, fd)      # device-resident buffers: pinned staging + pwrite()
+    opened.append((mapping, fd))
+    return mapping
 
   # (no msync: a shared mapping is coherent with the page cache, so readers see the bytes at once,
   # and they reach the disk when the kernel writes them back -- what a plain write() gives too;
   # the synchronous flush cost 19 ms of a 147 ms file -> file run)
-  return tflite_flatbuffer.serialize_with_external_buffers(model, _MIN_EXTERNAL_BUFFER_BYTES, sink)
+  try:
+    return tflite_flatbuffer.serialize_with_external_buffers(model, _MIN_EXTERNAL_BUFFER_BYTES, sink)
+  finally:
+    if opened:
+      runtime.finish_downloads()
+    for mapping, fd in opened:
+      runtime.forget_output_mapping(mapping)
+      os.close(fd)
 
 
 class ModelModifier:

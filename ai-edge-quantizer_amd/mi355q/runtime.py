@@ -44,6 +44,9 @@ def to_device(a, dtype=None) -> torch.Tensor:
       t = t.to(dtype)
     return t.to(device(), non_blocking=True).contiguous()
   arr = np.ascontiguousarray(a)
+  if _FILE_MAPPINGS and arr.nbytes >= _UPLOAD_MIN_TENSOR_BYTES and _file_range_of(arr) is not None:
+    t = upload_overlapped(arr)        # a weight inside a large mapped model file: read + copied by the io ring
+    return t if dtype is None or t.dtype == dtype else t.to(dtype)
   with warnings.catch_warnings():
     warnings.simplefilter("ignore")  # non-writable buffer warning for mmap views
     t = torch.from_numpy(arr)
@@ -52,14 +55,15 @@ def to_device(a, dtype=None) -> torch.Tensor:
   return t.to(device(), non_blocking=True)
 
 
-# ---- uploads that do not wait for the compute queue ---------------------------------------------
-_UPLOAD_SLOT_BYTES = 32 << 20     # (page-locking memory costs ~1 ms per MiB here: two small slots, kept for the process)
-_UPLOAD_MIN_FILE_BYTES = 2 << 30  # ... and only for models large enough to earn the 70 ms back
-_UPLOAD_READERS = 8
-_UPLOAD: dict = {}         # device index -> {"stream", "slots": [(pinned, event)], "next"}
+# ---- uploads that do not wait for the compute queue, downloads that do not fault the output in ------
+# (the transfers themselves are csrc/file_io.hip: pread / pwrite on the library's io threads through a ring of
+# three pinned 8 MiB slots -- page-locking costs ~1 ms per MiB here, once per process)
+_UPLOAD_MIN_FILE_BYTES = 1 << 30  # only models large enough to earn the ring's 24 ms back
+_UPLOAD_MIN_TENSOR_BYTES = 4 << 20
+_COPY_STREAMS: dict = {}   # device index -> the copy stream of the io ring
 _FILE_MAPPINGS: list = []  # (base address, length, path) of model files mapped by tfl_flatbuffer_utils
+_OUT_MAPPINGS: list = []   # (base address, length, file descriptor) of output files being built
 _FILE_FDS: dict = {}
-_READ_POOL: list = []
 
 
 def register_file_mapping(mapping, path) -> None:
@@ -73,12 +77,36 @@ def register_file_mapping(mapping, path) -> None:
   _FILE_MAPPINGS.append((base, len(mapping), str(path)))
 
 
+def register_output_mapping(mapping, fd: int) -> None:
+  """The writable mapping of an output file and its descriptor: device-resident buffers then reach
+  the file by pwrite() from pinned staging (HbmArray.copy_into) instead of a pageable copy that
+  faults every fresh page of the mapping in on one thread."""
+  base = np.frombuffer(mapping, dtype=np.uint8).ctypes.data
+  _OUT_MAPPINGS[:] = [m for m in _OUT_MAPPINGS if m[0] != base][-3:]
+  _OUT_MAPPINGS.append((base, len(mapping), fd))
+
+
+def forget_output_mapping(mapping) -> None:
+  try:
+    base = np.frombuffer(mapping, dtype=np.uint8).ctypes.data
+  except (ValueError, TypeError):
+    return
+  _OUT_MAPPINGS[:] = [m for m in _OUT_MAPPINGS if m[0] != base]
+
+
 def _file_range_of(arr: np.ndarray):
   addr = arr.ctypes.data
   for base, length, path in reversed(_FILE_MAPPINGS):
     if base <= addr and addr + arr.nbytes <= base + length:
       return (path, addr - base) if length >= _UPLOAD_MIN_FILE_BYTES else None
   return None
+
+
+def _copy_stream(dev) -> "torch.cuda.Stream":
+  st = _COPY_STREAMS.get(dev.index)
+  if st is None:
+    st = _COPY_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+  return st
 
 
 def upload_overlapped(a: np.ndarray) -> torch.Tensor:
@@ -88,57 +116,32 @@ def upload_overlapped(a: np.ndarray) -> torch.Tensor:
   to_device's pageable copy is ordered behind everything queued on the current stream and blocks
   the calling thread until it ran: under GPTQ, where every FULLY_CONNECTED queues tens of
   milliseconds of inverse and update, the op walk then advances in lock step with the GPU and the
-  model's 8 GB of weights cross PCIe while nothing computes. Here the bytes are read from the
-  FILE (pread() on a few reader threads: a kernel copy out of the page cache, no page-table
-  population of the mapping; 43 GB/s against 18 for the mapped pageable copy on a 6 GB file,
-  tools/h2d_big_probe.py) into one of two pinned 32 MiB slots and travel on a copy stream of their own;
+  model's 8 GB of weights cross PCIe while nothing computes; and it moves 24 GB/s (one staging
+  thread inside the runtime). Here the bytes are read from the
+  FILE (mi355q_file_to_device: pread() on the library's io threads -- a kernel copy out of the page
+  cache, no page-table population of the mapping -- into a ring of pinned slots) and travel on a
+  copy stream of their own;
   the current stream waits for them only where it first uses the tensor. The tensor is allocated
   on the copy stream (the block it lands in cannot still be read by compute queued earlier) and
-  recorded on the current one. Arrays that are not views of a registered mapping of at least 2 GiB take to_device."""
-  import concurrent.futures
+  recorded on the current one. Arrays that are not views of a registered mapping of at least 1 GiB
+  take the pageable copy."""
   import os
   where = _file_range_of(a) if isinstance(a, np.ndarray) and a.flags.c_contiguous else None
   if where is None:
-    return to_device(a)
+    with warnings.catch_warnings():
+      warnings.simplefilter("ignore")  # non-writable buffer warning for mmap views
+      return torch.from_numpy(np.ascontiguousarray(a)).to(device(), non_blocking=True)
   path, offset = where
   fd = _FILE_FDS.get(path)
   if fd is None:
     fd = _FILE_FDS[path] = os.open(path, os.O_RDONLY)
-  if not _READ_POOL:
-    _READ_POOL.append(concurrent.futures.ThreadPoolExecutor(max_workers=_UPLOAD_READERS, thread_name_prefix="mi355q-read"))
-  pool = _READ_POOL[0]
   dev = device()
-  st = _UPLOAD.get(dev.index)
-  if st is None:
-    st = _UPLOAD[dev.index] = {"stream": torch.cuda.Stream(device=dev), "slots": [], "next": 0}
-  copy_stream = st["stream"]
+  copy_stream = _copy_stream(dev)
   n = a.nbytes
   with torch.cuda.stream(copy_stream):
     out = torch.empty((n,), dtype=torch.uint8, device=dev)
-
-  def read(view, at):
-    got = 0
-    while got < len(view):
-      k = os.preadv(fd, [view[got:]], at + got)
-      if k <= 0:
-        raise OSError(f"short read from {path}")
-      got += k
-  for off in range(0, n, _UPLOAD_SLOT_BYTES):
-    size = min(_UPLOAD_SLOT_BYTES, n - off)
-    k = st["next"] % 2
-    st["next"] += 1
-    if len(st["slots"]) <= k:
-      st["slots"].append((torch.empty((_UPLOAD_SLOT_BYTES,), dtype=torch.uint8).pin_memory(), torch.cuda.Event()))
-    pinned, event = st["slots"][k]
-    event.synchronize()                        # the slot's previous transfer has left it
-    view = memoryview(pinned.numpy())
-    part = max(4 << 20, -(-size // _UPLOAD_READERS) + 4095 & ~4095)
-    jobs = [pool.submit(read, view[p:min(size, p + part)], offset + off + p) for p in range(0, size, part)]
-    for j in jobs:
-      j.result()
-    with torch.cuda.stream(copy_stream):
-      out[off:off + size].copy_(pinned[:size], non_blocking=True)
-      event.record(copy_stream)
+  _ffi.check(_ffi.lib().mi355q_file_to_device(fd, offset, n, ctypes.c_void_p(out.data_ptr()),
+                                              ctypes.c_void_p(copy_stream.cuda_stream)))
   done = torch.cuda.Event()
   done.record(copy_stream)
   cur = torch.cuda.current_stream()
@@ -148,11 +151,36 @@ def upload_overlapped(a: np.ndarray) -> torch.Tensor:
   return out.view(t).reshape(a.shape)
 
 
+def download_into_file(t: torch.Tensor, dst: np.ndarray) -> bool:
+  """Device bytes -> the output file whose mapping `dst` is a view of (register_output_mapping):
+  mi355q_device_to_file copies into the pinned ring on the copy stream and pwrite()s from there on
+  the io threads. False when `dst` is not inside a registered output mapping (finish_downloads()
+  before the file is handed back)."""
+  addr = dst.ctypes.data
+  hit = next(((base, fd) for base, length, fd in reversed(_OUT_MAPPINGS) if base <= addr and addr + dst.nbytes <= base + length), None)
+  if hit is None or not t.is_cuda or dst.nbytes < (1 << 20):
+    return False
+  base, fd = hit
+  src = t.contiguous().reshape(-1).view(torch.uint8)
+  copy_stream = _copy_stream(src.device)
+  copy_stream.wait_stream(torch.cuda.current_stream())     # the kernels that produce t
+  _ffi.check(_ffi.lib().mi355q_device_to_file(ctypes.c_void_p(src.data_ptr()), src.numel(), fd, addr - base,
+                                              ctypes.c_void_p(copy_stream.cuda_stream)))
+  src.record_stream(copy_stream)
+  return True
+
+
+def finish_downloads() -> None:
+  """Waits for the pwrite()s of download_into_file (before the output file is handed back)."""
+  if _COPY_STREAMS:
+    _ffi.check(_ffi.lib().mi355q_file_io_finish())
+
+
 def release_upload_files() -> None:
   """Closes the model files opened for pread (after the transfers that read them have left)."""
   import os
-  for st in _UPLOAD.values():
-    st["stream"].synchronize()
+  for st in _COPY_STREAMS.values():
+    st.synchronize()
   for fd in _FILE_FDS.values():
     try:
       os.close(fd)
@@ -162,20 +190,10 @@ def release_upload_files() -> None:
 
 
 def release_upload_staging() -> None:
-  """Gives the pinned staging slots (64 MB of page-locked host memory per device), the reader
-  threads and the file descriptors back."""
-  import os
-  for st in _UPLOAD.values():
-    st["stream"].synchronize()
-  _UPLOAD.clear()
-  for fd in _FILE_FDS.values():
-    try:
-      os.close(fd)
-    except OSError:
-      pass
-  _FILE_FDS.clear()
-  while _READ_POOL:
-    _READ_POOL.pop().shutdown(wait=True)
+  """Closes the files; the pinned ring (24 MB of page-locked host memory per device) and the io
+  threads go with mi355q_shutdown()."""
+  release_upload_files()
+  _COPY_STREAMS.clear()
 
 
 _NP_DTYPE: dict = {}     # torch dtype -> NumPy dtype
@@ -207,6 +225,8 @@ class HbmArray:
     """D2H straight into `dst` (a writable uint8 view of, e.g., the output file's mapping)."""
     if self._host is not None:
       dst[:] = np.ravel(self._host).view(np.uint8)
+      return
+    if download_into_file(self.device_tensor, dst):
       return
     with warnings.catch_warnings():
       warnings.simplefilter("ignore")

@@ -628,6 +628,7 @@ def serialize_with_external_buffers(model, min_size_bytes: int = 1024,
     if out is None:
       out = bytearray(start + packed)
     out[:total_fb] = fb
+    out[total_fb:start] = bytes(start - total_fb)     # (the sink may hand out an older file's pages: every gap is written)
     cursor = start
     for i, view in ext.items():
       buf = model.buffers[i]
@@ -639,6 +640,7 @@ def serialize_with_external_buffers(model, min_size_bytes: int = 1024,
         view.copy_into(np.frombuffer(out, dtype=np.uint8, count=n, offset=cursor))
       else:
         out[cursor:cursor + n] = view
+      out[cursor + n:min(_round_up_16(cursor + n), len(out))] = bytes(min(_round_up_16(cursor + n), len(out)) - cursor - n)
       cursor = _round_up_16(cursor + n)
   finally:
     for i, (d, o, s) in saved.items():

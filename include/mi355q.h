@@ -40,7 +40,8 @@ typedef enum mi355q_status {
   MI355Q_BAD_SHAPE = -2,   /* e.g. cols not divisible by block size */
   MI355Q_UNSUPPORTED = -3, /* valid request this build has no kernel for */
   MI355Q_HIP_ERROR = -4,   /* launch / runtime failure; see mi355q_last_error() */
-  MI355Q_RCCL_ERROR = -5   /* RCCL missing or a collective / communicator call failed */
+  MI355Q_RCCL_ERROR = -5,  /* RCCL missing or a collective / communicator call failed */
+  MI355Q_IO_ERROR = -6     /* pread / pwrite on a model file failed or came up short */
 } mi355q_status;
 
 int32_t mi355q_version(void);
@@ -471,6 +472,23 @@ int32_t mi355q_allreduce_hessian_f64(void* comm, double* hessian, int64_t d, dou
 size_t mi355q_hessian_exchange_workspace_bytes(int64_t d);
 int32_t mi355q_reduce_hessian_f64(void* comm, double* hessian, int64_t d, double weight, int32_t root,
                                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Model file <-> HBM without a host copy of the weights (the file path's io ring).
+ *   ref: utils/tfl_flatbuffer_utils.py:142-163  the model file is mapped / read whole into host memory;
+ *        model_modifier.py:290-391              the serializers copy every quantized buffer into one host
+ *                                               bytearray and write it out
+ * mi355q_file_to_device: bytes [file_offset, file_offset + nbytes) of the open file `fd` -> `dst` (device):
+ * pread() on the library's io threads into a ring of three pinned 8 MiB slots (made on first use, per
+ * device), hipMemcpyAsync on `copy_stream` (the caller orders its compute stream behind it). Returns when the
+ * last copy is ENQUEUED and every read is done. mi355q_device_to_file: `src` (device; the caller has ordered
+ * `copy_stream` behind its producer) -> the file at file_offset: asynchronous copies into the ring, pwrite()
+ * from there on the io threads; returns with the last writes possibly in flight -- mi355q_file_io_finish()
+ * waits for them and reports the first write error. A short read (end of file) or a failing pread / pwrite is
+ * MI355Q_IO_ERROR. One transfer enqueues at a time per process; mi355q_shutdown() releases ring and threads. */
+int32_t mi355q_file_to_device(int32_t fd, int64_t file_offset, int64_t nbytes, void* dst, void* copy_stream);
+int32_t mi355q_device_to_file(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset, void* copy_stream);
+int32_t mi355q_file_io_finish(void);
 
 #ifdef __cplusplus
 } /* extern "C" */

@@ -1,0 +1,127 @@
+"""The file path's io ring (csrc/file_io.hip; ref utils/tfl_flatbuffer_utils.py:142-163, model_modifier.py:290-391):
+model bytes must reach HBM and quantized bytes must reach the output file unchanged, through the C ABI directly and
+through Quantizer.quantize with the ring forced on for a small model."""
+import ctypes
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def m():
+  import torch
+  assert torch.cuda.is_available()
+  import __graft_entry__ as g
+  g.build()
+  import types
+  from mi355q import _ffi, quantizer, recipe, runtime
+  return types.SimpleNamespace(torch=torch, ffi=_ffi, rt=runtime, quantizer=quantizer, recipe=recipe)
+
+
+@pytest.mark.parametrize("nbytes,offset", [(1, 0), (4097, 3), (8 << 20, 0), ((8 << 20) + 1, 1824), (45_000_001, 77), (0, 5)])
+def test_file_to_device_and_back(m, tmp_path, nbytes, offset):
+  """Ranges shorter than a part, exactly one slot, one byte over a slot, several slots with a ragged tail, at
+  unaligned file offsets: the device holds the file's bytes, and the file written back from the device (into the
+  middle of a larger file) holds them again with its other bytes untouched."""
+  torch, L = m.torch, m.ffi.lib()
+  rng = np.random.default_rng(nbytes + offset)
+  blob = rng.integers(0, 256, offset + nbytes + 11, dtype=np.uint8)
+  src = str(tmp_path / "in.bin")
+  blob.tofile(src)
+  stream = torch.cuda.Stream()
+  dev = torch.zeros(max(nbytes, 1), dtype=torch.uint8, device="cuda")
+  torch.cuda.synchronize()           # (the fill runs on the default stream, the copies on `stream`)
+  fd = os.open(src, os.O_RDONLY)
+  try:
+    m.ffi.check(L.mi355q_file_to_device(fd, offset, nbytes, ctypes.c_void_p(dev.data_ptr()), ctypes.c_void_p(stream.cuda_stream)))
+  finally:
+    os.close(fd)
+  stream.synchronize()
+  assert np.array_equal(dev.cpu().numpy()[:nbytes], blob[offset:offset + nbytes])
+  dst = str(tmp_path / "out.bin")
+  frame = rng.integers(0, 256, nbytes + 200, dtype=np.uint8)
+  frame.tofile(dst)
+  fd = os.open(dst, os.O_RDWR)
+  try:
+    m.ffi.check(L.mi355q_device_to_file(ctypes.c_void_p(dev.data_ptr()), nbytes, fd, 100, ctypes.c_void_p(stream.cuda_stream)))
+    m.ffi.check(L.mi355q_file_io_finish())
+  finally:
+    os.close(fd)
+  back = np.fromfile(dst, dtype=np.uint8)
+  assert np.array_equal(back[100:100 + nbytes], blob[offset:offset + nbytes])
+  assert np.array_equal(back[:100], frame[:100]) and np.array_equal(back[100 + nbytes:], frame[100 + nbytes:])
+
+
+def test_short_file_and_bad_descriptor_are_io_errors(m, tmp_path):
+  """A range that runs past the end of the file, and a descriptor that is not open: MI355Q_IO_ERROR with a
+  message, nothing hangs, and the ring works again afterwards."""
+  torch, L = m.torch, m.ffi.lib()
+  src = str(tmp_path / "short.bin")
+  np.arange(5000, dtype=np.uint8).tofile(src)
+  stream = torch.cuda.Stream()
+  dev = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+  torch.cuda.synchronize()
+  fd = os.open(src, os.O_RDONLY)
+  try:
+    st = L.mi355q_file_to_device(fd, 0, 1 << 20, ctypes.c_void_p(dev.data_ptr()), ctypes.c_void_p(stream.cuda_stream))
+    assert st == -6 and b"end of file" in L.mi355q_last_error()
+    st = L.mi355q_file_to_device(fd, 0, 5000, ctypes.c_void_p(dev.data_ptr()), ctypes.c_void_p(stream.cuda_stream))
+    assert st == 0
+  finally:
+    os.close(fd)
+  stream.synchronize()
+  assert np.array_equal(dev.cpu().numpy()[:5000], np.arange(5000, dtype=np.uint8))
+  st = L.mi355q_file_to_device(fd, 0, 4096, ctypes.c_void_p(dev.data_ptr()), ctypes.c_void_p(stream.cuda_stream))   # closed above
+  assert st == -6 and L.mi355q_last_error()
+  st = L.mi355q_device_to_file(ctypes.c_void_p(dev.data_ptr()), 4096, fd, 0, ctypes.c_void_p(stream.cuda_stream))
+  assert st == 0 and L.mi355q_file_io_finish() == -6 and L.mi355q_last_error()
+  assert L.mi355q_file_io_finish() == 0
+
+
+def _sha(path):
+  h = hashlib.sha256()
+  with open(path, "rb") as f:
+    for chunk in iter(lambda: f.read(1 << 24), b""):
+      h.update(chunk)
+  return h.hexdigest()
+
+
+def test_quantizer_through_the_ring_writes_the_same_file(m, tmp_path, monkeypatch):
+  """The ring is for model files of a GiB and more; with the thresholds taken down a 4-layer model goes through
+  it (uploads by pread, output by pwrite) and the file must equal the pageable path's byte for byte -- also when
+  it replaces an older, longer file of the same name (no O_TRUNC: the length is set explicitly)."""
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  import file_bench
+  src = str(tmp_path / "small.tflite")
+  file_bench.build_model(src, 4, 1024, 2048 + 128)
+  rcp = m.recipe.dynamic_wi4b128_afp32()
+  plain = str(tmp_path / "plain.tflite")
+  m.quantizer.Quantizer(src, rcp).quantize(serialize_to_path=plain)
+  calls = {"up": 0, "down": 0}
+  up, down = m.rt.upload_overlapped, m.rt.download_into_file
+  monkeypatch.setattr(m.rt, "_UPLOAD_MIN_FILE_BYTES", 1)
+  monkeypatch.setattr(m.rt, "_UPLOAD_MIN_TENSOR_BYTES", 1)
+
+  def counted_up(a):
+    calls["up"] += 1
+    return up(a)
+
+  def counted_down(t, d):
+    took = down(t, d)
+    calls["down"] += int(took)
+    return took
+  monkeypatch.setattr(m.rt, "upload_overlapped", counted_up)
+  monkeypatch.setattr(m.rt, "download_into_file", counted_down)
+  ring = str(tmp_path / "ring.tflite")
+  with open(ring, "wb") as f:
+    f.write(b"\xff" * (os.path.getsize(plain) + 12345))       # an older, longer file in the way
+  m.quantizer.Quantizer(src, rcp).quantize(serialize_to_path=ring)
+  assert calls["up"] >= 4 and calls["down"] >= 3, calls   # (a buffer somebody already read on the host is copied from there)
+  assert os.path.getsize(ring) == os.path.getsize(plain)
+  assert _sha(ring) == _sha(plain)
