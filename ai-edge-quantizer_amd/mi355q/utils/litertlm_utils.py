@@ -19,6 +19,7 @@ import pathlib
 import struct
 from typing import Any, Mapping, Optional, Union
 
+from .. import runtime
 from . import tfl_flatbuffer_utils
 from . import tflite_flatbuffer as fb
 
@@ -159,14 +160,31 @@ class LiteRTLMFile:
     if not self._sections:
       raise ValueError("LiteRT-LM file has no sections")
     header, offsets, lengths, total = self._layout({section_id: section_bytes})
-    with open(path, "w+b") as f:
-      f.truncate(total)
-      out = mmap.mmap(f.fileno(), total)
+    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+    os.ftruncate(fd, total)
+    out = mmap.mmap(fd, total)
+    # device-resident buffers of the model reach the file through the io ring (pinned staging + pwrite());
+    # the caller finishes the writes and closes `fd` (close_built_in_place)
+    runtime.register_output_mapping(out, fd)
+    self._built_in_place = (out, fd)
     out[:len(header)] = header
     for sid in range(len(self._sections)):
       if sid != section_id:
         out[offsets[sid]:offsets[sid] + lengths[sid]] = memoryview(self.get_section_buffer(sid)).cast("B")
     return out, memoryview(out)[offsets[section_id]:offsets[section_id] + section_bytes], total
+
+  def close_built_in_place(self) -> None:
+    """Waits for the io ring's writes into the file open_with_section made and closes its descriptor."""
+    opened = getattr(self, "_built_in_place", None)
+    if opened is None:
+      return
+    self._built_in_place = None
+    mapping, fd = opened
+    try:
+      runtime.finish_downloads()
+    finally:
+      runtime.forget_output_mapping(mapping)
+      os.close(fd)
 
   def serialize(self, path: Path, section_data_overrides: Mapping[int, Any]) -> int:
     """Writes the file again with some sections replaced; returns the number of bytes written.
@@ -271,29 +289,32 @@ def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path, overw
     raise ValueError("No models were quantized, not creating output file.")
   replaced: dict[int, Any] = {}
   built_in_place: dict = {}
-  for sid, model_type, model_recipe in todo:
-    sink = None
-    if len(todo) == 1:
-      # the only section that changes: once its size is known the container is laid out and the
-      # model is serialized straight into its place in the output file
-      def sink(total, sid=sid):
-        t0 = time.perf_counter()
-        mapping, place, size = src.open_with_section(output_path, sid, total)
-        built_in_place.update(mapping=mapping, size=size)
-        if stats is not None:
-          stats["repack_s"] = stats.get("repack_s", 0.0) + (time.perf_counter() - t0)
-        return place
-    data = _pick(calibration_data, sid, model_type)
-    if data is not None:
-      result = distributed.calibrate_and_quantize_sharded(
-          src.get_section_buffer(sid), model_recipe, data, group=group, tensor_provider=tensor_provider, stats=stats,
-          sink=sink)
-    else:
-      result = distributed.quantize_model_sharded(
-          src.get_section_buffer(sid), model_recipe,
-          calibration_result=_pick(calibration_results, sid, model_type), group=group, sink=sink)
-    if result is not None:
-      replaced[sid] = result
+  try:
+    for sid, model_type, model_recipe in todo:
+      sink = None
+      if len(todo) == 1:
+        # the only section that changes: once its size is known the container is laid out and the
+        # model is serialized straight into its place in the output file
+        def sink(total, sid=sid):
+          t0 = time.perf_counter()
+          mapping, place, size = src.open_with_section(output_path, sid, total)
+          built_in_place.update(mapping=mapping, size=size)
+          if stats is not None:
+            stats["repack_s"] = stats.get("repack_s", 0.0) + (time.perf_counter() - t0)
+          return place
+      data = _pick(calibration_data, sid, model_type)
+      if data is not None:
+        result = distributed.calibrate_and_quantize_sharded(
+            src.get_section_buffer(sid), model_recipe, data, group=group, tensor_provider=tensor_provider, stats=stats,
+            sink=sink)
+      else:
+        result = distributed.quantize_model_sharded(
+            src.get_section_buffer(sid), model_recipe,
+            calibration_result=_pick(calibration_results, sid, model_type), group=group, sink=sink)
+      if result is not None:
+        replaced[sid] = result
+  finally:
+    src.close_built_in_place()     # (the io ring's writes into the output file are done, its descriptor is closed)
   if built_in_place:
     # (no msync: a shared mapping is coherent with the page cache, readers see the bytes at once)
     return built_in_place["size"]

@@ -229,10 +229,11 @@ def more_extras(torch, ops, gen, xs) -> dict:
     # the triangular product computes half of 2 n d^2; the inverse is d^3 (Cholesky + triangular inverse + product)
     c5[f"d{d}"] = {
         "hessian": {"ms": round(ms_h, 3), "tokens": tokens,
-                    "roofline": {"bound": "mfma", "achieved": round(6 * tokens * d * d / ms_h / 1e9, 1), "peak": MFMA_BF16_PEAK_TF,
-                                 "unit": "TFLOP/s", "frac": round(6 * tokens * d * d / ms_h / 1e9 / MFMA_BF16_PEAK_TF, 4),
-                                 "flops": "6 n d^2: lower triangle of X^T X, every float32 product as six bf16 MFMA products"
-                                          " (exact three-way split of both operands, xtx_bf16x3.hip)",
+                    "roofline": {"bound": "mfma", "achieved": round(3 * tokens * d * d / ms_h / 1e9, 1), "peak": MFMA_BF16_PEAK_TF,
+                                 "unit": "TFLOP/s", "frac": round(3 * tokens * d * d / ms_h / 1e9 / MFMA_BF16_PEAK_TF, 4),
+                                 "flops": "3 n d^2: lower triangle of X^T X, every float32 product as three f16 MFMA products"
+                                          " (two-way float16 split of both operands, xtx_f16x2.hip; the f16 and bf16 dense peaks are"
+                                          " the same); the kernel runs at the socket's power limit, profiles/r03_xtx_f16x2.txt",
                                  "float32_product_TFLOPs": round(tokens * d * d / ms_h / 1e9, 1),
                                  "mfma_f32_peak": MFMA_F32_PEAK_TF}},
         "hinv": {"ms": round(ms_i, 3),
