@@ -1204,6 +1204,18 @@ SideStream* side_stream() {
 namespace { void release_hinv_pools(); }
 namespace mi355q { void release_file_io(); }   // file_io.hip
 
+namespace { void prepare_hinv_pool(); }
+
+extern "C" int32_t mi355q_prepare_device(void) {
+  clear_error();
+  {
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    (void)side_stream();        // (look-ahead switched off or no device: nothing to prepare)
+  }
+  prepare_hinv_pool();          // ... and the lanes of the batched inverse, for the same reason
+  return MI355Q_OK;
+}
+
 extern "C" int32_t mi355q_shutdown(void) {
   clear_error();
   release_hinv_pools();
@@ -1501,6 +1513,11 @@ int hinv_lanes_for(int32_t count, int64_t d) { return d >= 4096 || count < 2 ? 1
 }  // namespace
 
 namespace {
+void prepare_hinv_pool() {
+  std::lock_guard<std::mutex> lock(g_hinv_pool_mutex);
+  (void)hinv_pool();
+}
+
 void release_hinv_pools() {
   std::lock_guard<std::mutex> lock(g_hinv_pool_mutex);
   for (HinvPool& p : g_hinv_pool) {

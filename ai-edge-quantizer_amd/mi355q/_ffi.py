@@ -94,6 +94,7 @@ PROTOTYPES = {
     "mi355q_file_to_device": (c_i32, [c_i32, c_i64, c_i64, c_ptr, c_ptr]),
     "mi355q_device_to_file": (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr]),
     "mi355q_file_io_finish": (c_i32, []),
+    "mi355q_prepare_device": (c_i32, []),
 }
 
 STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "BAD_SHAPE", -3: "UNSUPPORTED", -4: "HIP_ERROR",

@@ -255,6 +255,9 @@ def _check_info(info) -> None:
     raise np.linalg.LinAlgError("Matrix is not positive definite")
 
 
+_READERS_LEFT = "gptq readers left in this plan"
+
+
 def _device_hessian_inverse(hessian, damp_factor: float = 0.01):
   """(hinv float32 [d,d], info) on the device. A Hessian that lives in HBM remembers its
   inverse: q / k / v (and gate / up) share one input activation, hence one Hessian."""
@@ -279,17 +282,26 @@ def prefetch_hessian_inverses(plan_items, model_qsvs, damp_factor: float = 0.01)
   from ...utils import tfl_flatbuffer_utils
   todo: dict[int, list] = {}
   seen: set[int] = set()
+  readers: dict[int, list] = {}
   for graph_info, op, _, op_key, alg, _ in plan_items:
     if str(getattr(alg, "value", alg)) != ALGORITHM_KEY or op_key is None or not len(op.inputs):
       continue
     name = tfl_flatbuffer_utils.get_tensor_name(graph_info.subgraph_tensors[op.inputs[0]])
     qsv = model_qsvs.get(name) if model_qsvs else None
     h = qsv.get("hessian") if isinstance(qsv, dict) else None
-    if not isinstance(h, rt.HbmArray) or id(h) in seen or ("hinv", float(damp_factor)) in h.cache:
+    if not isinstance(h, rt.HbmArray):
+      continue
+    readers.setdefault(id(h), [h, 0])[1] += 1
+    if id(h) in seen or ("hinv", float(damp_factor)) in h.cache:
       continue
     seen.add(id(h))
     if h.shape[0] < 4096:          # larger ones fill the chip on their own (and need 4 GiB of scratch each)
       todo.setdefault(h.shape[0], []).append(h)
+  # how many ops of this plan read each Hessian: the apply queue gives an inverse back to the allocator when its
+  # last reader's apply is out (a d = 16384 inverse is 1 GiB, and a fresh GiB of HBM costs ~30 ms of hipMalloc:
+  # kept until the end of the model, every layer's inverse was a new allocation)
+  for h, n in readers.values():
+    h.cache[_READERS_LEFT] = n
   count = 0
   for hs in todo.values():
     if len(hs) < 2:
@@ -390,6 +402,7 @@ class _ApplyQueue:
     self._key = None
     self._entries: list = []
     self._hinv = None
+    self._hessian = None
     self._infos: list = []
     self._scales: list = []          # (placeholder, params) of per-row scales to hand over as ndarrays
     self.stats = host_queue.stats
@@ -406,8 +419,12 @@ class _ApplyQueue:
     if key != self._key:
       self.flush()
       self._key = key
+      self._hessian = hessian
       self._hinv, info = _device_hessian_inverse(hessian, 0.01)
       self._infos.append(info)
+    left = hessian.cache.get(_READERS_LEFT) if isinstance(hessian, rt.HbmArray) else None
+    if left is not None:
+      hessian.cache[_READERS_LEFT] = left - 1
     scale = _Pending(((rows, d // block_size) if block_size else (rows, 1)), np.dtype(np.float32), self)
     scale.device_tensor = scale_dev.reshape(scale.shape)
     if bits in (2, 4):
@@ -435,6 +452,13 @@ class _ApplyQueue:
     mode = 2 if bs else 1
     q_all = ops.gptq_apply(w, self._hinv, s, None, mode, bs, bits, bits >= 8, False, 8)
     self.stats["gptq_applies"] += 1
+    h = self._hessian
+    if isinstance(h, rt.HbmArray) and h.cache.get(_READERS_LEFT) == 0:
+      # the last op of the plan that reads this Hessian: its inverse goes back to the allocator
+      # (stream-ordered: the apply just enqueued still reads it, whoever gets the block next runs behind it)
+      h.cache.pop(("hinv", 0.01), None)
+      h.cache.pop(_READERS_LEFT, None)
+      self._hinv = self._key = None
     packed_all = ops.pack_bits(q_all, bits) if bits in (2, 4) else None
     row0 = 0
     d = w.shape[1]
@@ -454,7 +478,7 @@ class _ApplyQueue:
     """Block exit: last applies out, one copy for all per-row scales, one look at the infos."""
     import torch
     self.flush()
-    self._key = self._hinv = None
+    self._key = self._hinv = self._hessian = None
     if self._scales:
       flat = torch.cat([s.device_tensor.reshape(-1) for s, _ in self._scales]).cpu().numpy()
       pos = 0

@@ -14,12 +14,20 @@ import torch
 from . import _ffi
 
 
+_PREPARED: set = set()
+
+
 def require_gpu() -> None:
   if not torch.cuda.is_available():
     raise RuntimeError(
         "mi355q needs an AMD GPU (torch.cuda.is_available() is False); the product"
         " path has no CPU fallback.")
-  _ffi.lib()
+  dev = torch.cuda.current_device()
+  if dev not in _PREPARED:
+    # the library's look-ahead stream gets its hardware queue before this process creates stream pools
+    # (mi355q_prepare_device in include/mi355q.h: 56 against 76 ms for a d = 16384 Hessian inverse)
+    _ffi.check(_ffi.lib().mi355q_prepare_device())
+    _PREPARED.add(dev)
 
 
 def device() -> torch.device:

@@ -314,6 +314,14 @@ size_t mi355q_gptq_hinv_workspace_bytes(int64_t d);
 /* Releases the per-device side stream + events the blocked Cholesky creates on first use for
  * its look-ahead (the only state the library keeps between calls). Safe to call at any time. */
 int32_t mi355q_shutdown(void);
+/* Creates the current device's look-ahead stream NOW instead of on the first inverse of order >= 4096.
+ * The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, least used
+ * first: created after an application's stream pools (PyTorch makes 64 streams at its first
+ * torch.cuda.Stream()), the look-ahead stream can land on the caller's own hardware queue, where its
+ * trailing updates run IN TURN with the panel chain instead of beside it -- 76 instead of 56 ms for a
+ * d = 16384 inverse (tools/hinv_after_c5_probe.py; GPU_MAX_HW_QUEUES=16 has the same effect). The host
+ * side calls this before its first kernel on a device. Safe to call any number of times. */
+int32_t mi355q_prepare_device(void);
 int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d, double damp_factor, float* hinv_out,
                              int32_t* info_out, void* workspace, size_t workspace_bytes,
                              void* stream);

@@ -188,6 +188,22 @@ class GpuPhases:
       out[family] = out.get(family, 0.0) + e0.elapsed_time(e1)
     return {k: round(v / 1e3, 4) for k, v in sorted(out.items())}
 
+  def gaps(self, least_ms=5.0):
+    """Idle stretches of the compute stream between the timed calls: (start ms, length ms, family before, family
+    after), longest first, and the total. Start is measured from the first timed call."""
+    self.torch.cuda.synchronize()
+    if not self.events:
+      return []
+    t0 = self.events[0][1]
+    spans = sorted((t0.elapsed_time(e0), t0.elapsed_time(e1), f) for f, e0, e1 in self.events)
+    out, end, last = [], spans[0][1], spans[0][2]
+    for a, b, f in spans[1:]:
+      if a - end >= least_ms:
+        out.append((round(end, 1), round(a - end, 1), last, f))
+      if b > end:
+        end, last = b, f
+    return {"idle_ms_total": round(sum(g[1] for g in out), 1), "longest": sorted(out, key=lambda g: -g[1])[:12]}
+
   def calls(self, family):
     """Milliseconds of every call of one family, in call order."""
     self.torch.cuda.synchronize()
@@ -299,6 +315,9 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
       gpu_busy_s_rank0=busy, gpu_busy_total_s=None if busy is None else round(sum(busy.values()), 3),
       gpu_busy_frac=None if busy is None else round(sum(busy.values()) / (t2 - t0), 3),
       trace=trace or None,
+      hbm=dict(device_allocations=torch.cuda.memory_stats().get("num_device_alloc"), peak_reserved_GiB=round(torch.cuda.max_memory_reserved() / 2**30, 1),
+               peak_allocated_GiB=round(torch.cuda.max_memory_allocated() / 2**30, 1)),
+      idle_gaps=(timer.gaps() if timer and os.environ.get("MI355Q_C5_GAPS") else None),
       plan=dict(modelled_s_per_rank=[round(v, 4) for v in loads],
                 makespan_over_mean=round(max(loads) / (sum(loads) / world), 3) if sum(loads) else None))
   if os.path.exists(dst) and not keep:
