@@ -324,9 +324,11 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
         " can be obtained by running calibration on sample dataset.")
   qsvs = calibration_result if calibration_result is not None else {}
   gen.prefetch([it for it, o in zip(plan, owner) if o == rank], qsvs)
-  with requant_queue.batching():       # this rank's equally shaped weights leave in one launch per group
-    mine = {i: gen.materialize_op(it, qsvs) for i, (it, o) in enumerate(zip(plan, owner)) if o == rank}
-  gen.release_derived(qsvs)
+  try:
+    with requant_queue.batching():       # this rank's equally shaped weights leave in one launch per group
+      mine = {i: gen.materialize_op(it, qsvs) for i, (it, o) in enumerate(zip(plan, owner)) if o == rank}
+  finally:
+    gen.release_derived(qsvs)
   if world > 1:
     mine = _gather_results(mine, group)
     if mine is None:

@@ -210,10 +210,12 @@ class ParamsGenerator:
     # before the shared-constant checks of finish() compare parameters by value.
     plan = self.plan_ops(model_recipe_manager)
     self.prefetch(plan, model_qsvs)
-    with requant_queue.batching() as queue:
-      per_op = [self.materialize_op(item, model_qsvs) for item in plan]
+    try:
+      with requant_queue.batching() as queue:
+        per_op = [self.materialize_op(item, model_qsvs) for item in plan]
+    finally:
+      self.release_derived(model_qsvs)
     self.batch_stats = dict(queue.stats)
-    self.release_derived(model_qsvs)
     return self.finish(per_op)
 
   @staticmethod

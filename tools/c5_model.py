@@ -202,7 +202,15 @@ class GpuPhases:
         out.append((round(end, 1), round(a - end, 1), last, f))
       if b > end:
         end, last = b, f
-    return {"idle_ms_total": round(sum(g[1] for g in out), 1), "longest": sorted(out, key=lambda g: -g[1])[:12]}
+    small = 0.0
+    end = spans[0][1]
+    for a, b, f in spans[1:]:
+      if 0 < a - end < least_ms:
+        small += a - end
+      end = max(end, b)
+    return {"span_ms": round(end - spans[0][0], 1), "busy_ms": round(sum(b - a for a, b, _ in spans), 1),
+            "idle_ms_in_gaps_of_5ms_and_more": round(sum(g[1] for g in out), 1), "idle_ms_in_shorter_gaps": round(small, 1),
+            "longest": sorted(out, key=lambda g: -g[1])[:8]}
 
   def calls(self, family):
     """Milliseconds of every call of one family, in call order."""
