@@ -13,6 +13,7 @@ from __future__ import annotations
 import contextlib
 import copy
 import json
+import os
 from typing import Any, Callable, Iterable, Mapping, Optional
 
 import numpy as np
@@ -110,16 +111,22 @@ class Calibrator:
     return {"contents": contents, "stage": self._stage_sample(signature_key, contents, model_recipe_manager)}
 
   def _finish_step(self, signature_key: Optional[str], prepared: dict,
-                   model_recipe_manager: recipe_manager.RecipeManager) -> None:
-    """Second half: the statistics are on the host now; the ops are walked."""
+                   model_recipe_manager: recipe_manager.RecipeManager, lazy: bool = False) -> None:
+    """Second half: the ops are walked. The sample's (min, max) are on the host by now -- or,
+    with `lazy` (record_steps: nothing reads a recorded statistic before wait_for_statistics()),
+    are views of the pinned buffer their copy is still on its way into (NaN until it lands)."""
     self._tensor_content_map.update(prepared["contents"])
     stage = prepared["stage"]
     if stage is not None:
       arrays, dev, pinned, event, lo, hi = stage
-      event.synchronize()
-      mm = pinned.numpy().astype(np.float32, copy=True)
+      if lazy:
+        mm = pinned.numpy()
+        self._last_stage_event = event
+      else:
+        event.synchronize()
+        mm = pinned.numpy().astype(np.float32, copy=True)
       rt.stage_calibration_step({
-          id(a): {"host": a, "dev": d, "lo": lo, "hi": hi, "minmax": (mm[i, 0], mm[i, 1])}
+          id(a): {"host": a, "dev": d, "lo": lo, "hi": hi, "minmax": (mm[i, 0:1], mm[i, 1:2])}
           for i, (a, d) in enumerate(zip(arrays, dev))})
     from .algorithms.uniform_quantize import gptq
     readers = (self._plan(signature_key, model_recipe_manager)["hessian_readers"]
@@ -247,6 +254,7 @@ class Calibrator:
            else rt.to_device(np.ascontiguousarray(a).reshape(-1)) for a in arrays]
     mm = ops.act_minmax(dev, lo, hi)
     pinned = torch.empty(tuple(mm.shape), dtype=mm.dtype, pin_memory=True)
+    pinned.fill_(float("nan"))         # (a statistic read before its copy has landed must not look like one)
     pinned.copy_(mm, non_blocking=True)
     event = torch.cuda.Event()
     event.record()
@@ -288,10 +296,18 @@ class Calibrator:
     for prepared in self._steps_one_ahead(signature_key, dataset, model_recipe_manager):
       self._recording = []
       try:
-        self._finish_step(signature_key, prepared, model_recipe_manager)
+        self._finish_step(signature_key, prepared, model_recipe_manager, lazy=os.environ.get("MI355Q_CALIBRATION_LAZY", "1") != "0")
         yield self._recording
       finally:
         self._recording = None
+
+  def wait_for_statistics(self) -> None:
+    """The (min, max) of every step recorded by record_steps are on the host (their events may be
+    read, pickled or replayed after this)."""
+    event = getattr(self, "_last_stage_event", None)
+    if event is not None:
+      event.synchronize()
+      self._last_stage_event = None
 
   def record_step(self, signature_key: Optional[str], data: Any,
                   model_recipe_manager: recipe_manager.RecipeManager) -> list[tuple]:

@@ -455,6 +455,7 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
       shard = sample_shard(len(samples), rank, world)
       for k, events in zip(shard, local.record_steps(signature_key, (samples[j] for j in shard), rm)):
         mine.append((sig_idx, k, _set_hessians_aside(events, running)))
+  local.wait_for_statistics()       # (record_steps hands the samples' min / max over while their copies are in flight)
   if world > 1:
     parts = [None] * world
     dist.all_gather_object(parts, mine, group=group)
