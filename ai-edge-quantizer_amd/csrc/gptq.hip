@@ -1483,7 +1483,7 @@ extern "C" int32_t mi355q_gptq_hinv_from_product_f32(const float* product, int64
 // own slice of the workspace, instances on one lane follow each other. Every instance runs the
 // launches of mi355q_gptq_hinv_f64 unchanged: bit-identical results.
 namespace {
-constexpr int kHinvLanes = 8;
+constexpr int kHinvLanes = 16;
 struct HinvPool {
   hipStream_t lane[kHinvLanes] = {};
   hipEvent_t fork = nullptr, done[kHinvLanes] = {};

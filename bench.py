@@ -26,7 +26,7 @@ import time
 # PyTorch alone makes 64 streams at its first torch.cuda.Stream(): streams that share a queue run in turn. The
 # library's look-ahead stream and the lanes of the batched Hessian inverse want queues of their own
 # (include/mi355q.h, mi355q_prepare_device); it must be set before the runtime is loaded (import torch).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ai-edge-quantizer_amd"))
