@@ -72,6 +72,12 @@ python tools/pmc_big_kernels.py /tmp/prof_fetch > "$OUT/hinv16384_fetch.txt" 2>&
   MI355Q_HINV_FP64=1 timeout 300 python tools/hinv_accuracy.py 4096 16384 2>&1 | grep mode
   echo "# tools/gptq_apply_bench.py"
   timeout 200 python tools/gptq_apply_bench.py 2>&1 | grep op
+  echo "# tools/xtx_bench.py: Hessian product, two-way float16 split (xtx_f16x2.hip) against the three-way bfloat16 split"
+  timeout 300 python tools/xtx_bench.py 2>&1 | grep tokens
+  echo "# tools/io_ring_bench.py: 1 GiB file -> HBM and back through the io ring (csrc/file_io.hip)"
+  timeout 200 python tools/io_ring_bench.py 2>&1 | grep GB/s
+  echo "# the 18-layer run with its idle accounting (MI355Q_C5_GAPS=1) and per-call inverse / apply times (MI355Q_C5_TRACE)"
+  MI355Q_C5_GAPS=1 MI355Q_C5_TRACE=hinv,apply timeout 600 python tools/c5_model.py --layers 18 --variant gptq 2>&1 | tail -1
 } > "$OUT/c5_model.txt" 2>&1
 bash tools/pmc_traffic_refresh.sh "$ROUND" > "$OUT/pmc_traffic.log" 2>&1
 for a in "" "--resident"; do timeout 300 python tools/c4_bench.py --samples 128 $a 2>&1 | tail -1; done > "$OUT/c4_c5_public.txt"
