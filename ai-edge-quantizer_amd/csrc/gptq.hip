@@ -1212,7 +1212,10 @@ extern "C" int32_t mi355q_prepare_device(void) {
     std::lock_guard<std::mutex> lock(g_side_mutex);
     (void)side_stream();        // (look-ahead switched off or no device: nothing to prepare)
   }
-  prepare_hinv_pool();          // ... and the lanes of the batched inverse, for the same reason
+  // ... and the lanes of the batched inverse: a hardware queue costs ~4 ms to create now and 3 - 4 times that
+  // once the application has made its own streams (16 lanes made at the first batched call of an 18-layer
+  // run: 220 ms). Eight lanes: 35 ms here, 0.67 ms per d = 2048 inverse (sixteen: 70 ms and 0.59).
+  prepare_hinv_pool();
   return MI355Q_OK;
 }
 
@@ -1483,7 +1486,7 @@ extern "C" int32_t mi355q_gptq_hinv_from_product_f32(const float* product, int64
 // own slice of the workspace, instances on one lane follow each other. Every instance runs the
 // launches of mi355q_gptq_hinv_f64 unchanged: bit-identical results.
 namespace {
-constexpr int kHinvLanes = 16;
+constexpr int kHinvLanes = 8;
 struct HinvPool {
   hipStream_t lane[kHinvLanes] = {};
   hipEvent_t fork = nullptr, done[kHinvLanes] = {};

@@ -314,7 +314,8 @@ size_t mi355q_gptq_hinv_workspace_bytes(int64_t d);
 /* Releases the per-device side stream + events the blocked Cholesky creates on first use for
  * its look-ahead (the only state the library keeps between calls). Safe to call at any time. */
 int32_t mi355q_shutdown(void);
-/* Creates the current device's look-ahead stream NOW instead of on the first inverse of order >= 4096.
+/* Creates the current device's look-ahead stream and the eight lanes of the batched inverse NOW instead of on
+ * the first inverse that needs them (~35 ms; a hardware queue costs 3 - 4 times as much to create later).
  * The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, least used
  * first: created after an application's stream pools (PyTorch makes 64 streams at its first
  * torch.cuda.Stream()), the look-ahead stream can land on the caller's own hardware queue, where its
