@@ -31,13 +31,13 @@
 //           by global_load_lds and every wave issues 24 MFMAs on its 64 x 64 quadrant from 16
 //           fragment reads. h1 g1 has accumulators of its own, folded into a third set every 32 k
 //           tiles as in the three-way kernel.
-// What bounds it (profiles/r03_xtx_f16x2.txt): the staging alone (32 KB per stage and workgroup, 20 TB/s out of
-// the L2s chip-wide) and the MFMAs alone (1.9 PFLOP/s) each take about half of the kernel's time, and
-// their times ADD whatever the arrangement -- a deeper ring, the pieces spread between the MFMAs, staging
-// waves of their own beside the multiplying ones, two workgroups per CU -- with the matrix cores at
-// 38 % and no wave waiting for data: the sum of both energies at the socket's power limit. Fewer MFMAs (this
-// split) and fewer staged bytes per MFMA (a larger tile: 256 x 128 is what three accumulator sets leave
-// room for, a quarter less) are what is left.
+// What bounds it (profiles/r03_xtx_f16x2.txt): the staging alone (20 TB/s out of the L2s chip-wide) and the
+// MFMAs alone (1.9 PFLOP/s) each take about half of the kernel's time, and their times largely ADD whatever
+// the arrangement -- a deeper ring, the pieces spread between the MFMAs, staging waves of their own beside the
+// multiplying ones -- with the matrix cores at 38 % and the socket at its power limit (1310 W, 1.86 GHz).
+// What moves it is MFMAs per product (this split: three instead of six) and staged bytes per MFMA: for
+// d >= 4096 (a multiple of 256) the product runs on 128 x 256 tiles (xtx_f16x2_wide_kernel: eight waves, a
+// quarter fewer staged bytes, 65 -> 55 ms for the d = 16384 Hessian of 65536 tokens).
 // An infinite activation gives +-inf where x.T.dot(x) does (the h1 g1 sum decides; the NaN of an
 // inf * 0 cross term is dropped); the damped Cholesky refuses it.
 #include "common.h"
@@ -280,6 +280,138 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 
   }
 }
 
+// The same product on 128 x 256 output tiles, eight waves per workgroup (2 x 4 quadrants of 64 x 64, the
+// accumulators and fragment reads of a wave unchanged): a stage is 48 KB for twice the MFMAs of the 32 KB
+// stage above -- a quarter fewer bytes out of the L2 per MFMA, which is what the kernel's time goes with
+// (header). One workgroup per CU (96 KB of LDS, two waves per SIMD as above); an XCD's patch is 8 x 4 of
+// these tiles = its 32 CUs, resident together. Tile (ti, tj) covers rows 128 ti.. and columns 256 tj..; it is
+// needed when 2 tj <= ti (the tile on the diagonal of an even tile row also computes 128 columns above the
+// diagonal: valid entries of the symmetric product, never read). For d a multiple of 256 with >= 32 tile rows.
+constexpr int kWideOperandA = 2 * kPlaneTileB;         // 8 KB: both planes of 128 rows, one k tile
+constexpr int kWideOperandB = 4 * kPlaneTileB;         // 16 KB: both planes of 256 rows
+constexpr int kWideKt = kWideOperandA + kWideOperandB; // 24 KB per k tile
+constexpr int kWideStageB = 2 * kWideKt;               // 48 KB: two k tiles
+
+__global__ __launch_bounds__(512) void xtx_f16x2_wide_kernel(Xtx2Args a) {
+  constexpr int DEPTH = 2;      // (a ring of three stages, 144 KB, was measured: 55.7 against 55.8 ms)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
+  const int sup = (local / 32) * 8 + xcd, within = local % 32;
+  int si = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(sup) + 1.0f) - 1.0f) * 0.5f);
+  while ((si + 1) * (si + 2) / 2 <= sup) ++si;
+  while (si * (si + 1) / 2 > sup) --si;
+  const int sj = sup - si * (si + 1) / 2;
+  const int ti = si * kSuper + within / 4;          // 128-row tile
+  const int tj = sj * (kSuper / 2) + within % 4;    // 256-column tile
+  if (ti >= a.tiles || 2 * tj > ti) return;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 2, wc = wave & 3;           // this wave's 64 x 64 quadrant of the 128 x 256 tile
+  const int kt0 = blockIdx.y * a.kt_per_split;
+  const int kt1 = min(a.kt_total, kt0 + a.kt_per_split);
+
+  f32x16 acc[2][2], lo[2][2], top[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = top[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fch = ((lane >> 5) ^ ((frow >> 3) & 1)) * 16;
+  const int offA = (wr * 64 + frow) * kRowB + fch, offB = kWideOperandA + (wc * 64 + frow) * kRowB + fch;
+
+  const long long row_stride = static_cast<long long>(a.d) * kRowB;   // one plane of one k tile
+  const unsigned char* gA = a.planes + static_cast<long long>(ti) * kPlaneTileB + lane * 16;
+  const unsigned char* gB = a.planes + static_cast<long long>(tj) * (2 * kPlaneTileB) + lane * 16;
+
+  // 48 wave-wide 1 KB pieces per stage: per k tile 8 of A (plane x 4 pieces of 32 rows) and 16 of B (plane x 8)
+  auto stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int piece = q * 8 + wave;                 // 0 .. 47
+      const int kk = piece / 24, r = piece % 24;
+      const bool isB = r >= 8;
+      const int p = isB ? (r - 8) >> 3 : r >> 2, seg = isB ? (r - 8) & 7 : r & 3;
+      const unsigned char* src = (isB ? gB : gA) + (static_cast<long long>(kt + kk) * 2 + p) * row_stride + seg * 1024;
+      unsigned char* dst = lds + buf * kWideStageB + kk * kWideKt +
+                           (isB ? kWideOperandA + p * (2 * kPlaneTileB) : p * kPlaneTileB) + seg * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  const int nst = (kt1 - kt0) / 2;
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s)
+    if (s < nst && !(a.probe & 2)) stage(kt0 + 2 * s, s);
+  int buf = 0, fill = DEPTH - 1;
+  for (int s = 0; s < nst; ++s) {
+    const int behind = nst - 1 - s;          // stages issued after this one (six loads per stage and wave)
+    if (DEPTH >= 3 && behind >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // this stage has landed; every wave is done with the buffer refilled next
+    if (s + DEPTH - 1 < nst && !(a.probe & 2)) stage(kt0 + 2 * (s + DEPTH - 1), fill);
+    fill = fill + 1 == DEPTH ? 0 : fill + 1;
+    if (!(a.probe & 1))
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const unsigned char* img = lds + buf * kWideStageB + kk * kWideKt;
+      f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          fa[i][p] = *reinterpret_cast<const f16x8*>(img + offA + p * kPlaneTileB + i * 32 * kRowB);
+          fb[i][p] = *reinterpret_cast<const f16x8*>(img + offB + p * (2 * kPlaneTileB) + i * 32 * kRowB);
+        }
+#define MI355Q_TERM(ACC, PA, PB)                                                                \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA], fb[j][PB], ACC[i][j], 0, 0, 0)
+      MI355Q_TERM(lo, 0, 1);
+      MI355Q_TERM(lo, 1, 0);
+      MI355Q_TERM(acc, 0, 0);
+#undef MI355Q_TERM
+    }
+    buf = buf + 1 == DEPTH ? 0 : buf + 1;
+    if ((s & (kFold / 2 - 1)) == kFold / 2 - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            top[i][j][r] = top[i][j][r] + acc[i][j][r];
+            acc[i][j][r] = 0.f;
+          }
+    }
+  }
+
+  float* c = a.c + (a.partial ? static_cast<long long>(blockIdx.y) * a.d * a.d : 0);
+  const int row0 = ti * kTile + wr * 64 + 4 * (lane >> 5), col0 = tj * (2 * kTile) + wc * 64 + (lane & 31);
+  float* base = c + static_cast<long long>(row0) * a.d + col0;
+  const int ec[2] = {a.exps[col0], a.exps[col0 + 32]};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float old[16];
+      int er[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        er[r] = a.exps[row0 + i * 32 + (r & 3) + 8 * (r >> 2)];
+        old[r] = a.accumulate ? base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float big = top[i][j][r] + acc[i][j][r];
+        const float sum = __builtin_isinf(big) ? big : big + lo[i][j][r];
+        const float v = __builtin_ldexpf(sum, -(er[r] + ec[j]));
+        base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] = a.accumulate ? old[r] + v : v;
+      }
+    }
+  }
+}
+
 // c (+)= partial[0] + partial[1] + ... (slices added in order) over the lower-triangular tiles
 __global__ __launch_bounds__(256) void xtx2_reduce_kernel(const float* __restrict__ partial, int splits, int d,
                                                          int accumulate, float* __restrict__ c) {
@@ -366,7 +498,19 @@ int32_t xtx_f16x2(const float* x, int64_t n, int64_t d, float* p, void* workspac
       hipLaunchKernelGGL(kernel, dim3(gx, static_cast<unsigned>(splits)), dim3(256), static_cast<size_t>(stages) * kStageB, st, a);
       return hipSuccess;
     };
-    const hipError_t le = depth == 2 ? launch(xtx_f16x2_kernel<2>, 2) : depth == 3 ? launch(xtx_f16x2_kernel<3>, 3) : launch(xtx_f16x2_kernel<4>, 4);
+    hipError_t le;
+    static const bool wide_ok = [] { const char* e = getenv("MI355Q_XTX_NARROW"); return e == nullptr || *e == 0; }();
+    if (wide_ok && a.patches && d % (2 * kTile) == 0 && splits == 1) {
+      // 128 x 256 tiles: the grid is the same 8-XCD patch list, 32 workgroups per patch
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xtx_f16x2_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWideStageB))
+        le = e;
+      else {
+        hipLaunchKernelGGL(xtx_f16x2_wide_kernel, dim3(gx / 2, 1), dim3(512), 2 * kWideStageB, st, a);
+        le = hipSuccess;
+      }
+    } else {
+      le = depth == 2 ? launch(xtx_f16x2_kernel<2>, 2) : depth == 3 ? launch(xtx_f16x2_kernel<3>, 3) : launch(xtx_f16x2_kernel<4>, 4);
+    }
     if (le != hipSuccess) return fail(MI355Q_HIP_ERROR, "xtx f16x2 LDS attribute: %s", hipGetErrorString(le));
     if (splits > 1)
       hipLaunchKernelGGL(xtx2_reduce_kernel, dim3(2048), dim3(256), 0, st, partial, splits, static_cast<int>(d),
