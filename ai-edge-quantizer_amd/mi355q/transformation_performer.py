@@ -38,8 +38,8 @@ class TransformationPerformer:
         _T.DUPLICATE_BUFFER: graph_edits.duplicate_buffer,
         _T.DUPLICATE_TENSOR: graph_edits.duplicate_tensor,
         _T.EMULATED_SUBCHANNEL: _deprecated,      # ref transformation_utils.py:286-290
-        # the custom-op form stores its options as a FlexBuffer (third-party encoder, unpinned)
-        _T.INSERT_HADAMARD_ROTATION: _unsupported("INSERT_HADAMARD_ROTATION (custom op with FlexBuffer options)"),
+        # (the custom op's options are a FlexBuffer: utils/flexbuffer.py)
+        _T.INSERT_HADAMARD_ROTATION: graph_edits.insert_hadamard_rotation,
         _T.INSERT_DECOMPOSED_HADAMARD_ROTATION: graph_edits.insert_decomposed_hadamard_rotation,
         _T.INSERT_MULTIPLY: graph_edits.insert_multiply,
     }

@@ -194,6 +194,62 @@ def insert_decomposed_hadamard_rotation(ti: _Input) -> qtyping.TransformationInf
   return qtyping.TransformationInfo(op_id=at, num_ops_added=3, output_tensor_id=post_out)
 
 
+def insert_hadamard_rotation(ti: _Input) -> qtyping.TransformationInfo:
+  """x -> CUSTOM "aeq.hadamard_rotation"(x) feeding the FULLY_CONNECTED consumers (or everything after
+  an EMBEDDING_LOOKUP producer) whose weights were rotated; the op's options are the FlexBuffer map
+  {hadamard_size, random_binary_vector} (ref insert_hadamard_rotation.py:24-156; the FlexBuffer
+  itself: utils/flexbuffer.py -- the reference's encoder is a third-party package, its bytes unpinned)."""
+  from ..utils import flexbuffer
+  p = ti.quant_params
+  if not isinstance(p, qtyping.UniformQuantParams):
+    raise ValueError("Hadamard rotation supports uniform quantization only")
+  if p.hadamard is None:
+    raise ValueError("Hadamard rotation quantization params are not set but op insertion is"
+                     " requested.")
+  sg, model = ti.subgraph, ti.model
+  tensor = sg.tensors[ti.tensor_id]
+  if tensor.type != qtyping.TensorType.FLOAT32:
+    raise ValueError(f"The Hadamard rotation op supports float32 tensors only. Got {tensor.type}"
+                     " tensor.")
+  code = transformation_utils.add_op_code(qtyping.BuiltinOperator.CUSTOM, model.operatorCodes,
+                                          "aeq.hadamard_rotation")
+  options = flexbuffer.encode_map({
+      "hadamard_size": int(p.hadamard.hadamard_size),
+      "random_binary_vector": np.asarray(p.hadamard.random_binary_vector).tolist(),
+  })
+  rotated = transformation_utils.add_new_activation_tensor(
+      _raw_name(tensor) + b"_rotated",
+      tensor.shapeSignature if tensor.shapeSignature is not None else tensor.shape,
+      qtyping.TensorType.FLOAT32, sg)
+  op = qtyping.OperatorT(opcodeIndex=code, inputs=[ti.tensor_id], outputs=[rotated],
+                         customOptions=np.frombuffer(options, dtype=np.uint8))
+  after_embedding = (ti.producer != -1
+                     and _op_code_of(ti, ti.producer) == qtyping.BuiltinOperator.EMBEDDING_LOOKUP)
+  if after_embedding:
+    for consumer in ti.consumers:
+      if consumer == -1:        # a graph output: handled below
+        continue
+      inputs = sg.operators[consumer].inputs
+      for k, tid in enumerate(inputs):
+        if tid == ti.tensor_id:
+          inputs[k] = rotated
+  else:
+    updated = False
+    for consumer in ti.consumers:
+      if _op_code_of(ti, consumer) == qtyping.BuiltinOperator.FULLY_CONNECTED:
+        sg.operators[consumer].inputs[0] = rotated
+        updated = True
+    if not updated:
+      raise ValueError("The Hadamard rotation op supports embedding lookup and fully connected"
+                       " ops only, but no such ops were found.")
+  for k, tid in enumerate(sg.outputs):
+    if tid == ti.tensor_id:
+      sg.outputs[k] = rotated
+  at = max(ti.producer + 1, min(ti.consumers))
+  sg.operators.insert(at, op)
+  return qtyping.TransformationInfo(op_id=at, num_ops_added=1, output_tensor_id=rotated)
+
+
 def insert_multiply(ti: _Input) -> qtyping.TransformationInfo:
   """x -> MUL(x, multiplier) feeding the FULLY_CONNECTED consumers whose weight columns OSCAR
   scaled by 1/multiplier; the constant is shared between ops asking for the same vector

@@ -242,13 +242,22 @@ def test_hadamard_recipe_materializes_rotation_instruction(m):
   hm = sg.tensors[sg.operators[1].inputs[1]]
   H = np.asarray(model.buffers[hm.buffer].data).view(np.float32).reshape(64, 64)
   assert np.allclose(H @ H.T, np.eye(64), atol=1e-6) and sg.operators[3].inputs[0] == sg.operators[2].outputs[0]
-  # the custom-op form needs FlexBuffer-encoded options (third-party encoder): refused loudly
+  # the custom-op form: ONE "aeq.hadamard_rotation" op in front of the FC, its options a FlexBuffer map
+  # (ref transformations/insert_hadamard_rotation.py; tests/test_hadamard_custom_op.py has the details)
+  from mi355q.utils import flexbuffer
   rm2 = m.rm.RecipeManager()
   rm2.load_quantization_recipe(m.recipe.dynamic_wi8_afp32(algorithm_key="HADAMARD_ROTATION"))
-  model2, _ = build_fc_model(m, w, bias)
+  model2, sg2 = build_fc_model(m, w, bias)
   params2 = params_generator.ParamsGenerator(model2).generate_quantization_parameters(rm2)
-  with pytest.raises(NotImplementedError, match="INSERT_HADAMARD_ROTATION"):
-    m.quantizer.apply_quantize_tensor_transformations(model2, params2)
+  assert params2["x"].consumers[0].transformations == [q.QuantTransformation.INSERT_HADAMARD_ROTATION]
+  n_ops2 = len(sg2.operators)
+  m.quantizer.apply_quantize_tensor_transformations(model2, params2)
+  assert len(sg2.operators) == n_ops2 + 1
+  codes2 = [model2.operatorCodes[op.opcodeIndex].builtinCode for op in sg2.operators]
+  assert codes2 == [B.CUSTOM, B.FULLY_CONNECTED] and sg2.operators[1].inputs[0] == sg2.operators[0].outputs[0]
+  opts = flexbuffer.decode(bytes(np.asarray(sg2.operators[0].customOptions, np.uint8)))
+  hp = params2["w"].consumers[0].parameters.hadamard
+  assert opts == {"hadamard_size": int(hp.hadamard_size), "random_binary_vector": np.asarray(hp.random_binary_vector).tolist()}
 
 
 
