@@ -279,3 +279,50 @@ def test_down_proj_through_get_tensor_quant_params(m, big):
   ref = _oracle_rows(w[rows], ref_scale[rows], hinv_host, 4)
   parity_rates.check("gptq.get_tensor_quant_params [256,16384] int4, 16 rows vs oracle (same Hinv)",
                      np.asarray(p.quantized_data)[rows], ref, parity_rates.T2)
+
+
+def test_full_chain_with_llm_like_activations_d4096(m):
+  """Activations shaped like a decoder's, not like white noise: per-token scales spread over a decade
+  (log-normal), eight massive channels 60 x the rest, a third of the entries gated to (almost) zero, a non-zero
+  mean per channel -- at d = 4096, where the Hessian runs on the two-way float16 split with 128 x 256 tiles
+  (xtx_f16x2.hip: a per-column power of two, 22 of 24 bits kept). The whole chain -- Hessian, damped inverse,
+  OBS apply through get_tensor_quant_params -- against the oracle's own chain (float32 x.T.dot(x), FP64
+  Cholesky, single-precision triangular inverse and product: ref gptq.py:100-216), with the oracle's own
+  reproducibility (its Hessian summed in two halves) measured beside it."""
+  torch, q_ = m.torch, m.q
+  d, tokens, rows = 4096, 8192, 48
+  gen = torch.Generator(device="cuda").manual_seed(4242)
+  x = torch.randn((tokens, d), generator=gen, device="cuda")
+  x = x * torch.exp(0.8 * torch.randn((tokens, 1), generator=gen, device="cuda"))          # per-token scale
+  x = x + 0.3 * torch.randn((1, d), generator=gen, device="cuda")                           # per-channel mean
+  x[:, torch.randint(0, d, (8,), generator=gen, device="cuda")] *= 60.0                     # massive channels
+  x = torch.where(torch.rand((tokens, d), generator=gen, device="cuda") < 0.33, x * 1e-4, x).contiguous()
+  xs = x.reshape(16, tokens // 16, d)                                                        # 16 samples
+  h = m.ops.gptq_xtx(x, 2.0 / 16)
+  ref64 = (x.double().T @ x.double()) * (2.0 / 16)
+  mag = (x.double().abs().T @ x.double().abs()) * (2.0 / 16)
+  parity_rates.note("hessian f16 split, LLM-like activations d=4096 vs FP64 product (per-entry scale)", "max_rel_error",
+                    float(((h - ref64).abs() / mag.clamp_min(1e-300)).max()), 1e-6)
+  del ref64, mag
+  xh = xs.cpu().numpy()
+  hess = O.gptq_hessian(xh)
+  x2 = xh.reshape(-1, d)
+  half = x2.shape[0] // 2
+  hess_b = (2.0 / np.array(16)) * (x2[:half].T.dot(x2[:half]) + x2[half:].T.dot(x2[half:]))
+  del xh, x2
+  parity_rates.check_rel("LLM-like activations: Hessian d=4096 vs oracle x.T.dot(x)", h.cpu().numpy(), hess, 2e-6)
+  w = np.random.default_rng(4243).standard_normal((rows, d), dtype=np.float32) * np.float32(0.02)
+  cfg = q_.TensorQuantizationConfig(num_bits=4, symmetric=True, granularity=q_.QuantGranularity.CHANNELWISE)
+  info = q_.OpInfo(op=q_.OperatorT(), op_name=q_.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
+                   op_quant_config=q_.OpQuantizationConfig(weight_tensor_config=cfg))
+  p = m.gptq.get_tensor_quant_params(info, cfg, w, {"activation_tensor_qsv": {"hessian": m.rt.HbmArray(h), "num_samples": 16}})
+  ref_scale = O.min_max_quant_params(w, 4, True, "CHANNELWISE")["scale"]
+  assert np.array_equal(p.scale, ref_scale)
+  zp = np.zeros((rows, 1), np.int8)
+  ref = O.gptq_apply(w, ref_scale, zp, 4, True, None, "CHANNELWISE", hinv=O.gptq_hessian_inverse(hess, product="matmul"))
+  ref_b = O.gptq_apply(w, ref_scale, zp, 4, True, None, "CHANNELWISE", hinv=O.gptq_hessian_inverse(hess_b, product="matmul"))
+  floor = float((ref != ref_b).mean())
+  parity_rates.note("reference noise floor: oracle FULL CHAIN [48,4096] int4, LLM-like activations, Hessian summed in another order",
+                    "int_mismatch_fraction", floor, 1.0)
+  parity_rates.check("LLM-like activations: get_tensor_quant_params [48,4096] int4 vs oracle FULL CHAIN (sgemm product)",
+                     np.asarray(p.quantized_data), ref, max(parity_rates.T2, 4 * floor))
