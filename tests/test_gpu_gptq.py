@@ -414,11 +414,12 @@ def test_hessian_bf16_split_structured_inputs(m, kind):
                     2e-6 if kind == "constant" else 1e-6)
 
 
-@pytest.mark.parametrize("n,d", [(2048, 256), (300, 192)])
+@pytest.mark.parametrize("n,d", [(2048, 256), (300, 192), (2048, 4096)])
 def test_hessian_with_infinite_activations_against_oracle(m, n, d):
   """An inf among the activations (ref gptq.py:100-107 computes x.T.dot(x) whatever x holds): row and
   column of that channel are +-inf exactly where NumPy's sgemm has them, every other entry is the
-  ordinary product. (2048, 256) takes the bf16 split, (300, 192) the FP32-MFMA product."""
+  ordinary product. (2048, 256) takes the float16 split on 128 x 128 tiles, (2048, 4096) on 128 x 256 tiles
+  (the column's power of two comes from its largest FINITE entry), (300, 192) the FP32-MFMA product."""
   rng = np.random.default_rng(n)
   x = rng.standard_normal((1, n, d), dtype=np.float32)
   x[0, 17, 5] = np.inf
