@@ -125,3 +125,39 @@ def test_quantizer_through_the_ring_writes_the_same_file(m, tmp_path, monkeypatc
   assert calls["up"] >= 4 and calls["down"] >= 3, calls   # (a buffer somebody already read on the host is copied from there)
   assert os.path.getsize(ring) == os.path.getsize(plain)
   assert _sha(ring) == _sha(plain)
+
+
+def test_container_written_through_the_ring_equals_the_pageable_copy(m, tmp_path, monkeypatch):
+  """A one-layer decoder-shaped `.litertlm` (projections of 1 MB and more once packed) quantized in place
+  (LiteRTLMFile.open_with_section registers the output mapping: device-resident buffers leave by pinned
+  staging + pwrite) against the same call with the ring switched off on both sides."""
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  import c5_model
+  from mi355q.utils import litertlm_utils
+  src = str(tmp_path / "one_layer.litertlm")
+  c5_model.write_litertlm(c5_model.build_model(1, 512, 128, 4096), src)
+  rcp = c5_model.recipe("hadamard", 4, max_hadamard_size=4096)
+  plain = str(tmp_path / "plain.litertlm")
+  with monkeypatch.context() as mp:
+    mp.setattr(m.rt, "download_into_file", lambda t, d: False)
+    n_plain = litertlm_utils.quantize_litertlm(src, rcp, plain)
+  took = {"down": 0, "up": 0}
+  down, up = m.rt.download_into_file, m.rt.upload_overlapped
+
+  def counted_down(t, d):
+    ok = down(t, d)
+    took["down"] += int(ok)
+    return ok
+
+  def counted_up(a):
+    took["up"] += 1
+    return up(a)
+  monkeypatch.setattr(m.rt, "_UPLOAD_MIN_FILE_BYTES", 1)
+  monkeypatch.setattr(m.rt, "_UPLOAD_MIN_TENSOR_BYTES", 1)
+  monkeypatch.setattr(m.rt, "download_into_file", counted_down)
+  monkeypatch.setattr(m.rt, "upload_overlapped", counted_up)
+  ring = str(tmp_path / "ring.litertlm")
+  n_ring = litertlm_utils.quantize_litertlm(src, rcp, ring)
+  assert took["down"] >= 3 and took["up"] >= 7, took
+  assert n_ring == n_plain == os.path.getsize(ring) == os.path.getsize(plain)
+  assert _sha(ring) == _sha(plain)
