@@ -7,6 +7,8 @@ include/mi355q.h.
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 import torch
 
@@ -203,6 +205,7 @@ def cast_f16(x: torch.Tensor) -> torch.Tensor:
 _TABLE_SLOTS = 8
 _TABLE_CAPACITY = 8192          # entries per row of a slot (2 rows of int64: 128 KB of pinned memory)
 _TABLE_RING: dict = {}          # device index -> {"slots": [(pinned int64 [2, capacity], event)], "next": 0}
+_TABLE_LOCK = threading.Lock()
 
 
 def _table_to_device(pointers, lengths) -> torch.Tensor:
@@ -211,18 +214,19 @@ def _table_to_device(pointers, lengths) -> torch.Tensor:
   dev = rt.device()
   if n > _TABLE_CAPACITY:
     return torch.tensor([pointers, lengths], dtype=torch.int64).to(dev)
-  ring = _TABLE_RING.setdefault(dev.index, {"slots": [], "next": 0})
-  k = ring["next"] % _TABLE_SLOTS
-  ring["next"] += 1
-  if len(ring["slots"]) <= k:
-    ring["slots"].append((torch.empty((2, _TABLE_CAPACITY), dtype=torch.int64, pin_memory=True), torch.cuda.Event()))
-  pinned, event = ring["slots"][k]
-  event.synchronize()                     # the copy that last read this slot (eight tables ago)
-  pinned[0, :n] = torch.tensor(pointers, dtype=torch.int64)
-  pinned[1, :n] = torch.tensor(lengths, dtype=torch.int64)
-  out = torch.empty((2, n), dtype=torch.int64, device=dev)
-  out.copy_(pinned[:, :n], non_blocking=True)
-  event.record()
+  with _TABLE_LOCK:                         # (slot choice, fill and enqueue as one step: threads share the ring)
+    ring = _TABLE_RING.setdefault(dev.index, {"slots": [], "next": 0})
+    k = ring["next"] % _TABLE_SLOTS
+    ring["next"] += 1
+    if len(ring["slots"]) <= k:
+      ring["slots"].append((torch.empty((2, _TABLE_CAPACITY), dtype=torch.int64, pin_memory=True), torch.cuda.Event()))
+    pinned, event = ring["slots"][k]
+    event.synchronize()                     # the copy that last read this slot (eight tables ago)
+    pinned[0, :n] = torch.tensor(pointers, dtype=torch.int64)
+    pinned[1, :n] = torch.tensor(lengths, dtype=torch.int64)
+    out = torch.empty((2, n), dtype=torch.int64, device=dev)
+    out.copy_(pinned[:, :n], non_blocking=True)
+    event.record()
   return out
 
 
