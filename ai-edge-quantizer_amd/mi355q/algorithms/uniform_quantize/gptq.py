@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import contextlib
 import dataclasses
+import os
 from collections.abc import Mapping, MutableMapping, Sequence
 from typing import Any, Optional
 
@@ -70,6 +71,30 @@ def calibrate(tfl_op, graph_info: qtyping.GraphInfo,
   return out
 
 
+_BORROWED: Optional[list] = None
+
+
+@contextlib.contextmanager
+def borrowing():
+  """Inside this block (one calibration step) the per-sample statistic that `calibrate` returns for a staged
+  activation only REFERS to the sample's tokens; the merge that follows (qsv_utils._gptq_merge_hessian ->
+  absorb) copies them once, into the running statistic's slab, instead of twice (a slab of the sample's own
+  first). What has not been merged when the block exits -- a tensor's first sample becomes the running
+  statistic itself -- takes its copy then: the tokens may change afterwards."""
+  global _BORROWED
+  if os.environ.get("MI355Q_GPTQ_BORROW", "1") == "0":     # (for A / B timing)
+    yield
+    return
+  outer, _BORROWED = _BORROWED, []
+  mine = _BORROWED
+  try:
+    yield
+  finally:
+    _BORROWED = outer
+    for acc in mine:
+      acc.own()
+
+
 class HessianAccumulator(rt.HbmArray):
   """float64 [d, d] = the sample-weighted mean of (2/n_i) X_i^T X_i over the samples added so far.
 
@@ -98,15 +123,27 @@ class HessianAccumulator(rt.HbmArray):
     self._fill = 0
     self._n_pending = 0.0
     self._value = None            # the float64 statistic, while nothing changed since it was formed
+    self._borrowed = None         # (x2d, num_samples) of ONE sample still in the caller's tensor (see borrowing())
     self._host = None
     self.cache = {}
     self.packed = None
 
   @classmethod
-  def of(cls, x2d, num_samples: float) -> "HessianAccumulator":
+  def of(cls, x2d, num_samples: float, borrow: bool = False) -> "HessianAccumulator":
+    """The statistic of one sample. `borrow`: the tokens stay where they are until this statistic is merged
+    into another one (absorb: ONE copy, into the running slab) or read (own())."""
     acc = cls(x2d.shape[1])
-    acc.add(x2d, num_samples)
+    if borrow:
+      acc._borrowed = (x2d, float(num_samples))
+    else:
+      acc.add(x2d, num_samples)
     return acc
+
+  def own(self) -> None:
+    """A borrowed sample is taken over (copied into this statistic's own slab, or multiplied)."""
+    if self._borrowed is not None:
+      (x2d, n), self._borrowed = self._borrowed, None
+      self.add(x2d, n)
 
   def _touched(self) -> None:
     self._value = self._host = None
@@ -115,6 +152,7 @@ class HessianAccumulator(rt.HbmArray):
   def add(self, x2d, num_samples: float) -> None:
     """x2d: float32 device tensor [tokens, d] (copied: the caller's buffer may change)."""
     import torch
+    self.own()
     t = int(x2d.shape[0])
     self._touched()
     if t >= self.SLAB_TOKENS:        # a slab's worth on its own: multiplied where it lies
@@ -146,6 +184,9 @@ class HessianAccumulator(rt.HbmArray):
   def absorb(self, other: "HessianAccumulator") -> None:
     """self <- the mean over both sets of samples."""
     self._touched()
+    if other._borrowed is not None:   # pylint: disable=protected-access
+      (x2d, n), other._borrowed = other._borrowed, None   # pylint: disable=protected-access
+      self.add(x2d, n)
     if other._fill:   # pylint: disable=protected-access
       self.add(other._slab[:other._fill], other._n_pending)   # pylint: disable=protected-access
     if other._prod is not None:   # pylint: disable=protected-access
@@ -159,6 +200,7 @@ class HessianAccumulator(rt.HbmArray):
       self._join(other._mean, other._n_done)   # pylint: disable=protected-access
 
   def flush(self) -> None:
+    self.own()
     if not self._fill:
       return
     self._prod = ops.gptq_xtx_accum(self._slab[:self._fill], self._prod)
@@ -194,6 +236,7 @@ class HessianAccumulator(rt.HbmArray):
   @device_tensor.setter
   def device_tensor(self, value) -> None:
     self._mean, self._prod, self._n_prod, self._fill, self._n_pending = value, None, 0.0, 0, 0.0
+    self._borrowed = None
     self._value = value
 
   @property
@@ -233,7 +276,10 @@ def hessian_of(tensor_content: np.ndarray, num_samples):
   rec = rt.staged(tensor_content)        # the calibrator put this sample's activations in HBM
   if rec is not None and tensor_content.dtype == np.float32:
     xd = rec["dev"].reshape(-1, tensor_content.shape[-1])
-    return HessianAccumulator.of(xd, float(np.asarray(num_samples)))
+    acc = HessianAccumulator.of(xd, float(np.asarray(num_samples)), borrow=_BORROWED is not None)
+    if _BORROWED is not None:
+      _BORROWED.append(acc)
+    return acc
   x = np.ascontiguousarray(tensor_content.reshape([-1, tensor_content.shape[-1]]))
   if x.dtype == np.float32:   # stays in HBM: merged per sample and consumed by the GPU again
     return HessianAccumulator.of(rt.to_device(x), float(np.asarray(num_samples)))

@@ -133,7 +133,13 @@ class Calibrator:
                if self._hessians == "consumed" else None)
     try:
       with gptq.hessians_only_for(readers):
-        self._walk(signature_key, model_recipe_manager)
+        if self._recording is None:
+          # every per-sample Hessian statistic is merged inside the walk: its tokens are copied once, where
+          # they are merged (record_steps keeps the same window open until its consumer has merged)
+          with gptq.borrowing():
+            self._walk(signature_key, model_recipe_manager)
+        else:
+          self._walk(signature_key, model_recipe_manager)
     finally:
       rt.clear_calibration_step()
 
@@ -293,13 +299,17 @@ class Calibrator:
                    model_recipe_manager: recipe_manager.RecipeManager):
     """record_step over a sequence of samples, the next one's statistics already on their way
     while this one is walked (yields one event list per sample, in order)."""
+    from .algorithms.uniform_quantize import gptq
     for prepared in self._steps_one_ahead(signature_key, dataset, model_recipe_manager):
       self._recording = []
-      try:
-        self._finish_step(signature_key, prepared, model_recipe_manager, lazy=os.environ.get("MI355Q_CALIBRATION_LAZY", "1") != "0")
-        yield self._recording
-      finally:
-        self._recording = None
+      # (the consumer merges this sample's Hessian statistics before it asks for the next sample: until then
+      # they only refer to the sample's tokens, gptq.borrowing())
+      with gptq.borrowing():
+        try:
+          self._finish_step(signature_key, prepared, model_recipe_manager, lazy=os.environ.get("MI355Q_CALIBRATION_LAZY", "1") != "0")
+          yield self._recording
+        finally:
+          self._recording = None
 
   def wait_for_statistics(self) -> None:
     """The (min, max) of every step recorded by record_steps are on the host (their events may be

@@ -453,8 +453,10 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
     for sig_idx, (signature_key, dataset) in enumerate(calibration_data.items()):
       samples = dataset if hasattr(dataset, "__len__") and hasattr(dataset, "__getitem__") else list(dataset)
       shard = sample_shard(len(samples), rank, world)
-      for k, events in zip(shard, local.record_steps(signature_key, (samples[j] for j in shard), rm)):
+      steps = local.record_steps(signature_key, (samples[j] for j in shard), rm)
+      for k, events in zip(shard, steps):
         mine.append((sig_idx, k, _set_hessians_aside(events, running)))
+      steps.close()        # (the last step's window: zip stops without resuming the generator)
   local.wait_for_statistics()       # (record_steps hands the samples' min / max over while their copies are in flight)
   if world > 1:
     parts = [None] * world
