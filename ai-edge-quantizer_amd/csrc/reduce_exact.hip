@@ -667,6 +667,11 @@ __device__ __forceinline__ void piece_runs_sparse(unsigned word, unsigned carry,
 // THREADS = 512 / 1024 (one piece per thread) for rows of up to 8192 / 16384 elements: with 256
 // threads and two to four pieces each, such a row (70 - 140 KB of LDS) left its CU with one wave
 // per SIMD walking four pieces one after the other.
+// 16-byte list loads the chain wave keeps in flight per half step: 8 (32 entries ahead) cost the whole workgroup 64
+// VGPRs and left 26 - 29 spilled at the 128 the occupancy allows; 4 leave 4 - 8 spilled and are 2 - 4 % faster; 2 are slower
+#ifndef MI355Q_OCTAV_CHAIN_Q
+#define MI355Q_OCTAV_CHAIN_Q 4
+#endif
 template <int SLOTS, int THREADS>
 __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SLOTS == 2 ? 2 : 1))) void octav_rows_kernel(OctavArgs a) {
   constexpr int kRowsThreads = THREADS, kWaves = THREADS / kWave;
@@ -917,23 +922,24 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
       // last read-ahead fetches is never added.
       if (wave == chain_wave) {
         const float4* l4 = reinterpret_cast<const float4*>((lane & 1) ? list_neg : list_pos);
-        const int npair = kmax >> 6;
+        constexpr int Q = MI355Q_OCTAV_CHAIN_Q;      // 16-byte loads in flight per half step
+        const int npair = kmax / (8 * Q);
         float acc = 0.f;
-        float4 qa[8], qb[8];
+        float4 qa[Q], qb[Q];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) qa[k] = l4[k];
+        for (int k = 0; k < Q; ++k) qa[k] = l4[k];
         for (int pr = 0; pr < npair; ++pr) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) qb[k] = l4[(2 * pr + 1) * 8 + k];
+          for (int k = 0; k < Q; ++k) qb[k] = l4[(2 * pr + 1) * Q + k];
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { acc = acc + qa[k].x; acc = acc + qa[k].y; acc = acc + qa[k].z; acc = acc + qa[k].w; }
+          for (int k = 0; k < Q; ++k) { acc = acc + qa[k].x; acc = acc + qa[k].y; acc = acc + qa[k].z; acc = acc + qa[k].w; }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) qa[k] = l4[(2 * pr + 2) * 8 + k];
+          for (int k = 0; k < Q; ++k) qa[k] = l4[(2 * pr + 2) * Q + k];
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { acc = acc + qb[k].x; acc = acc + qb[k].y; acc = acc + qb[k].z; acc = acc + qb[k].w; }
+          for (int k = 0; k < Q; ++k) { acc = acc + qb[k].x; acc = acc + qb[k].y; acc = acc + qb[k].z; acc = acc + qb[k].w; }
           __builtin_amdgcn_sched_barrier(0);
         }
         if (lane < 2) sh->sum[lane] = acc;
