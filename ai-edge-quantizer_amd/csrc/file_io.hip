@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
+#include <new>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -36,9 +37,16 @@ struct Latch {                       // the parts of one slot still in flight
   std::mutex m;
   std::condition_variable cv;
   int open = 0;
+  int error = 0;                     // first errno of a failed or short READ into this slot (-1: unexpected end of file)
   void wait() {
     std::unique_lock<std::mutex> l(m);
     cv.wait(l, [&] { return open == 0; });
+  }
+  int take_error() {                 // (after wait())
+    std::lock_guard<std::mutex> l(m);
+    const int e = error;
+    error = 0;
+    return e;
   }
 };
 
@@ -57,7 +65,9 @@ struct Pool {
   std::deque<Job> q;
   std::vector<std::thread> threads;
   bool stop = false;
-  int error = 0;                     // first errno of a failed or short transfer (-1: unexpected end of file)
+  int write_error = 0;               // first errno of a failed or short WRITE; reported (and cleared) by mi355q_file_io_finish only.
+                                     // Read errors stay with the slot they spoiled (Latch::error): the transfer that owns the slot
+                                     // sees them before the slot's bytes are copied anywhere.
 
   void run() {
     for (;;) {
@@ -78,12 +88,13 @@ struct Pool {
         if (k <= 0) { err = k < 0 ? errno : -1; break; }
         done += static_cast<size_t>(k);
       }
-      if (err) {
+      if (err && j.write) {
         std::lock_guard<std::mutex> l(m);
-        if (!error) error = err;
+        if (!write_error) write_error = err;
       }
       {
         std::lock_guard<std::mutex> l(j.latch->m);
+        if (err && !j.write && !j.latch->error) j.latch->error = err;
         if (--j.latch->open == 0) j.latch->cv.notify_all();
       }
     }
@@ -117,7 +128,7 @@ struct Pool {
     for (std::thread& t : threads) t.join();
     threads.clear();
     stop = false;
-    error = 0;
+    write_error = 0;
   }
 };
 
@@ -130,31 +141,59 @@ struct Ring {
 };
 
 std::mutex g_mutex;          // one transfer at a time enqueues (the ring is per device, the pool per process)
-Pool g_pool;
+Pool* g_pool = nullptr;      // owned by the process that started its threads (g_pool_pid)
+pid_t g_pool_pid = 0;
 Ring g_ring[64];
 
+// The io threads exist only in the process that started them: a fork()ed child inherits the Pool object with a
+// non-empty thread list, queue and (possibly held) mutexes but none of the threads, and every transfer would wait on a
+// latch nobody opens. The child therefore abandons the inherited pool (never destroyed: its std::thread objects are
+// joinable and name threads of another process) and starts its own. (The HIP runtime does not survive fork() either;
+// the ring's pinned slots are re-made the same way.)
+Pool& pool() {
+  const pid_t me = getpid();
+  if (!g_pool || g_pool_pid != me) {
+    if (g_pool)
+      for (Ring& r : g_ring) new (&r) Ring();
+    g_pool = new Pool();
+    g_pool_pid = me;
+  }
+  return *g_pool;
+}
+
+void free_ring(Ring& r) {
+  for (int s = 0; s < kSlots; ++s) {
+    if (r.left[s]) (void)hipEventDestroy(r.left[s]);
+    if (r.pinned[s]) (void)hipHostFree(r.pinned[s]);
+    r.pinned[s] = nullptr;
+    r.left[s] = nullptr;
+  }
+  r.ready = false;
+  r.next = 0;
+}
+
 Ring* ring_of_current_device() {
+  Pool& p = pool();
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   Ring& r = g_ring[dev];
   if (!r.ready) {
     for (int s = 0; s < kSlots; ++s) {
-      if (hipHostMalloc(reinterpret_cast<void**>(&r.pinned[s]), kSlotBytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-      if (hipEventCreateWithFlags(&r.left[s], hipEventDisableTiming) != hipSuccess) return nullptr;
+      if (hipHostMalloc(reinterpret_cast<void**>(&r.pinned[s]), kSlotBytes, hipHostMallocDefault) != hipSuccess ||
+          hipEventCreateWithFlags(&r.left[s], hipEventDisableTiming) != hipSuccess) {
+        const hipError_t why = hipGetLastError();
+        free_ring(r);                  // a half-made ring is given back, not left pinned
+        (void)why;
+        return nullptr;
+      }
     }
     r.ready = true;
   }
-  g_pool.start();
+  p.start();
   return &r;
 }
 
-int32_t io_error(const char* what) {
-  int err;
-  {
-    std::lock_guard<std::mutex> l(g_pool.m);
-    err = g_pool.error;
-    g_pool.error = 0;
-  }
+int32_t describe_io_error(const char* what, int err) {
   if (!err) return MI355Q_OK;
   return fail(MI355Q_IO_ERROR, "%s: %s", what, err < 0 ? "unexpected end of file" : strerror(err));
 }
@@ -163,19 +202,16 @@ int32_t io_error(const char* what) {
 
 void release_file_io() {
   std::lock_guard<std::mutex> lock(g_mutex);
+  if (!g_pool || g_pool_pid != getpid()) return;       // nothing of this process to give back
   for (Ring& r : g_ring) {
     if (!r.ready) continue;
     for (int s = 0; s < kSlots; ++s) {
       r.io[s].wait();
-      if (r.left[s]) { (void)hipEventSynchronize(r.left[s]); (void)hipEventDestroy(r.left[s]); }
-      if (r.pinned[s]) (void)hipHostFree(r.pinned[s]);
-      r.pinned[s] = nullptr;
-      r.left[s] = nullptr;
+      if (r.left[s]) (void)hipEventSynchronize(r.left[s]);
     }
-    r.ready = false;
-    r.next = 0;
+    free_ring(r);
   }
-  g_pool.shutdown();
+  g_pool->shutdown();
 }
 
 }  // namespace mi355q
@@ -191,29 +227,41 @@ extern "C" int32_t mi355q_file_to_device(int32_t fd, int64_t file_offset, int64_
   Ring* r = ring_of_current_device();
   if (!r) return fail(MI355Q_HIP_ERROR, "pinned staging for the io ring: %s", hipGetErrorString(hipGetLastError()));
   hipStream_t st = as_stream(copy_stream);
+  Pool& p = pool();
   struct Sent { int slot; long long off; size_t size; };
   std::deque<Sent> reading;
+  int read_error = 0;                 // once set, no further slot is copied to the device (its bytes are not the file's)
   auto send_oldest = [&]() -> hipError_t {
     const Sent s = reading.front();
     reading.pop_front();
     r->io[s.slot].wait();
+    if (const int e = r->io[s.slot].take_error())
+      if (!read_error) read_error = e;
+    if (read_error) return hipSuccess;
     if (hipError_t e = hipMemcpyAsync(static_cast<unsigned char*>(dst) + s.off, r->pinned[s.slot], s.size, hipMemcpyHostToDevice, st)) return e;
     return hipEventRecord(r->left[s.slot], st);
   };
-  for (long long off = 0; off < nbytes; off += static_cast<long long>(kSlotBytes)) {
+  hipError_t hip_error = hipSuccess;   // (slots still being read are always waited for: the io threads write into them)
+  for (long long off = 0; off < nbytes && !read_error && !hip_error; off += static_cast<long long>(kSlotBytes)) {
     const size_t size = static_cast<size_t>(nbytes - off < static_cast<long long>(kSlotBytes) ? nbytes - off : static_cast<long long>(kSlotBytes));
-    if (static_cast<int>(reading.size()) >= kSlots - 1)
-      if (hipError_t e = send_oldest()) return fail(MI355Q_HIP_ERROR, "upload copy: %s", hipGetErrorString(e));
+    if (static_cast<int>(reading.size()) >= kSlots - 1) {
+      hip_error = send_oldest();
+      if (read_error || hip_error) break;
+    }
     const int slot = r->next;
     r->next = (r->next + 1) % kSlots;
     r->io[slot].wait();                                  // (writes of an earlier download)
     (void)hipEventSynchronize(r->left[slot]);            // the slot's previous copy has left it
-    g_pool.submit(fd, file_offset + off, r->pinned[slot], size, false, &r->io[slot]);
+    p.submit(fd, file_offset + off, r->pinned[slot], size, false, &r->io[slot]);
     reading.push_back(Sent{slot, off, size});
   }
-  while (!reading.empty())
-    if (hipError_t e = send_oldest()) return fail(MI355Q_HIP_ERROR, "upload copy: %s", hipGetErrorString(e));
-  return io_error("reading the model file");
+  while (!reading.empty()) {
+    const hipError_t e = send_oldest();
+    if (e && !hip_error) hip_error = e;
+  }
+  if (read_error) return describe_io_error("reading the model file", read_error);
+  if (hip_error) return fail(MI355Q_HIP_ERROR, "upload copy: %s", hipGetErrorString(hip_error));
+  return MI355Q_OK;
 }
 
 extern "C" int32_t mi355q_device_to_file(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset, void* copy_stream) {
@@ -225,12 +273,13 @@ extern "C" int32_t mi355q_device_to_file(const void* src, int64_t nbytes, int32_
   Ring* r = ring_of_current_device();
   if (!r) return fail(MI355Q_HIP_ERROR, "pinned staging for the io ring: %s", hipGetErrorString(hipGetLastError()));
   hipStream_t st = as_stream(copy_stream);
+  Pool& p = pool();
   int pending_slot = -1;
   long long pending_off = 0;
   size_t pending_size = 0;
   auto drain = [&] {            // the pending slot's copy has arrived: hand it to the writers
     (void)hipEventSynchronize(r->left[pending_slot]);
-    g_pool.submit(fd, file_offset + pending_off, r->pinned[pending_slot], pending_size, true, &r->io[pending_slot]);
+    p.submit(fd, file_offset + pending_off, r->pinned[pending_slot], pending_size, true, &r->io[pending_slot]);
   };
   for (long long off = 0; off < nbytes; off += static_cast<long long>(kSlotBytes)) {
     const size_t size = static_cast<size_t>(nbytes - off < static_cast<long long>(kSlotBytes) ? nbytes - off : static_cast<long long>(kSlotBytes));
@@ -250,11 +299,16 @@ extern "C" int32_t mi355q_device_to_file(const void* src, int64_t nbytes, int32_
 
 extern "C" int32_t mi355q_file_io_finish(void) {
   clear_error();
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (!g_pool || g_pool_pid != getpid()) return MI355Q_OK;   // no transfer of this process is open
+  for (Ring& r : g_ring)
+    if (r.ready)
+      for (int s = 0; s < kSlots; ++s) r.io[s].wait();
+  int err;
   {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    for (Ring& r : g_ring)
-      if (r.ready)
-        for (int s = 0; s < kSlots; ++s) r.io[s].wait();
+    std::lock_guard<std::mutex> l(g_pool->m);
+    err = g_pool->write_error;
+    g_pool->write_error = 0;
   }
-  return io_error("writing the output file");
+  return describe_io_error("writing the output file", err);
 }

@@ -91,7 +91,7 @@ def rccl_comm(group=None) -> Optional[ctypes.c_void_p]:
   _COMMS.append((group, comm))     # the entry keeps `group` alive, so its identity stays unique
   if not _ATEXIT[0]:
     import atexit
-    atexit.register(destroy_rccl_comms)
+    atexit.register(_destroy_rccl_comms_at_exit)
     _ATEXIT[0] = True
   return comm
 
@@ -121,13 +121,34 @@ def new_rccl_comm(rank: int, world: int, broadcast: Callable[[Optional[bytes]], 
   return comm
 
 
-def destroy_rccl_comms() -> None:
-  """Destroys every cached communicator (also registered with atexit; call it before
-  dist.destroy_process_group() when groups are torn down and re-created in one process)."""
+def destroy_rccl_comms(group=_ATEXIT) -> None:
+  """Destroys the cached communicator of `group` (default: every cached communicator). Call it
+  before dist.destroy_process_group(): ncclCommDestroy talks to the peers, and the cache entry
+  keeps the group object alive. Raises when RCCL reports a failure."""
   from . import _ffi
-  comms, _COMMS[:] = list(_COMMS), []
-  for _, comm in comms:
+  doomed = [e for e in _COMMS if group is _ATEXIT or e[0] is group]
+  _COMMS[:] = [e for e in _COMMS if not any(e is d for d in doomed)]
+  for _, comm in doomed:
     _ffi.check(_ffi.lib().mi355q_comm_destroy(comm))
+
+
+def _destroy_rccl_comms_at_exit() -> None:
+  """Interpreter exit: the process group or the HIP context may already be gone, and a peer may
+  have left -- ncclCommDestroy could fail or wait for it. Communicators are destroyed only while
+  the process group still stands; otherwise they are abandoned to process teardown. Never raises."""
+  comms, _COMMS[:] = list(_COMMS), []
+  try:
+    if not comms or not dist.is_available() or not dist.is_initialized():
+      return
+    from . import _ffi
+    L = _ffi.lib()
+    for _, comm in comms:
+      if L.mi355q_comm_destroy(comm) != 0:
+        import sys
+        print("mi355q: RCCL communicator not destroyed cleanly at exit: "
+              + L.mi355q_last_error().decode("utf-8", "replace"), file=sys.stderr)
+  except Exception:  # noqa: BLE001 - exit path
+    pass
 
 
 # ------------------------------------------------- weight requantization ---
@@ -323,6 +344,8 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
         "Model quantization statistics values (QSVs) are required for the input recipe. This"
         " can be obtained by running calibration on sample dataset.")
   qsvs = calibration_result if calibration_result is not None else {}
+  if world > 1:
+    _require_hessians_where_read([it for it, o in zip(plan, owner) if o == rank], qsvs, rank)
   gen.prefetch([it for it, o in zip(plan, owner) if o == rank], qsvs)
   try:
     with requant_queue.batching():       # this rank's equally shaped weights leave in one launch per group
@@ -335,6 +358,29 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
       return None
   params = gen.finish(mine[i] for i in range(len(plan)))
   return model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path, sink=sink)
+
+
+def _require_hessians_where_read(items: Sequence[tuple], qsvs: dict, rank: int) -> None:
+  """A sharded run keeps each GPTQ Hessian on ONE rank (hessian_owners, from op_cost's view of which
+  ops read it). gptq.get_tensor_quant_params, like the reference (ref gptq.py:291-293), quantizes
+  with plain min / max when its activation's QSV has no "hessian" -- so an op that reads a Hessian
+  this rank gave away would be quantized WITHOUT GPTQ, silently and differently from the
+  one-process run. The reader set here is the Calibrator's own (calibrator._plan: every GPTQ op
+  reads the Hessian of its first input); a calibrated first input (it has "num_samples") without
+  its Hessian on the rank that owns the op is refused."""
+  from .utils import tfl_flatbuffer_utils
+  for graph_info, op, _, op_key, alg, _ in items:
+    if str(getattr(alg, "value", alg)) != "GPTQ" or op_key is None or not len(getattr(op, "inputs", ())):
+      continue
+    if not any(tid != -1 and graph_info.buffers[graph_info.subgraph_tensors[tid].buffer].data is not None
+               for tid in op.inputs[1:]):
+      continue                      # no constant operand: nothing GPTQ would update
+    name = tfl_flatbuffer_utils.get_tensor_name(graph_info.subgraph_tensors[op.inputs[0]])
+    qsv = qsvs.get(name)
+    if isinstance(qsv, dict) and "num_samples" in qsv and "hessian" not in qsv:
+      raise RuntimeError(
+          f"rank {rank} owns a GPTQ op reading the Hessian of '{name}', but that Hessian was reduced to another rank:"
+          " the op plan and the Hessian owners disagree (distributed.op_cost vs calibrator._plan).")
 
 
 def _gather_results(mine: dict, group=None) -> Optional[dict]:

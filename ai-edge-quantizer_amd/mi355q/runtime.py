@@ -6,7 +6,9 @@ device pointers + the current HIP stream to libmi355q.
 from __future__ import annotations
 
 import ctypes
+import os
 import warnings
+import weakref
 
 import numpy as np
 import torch
@@ -69,20 +71,54 @@ def to_device(a, dtype=None) -> torch.Tensor:
 _UPLOAD_MIN_FILE_BYTES = 1 << 30  # only models large enough to earn the ring's 24 ms back
 _UPLOAD_MIN_TENSOR_BYTES = 4 << 20
 _COPY_STREAMS: dict = {}   # device index -> the copy stream of the io ring
-_FILE_MAPPINGS: list = []  # (base address, length, path) of model files mapped by tfl_flatbuffer_utils
+_FILE_MAPPINGS: list = []  # _FileMapping records of model files mapped by tfl_flatbuffer_utils
 _OUT_MAPPINGS: list = []   # (base address, length, file descriptor) of output files being built
-_FILE_FDS: dict = {}
 
 
-def register_file_mapping(mapping, path) -> None:
+class _FileMapping:
+  """A mapped model file as the upload path knows it. The record lives exactly as long as the
+  mapping does: it holds a weak reference to the mmap object whose finalizer removes the record and
+  closes the descriptor, so an address range that the allocator hands out again after the munmap
+  can never be mistaken for the file. The descriptor is a dup() of the one the mapping was made
+  from -- the same inode whatever happens to the path afterwards."""
+  __slots__ = ("base", "length", "fd", "ref", "__weakref__")
+
+  def __init__(self, mapping, fd: int):
+    self.base = np.frombuffer(mapping, dtype=np.uint8).ctypes.data
+    self.length = len(mapping)
+    self.fd = os.dup(fd)
+    self.ref = weakref.ref(mapping, self._gone)
+
+  def _gone(self, _ref=None) -> None:
+    try:
+      _FILE_MAPPINGS.remove(self)
+    except ValueError:
+      pass
+    fd, self.fd = self.fd, -1
+    if fd >= 0:
+      try:
+        os.close(fd)
+      except OSError:
+        pass
+
+  def alive(self) -> bool:
+    m = self.ref()
+    return m is not None and not getattr(m, "closed", False) and self.fd >= 0
+
+
+def register_file_mapping(mapping, fd: int) -> None:
   """Remembers where a model file is mapped, so that a weight that is a view of the mapping can also
-  be fetched with pread() from the file itself (upload_overlapped)."""
+  be fetched with pread() from the file itself (upload_overlapped). `fd`: the descriptor the
+  mapping was made from (duplicated here; the caller may close its own)."""
   try:
-    base = np.frombuffer(mapping, dtype=np.uint8).ctypes.data
-  except (ValueError, TypeError):
+    rec = _FileMapping(mapping, fd)
+  except (ValueError, TypeError, OSError):
     return
-  _FILE_MAPPINGS[:] = [m for m in _FILE_MAPPINGS if m[0] != base][-15:]
-  _FILE_MAPPINGS.append((base, len(mapping), str(path)))
+  for old in [m for m in _FILE_MAPPINGS if m.base == rec.base or not m.alive()]:
+    old._gone()  # pylint: disable=protected-access
+  for old in _FILE_MAPPINGS[:-15]:
+    old._gone()  # pylint: disable=protected-access
+  _FILE_MAPPINGS.append(rec)
 
 
 def register_output_mapping(mapping, fd: int) -> None:
@@ -102,11 +138,29 @@ def forget_output_mapping(mapping) -> None:
   _OUT_MAPPINGS[:] = [m for m in _OUT_MAPPINGS if m[0] != base]
 
 
+def _backing_mapping(arr):
+  """The object at the end of `arr`'s chain of bases (ndarray.base / memoryview.obj): for a weight
+  read from a mapped model file, the mmap itself."""
+  obj = arr
+  for _ in range(16):
+    nxt = obj.base if isinstance(obj, np.ndarray) else obj.obj if isinstance(obj, memoryview) else None
+    if nxt is None:
+      return obj
+    obj = nxt
+  return obj
+
+
 def _file_range_of(arr: np.ndarray):
+  """(descriptor, file offset) when `arr` is a view of a registered, still mapped model file of at
+  least 1 GiB; None otherwise. Both the address range AND the array's ownership chain must name
+  the mapping: an array that merely landed in addresses a dead mapping used to occupy is copied
+  as the ordinary array it is."""
   addr = arr.ctypes.data
-  for base, length, path in reversed(_FILE_MAPPINGS):
-    if base <= addr and addr + arr.nbytes <= base + length:
-      return (path, addr - base) if length >= _UPLOAD_MIN_FILE_BYTES else None
+  for rec in reversed(_FILE_MAPPINGS):
+    if rec.base <= addr and addr + arr.nbytes <= rec.base + rec.length:
+      if not rec.alive() or _backing_mapping(arr) is not rec.ref():
+        return None
+      return (rec.fd, addr - rec.base) if rec.length >= _UPLOAD_MIN_FILE_BYTES else None
   return None
 
 
@@ -133,16 +187,12 @@ def upload_overlapped(a: np.ndarray) -> torch.Tensor:
   on the copy stream (the block it lands in cannot still be read by compute queued earlier) and
   recorded on the current one. Arrays that are not views of a registered mapping of at least 1 GiB
   take the pageable copy."""
-  import os
   where = _file_range_of(a) if isinstance(a, np.ndarray) and a.flags.c_contiguous else None
   if where is None:
     with warnings.catch_warnings():
       warnings.simplefilter("ignore")  # non-writable buffer warning for mmap views
       return torch.from_numpy(np.ascontiguousarray(a)).to(device(), non_blocking=True)
-  path, offset = where
-  fd = _FILE_FDS.get(path)
-  if fd is None:
-    fd = _FILE_FDS[path] = os.open(path, os.O_RDONLY)
+  fd, offset = where        # (mi355q_file_to_device returns when its preads are done: `a` keeps the mapping, and so fd, alive)
   dev = device()
   copy_stream = _copy_stream(dev)
   n = a.nbytes
@@ -185,16 +235,12 @@ def finish_downloads() -> None:
 
 
 def release_upload_files() -> None:
-  """Closes the model files opened for pread (after the transfers that read them have left)."""
-  import os
+  """Waits for the uploads in flight. (The descriptors belong to the mappings they were
+  duplicated for and are closed when those are unmapped: _FileMapping.)"""
   for st in _COPY_STREAMS.values():
     st.synchronize()
-  for fd in _FILE_FDS.values():
-    try:
-      os.close(fd)
-    except OSError:
-      pass
-  _FILE_FDS.clear()
+  for rec in [m for m in _FILE_MAPPINGS if not m.alive()]:
+    rec._gone()  # pylint: disable=protected-access
 
 
 def release_upload_staging() -> None:

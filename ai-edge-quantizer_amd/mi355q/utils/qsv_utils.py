@@ -89,9 +89,17 @@ def gptq_and_moving_average_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qt
   if not qsv:
     return new_qsv
   out = moving_average_update(qsv, new_qsv)
-  if "hessian" not in qsv and "hessian" not in new_qsv:
-    # a tensor no op reads a Hessian from (Calibrator(hessians="consumed")): min / max / count only
-    out["num_samples"] = qsv["num_samples"] + new_qsv["num_samples"]
+  if "hessian" not in qsv or "hessian" not in new_qsv:
+    # Neither side: a tensor no op reads a Hessian from (Calibrator(hessians="consumed")): min / max /
+    # count only. One side only (a resumed calibration whose earlier result came from hessians="all",
+    # an earlier build or the reference, where every runtime tensor carries one; or a tensor read by a
+    # GPTQ op under one signature's plan only): the samples of the side without a Hessian cannot
+    # weigh in, so the existing Hessian is kept as the mean over ITS samples and the counts add --
+    # the Hessian of a tensor nobody reads is never looked at, and a reader's always has both sides.
+    out["num_samples"] = qsv.get("num_samples", 0) + new_qsv.get("num_samples", 0)
+    kept = qsv.get("hessian", new_qsv.get("hessian"))
+    if kept is not None:
+      out["hessian"] = kept
     return out
   out["hessian"], out["num_samples"] = _gptq_merge_hessian(qsv, new_qsv)
   return out

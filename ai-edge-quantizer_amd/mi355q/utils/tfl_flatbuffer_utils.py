@@ -106,11 +106,11 @@ def get_model_content(tflite_path: Path) -> memoryview:
     if os.fstat(f.fileno()).st_size == 0:
       raise ValueError(f"{tflite_path} is empty")
     mapping = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
-  try:
-    from .. import runtime          # (weights that are views of this mapping can be read from the file)
-    runtime.register_file_mapping(mapping, os.path.abspath(tflite_path))
-  except Exception:  # noqa: BLE001 - host-only tools import this module without a GPU runtime
-    pass
+    try:
+      from .. import runtime          # (weights that are views of this mapping can be read from the file)
+      runtime.register_file_mapping(mapping, f.fileno())
+    except Exception:  # noqa: BLE001 - host-only tools import this module without a GPU runtime
+      pass
   return memoryview(mapping)
 
 

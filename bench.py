@@ -43,7 +43,8 @@ ALG_BYTES = ROWS * COLS * 4 + ROWS * COLS + ROWS * 4 + ROWS
 
 def parse():
   p = argparse.ArgumentParser()
-  p.add_argument("--gpus", type=int, default=1)
+  p.add_argument("--gpus", type=int, default=None,
+                 help="ranks = GPUs of this node; a plain `python bench.py --gpus N` starts the N ranks itself")
   p.add_argument("--steps", type=int, default=200)
   p.add_argument("--warmup", type=int, default=20)
   p.add_argument("--cpu-seconds", type=float, default=10.0,
@@ -368,16 +369,53 @@ def collective_probe(torch, dist, rank, world, backend):
   return res
 
 
+def free_port() -> int:
+  import socket
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def launch_command(gpus: int, argv, port: int):
+  """The command line a plain `python bench.py --gpus N` turns itself into: N ranks of this
+  node, one per GPU, rendezvous on the loopback address (the container's hostname may not resolve)."""
+  return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(args) -> int:
+  """`--gpus N` (N > 1) without a launcher's environment: start the N ranks here and hand back
+  their exit status. Rank 0's JSON line goes to this process's stdout (inherited)."""
+  import subprocess
+  backend = os.environ.get("MI355Q_BENCH_BACKEND", "nccl")
+  if backend == "nccl":
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+      raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (one rank per GPU over RCCL;"
+                       " MI355Q_BENCH_BACKEND=gloo shares cuda:0 for a control-path check)")
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  env.setdefault("OMP_NUM_THREADS", "8")
+  cmd = launch_command(args.gpus, sys.argv[1:], free_port())
+  print("bench.py: starting " + " ".join(cmd[1:8]) + " ...", file=sys.stderr, flush=True)
+  return subprocess.run(cmd, env=env).returncode
+
+
 def main():
   args = parse()
+  if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+    sys.exit(spawn_ranks(args))
   import torch
   import torch.distributed as dist
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
+  if args.gpus is not None and args.gpus != world:
+    raise SystemExit(f"bench.py --gpus {args.gpus} inside a launcher with WORLD_SIZE={world}: they must agree")
   if not torch.cuda.is_available():
-    raise SystemExit("bench.py needs a GPU (no CPU fallback on the product path)")
+    raise SystemExit(f"bench.py needs a GPU (no CPU fallback on the product path); rank {rank} of {world}")
   # MI355Q_BENCH_BACKEND=gloo lets the N > 1 control path (barriers, max-reduce, rank-0 line) be
   # exercised on a one-GPU box: all ranks then share cuda:0 (RCCL refuses duplicate devices)
   backend = os.environ.get("MI355Q_BENCH_BACKEND", "nccl")

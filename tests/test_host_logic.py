@@ -1,6 +1,8 @@
 """CPU-only tests of the host side of the drop-in layer: value types, registry,
 recipe resolution, the O(#scales) parameter math and argument validation that
 happens before any kernel is launched."""
+import os
+
 import numpy as np
 import pytest
 
@@ -455,3 +457,85 @@ def test_quantizer_recipe_editing_api_and_policy_file(tmp_path):
           weight_tensor_config=q.TensorQuantizationConfig(num_bits=4), compute_precision=q.ComputePrecision.INTEGER))
   finally:
     am.register_config_check_policy_func("min_max_uniform_quantize", default_policy.DEFAULT_CONFIG_CHECK_POLICY)
+
+
+# ---- runtime: the registry of mapped model files ---------------------------
+def _mapped_weights(tmp_path, name, nbytes):
+  from mi355q.utils import tfl_flatbuffer_utils
+  path = tmp_path / name
+  path.write_bytes(bytes(range(256)) * (nbytes // 256))
+  view = tfl_flatbuffer_utils.get_model_content(str(path))
+  return path, view
+
+
+def test_file_mapping_registry_dies_with_the_mapping(tmp_path, monkeypatch):
+  """A weight that is a view of a live registered mapping resolves to (descriptor, offset); once
+  the mapping is gone no array -- wherever the allocator puts it -- resolves to the dead file."""
+  import gc
+  from mi355q import runtime as rt
+  monkeypatch.setattr(rt, "_UPLOAD_MIN_FILE_BYTES", 1 << 20)
+  before = len(rt._FILE_MAPPINGS)
+  path, view = _mapped_weights(tmp_path, "a.bin", 8 << 20)
+  assert len(rt._FILE_MAPPINGS) == before + 1
+  rec = rt._FILE_MAPPINGS[-1]
+  w = np.frombuffer(view[4096:4096 + (4 << 20)], dtype=np.float32)
+  fd, off = rt._file_range_of(w)
+  assert off == 4096 and fd == rec.fd and os.fstat(fd).st_ino == os.stat(path).st_ino
+  # the file is replaced under the same path: the descriptor still names the mapped inode
+  os.replace(path, str(path) + ".old")
+  path.write_bytes(b"\0" * 16)
+  assert os.fstat(rt._file_range_of(w)[0]).st_ino == os.stat(str(path) + ".old").st_ino
+  # an array that is NOT a view of the mapping but lies inside its address range (simulated: a
+  # fake record over a plain array's addresses) is not taken for the file
+  plain = np.zeros(1 << 20, np.uint8)
+  fake = rt._FileMapping.__new__(rt._FileMapping)
+  fake.base, fake.length, fake.fd, fake.ref = plain.ctypes.data, plain.nbytes, rec.fd, rec.ref
+  rt._FILE_MAPPINGS.append(fake)
+  try:
+    assert rt._file_range_of(plain[: 1 << 19]) is None
+  finally:
+    rt._FILE_MAPPINGS.remove(fake)
+  held_fd = rec.fd
+  del w, view
+  gc.collect()
+  assert rec not in rt._FILE_MAPPINGS and rec.fd == -1 and len(rt._FILE_MAPPINGS) == before
+  with pytest.raises(OSError):
+    os.fstat(held_fd)
+  fresh = [np.zeros(4 << 20, np.uint8) for _ in range(4)]
+  assert all(rt._file_range_of(a) is None for a in fresh)
+
+
+# ---- GPTQ statistics with a Hessian on one side only (ADVICE r03) -----------------------------
+def test_gptq_update_with_a_hessian_on_one_side_only():
+  """A calibration resumed from a result in the reference's layout (every runtime tensor carries a
+  Hessian) against this build's default (only read Hessians exist): the merge must not index a
+  missing "hessian"; the existing one is kept, the counts add, min / max follow the moving average."""
+  from mi355q.utils import qsv_utils
+  h = np.eye(4) * 3.0
+  with_h = {"min": np.array([[-1.0]], np.float32), "max": np.array([[2.0]], np.float32), "hessian": h, "num_samples": 5}
+  without = {"min": np.array([[-3.0]], np.float32), "max": np.array([[1.0]], np.float32), "num_samples": 7}
+  for a, b in ((with_h, without), (without, with_h)):
+    out = qsv_utils.gptq_and_moving_average_update(dict(a), dict(b))
+    assert out["num_samples"] == 12 and out["hessian"] is h
+    ema = qsv_utils.moving_average_update(dict(a), dict(b))
+    assert np.array_equal(out["min"], ema["min"]) and np.array_equal(out["max"], ema["max"])
+  out = qsv_utils.gptq_and_moving_average_update(dict(without), dict(without))
+  assert "hessian" not in out and out["num_samples"] == 14
+
+
+def test_sharded_quantize_refuses_a_gptq_op_whose_hessian_went_elsewhere():
+  from mi355q import distributed as D
+  w = q.TensorT(name=b"w", shape=[4, 8], buffer=1)
+  x = q.TensorT(name=b"x", shape=[1, 8], buffer=0)
+  y = q.TensorT(name=b"y", shape=[1, 4], buffer=0)
+  buffers = [q.BufferT(), q.BufferT(data=np.zeros(128, np.uint8))]
+  gi = q.GraphInfo([x, w, y], buffers)
+  op = q.OperatorT(inputs=[0, 1, -1], outputs=[2])
+  item = (gi, op, None, q.TFLOperationName.FULLY_CONNECTED, am.AlgorithmName.GPTQ, None)
+  ok = {"x": {"min": 0, "max": 1, "num_samples": 3, "hessian": np.eye(8)}}
+  D._require_hessians_where_read([item], ok, 1)
+  D._require_hessians_where_read([item], {}, 1)                      # uncalibrated: the reference's min / max path
+  with pytest.raises(RuntimeError, match="reduced to another rank"):
+    D._require_hessians_where_read([item], {"x": {"min": 0, "max": 1, "num_samples": 3}}, 1)
+  other = (gi, op, None, q.TFLOperationName.FULLY_CONNECTED, am.AlgorithmName.MIN_MAX_UNIFORM_QUANT, None)
+  D._require_hessians_where_read([other], {"x": {"min": 0, "max": 1, "num_samples": 3}}, 1)
