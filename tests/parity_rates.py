@@ -42,6 +42,35 @@ def check(name: str, got, ref, bound: float, max_step: int = 1) -> float:
   return frac
 
 
+def _mismatch(a, b) -> tuple[float, int]:
+  a, b = np.asarray(a), np.asarray(b)
+  assert a.shape == b.shape, (a.shape, b.shape)
+  diff = np.abs(a.astype(np.int32) - b.astype(np.int32))
+  return (float((diff != 0).mean()) if diff.size else 0.0), (int(diff.max()) if diff.size else 0)
+
+
+def check_with_floor(name: str, got, ref, ref_reordered, cap: float, k: float = 2.0, max_step: int = 1) -> float:
+  """A comparison whose reference is itself order-dependent (the reference runs sgemm / LAPACK): the
+  oracle is evaluated twice -- as the reference states the arithmetic (`ref`) and with one float32
+  sum taken in another order (`ref_reordered`: what a BLAS with another K blocking or thread count
+  returns) -- and THREE rates are recorded: GPU vs oracle, GPU vs re-ordered oracle, oracle vs
+  re-ordered oracle (the floor any implementation of that arithmetic sits on).
+
+  Bound = min(cap, max(T2, k * floor)). `cap` is a constant written in the test (<= 2 x the rate
+  recorded when it was written): a change that inflates the floor cannot loosen the gate unnoticed."""
+  frac, worst = _mismatch(got, ref)
+  frac_b, worst_b = _mismatch(got, ref_reordered)
+  floor, _ = _mismatch(ref, ref_reordered)
+  bound = min(cap, max(T2, k * floor))
+  _append({"test": name, "kind": "int_mismatch_fraction", "observed": frac, "max_step": worst, "bound": bound,
+           "elements": int(np.asarray(got).size), "vs_reordered_oracle": frac_b, "oracle_vs_reordered_oracle": floor,
+           "cap": cap, "floor_factor": k})
+  assert worst <= max_step and worst_b <= max_step, f"{name}: a value differs by {max(worst, worst_b)} steps"
+  assert frac <= bound, (f"{name}: {frac:.3e} of the integers differ (bound {bound:.1e} = min(cap {cap:.1e}, max(T2, {k} x floor"
+                         f" {floor:.3e})); vs the re-ordered oracle {frac_b:.3e})")
+  return frac
+
+
 def check_rel(name: str, got, ref, bound: float) -> float:
   """Floating-point results: max |got - ref| / max |ref| <= bound."""
   got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)

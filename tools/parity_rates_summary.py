@@ -20,9 +20,13 @@ def main():
   print("# T2 comparisons of `pytest -m gpu` on MI355X: observed vs asserted bound")
   print("# (int_mismatch_fraction: share of integers that differ from the oracle / reference fixture,")
   print("#  never by more than one step; bounds are <= 10 x observed, floor 1e-5 = SURVEY section 7)")
-  print(f"{'observed':>11} {'bound':>8} {'step':>4} {'elements':>9}  kind / comparison")
+  print("# floor-based comparisons (tests/parity_rates.py check_with_floor) carry three rates: GPU vs oracle (observed), GPU vs the")
+  print("#  oracle with one float32 sum re-ordered (vs_reord), oracle vs re-ordered oracle (floor); bound = min(cap, max(1e-5, k x floor))")
+  print(f"{'observed':>11} {'bound':>8} {'step':>4} {'elements':>9} {'vs_reord':>10} {'floor':>10} {'cap':>8}  kind / comparison")
   for name, r in rows.items():
-    print(f"{r['observed']:11.3e} {r['bound']:8.0e} {str(r.get('max_step', '-')):>4} {str(r.get('elements', '-')):>9}"
+    three = (f"{r['vs_reordered_oracle']:10.3e} {r['oracle_vs_reordered_oracle']:10.3e} {r['cap']:8.0e}" if "cap" in r
+             else f"{'-':>10} {'-':>10} {'-':>8}")
+    print(f"{r['observed']:11.3e} {r['bound']:8.0e} {str(r.get('max_step', '-')):>4} {str(r.get('elements', '-')):>9} {three}"
           f"  {r['kind']}: {name}")
 
 
