@@ -119,6 +119,21 @@ __global__ __launch_bounds__(256) void unpack_lower_f64_kernel(const double* __r
   }
 }
 
+// The same for the float32 product (lower triangle valid on both sides): pack, and unpack into the lower triangle.
+__global__ __launch_bounds__(256) void pack_lower_f32_kernel(const float* __restrict__ p, long long d, float* __restrict__ packed) {
+  const long long i = blockIdx.y;
+  const long long row = i * (i + 1) / 2;
+  for (long long j = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; j <= i; j += static_cast<long long>(gridDim.x) * 256)
+    packed[row + j] = p != nullptr ? p[i * d + j] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void unpack_lower_f32_kernel(const float* __restrict__ packed, long long d, float* __restrict__ p) {
+  const long long i = blockIdx.y;
+  const long long row = i * (i + 1) / 2;
+  for (long long j = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; j <= i; j += static_cast<long long>(gridDim.x) * 256)
+    p[i * d + j] = packed[row + j];
+}
+
 inline ncclComm_t as_comm(void* c) { return reinterpret_cast<ncclComm_t>(c); }
 
 }  // namespace
@@ -267,6 +282,45 @@ extern "C" int32_t mi355q_reduce_hessian_f64(void* comm, double* hessian, int64_
     const unsigned t32 = static_cast<unsigned>((d + 31) / 32);
     hipLaunchKernelGGL(unpack_lower_f64_kernel, dim3(t32, t32), dim3(256), 0, st, packed, static_cast<long long>(d), hessian);
     MI355Q_CHECK_LAUNCH("hessian unpack launch");
+  }
+  return MI355Q_OK;
+}
+
+extern "C" size_t mi355q_product_exchange_workspace_bytes(int64_t d) {
+  if (d <= 0) return 0;
+  return static_cast<size_t>(d) * static_cast<size_t>(d + 1) / 2 * sizeof(float);
+}
+
+extern "C" int32_t mi355q_reduce_product_f32(void* comm, float* product, int64_t d, int32_t root, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (!comm) return fail(MI355Q_BAD_ARG, "null communicator");
+  if (d < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (d == 0) return MI355Q_OK;
+  if (d > 0x7FFFFFFF) return fail(MI355Q_UNSUPPORTED, "dimension too large");
+  const size_t need = mi355q_product_exchange_workspace_bytes(d);
+  if (!workspace || workspace_bytes < need) return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  const Rccl* R = rccl();
+  if (!R) return no_rccl();
+  int nranks = 0, me = 0;
+  MI355Q_RCCL(R->CommCount(as_comm(comm), &nranks), "ncclCommCount");
+  MI355Q_RCCL(R->CommUserRank(as_comm(comm), &me), "ncclCommUserRank");
+  if (root >= nranks) return fail(MI355Q_BAD_ARG, "root %d of %d ranks", root, nranks);
+  const bool receives = root < 0 || root == me;
+  if (receives && !product) return fail(MI355Q_BAD_ARG, "the receiving rank needs a product buffer");
+  float* packed = static_cast<float*>(workspace);
+  const size_t n = static_cast<size_t>(d) * static_cast<size_t>(d + 1) / 2;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid(static_cast<unsigned>((d + 2047) / 2048 < 1 ? 1 : (d + 2047) / 2048), static_cast<unsigned>(d));
+  hipLaunchKernelGGL(pack_lower_f32_kernel, grid, dim3(256), 0, st, product, static_cast<long long>(d), packed);
+  MI355Q_CHECK_LAUNCH("product pack launch");
+  if (root < 0)
+    MI355Q_RCCL(R->AllReduce(packed, packed, n, ncclFloat32, ncclSum, as_comm(comm), st), "ncclAllReduce(product)");
+  else
+    MI355Q_RCCL(R->Reduce(packed, packed, n, ncclFloat32, ncclSum, root, as_comm(comm), st), "ncclReduce(product)");
+  if (receives) {
+    hipLaunchKernelGGL(unpack_lower_f32_kernel, grid, dim3(256), 0, st, packed, static_cast<long long>(d), product);
+    MI355Q_CHECK_LAUNCH("product unpack launch");
   }
   return MI355Q_OK;
 }

@@ -19,7 +19,7 @@
 // largest, below 2^-39 of that largest: 2^-22 of sum |x||y| per entry at the very worst, a few 1e-8
 // of it observed -- the accumulation order of the float32 sgemm this replaces moves its result
 // by more (4e-6 for the FP32 MFMA product, tests/test_gpu_gptq.py). Tolerance class T2.
-// MI355Q_XTX_BF16X3=1 selects the three-way split instead.
+// Selected by MI355Q_XTX_F16X2=1 (mi355q.ops.hessian_product("fast")); the three-way split is the default.
 //
 // Per slab of <= 16384 tokens:
 //   colmax  the largest finite |x| of every column (atomicMax on the bit patterns)
@@ -440,9 +440,14 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+// Opt-in (round 4): MI355Q_XTX_F16X2=1, read per call. The default Hessian product is the exact three-way bfloat16
+// split (xtx_bf16x3.hip): with it the d = 16384 GPTQ chain reproduces the oracle's integers (0 of 1 048 576,
+// profiles/r04_parity_rates.txt), with this kernel's 22-23 of 24 mantissa bits 1.2e-3 of them differ -- at the
+// reference's own re-ordering floor (1.5e-3), but parity comes before the 1.8 x this kernel is faster.
 bool xtx_f16x2_usable(int64_t n, int64_t d) {
-  return d % kTile == 0 && d >= 256 && n >= 1024 && getenv("MI355Q_XTX_FP32_MFMA") == nullptr &&
-         getenv("MI355Q_XTX_BF16X3") == nullptr;
+  const char* fast = getenv("MI355Q_XTX_F16X2");
+  return fast != nullptr && fast[0] != '\0' && fast[0] != '0' && d % kTile == 0 && d >= 256 && n >= 1024 &&
+         getenv("MI355Q_XTX_FP32_MFMA") == nullptr && getenv("MI355Q_XTX_BF16X3") == nullptr;
 }
 
 size_t xtx_f16x2_workspace_bytes(int64_t n, int64_t d) {

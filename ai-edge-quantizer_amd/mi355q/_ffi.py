@@ -91,6 +91,8 @@ PROTOTYPES = {
     "mi355q_allreduce_hessian_f64": (c_i32, [c_ptr, c_ptr, c_i64, c_f64, c_ptr]),
     "mi355q_hessian_exchange_workspace_bytes": (c_size, [c_i64]),
     "mi355q_reduce_hessian_f64": (c_i32, [c_ptr, c_ptr, c_i64, c_f64, c_i32, c_ptr, c_size, c_ptr]),
+    "mi355q_product_exchange_workspace_bytes": (c_size, [c_i64]),
+    "mi355q_reduce_product_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_size, c_ptr]),
     "mi355q_file_to_device": (c_i32, [c_i32, c_i64, c_i64, c_ptr, c_ptr]),
     "mi355q_device_to_file": (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr]),
     "mi355q_file_io_finish": (c_i32, []),

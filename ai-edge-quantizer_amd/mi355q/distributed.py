@@ -701,6 +701,31 @@ def allreduce_hessian(weighted_sum, num_samples: int, group=None):
 allreduce_second_moment = allreduce_hessian   # OSCAR mu2: same sample-weighted mean
 
 
+def _product_form_everywhere(names: Sequence[str], local: dict, group, comm) -> dict[str, bool]:
+  """name -> every rank's statistic of it is a float32 product (or the rank saw no sample of it): what the product-form
+  exchange needs. One small all-reduce(min) for all names. MI355Q_X2_F64=1 keeps the float64 exchange."""
+  if os.environ.get("MI355Q_X2_F64"):
+    return {}
+  flags = []
+  for name in names:
+    h = local.get(name, (None, 0.0))[0]
+    flags.append(1.0 if h is None or (hasattr(h, "product_form") and h.product_form() is not None) else 0.0)
+  if not flags:
+    return {}
+  if comm is not None:
+    from . import _ffi
+    from . import runtime as rt
+    lo = torch.tensor(flags, dtype=torch.float32, device=rt.device())
+    hi = lo.clone()
+    _ffi.check(_ffi.lib().mi355q_allreduce_minmax_f32(comm, rt.ptr(lo), rt.ptr(hi), lo.numel(), rt.stream_ptr()))
+    agreed = lo.cpu().tolist()
+  else:
+    t = torch.tensor(flags, dtype=torch.float32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    agreed = t.tolist()
+  return {name: v >= 1.0 for name, v in zip(names, agreed)}
+
+
 def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dict[str, tuple[int, float]],
                                 group=None, owners: Optional[dict[str, int]] = None) -> dict[str, Any]:
   """X2: the sample-weighted mean of every GPTQ Hessian over all ranks.
@@ -712,7 +737,11 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
   spent on counts). Per distinct Hessian, in sorted-name order on every rank: the packed lower
   triangle of H_rank * n_rank / N (the matrix is symmetric: d (d + 1) / 2 float64, 1 GiB at
   d = 16384 instead of 2) goes through one collective -- mi355q_reduce_hessian_f64 over RCCL when
-  ranks own GPUs; nothing d x d is ever pickled. `owners` (tensor name -> rank, from
+  ranks own GPUs; nothing d x d is ever pickled. Round 4: when every rank holds the statistic as the
+  float32 product it accumulated (gptq.HessianAccumulator: the normal case on GPUs) the PRODUCTS are
+  summed instead -- mi355q_reduce_product_f32: packed float32 triangle, 0.5 GiB at d = 16384, no
+  float64 d x d array on any rank -- and the receiving ranks keep product form (the damped inverse
+  reads it as it is). Equal to the float64 exchange within float32 summation (1e-7 relative). `owners` (tensor name -> rank, from
   hessian_owners(): the one rank whose ops read that Hessian) turns the all-reduce into a reduce to
   that rank, half the ring traffic again; without it every rank ends with every mean.
   Returns {name: H} (runtime.HbmArray when the data lives in HBM) for the Hessians this rank holds.
@@ -729,13 +758,39 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
     from . import runtime as rt
     ops.release_scratch()
   scratch = None
-  for name in sorted(totals):
+  names = sorted(totals)
+  in_product_form = _product_form_everywhere(names, local, group, comm) if (world > 1 and on_gpu) else {}
+  for name in names:
     d, total = totals[name]
     h, n_rank = local.get(name, (None, 0.0))
     root = -1 if owners is None else int(owners.get(name, -1))
     mine = root < 0 or root == rank
     if world == 1:
       out[name] = h
+      continue
+    if in_product_form.get(name):
+      # the statistic travels in the form it is kept in: the float32 product's packed lower triangle, summed in
+      # float32 (0.5 GiB per d = 16384 Hessian); the receiving ranks keep it as a product (alpha = 2 / N)
+      from .algorithms.uniform_quantize import gptq
+      prod = None if h is None else h.product_form()[0]
+      if prod is None and mine:
+        prod = torch.zeros((d, d), dtype=torch.float32, device=rt.device())
+      if comm is not None:
+        L = _ffi.lib()
+        need = L.mi355q_product_exchange_workspace_bytes(d)
+        if scratch is None or scratch.numel() < need:
+          scratch = None
+          scratch = rt.empty((need,), torch.uint8)
+        _ffi.check(L.mi355q_reduce_product_f32(comm, rt.ptr(prod), d, root, rt.ptr(scratch), scratch.numel(), rt.stream_ptr()))
+      else:                                                     # test transport: ranks share a GPU
+        host = torch.zeros((d, d), dtype=torch.float32) if prod is None else torch.tril(prod).cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        if mine:
+          prod.copy_(host)
+      if mine:
+        acc = gptq.HessianAccumulator(d)
+        acc._prod, acc._n_prod = prod, float(total)   # pylint: disable=protected-access
+        out[name] = acc
       continue
     weight = float(n_rank) / float(total) if total else 0.0
     if on_gpu:

@@ -499,6 +499,36 @@ def gptq_hinv_batched(hessians, damp_factor: float = 0.01):
   return [(hinv[i], info[i:i + 1]) for i in range(n)]
 
 
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def hessian_product(mode: str = "exact"):
+  """The kernel GPTQ's Hessian products (mi355q_gptq_xtx_f32 / _accum_f32) run on inside this block.
+
+  "exact" (the default everywhere): every float32 product from the exact three-way bfloat16 split, six
+  bf16 MFMA products (xtx_bf16x3.hip) -- float32-sgemm-class like the reference's x.T.dot(x), and what the
+  recorded parity rates are taken with (the d = 16384 chain reproduces the oracle's integers).
+  "fast": the two-way float16 split, three f16 MFMA products, 22-23 of the 24 mantissa bits, 1.8 x faster;
+  1.2e-3 of the d = 16384 integers then differ from the oracle's (profiles/r04_parity_rates.txt). The
+  library reads MI355Q_XTX_F16X2 per call, which is what this sets."""
+  import os
+  if mode not in ("exact", "fast"):
+    raise ValueError("hessian_product mode must be 'exact' or 'fast'")
+  before = os.environ.get("MI355Q_XTX_F16X2")
+  if mode == "fast":
+    os.environ["MI355Q_XTX_F16X2"] = "1"
+  else:
+    os.environ.pop("MI355Q_XTX_F16X2", None)
+  try:
+    yield
+  finally:
+    if before is None:
+      os.environ.pop("MI355Q_XTX_F16X2", None)
+    else:
+      os.environ["MI355Q_XTX_F16X2"] = before
+
+
 def gptq_apply(w: torch.Tensor, hinv: torch.Tensor, scale: torch.Tensor,
                zero_point: torch.Tensor | None, scale_mode: int, block_size: int, bits: int,
                narrow: bool, zp_via_f64: bool, diff_bits: int) -> torch.Tensor:

@@ -225,6 +225,8 @@ def more_extras(torch, ops, gen, xs) -> dict:
     x = torch.randn((tokens, d), generator=gen, device="cuda")
     reps = 10 if d == 2048 else 3
     ms_h = timed_ms(torch, lambda: ops.gptq_xtx(x, 2.0 / 128), reps, 1)
+    with ops.hessian_product("fast"):
+      ms_h_fast = timed_ms(torch, lambda: ops.gptq_xtx(x, 2.0 / 128), reps, 1)
     h = ops.gptq_xtx(x, 2.0 / 128)
     del x
     ms_i = timed_ms(torch, lambda: ops.gptq_hinv(h, 0.01), reps, 1)
@@ -236,13 +238,18 @@ def more_extras(torch, ops, gen, xs) -> dict:
     # the triangular product computes half of 2 n d^2; the inverse is d^3 (Cholesky + triangular inverse + product)
     c5[f"d{d}"] = {
         "hessian": {"ms": round(ms_h, 3), "tokens": tokens,
-                    "roofline": {"bound": "mfma", "achieved": round(3 * tokens * d * d / ms_h / 1e9, 1), "peak": MFMA_BF16_PEAK_TF,
-                                 "unit": "TFLOP/s", "frac": round(3 * tokens * d * d / ms_h / 1e9 / MFMA_BF16_PEAK_TF, 4),
-                                 "flops": "3 n d^2: lower triangle of X^T X, every float32 product as three f16 MFMA products"
-                                          " (two-way float16 split of both operands, xtx_f16x2.hip; the f16 and bf16 dense peaks are"
-                                          " the same); the kernel runs at the socket's power limit, profiles/r03_xtx_f16x2.txt",
+                    "roofline": {"bound": "mfma", "achieved": round(6 * tokens * d * d / ms_h / 1e9, 1), "peak": MFMA_BF16_PEAK_TF,
+                                 "unit": "TFLOP/s", "frac": round(6 * tokens * d * d / ms_h / 1e9 / MFMA_BF16_PEAK_TF, 4),
+                                 "flops": "6 n d^2: lower triangle of X^T X, every float32 product as six bf16 MFMA products (the exact"
+                                          " three-way bfloat16 split of both operands, xtx_bf16x3.hip: the default since round 4 -- with"
+                                          " it the d = 16384 GPTQ chain reproduces the oracle's integers, profiles/r04_parity_rates.txt)",
                                  "float32_product_TFLOPs": round(tokens * d * d / ms_h / 1e9, 1),
-                                 "mfma_f32_peak": MFMA_F32_PEAK_TF}},
+                                 "mfma_f32_peak": MFMA_F32_PEAK_TF},
+                    "fast_f16x2": {"ms": round(ms_h_fast, 3), "how": "ops.hessian_product('fast') / MI355Q_XTX_F16X2=1",
+                                   "roofline_frac": round(3 * tokens * d * d / ms_h_fast / 1e9 / MFMA_BF16_PEAK_TF, 4),
+                                   "note": "two-way float16 split, three f16 MFMA products per float32 product, 22-23 of 24 mantissa"
+                                           " bits: 1.2e-3 of the d = 16384 integers differ from the oracle's (its own re-ordering"
+                                           " floor: 1.5e-3); opt-in"}},
         "hinv": {"ms": round(ms_i, 3),
                  "roofline": {"bound": "mfma", "achieved": round(d ** 3 / ms_i / 1e9, 1), "peak": MFMA_F64_PEAK_TF,
                               "unit": "TFLOP/s", "frac": round(d ** 3 / ms_i / 1e9 / MFMA_F64_PEAK_TF, 4),
@@ -286,11 +293,19 @@ def sharded_configs(torch, dist, rank, world, workdir):
       dist.barrier()
 
   def timed(fn):
+    """(seconds between the barriers = the job's time, every rank's own seconds before the closing barrier)."""
     barrier()
     t0 = time.perf_counter()
     fn()
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
     barrier()
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    per_rank = [round(own, 4)]
+    if world > 1:
+      per_rank = [None] * world
+      dist.all_gather_object(per_rank, round(own, 4))
+    return dt, per_rank
   out = {}
   # ---- C3
   layers, rows, cols = 32, 4096, 11008
@@ -300,8 +315,13 @@ def sharded_configs(torch, dist, rank, world, workdir):
   barrier()
   rcp = recipe.dynamic_wi4b128_afp32()
   D.quantize_model_sharded(src, rcp)                       # page cache + clocks warm
-  dt = min(timed(lambda: D.quantize_model_sharded(src, rcp, serialize_to_path=dst)) for _ in range(2))
+  dt, per_rank = min((timed(lambda: D.quantize_model_sharded(src, rcp, serialize_to_path=dst)) for _ in range(2)), key=lambda r: r[0])
+  _, _, _, owner, costs = D.plan_model_shards(src, rcp, world)
+  loads = D.plan_loads(costs, owner, world)
   out["c3_32x4096x11008_int4_b128"] = {"seconds": round(dt, 4), "weight_GBps": round(layers * rows * cols * 4 / dt / 1e9, 2),
+                                       "seconds_per_rank": per_rank,
+                                       "plan": {"ops_per_rank": [owner.count(r) for r in range(world)],
+                                                "makespan_over_mean": round(max(loads) / (sum(loads) / world), 3) if sum(loads) else None},
                                        "note": "file in (mmap, H2D) -> ops sharded by cost -> gather to rank 0 -> file out"}
   barrier()
   if rank == 0:
@@ -316,19 +336,20 @@ def sharded_configs(torch, dist, rank, world, workdir):
   data = {"serving_default": [pool[k % 4] for k in range(512)]}
   static = recipe.static_wi8_ai8()
   D.calibrate_sharded(model, static, {"serving_default": data["serving_default"][:2 * world]})
-  dt = timed(lambda: D.calibrate_sharded(model, static, data))
+  dt, per_rank = timed(lambda: D.calibrate_sharded(model, static, data))
   out["c4_512_samples_static_wi8_ai8"] = {"seconds": round(dt, 4), "samples_per_s": round(512 / dt, 1),
+                                          "seconds_per_rank": per_rank, "samples_per_rank": [len(D.sample_shard(512, r, world)) for r in range(world)],
                                           "activation_GBps": round(512 * 32 * 256 * 4096 * 4 / dt / 1e9, 1),
                                           "note": "samples resident in HBM; statistics all-gathered, replayed in dataset order"}
   del pool, data, model
   # ---- C5
   c5dir = c5_model.scratch_dir(20 << 30, workdir)
   c5src = c5_model.prepare(18, workdir=c5dir)
-  for variant in ("gptq", "mixed"):
-    res = c5_model.run(18, 128, 512, variant, workdir=c5dir, src=c5src, phases=(world == 1))
+  for variant, hessian in (("gptq", "exact"), ("gptq", "fast"), ("mixed", "exact")):
+    res = c5_model.run(18, 128, 512, variant, workdir=c5dir, src=c5src, phases=True, hessian=hessian)
     if rank == 0:
       res.pop("trace", None)
-      out[f"c5_{variant}"] = res
+      out[f"c5_{variant}" + ("_fast_hessian" if hessian == "fast" else "")] = res
   barrier()
   if rank == 0 and os.path.exists(c5src):
     os.remove(c5src)

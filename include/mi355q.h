@@ -481,6 +481,19 @@ int32_t mi355q_allreduce_hessian_f64(void* comm, double* hessian, int64_t d, dou
 size_t mi355q_hessian_exchange_workspace_bytes(int64_t d);
 int32_t mi355q_reduce_hessian_f64(void* comm, double* hessian, int64_t d, double weight, int32_t root,
                                   void* workspace, size_t workspace_bytes, void* stream);
+/* X2 in the form the statistic is kept in: the mean of ref utils/qsv_utils.py:71-102 over all samples is
+ * (2 / N) * sum over ranks of P_rank, P_rank = sum of X^T X over the rank's own samples -- the FLOAT32
+ * product mi355q_gptq_xtx_accum_f32 accumulates (lower triangle valid). Only that triangle travels, as
+ * float32: d (d + 1) / 2 * 4 bytes, 0.5 GiB at d = 16384 (a quarter of the float64 all-reduce, half of the
+ * packed float64 reduce), summed across ranks in float32 -- the precision in which a single process adds
+ * its own slabs' products -- by one reduce(sum) to `root` (root < 0: all-reduce). The receiving ranks end
+ * with the sum in `product`'s lower triangle and keep the statistic in product form
+ * (mi355q_gptq_hinv_from_product_f32 with alpha = 2 / N reads it as it is); no float64 d x d array is
+ * made on any rank. product == NULL: this rank saw no sample (it contributes zeros and must not be `root`).
+ * workspace: mi355q_product_exchange_workspace_bytes(d) bytes. */
+size_t mi355q_product_exchange_workspace_bytes(int64_t d);
+int32_t mi355q_reduce_product_f32(void* comm, float* product, int64_t d, int32_t root, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Model file <-> HBM without a host copy of the weights (the file path's io ring).

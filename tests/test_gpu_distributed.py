@@ -140,6 +140,18 @@ def _worker_rccl_single(rank, world, port, out):
     ok &= bool(np.array_equal(hs.cpu().numpy(), sym * 0.5))
   ok &= L.mi355q_reduce_hessian_f64(comm, rt.ptr(hs), 67, 0.5, 1, rt.ptr(ws), need, st) == -1      # no rank 1
   ok &= L.mi355q_reduce_hessian_f64(comm, rt.ptr(hs), 67, 0.5, 0, rt.ptr(ws), need - 8, st) == -1  # workspace too small
+  # the float32 product form (round 4): only the lower triangle travels and only it is written back
+  prod = torch.from_numpy(rng.standard_normal((67, 67)).astype(np.float32)).cuda()
+  need32 = L.mi355q_product_exchange_workspace_bytes(67)
+  ok &= need32 == 67 * 68 // 2 * 4
+  ws32 = torch.empty((need32,), dtype=torch.uint8, device="cuda")
+  for root in (-1, 0):
+    pp = prod.clone()
+    _ffi.check(L.mi355q_reduce_product_f32(comm, rt.ptr(pp), 67, root, rt.ptr(ws32), need32, st))
+    ok &= bool(torch.equal(pp, prod))                      # a world of one: the sum is the rank's own product
+  ok &= L.mi355q_reduce_product_f32(comm, None, 67, 0, rt.ptr(ws32), need32, st) == -1            # the receiving rank has no buffer
+  ok &= L.mi355q_reduce_product_f32(comm, rt.ptr(pp), 67, 1, rt.ptr(ws32), need32, st) == -1      # no rank 1
+  ok &= L.mi355q_reduce_product_f32(comm, rt.ptr(pp), 67, 0, rt.ptr(ws32), need32 - 4, st) == -1  # workspace too small
   ok &= L.mi355q_allreduce_sum_f32(None, rt.ptr(f32), 4, st) == -1                    # null communicator
   # a second communicator from an explicit unique-id hand-over (what a non-torch rendezvous would do)
   other = D.new_rccl_comm(0, 1, lambda uid: uid)
@@ -214,6 +226,14 @@ def _worker_calibrate_gptq(rank, world, port, out):
     return real_gather(parts, obj, group=group)
   dist.all_gather_object = counting_gather
   got = D.calibrate_sharded(path, _gptq_recipe(), data)
+  # the exchange above summed the ranks' float32 PRODUCTS (packed triangle); the float64 exchange of round 3
+  # (MI355Q_X2_F64=1: every rank's product scaled into a float64 Hessian first) must give the same mean
+  os.environ["MI355Q_X2_F64"] = "1"
+  got64 = D.calibrate_sharded(path, _gptq_recipe(), data)
+  del os.environ["MI355Q_X2_F64"]
+  h32, h64 = np.asarray(got["x"]["hessian"]), np.asarray(got64["x"]["hessian"])
+  rel_forms = float(np.max(np.abs(h32 - h64)) / np.max(np.abs(h64)))
+  kept_as_product = hasattr(got["x"]["hessian"], "product_form") and got["x"]["hessian"].product_form() is not None
   rm = recipe_manager.RecipeManager()
   rm.load_quantization_recipe(_gptq_recipe())
   single = calibrator.Calibrator(fu.read_model(path))
@@ -226,15 +246,18 @@ def _worker_calibrate_gptq(rank, world, port, out):
   ok &= all(np.array_equal(np.asarray(got[n][k]), np.asarray(want[n][k])) for n in want for k in ("min", "max"))
   ok &= int(got["x"]["num_samples"]) == int(want["x"]["num_samples"]) == sum(s["x"].shape[0] for s in data["serving_default"])
   ok &= "hessian_dim" not in got["x"]
-  out.put((rank, bool(ok), rel, max(sizes), hw.nbytes))
+  out.put((rank, bool(ok), rel, max(sizes), hw.nbytes, rel_forms, kept_as_product))
   dist.barrier()
   dist.destroy_process_group()
 
 
 def test_two_ranks_reduce_gptq_hessians_in_hbm():
   results = _run(_worker_calibrate_gptq, timeout=600)
-  for rank, ok, rel, gathered_bytes, hessian_bytes in results:
+  for rank, ok, rel, gathered_bytes, hessian_bytes, rel_forms, kept_as_product in results:
     assert ok, rank
+    # X2 as packed float32 product triangles against X2 as float64 Hessians: the same mean within float32 summation
+    assert rel_forms <= 1e-7, rel_forms
+    assert kept_as_product        # the receiving rank keeps product form: the damped inverse reads it as it is
     # vs the one-process calibration: every process multiplies the tokens of its own samples in one
     # float32-accumulated product (gptq.HessianAccumulator), so two ranks add two such products in FP64
     # where one process forms a single one -- float32 accumulation noise, far inside T2's 2e-6 (the

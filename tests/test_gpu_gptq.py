@@ -256,10 +256,30 @@ for d, n in ((256, 1024), (384, 1500), (2048, 20000)):
 """
 
 
-def test_hessian_bf16_split_product(m, tmp_path):
-  """d a multiple of 128 and >= 1024 tokens: X^T X runs on the f16 matrix cores, every float32
-  (scaled by a power of two per column) split into two float16 (xtx_f16x2.hip: 22 of the 24 bits,
-  three exact products per pair). Checked against the FP64 product (1e-6 of each
+import contextlib
+
+
+@contextlib.contextmanager
+def hessian_kernel(name):
+  """The split kernel the Hessian product of this block runs on: "bf16x3" (the default: exact three-way
+  bfloat16 split, six products) or "f16x2" (MI355Q_XTX_F16X2=1, read per call: two-way float16 split, 22-23
+  of the 24 bits, three products)."""
+  import os
+  assert name in ("bf16x3", "f16x2")
+  if name == "f16x2":
+    os.environ["MI355Q_XTX_F16X2"] = "1"
+  try:
+    yield
+  finally:
+    os.environ.pop("MI355Q_XTX_F16X2", None)
+
+
+@pytest.mark.parametrize("kernel", ["bf16x3", "f16x2"])
+def test_hessian_bf16_split_product(m, tmp_path, kernel):
+  """d a multiple of 128 and >= 1024 tokens: X^T X runs on the bf16 / f16 matrix cores: every float32
+  split into three bfloat16 (xtx_bf16x3.hip: all 24 bits, six exact products per pair; the default) or,
+  scaled by a power of two per column, into two float16 (xtx_f16x2.hip: 22 of the 24 bits,
+  three exact products per pair; MI355Q_XTX_F16X2=1). Checked against the FP64 product (1e-6 of each
   entry's own scale sum |x||y|: observed 3e-7, the FP32-MFMA path is allowed 4e-6), for exact
   symmetry and run-to-run determinism, over ragged token counts, a second slab that accumulates
   (20 000 tokens) and split-K partials, with entries across 30 binades and non-zero means; against
@@ -272,6 +292,8 @@ def test_hessian_bf16_split_product(m, tmp_path):
   import torch
   shapes = ((256, 1024), (384, 1500), (2048, 20000))
   got = {}
+  stack = contextlib.ExitStack()
+  stack.enter_context(hessian_kernel(kernel))
   for d, n in shapes:
     gen = torch.Generator(device="cuda").manual_seed(7 * d + n)
     x = torch.randn((n, d), generator=gen, device="cuda")
@@ -282,14 +304,17 @@ def test_hessian_bf16_split_product(m, tmp_path):
     # entries span 60 binades: the error is measured against the scale of each entry's own sum
     mag = (x.double().abs().T @ x.double().abs()) * (2.0 / n)
     err = float(((h - ref).abs() / mag).max())
-    parity_rates.note(f"hessian f16 split d={d} {n} tokens vs FP64 product (per-entry scale)", "max_rel_error", err, 1e-6)
+    parity_rates.note(f"hessian {kernel} split d={d} {n} tokens vs FP64 product (per-entry scale)", "max_rel_error", err, 1e-6)
     assert err <= 1e-6, (d, n, err)
     assert torch.equal(h, h.T)
     assert torch.equal(h, m.ops.gptq_xtx(x, 2.0 / n))
     got[(d, n)] = h.cpu()
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  for switch, bound in (("MI355Q_XTX_FP32_MFMA", 4e-6), ("MI355Q_XTX_BF16X3", 1e-6)):
-    env = dict(os.environ, **{switch: "1"})
+  other_split = {"MI355Q_XTX_F16X2": "1"} if kernel == "bf16x3" else {}
+  for switch, extra, bound in (("MI355Q_XTX_FP32_MFMA", {"MI355Q_XTX_FP32_MFMA": "1"}, 4e-6),
+                               ("the other split kernel", other_split, 1e-6)):
+    env = {k: v for k, v in os.environ.items() if k != "MI355Q_XTX_F16X2"}
+    env.update(extra)
     out = subprocess.run([sys.executable, "-c", _XTX_FP32_CHILD, root, str(tmp_path)], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -298,7 +323,7 @@ def test_hessian_bf16_split_product(m, tmp_path):
       x = torch.load(str(tmp_path / f"x_{d}_{n}.pt")).double()
       mag = (x.abs().T @ x.abs()) * (2.0 / n)
       diff = float(((got[(d, n)] - other).abs() / mag).max())
-      parity_rates.note(f"hessian f16 split vs {switch} d={d} {n} tokens (per-entry scale)", "max_rel_error", diff, bound)
+      parity_rates.note(f"hessian {kernel} split vs {switch} d={d} {n} tokens (per-entry scale)", "max_rel_error", diff, bound)
   # wide layer: slabs of 16384 tokens, the second one accumulates into the float32 product
   d, n = 8192, 17000
   gen = torch.Generator(device="cuda").manual_seed(11)
@@ -308,12 +333,13 @@ def test_hessian_bf16_split_product(m, tmp_path):
   ref = (x.double().T @ x[:, strip].double()) * (2.0 / n)
   mag = (x.double().abs().T @ x[:, strip].double().abs()) * (2.0 / n)
   err = float(((h[:, strip] - ref).abs() / mag).max())
-  parity_rates.note(f"hessian f16 split d={d} {n} tokens (two slabs) vs FP64 product (per-entry scale)", "max_rel_error", err, 1e-6)
+  parity_rates.note(f"hessian {kernel} split d={d} {n} tokens (two slabs) vs FP64 product (per-entry scale)", "max_rel_error", err, 1e-6)
   assert torch.equal(h, h.T)
   del x, h, ref, mag
   x = torch.randn((1024, 256), device="cuda")
   x[100, 7] = float("inf")
   h = m.ops.gptq_xtx(x, 2.0 / 1024)
+  stack.close()
   assert not bool(torch.isfinite(h[7]).all())
   _, info = m.ops.gptq_hinv(h, 0.01)
   assert int(info.item()) != 0
@@ -343,27 +369,30 @@ def test_hessian_wide_tiles_equal_narrow_tiles(m, tmp_path):
   x = torch.randn((16384 + 1777, 4096), generator=gen, device="cuda") * torch.exp2(
       torch.randint(-8, 8, (1, 4096), generator=gen, device="cuda").float()) + 0.125
   torch.save(x.cpu(), str(tmp_path / "x_wide.pt"))
-  wide = m.ops.gptq_xtx(x, 2.0 / x.shape[0])
+  with hessian_kernel("f16x2"):            # (the wide tiles belong to the two-way float16 kernel)
+    wide = m.ops.gptq_xtx(x, 2.0 / x.shape[0])
   ref = (x.double().T @ x.double()) * (2.0 / x.shape[0])
   mag = (x.double().abs().T @ x.double().abs()) * (2.0 / x.shape[0])
   err = float(((wide - ref).abs() / mag).max())
   parity_rates.note("hessian f16 split on 128 x 256 tiles, d=4096, 18161 tokens vs FP64 product (per-entry scale)", "max_rel_error", err, 1e-6)
   assert torch.equal(wide, wide.T)
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  out = subprocess.run([sys.executable, "-c", _XTX_NARROW_CHILD, root, str(tmp_path)], env=dict(os.environ, MI355Q_XTX_NARROW="1"),
+  out = subprocess.run([sys.executable, "-c", _XTX_NARROW_CHILD, root, str(tmp_path)], env=dict(os.environ, MI355Q_XTX_NARROW="1", MI355Q_XTX_F16X2="1"),
                        capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stderr[-2000:]
   assert torch.equal(wide.cpu(), torch.load(str(tmp_path / "narrow.pt")))
   del x, wide, ref, mag
   x = torch.randn((2048, 4352), generator=gen, device="cuda")
-  h = m.ops.gptq_xtx(x, 2.0 / 2048)
+  with hessian_kernel("f16x2"):
+    h = m.ops.gptq_xtx(x, 2.0 / 2048)
   ref = (x.double().T @ x.double()) * (2.0 / 2048)
   mag = (x.double().abs().T @ x.double().abs()) * (2.0 / 2048)
   assert float(((h - ref).abs() / mag).max()) <= 1e-6 and torch.equal(h, h.T)
 
 
+@pytest.mark.parametrize("kernel", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("kind", ["grid", "wide_range", "tiny", "huge", "integers", "constant", "outliers", "sparse"])
-def test_hessian_bf16_split_structured_inputs(m, kind):
+def test_hessian_bf16_split_structured_inputs(m, kind, kernel):
   """Inputs whose rounding errors are not random: values on a coarse grid (activations that were
   quantized before), columns spread over 80 binades inside one tensor, magnitudes near the bottom and
   the top of the float32 range (the per-column power of two keeps both float16 pieces in range; products
@@ -395,7 +424,8 @@ def test_hessian_bf16_split_structured_inputs(m, kind):
     x = x * (torch.rand((n, d), generator=gen, device="cuda") < 0.05)
   else:
     x = torch.full((n, d), 0.1, device="cuda")
-  h = m.ops.gptq_xtx(x, 2.0 / n)
+  with hessian_kernel(kernel):
+    h = m.ops.gptq_xtx(x, 2.0 / n)
   ref = (x.double().T @ x.double()) * (2.0 / n)
   assert torch.equal(h, h.T)
   if kind == "integers":
@@ -406,11 +436,11 @@ def test_hessian_bf16_split_structured_inputs(m, kind):
     err = float(((h - ref).abs() / (dg[:, None] * dg[None, :])).max())
     # (one product dominates such a sum and carries the split's full 2^-22; numpy's float32 x.T.dot(x) is at
     # 3.6e-6 on this input -- small terms added to a large float32 sum)
-    parity_rates.note("hessian f16 split, outlier activations, vs FP64 product (sqrt(H_ii H_jj) scale)", "max_rel_error", err, 4e-6)
+    parity_rates.note(f"hessian {kernel} split, outlier activations, vs FP64 product (sqrt(H_ii H_jj) scale)", "max_rel_error", err, 4e-6)
     return
   mag = (x.double().abs().T @ x.double().abs()) * (2.0 / n)
   err = float(((h - ref).abs() / mag.clamp_min(1e-300)).max())
-  parity_rates.note(f"hessian f16 split, {kind} inputs, vs FP64 product (per-entry scale)", "max_rel_error", err,
+  parity_rates.note(f"hessian {kernel} split, {kind} inputs, vs FP64 product (per-entry scale)", "max_rel_error", err,
                     2e-6 if kind == "constant" else 1e-6)
 
 

@@ -248,7 +248,7 @@ def prepare(layers=18, shapes=(D, DKV, DFF), workdir="/tmp"):
 
 
 def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="/tmp", bits=4,
-        shapes=(D, DKV, DFF), keep=False, phases=True, out_tokens=None, src=None):
+        shapes=(D, DKV, DFF), keep=False, phases=True, out_tokens=None, src=None, hessian="exact"):
   """One call -- litertlm_utils.quantize_litertlm(container, recipe, out, calibration_data=...) -- timed
   from opening the container to the written file. Returns a dict (rank 0) or None. Works under
   torchrun: samples and ops are sharded over the ranks, Hessians reduced to their owners."""
@@ -292,7 +292,8 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
     prof = cProfile.Profile()
     prof.enable()
   t0 = time.perf_counter()
-  n_out = litertlm_utils.quantize_litertlm(src, rcp, dst, overwrite=True, calibration_data=data, stats=stats)
+  with ops.hessian_product(hessian):      # "exact": the default three-way bfloat16 split; "fast": the opt-in two-way float16 one
+    n_out = litertlm_utils.quantize_litertlm(src, rcp, dst, overwrite=True, calibration_data=data, stats=stats)
   torch.cuda.synchronize()
   if prof is not None:
     import pstats
@@ -306,6 +307,14 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
   if timer:
     timer.__exit__()
   del data
+  # every rank's own account (a scaling run is read rank by rank: who waited for whom)
+  mine_rec = dict(rank=rank, samples=len(Dm.sample_shard(sequences // batch, rank, world)) if need_cal else 0,
+                  calibrate_s=round(stats.get("calibrate_s", 0.0), 3), quantize_and_write_s=round(stats.get("quantize_and_write_s", 0.0), 3),
+                  gpu_busy_s=None if busy is None else round(sum(busy.values()), 3), gpu_busy_by_family_s=busy)
+  per_rank = [mine_rec]
+  if world > 1:
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine_rec)
   if rank != 0:
     return None
   per = projections(d, dkv, dff)
@@ -313,6 +322,7 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
   _, _, plan, owner, costs = Dm.plan_model_shards(litertlm_utils.LiteRTLMFile(src).get_section_buffer(0), rcp, world)
   loads = Dm.plan_loads(costs, owner, world)
   out = dict(
+      hessian_product=hessian,
       workload=f"C5 {variant}: {layers} Gemma-2B-shaped layers (d={d}, kv={dkv}, ff={dff}) in a .litertlm,"
                f" {sequences} x {tokens} calibration tokens resident in HBM, int{bits} channelwise, one"
                " quantize_litertlm(calibration_data=...) call",
@@ -322,7 +332,7 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
       weight_GBps=round(weight_bytes / (t2 - t0) / 1e9, 2), out_bytes=n_out, build_s=round(t_build, 2),
       gpu_busy_s_rank0=busy, gpu_busy_total_s=None if busy is None else round(sum(busy.values()), 3),
       gpu_busy_frac=None if busy is None else round(sum(busy.values()) / (t2 - t0), 3),
-      trace=trace or None,
+      trace=trace or None, per_rank=per_rank,
       hbm=dict(device_allocations=torch.cuda.memory_stats().get("num_device_alloc"), peak_reserved_GiB=round(torch.cuda.max_memory_reserved() / 2**30, 1),
                peak_allocated_GiB=round(torch.cuda.max_memory_allocated() / 2**30, 1)),
       idle_gaps=(timer.gaps() if timer and os.environ.get("MI355Q_C5_GAPS") else None),
@@ -346,13 +356,14 @@ def main():
   ap.add_argument("--dir", default=None, help="default: /dev/shm when it has room, else $TMPDIR")
   ap.add_argument("--keep", action="store_true")
   ap.add_argument("--no-phases", action="store_true")
+  ap.add_argument("--hessian", default="exact", choices=("exact", "fast"), help="Hessian product: three-way bf16 split / two-way f16 split")
   a = ap.parse_args()
   import __graft_entry__ as g
   g.build()
   from mi355q import distributed as Dm
   rank, world = Dm.init()
   workdir = a.dir or scratch_dir(a.layers * 1000 * (1 << 20))
-  res = run(a.layers, a.sequences, a.tokens, a.variant, a.batch, workdir, a.bits, keep=a.keep, phases=not a.no_phases)
+  res = run(a.layers, a.sequences, a.tokens, a.variant, a.batch, workdir, a.bits, keep=a.keep, phases=not a.no_phases, hessian=a.hessian)
   if rank == 0:
     print(json.dumps(res), flush=True)
   if world > 1:

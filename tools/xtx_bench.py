@@ -16,7 +16,7 @@ for d, n in shapes:
   ref = x.double().T @ x[:, strip].double()
   mag = x.double().abs().T @ x[:, strip].double().abs()
   row = {"d": d, "tokens": n, "triangle_TFLOP": round(n * d * (d + 128) / 1e12, 2)}
-  for name, env in (("f16x2", None), ("bf16x3", "MI355Q_XTX_BF16X3")):
+  for name, env in (("f16x2", "MI355Q_XTX_F16X2"), ("bf16x3", None)):
     if env: os.environ[env] = "1"
     prod = ops.gptq_xtx_accum(x, None)
     torch.cuda.synchronize()
