@@ -1691,9 +1691,12 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
       // W[:, g1:] -= err[:, group] @ Hinv[g0:g1, g1:]. One K = 256 product rounds the far columns once
       // where the reference's per-block `W[:, rest] -= err_blk @ Hinv[blk, rest]` (gptq.py:213-214) rounds
       // them four times. At 4 bits that never moved an integer (0 of 393 216 against the oracle); on an
-      // 8-bit grid, 18 x finer, it did -- 2.4e-4 of them at [16384, 2048], where re-ordering the sums INSIDE
-      // the oracle's block products moves none -- so 8-bit targets take the reference's sequence: one
-      // product and one subtraction per 64-column block (a quarter of the speed-up of the lazy update).
+      // 8-bit grid, 18 x finer, it did, so 8-bit targets take the reference's sequence: one product and one
+      // subtraction per 64-column block (a quarter of the speed-up of the lazy update). What remains at 8 bits
+      // is the order of the float32 additions INSIDE a block's product: with the same inverse 63 of 262 144
+      // integers at [16384, 2048] differ from the as-stated oracle (one K = 64 sgemm pass) and NONE from the
+      // oracle with that product formed as two K = 32 halves -- the oracle's own re-ordering floor is the
+      // same 63 (profiles/r04_parity_rates.txt: three rates per floor-based comparison).
       static const int far_env = [] { const char* e = getenv("MI355Q_GPTQ_FAR_PER_BLOCK"); return e ? atoi(e) : -1; }();
       const bool per_block = far_env >= 0 ? far_env != 0 : bits >= 8;
       const int step = per_block ? NB : g1 - g0;

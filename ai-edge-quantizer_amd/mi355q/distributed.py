@@ -352,12 +352,58 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
       mine = {i: gen.materialize_op(it, qsvs) for i, (it, o) in enumerate(zip(plan, owner)) if o == rank}
   finally:
     gen.release_derived(qsvs)
-  if world > 1:
-    mine = _gather_results(mine, group)
-    if mine is None:
-      return None
-  params = gen.finish(mine[i] for i in range(len(plan)))
-  return model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path, sink=sink)
+  if world == 1:
+    params = gen.finish(mine[i] for i in range(len(plan)))
+    return model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path, sink=sink)
+  # The results are gathered on rank 0, which merges them, applies the transformations and lays the file out. When a file
+  # is being written, the quantized payloads themselves stay in their ranks' HBM (runtime.remote_payloads) and every rank
+  # writes its own to the offsets rank 0's layout gave them: no gigabyte of pickles through rank 0's host memory.
+  from . import runtime as rt
+  remote = (serialize_to_path is not None or sink is not None) and torch.cuda.is_available() and not os.environ.get("MI355Q_GATHER_PAYLOADS")
+  if remote:
+    with rt.remote_payloads(rank):
+      gathered = _gather_results(mine, group)
+  else:
+    gathered = _gather_results(mine, group)
+  out = None
+  writes = None
+  try:
+    if gathered is not None:
+      params = gen.finish(gathered[i] for i in range(len(plan)))
+      out = model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path, sink=sink)
+      writes = rt.take_remote_writes() if remote else None
+  finally:
+    if remote:           # (a failure on rank 0 must not leave the others waiting in the broadcast)
+      box = [writes]
+      dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+      _write_remote_payloads(box[0] or [], rank)
+      dist.barrier(group=group)     # the file is complete when any rank returns
+  return out
+
+
+def _write_remote_payloads(writes: Sequence[tuple], rank: int) -> None:
+  """This rank's quantized payloads, still in HBM, into the shared output file at the offsets rank 0's layout
+  noted for them (runtime.RemoteBuffer.copy_into): pinned staging + pwrite() on this rank's own io ring."""
+  from . import runtime as rt
+  fds: dict[str, int] = {}
+  try:
+    for owner, key, path, offset, nbytes in writes:
+      if owner != rank:
+        continue
+      arr = rt._REMOTE_LOCAL[key]   # pylint: disable=protected-access
+      t = arr.device_tensor
+      if t.numel() * t.element_size() != nbytes:
+        raise RuntimeError(f"payload {key}: {t.numel() * t.element_size()} bytes here, {nbytes} in the layout")
+      fd = fds.get(path)
+      if fd is None:
+        fd = fds[path] = os.open(path, os.O_RDWR)
+      rt.write_to_file(t, fd, offset)
+    if fds:
+      rt.finish_downloads()
+  finally:
+    for fd in fds.values():
+      os.close(fd)
+    rt._REMOTE_LOCAL.clear()   # pylint: disable=protected-access
 
 
 def _require_hessians_where_read(items: Sequence[tuple], qsvs: dict, rank: int) -> None:

@@ -228,6 +228,99 @@ def download_into_file(t: torch.Tensor, dst: np.ndarray) -> bool:
   return True
 
 
+def write_to_file(t: torch.Tensor, fd: int, offset: int) -> None:
+  """Device bytes -> `fd` at `offset` through the io ring (this rank's own descriptor of a file another rank laid out)."""
+  src = t.contiguous().reshape(-1).view(torch.uint8)
+  copy_stream = _copy_stream(src.device)
+  copy_stream.wait_stream(torch.cuda.current_stream())
+  _ffi.check(_ffi.lib().mi355q_device_to_file(ctypes.c_void_p(src.data_ptr()), src.numel(), fd, int(offset),
+                                              ctypes.c_void_p(copy_stream.cuda_stream)))
+  src.record_stream(copy_stream)
+
+
+def output_file_range_of(dst: np.ndarray):
+  """(path, offset) of `dst` inside a registered output mapping, or None."""
+  addr = dst.ctypes.data
+  for base, length, fd in reversed(_OUT_MAPPINGS):
+    if base <= addr and addr + dst.nbytes <= base + length:
+      return os.readlink(f"/proc/self/fd/{fd}"), addr - base
+  return None
+
+
+# ---- quantized payloads that stay on the rank that made them (sharded runs that write a file) ----------------
+# distributed.quantize_model_sharded gathers the per-op RESULTS on rank 0, which lays the output file out. The payloads --
+# a gigabyte of quantized weights for a Gemma-2B -- need not make that trip as pickles through rank 0's host memory:
+# while the results are pickled inside remote_payloads(), a device-resident payload is replaced by a RemoteBuffer (rank,
+# key, sizes) and stays in its rank's HBM; rank 0's serializer "copies" a RemoteBuffer into the output mapping by noting
+# the file offset it was given; afterwards every rank writes its own payloads to those offsets of the shared file through
+# its io ring (distributed._write_remote_payloads).
+_REMOTE_RANK: list = [None]
+_REMOTE_LOCAL: dict = {}      # key -> HbmArray, on the rank that owns it
+_REMOTE_WRITES: list = []     # rank 0: (rank, key, path, offset, nbytes) noted by RemoteBuffer.copy_into
+_REMOTE_SEQ = [0]
+
+
+class remote_payloads:   # pylint: disable=invalid-name
+  """Context: HbmArrays pickled inside it travel as RemoteBuffer records; the arrays stay registered here."""
+
+  def __init__(self, rank: int):
+    self.rank = int(rank)
+
+  def __enter__(self):
+    _REMOTE_LOCAL.clear()
+    _REMOTE_RANK[0] = self.rank
+    return self
+
+  def __exit__(self, *exc):
+    _REMOTE_RANK[0] = None
+
+
+def take_remote_writes() -> list:
+  out = list(_REMOTE_WRITES)
+  _REMOTE_WRITES.clear()
+  return out
+
+
+class RemoteBuffer:
+  """What an HbmArray unpickles to when its bytes stayed behind (see remote_payloads)."""
+  __array_priority__ = 100.0
+
+  def __init__(self, rank: int, key: str, shape, dtype: str, nbytes: int, packed_nbytes: int):
+    self.rank, self.key, self._shape, self._dtype = int(rank), key, tuple(int(v) for v in shape), np.dtype(dtype)
+    self._nbytes, self._packed_nbytes = int(nbytes), int(packed_nbytes)
+
+  shape = property(lambda self: self._shape)
+  ndim = property(lambda self: len(self._shape))
+  dtype = property(lambda self: self._dtype)
+  nbytes = property(lambda self: self._nbytes)
+  size = property(lambda self: int(np.prod(self._shape, dtype=np.int64)))
+
+  @property
+  def packed(self):
+    if not self._packed_nbytes:
+      return None
+    return RemoteBuffer(self.rank, self.key + "/packed", (self._packed_nbytes,), "uint8", self._packed_nbytes, 0)
+
+  def copy_into(self, dst: np.ndarray) -> None:
+    where = output_file_range_of(dst)
+    if where is None or dst.nbytes != self._nbytes:
+      raise RuntimeError(f"the quantized payload {self.key} lives in the HBM of rank {self.rank}: it can only be written into"
+                         " a file that is being built through a registered output mapping")
+    _REMOTE_WRITES.append((self.rank, self.key, where[0], int(where[1]), self._nbytes))
+
+  def __array__(self, dtype=None, copy=None):
+    raise RuntimeError(f"the quantized payload {self.key} lives in the HBM of rank {self.rank} (sharded run writing a file)")
+
+  def __len__(self) -> int:
+    return self._shape[0]
+
+  def __reduce__(self):
+    return (RemoteBuffer, (self.rank, self.key, self._shape, str(self._dtype), self._nbytes, self._packed_nbytes))
+
+  def __repr__(self):
+    return f"RemoteBuffer(rank={self.rank}, key={self.key}, shape={self._shape}, dtype={self._dtype})"
+
+
 def finish_downloads() -> None:
   """Waits for the pwrite()s of download_into_file (before the output file is handed back)."""
   if _COPY_STREAMS:
@@ -350,6 +443,15 @@ class HbmArray:
     # crosses process boundaries (gather of sharded results) as host data. A sub-byte quantized
     # weight travels as the packed bytes the model file stores -- a third of what the int8
     # containers plus the packed bytes would be; the containers are unpacked on arrival only if read.
+    if _REMOTE_RANK[0] is not None and self.nbytes >= (1 << 16):
+      _REMOTE_SEQ[0] += 1
+      key = f"r{_REMOTE_RANK[0]}/{_REMOTE_SEQ[0]}"
+      _REMOTE_LOCAL[key] = self
+      packed_nbytes = 0
+      if isinstance(self.packed, HbmArray):
+        _REMOTE_LOCAL[key + "/packed"] = self.packed
+        packed_nbytes = self.packed.nbytes
+      return (RemoteBuffer, (_REMOTE_RANK[0], key, self.shape, str(self.dtype), self.nbytes, packed_nbytes))
     if self.packed is not None and self.dtype == np.int8 and self.size:
       bits = self.packed.size * 8 // self.size
       if bits in (2, 4):

@@ -282,7 +282,7 @@ def _worker_c5_fused(rank, world, port, out):
   data = {"serving_default": samples}
   rcp = C.recipe("gptq")
   calls = {"hinv": 0}
-  real, real_batched = ops.gptq_hinv, ops.gptq_hinv_batched
+  real, real_batched, real_product = ops.gptq_hinv, ops.gptq_hinv_batched, ops.gptq_hinv_from_product
 
   def counting(*a, **k):
     calls["hinv"] += 1
@@ -291,10 +291,14 @@ def _worker_c5_fused(rank, world, port, out):
   def counting_batched(hs, *a, **k):
     calls["hinv"] += len(hs)
     return real_batched(hs, *a, **k)
-  ops.gptq_hinv, ops.gptq_hinv_batched = counting, counting_batched
+
+  def counting_product(*a, **k):          # (a Hessian that arrived as the ranks' summed float32 product is inverted from it)
+    calls["hinv"] += 1
+    return real_product(*a, **k)
+  ops.gptq_hinv, ops.gptq_hinv_batched, ops.gptq_hinv_from_product = counting, counting_batched, counting_product
   sharded = D.calibrate_and_quantize_sharded(path, rcp, data)
   mine = calls["hinv"]
-  ops.gptq_hinv, ops.gptq_hinv_batched = real, real_batched
+  ops.gptq_hinv, ops.gptq_hinv_batched, ops.gptq_hinv_from_product = real, real_batched, real_product
   single = None
   if rank == 0:
     qz = quantizer.Quantizer(path, rcp)
