@@ -220,6 +220,130 @@ __global__ __launch_bounds__(256) void xtx_bf16x3_kernel(XtxArgs a) {
   }
 }
 
+// The same product on 128 x 256 output tiles, eight waves per workgroup (2 x 4 quadrants of 64 x 64; a wave's
+// accumulators, fragment reads and 24 MFMAs per k tile unchanged), two k tiles per stage: a stage is 72 KB for 384
+// MFMAs where the kernel above stages 24 KB for 96 -- a quarter fewer bytes out of the L2 per MFMA and half the
+// barriers -- double-buffered (144 KB of LDS, one workgroup per CU, two waves per SIMD). Round 4: the exact split is
+// the default Hessian product again (parity), so what xtx_f16x2.hip gained from wide tiles is taken here too. An XCD's
+// patch is 8 x 4 of these tiles = its 32 CUs, resident together. Tile (ti, tj) covers rows 128 ti.. and columns
+// 256 tj..; it is needed when 2 tj <= ti (the tile on the diagonal of an even tile row also computes 128 columns
+// above the diagonal: valid entries of the symmetric product, never read). Same products, same accumulator
+// structure, same k order per output as the narrow kernel: the same bits (tests/test_gpu_gptq.py).
+constexpr int kWideA = 3 * kPlaneTileB;            // 12 KB: three planes of 128 rows, one k tile
+constexpr int kWideB = 6 * kPlaneTileB;            // 24 KB: three planes of 256 rows
+constexpr int kWideKt = kWideA + kWideB;           // 36 KB per k tile
+constexpr int kWideStageB = 2 * kWideKt;           // 72 KB: two k tiles
+
+__global__ __launch_bounds__(512) void xtx_bf16x3_wide_kernel(XtxArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
+  const int sup = (local / 32) * 8 + xcd, within = local % 32;
+  int si = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(sup) + 1.0f) - 1.0f) * 0.5f);
+  while ((si + 1) * (si + 2) / 2 <= sup) ++si;
+  while (si * (si + 1) / 2 > sup) --si;
+  const int sj = sup - si * (si + 1) / 2;
+  const int ti = si * kSuper + within / 4;          // 128-row tile
+  const int tj = sj * (kSuper / 2) + within % 4;    // 256-column tile
+  if (ti >= a.tiles || 2 * tj > ti) return;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 2, wc = wave & 3;           // this wave's 64 x 64 quadrant of the 128 x 256 tile
+  const int kt0 = 0, kt1 = a.kt_total;               // (no split-K: wide tiles are for d >= 4096)
+
+  f32x16 acc[2][2], lo[2][2], top[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = top[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fch = ((lane >> 5) ^ ((frow >> 3) & 1)) * 16;
+  const int offA = (wr * 64 + frow) * kRowB + fch, offB = kWideA + (wc * 64 + frow) * kRowB + fch;
+
+  const long long row_stride = static_cast<long long>(a.d) * kRowB;   // one plane of one k tile
+  const unsigned char* gA = a.planes + static_cast<long long>(ti) * kPlaneTileB + lane * 16;
+  const unsigned char* gB = a.planes + static_cast<long long>(tj) * (2 * kPlaneTileB) + lane * 16;
+
+  // 36 wave-wide 1 KB pieces per k tile: 12 of A (plane x 4 pieces of 32 rows) and 24 of B (plane x 8); 72 per stage,
+  // nine per wave
+  auto stage = [&](int kt, int buf, int count) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int piece = q * 8 + wave;                 // 0 .. 71
+      const int kk = piece / 36, r = piece % 36;
+      const bool isB = r >= 12;
+      const int pl = isB ? (r - 12) >> 3 : r >> 2, seg = isB ? (r - 12) & 7 : r & 3;
+      const unsigned char* src = (isB ? gB : gA) + (static_cast<long long>(kt + (kk < count ? kk : 0)) * 3 + pl) * row_stride + seg * 1024;
+      unsigned char* dst = lds + buf * kWideStageB + kk * kWideKt + (isB ? kWideA + pl * (2 * kPlaneTileB) : pl * kPlaneTileB) + seg * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  const int nst = (kt1 - kt0 + 1) / 2;               // (an odd last k tile: the stage's second half is loaded again from the first and skipped)
+  if (nst > 0) stage(kt0, 0, kt1 - kt0 >= 2 ? 2 : 1);
+  for (int s = 0; s < nst; ++s) {
+    const int buf = s & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // this stage has landed; every wave is done with the other buffer
+    if (s + 1 < nst) stage(kt0 + 2 * (s + 1), buf ^ 1, kt1 - (kt0 + 2 * (s + 1)) >= 2 ? 2 : 1);
+    const int here = kt1 - (kt0 + 2 * s) >= 2 ? 2 : 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk < here) {
+        const unsigned char* img = lds + buf * kWideStageB + kk * kWideKt;
+        bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            fa[i][pl] = *reinterpret_cast<const bf16x8*>(img + offA + pl * kPlaneTileB + i * 32 * kRowB);
+            fb[i][pl] = *reinterpret_cast<const bf16x8*>(img + offB + pl * (2 * kPlaneTileB) + i * 32 * kRowB);
+          }
+#define MI355Q_TERM(ACC, PA, PB)                                                                \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], ACC[i][j], 0, 0, 0)
+        MI355Q_TERM(lo, 0, 2);
+        MI355Q_TERM(lo, 1, 1);
+        MI355Q_TERM(lo, 2, 0);
+        MI355Q_TERM(lo, 0, 1);
+        MI355Q_TERM(lo, 1, 0);
+        MI355Q_TERM(acc, 0, 0);
+#undef MI355Q_TERM
+        if (((2 * s + kk) & (kFold - 1)) == kFold - 1) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                top[i][j][r] = top[i][j][r] + acc[i][j][r];
+                acc[i][j][r] = 0.f;
+              }
+        }
+      }
+    }
+  }
+
+  float* base = a.c + static_cast<long long>(ti * kTile + wr * 64 + 4 * (lane >> 5)) * a.d + tj * (2 * kTile) + wc * 64 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        old[r] = a.accumulate ? base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float big = top[i][j][r] + acc[i][j][r];
+        const float v = __builtin_isinf(big) ? big : big + lo[i][j][r];
+        base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] = a.accumulate ? old[r] + v : v;
+      }
+    }
+  }
+}
+
 // ---- the same exact split for GPTQ's update behind a group of columns (gptq.hip):
 //   W[:, g1:] -= E @ Hinv[g0:g1, g1:],  E = the group's errors [rows, kk] float32 (kk <= 256).
 // Hinv's planes are made once per call by xtx_split_kernel (x = Hinv: "token" = row k of Hinv,
@@ -681,7 +805,15 @@ int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspa
     } else {
       gx = static_cast<unsigned>(tiles * (tiles + 1) / 2);
     }
-    hipLaunchKernelGGL(xtx_bf16x3_kernel, dim3(gx, static_cast<unsigned>(splits)), dim3(256), 4 * kOperandB, st, a);
+    static const bool wide_ok = [] { const char* e = getenv("MI355Q_XTX_NARROW"); return e == nullptr || *e == 0; }();
+    if (wide_ok && a.patches && d % (2 * kTile) == 0 && splits == 1) {
+      // 128 x 256 tiles: the same 8-XCD patch list, 32 workgroups per patch
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xtx_bf16x3_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWideStageB))
+        return fail(MI355Q_HIP_ERROR, "xtx bf16x3 LDS attribute: %s", hipGetErrorString(e));
+      hipLaunchKernelGGL(xtx_bf16x3_wide_kernel, dim3(gx / 2, 1), dim3(512), 2 * kWideStageB, st, a);
+    } else {
+      hipLaunchKernelGGL(xtx_bf16x3_kernel, dim3(gx, static_cast<unsigned>(splits)), dim3(256), 4 * kOperandB, st, a);
+    }
     if (splits > 1)
       hipLaunchKernelGGL(xtx_reduce_kernel, dim3(2048), dim3(256), 0, st, partial, splits, static_cast<int>(d),
                          (k0 > 0 || accumulate_first) ? 1 : 0, p);

@@ -356,8 +356,9 @@ torch.save(ops.gptq_xtx(x, 2.0 / x.shape[0]).cpu(), sys.argv[2] + "/narrow.pt")
 """
 
 
-def test_hessian_wide_tiles_equal_narrow_tiles(m, tmp_path):
-  """d >= 4096 (a multiple of 256) runs on 128 x 256 output tiles (xtx_f16x2_wide_kernel), everything else on
+@pytest.mark.parametrize("kernel", ["bf16x3", "f16x2"])
+def test_hessian_wide_tiles_equal_narrow_tiles(m, tmp_path, kernel):
+  """d >= 4096 (a multiple of 256) runs on 128 x 256 output tiles (xtx_bf16x3_wide_kernel / xtx_f16x2_wide_kernel), everything else on
   128 x 128: the same products in the same order, so the same bits -- checked at d = 4096 with a ragged token
   count over two slabs (the second accumulates), against MI355Q_XTX_NARROW=1 in a child process; and at
   d = 4352 (a multiple of 128 only: narrow tiles whatever the switch) the product still passes its own check."""
@@ -369,21 +370,24 @@ def test_hessian_wide_tiles_equal_narrow_tiles(m, tmp_path):
   x = torch.randn((16384 + 1777, 4096), generator=gen, device="cuda") * torch.exp2(
       torch.randint(-8, 8, (1, 4096), generator=gen, device="cuda").float()) + 0.125
   torch.save(x.cpu(), str(tmp_path / "x_wide.pt"))
-  with hessian_kernel("f16x2"):            # (the wide tiles belong to the two-way float16 kernel)
+  with hessian_kernel(kernel):
     wide = m.ops.gptq_xtx(x, 2.0 / x.shape[0])
   ref = (x.double().T @ x.double()) * (2.0 / x.shape[0])
   mag = (x.double().abs().T @ x.double().abs()) * (2.0 / x.shape[0])
   err = float(((wide - ref).abs() / mag).max())
-  parity_rates.note("hessian f16 split on 128 x 256 tiles, d=4096, 18161 tokens vs FP64 product (per-entry scale)", "max_rel_error", err, 1e-6)
+  parity_rates.note(f"hessian {kernel} split on 128 x 256 tiles, d=4096, 18161 tokens vs FP64 product (per-entry scale)", "max_rel_error", err, 1e-6)
   assert torch.equal(wide, wide.T)
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  out = subprocess.run([sys.executable, "-c", _XTX_NARROW_CHILD, root, str(tmp_path)], env=dict(os.environ, MI355Q_XTX_NARROW="1", MI355Q_XTX_F16X2="1"),
+  child_env = dict(os.environ, MI355Q_XTX_NARROW="1")
+  if kernel == "f16x2":
+    child_env["MI355Q_XTX_F16X2"] = "1"
+  out = subprocess.run([sys.executable, "-c", _XTX_NARROW_CHILD, root, str(tmp_path)], env=child_env,
                        capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stderr[-2000:]
   assert torch.equal(wide.cpu(), torch.load(str(tmp_path / "narrow.pt")))
   del x, wide, ref, mag
   x = torch.randn((2048, 4352), generator=gen, device="cuda")
-  with hessian_kernel("f16x2"):
+  with hessian_kernel(kernel):
     h = m.ops.gptq_xtx(x, 2.0 / 2048)
   ref = (x.double().T @ x.double()) * (2.0 / 2048)
   mag = (x.double().abs().T @ x.double().abs()) * (2.0 / 2048)
