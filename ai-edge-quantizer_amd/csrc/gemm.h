@@ -24,6 +24,11 @@ struct GemmArgs {
   int batch;           // > 1: grid.z independent problems of this shape; operand b starts
   long long sa, sb, sc;  //      batch strides (elements) after problem b - 1 (no split-K then)
   float* c32;          // not null (beta == 0, no split-K): alpha * (A.B) is stored here as float32, same strides, C untouched
+  // An OUTER batch on top (gptq.hip: the same GEMM of several equally sized Hessian inverses in one launch): grid.z =
+  // max(batch, 1) * outer, outer problem o starts oa / ob / oc elements (oc32 floats for c32) after problem o - 1. It
+  // takes no part in the choice of the tile kernel, which stays the single problem's: the same bits as `outer` launches.
+  int outer;
+  long long oa, ob, oc, oc32;
 };
 
 // Number of K slices launch_gemm would use for this shape (1 = no split) and the

@@ -229,8 +229,17 @@ __device__ __forceinline__ void store_tile(const Stage<TL>& st, typename TL::Ele
 
 template <typename T>
 __device__ __forceinline__ void batch_offset(GemmArgs<T>& g) {
+  long long b = blockIdx.z;
+  if (g.outer > 1) {
+    const long long inner = g.batch > 1 ? g.batch : 1;
+    const long long o = b / inner;
+    b -= o * inner;
+    g.A += o * g.oa;
+    g.B += o * g.ob;
+    g.C += o * g.oc;
+    if (g.c32 != nullptr) g.c32 += o * g.oc32;
+  }
   if (g.batch > 1) {
-    const long long b = blockIdx.z;
     g.A += b * g.sa;
     g.B += b * g.sb;
     g.C += b * g.sc;
@@ -636,7 +645,7 @@ int32_t launch_with(const GemmArgs<typename TL::Elem>& g, hipStream_t st, void* 
   using T = typename TL::Elem;
   constexpr int BM = TL::BM;
   int slices = 1;
-  if (g.batch > 1) {
+  if (g.batch > 1 || g.outer > 1) {
     splitk_ws = nullptr;
   }
   if (splitk_ws != nullptr && g.k_mode == 0) {
@@ -644,7 +653,7 @@ int32_t launch_with(const GemmArgs<typename TL::Elem>& g, hipStream_t st, void* 
     if (static_cast<size_t>(slices) * g.M * g.N * sizeof(T) > splitk_ws_bytes) slices = 1;
   }
   const dim3 grid(static_cast<unsigned>((g.N + BM - 1) / BM), static_cast<unsigned>((g.M + BM - 1) / BM),
-                  static_cast<unsigned>(g.batch > 1 ? g.batch : slices));
+                  static_cast<unsigned>((g.batch > 1 ? g.batch : slices) * (g.outer > 1 ? g.outer : 1)));
   // whole tiles + 16-byte loadable operands: the lean kernel
   const bool whole = g.M % BM == 0 && g.N % BM == 0 && g.K % TL::BK == 0 && a_mode != kGeneric &&
                      b_mode != kGeneric;

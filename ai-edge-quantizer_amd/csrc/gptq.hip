@@ -614,7 +614,8 @@ __device__ __forceinline__ void merge_level(const double* __restrict__ Lp, doubl
 
 // Every diagonal NB-block of the finished factor := its inverse, in place (one workgroup per
 // block): pairwise merging in LDS, levels s = 1, 2, ..., 32 with X21 = -X22 (L21 X11).
-__global__ __launch_bounds__(256) void diag_inverse_kernel(double* __restrict__ a, int d) {
+__global__ __launch_bounds__(256) void diag_inverse_kernel(double* __restrict__ a, int d, long long matrix_stride = 0) {
+  a += static_cast<long long>(blockIdx.z) * matrix_stride;
   __shared__ double Lp[NB * (NB + 1) / 2];   // packed lower triangles
   __shared__ double Xp[NB * (NB + 1) / 2];
   __shared__ double T[NB * NB / 4];          // per level: all pairs' s x s products (32 * s values)
@@ -656,6 +657,214 @@ __global__ __launch_bounds__(256) void mirror_lower_f32_kernel(float* __restrict
   for (int r = ty; r < 32; r += 8) {
     const int i = bi * 32 + r, j = bj * 32 + tx;
     if (i < d && j < d && j > i) h[static_cast<long long>(i) * d + j] = tile[tx][r];
+  }
+}
+
+// ---- several equally sized inverses in lock step (d < 4096, a multiple of 64) ---------------------------------
+// A d = 2048 inverse is a chain of 32 dependent 64-column steps; alone, each step is one launch whose every workgroup
+// factors the diagonal block again (chol_step_kernel: free on an idle chip, 117 KB of LDS, one workgroup per CU).
+// Eight such chains on eight streams (round 3) therefore share the chip badly: 0.67 ms per inverse where 0.11 would be
+// the FP64 peak's. Here G matrices advance through the SAME step together, blockIdx.z = matrix, three launches per
+// step whatever G is:
+//   potf2_batched_kernel   one workgroup per matrix factors its diagonal block ONCE (potf2_core) and leaves L11^T in the
+//                          quad layout of the panel solve in the matrix's `lt` slot;
+//   solve_batched_kernel   one workgroup per 64-row tile of the panel below: the DPP-quad forward substitution of the
+//                          step kernel (trsm_quad_in_lds), once per tile instead of once per trailing tile's workgroup;
+//   update_batched_kernel  the rank-64 update of the outer block's remaining columns on FP64 MFMA, the step kernel's
+//                          own product loop; 66 KB of LDS: two workgroups per CU.
+// Every element sees the operations of the single call in the same order (the same device functions on the same
+// values): bit-identical inverses (tests/test_gpu_gptq.py). The GEMMs between outer blocks, the triangular-inverse
+// levels and L^-T L^-1 go out once for all matrices (GemmArgs::outer), the damped copy and the final mirror take the
+// callers' G pointers as a kernel-argument table.
+constexpr int kHinvGroup = 32;
+struct HinvTable {
+  const double* h[kHinvGroup];     // the Hessians
+  float* out[kHinvGroup];          // their inverses
+};
+
+__global__ __launch_bounds__(256) void diag_sum_batched_kernel(HinvTable t, int d, double* __restrict__ scal, long long matrix_stride) {
+  __shared__ double part[256];
+  const double* h = t.h[blockIdx.z];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    const double v = h[static_cast<long long>(i) * d + i];
+    s += (v != 0.0) ? v : 1.0;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scal[static_cast<long long>(blockIdx.z) * matrix_stride] = part[0];
+}
+
+__global__ __launch_bounds__(256) void copy_damped_lower_batched_kernel(HinvTable t, int d, const double* __restrict__ scal, double damp,
+                                                                       double* __restrict__ a, long long matrix_stride) {
+  const double* h = t.h[blockIdx.z];
+  a += static_cast<long long>(blockIdx.z) * matrix_stride;
+  const double add = damp * (scal[static_cast<long long>(blockIdx.z) * matrix_stride] / static_cast<double>(d));
+  const long long n = static_cast<long long>(d) * d;
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; e < n; e += stride) {
+    const int i = static_cast<int>(e / d), j = static_cast<int>(e % d);
+    double v = 0.0;
+    if (j < i) v = h[e];
+    if (j == i) { v = h[e]; v = ((v != 0.0) ? v : 1.0) + add; }
+    if (j - i < kZeroBand) a[e] = v;
+  }
+}
+
+// the diagonal block at (k, k) of every matrix: L11 in place, L11^T (1 / L_jj on the diagonal) in trsm_quad_item's layout in `ltq`
+__global__ __launch_bounds__(kPotf2Threads) void potf2_batched_kernel(double* __restrict__ a, long long matrix_stride, int d, int k,
+                                                                     int* __restrict__ info, double* __restrict__ ltq) {
+  static_assert(kPotf2Waves == 8, "the quad layout of the panel solve");
+  __shared__ Potf2Shared sh;
+  a += static_cast<long long>(blockIdx.z) * matrix_stride;
+  ltq += static_cast<long long>(blockIdx.z) * matrix_stride;
+  const int tid = threadIdx.x, r = tid & 63, cq = tid >> 6;
+  double v[kPW];
+  const double* row = a + static_cast<long long>(k + r) * d + k;
+#pragma unroll
+  for (int i = 0; i < kPW; ++i) {
+    const int c = cq * kPW + i;
+    const double g = row[c];
+    v[i] = c <= r ? g : 0.0;
+  }
+  const int first_bad = potf2_core(v, sh, tid);
+  double* out = a + static_cast<long long>(k + r) * d + k;
+#pragma unroll
+  for (int i = 0; i < kPW; ++i) {
+    const int c = cq * kPW + i;
+    const double y = sh.ys[c];
+    const double l = v[i] * y;                  // on the diagonal u = p: sqrt(p)
+    ltq[(c * 4 + (r & 3)) * 16 + (r >> 2)] = c == r ? y : l;
+    if (c <= r) out[c] = l;
+  }
+  if (tid == 0 && first_bad < NB) atomicCAS(info + blockIdx.z, 0, k + first_bad + 1);
+}
+
+// L21 tile blockIdx.x of every matrix := A21 inv(L11)^T, in place
+__global__ __launch_bounds__(256) void solve_batched_kernel(double* __restrict__ a, long long matrix_stride, int d, int k,
+                                                           const double* __restrict__ ltq) {
+  __shared__ Pair Lt[NB * NB / 2];
+  __shared__ double X[NB * (NB + 1)];
+  a += static_cast<long long>(blockIdx.z) * matrix_stride;
+  ltq += static_cast<long long>(blockIdx.z) * matrix_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* tile = a + static_cast<long long>(k + NB + blockIdx.x * NB) * d + k;
+  double g[NB * NB / 256];
+#pragma unroll
+  for (int it = 0; it < NB * NB / 256; ++it) {
+    const int e = tid + 256 * it;
+    g[it] = tile[static_cast<long long>(e >> 6) * d + (e & 63)];
+  }
+  {
+    const Pair* src = reinterpret_cast<const Pair*>(ltq);
+#pragma unroll
+    for (int it = 0; it < NB * NB / 2 / 256; ++it) Lt[tid + 256 * it] = src[tid + 256 * it];
+  }
+#pragma unroll
+  for (int it = 0; it < NB * NB / 256; ++it) {
+    const int e = tid + 256 * it;
+    X[(e >> 6) * (NB + 1) + (e & 63)] = g[it];
+  }
+  __syncthreads();
+  trsm_quad_in_lds(X, Lt, wave, lane);
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NB * NB / 256; ++it) {
+    const int e = tid + 256 * it;
+    tile[static_cast<long long>(e >> 6) * d + (e & 63)] = X[(e >> 6) * (NB + 1) + (e & 63)];
+  }
+}
+
+// trailing tile (blockIdx.x, blockIdx.y) of every matrix -= L21 tile i . L21 tile j ^T  (tiles above the diagonal: nothing)
+__global__ __launch_bounds__(kPotf2Threads) void update_batched_kernel(double* __restrict__ a, long long matrix_stride, int d, int k) {
+  constexpr int T = kPotf2Threads, W = kPotf2Waves;
+  constexpr int SC = NB / (W / 2), MB = SC / 16;
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (tj > ti) return;
+  __shared__ double Xi[NB * (NB + 1)], Xj[NB * (NB + 1)];
+  a += static_cast<long long>(blockIdx.z) * matrix_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double gi[NB * NB / T], gj[NB * NB / T];
+  {
+    const double* src_i = a + static_cast<long long>(k + NB + ti * NB) * d + k;
+    const double* src_j = a + static_cast<long long>(k + NB + tj * NB) * d + k;
+#pragma unroll
+    for (int it = 0; it < NB * NB / T; ++it) {
+      const int e = tid + T * it;
+      gi[it] = src_i[static_cast<long long>(e >> 6) * d + (e & 63)];
+      gj[it] = src_j[static_cast<long long>(e >> 6) * d + (e & 63)];
+    }
+  }
+  const int wy = wave / (W / 2), wx = wave % (W / 2);
+  double* ctile = a + static_cast<long long>(k + NB + ti * NB) * d + (k + NB + tj * NB);
+  double cold[2][MB][4];
+#pragma unroll
+  for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cold[ma][mb][r] = ctile[static_cast<long long>(wy * 32 + ma * 16 + (lane >> 4) + 4 * r) * d + wx * SC + mb * 16 + (lane & 15)];
+#pragma unroll
+  for (int it = 0; it < NB * NB / T; ++it) {
+    const int e = tid + T * it, rr = e >> 6, c = e & 63;
+    Xi[rr * (NB + 1) + c] = gi[it];
+    Xj[rr * (NB + 1) + c] = gj[it];
+  }
+  __syncthreads();
+  const double* XJ = tj == ti ? Xi : Xj;
+  __attribute__((ext_vector_type(4))) double acc[2][MB];
+#pragma unroll
+  for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[ma][mb] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k0 = 0; k0 < NB; k0 += 4) {
+    double af[2], bf[MB];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) af[t2] = Xi[(wy * 32 + t2 * 16 + (lane & 15)) * (NB + 1) + k0 + (lane >> 4)];
+#pragma unroll
+    for (int t2 = 0; t2 < MB; ++t2) bf[t2] = XJ[(wx * SC + t2 * 16 + (lane & 15)) * (NB + 1) + k0 + (lane >> 4)];
+#pragma unroll
+    for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        acc[ma][mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ma], bf[mb], acc[ma][mb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wy * 32 + ma * 16 + (lane >> 4) + 4 * r, col = wx * SC + mb * 16 + (lane & 15);
+        const double cnew = cold[ma][mb][r] - acc[ma][mb][r];
+        if (tj != ti || col <= row) ctile[static_cast<long long>(row) * d + col] = cnew;
+      }
+}
+
+// out[z] = the symmetric float32 matrix whose lower triangle is src + z * matrix_stride (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void mirror_out_batched_kernel(HinvTable t, const float* __restrict__ src, long long matrix_stride, int d) {
+  __shared__ float tile[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;          // tiles (bj, bi) [lower] and (bi, bj) [upper], bj >= bi
+  if (bj < bi) return;
+  src += static_cast<long long>(blockIdx.z) * matrix_stride;
+  float* out = t.out[blockIdx.z];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bj * 32 + r, j = bi * 32 + tx;
+    const float v = (i < d && j < d) ? src[static_cast<long long>(i) * d + j] : 0.f;
+    tile[r][tx] = v;
+    if (i < d && j < d && j <= i) out[static_cast<long long>(i) * d + j] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    if (i < d && j < d && j > i) out[static_cast<long long>(i) * d + j] = tile[tx][r];
   }
 }
 
@@ -1513,6 +1722,105 @@ HinvPool* hinv_pool() {
 
 size_t hinv_lane_bytes(int64_t d) { return (mi355q_gptq_hinv_workspace_bytes(d) + 255) & ~static_cast<size_t>(255); }
 int hinv_lanes_for(int32_t count, int64_t d) { return d >= 4096 || count < 2 ? 1 : (count < kHinvLanes ? count : kHinvLanes); }
+
+// matrices that advance in lock step (hinv_lockstep): whole 64-column steps only, at most kHinvGroup, at most 4 GiB of workspace
+bool hinv_lockstep_ok(int32_t count, int64_t d) {
+  static const bool on = getenv("MI355Q_HINV_LANES") == nullptr;
+  return on && count >= 2 && d >= 2 * NB && d < 4096 && d % NB == 0;
+}
+int hinv_group_for(int32_t count, int64_t d) {
+  const size_t fit = (static_cast<size_t>(4) << 30) / hinv_lane_bytes(d);
+  int g = count < kHinvGroup ? count : kHinvGroup;
+  if (static_cast<size_t>(g) > fit) g = static_cast<int>(fit);
+  return g < 1 ? 1 : g;
+}
+
+// G <= kHinvGroup damped inverses of order d, all steps in lock step (the kernels above). ws: G slices of `per` bytes,
+// each laid out as mi355q_gptq_hinv_f64's workspace.
+int32_t hinv_lockstep(const double* const* hessians, int G, int d, double damp_factor, float* const* outs, int32_t* info,
+                      unsigned char* ws, size_t per, hipStream_t st) {
+  HinvTable tab{};
+  for (int z = 0; z < G; ++z) {
+    if (!hessians[z] || !outs[z]) return fail(MI355Q_BAD_ARG, "null pointer");
+    tab.h[z] = hessians[z];
+    tab.out[z] = outs[z];
+  }
+  const long long ms = static_cast<long long>(per / sizeof(double));      // matrix stride in doubles
+  double* a = reinterpret_cast<double*>(ws);
+  double* out = a + static_cast<size_t>(d) * d;
+  double* lt = out + static_cast<size_t>(d) * d;
+  double* scal = lt + NB * NB + static_cast<size_t>(d) * NB * 2;
+  const int nblocks = d / NB;
+  const unsigned uG = static_cast<unsigned>(G);
+  if (hipMemsetAsync(info, 0, sizeof(int32_t) * G, st) != hipSuccess) return fail(MI355Q_HIP_ERROR, "hipMemsetAsync failed");
+  hipLaunchKernelGGL(diag_sum_batched_kernel, dim3(1, 1, uG), dim3(256), 0, st, tab, d, scal, ms);
+  hipLaunchKernelGGL(copy_damped_lower_batched_kernel, dim3(grid1d(static_cast<long long>(d) * d), 1, uG), dim3(256), 0, st, tab, d,
+                     scal, damp_factor, a, ms);
+  MI355Q_CHECK_LAUNCH("gptq damp launch");
+  static const int OB = [] { const char* e = getenv("MI355Q_CHOL_OB"); const int v = e ? atoi(e) : 0; return v >= 64 && v % 64 == 0 ? v : 8 * NB; }();
+  for (int k0 = 0; k0 < d; k0 += OB) {
+    const int ob = d - k0 < OB ? d - k0 : OB;
+    for (int k = k0; k < k0 + ob; k += NB) {
+      const int m = d - k - NB;             // rows below the diagonal block
+      const int w = k0 + ob - k - NB;       // columns left in this outer block
+      hipLaunchKernelGGL(potf2_batched_kernel, dim3(1, 1, uG), dim3(kPotf2Threads), 0, st, a, ms, d, k, info, lt);
+      if (m > 0) {
+        hipLaunchKernelGGL(solve_batched_kernel, dim3(static_cast<unsigned>(m / NB), 1, uG), dim3(256), 0, st, a, ms, d, k, lt);
+        if (w > 0)
+          hipLaunchKernelGGL(update_batched_kernel, dim3(static_cast<unsigned>(m / NB), static_cast<unsigned>(w / NB), uG),
+                             dim3(kPotf2Threads), 0, st, a, ms, d, k);
+      }
+    }
+    const int m2 = d - k0 - ob;
+    if (m2 > 0) {
+      const double* l = a + static_cast<long long>(k0 + ob) * d + k0;
+      double* c = a + static_cast<long long>(k0 + ob) * d + k0 + ob;
+      GemmArgs<double> gu{l, d, 1, l, 1, d, c, d, 1, m2, m2, ob, -1.0, 1.0, 1, 0};
+      gu.outer = G; gu.oa = gu.ob = gu.oc = ms;
+      if (int32_t e = launch_gemm<double>(gu, st)) return e;
+    }
+  }
+  MI355Q_CHECK_LAUNCH("gptq cholesky launch");
+  hipLaunchKernelGGL(diag_inverse_kernel, dim3(static_cast<unsigned>(nblocks), 1, uG), dim3(256), 0, st, a, d, ms);
+  for (long long s = NB; s < d; s *= 2) {
+    long long first = 0;
+    const long long full = (d - s) / (2 * s) + ((d - s) % (2 * s) >= s ? 1 : 0);
+    if (full >= 2 && s <= 2048) {
+      const int n = static_cast<int>(s);
+      const long long hop = 2 * s * (static_cast<long long>(d) + 1);
+      GemmArgs<double> g1{a + s * d, d, 1, a, d, 1, out, n, 1, n, n, n, 1.0, 0.0, 0, 3, static_cast<int>(full), hop, hop, s * s};
+      g1.outer = G; g1.oa = g1.ob = g1.oc = ms;
+      if (int32_t e = launch_gemm<double>(g1, st)) return e;
+      GemmArgs<double> g2{a + s * d + s, d, 1, out, n, 1, a + s * d, d, 1, n, n, n, -1.0, 0.0, 0, 1, static_cast<int>(full), hop, s * s, hop};
+      g2.outer = G; g2.oa = g2.ob = g2.oc = ms;
+      if (int32_t e = launch_gemm<double>(g2, st)) return e;
+      first = full * 2 * s;
+    }
+    for (long long p = first; p + s < d; p += 2 * s) {
+      const int n2 = static_cast<int>(d - (p + s) < s ? d - (p + s) : s);
+      const int n1 = static_cast<int>(s);
+      double* l11 = a + p * d + p;
+      double* l21 = a + (p + s) * d + p;
+      double* l22 = a + (p + s) * d + (p + s);
+      GemmArgs<double> g1{l21, d, 1, l11, d, 1, out, n1, 1, n2, n1, n1, 1.0, 0.0, 0, 3};
+      g1.outer = G; g1.oa = g1.ob = g1.oc = ms;
+      if (int32_t e = launch_gemm<double>(g1, st)) return e;
+      GemmArgs<double> g2{l22, d, 1, out, n1, 1, l21, d, 1, n2, n1, n2, -1.0, 0.0, 0, 1};
+      g2.outer = G; g2.oa = g2.ob = g2.oc = ms;
+      if (int32_t e = launch_gemm<double>(g2, st)) return e;
+    }
+  }
+  MI355Q_CHECK_LAUNCH("gptq trtri launch");
+  // H^-1 = L^-T L^-1, lower half, as float32 into the slice's `out` region; then out[z] <- its mirror image
+  GemmArgs<double> gp{a, 1, d, a, d, 1, out, d, 1, d, d, d, 1.0, 0.0, 1, 2};
+  gp.c32 = reinterpret_cast<float*>(out);
+  gp.outer = G; gp.oa = gp.ob = gp.oc = ms; gp.oc32 = 2 * ms;
+  if (int32_t e = launch_gemm<double>(gp, st)) return e;
+  const unsigned nt = static_cast<unsigned>((d + 31) / 32);
+  hipLaunchKernelGGL(mirror_out_batched_kernel, dim3(nt, nt, uG), dim3(256), 0, st, tab, reinterpret_cast<const float*>(out), 2 * ms, d);
+  MI355Q_CHECK_LAUNCH("gptq mirror launch");
+  return MI355Q_OK;
+}
 }  // namespace
 
 namespace {
@@ -1539,6 +1847,7 @@ void release_hinv_pools() {
 
 extern "C" size_t mi355q_gptq_hinv_batched_workspace_bytes(int32_t count, int64_t d) {
   if (count <= 0 || d <= 0) return 0;
+  if (hinv_lockstep_ok(count, d)) return hinv_lane_bytes(d) * static_cast<size_t>(hinv_group_for(count, d));
   return hinv_lane_bytes(d) * static_cast<size_t>(hinv_lanes_for(count, d));
 }
 
@@ -1552,6 +1861,20 @@ extern "C" int32_t mi355q_gptq_hinv_f64_batched(const double* const* hessians_ho
   const size_t need = mi355q_gptq_hinv_batched_workspace_bytes(count, d);
   if (!workspace || workspace_bytes < need) return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
   const size_t per = hinv_lane_bytes(d);
+  if (hinv_lockstep_ok(count, d)) {
+    // equally sized small Hessians advance through every step together: three launches per 64-column step for all of them
+    const int group = hinv_group_for(count, d);
+    for (int32_t i = 0; i < count; i += group) {
+      const int g = count - i < group ? count - i : group;
+      if (g == 1) {
+        if (int32_t e = mi355q_gptq_hinv_f64(hessians_host[i], d, damp_factor, hinv_out_host[i], info_out + i, workspace, per, stream)) return e;
+      } else if (int32_t e = hinv_lockstep(hessians_host + i, g, static_cast<int>(d), damp_factor, hinv_out_host + i, info_out + i,
+                                           static_cast<unsigned char*>(workspace), per, as_stream(stream))) {
+        return e;
+      }
+    }
+    return MI355Q_OK;
+  }
   int lanes = hinv_lanes_for(count, d);
   std::unique_lock<std::mutex> lock(g_hinv_pool_mutex, std::defer_lock);
   HinvPool* pool = nullptr;
