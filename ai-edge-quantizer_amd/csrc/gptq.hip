@@ -1548,6 +1548,22 @@ int32_t hinv_impl(const double* hessian, const float* product, double alpha, int
         step_panel_ready = true;     // the next step's block column (if it is fused too) is in step_panel[step_parity]
         continue;
       }
+      // whole tiles: the three non-redundant step kernels of the lock-step batch (one matrix): the panel solve on DPP
+      // quads (four waves per 64-row tile instead of one lane per row) and the in-block update on the step kernel's MFMA
+      // loop, no workgroup repeating another's work -- beside the look-ahead GEMM, where the chain is what the wall clock
+      // follows for two thirds of the outer blocks of a d = 16384 factorization
+      static const bool asu = [] { const char* e = getenv("MI355Q_CHOL_ASU"); return e == nullptr || atoi(e) != 0; }();
+      if (asu && nb == NB && m % NB == 0 && w % NB == 0) {
+        hipLaunchKernelGGL(potf2_batched_kernel, dim3(1, 1, 1), dim3(kPotf2Threads), 0, st, a, 0LL, d, k, info_out, lt);
+        if (m > 0) {
+          hipLaunchKernelGGL(solve_batched_kernel, dim3(static_cast<unsigned>(m / NB), 1, 1), dim3(256), 0, st, a, 0LL, d, k, lt);
+          if (w > 0)
+            hipLaunchKernelGGL(update_batched_kernel, dim3(static_cast<unsigned>(m / NB), static_cast<unsigned>(w / NB), 1),
+                               dim3(kPotf2Threads), 0, st, a, 0LL, d, k);
+        }
+        step_panel_ready = false;
+        continue;
+      }
       hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(kPotf2Threads), 0, st, a, d, k, nb, info_out, lt MI355Q_PROF_ARG);
       if (m > 0) {
         hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + 63) / 64), dim3(64), 0, st, a, d, k, nb, m, lt MI355Q_PROF_ARG);
