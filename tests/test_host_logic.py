@@ -539,3 +539,45 @@ def test_sharded_quantize_refuses_a_gptq_op_whose_hessian_went_elsewhere():
     D._require_hessians_where_read([item], {"x": {"min": 0, "max": 1, "num_samples": 3}}, 1)
   other = (gi, op, None, q.TFLOperationName.FULLY_CONNECTED, am.AlgorithmName.MIN_MAX_UNIFORM_QUANT, None)
   D._require_hessians_where_read([other], {"x": {"min": 0, "max": 1, "num_samples": 3}}, 1)
+
+
+# ---- payloads that stay on their rank (sharded runs that write a file) -------------------------
+def test_remote_payload_records_instead_of_bytes(tmp_path):
+  """Inside runtime.remote_payloads() a device-resident payload pickles to a RemoteBuffer record (its bytes
+  stay registered on the owning rank); the serializer's copy_into() of such a record notes the file
+  offset it was given instead of copying, and refuses a destination that is no registered output file."""
+  import mmap
+  import pickle
+  import torch
+  from mi355q import runtime as rt
+  big = rt.HbmArray(torch.arange(1 << 17, dtype=torch.int32).to(torch.int8).reshape(256, 512))
+  big.packed = rt.HbmArray(torch.zeros(1 << 16, dtype=torch.uint8))
+  small = rt.HbmArray(torch.zeros(16, dtype=torch.int8))
+  with rt.remote_payloads(3):
+    got, got_small = pickle.loads(pickle.dumps(big)), pickle.loads(pickle.dumps(small))
+  assert isinstance(got, rt.RemoteBuffer) and got.rank == 3 and got.shape == (256, 512) and got.dtype == np.int8
+  assert got.nbytes == 1 << 17 and got.packed.nbytes == 1 << 16 and got.packed.key == got.key + "/packed"
+  assert rt._REMOTE_LOCAL[got.key] is big and rt._REMOTE_LOCAL[got.packed.key] is big.packed
+  assert not isinstance(got_small, rt.RemoteBuffer)            # small payloads travel as bytes
+  assert not isinstance(pickle.loads(pickle.dumps(big)), rt.RemoteBuffer)   # outside the block: host data as before
+  with pytest.raises(RuntimeError, match="rank 3"):
+    np.asarray(got)
+  path = tmp_path / "out.bin"
+  fd = os.open(str(path), os.O_RDWR | os.O_CREAT, 0o644)
+  os.ftruncate(fd, 1 << 20)
+  mapping = mmap.mmap(fd, 1 << 20)
+  rt.register_output_mapping(mapping, fd)
+  try:
+    rt.take_remote_writes()
+    got.packed.copy_into(np.frombuffer(mapping, dtype=np.uint8, count=1 << 16, offset=4096))
+    (rank, key, where, offset, nbytes), = rt.take_remote_writes()
+    assert (rank, key, offset, nbytes) == (3, got.packed.key, 4096, 1 << 16) and os.path.samefile(where, path)
+    with pytest.raises(RuntimeError, match="registered output mapping"):
+      got.packed.copy_into(np.zeros(1 << 16, np.uint8))
+    with pytest.raises(RuntimeError):                          # a size that is not the payload's
+      got.packed.copy_into(np.frombuffer(mapping, dtype=np.uint8, count=100, offset=0))
+  finally:
+    rt.forget_output_mapping(mapping)
+    rt._REMOTE_LOCAL.clear()
+    mapping.close()
+    os.close(fd)
