@@ -108,6 +108,22 @@ MFMA_F32_PEAK_TF, MFMA_F64_PEAK_TF = 157.3, 78.6   # dense MFMA peaks (MI355X_MI
 MFMA_BF16_PEAK_TF = 2500.0
 
 
+def hinv_roofline(d: int, ms: float) -> dict:
+  """The damped inverse against the matrix cores it runs on: the Cholesky factorization (d^3 / 3) is FP64 MFMA at every
+  order; the triangular inverse and L^-T L^-1 (2 d^3 / 3, single precision in the reference) are FP64 MFMA below d = 4096 and
+  six bf16 MFMA products per float32 product from there on. frac = the time those flops take at the dense peaks / the time
+  measured (pricing all of d^3 at the FP64 peak, as rounds 2 - 3 did, gives > 1 once two thirds of it left the FP64 pipe)."""
+  chol, rest = d ** 3 / 3.0, 2.0 * d ** 3 / 3.0
+  if d >= 4096:
+    ideal_ms = chol / (MFMA_F64_PEAK_TF * 1e9) + 6.0 * rest / (MFMA_BF16_PEAK_TF * 1e9)
+    how = "Cholesky d^3 / 3 at the FP64 MFMA peak + triangular inverse and L^-T L^-1 (2 d^3 / 3) as 6 bf16 MFMA products each at the bf16 peak"
+  else:
+    ideal_ms = (chol + rest) / (MFMA_F64_PEAK_TF * 1e9)
+    how = "d^3 at the FP64 MFMA peak (everything in FP64 below d = 4096)"
+  return {"bound": "mfma", "achieved": round(d ** 3 / ms / 1e9, 1), "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s (d^3 / time)",
+          "frac": round(ideal_ms / ms, 4), "ideal_ms_at_peaks": round(ideal_ms, 3), "flops": how}
+
+
 def timed_ms(torch, fn, reps: int, warm: int = 2) -> float:
   for _ in range(warm):
     fn()
@@ -251,10 +267,7 @@ def more_extras(torch, ops, gen, xs) -> dict:
                                            " bits: 1.2e-3 of the d = 16384 integers differ from the oracle's (its own re-ordering"
                                            " floor: 1.5e-3); opt-in"}},
         "hinv": {"ms": round(ms_i, 3),
-                 "roofline": {"bound": "mfma", "achieved": round(d ** 3 / ms_i / 1e9, 1), "peak": MFMA_F64_PEAK_TF,
-                              "unit": "TFLOP/s", "frac": round(d ** 3 / ms_i / 1e9 / MFMA_F64_PEAK_TF, 4),
-                              "flops": "d^3 priced as FP64 MFMA: Cholesky in FP64 (d^3 / 3); for d >= 4096 the triangular inverse"
-                                       " and L^-T L^-1 (2 d^3 / 3, single precision in the reference) run on the bf16 split"}},
+                 "roofline": hinv_roofline(d, ms_i)},
         "apply_2048_rows_int4": {"ms": round(ms_a, 3),
                                  "roofline": ({"bound": "mfma", "achieved": round(2 * rows * d * d / ms_a / 1e9, 1),
                                                "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
