@@ -497,18 +497,20 @@ def test_inverse_from_the_float32_product_equals_inverse_of_the_finished_hessian
   assert np.asarray(acc).dtype == np.float64                              # ... and still readable as the float64 statistic
 
 
-@pytest.mark.parametrize("d,count", [(2048, 11), (320, 3), (4224, 2)])
+@pytest.mark.parametrize("d,count", [(2048, 11), (320, 3), (4224, 2), (128, 1), (192, 39), (1024, 5), (300, 3)])
 def test_batched_inverses_equal_single_calls_bit_for_bit(m, d, count):
-  """mi355q_gptq_hinv_f64_batched: the chains of independent Hessians interleave on a stream pool
-  (d < 4096) or follow each other (d >= 4096); each instance runs the single call's launches."""
+  """mi355q_gptq_hinv_f64_batched: equally sized Hessians of an order below 4096 that is a multiple of 64 advance
+  through every 64-column step in lock step, up to 32 at a time (192 x 40: a full group and a tail of 8; 128: two
+  steps, the second without a panel); other orders below 4096 interleave their chains on a stream pool (300), orders
+  from 4096 on follow each other (4224). Every instance returns the single call's bits, the indefinite one its info."""
   torch = m.torch
   hs = []
   for i in range(count):
     gen = torch.Generator(device="cuda").manual_seed(900 + 7 * i + d)
     x = torch.randn((d + 64 * (i + 1), d), generator=gen, device="cuda") * (1.0 + 0.25 * i)
     hs.append(m.ops.gptq_xtx(x, 2.0 / (i + 1)))
-  hs[1][5, :] = 0.0
-  hs[1][:, 5] = 0.0                               # a dead channel in one of them
+  hs[min(1, count - 1)][5, :] = 0.0
+  hs[min(1, count - 1)][:, 5] = 0.0               # a dead channel in one of them
   bad = hs[-1].clone()
   bad[3, 3] = -1e6                                # ... and one that is not positive definite
   hs.append(bad)
@@ -542,6 +544,15 @@ def test_workspaces_and_outputs_are_written_before_they_are_read(m, monkeypatch)
       gen = torch.Generator(device="cuda").manual_seed(d)
       x = torch.randn((2 * d, d), generator=gen, device="cuda", dtype=torch.float64)
       hinv, info = m.ops.gptq_hinv(((x.T @ x) / (2 * d)).contiguous(), 0.01)
+      out += [hinv.clone(), info.clone()]
+    # three inverses in lock step (their workspace slices, the diagonal blocks' transposes, the float32 lower triangles
+    # the mirror kernel reads)
+    hs = []
+    for i in range(3):
+      gen = torch.Generator(device="cuda").manual_seed(640 + i)
+      x = torch.randn((1400, 640), generator=gen, device="cuda", dtype=torch.float64)
+      hs.append(((x.T @ x) / 1400).contiguous())
+    for hinv, info in m.ops.gptq_hinv_batched(hs, 0.01):
       out += [hinv.clone(), info.clone()]
     gen = torch.Generator(device="cuda").manual_seed(9)
     x = torch.randn((4096, 2048), generator=gen, device="cuda")
