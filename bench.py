@@ -108,6 +108,63 @@ MFMA_F32_PEAK_TF, MFMA_F64_PEAK_TF = 157.3, 78.6   # dense MFMA peaks (MI355X_MI
 MFMA_BF16_PEAK_TF = 2500.0
 
 
+class ClockSampler:
+  """Shader clock (MHz) and socket power (W) of GPU `index` while a block runs, from the amdgpu hwmon files
+  (freq1_input, power1_average / power1_input), sampled every 20 ms by a helper thread. The Hessian products run at the
+  socket's power limit: their time moves with the clock a box sustains, and this is what makes a box-to-box spread
+  attributable. All fields None when the files are not there."""
+
+  def __init__(self, index: int = 0):
+    import glob
+    self.freq = self.power = None
+    for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+      mons = sorted(glob.glob(card + "/hwmon/hwmon*"))
+      if not mons or not os.path.exists(mons[0] + "/freq1_input"):
+        continue
+      if index == 0:
+        self.freq = mons[0] + "/freq1_input"
+        self.power = next((mons[0] + "/" + n for n in ("power1_average", "power1_input") if os.path.exists(mons[0] + "/" + n)), None)
+        break
+      index -= 1
+    self.mhz, self.watts, self._stop, self._thread = [], [], False, None
+
+  @staticmethod
+  def _read(path):
+    try:
+      with open(path) as fh:
+        return float(fh.read().strip())
+    except (OSError, ValueError):
+      return None
+
+  def __enter__(self):
+    if self.freq is not None:
+      import threading
+
+      def loop():
+        while not self._stop:
+          f = self._read(self.freq)
+          if f:
+            self.mhz.append(f / 1e6)
+          w = self._read(self.power) if self.power else None
+          if w:
+            self.watts.append(w / 1e6)
+          time.sleep(0.02)
+      self._thread = threading.Thread(target=loop, daemon=True)
+      self._thread.start()
+    return self
+
+  def __exit__(self, *exc):
+    self._stop = True
+    if self._thread is not None:
+      self._thread.join(1.0)
+
+  def summary(self) -> dict:
+    if not self.mhz:
+      return {"sclk_MHz_mean": None, "sclk_MHz_min": None, "socket_W_mean": None, "samples": 0}
+    return {"sclk_MHz_mean": round(sum(self.mhz) / len(self.mhz)), "sclk_MHz_min": round(min(self.mhz)),
+            "socket_W_mean": round(sum(self.watts) / len(self.watts)) if self.watts else None, "samples": len(self.mhz)}
+
+
 def hinv_roofline(d: int, ms: float) -> dict:
   """The damped inverse against the matrix cores it runs on: the Cholesky factorization (d^3 / 3) is FP64 MFMA at every
   order; the triangular inverse and L^-T L^-1 (2 d^3 / 3, single precision in the reference) are FP64 MFMA below d = 4096 and
@@ -240,9 +297,12 @@ def more_extras(torch, ops, gen, xs) -> dict:
   for d, tokens in ((2048, 65536), (16384, 16384)):
     x = torch.randn((tokens, d), generator=gen, device="cuda")
     reps = 10 if d == 2048 else 3
-    ms_h = timed_ms(torch, lambda: ops.gptq_xtx(x, 2.0 / 128), reps, 1)
-    with ops.hessian_product("fast"):
-      ms_h_fast = timed_ms(torch, lambda: ops.gptq_xtx(x, 2.0 / 128), reps, 1)
+    # (the d = 16384 product is repeated for ~0.3 s so that the clock sampler sees the sustained state, not the ramp)
+    reps_h = reps if d == 2048 else 12
+    with ClockSampler() as clk:
+      ms_h = timed_ms(torch, lambda: ops.gptq_xtx(x, 2.0 / 128), reps_h, 1)
+    with ops.hessian_product("fast"), ClockSampler() as clk_fast:
+      ms_h_fast = timed_ms(torch, lambda: ops.gptq_xtx(x, 2.0 / 128), reps_h, 1)
     h = ops.gptq_xtx(x, 2.0 / 128)
     del x
     ms_i = timed_ms(torch, lambda: ops.gptq_hinv(h, 0.01), reps, 1)
@@ -261,7 +321,9 @@ def more_extras(torch, ops, gen, xs) -> dict:
                                           " it the d = 16384 GPTQ chain reproduces the oracle's integers, profiles/r04_parity_rates.txt)",
                                  "float32_product_TFLOPs": round(tokens * d * d / ms_h / 1e9, 1),
                                  "mfma_f32_peak": MFMA_F32_PEAK_TF},
+                    "clock_while_timed": clk.summary(),
                     "fast_f16x2": {"ms": round(ms_h_fast, 3), "how": "ops.hessian_product('fast') / MI355Q_XTX_F16X2=1",
+                                   "clock_while_timed": clk_fast.summary(),
                                    "roofline_frac": round(3 * tokens * d * d / ms_h_fast / 1e9 / MFMA_BF16_PEAK_TF, 4),
                                    "note": "two-way float16 split, three f16 MFMA products per float32 product, 22-23 of 24 mantissa"
                                            " bits: 1.2e-3 of the d = 16384 integers differ from the oracle's (its own re-ordering"
