@@ -443,7 +443,9 @@ class HbmArray:
     # crosses process boundaries (gather of sharded results) as host data. A sub-byte quantized
     # weight travels as the packed bytes the model file stores -- a third of what the int8
     # containers plus the packed bytes would be; the containers are unpacked on arrival only if read.
-    if _REMOTE_RANK[0] is not None and self.nbytes >= (1 << 16):
+    # (integer payloads only: what the serializer copies into the file byte for byte. Blockwise scales, float32 arrays the
+    # transformation layer reads as values, travel as host data like before.)
+    if _REMOTE_RANK[0] is not None and self.nbytes >= (1 << 16) and self.dtype in (np.int8, np.uint8):
       _REMOTE_SEQ[0] += 1
       key = f"r{_REMOTE_RANK[0]}/{_REMOTE_SEQ[0]}"
       _REMOTE_LOCAL[key] = self

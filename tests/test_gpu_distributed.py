@@ -61,6 +61,20 @@ def _worker(rank, world, port, out):
     sharded = D.quantize_model_sharded(big, _recipe(key, bits, gran))
     single = bytes(quantizer.Quantizer(big, _recipe(key, bits, gran)).quantize().quantized_model) if rank == 0 else None
     got.append((None if sharded is None else bytes(sharded), single))
+    # ... and written to a FILE: the quantized payloads then stay in their ranks' HBM and every rank writes its own into
+    # the file rank 0 laid out (runtime.RemoteBuffer); blockwise scales (64 KiB of float32 here) still travel as values
+    out_path = big + f".{bits}.q.tflite"
+    ret = D.quantize_model_sharded(big, _recipe(key, bits, gran), serialize_to_path=out_path)
+    dist.barrier()
+    if rank == 0:
+      with open(out_path, "rb") as fh:
+        on_disk = fh.read()
+      got.append((on_disk, single))
+      assert ret is not None
+      os.remove(out_path)
+    else:
+      got.append((None, None))
+      assert ret is None
   dist.barrier()
   if rank == 0:
     os.remove(big)
@@ -76,8 +90,8 @@ def _worker(rank, world, port, out):
 
 def test_two_ranks_quantize_model_files_like_one():
   (r0, got0), (r1, got1) = _run(_worker, timeout=600)
-  assert len(got0) == len(_CASES) + 2
-  for case, (sharded, single), (other, _) in zip([("big", 4), ("big", 8)] + _CASES, got0, got1):
+  assert len(got0) == len(_CASES) + 4
+  for case, (sharded, single), (other, _) in zip([("big", 4), ("big file", 4), ("big", 8), ("big file", 8)] + _CASES, got0, got1):
     assert other is None and sharded is not None, case
     assert sharded == single, case
 

@@ -559,6 +559,8 @@ def test_remote_payload_records_instead_of_bytes(tmp_path):
   assert got.nbytes == 1 << 17 and got.packed.nbytes == 1 << 16 and got.packed.key == got.key + "/packed"
   assert rt._REMOTE_LOCAL[got.key] is big and rt._REMOTE_LOCAL[got.packed.key] is big.packed
   assert not isinstance(got_small, rt.RemoteBuffer)            # small payloads travel as bytes
+  with rt.remote_payloads(3):                                  # ... and so do float arrays (blockwise scales are read as values)
+    assert not isinstance(pickle.loads(pickle.dumps(rt.HbmArray(torch.zeros(1 << 16, dtype=torch.float32)))), rt.RemoteBuffer)
   assert not isinstance(pickle.loads(pickle.dumps(big)), rt.RemoteBuffer)   # outside the block: host data as before
   with pytest.raises(RuntimeError, match="rank 3"):
     np.asarray(got)
