@@ -445,7 +445,9 @@ class HbmArray:
     # containers plus the packed bytes would be; the containers are unpacked on arrival only if read.
     # (integer payloads only: what the serializer copies into the file byte for byte. Blockwise scales, float32 arrays the
     # transformation layer reads as values, travel as host data like before.)
-    if _REMOTE_RANK[0] is not None and self.nbytes >= (1 << 16) and self.dtype in (np.int8, np.uint8):
+    # From 256 KiB on: one such payload alone puts the model over the serializer's inline limit (model_modifier), so a
+    # RemoteBuffer always meets the external-buffer layout, which copies payloads with copy_into().
+    if _REMOTE_RANK[0] is not None and self.nbytes >= (1 << 18) and self.dtype in (np.int8, np.uint8):
       _REMOTE_SEQ[0] += 1
       key = f"r{_REMOTE_RANK[0]}/{_REMOTE_SEQ[0]}"
       _REMOTE_LOCAL[key] = self

@@ -44,6 +44,11 @@ def get_constant_buffer(data: np.ndarray, model: Any, force_duplicate_buffer: bo
     table = {}
     for i, b in enumerate(model.buffers):
       if b.data is not None:
+        if getattr(b.data, "rank", None) is not None and hasattr(b.data, "key"):
+          # runtime.RemoteBuffer: a quantized weight whose bytes stayed in another rank's HBM (sharded run that writes a
+          # file). It cannot be offered for sharing -- its bytes are not here -- and nothing this function is asked for
+          # (scale tensors, zero points, small new constants) is a quantized weight's payload.
+          continue
         d = np.ravel(np.asarray(b.data)).view(np.uint8)
         _remember(table, d, i)
     model._buffers_by_content = table

@@ -550,17 +550,17 @@ def test_remote_payload_records_instead_of_bytes(tmp_path):
   import pickle
   import torch
   from mi355q import runtime as rt
-  big = rt.HbmArray(torch.arange(1 << 17, dtype=torch.int32).to(torch.int8).reshape(256, 512))
-  big.packed = rt.HbmArray(torch.zeros(1 << 16, dtype=torch.uint8))
+  big = rt.HbmArray(torch.arange(1 << 19, dtype=torch.int32).to(torch.int8).reshape(1024, 512))
+  big.packed = rt.HbmArray(torch.zeros(1 << 18, dtype=torch.uint8))
   small = rt.HbmArray(torch.zeros(16, dtype=torch.int8))
   with rt.remote_payloads(3):
     got, got_small = pickle.loads(pickle.dumps(big)), pickle.loads(pickle.dumps(small))
-  assert isinstance(got, rt.RemoteBuffer) and got.rank == 3 and got.shape == (256, 512) and got.dtype == np.int8
-  assert got.nbytes == 1 << 17 and got.packed.nbytes == 1 << 16 and got.packed.key == got.key + "/packed"
+  assert isinstance(got, rt.RemoteBuffer) and got.rank == 3 and got.shape == (1024, 512) and got.dtype == np.int8
+  assert got.nbytes == 1 << 19 and got.packed.nbytes == 1 << 18 and got.packed.key == got.key + "/packed"
   assert rt._REMOTE_LOCAL[got.key] is big and rt._REMOTE_LOCAL[got.packed.key] is big.packed
   assert not isinstance(got_small, rt.RemoteBuffer)            # small payloads travel as bytes
   with rt.remote_payloads(3):                                  # ... and so do float arrays (blockwise scales are read as values)
-    assert not isinstance(pickle.loads(pickle.dumps(rt.HbmArray(torch.zeros(1 << 16, dtype=torch.float32)))), rt.RemoteBuffer)
+    assert not isinstance(pickle.loads(pickle.dumps(rt.HbmArray(torch.zeros(1 << 18, dtype=torch.float32)))), rt.RemoteBuffer)
   assert not isinstance(pickle.loads(pickle.dumps(big)), rt.RemoteBuffer)   # outside the block: host data as before
   with pytest.raises(RuntimeError, match="rank 3"):
     np.asarray(got)
@@ -571,11 +571,11 @@ def test_remote_payload_records_instead_of_bytes(tmp_path):
   rt.register_output_mapping(mapping, fd)
   try:
     rt.take_remote_writes()
-    got.packed.copy_into(np.frombuffer(mapping, dtype=np.uint8, count=1 << 16, offset=4096))
+    got.packed.copy_into(np.frombuffer(mapping, dtype=np.uint8, count=1 << 18, offset=4096))
     (rank, key, where, offset, nbytes), = rt.take_remote_writes()
-    assert (rank, key, offset, nbytes) == (3, got.packed.key, 4096, 1 << 16) and os.path.samefile(where, path)
+    assert (rank, key, offset, nbytes) == (3, got.packed.key, 4096, 1 << 18) and os.path.samefile(where, path)
     with pytest.raises(RuntimeError, match="registered output mapping"):
-      got.packed.copy_into(np.zeros(1 << 16, np.uint8))
+      got.packed.copy_into(np.zeros(1 << 18, np.uint8))
     with pytest.raises(RuntimeError):                          # a size that is not the payload's
       got.packed.copy_into(np.frombuffer(mapping, dtype=np.uint8, count=100, offset=0))
   finally:

@@ -3,7 +3,7 @@
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'
 # Everything lands under gpurun_out/<round>/; copy what is to be judged into profiles/.
 set -u
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$ROUND
 mkdir -p "$OUT"
@@ -29,6 +29,8 @@ trace hinv16384 python "$R/tools/hinv_profile.py" 16384
   echo "## d = 2048, the first kernels of the chain (start / duration / gap to the previous kernel, us)"
   python tools/kernel_timeline.py /tmp/prof_hinv2048 | head -14
   echo "## d = 16384"; python tools/make_gptq_profiles.py --phases /tmp/prof_hinv16384
+  echo "## d = 16384, per outer block of the Cholesky (tools/hinv_chain_timeline.py): span against the look-ahead GEMM"
+  python tools/hinv_chain_timeline.py /tmp/prof_hinv16384
   echo "## tools/kbench/potf2_bench (one 64 x 64 diagonal block + the 1984 rows below it; cycles of workgroup 0)"
   timeout 60 tools/kbench/potf2_bench
   echo "## tools/kbench/lat_bench (one wave: cycles per instruction)"
@@ -65,6 +67,8 @@ python tools/pmc_big_kernels.py /tmp/prof_fetch > "$OUT/hinv16384_fetch.txt" 2>&
 {
   echo "# tools/c5_model.py: BASELINE config 5 as one quantize_litertlm(calibration_data=...) call, 18 Gemma-2B-shaped layers, one GPU"
   for v in gptq mixed hadamard; do timeout 600 python tools/c5_model.py --layers 18 --variant $v 2>&1 | tail -1; done
+  echo "# the same GPTQ run with the opt-in two-way float16 Hessian product (--hessian fast)"
+  timeout 600 python tools/c5_model.py --layers 18 --variant gptq --hessian fast 2>&1 | tail -1
   echo "# tools/hinv_batched_bench.py: d = 2048 inverses, one call each vs mi355q_gptq_hinv_f64_batched"
   timeout 200 python tools/hinv_batched_bench.py 2048 54 2>&1 | tail -1
   echo "# tools/hinv_accuracy.py: time and error vs the exact FP64 inverse (bf16 split for the float32 steps, then FP64 throughout)"
@@ -80,6 +84,10 @@ python tools/pmc_big_kernels.py /tmp/prof_fetch > "$OUT/hinv16384_fetch.txt" 2>&
   MI355Q_C5_GAPS=1 MI355Q_C5_TRACE=hinv,apply timeout 600 python tools/c5_model.py --layers 18 --variant gptq 2>&1 | tail -1
 } > "$OUT/c5_model.txt" 2>&1
 bash tools/pmc_traffic_refresh.sh "$ROUND" > "$OUT/pmc_traffic.log" 2>&1
+{
+  echo "# tools/gptq_parity_instances.py: the d = 16384 full chain on several instances, GPU (exact / fast Hessian product) vs the oracle's own chain"
+  timeout 1500 python tools/gptq_parity_instances.py 3 32 2>&1 | grep "^{"
+} > "$OUT/gptq_parity_instances.txt" 2>&1
 for a in "" "--resident"; do timeout 300 python tools/c4_bench.py --samples 128 $a 2>&1 | tail -1; done > "$OUT/c4_c5_public.txt"
 for a in "" "--resident"; do timeout 600 python tools/c5_bench.py --samples 4 $a 2>&1 | tail -1; done >> "$OUT/c4_c5_public.txt"
 timeout 300 python tools/file_bench.py 2>&1 | tail -1 >> "$OUT/c4_c5_public.txt"
