@@ -319,6 +319,16 @@ def _device_hessian_inverse(hessian, damp_factor: float = 0.01):
   return ops.gptq_hinv(rt.to_device(np.ascontiguousarray(hessian, dtype=np.float64)), damp_factor)
 
 
+def hessian_name_of(plan_item) -> Optional[str]:
+  """Name of the activation whose Hessian a planned op reads (its first input, ref :243-300), None when the op
+  is not a GPTQ op."""
+  from ...utils import tfl_flatbuffer_utils
+  graph_info, op, _, op_key, alg, _ = plan_item
+  if str(getattr(alg, "value", alg)) != ALGORITHM_KEY or op_key is None or not len(op.inputs):
+    return None
+  return tfl_flatbuffer_utils.get_tensor_name(graph_info.subgraph_tensors[op.inputs[0]])
+
+
 def prefetch_hessian_inverses(plan_items, model_qsvs, damp_factor: float = 0.01) -> int:
   """Inverts, in one batched call per order, every Hessian the GPTQ ops among `plan_items`
   (ParamsGenerator.plan_ops tuples) will read and that has no cached inverse yet. A model has
