@@ -14,6 +14,8 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
+#include <string>
+#include <unordered_map>
 #include <new>
 #include <mutex>
 #include <thread>
@@ -140,21 +142,26 @@ struct Ring {
   bool ready = false;
 };
 
-std::mutex g_mutex;          // one transfer at a time enqueues (the ring is per device, the pool per process)
+std::mutex g_mutex[2];       // one transfer per direction enqueues at a time (a ring per device and direction -- PCIe carries both
+                             // ways at once --, the pool per process); [0] uploads, [1] downloads
 Pool* g_pool = nullptr;      // owned by the process that started its threads (g_pool_pid)
 pid_t g_pool_pid = 0;
-Ring g_ring[64];
+Ring g_ring[2][64];
 
 // The io threads exist only in the process that started them: a fork()ed child inherits the Pool object with a
 // non-empty thread list, queue and (possibly held) mutexes but none of the threads, and every transfer would wait on a
 // latch nobody opens. The child therefore abandons the inherited pool (never destroyed: its std::thread objects are
 // joinable and name threads of another process) and starts its own. (The HIP runtime does not survive fork() either;
 // the ring's pinned slots are re-made the same way.)
+std::mutex g_setup_mutex;    // pool, io threads and rings are made on first use, from either direction's thread
+
 Pool& pool() {
+  std::lock_guard<std::mutex> setup(g_setup_mutex);
   const pid_t me = getpid();
   if (!g_pool || g_pool_pid != me) {
     if (g_pool)
-      for (Ring& r : g_ring) new (&r) Ring();
+      for (auto& side : g_ring)
+        for (Ring& r : side) new (&r) Ring();
     g_pool = new Pool();
     g_pool_pid = me;
   }
@@ -172,11 +179,12 @@ void free_ring(Ring& r) {
   r.next = 0;
 }
 
-Ring* ring_of_current_device() {
+Ring* ring_of_current_device(int side) {
   Pool& p = pool();
+  std::lock_guard<std::mutex> setup(g_setup_mutex);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  Ring& r = g_ring[dev];
+  Ring& r = g_ring[side][dev];
   if (!r.ready) {
     for (int s = 0; s < kSlots; ++s) {
       if (hipHostMalloc(reinterpret_cast<void**>(&r.pinned[s]), kSlotBytes, hipHostMallocDefault) != hipSuccess ||
@@ -200,17 +208,22 @@ int32_t describe_io_error(const char* what, int err) {
 
 }  // namespace
 
+void stop_transfer_driver();     // (below: the thread behind mi355q_file_io_submit_*)
+
 void release_file_io() {
-  std::lock_guard<std::mutex> lock(g_mutex);
+  stop_transfer_driver();
+  std::lock_guard<std::mutex> up(g_mutex[0]);
+  std::lock_guard<std::mutex> down(g_mutex[1]);
   if (!g_pool || g_pool_pid != getpid()) return;       // nothing of this process to give back
-  for (Ring& r : g_ring) {
-    if (!r.ready) continue;
-    for (int s = 0; s < kSlots; ++s) {
-      r.io[s].wait();
-      if (r.left[s]) (void)hipEventSynchronize(r.left[s]);
+  for (auto& side : g_ring)
+    for (Ring& r : side) {
+      if (!r.ready) continue;
+      for (int s = 0; s < kSlots; ++s) {
+        r.io[s].wait();
+        if (r.left[s]) (void)hipEventSynchronize(r.left[s]);
+      }
+      free_ring(r);
     }
-    free_ring(r);
-  }
   g_pool->shutdown();
 }
 
@@ -218,13 +231,15 @@ void release_file_io() {
 
 using namespace mi355q;
 
-extern "C" int32_t mi355q_file_to_device(int32_t fd, int64_t file_offset, int64_t nbytes, void* dst, void* copy_stream) {
-  clear_error();
+namespace {
+
+// gate: an event of the caller's that `copy_stream` waits for before the first copy (a download's producer), or null
+int32_t upload_body(int32_t fd, int64_t file_offset, int64_t nbytes, void* dst, void* copy_stream) {
   if (nbytes < 0 || file_offset < 0 || fd < 0) return fail(MI355Q_BAD_ARG, "bad file range");
   if (nbytes == 0) return MI355Q_OK;
   if (!dst) return fail(MI355Q_BAD_ARG, "null pointer");
-  std::lock_guard<std::mutex> lock(g_mutex);
-  Ring* r = ring_of_current_device();
+  std::lock_guard<std::mutex> lock(g_mutex[0]);
+  Ring* r = ring_of_current_device(0);
   if (!r) return fail(MI355Q_HIP_ERROR, "pinned staging for the io ring: %s", hipGetErrorString(hipGetLastError()));
   hipStream_t st = as_stream(copy_stream);
   Pool& p = pool();
@@ -264,15 +279,18 @@ extern "C" int32_t mi355q_file_to_device(int32_t fd, int64_t file_offset, int64_
   return MI355Q_OK;
 }
 
-extern "C" int32_t mi355q_device_to_file(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset, void* copy_stream) {
-  clear_error();
+int32_t download_body(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset, void* copy_stream, hipEvent_t gate) {
   if (nbytes < 0 || file_offset < 0 || fd < 0) return fail(MI355Q_BAD_ARG, "bad file range");
   if (nbytes == 0) return MI355Q_OK;
   if (!src) return fail(MI355Q_BAD_ARG, "null pointer");
-  std::lock_guard<std::mutex> lock(g_mutex);
-  Ring* r = ring_of_current_device();
+  std::lock_guard<std::mutex> lock(g_mutex[1]);
+  Ring* r = ring_of_current_device(1);
   if (!r) return fail(MI355Q_HIP_ERROR, "pinned staging for the io ring: %s", hipGetErrorString(hipGetLastError()));
   hipStream_t st = as_stream(copy_stream);
+  // (the payload's producer has finished before the first copy is enqueued: this thread's only job is to wait, and the
+  // copy stream then never holds a copy that waits behind compute)
+  if (gate)
+    if (hipError_t e = hipEventSynchronize(gate)) return fail(MI355Q_HIP_ERROR, "download gate: %s", hipGetErrorString(e));
   Pool& p = pool();
   int pending_slot = -1;
   long long pending_off = 0;
@@ -297,18 +315,217 @@ extern "C" int32_t mi355q_device_to_file(const void* src, int64_t nbytes, int32_
   return MI355Q_OK;               // (write errors surface in mi355q_file_io_finish)
 }
 
+// ---- transfers that do not hold the caller: mi355q_file_io_submit_upload / _download / mi355q_file_io_wait ------------
+// The two bodies above return when their last device copy is ENQUEUED, which for an upload is when the last pread is
+// done: a model's weights cross at the ring's rate while the calling thread stands still. Submitted transfers run the
+// same bodies on one driver thread, first in first out; the caller meets a transfer again only where it needs it
+// (mi355q_file_io_wait: its device copies are enqueued and `consumer_stream` is ordered behind them).
+struct Transfer {
+  bool upload = true;
+  int32_t fd = -1;
+  int64_t file_offset = 0, nbytes = 0;
+  void* device_ptr = nullptr;
+  void* stream = nullptr;
+  hipEvent_t gate = nullptr;      // download: the caller's event behind which the payload is final (may be null)
+  int device = 0;
+  bool enqueued = false;
+  int32_t status = MI355Q_OK;
+  std::string message;
+};
+
+struct Driver {
+  std::mutex m;
+  std::condition_variable cv;          // work for the thread / a transfer has been enqueued
+  std::deque<int64_t> queue;
+  std::unordered_map<int64_t, Transfer> all;
+  int64_t next_ticket = 1;
+  bool busy = false, stop = false;
+  int32_t download_status = MI355Q_OK;   // first failure of a submitted download: reported (and cleared) by mi355q_file_io_finish
+  std::string download_message;
+  std::thread thread;
+  pid_t pid = 0;
+
+  void run() {
+    for (;;) {
+      int64_t ticket;
+      Transfer t;
+      {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return stop || !queue.empty(); });
+        if (queue.empty()) return;
+        ticket = queue.front();
+        queue.pop_front();
+        t = all[ticket];
+        busy = true;
+      }
+      int32_t status = MI355Q_OK;
+      std::string message;
+      if (hipSetDevice(t.device) != hipSuccess) {
+        status = MI355Q_HIP_ERROR;
+        message = "hipSetDevice on the transfer thread failed";
+      } else {
+        status = t.upload ? upload_body(t.fd, t.file_offset, t.nbytes, t.device_ptr, t.stream)
+                          : download_body(t.device_ptr, t.nbytes, t.fd, t.file_offset, t.stream, t.gate);
+        if (status != MI355Q_OK) message = mi355q_last_error();      // (this thread's)
+      }
+      {
+        std::lock_guard<std::mutex> l(m);
+        auto it = all.find(ticket);
+        if (it != all.end()) {
+          if (t.upload) {
+            it->second.enqueued = true;
+            it->second.status = status;
+            it->second.message = message;
+          } else {                         // nobody waits for a download: its record goes, its failure stays
+            all.erase(it);
+            if (status != MI355Q_OK && download_status == MI355Q_OK) {
+              download_status = status;
+              download_message = message;
+            }
+          }
+        }
+        busy = false;
+      }
+      cv.notify_all();
+    }
+  }
+};
+
+Driver* g_driver[2] = {nullptr, nullptr};     // [0] uploads, [1] downloads: the two directions do not queue behind each other
+std::mutex g_driver_mutex;
+
+Driver* driver_if_any(int side) {
+  std::lock_guard<std::mutex> l(g_driver_mutex);
+  Driver* d = g_driver[side];
+  return d && d->pid == getpid() ? d : nullptr;
+}
+
+Driver& driver(int side) {
+  std::lock_guard<std::mutex> l(g_driver_mutex);
+  const pid_t me = getpid();
+  if (!g_driver[side] || g_driver[side]->pid != me) {     // (a fork()ed child has the object but not the thread: it starts its own)
+    g_driver[side] = new Driver();
+    g_driver[side]->pid = me;
+    g_driver[side]->thread = std::thread([d = g_driver[side]] { d->run(); });
+  }
+  return *g_driver[side];
+}
+
+int32_t submit(Transfer t, int64_t* ticket) {
+  if (hipGetDevice(&t.device) != hipSuccess) return fail(MI355Q_HIP_ERROR, "hipGetDevice: %s", hipGetErrorString(hipGetLastError()));
+  Driver& d = driver(t.upload ? 0 : 1);
+  {
+    std::lock_guard<std::mutex> l(d.m);
+    *ticket = d.next_ticket++;
+    d.all[*ticket] = t;
+    d.queue.push_back(*ticket);
+  }
+  d.cv.notify_all();
+  return MI355Q_OK;
+}
+
+}  // namespace
+
+namespace mi355q {
+void stop_transfer_driver() {
+  for (int side = 0; side < 2; ++side) {
+    Driver* d = driver_if_any(side);
+    if (!d) continue;
+    {
+      std::lock_guard<std::mutex> l(d->m);
+      d->stop = true;
+    }
+    d->cv.notify_all();
+    if (d->thread.joinable()) d->thread.join();        // (runs the queue dry first)
+    std::lock_guard<std::mutex> l(g_driver_mutex);
+    delete d;
+    g_driver[side] = nullptr;
+  }
+}
+}  // namespace mi355q
+
+extern "C" int32_t mi355q_file_to_device(int32_t fd, int64_t file_offset, int64_t nbytes, void* dst, void* copy_stream) {
+  clear_error();
+  return upload_body(fd, file_offset, nbytes, dst, copy_stream);
+}
+
+extern "C" int32_t mi355q_device_to_file(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset, void* copy_stream) {
+  clear_error();
+  return download_body(src, nbytes, fd, file_offset, copy_stream, nullptr);
+}
+
+extern "C" int32_t mi355q_file_io_submit_upload(int32_t fd, int64_t file_offset, int64_t nbytes, void* dst, void* copy_stream,
+                                                int64_t* ticket) {
+  clear_error();
+  if (!ticket) return fail(MI355Q_BAD_ARG, "null ticket");
+  if (nbytes < 0 || file_offset < 0 || fd < 0) return fail(MI355Q_BAD_ARG, "bad file range");
+  if (nbytes > 0 && !dst) return fail(MI355Q_BAD_ARG, "null pointer");
+  Transfer t;
+  t.upload = true; t.fd = fd; t.file_offset = file_offset; t.nbytes = nbytes; t.device_ptr = dst; t.stream = copy_stream;
+  return submit(t, ticket);
+}
+
+extern "C" int32_t mi355q_file_io_submit_download(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset, void* copy_stream,
+                                                  void* ready_event) {
+  clear_error();
+  if (nbytes < 0 || file_offset < 0 || fd < 0) return fail(MI355Q_BAD_ARG, "bad file range");
+  if (nbytes == 0) return MI355Q_OK;
+  if (!src) return fail(MI355Q_BAD_ARG, "null pointer");
+  Transfer t;
+  t.upload = false; t.fd = fd; t.file_offset = file_offset; t.nbytes = nbytes; t.device_ptr = const_cast<void*>(src); t.stream = copy_stream;
+  t.gate = reinterpret_cast<hipEvent_t>(ready_event);
+  int64_t ticket = 0;
+  return submit(t, &ticket);
+}
+
+extern "C" int32_t mi355q_file_io_wait(int64_t ticket) {
+  clear_error();
+  Driver* d = driver_if_any(0);
+  if (!d) return fail(MI355Q_BAD_ARG, "no such transfer (ticket %lld)", static_cast<long long>(ticket));
+  Transfer t;
+  {
+    std::unique_lock<std::mutex> l(d->m);
+    auto it = d->all.find(ticket);
+    if (it == d->all.end()) return fail(MI355Q_BAD_ARG, "no such transfer (ticket %lld)", static_cast<long long>(ticket));
+    d->cv.wait(l, [&] { return d->all[ticket].enqueued; });
+    t = d->all[ticket];
+    d->all.erase(ticket);
+  }
+  // (the caller orders its consumers behind the copies the way it always did: an event it records on the copy stream NOW
+  // lies behind every copy of this transfer, all of which are enqueued)
+  if (t.status != MI355Q_OK) return fail(static_cast<mi355q_status>(t.status), "%s", t.message.c_str());
+  return MI355Q_OK;
+}
+
 extern "C" int32_t mi355q_file_io_finish(void) {
   clear_error();
-  std::lock_guard<std::mutex> lock(g_mutex);
+  int32_t submitted_status = MI355Q_OK;
+  std::string submitted_message;
+  for (int side = 0; side < 2; ++side) {      // submitted transfers first: all enqueued, none running
+    Driver* d = driver_if_any(side);
+    if (!d) continue;
+    std::unique_lock<std::mutex> l(d->m);
+    d->cv.wait(l, [&] { return d->queue.empty() && !d->busy; });
+    if (d->download_status != MI355Q_OK && submitted_status == MI355Q_OK) {
+      submitted_status = d->download_status;
+      submitted_message = d->download_message;
+    }
+    d->download_status = MI355Q_OK;
+    d->download_message.clear();
+  }
+  std::lock_guard<std::mutex> up(g_mutex[0]);
+  std::lock_guard<std::mutex> down(g_mutex[1]);
   if (!g_pool || g_pool_pid != getpid()) return MI355Q_OK;   // no transfer of this process is open
-  for (Ring& r : g_ring)
-    if (r.ready)
-      for (int s = 0; s < kSlots; ++s) r.io[s].wait();
+  for (auto& side : g_ring)
+    for (Ring& r : side)
+      if (r.ready)
+        for (int s = 0; s < kSlots; ++s) r.io[s].wait();
   int err;
   {
     std::lock_guard<std::mutex> l(g_pool->m);
     err = g_pool->write_error;
     g_pool->write_error = 0;
   }
+  if (submitted_status != MI355Q_OK) return fail(static_cast<mi355q_status>(submitted_status), "%s", submitted_message.c_str());
   return describe_io_error("writing the output file", err);
 }

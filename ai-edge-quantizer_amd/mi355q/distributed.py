@@ -346,19 +346,24 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
   qsvs = calibration_result if calibration_result is not None else {}
   if world > 1:
     _require_hessians_where_read([it for it, o in zip(plan, owner) if o == rank], qsvs, rank)
+  from . import runtime as rt
   gen.prefetch([it for it, o in zip(plan, owner) if o == rank], qsvs)
+  rt.mark("quantize: prefetched (host)")
   try:
     with requant_queue.batching():       # this rank's equally shaped weights leave in one launch per group
       mine = {i: gen.materialize_op(it, qsvs) for i, (it, o) in enumerate(zip(plan, owner)) if o == rank}
   finally:
     gen.release_derived(qsvs)
+  rt.mark("quantize: ops walked (host)")
   if world == 1:
     params = gen.finish(mine[i] for i in range(len(plan)))
-    return model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path, sink=sink)
+    rt.mark("quantize: params finished (host)", sync=True)
+    out = model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path, sink=sink)
+    rt.mark("quantize: model modified and serialized (host)")
+    return out
   # The results are gathered on rank 0, which merges them, applies the transformations and lays the file out. When a file
   # is being written, the quantized payloads themselves stay in their ranks' HBM (runtime.remote_payloads) and every rank
   # writes its own to the offsets rank 0's layout gave them: no gigabyte of pickles through rank 0's host memory.
-  from . import runtime as rt
   remote = (serialize_to_path is not None or sink is not None) and torch.cuda.is_available() and not os.environ.get("MI355Q_GATHER_PAYLOADS")
   if remote:
     with rt.remote_payloads(rank):
@@ -457,12 +462,17 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
   import time
   rank, world = _world(group)
   t0 = time.perf_counter()
+  from . import runtime as rt
+  rt.mark("call")
   planned = plan_model_shards(float_model, recipe, world)
-  qz, _, plan, owner, costs = planned
+  rt.mark("planned")
+  qz, gen, plan, owner, costs = planned
   owners = hessian_owners(plan, owner, costs) if world > 1 else None
   qsvs = None
   if qz._recipe_manager.need_calibration():  # pylint: disable=protected-access
     mine_items = [it for it, o in zip(plan, owner) if o == rank]
+    # calibration reads activations only: the weights this rank will quantize afterwards cross PCIe underneath it
+    gen.prefetch_weights(mine_items)
 
     def start_inverses(merged: dict) -> None:
       """The damped inverses this rank's ops will read, started as soon as the Hessians are final: the small ones in
@@ -473,6 +483,7 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
         return
       by_name = {name: {"hessian": h} for name, h in merged.items() if h is not None}
       gptq.prefetch_hessian_inverses(mine_items, by_name)
+      rt.mark("small inverses started (host)")
       started = 0
       for item in mine_items:
         name = gptq.hessian_name_of(item)
@@ -484,11 +495,13 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
             break
     qsvs = calibrate_sharded(qz.float_model, recipe, calibration_data, tensor_provider=tensor_provider, group=group,
                              hessian_owners=owners, after_hessians=start_inverses)
+  rt.mark("calibrated (host)", sync=True)
   if torch.cuda.is_available():
     torch.cuda.synchronize()
   t1 = time.perf_counter()
   out = quantize_model_sharded(qz.float_model, recipe, calibration_result=qsvs, serialize_to_path=serialize_to_path,
                                group=group, planned=planned, sink=sink)
+  rt.mark("quantized and written (host)", sync=True)
   if torch.cuda.is_available():
     torch.cuda.synchronize()
   if stats is not None:
@@ -570,7 +583,10 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
       for k, events in zip(shard, steps):
         mine.append((sig_idx, k, _set_hessians_aside(events, running)))
       steps.close()        # (the last step's window: zip stops without resuming the generator)
-  local.wait_for_statistics()       # (record_steps hands the samples' min / max over while their copies are in flight)
+  from . import runtime as rt
+  rt.mark("samples walked (host)")
+  local.wait_for_statistics()
+  rt.mark("statistics on the host")       # (record_steps hands the samples' min / max over while their copies are in flight)
   if world > 1:
     parts = [None] * world
     dist.all_gather_object(parts, mine, group=group)
@@ -592,9 +608,12 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
     final.load_model_qsvs(previous_calibration_result)
   earlier = {name: (qsv["hessian"], qsv["num_samples"]) for name, qsv in final.get_model_qsvs().items()
              if isinstance(qsv, dict) and "hessian" in qsv}
+  rt.mark("hessians merged (host)")
   if after_hessians is not None and not earlier:
     after_hessians(merged)
+  rt.mark("inverses started (host)")
   final.replay((events for _, _, events in mine), update_overrides={_HESSIAN_ASIDE: _ema_and_count_update})
+  rt.mark("replayed (host)")
   qsvs = final.get_model_qsvs()
   for name in totals:
     if name not in merged:          # reduced to another rank: this one never reads it

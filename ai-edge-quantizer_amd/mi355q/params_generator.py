@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Any, Optional
 
+import numpy as np
+
 from . import algorithm_manager
 from . import default_policy
 from . import qtyping
@@ -220,11 +222,32 @@ class ParamsGenerator:
 
   @staticmethod
   def prefetch(plan_items, model_qsvs) -> None:
-    """Work that is cheaper done for all of `plan_items` at once than op by op: the damped inverses of
-    the small GPTQ Hessians (batched on the device)."""
+    """Work that is cheaper done for all of `plan_items` at once than op by op: the uploads of the weights the
+    quantized ops read from a mapped model file (started now, in plan order, on the library's upload thread:
+    runtime.prefetch_uploads) and the damped inverses of the small GPTQ Hessians (batched on the device)."""
+    ParamsGenerator.prefetch_weights(plan_items)
     if model_qsvs and any(isinstance(q, dict) and "hessian" in q for q in model_qsvs.values()):
       from .algorithms.uniform_quantize import gptq
       gptq.prefetch_hessian_inverses(plan_items, model_qsvs)
+
+  @staticmethod
+  def prefetch_weights(plan_items) -> int:
+    """The constant operands (1 MiB and more, views of a mapped model file) of the ops the plan quantizes."""
+    from . import runtime as rt
+    no_q = algorithm_manager.AlgorithmName.NO_QUANTIZE
+    arrays, seen = [], set()
+    for graph_info, op, _, _, alg, _ in plan_items:
+      if alg == no_q:
+        continue
+      for tid in getattr(op, "inputs", ()):
+        if tid == -1:
+          continue
+        buffer_id = graph_info.subgraph_tensors[tid].buffer
+        data = graph_info.buffers[buffer_id].data if buffer_id else None
+        if isinstance(data, np.ndarray) and data.nbytes >= (1 << 20) and buffer_id not in seen:
+          seen.add(buffer_id)
+          arrays.append(data)
+    return rt.prefetch_uploads(arrays) if arrays else 0
 
   @staticmethod
   def release_derived(model_qsvs) -> None:

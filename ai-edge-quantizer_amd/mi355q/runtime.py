@@ -18,6 +18,21 @@ from . import _ffi
 
 _PREPARED: set = set()
 
+# MI355Q_TIMELINE=1: wall-clock marks at the phase boundaries of a whole-model call (tools/c5_model.py prints them).
+# `sync=True` marks wait for the GPU first, so the difference of two such marks is wall time with the GPU drained.
+TIMELINE: list = []
+_TIMELINE_ON = bool(os.environ.get("MI355Q_TIMELINE"))
+
+
+def mark(label: str, sync: bool = False) -> None:
+  if not _TIMELINE_ON:
+    return
+  import time
+  t_host = time.perf_counter()
+  if sync and torch.cuda.is_available():
+    torch.cuda.synchronize()
+  TIMELINE.append((label, t_host, time.perf_counter()))
+
 
 def require_gpu() -> None:
   if not torch.cuda.is_available():
@@ -70,7 +85,9 @@ def to_device(a, dtype=None) -> torch.Tensor:
 # three pinned 8 MiB slots -- page-locking costs ~1 ms per MiB here, once per process)
 _UPLOAD_MIN_FILE_BYTES = 1 << 30  # only models large enough to earn the ring's 24 ms back
 _UPLOAD_MIN_TENSOR_BYTES = 4 << 20
-_COPY_STREAMS: dict = {}   # device index -> the copy stream of the io ring
+_COPY_STREAMS: dict = {}   # device index -> the upload stream of the io ring
+_DOWNLOAD_STREAMS: dict = {}   # device index -> the download stream (the two directions do not queue behind each other)
+_DOWNLOADS_IN_FLIGHT: list = []    # (payload tensor, ready event) of submitted downloads, kept until finish_downloads()
 _FILE_MAPPINGS: list = []  # _FileMapping records of model files mapped by tfl_flatbuffer_utils
 _OUT_MAPPINGS: list = []   # (base address, length, file descriptor) of output files being built
 
@@ -171,6 +188,76 @@ def _copy_stream(dev) -> "torch.cuda.Stream":
   return st
 
 
+def _download_stream(dev) -> "torch.cuda.Stream":
+  st = _DOWNLOAD_STREAMS.get(dev.index)
+  if st is None:
+    st = _DOWNLOAD_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+  return st
+
+
+# ---- weights on their way to HBM before anybody asks for them ------------------------------------------------------
+# mi355q_file_to_device holds its caller until the file has been read; a model's op walk -- the thread that launches
+# the kernels -- stood still for 0.62 s of a Gemma-2B GPTQ run that way. prefetch_uploads() hands the weights a plan
+# will read to the library's upload thread (mi355q_file_io_submit_upload) in plan order; upload_overlapped() then finds
+# the tensor, waits only if its copies are not enqueued yet and orders the current stream behind them.
+PREFETCH_WINDOW_BYTES = int(os.environ.get("MI355Q_PREFETCH_BYTES", 32 << 30))   # submitted and not yet consumed
+_PREFETCHED: dict = {}     # (fd, offset, nbytes) -> (uint8 tensor, ticket)
+_PREFETCH_WAITING: dict = {}   # (fd, offset, nbytes) -> None, in plan order: beyond the window, submitted as earlier ones are consumed
+_PREFETCH_OUTSTANDING = [0]
+
+
+def _submit_upload(key) -> None:
+  fd, offset, n = key
+  dev = device()
+  copy_stream = _copy_stream(dev)
+  with torch.cuda.stream(copy_stream):
+    out = torch.empty((n,), dtype=torch.uint8, device=dev)
+  ticket = ctypes.c_int64(0)
+  _ffi.check(_ffi.lib().mi355q_file_io_submit_upload(fd, offset, n, ctypes.c_void_p(out.data_ptr()),
+                                                     ctypes.c_void_p(copy_stream.cuda_stream), ctypes.byref(ticket)))
+  _PREFETCHED[key] = (out, ticket.value)
+  _PREFETCH_OUTSTANDING[0] += n
+
+
+def _top_up_prefetch() -> None:
+  while _PREFETCH_WAITING and _PREFETCH_OUTSTANDING[0] < PREFETCH_WINDOW_BYTES:
+    key = next(iter(_PREFETCH_WAITING))
+    del _PREFETCH_WAITING[key]
+    _submit_upload(key)
+
+
+def prefetch_uploads(arrays) -> int:
+  """Starts the uploads of the file-backed weights among `arrays` (views of a registered model-file mapping, 1 MiB
+  and more), in the given order, without waiting for any of them; at most PREFETCH_WINDOW_BYTES are in HBM unconsumed
+  at a time. Returns the bytes queued. Whatever is not consumed is dropped by cancel_prefetch()."""
+  if os.environ.get("MI355Q_NO_PREFETCH") or not torch.cuda.is_available():
+    return 0
+  total = 0
+  for a in arrays:
+    if not isinstance(a, np.ndarray) or not a.flags.c_contiguous or a.nbytes < (1 << 20):
+      continue
+    where = _file_range_of(a)
+    if where is None:
+      continue
+    key = (where[0], where[1], a.nbytes)
+    if key in _PREFETCHED or key in _PREFETCH_WAITING:
+      continue
+    _PREFETCH_WAITING[key] = None
+    total += a.nbytes
+  _top_up_prefetch()
+  return total
+
+
+def cancel_prefetch() -> None:
+  """Uploads nobody consumed: waited for (the upload thread writes into their tensors) and dropped."""
+  _PREFETCH_WAITING.clear()
+  entries = list(_PREFETCHED.values())
+  _PREFETCHED.clear()
+  _PREFETCH_OUTSTANDING[0] = 0
+  for _, ticket in entries:
+    _ffi.lib().mi355q_file_io_wait(ticket)     # (a read error of a tensor nobody reads is nobody's error)
+
+
 def upload_overlapped(a: np.ndarray) -> torch.Tensor:
   """A weight that is a view of a mapped model file -> device tensor, without waiting for the compute
   already queued on the current stream.
@@ -180,62 +267,66 @@ def upload_overlapped(a: np.ndarray) -> torch.Tensor:
   milliseconds of inverse and update, the op walk then advances in lock step with the GPU and the
   model's 8 GB of weights cross PCIe while nothing computes; and it moves 24 GB/s (one staging
   thread inside the runtime). Here the bytes are read from the
-  FILE (mi355q_file_to_device: pread() on the library's io threads -- a kernel copy out of the page
+  FILE (pread() on the library's io threads -- a kernel copy out of the page
   cache, no page-table population of the mapping -- into a ring of pinned slots) and travel on a
   copy stream of their own;
   the current stream waits for them only where it first uses the tensor. The tensor is allocated
   on the copy stream (the block it lands in cannot still be read by compute queued earlier) and
-  recorded on the current one. Arrays that are not views of a registered mapping of at least 1 GiB
+  recorded on the current one. A weight that prefetch_uploads() announced is already on its way (or there); the
+  others are submitted here and waited for. Arrays that are not views of a registered mapping of at least 1 GiB
   take the pageable copy."""
   where = _file_range_of(a) if isinstance(a, np.ndarray) and a.flags.c_contiguous else None
   if where is None:
     with warnings.catch_warnings():
       warnings.simplefilter("ignore")  # non-writable buffer warning for mmap views
       return torch.from_numpy(np.ascontiguousarray(a)).to(device(), non_blocking=True)
-  fd, offset = where        # (mi355q_file_to_device returns when its preads are done: `a` keeps the mapping, and so fd, alive)
-  dev = device()
-  copy_stream = _copy_stream(dev)
-  n = a.nbytes
-  with torch.cuda.stream(copy_stream):
-    out = torch.empty((n,), dtype=torch.uint8, device=dev)
-  _ffi.check(_ffi.lib().mi355q_file_to_device(fd, offset, n, ctypes.c_void_p(out.data_ptr()),
-                                              ctypes.c_void_p(copy_stream.cuda_stream)))
+  key = (where[0], where[1], a.nbytes)   # (the transfer is over when mi355q_file_io_wait returns: `a` keeps the mapping, and so fd, alive)
+  if key not in _PREFETCHED:
+    _PREFETCH_WAITING.pop(key, None)
+    _submit_upload(key)
+  out, ticket = _PREFETCHED.pop(key)
+  _PREFETCH_OUTSTANDING[0] -= a.nbytes
+  _ffi.check(_ffi.lib().mi355q_file_io_wait(ticket))      # every copy of the transfer is enqueued on the copy stream
   done = torch.cuda.Event()
-  done.record(copy_stream)
+  done.record(_copy_stream(out.device))
   cur = torch.cuda.current_stream()
   cur.wait_event(done)
   out.record_stream(cur)
+  _top_up_prefetch()
   t = torch.from_numpy(np.empty(0, a.dtype)).dtype
   return out.view(t).reshape(a.shape)
 
 
-def download_into_file(t: torch.Tensor, dst: np.ndarray) -> bool:
+def _submit_download(src: torch.Tensor, fd: int, offset: int, ready=None) -> None:
+  """`src` (flat uint8, device) -> fd at offset on the library's download thread. The copies wait for `ready` (an event
+  recorded behind the payload's producer; default: everything queued on the current stream now), not for what
+  is queued later; `src` and the event are kept until finish_downloads()."""
+  if ready is None:
+    ready = torch.cuda.Event()
+    ready.record()
+  st = _download_stream(src.device)
+  _ffi.check(_ffi.lib().mi355q_file_io_submit_download(ctypes.c_void_p(src.data_ptr()), src.numel(), fd, int(offset),
+                                                       ctypes.c_void_p(st.cuda_stream), ctypes.c_void_p(ready.cuda_event)))
+  _DOWNLOADS_IN_FLIGHT.append((src, ready))
+
+
+def download_into_file(t: torch.Tensor, dst: np.ndarray, ready=None) -> bool:
   """Device bytes -> the output file whose mapping `dst` is a view of (register_output_mapping):
-  mi355q_device_to_file copies into the pinned ring on the copy stream and pwrite()s from there on
-  the io threads. False when `dst` is not inside a registered output mapping (finish_downloads()
-  before the file is handed back)."""
+  asynchronous copies into the pinned download ring and pwrite() from there on the io threads, driven by the
+  library's download thread (mi355q_file_io_submit_download): the call returns at once. False when `dst` is not inside
+  a registered output mapping (finish_downloads() before the file is handed back)."""
   addr = dst.ctypes.data
   hit = next(((base, fd) for base, length, fd in reversed(_OUT_MAPPINGS) if base <= addr and addr + dst.nbytes <= base + length), None)
   if hit is None or not t.is_cuda or dst.nbytes < (1 << 20):
     return False
   base, fd = hit
-  src = t.contiguous().reshape(-1).view(torch.uint8)
-  copy_stream = _copy_stream(src.device)
-  copy_stream.wait_stream(torch.cuda.current_stream())     # the kernels that produce t
-  _ffi.check(_ffi.lib().mi355q_device_to_file(ctypes.c_void_p(src.data_ptr()), src.numel(), fd, addr - base,
-                                              ctypes.c_void_p(copy_stream.cuda_stream)))
-  src.record_stream(copy_stream)
+  _submit_download(t.contiguous().reshape(-1).view(torch.uint8), fd, addr - base, ready)
   return True
 
 
 def write_to_file(t: torch.Tensor, fd: int, offset: int) -> None:
   """Device bytes -> `fd` at `offset` through the io ring (this rank's own descriptor of a file another rank laid out)."""
-  src = t.contiguous().reshape(-1).view(torch.uint8)
-  copy_stream = _copy_stream(src.device)
-  copy_stream.wait_stream(torch.cuda.current_stream())
-  _ffi.check(_ffi.lib().mi355q_device_to_file(ctypes.c_void_p(src.data_ptr()), src.numel(), fd, int(offset),
-                                              ctypes.c_void_p(copy_stream.cuda_stream)))
-  src.record_stream(copy_stream)
+  _submit_download(t.contiguous().reshape(-1).view(torch.uint8), fd, offset)
 
 
 def output_file_range_of(dst: np.ndarray):
@@ -323,13 +414,17 @@ class RemoteBuffer:
 
 def finish_downloads() -> None:
   """Waits for the pwrite()s of download_into_file (before the output file is handed back)."""
-  if _COPY_STREAMS:
-    _ffi.check(_ffi.lib().mi355q_file_io_finish())
+  if _COPY_STREAMS or _DOWNLOAD_STREAMS:
+    try:
+      _ffi.check(_ffi.lib().mi355q_file_io_finish())
+    finally:
+      del _DOWNLOADS_IN_FLIGHT[:]
 
 
 def release_upload_files() -> None:
   """Waits for the uploads in flight. (The descriptors belong to the mappings they were
   duplicated for and are closed when those are unmapped: _FileMapping.)"""
+  cancel_prefetch()
   for st in _COPY_STREAMS.values():
     st.synchronize()
   for rec in [m for m in _FILE_MAPPINGS if not m.alive()]:
@@ -341,6 +436,7 @@ def release_upload_staging() -> None:
   threads go with mi355q_shutdown()."""
   release_upload_files()
   _COPY_STREAMS.clear()
+  _DOWNLOAD_STREAMS.clear()
 
 
 _NP_DTYPE: dict = {}     # torch dtype -> NumPy dtype

@@ -512,6 +512,29 @@ int32_t mi355q_file_to_device(int32_t fd, int64_t file_offset, int64_t nbytes, v
 int32_t mi355q_device_to_file(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset, void* copy_stream);
 int32_t mi355q_file_io_finish(void);
 
+/* The same transfers without holding the caller (round 4). mi355q_file_to_device returns when the file has been READ --
+ * a model's weights cross at the ring's rate while the calling thread, the one that walks the ops and launches the
+ * kernels, stands still (0.62 s of a 3.6 s Gemma-2B GPTQ run; 30 of the 60 ms of a 1.4 GB file -> file run).
+ *   mi355q_file_io_submit_upload    queues the transfer on the library's upload thread (first in, first out) and
+ *                                   returns a ticket at once; `dst` and `fd` stay valid until the ticket is waited for.
+ *   mi355q_file_io_wait             blocks until the ticket's last copy is ENQUEUED on its copy stream (an event the
+ *                                   caller records on that stream afterwards lies behind all of them), frees the
+ *                                   ticket and returns the transfer's status (a short or failing read is
+ *                                   MI355Q_IO_ERROR here; nothing of a spoiled slot was copied).
+ *   mi355q_file_io_submit_download  queues `src` -> file on the download thread (its own ring: uploads and
+ *                                   downloads run at the same time). `ready_event`, when not null, is a hipEvent_t
+ *                                   the caller has RECORDED behind the payload's producer: the download thread waits for it
+ *                                   (hipEventSynchronize) before it enqueues the first copy -- for that producer, not
+ *                                   for everything queued on the compute stream. No ticket:
+ *                                   mi355q_file_io_finish waits for every submitted transfer of both directions
+ *                                   and the writes behind them, and reports the first failure.
+ * ref: the same two call sites (utils/tfl_flatbuffer_utils.py:142-163, model_modifier.py:290-391). */
+int32_t mi355q_file_io_submit_upload(int32_t fd, int64_t file_offset, int64_t nbytes, void* dst, void* copy_stream,
+                                     int64_t* ticket);
+int32_t mi355q_file_io_wait(int64_t ticket);
+int32_t mi355q_file_io_submit_download(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset,
+                                       void* copy_stream, void* ready_event);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -84,6 +84,67 @@ def test_short_file_and_bad_descriptor_are_io_errors(m, tmp_path):
   assert L.mi355q_file_io_finish() == 0
 
 
+def test_submitted_transfers_do_not_hold_the_caller_and_arrive_whole(m, tmp_path):
+  """mi355q_file_io_submit_upload / _wait / _submit_download (round 4): several uploads queued at once return before
+  they ran, each ticket's wait hands over the file's bytes (the consumer ordered behind an event recorded on the copy
+  stream after the wait); downloads gated on a producer's event write the PRODUCED bytes (a kernel queued behind a
+  long one), at the same time as uploads; a short file is the waiting ticket's MI355Q_IO_ERROR and a bad descriptor
+  of a download is reported by mi355q_file_io_finish, once."""
+  torch, L = m.torch, m.ffi.lib()
+  rng = np.random.default_rng(11)
+  sizes = [(20 << 20) + 3, 4097, (8 << 20), 1]
+  blobs, fds, devs, tickets = [], [], [], []
+  up, down = torch.cuda.Stream(), torch.cuda.Stream()
+  for i, n in enumerate(sizes):
+    blob = rng.integers(0, 256, n + 9, dtype=np.uint8)
+    path = str(tmp_path / f"in{i}.bin")
+    blob.tofile(path)
+    blobs.append(blob)
+    fds.append(os.open(path, os.O_RDONLY))
+    devs.append(torch.zeros(n, dtype=torch.uint8, device="cuda"))
+  torch.cuda.synchronize()
+  out_path = str(tmp_path / "out.bin")
+  np.zeros(sum(sizes) + 64, np.uint8).tofile(out_path)
+  out_fd = os.open(out_path, os.O_RDWR)
+  try:
+    for fd, n, dev in zip(fds, sizes, devs):
+      t = ctypes.c_int64(0)
+      m.ffi.check(L.mi355q_file_io_submit_upload(fd, 7, n, ctypes.c_void_p(dev.data_ptr()), ctypes.c_void_p(up.cuda_stream), ctypes.byref(t)))
+      tickets.append(t.value)
+    assert len(set(tickets)) == len(tickets) and all(t > 0 for t in tickets)
+    # a producer that finishes late: the download of its result must wait for IT
+    big = torch.randn((8192, 8192), device="cuda")
+    for _ in range(20):
+      big = big @ big * 1e-4
+    produced = (torch.arange(5 << 20, device="cuda", dtype=torch.int32) % 251).to(torch.uint8)
+    ready = torch.cuda.Event()
+    ready.record()
+    m.ffi.check(L.mi355q_file_io_submit_download(ctypes.c_void_p(produced.data_ptr()), produced.numel(), out_fd, 32,
+                                                 ctypes.c_void_p(down.cuda_stream), ctypes.c_void_p(ready.cuda_event)))
+    for t, n, dev, blob in zip(tickets, sizes, devs, blobs):
+      m.ffi.check(L.mi355q_file_io_wait(t))
+      done = torch.cuda.Event()
+      done.record(up)
+      torch.cuda.current_stream().wait_event(done)
+      assert np.array_equal((dev + 0).cpu().numpy(), blob[7:7 + n])       # (dev + 0: a kernel on the consumer stream)
+    assert L.mi355q_file_io_wait(tickets[0]) == -1                         # a ticket is waited for once
+    m.ffi.check(L.mi355q_file_io_finish())
+    back = np.fromfile(out_path, np.uint8)
+    assert np.array_equal(back[32:32 + produced.numel()], produced.cpu().numpy()) and not back[:32].any()
+    # failures: a range past the end of the file belongs to its ticket; a closed descriptor of a download to finish()
+    t = ctypes.c_int64(0)
+    m.ffi.check(L.mi355q_file_io_submit_upload(fds[1], 0, 1 << 20, ctypes.c_void_p(devs[0].data_ptr()), ctypes.c_void_p(up.cuda_stream), ctypes.byref(t)))
+    assert L.mi355q_file_io_wait(t.value) == -6 and b"end of file" in L.mi355q_last_error()
+  finally:
+    for fd in fds:
+      os.close(fd)
+    os.close(out_fd)
+  m.ffi.check(L.mi355q_file_io_submit_download(ctypes.c_void_p(produced.data_ptr()), 4096, out_fd, 0, ctypes.c_void_p(down.cuda_stream), None))
+  assert L.mi355q_file_io_finish() == -6 and L.mi355q_last_error()
+  assert L.mi355q_file_io_finish() == 0
+  del big
+
+
 def _sha(path):
   h = hashlib.sha256()
   with open(path, "rb") as f:

@@ -338,6 +338,10 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
       idle_gaps=(timer.gaps() if timer and os.environ.get("MI355Q_C5_GAPS") else None),
       plan=dict(modelled_s_per_rank=[round(v, 4) for v in loads],
                 makespan_over_mean=round(max(loads) / (sum(loads) / world), 3) if sum(loads) else None))
+  from mi355q import runtime as rt
+  if rt.TIMELINE:      # MI355Q_TIMELINE=1: (label, ms since the call began when the host got there, ms when the GPU had drained if waited for)
+    out["timeline"] = [(label, round((a - t0) * 1e3, 1), round((b - t0) * 1e3, 1)) for label, a, b in rt.TIMELINE]
+    del rt.TIMELINE[:]
   if os.path.exists(dst) and not keep:
     os.remove(dst)
   if own_src and not keep and os.path.exists(src):
