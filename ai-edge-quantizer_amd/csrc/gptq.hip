@@ -1415,6 +1415,24 @@ namespace mi355q { void release_file_io(); }   // file_io.hip
 
 namespace { void prepare_hinv_pool(); }
 
+// Device memory of the caller's own (host code: ctypes releases the interpreter lock around these, the framework's
+// allocator does not around its hipMalloc): see include/mi355q.h.
+extern "C" int32_t mi355q_device_alloc(size_t nbytes, void** out) {
+  clear_error();
+  if (!out) return fail(MI355Q_BAD_ARG, "null pointer");
+  *out = nullptr;
+  if (nbytes == 0) return MI355Q_OK;
+  if (hipError_t e = hipMalloc(out, nbytes)) return fail(MI355Q_HIP_ERROR, "hipMalloc(%zu): %s", nbytes, hipGetErrorString(e));
+  return MI355Q_OK;
+}
+
+extern "C" int32_t mi355q_device_free(void* p) {
+  clear_error();
+  if (!p) return MI355Q_OK;
+  if (hipError_t e = hipFree(p)) return fail(MI355Q_HIP_ERROR, "hipFree: %s", hipGetErrorString(e));
+  return MI355Q_OK;
+}
+
 extern "C" int32_t mi355q_prepare_device(void) {
   clear_error();
   {

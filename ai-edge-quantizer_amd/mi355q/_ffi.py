@@ -100,6 +100,8 @@ PROTOTYPES = {
     "mi355q_file_io_wait": (c_i32, [c_i64]),
     "mi355q_file_io_submit_download": (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr]),
     "mi355q_prepare_device": (c_i32, []),
+    "mi355q_device_alloc": (c_i32, [c_size, ctypes.POINTER(ctypes.c_void_p)]),
+    "mi355q_device_free": (c_i32, [c_ptr]),
 }
 
 STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "BAD_SHAPE", -3: "UNSUPPORTED", -4: "HIP_ERROR",

@@ -329,6 +329,19 @@ def hessian_name_of(plan_item) -> Optional[str]:
   return tfl_flatbuffer_utils.get_tensor_name(graph_info.subgraph_tensors[op.inputs[0]])
 
 
+def largest_hessian_order(plan_items) -> int:
+  """The largest input width among the FULLY_CONNECTED-like GPTQ ops of a plan (0: none): the order of the largest
+  Hessian its calibration will produce."""
+  best = 0
+  for graph_info, op, _, op_key, alg, _ in plan_items:
+    if str(getattr(alg, "value", alg)) != ALGORITHM_KEY or op_key is None or len(op.inputs) < 2 or op.inputs[1] == -1:
+      continue
+    shape = graph_info.subgraph_tensors[op.inputs[1]].shape
+    if shape is not None and len(shape) == 2:
+      best = max(best, int(shape[-1]))
+  return best
+
+
 def prefetch_hessian_inverses(plan_items, model_qsvs, damp_factor: float = 0.01) -> int:
   """Inverts, in one batched call per order, every Hessian the GPTQ ops among `plan_items`
   (ParamsGenerator.plan_ops tuples) will read and that has no cached inverse yet. A model has
@@ -516,12 +529,16 @@ class _ApplyQueue:
       h.cache.pop(_READERS_LEFT, None)
       self._hinv = self._key = None
     packed_all = ops.pack_bits(q_all, bits) if bits in (2, 4) else None
+    produced = torch.cuda.Event()      # behind this group's payloads: the file writer waits for THEM, not for the ops queued later
+    produced.record()
     row0 = 0
     d = w.shape[1]
     for w_e, _, q, packed, _, _ in entries:
       rows = w_e.shape[0]
       q.device_tensor = q_all[row0:row0 + rows]
+      q.ready = produced
       if packed is not None:
+        packed.ready = produced
         per = 8 // bits
         packed.device_tensor = packed_all[row0 * d // per:(row0 + rows) * d // per]
       row0 += rows

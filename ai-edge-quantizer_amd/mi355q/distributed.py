@@ -346,21 +346,29 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
   qsvs = calibration_result if calibration_result is not None else {}
   if world > 1:
     _require_hessians_where_read([it for it, o in zip(plan, owner) if o == rank], qsvs, rank)
+  import contextlib
   from . import runtime as rt
   gen.prefetch([it for it, o in zip(plan, owner) if o == rank], qsvs)
   rt.mark("quantize: prefetched (host)")
-  try:
-    with requant_queue.batching():       # this rank's equally shaped weights leave in one launch per group
-      mine = {i: gen.materialize_op(it, qsvs) for i, (it, o) in enumerate(zip(plan, owner)) if o == rank}
-  finally:
-    gen.release_derived(qsvs)
-  rt.mark("quantize: ops walked (host)")
-  if world == 1:
-    params = gen.finish(mine[i] for i in range(len(plan)))
-    rt.mark("quantize: params finished (host)", sync=True)
-    out = model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path, sink=sink)
-    rt.mark("quantize: model modified and serialized (host)")
-    return out
+  # (one process writing a file: the block stays open over the writer, see Quantizer.quantize)
+  writes_here = world == 1 and (serialize_to_path is not None or sink is not None)
+  with (requant_queue.batching() if writes_here else contextlib.nullcontext()):
+    try:
+      with requant_queue.batching():       # this rank's equally shaped weights leave in one launch per group
+        mine = {i: gen.materialize_op(it, qsvs) for i, (it, o) in enumerate(zip(plan, owner)) if o == rank}
+    finally:
+      gen.release_derived(qsvs)
+    rt.mark("quantize: ops walked (host)")
+    if world == 1:
+      params = gen.finish(mine[i] for i in range(len(plan)))
+      rt.mark("quantize: params finished (host)")
+      try:
+        out = model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path, sink=sink)
+      finally:
+        if writes_here:
+          rt.release_upload_files()       # (gen.release_derived left them to the open block)
+      rt.mark("quantize: model modified and serialized (host)")
+      return out
   # The results are gathered on rank 0, which merges them, applies the transformations and lays the file out. When a file
   # is being written, the quantized payloads themselves stay in their ranks' HBM (runtime.remote_payloads) and every rank
   # writes its own to the offsets rank 0's layout gave them: no gigabyte of pickles through rank 0's host memory.
@@ -469,10 +477,24 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
   qz, gen, plan, owner, costs = planned
   owners = hessian_owners(plan, owner, costs) if world > 1 else None
   qsvs = None
+  reserved: list = []          # ops.HinvWorkspace of the large inverses, released when the call is over
   if qz._recipe_manager.need_calibration():  # pylint: disable=protected-access
     mine_items = [it for it, o in zip(plan, owner) if o == rank]
     # calibration reads activations only: the weights this rank will quantize afterwards cross PCIe underneath it
-    gen.prefetch_weights(mine_items)
+    # (announced here; calibrate_sharded's sample loop starts a quarter GiB of them per sample -- their tensors are
+    # fresh HBM, ~30 ms of hipMalloc per GiB on the thread that also has to keep the GPU fed)
+    gen.prefetch_weights(mine_items, submit=False)
+
+    def between_samples(walked: int) -> None:
+      """Host work that costs hipMalloc time, done while the GPU has samples queued: a quarter GiB of the announced
+      weight uploads per sample, and (once) the HBM the first large inverse will take."""
+      from .algorithms.uniform_quantize import gptq
+      from . import ops
+      rt.pump_prefetch()
+      if walked == 2 and torch.cuda.is_available():
+        d = gptq.largest_hessian_order(mine_items)
+        if d >= 4096:
+          reserved.append(ops.HinvWorkspace(d).install())      # (allocated on a helper thread: ops.HinvWorkspace)
 
     def start_inverses(merged: dict) -> None:
       """The damped inverses this rank's ops will read, started as soon as the Hessians are final: the small ones in
@@ -493,17 +515,22 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
           started += 1
           if started == 2:
             break
-    qsvs = calibrate_sharded(qz.float_model, recipe, calibration_data, tensor_provider=tensor_provider, group=group,
-                             hessian_owners=owners, after_hessians=start_inverses)
-  rt.mark("calibrated (host)", sync=True)
-  if torch.cuda.is_available():
-    torch.cuda.synchronize()
-  t1 = time.perf_counter()
-  out = quantize_model_sharded(qz.float_model, recipe, calibration_result=qsvs, serialize_to_path=serialize_to_path,
-                               group=group, planned=planned, sink=sink)
-  rt.mark("quantized and written (host)", sync=True)
-  if torch.cuda.is_available():
-    torch.cuda.synchronize()
+  try:
+    if qz._recipe_manager.need_calibration():  # pylint: disable=protected-access
+      qsvs = calibrate_sharded(qz.float_model, recipe, calibration_data, tensor_provider=tensor_provider, group=group,
+                               hessian_owners=owners, after_hessians=start_inverses, between_samples=between_samples)
+    rt.mark("calibrated (host)", sync=True)
+    if torch.cuda.is_available():
+      torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    out = quantize_model_sharded(qz.float_model, recipe, calibration_result=qsvs, serialize_to_path=serialize_to_path,
+                                 group=group, planned=planned, sink=sink)
+    rt.mark("quantized and written (host)", sync=True)
+  finally:
+    if torch.cuda.is_available():
+      torch.cuda.synchronize()
+    for ws in reserved:
+      ws.release()
   if stats is not None:
     stats["calibrate_s"] = stats.get("calibrate_s", 0.0) + (t1 - t0)
     stats["quantize_and_write_s"] = stats.get("quantize_and_write_s", 0.0) + (time.perf_counter() - t1)
@@ -550,7 +577,8 @@ def _ema_and_count_update(qsv, new_qsv):
 def calibrate_sharded(float_model, recipe, calibration_data, previous_calibration_result=None,
                       tensor_provider=None, group=None, hessians: str = "consumed",
                       hessian_owners: Optional[dict[str, int]] = None,
-                      after_hessians: Optional[Callable[[dict], None]] = None) -> dict:
+                      after_hessians: Optional[Callable[[dict], None]] = None,
+                      between_samples: Optional[Callable[[int], None]] = None) -> dict:
   """`Quantizer(float_model, recipe).calibrate(calibration_data)` with every signature's samples
   sharded contiguously over the ranks of `group` (BASELINE config 4: 512 samples over 8 GPUs;
   config 5: GPTQ Hessians).
@@ -572,6 +600,7 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
   rm = qz._recipe_manager  # pylint: disable=protected-access
   if not rm.need_calibration():
     return {}
+  from . import runtime as rt
   local = calibrator.Calibrator(qz.float_model, tensor_provider=tensor_provider, hessians=hessians)
   mine = []                                    # (signature index, sample index, events)
   running: dict[str, list] = {}                # tensor name -> [Hessian mean over my samples, count]
@@ -582,8 +611,9 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
       steps = local.record_steps(signature_key, (samples[j] for j in shard), rm)
       for k, events in zip(shard, steps):
         mine.append((sig_idx, k, _set_hessians_aside(events, running)))
+        if between_samples is not None:      # (the caller's host work that is better done while the GPU has samples queued)
+          between_samples(len(mine))
       steps.close()        # (the last step's window: zip stops without resuming the generator)
-  from . import runtime as rt
   rt.mark("samples walked (host)")
   local.wait_for_statistics()
   rt.mark("statistics on the host")       # (record_steps hands the samples' min / max over while their copies are in flight)

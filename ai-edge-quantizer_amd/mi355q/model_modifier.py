@@ -19,9 +19,11 @@ from typing import Any, Optional
 import numpy as np
 
 from . import qtyping
+from . import requant_queue
 from . import runtime
 from . import transformation_instruction_generator
 from . import transformation_performer
+from .transformations import transformation_utils
 from .utils import tfl_flatbuffer_utils
 from .utils import tflite_flatbuffer
 
@@ -134,10 +136,18 @@ def serialize_model(model: Any, serialize_to_path: Optional[tfl_flatbuffer_utils
   # and they reach the disk when the kernel writes them back -- what a plain write() gives too;
   # the synchronous flush cost 19 ms of a 147 ms file -> file run)
   try:
-    return tflite_flatbuffer.serialize_with_external_buffers(model, _MIN_EXTERNAL_BUFFER_BYTES, sink)
+    def before_values():      # every payload has its place and is on its way: the one wait for the accelerator
+      runtime.mark("writer: every payload handed over (host)")
+      requant_queue.complete_active()
+      runtime.mark("writer: values in (host)")
+      transformation_utils.verify_late_constants(model)     # (may raise SharingNotDecided: modify_model builds again)
+    return tflite_flatbuffer.serialize_with_external_buffers(model, _MIN_EXTERNAL_BUFFER_BYTES, sink, before_values=before_values,
+                                                             on_layout=lambda: runtime.mark("writer: flatbuffer laid out (host)"))
   finally:
+    runtime.mark("writer: flatbuffer complete (host)")
     if opened:
       runtime.finish_downloads()
+    runtime.mark("writer: file written (host)")
     for mapping, fd in opened:
       runtime.forget_output_mapping(mapping)
       os.close(fd)
@@ -151,8 +161,24 @@ class ModelModifier:
                    serialize_to_path: Optional[tfl_flatbuffer_utils.Path] = None,
                    enable_progress_bar: Optional[bool] = None, sink=None):
     del enable_progress_bar
+    # Inside a caller's requant_queue.batching() block that covers this call (Quantizer.quantize with a path), constants
+    # still in HBM are laid out unread (transformation_utils.get_constant_buffer); should two of them turn out equal --
+    # the reference would have shared one buffer -- everything is built once more with the values read first.
+    late = (serialize_to_path is not None or sink is not None) and requant_queue.active() is not None
+    if late:
+      runtime._LATE_CONSTANTS[0] += 1   # pylint: disable=protected-access
+      try:
+        return self._modify(params, serialize_to_path, sink)
+      except transformation_utils.SharingNotDecided:
+        pass
+      finally:
+        runtime._LATE_CONSTANTS[0] -= 1   # pylint: disable=protected-access
+    return self._modify(params, serialize_to_path, sink)
+
+  def _modify(self, params, serialize_to_path, sink):
     quantized = copy_with_views(self._model)
     insts = apply_transformations(quantized, params)
+    runtime.mark("writer: transformations applied (host)")
     if _inserted_before_output(insts, _T.ADD_DEQUANTIZE):
       _repoint_signature_outputs(quantized, "_dequant")
     if _inserted_before_output(insts, _T.ADD_QUANTIZE):

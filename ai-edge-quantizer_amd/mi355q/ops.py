@@ -469,10 +469,61 @@ def gptq_hinv_from_product(product: torch.Tensor, alpha: float, damp_factor: flo
   info = rt.empty((1,), torch.int32)
   L = _ffi.lib()
   nbytes = L.mi355q_gptq_hinv_workspace_bytes(d)
-  ws = rt.empty((max(nbytes, 1),), torch.uint8)
+  held = HinvWorkspace.current.pointer(nbytes) if HinvWorkspace.current is not None else None
+  ws = None if held is not None else rt.empty((max(nbytes, 1),), torch.uint8)
   _ffi.check(L.mi355q_gptq_hinv_from_product_f32(rt.ptr(_f32(product)), d, float(alpha), float(damp_factor), rt.ptr(hinv),
-                                                 rt.ptr(info), rt.ptr(ws), nbytes, rt.stream_ptr()))
+                                                 rt.ptr(info), held if held is not None else rt.ptr(ws), nbytes, rt.stream_ptr()))
   return hinv, info
+
+
+class HinvWorkspace:
+  """The workspace of the d >= 4096 inverses (5 GiB at d = 16384), allocated ahead of their first call on a helper
+  thread: a fresh GiB of HBM costs its caller ~30 ms of hipMalloc, and whoever starts the first large inverse does so
+  on a GPU that has just run dry (the end of calibration). mi355q_device_alloc runs without the interpreter lock and
+  outside the framework's allocator (whose lock would stall every allocation of the feeding thread meanwhile).
+  gptq_hinv_from_product() uses it while one is installed (`with`, or install() / release()); calls on one stream
+  follow each other, so one workspace serves them all."""
+  current = None
+
+  def __init__(self, d: int):
+    import ctypes
+    import threading
+    rt.require_gpu()
+    self.nbytes = int(_ffi.lib().mi355q_gptq_hinv_workspace_bytes(d))
+    self.d = d
+    self._ptr = ctypes.c_void_p()
+    self._status = 0
+    self._device = torch.cuda.current_device()
+
+    def work():
+      torch.cuda.set_device(self._device)
+      self._status = _ffi.lib().mi355q_device_alloc(self.nbytes, ctypes.byref(self._ptr))
+    self._thread = threading.Thread(target=work, name="mi355q-hinv-workspace", daemon=True)
+    self._thread.start()
+
+  def pointer(self, nbytes: int):
+    """Device pointer when the workspace is there and large enough, else None (the caller allocates its own)."""
+    self._thread.join()
+    return self._ptr if self._status == 0 and self._ptr.value and nbytes <= self.nbytes else None
+
+  def install(self):
+    HinvWorkspace.current = self
+    return self
+
+  def release(self) -> None:
+    """Call with the stream that used it drained (hipFree waits for the device anyway)."""
+    if HinvWorkspace.current is self:
+      HinvWorkspace.current = None
+    self._thread.join()
+    if self._ptr.value:
+      _ffi.lib().mi355q_device_free(self._ptr)
+      self._ptr.value = None
+
+  def __enter__(self):
+    return self.install()
+
+  def __exit__(self, *exc):
+    self.release()
 
 
 def gptq_hinv_batched(hessians, damp_factor: float = 0.01):

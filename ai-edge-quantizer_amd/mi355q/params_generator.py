@@ -231,7 +231,7 @@ class ParamsGenerator:
       gptq.prefetch_hessian_inverses(plan_items, model_qsvs)
 
   @staticmethod
-  def prefetch_weights(plan_items) -> int:
+  def prefetch_weights(plan_items, submit: bool = True) -> int:
     """The constant operands (1 MiB and more, views of a mapped model file) of the ops the plan quantizes."""
     from . import runtime as rt
     no_q = algorithm_manager.AlgorithmName.NO_QUANTIZE
@@ -247,7 +247,7 @@ class ParamsGenerator:
         if isinstance(data, np.ndarray) and data.nbytes >= (1 << 20) and buffer_id not in seen:
           seen.add(buffer_id)
           arrays.append(data)
-    return rt.prefetch_uploads(arrays) if arrays else 0
+    return rt.prefetch_uploads(arrays, submit) if arrays else 0
 
   @staticmethod
   def release_derived(model_qsvs) -> None:
@@ -259,4 +259,5 @@ class ParamsGenerator:
       if hasattr(h, "cache"):
         h.cache.clear()
     from . import runtime as rt
-    rt.release_upload_files()
+    if requant_queue.active() is None:      # (an outer block -- the writer's -- still meets announced uploads: it releases them)
+      rt.release_upload_files()

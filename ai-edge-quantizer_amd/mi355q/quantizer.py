@@ -8,6 +8,7 @@ calibration results (QSVs) are passed in.
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 import json
 import os
@@ -21,6 +22,7 @@ from . import model_modifier
 from . import params_generator
 from . import qtyping
 from . import recipe_manager
+from . import requant_queue
 from .utils import tfl_flatbuffer_utils
 from .utils import tflite_flatbuffer
 
@@ -151,10 +153,22 @@ class Quantizer:
     if not self.get_quantization_recipe():
       raise RuntimeError("Can not quantize without a quantization recipe.")
     generator = params_generator.ParamsGenerator(self.float_model)
-    params = generator.generate_quantization_parameters(self._recipe_manager, calibration_result)
-    self.batch_stats = getattr(generator, "batch_stats", None)   # launches / tensors of the batched path
     modifier = model_modifier.ModelModifier(self.float_model)
-    serialized = modifier.modify_model(params, serialize_to_path=serialize_to_path)
+    # One block around the op walk AND the writer when a file is written: the walk's own block joins it, so results
+    # stay placeholders until somebody reads them; the writer lays the file out from their sizes, sends every quantized
+    # buffer on its way behind its own producer and takes the values the flatbuffer stores (per-channel scales) last
+    # (model_modifier.serialize_model, utils/tflite_flatbuffer.serialize_with_external_buffers).
+    from . import runtime as rt
+    rt.mark("quantize: call")
+    with (requant_queue.batching() if serialize_to_path else contextlib.nullcontext()) as block:
+      params = generator.generate_quantization_parameters(self._recipe_manager, calibration_result)
+      rt.mark("quantize: parameters generated (host)")
+      serialized = modifier.modify_model(params, serialize_to_path=serialize_to_path)
+    rt.mark("quantize: model modified and serialized (host)")
+    # launches / tensors of the batched path (with a file written, some launches left from inside the writer)
+    self.batch_stats = dict(block.stats) if block is not None else getattr(generator, "batch_stats", None)
+    if serialize_to_path:
+      rt.release_upload_files()
     self.quantized_model_object = modifier.quantized_model_object
     self._result = QuantizationResult(self.get_quantization_recipe(), serialized)
     return self._result

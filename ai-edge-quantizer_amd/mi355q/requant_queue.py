@@ -64,6 +64,7 @@ class PendingArray(rt.HbmArray):
   _unpack = None        # (packed sibling, element count, bits)
   _tensor = None
   _host = None
+  _slot = None          # the queue slot whose launch produces the values (RequantQueue.resolve)
   packed = None
   f16 = None
 
@@ -82,7 +83,7 @@ class PendingArray(rt.HbmArray):
         self._tensor = ops.unpack_bits(packed.device_tensor, n, bits).reshape(self._shape)
       else:
         if self._source is None:
-          self._queue.flush()
+          self._queue.resolve(self._slot)
         group, i = self._source
         self._tensor = group[i].reshape(self._shape)
     return self._tensor
@@ -122,7 +123,7 @@ class PendingArray(rt.HbmArray):
   def numpy(self) -> np.ndarray:
     if self._host is None:
       if self._unpack is None and self._source is None:
-        self._queue.flush()
+        self._queue.resolve(self._slot)
       if self._wave is not None:                 # rode along in the wave's pinned scale copy
         self._host = self._wave.host_values(*self._host_at).reshape(self._shape)
       else:
@@ -196,9 +197,11 @@ class RequantQueue:
       x = tensor_content.device_tensor
       if x.dtype != torch.float32 or not x.is_contiguous():
         x = x.float().contiguous()
+    elif rt.announced(tensor_content):
+      x = tensor_content                 # on its way to HBM already (runtime.prefetch_uploads): met again where it is launched
     else:
       x = rt.to_device(tensor_content)
-    if x.data_ptr() % 16:
+    if not isinstance(x, np.ndarray) and x.data_ptr() % 16:
       x = x.clone()                      # the batched kernel takes 16-byte aligned buffers
     shape = tuple(tensor_content.shape)
     scale = PendingArray(tuple(scale_shape), _F32, self)
@@ -215,6 +218,9 @@ class RequantQueue:
       sub_byte = False
     key = (rows, cols, block, num_bits, sub_byte)
     slot = _Slot(x, scale, out, key)
+    scale._slot = out._slot = q._slot = slot     # pylint: disable=protected-access
+    if block:
+      scale.f16._slot = slot                     # pylint: disable=protected-access
     group = self._groups.get(key)
     if group is None:
       group = self._groups[key] = []
@@ -238,6 +244,28 @@ class RequantQueue:
       self._pending_bytes -= len(group) * rows * cols * 4
       self._launch({slot.key: group})
 
+  # ------------------------------------------------------------------------------ resolve
+  def resolve(self, slot) -> None:
+    """Somebody needs the values of `slot` now. Tensors already in HBM leave all together (flush). A group whose
+    sources are still arriving from the model file (submit kept the host view: the upload thread is at work) sends
+    only the slots up to and including this one -- uploads arrive in the order they were announced, so those are
+    there or next -- and the later ones keep waiting: the writer asks payload by payload, in that same order, and
+    each one's bytes start for the output file while the following weights are still on their way in."""
+    group = self._groups.get(slot.key) if slot is not None else None
+    at = next((i for i, s in enumerate(group) if s is slot), None) if group else None
+    if at is None or not any(isinstance(s.x, np.ndarray) for s in group[:at + 1]):
+      self.flush()
+      return
+    head, rest = group[:at + 1], group[at + 1:]
+    if rest:
+      self._groups[slot.key] = rest
+    else:
+      del self._groups[slot.key]
+    rows, cols = slot.key[0], slot.key[1]
+    self._pending -= len(head)
+    self._pending_bytes -= len(head) * rows * cols * 4
+    self._launch({slot.key: head})
+
   # -------------------------------------------------------------------------------- flush
   def flush(self) -> None:
     """Issues everything pending: one launch per shape group, one asynchronous copy of the
@@ -256,6 +284,11 @@ class RequantQueue:
     row_scales = []          # (slots, scale_all) of the groups whose scales go to the host
     for (rows, cols, block, bits, sub_byte), slots in groups.items():
       n = len(slots)
+      for s in slots:
+        if isinstance(s.x, np.ndarray):        # announced weight: waits here if its copies are not enqueued yet
+          s.x = rt.to_device(s.x)
+          if s.x.data_ptr() % 16:
+            s.x = s.x.clone()
       nscale = rows * (cols // block) if block else rows
       out_bytes = rows * cols * bits // 8 if sub_byte else rows * cols
       scale_all = torch.empty((n, nscale), dtype=torch.float32, device=dev)
@@ -280,11 +313,15 @@ class RequantQueue:
             ptr(1) if sub_byte else None, ptr(2), ptr(3) if block else None, stream))
         self.stats["launches"] += 1
       self.stats["tensors"] += n
+      produced = torch.cuda.Event()            # behind this group's outputs (runtime.HbmArray.copy_into: the file writer's gate)
+      produced.record()
       for i, s in enumerate(slots):
         s.scale._source = (scale_all, i)       # pylint: disable=protected-access
         s.out._source = (out_all, i)           # pylint: disable=protected-access
+        s.out.ready = s.scale.ready = produced
         if block:
           s.scale.f16._source = (f16_all, i)   # pylint: disable=protected-access
+          s.scale.f16.ready = produced
         s.x = None                             # the FP32 copy in HBM is no longer needed
       if not block:
         row_scales.append((slots, scale_all))
@@ -324,6 +361,14 @@ ENABLED = os.environ.get("MI355Q_NO_BATCH", "") in ("", "0")
 
 def active() -> Optional[RequantQueue]:
   return getattr(_LOCAL, "queue", None)
+
+
+def complete_active() -> None:
+  """The open block's launches out and its host values in (what leaving the block does), with the block still open: a
+  writer that has handed every payload its place in the output file takes the values (per-channel scales) last."""
+  queue = active()
+  if queue is not None:
+    queue.finish()
 
 
 @contextlib.contextmanager

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+from typing import Optional
 import warnings
 import weakref
 
@@ -31,7 +32,7 @@ def mark(label: str, sync: bool = False) -> None:
   t_host = time.perf_counter()
   if sync and torch.cuda.is_available():
     torch.cuda.synchronize()
-  TIMELINE.append((label, t_host, time.perf_counter()))
+  TIMELINE.append((label, t_host, time.perf_counter(), torch.cuda.memory_stats().get("num_device_alloc", 0) if torch.cuda.is_available() else 0))
 
 
 def require_gpu() -> None:
@@ -69,7 +70,7 @@ def to_device(a, dtype=None) -> torch.Tensor:
       t = t.to(dtype)
     return t.to(device(), non_blocking=True).contiguous()
   arr = np.ascontiguousarray(a)
-  if _FILE_MAPPINGS and arr.nbytes >= _UPLOAD_MIN_TENSOR_BYTES and _file_range_of(arr) is not None:
+  if _FILE_MAPPINGS and (arr.nbytes >= _UPLOAD_MIN_TENSOR_BYTES or announced(arr)) and _file_range_of(arr) is not None:
     t = upload_overlapped(arr)        # a weight inside a large mapped model file: read + copied by the io ring
     return t if dtype is None or t.dtype == dtype else t.to(dtype)
   with warnings.catch_warnings():
@@ -219,17 +220,22 @@ def _submit_upload(key) -> None:
   _PREFETCH_OUTSTANDING[0] += n
 
 
-def _top_up_prefetch() -> None:
-  while _PREFETCH_WAITING and _PREFETCH_OUTSTANDING[0] < PREFETCH_WINDOW_BYTES:
+def _top_up_prefetch(at_most_bytes: Optional[int] = None) -> int:
+  done = 0
+  while _PREFETCH_WAITING and _PREFETCH_OUTSTANDING[0] < PREFETCH_WINDOW_BYTES and (at_most_bytes is None or done < at_most_bytes):
     key = next(iter(_PREFETCH_WAITING))
     del _PREFETCH_WAITING[key]
     _submit_upload(key)
+    done += key[2]
+  return done
 
 
-def prefetch_uploads(arrays) -> int:
-  """Starts the uploads of the file-backed weights among `arrays` (views of a registered model-file mapping, 1 MiB
-  and more), in the given order, without waiting for any of them; at most PREFETCH_WINDOW_BYTES are in HBM unconsumed
-  at a time. Returns the bytes queued. Whatever is not consumed is dropped by cancel_prefetch()."""
+def prefetch_uploads(arrays, submit: bool = True) -> int:
+  """Announces the file-backed weights among `arrays` (views of a registered model-file mapping, 1 MiB and more) in
+  the order they will be read, and (`submit`) starts their uploads without waiting for any of them; at most
+  PREFETCH_WINDOW_BYTES are in HBM unconsumed at a time. With submit=False nothing starts yet: pump_prefetch() starts
+  a bounded amount per call (a fresh GiB of HBM costs its caller ~30 ms of hipMalloc: a caller that has a GPU to keep
+  fed spreads that over its loop). Returns the bytes announced. Whatever is not consumed is dropped by cancel_prefetch()."""
   if os.environ.get("MI355Q_NO_PREFETCH") or not torch.cuda.is_available():
     return 0
   total = 0
@@ -244,8 +250,25 @@ def prefetch_uploads(arrays) -> int:
       continue
     _PREFETCH_WAITING[key] = None
     total += a.nbytes
-  _top_up_prefetch()
+  if submit:
+    _top_up_prefetch()
   return total
+
+
+def announced(a) -> bool:
+  """Is `a` a weight whose upload prefetch_uploads() was told about (and nobody has consumed yet)?"""
+  if not (_PREFETCHED or _PREFETCH_WAITING) or not isinstance(a, np.ndarray) or not a.flags.c_contiguous:
+    return False
+  where = _file_range_of(a)
+  if where is None:
+    return False
+  key = (where[0], where[1], a.nbytes)
+  return key in _PREFETCHED or key in _PREFETCH_WAITING
+
+
+def pump_prefetch(at_most_bytes: int = 256 << 20) -> int:
+  """Starts up to `at_most_bytes` more of the announced uploads (at least one, if any is waiting and the window has room)."""
+  return _top_up_prefetch(at_most_bytes) if _PREFETCH_WAITING else 0
 
 
 def cancel_prefetch() -> None:
@@ -442,6 +465,68 @@ def release_upload_staging() -> None:
 _NP_DTYPE: dict = {}     # torch dtype -> NumPy dtype
 
 
+class LateVector:
+  """The flat view of a device-resident result (per-channel scales) whose VALUES the flatbuffer writer may take last:
+  size and dtype are known now, `np.asarray()` waits for the values (utils/tflite_flatbuffer.py: `late_values`).
+  Every other consumer sees an ndarray-like: reading it completes the producer first, as reading the HbmArray would."""
+  late_values = True
+
+  def __init__(self, source: "HbmArray"):
+    self._source = source
+    self.dtype = source.dtype
+    self.size = source.size
+    self.nbytes = source.size * source.dtype.itemsize
+    self.shape = (self.size,)
+    self.ndim = 1
+
+  def __array__(self, dtype=None, copy=None):
+    a = np.ravel(np.asarray(self._source))
+    return a if dtype is None or a.dtype == dtype else a.astype(dtype)
+
+  def __len__(self) -> int:
+    return self.size
+
+  def __getitem__(self, idx):
+    return np.asarray(self)[idx]
+
+  def __iter__(self):
+    return iter(np.asarray(self))
+
+  def tolist(self):
+    return np.asarray(self).tolist()
+
+  def __eq__(self, other):
+    return np.asarray(self) == other
+
+  def __ne__(self, other):
+    return np.asarray(self) != other
+
+  __hash__ = None
+
+  def __getattr__(self, name):      # anything else NumPy offers: on the values
+    if name.startswith("_"):
+      raise AttributeError(name)
+    return getattr(np.asarray(self), name)
+
+  def __repr__(self):
+    return f"LateVector(size={self.size}, dtype={self.dtype})"
+
+
+_LATE_CONSTANTS = [0]      # > 0 while a writer that verifies them is at work (model_modifier.ModelModifier.modify_model)
+
+
+def late_constants_allowed() -> bool:
+  return _LATE_CONSTANTS[0] > 0
+
+
+def late_vector(values, dtype):
+  """`values` as the flat `dtype` vector a flatbuffer table stores: a LateVector when they are still in HBM with that
+  dtype and nobody has read them on the host, else the ndarray."""
+  if isinstance(values, HbmArray) and getattr(values, "_host", None) is None and values.dtype == dtype:
+    return LateVector(values)
+  return np.ravel(values).astype(dtype, copy=False)
+
+
 class HbmArray:
   """A result that lives in HBM and reaches the host only if somebody asks for it.
 
@@ -453,6 +538,7 @@ class HbmArray:
   first use.
   """
   __array_priority__ = 100.0
+  ready = None          # torch.cuda.Event recorded behind the kernels that produced the values, when the producer offers one
 
   def __init__(self, tensor: torch.Tensor):
     self.device_tensor = tensor
@@ -469,7 +555,9 @@ class HbmArray:
     if self._host is not None:
       dst[:] = np.ravel(self._host).view(np.uint8)
       return
-    if download_into_file(self.device_tensor, dst):
+    t = self.device_tensor                  # (a placeholder's last launch leaves here and sets `ready`)
+    ready = getattr(self, "ready", None)    # the event behind this payload's own producer, when the producer recorded one
+    if download_into_file(t, dst) if ready is None else download_into_file(t, dst, ready):
       return
     with warnings.catch_warnings():
       warnings.simplefilter("ignore")

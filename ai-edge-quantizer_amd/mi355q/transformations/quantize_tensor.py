@@ -44,7 +44,8 @@ def _perform_channelwise_quantization(ti: transformation_utils.TransformationInp
   """scale f32[ch], zeroPoint int64[ch], quantizedDimension (ref :76-104)."""
   p = ti.quant_params
   q = qtyping.QuantizationParametersT()
-  q.scale = np.ravel(p.scale).astype(np.float32, copy=False)
+  # (scales still in HBM keep their place in the flatbuffer and are read last: runtime.LateVector)
+  q.scale = transformation_utils.rt.late_vector(p.scale, np.dtype(np.float32))
   if p.zero_point is not None:
     q.zeroPoint = np.ravel(p.zero_point).astype(np.int64, copy=False)
   if p.quantized_dimension is not None:
@@ -60,8 +61,11 @@ def _perform_blockwise_quantization(ti: transformation_utils.TransformationInput
   tensor = ti.subgraph.tensors[ti.tensor_id]
   details = qtyping.BlockwiseQuantizationT()
   f16 = getattr(p.scale, "f16", None)     # written by the launch that quantized (requant_queue)
-  scales_f16 = np.asarray(f16) if f16 is not None else uniform_quantize_tensor.round_to_bf16(
-      np.asarray(p.scale, dtype=np.float32)).astype(np.float16)
+  if f16 is not None and transformation_utils._still_on_device(f16):   # pylint: disable=protected-access
+    scales_f16 = f16            # stays in HBM: its buffer is laid out from its size and written by the file writer
+  else:
+    scales_f16 = np.asarray(f16) if f16 is not None else uniform_quantize_tensor.round_to_bf16(
+        np.asarray(p.scale, dtype=np.float32)).astype(np.float16)
   name = tensor.name if isinstance(tensor.name, (bytes, bytearray)) else str(tensor.name).encode()
   details.scales = transformation_utils.add_new_constant_tensor(
       name + b"_scales", scales_f16, qtyping.TensorType.FLOAT16, ti.subgraph, ti.model)

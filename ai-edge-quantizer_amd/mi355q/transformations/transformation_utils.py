@@ -31,17 +31,33 @@ def _content_key(view: np.ndarray):
   return (view.size, view[:16].tobytes())
 
 
+class SharingNotDecided(Exception):
+  """A constant's bytes were still being computed when its buffer was added, it was assumed to equal no other such
+  constant of its size, and the values say otherwise: the model has to be built again with the values read first."""
+
+
+def _still_on_device(data) -> bool:
+  return isinstance(data, rt.HbmArray) and getattr(data, "_host", None) is None and rt.late_constants_allowed()
+
+
 def get_constant_buffer(data: np.ndarray, model: Any, force_duplicate_buffer: bool = False) -> int:
   """Id of a buffer holding exactly `data`'s bytes; appended when the model has none.
 
   Same sharing rule as ref :119-164: the lookup table is built once per model from the buffers
   present at that time (a later buffer with equal bytes shadows an earlier one) and only grows
   by the buffers added through this function.
+
+  A constant whose values are still in HBM (blockwise scales written by the launch that quantized: 1.4 MB per
+  FULLY_CONNECTED of a C3 layer) would have to be read -- a wait for the GPU per tensor -- only to learn that it
+  equals no other buffer. While a file is being written it is added unread when no HOST buffer has its size (equal
+  bytes need equal sizes), remembered by size, and verify_late_constants() compares the device-resident constants
+  of equal size with each other once their values exist; a match raises SharingNotDecided and the caller builds
+  the model again the slow way (values first). The result is the reference's sharing either way.
   """
-  view = np.ravel(np.ascontiguousarray(data)).view(np.uint8)
   table = getattr(model, "_buffers_by_content", None)
   if table is None:
     table = {}
+    late: dict[int, list] = {}
     for i, b in enumerate(model.buffers):
       if b.data is not None:
         if getattr(b.data, "rank", None) is not None and hasattr(b.data, "key"):
@@ -49,9 +65,25 @@ def get_constant_buffer(data: np.ndarray, model: Any, force_duplicate_buffer: bo
           # file). It cannot be offered for sharing -- its bytes are not here -- and nothing this function is asked for
           # (scale tensors, zero points, small new constants) is a quantized weight's payload.
           continue
+        if _still_on_device(b.data):
+          late.setdefault(b.data.nbytes, []).append((b.data, i))
+          continue
         d = np.ravel(np.asarray(b.data)).view(np.uint8)
         _remember(table, d, i)
     model._buffers_by_content = table
+    model._late_constants = late
+  late = model._late_constants
+  if _still_on_device(data) and not force_duplicate_buffer and data.nbytes not in table.get(_SIZES, ()):
+    buf = qtyping.BufferT()
+    buf.data = data
+    buf.offset = 0
+    buf.size = 0
+    model.buffers.append(buf)
+    late.setdefault(data.nbytes, []).append((data, len(model.buffers) - 1))
+    return len(model.buffers) - 1
+  view = np.ravel(np.ascontiguousarray(data)).view(np.uint8)
+  for held, idx in late.pop(view.size, ()):          # device-resident buffers of this size: now they have to be read
+    _remember(table, np.ravel(np.asarray(held)).view(np.uint8), idx)
   if not force_duplicate_buffer:
     for held, idx in table.get(_content_key(view), ()):
       if held.size == view.size and np.array_equal(held, view):
@@ -65,7 +97,31 @@ def get_constant_buffer(data: np.ndarray, model: Any, force_duplicate_buffer: bo
   return len(model.buffers) - 1
 
 
+def verify_late_constants(model: Any) -> None:
+  """The device-resident constants get_constant_buffer() added unread, compared by size class now that their values
+  exist (two checksums per constant in one pass over each class, exact comparison where both tie)."""
+  import torch
+  late = getattr(model, "_late_constants", None) or {}
+  for nbytes, entries in late.items():
+    added = list(entries)      # (also the device-resident buffers the model already had when the table was built)
+    if len(added) < 2:
+      continue
+    flat = torch.stack([d.device_tensor.contiguous().reshape(-1).view(torch.uint8) for d, _ in added]).to(torch.int64)
+    weights = (torch.arange(nbytes, device=flat.device, dtype=torch.int64) % 65521) + 1
+    marks = torch.stack([flat.sum(dim=1), (flat * weights).sum(dim=1)], dim=1).cpu().numpy()
+    seen: dict = {}
+    for row, (d, i) in zip(map(tuple, marks), added):
+      for other, j in seen.get(row, ()):
+        if torch.equal(other.device_tensor.reshape(-1).view(torch.uint8), d.device_tensor.reshape(-1).view(torch.uint8)):
+          raise SharingNotDecided(f"buffers {j} and {i} hold the same {nbytes} bytes")
+      seen.setdefault(row, []).append((d, i))
+
+
+_SIZES = "byte sizes of the host buffers in the table"
+
+
 def _remember(table: dict, view: np.ndarray, idx: int) -> None:
+  table.setdefault(_SIZES, set()).add(view.size)
   bucket = table.setdefault(_content_key(view), [])
   for n, (held, _) in enumerate(bucket):
     if held.size == view.size and np.array_equal(held, view):

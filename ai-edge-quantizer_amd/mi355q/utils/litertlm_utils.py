@@ -159,6 +159,7 @@ class LiteRTLMFile:
     serialized once, into the file, instead of into memory and from there into the file)."""
     if not self._sections:
       raise ValueError("LiteRT-LM file has no sections")
+    self.close_built_in_place()      # (a writer that builds its model a second time asks again)
     header, offsets, lengths, total = self._layout({section_id: section_bytes})
     fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
     os.ftruncate(fd, total)

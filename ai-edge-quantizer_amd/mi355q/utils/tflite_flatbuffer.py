@@ -392,6 +392,8 @@ class Builder:
     self.minalign = 1
     self.vtables: dict[bytes, int] = {}
     self.patch_points: dict[Any, int] = {}   # key -> offset-from-end of a field to patch later
+    self.late_vectors: Optional[list] = None   # a list: vectors whose VALUES arrive later are accepted -> (offset-from-end of
+                                               # the elements, the vector); None: every vector is read when it is packed
 
   def offset(self) -> int:
     return self.size
@@ -541,6 +543,11 @@ def _pack(b: Builder, obj, name: str) -> int:
       continue
     if kind == "str":
       child[fname] = b.string(v)
+    elif kind[0] == "vec" and b.late_vectors is not None and getattr(v, "late_values", False) and v.dtype == _NP[kind[1]]:
+      # values still on their way from the accelerator (per-channel scales): count and size are known, the
+      # elements are reserved and filled in when they are there (serialize_with_external_buffers)
+      child[fname] = b.vector_bytes(bytes(v.nbytes), v.size, v.dtype.itemsize, _VEC_ALIGN.get((name, fname), 0))
+      b.late_vectors.append((child[fname] - 4, v))       # (the count sits in front of the elements)
     elif kind[0] == "vec":
       arr = np.ascontiguousarray(np.asarray(v, dtype=_NP[kind[1]]) if not (
           isinstance(v, np.ndarray) and v.dtype == _NP[kind[1]]) else v).ravel()
@@ -585,13 +592,21 @@ def _round_up_16(n: int) -> int:
 
 
 def serialize_with_external_buffers(model, min_size_bytes: int = 1024,
-                                    sink: Optional[Callable[[int], Any]] = None):
+                                    sink: Optional[Callable[[int], Any]] = None,
+                                    before_values: Optional[Callable[[], None]] = None,
+                                    on_layout: Optional[Callable[[], None]] = None):
   """Flatbuffer + buffers >= `min_size_bytes` laid out behind it, each at a 16-byte aligned
   offset recorded in `Buffer.offset/size` (the reference's large-model layout,
   model_modifier.py:48-77, 290-377).
 
   `sink(total_bytes)` may return a writable buffer (e.g. an mmap of the output file) to build
   into; otherwise a bytearray is returned. Buffer payloads may be NumPy arrays of any dtype.
+
+  The layout needs sizes only. Vectors whose values are still being computed (objects with `late_values`, a dtype
+  and a size: per-channel scales in HBM) get their place in the flatbuffer and are filled in LAST, after every
+  payload has been handed its place (`copy_into`: a device-resident payload starts its own way into the file there,
+  behind its own producer) and after `before_values()` -- the caller's one wait for the accelerator (it may also raise to
+  have the model built again: model_modifier.serialize_model).
   """
   ext: dict[int, Any] = {}      # buffer id -> memoryview of its bytes, or a device-resident payload
   sizes: dict[int, int] = {}
@@ -619,11 +634,14 @@ def serialize_with_external_buffers(model, min_size_bytes: int = 1024,
     buf.data, buf.offset, buf.size, buf._external = None, 1, 1, True
   try:
     b = Builder()
+    b.late_vectors = []
     root = _pack(b, model, "Model")
     patch = dict(b.patch_points)
     fb = b.finish(root)
     total_fb = len(fb)
     start = _round_up_16(total_fb)
+    if on_layout is not None:
+      on_layout()
     out = sink(start + packed) if sink is not None else None
     if out is None:
       out = bytearray(start + packed)
@@ -642,6 +660,15 @@ def serialize_with_external_buffers(model, min_size_bytes: int = 1024,
         out[cursor:cursor + n] = view
       out[cursor + n:min(_round_up_16(cursor + n), len(out))] = bytes(min(_round_up_16(cursor + n), len(out)) - cursor - n)
       cursor = _round_up_16(cursor + n)
+    if before_values is not None:
+      before_values()
+    if b.late_vectors:
+      for from_end, vec in b.late_vectors:
+        pos = total_fb - from_end
+        data = np.ascontiguousarray(np.asarray(vec)).reshape(-1)
+        if data.nbytes != vec.nbytes:
+          raise ValueError(f"a late vector changed its size: {data.nbytes} bytes for {vec.nbytes} reserved")
+        out[pos:pos + data.nbytes] = data.view(np.uint8).tobytes()
   finally:
     for i, (d, o, s) in saved.items():
       buf = model.buffers[i]

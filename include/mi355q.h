@@ -323,6 +323,13 @@ int32_t mi355q_shutdown(void);
  * d = 16384 inverse (tools/hinv_after_c5_probe.py; GPU_MAX_HW_QUEUES=16 has the same effect). The host
  * side calls this before its first kernel on a device. Safe to call any number of times. */
 int32_t mi355q_prepare_device(void);
+/* hipMalloc / hipFree for a workspace the host side wants to own itself (round 4). A fresh GiB of HBM costs its caller
+ * ~30 ms, the workspace of a d = 16384 inverse is 5 GiB, and the framework's caching allocator holds its lock (and the
+ * interpreter's) for that long; through these two a helper thread of the host side allocates while the thread that
+ * feeds the GPU goes on (mi355q/ops.py: HinvWorkspace). mi355q_device_free(NULL) is a no-op; freeing waits for the
+ * device like hipFree. */
+int32_t mi355q_device_alloc(size_t nbytes, void** out);
+int32_t mi355q_device_free(void* p);
 int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d, double damp_factor, float* hinv_out,
                              int32_t* info_out, void* workspace, size_t workspace_bytes,
                              void* stream);

@@ -74,9 +74,10 @@ L = _ffi.lib()
 bad = []
 for name, (res, args) in _ffi.PROTOTYPES.items():
   # (device_info's pointers are optional outputs; without a device it reports HIP_ERROR;
-  #  destroying no communicator is a no-op, like free(NULL); waiting for no file writes is OK)
+  #  destroying no communicator and freeing no device memory are no-ops, like free(NULL); waiting for no file writes is OK)
   if res is not _ffi.c_i32 or name in ("mi355q_version", "mi355q_shutdown", "mi355q_device_info",
-                                       "mi355q_comm_destroy", "mi355q_file_io_finish", "mi355q_prepare_device"):
+                                       "mi355q_comm_destroy", "mi355q_file_io_finish", "mi355q_prepare_device",
+                                       "mi355q_device_free"):
     continue
   for mode, size in (("sizes 8", 8), ("sizes -1", -1), ("sizes 0", 0), ("sizes 128", 128)):
     vals = []

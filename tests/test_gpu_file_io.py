@@ -173,8 +173,8 @@ def test_quantizer_through_the_ring_writes_the_same_file(m, tmp_path, monkeypatc
     calls["up"] += 1
     return up(a)
 
-  def counted_down(t, d):
-    took = down(t, d)
+  def counted_down(t, d, *gate):
+    took = down(t, d, *gate)
     calls["down"] += int(took)
     return took
   monkeypatch.setattr(m.rt, "upload_overlapped", counted_up)
@@ -186,6 +186,49 @@ def test_quantizer_through_the_ring_writes_the_same_file(m, tmp_path, monkeypatc
   assert calls["up"] >= 4 and calls["down"] >= 3, calls   # (a buffer somebody already read on the host is copied from there)
   assert os.path.getsize(ring) == os.path.getsize(plain)
   assert _sha(ring) == _sha(plain)
+
+
+def test_equal_blockwise_scales_share_one_buffer_whether_read_early_or_late(m, tmp_path, monkeypatch):
+  """Two layers with the same weights have the same blockwise scales, and the reference's add_new_constant_tensor
+  shares one buffer between equal constants (ref transformation_utils.py:119-164). While a file is written the
+  scales stay in HBM and are laid out unread on the assumption that they differ; the writer verifies it once the
+  values exist and, here, has to build the model again. The file must be the one the values-first path writes."""
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  import file_bench
+  from mi355q.transformations import transformation_utils as tu
+  from mi355q.utils import tfl_flatbuffer_utils
+  src = str(tmp_path / "twins.tflite")
+  file_bench.build_model(src, 4, 1024, 2048 + 128, same=(2,))
+  rcp = m.recipe.dynamic_wi4b128_afp32()
+  monkeypatch.setattr(m.rt, "_UPLOAD_MIN_FILE_BYTES", 1)
+  monkeypatch.setattr(m.rt, "_UPLOAD_MIN_TENSOR_BYTES", 1)
+  early = str(tmp_path / "early.tflite")
+  with monkeypatch.context() as mp:
+    mp.setattr(m.rt, "late_constants_allowed", lambda: False)
+    m.quantizer.Quantizer(src, rcp).quantize(serialize_to_path=early)
+  undecided = []
+  verify = tu.verify_late_constants
+
+  def counted(model):
+    try:
+      verify(model)
+    except tu.SharingNotDecided as e:
+      undecided.append(str(e))
+      raise
+  monkeypatch.setattr(tu, "verify_late_constants", counted)
+  late = str(tmp_path / "late.tflite")
+  m.quantizer.Quantizer(src, rcp).quantize(serialize_to_path=late)
+  assert len(undecided) == 1, undecided
+  assert _sha(late) == _sha(early)
+  model = tfl_flatbuffer_utils.read_model(late)
+  by_name = {bytes(t.name): t.buffer for t in model.subgraphs[0].tensors}
+  assert by_name[b"w0_scales"] == by_name[b"w2_scales"] != by_name[b"w1_scales"]
+  # ... and with distinct weights nothing is built twice
+  del undecided[:]
+  src2 = str(tmp_path / "distinct.tflite")
+  file_bench.build_model(src2, 4, 1024, 2048 + 128)
+  m.quantizer.Quantizer(src2, rcp).quantize(serialize_to_path=str(tmp_path / "d.tflite"))
+  assert not undecided
 
 
 def test_container_written_through_the_ring_equals_the_pageable_copy(m, tmp_path, monkeypatch):
@@ -200,13 +243,13 @@ def test_container_written_through_the_ring_equals_the_pageable_copy(m, tmp_path
   rcp = c5_model.recipe("hadamard", 4, max_hadamard_size=4096)
   plain = str(tmp_path / "plain.litertlm")
   with monkeypatch.context() as mp:
-    mp.setattr(m.rt, "download_into_file", lambda t, d: False)
+    mp.setattr(m.rt, "download_into_file", lambda t, d, *gate: False)
     n_plain = litertlm_utils.quantize_litertlm(src, rcp, plain)
   took = {"down": 0, "up": 0}
   down, up = m.rt.download_into_file, m.rt.upload_overlapped
 
-  def counted_down(t, d):
-    ok = down(t, d)
+  def counted_down(t, d, *gate):
+    ok = down(t, d, *gate)
     took["down"] += int(ok)
     return ok
 

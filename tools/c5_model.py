@@ -339,8 +339,8 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
       plan=dict(modelled_s_per_rank=[round(v, 4) for v in loads],
                 makespan_over_mean=round(max(loads) / (sum(loads) / world), 3) if sum(loads) else None))
   from mi355q import runtime as rt
-  if rt.TIMELINE:      # MI355Q_TIMELINE=1: (label, ms since the call began when the host got there, ms when the GPU had drained if waited for)
-    out["timeline"] = [(label, round((a - t0) * 1e3, 1), round((b - t0) * 1e3, 1)) for label, a, b in rt.TIMELINE]
+  if rt.TIMELINE:      # MI355Q_TIMELINE=1: (label, ms since the call began when the host got there, ms when the GPU had drained if waited for, hipMallocs so far)
+    out["timeline"] = [(label, round((a - t0) * 1e3, 1), round((b - t0) * 1e3, 1), n) for label, a, b, n in rt.TIMELINE]
     del rt.TIMELINE[:]
   if os.path.exists(dst) and not keep:
     os.remove(dst)

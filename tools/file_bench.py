@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "ai-edge-quantizer_amd"))
 sys.path.insert(0, ROOT)
 
 
-def build_model(path, layers, rows, cols):
+def build_model(path, layers, rows, cols, same=()):
+  """`same`: layer indices that get layer 0's weights (equal constants: the writer's buffer sharing)."""
   from mi355q import qtyping as q
   from mi355q import model_modifier
   rng = np.random.default_rng(0)
@@ -29,7 +30,7 @@ def build_model(path, layers, rows, cols):
   base = rng.standard_normal((rows, cols), dtype=np.float32) * np.float32(0.02)
   prev = 0
   for i in range(layers):
-    w = base if i == 0 else np.roll(base, i, axis=1) + np.float32(i * 1e-4)   # distinct content, cheap to make
+    w = base if i == 0 or i in same else np.roll(base, i, axis=1) + np.float32(i * 1e-4)   # distinct content, cheap to make
     model.buffers.append(q.BufferT(data=w.reshape(-1).view(np.uint8)))
     sg.tensors.append(q.TensorT(name=f"w{i}".encode(), shape=[rows, cols], buffer=len(model.buffers) - 1))
     wid = len(sg.tensors) - 1
@@ -68,7 +69,9 @@ def main():
   rcp = recipe.dynamic_wi4b128_afp32() if a.recipe == "wi4b128" else recipe.dynamic_wi8_afp32()
   weight_bytes = a.layers * a.rows * a.cols * 4
   best = None
+  res = qz = None
   for _ in range(a.repeat):
+    res = qz = None              # (the last result maps the output file: its pages go when the mapping does, not inside the timing)
     if os.path.exists(dst):
       os.remove(dst)
     torch.cuda.synchronize()
@@ -79,6 +82,10 @@ def main():
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
     best = min(best, t_all) if best else t_all
+    from mi355q import runtime as rt
+    if rt.TIMELINE:      # MI355Q_TIMELINE=1
+      print(json.dumps({"seconds": round(t_all, 4), "timeline": [(label, round((a - t0) * 1e3, 2)) for label, a, _, _ in rt.TIMELINE]}))
+      del rt.TIMELINE[:]
   print(json.dumps(dict(workload=f"{a.layers} x FC {a.rows}x{a.cols} fp32 .tflite -> {a.recipe}",
                         weight_bytes=weight_bytes, in_file=os.path.getsize(src), out_file=os.path.getsize(dst),
                         seconds=round(best, 4), gbps=round(weight_bytes / best / 1e9, 2),
