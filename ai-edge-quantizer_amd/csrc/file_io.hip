@@ -42,7 +42,10 @@ namespace {
 constexpr size_t kSlotBytes = 8u << 20;
 constexpr int kSlots = 3;
 constexpr size_t kPartBytes = 1u << 20;
-constexpr int kThreads = 4;            // (3 - 6 threads read 44 - 51 GB/s out of the page cache; 8 and more 32: tools/io_ring_bench.py)
+constexpr int kThreads = 4;            // readers (3 - 6 threads read 44 - 51 GB/s out of the page cache; 8 and more 32: tools/io_ring_bench.py)
+constexpr int kWriteThreads = 2;       // writers of their own: a 1 MiB pwrite() into a fresh file holds its thread ~5 x as long as a
+                                       // pread() of a cached one (page allocation), and in one pool 186 MB of writes took a third of
+                                       // the thread time that 1.4 GB of reads needed (round 4: 46 -> 3x ms for a 1.4 GB file -> file run)
 
 struct Latch {                       // the parts of one slot still in flight
   std::mutex m;
@@ -73,22 +76,22 @@ struct Job {
 struct Pool {
   std::mutex m;
   std::condition_variable cv;
-  std::deque<Job> q;
+  std::deque<Job> q[2];              // [0] reads, [1] writes: each has threads of its own
   std::vector<std::thread> threads;
   bool stop = false;
   int write_error = 0;               // first errno of a failed or short WRITE; reported (and cleared) by mi355q_file_io_finish only.
                                      // Read errors stay with the slot they spoiled (Latch::error): the transfer that owns the slot
                                      // sees them before the slot's bytes are copied anywhere.
 
-  void run() {
+  void run(int side) {
     for (;;) {
       Job j;
       {
         std::unique_lock<std::mutex> l(m);
-        cv.wait(l, [&] { return stop || !q.empty(); });
-        if (q.empty()) return;
-        j = q.front();
-        q.pop_front();
+        cv.wait(l, [&] { return stop || !q[side].empty(); });
+        if (q[side].empty()) return;
+        j = q[side].front();
+        q[side].pop_front();
       }
       size_t done = 0;
       int err = 0;
@@ -114,7 +117,10 @@ struct Pool {
     if (!threads.empty()) return;
     const char* e = getenv("MI355Q_IO_THREADS");
     const int n = e && atoi(e) > 0 && atoi(e) <= 64 ? atoi(e) : kThreads;
-    for (int i = 0; i < n; ++i) threads.emplace_back([this] { run(); });
+    const char* w = getenv("MI355Q_IO_WRITE_THREADS");
+    const int nw = w && atoi(w) > 0 && atoi(w) <= 64 ? atoi(w) : kWriteThreads;
+    for (int i = 0; i < n; ++i) threads.emplace_back([this] { run(0); });
+    for (int i = 0; i < nw; ++i) threads.emplace_back([this] { run(1); });
   }
   void submit(int fd, long long at, unsigned char* p, size_t n, bool write, Latch* latch) {
     const int parts = static_cast<int>((n + kPartBytes - 1) / kPartBytes);
@@ -125,7 +131,7 @@ struct Pool {
     {
       std::lock_guard<std::mutex> l(m);
       for (size_t o = 0; o < n; o += kPartBytes)
-        q.push_back(Job{fd, at + static_cast<long long>(o), p + o, n - o < kPartBytes ? n - o : kPartBytes, write, latch});
+        q[write ? 1 : 0].push_back(Job{fd, at + static_cast<long long>(o), p + o, n - o < kPartBytes ? n - o : kPartBytes, write, latch});
     }
     cv.notify_all();
   }

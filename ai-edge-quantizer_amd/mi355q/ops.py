@@ -7,6 +7,7 @@ include/mi355q.h.
 """
 from __future__ import annotations
 
+import os
 import threading
 
 import numpy as np
@@ -202,7 +203,10 @@ def cast_f16(x: torch.Tensor) -> torch.Tensor:
   return out
 
 
-_TABLE_SLOTS = 8
+# How far the host may run ahead of the GPU in tables (one per calibration sample): with 8 the op walk of an 18-layer GPTQ
+# calibration stood still during every burst of Hessian products (one per 32 samples, 0.4 s each) and the GPU then waited for the
+# walk of the next 24 samples (4 ms each); 64 x 128 KB of pinned memory let the walk finish while the products run.
+_TABLE_SLOTS = int(os.environ.get("MI355Q_TABLE_SLOTS", 64))
 _TABLE_CAPACITY = 8192          # entries per row of a slot (2 rows of int64: 128 KB of pinned memory)
 _TABLE_RING: dict = {}          # device index -> {"slots": [(pinned int64 [2, capacity], event)], "next": 0}
 _TABLE_LOCK = threading.Lock()
@@ -542,11 +546,12 @@ def gptq_hinv_batched(hessians, damp_factor: float = 0.01):
   info = rt.empty((n,), torch.int32)
   L = _ffi.lib()
   nbytes = L.mi355q_gptq_hinv_batched_workspace_bytes(n, d)
-  ws = rt.empty((max(nbytes, 1),), torch.uint8)
+  held = HinvWorkspace.current.pointer(nbytes) if HinvWorkspace.current is not None else None   # (calls on one stream follow each other)
+  ws = None if held is not None else rt.empty((max(nbytes, 1),), torch.uint8)
   src = (ctypes.c_void_p * n)(*[h.data_ptr() for h in hs])
   dst = (ctypes.c_void_p * n)(*[hinv[i].data_ptr() for i in range(n)])
-  _ffi.check(L.mi355q_gptq_hinv_f64_batched(src, n, d, float(damp_factor), dst, rt.ptr(info), rt.ptr(ws), nbytes,
-                                            rt.stream_ptr()))
+  _ffi.check(L.mi355q_gptq_hinv_f64_batched(src, n, d, float(damp_factor), dst, rt.ptr(info),
+                                            held if held is not None else rt.ptr(ws), nbytes, rt.stream_ptr()))
   return [(hinv[i], info[i:i + 1]) for i in range(n)]
 
 

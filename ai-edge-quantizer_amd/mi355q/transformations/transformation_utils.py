@@ -60,7 +60,7 @@ def get_constant_buffer(data: np.ndarray, model: Any, force_duplicate_buffer: bo
     late: dict[int, list] = {}
     for i, b in enumerate(model.buffers):
       if b.data is not None:
-        if getattr(b.data, "rank", None) is not None and hasattr(b.data, "key"):
+        if isinstance(b.data, rt.RemoteBuffer):    # (isinstance, not getattr: an HbmArray answers unknown attributes from its host copy)
           # runtime.RemoteBuffer: a quantized weight whose bytes stayed in another rank's HBM (sharded run that writes a
           # file). It cannot be offered for sharing -- its bytes are not here -- and nothing this function is asked for
           # (scale tensors, zero points, small new constants) is a quantized weight's payload.
