@@ -83,6 +83,14 @@ python tools/pmc_big_kernels.py /tmp/prof_fetch > "$OUT/hinv16384_fetch.txt" 2>&
   echo "# the 18-layer run with its idle accounting (MI355Q_C5_GAPS=1) and per-call inverse / apply times (MI355Q_C5_TRACE)"
   MI355Q_C5_GAPS=1 MI355Q_C5_TRACE=hinv,apply timeout 600 python tools/c5_model.py --layers 18 --variant gptq 2>&1 | tail -1
 } > "$OUT/c5_model.txt" 2>&1
+{
+  echo "# Where the wall clock of the whole-model calls goes: marks at the phase boundaries (MI355Q_TIMELINE=1, runtime.mark)."
+  echo "# tools/c5_model.py --layers 18 --variant gptq (BASELINE config 5, exact Hessian product), two processes:"
+  for i in 1 2; do MI355Q_TIMELINE=1 MI355Q_C5_GAPS=1 timeout 600 python tools/c5_model.py --layers 18 --variant gptq 2>/dev/null | tail -1 | python tools/timeline_print.py; done
+  echo "# tools/file_bench.py (1.44 GB .tflite -> int4 blockwise-128 / int8 per-channel; every repeat, the last line is the best):"
+  MI355Q_TIMELINE=1 timeout 300 python tools/file_bench.py --repeat 3 2>/dev/null | python tools/timeline_print.py
+  MI355Q_TIMELINE=1 timeout 300 python tools/file_bench.py --repeat 3 --recipe wi8 2>/dev/null | python tools/timeline_print.py
+} > "$OUT/c5_timeline.txt" 2>&1
 bash tools/pmc_traffic_refresh.sh "$ROUND" > "$OUT/pmc_traffic.log" 2>&1
 {
   echo "# tools/gptq_parity_instances.py: the d = 16384 full chain on several instances, GPU (exact / fast Hessian product) vs the oracle's own chain"
@@ -90,6 +98,7 @@ bash tools/pmc_traffic_refresh.sh "$ROUND" > "$OUT/pmc_traffic.log" 2>&1
 } > "$OUT/gptq_parity_instances.txt" 2>&1
 for a in "" "--resident"; do timeout 300 python tools/c4_bench.py --samples 128 $a 2>&1 | tail -1; done > "$OUT/c4_c5_public.txt"
 for a in "" "--resident"; do timeout 600 python tools/c5_bench.py --samples 4 $a 2>&1 | tail -1; done >> "$OUT/c4_c5_public.txt"
-timeout 300 python tools/file_bench.py 2>&1 | tail -1 >> "$OUT/c4_c5_public.txt"
+timeout 300 python tools/file_bench.py --repeat 3 2>&1 | tail -1 >> "$OUT/c4_c5_public.txt"
+timeout 300 python tools/file_bench.py --repeat 3 --recipe wi8 2>&1 | tail -1 >> "$OUT/c4_c5_public.txt"
 ls -la "$OUT"
 cat "$OUT/gpu_tests_tail.txt"
