@@ -583,3 +583,82 @@ def test_remote_payload_records_instead_of_bytes(tmp_path):
     rt._REMOTE_LOCAL.clear()
     mapping.close()
     os.close(fd)
+
+
+def test_late_vectors_are_laid_out_from_their_size_and_filled_last(tmp_path):
+  """The external-buffer writer reserves a vector whose values arrive later (runtime.LateVector: per-channel scales
+  still in HBM) from its size and dtype, hands every payload its place, calls before_values() and only then reads
+  the vector: the file equals the one written with the values known from the start, and nothing reads them before."""
+  import torch
+  from mi355q import runtime as rt
+  from mi355q.utils import tflite_flatbuffer as fb
+  model = tfl_flatbuffer_utils.read_model(os.path.join(os.path.dirname(__file__), "golden", "models", "conv_fc_mnist.tflite"))
+  sg = model.subgraphs[0]
+  scales = np.linspace(0.01, 0.5, 37, dtype=np.float32)
+  target = next(t for t in sg.tensors if t.buffer and model.buffers[t.buffer].data is not None and model.buffers[t.buffer].data.nbytes > 4096)
+  quant = q.QuantizationParametersT()
+  quant.scale = scales
+  quant.zeroPoint = np.zeros(37, np.int64)
+  target.quantization = quant
+  eager = bytes(fb.serialize_with_external_buffers(model, 1024))
+  reads = []
+
+  class Watched(rt.HbmArray):
+    def numpy(self):
+      reads.append("read")
+      return super().numpy()
+  quant.scale = rt.late_vector(Watched(torch.from_numpy(scales.copy())), np.dtype(np.float32))
+  assert isinstance(quant.scale, rt.LateVector) and quant.scale.size == 37 and quant.scale.nbytes == 148
+  order = []
+  late = bytes(fb.serialize_with_external_buffers(model, 1024, before_values=lambda: order.append(len(reads))))
+  assert order == [0] and reads, (order, reads)          # nothing was read before the hook, something after
+  assert late == eager
+  # the inline writer (no place to fill in later) and plain NumPy consumers read the values on the spot
+  assert bytes(fb.write_model(model)) == bytes(fb.write_model(model))
+  assert np.array_equal(np.asarray(quant.scale), scales) and quant.scale.tolist() == scales.tolist() and (quant.scale == scales).all()
+  # a value that is already on the host, or of another dtype, is an ndarray as before
+  assert isinstance(rt.late_vector(scales, np.dtype(np.float32)), np.ndarray)
+  assert isinstance(rt.late_vector(rt.HbmArray(torch.zeros(4, dtype=torch.float64)), np.dtype(np.float32)), np.ndarray)
+
+
+def test_late_constants_share_buffers_like_the_values_first_path(monkeypatch):
+  """transformation_utils.get_constant_buffer with constants still in HBM (while a verifying writer is at work): added
+  unread when no host buffer has their size; a host constant of that size makes them be read; verify_late_constants
+  finds two equal ones (SharingNotDecided) and passes distinct ones -- and outside a writer nothing is late."""
+  import torch
+  from mi355q import runtime as rt
+  from mi355q.transformations import transformation_utils as tu
+
+  def model_with(*host):
+    m = q.ModelT(version=3)
+    m.buffers = [q.BufferT()] + [q.BufferT(data=np.asarray(h).view(np.uint8)) for h in host]
+    return m
+  a = rt.HbmArray(torch.arange(512, dtype=torch.float16))
+  b = rt.HbmArray(torch.arange(512, dtype=torch.float16) + 1)
+  twin = rt.HbmArray(torch.arange(512, dtype=torch.float16))
+  # outside a writer: read and compared on the spot (twin shares a's buffer)
+  m = model_with(np.zeros(7, np.float32))
+  ia, ib, it = (tu.get_constant_buffer(x, m) for x in (a, b, twin))
+  assert ia != ib and it == ia and isinstance(m.buffers[ia].data, np.ndarray)
+  for x in (a, b, twin):
+    x._host = None
+  monkeypatch.setattr(rt, "_LATE_CONSTANTS", [1])
+  m = model_with(np.zeros(7, np.float32))
+  ia, ib = tu.get_constant_buffer(a, m), tu.get_constant_buffer(b, m)
+  assert m.buffers[ia].data is a and m.buffers[ib].data is b and a._host is None and b._host is None     # unread
+  tu.verify_late_constants(m)                                                                             # distinct: fine
+  it = tu.get_constant_buffer(twin, m)
+  assert it not in (ia, ib) and m.buffers[it].data is twin
+  with pytest.raises(tu.SharingNotDecided):
+    tu.verify_late_constants(m)
+  # a HOST constant of the same size arrives: the late ones are read now and take part in the comparison
+  m = model_with(np.zeros(7, np.float32))
+  ia = tu.get_constant_buffer(a, m)
+  same_bytes = np.arange(512, dtype=np.float16)
+  assert tu.get_constant_buffer(same_bytes, m) == ia
+  assert tu.get_constant_buffer(np.arange(512, dtype=np.float16) + 5, m) not in (ia,)
+  # a host buffer of that size already in the model: the device constant is read at once
+  for x in (a, b, twin):
+    x._host = None
+  m = model_with(np.arange(512, dtype=np.float16))
+  assert tu.get_constant_buffer(twin, m) == 1
