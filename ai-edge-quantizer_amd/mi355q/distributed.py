@@ -478,6 +478,7 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
   owners = hessian_owners(plan, owner, costs) if world > 1 else None
   qsvs = None
   reserved: list = []          # ops.HinvWorkspace of the large inverses, released when the call is over
+  markers: list = []           # events behind the last samples' work (between_samples)
   if qz._recipe_manager.need_calibration():  # pylint: disable=protected-access
     mine_items = [it for it, o in zip(plan, owner) if o == rank]
     # calibration reads activations only: the weights this rank will quantize afterwards cross PCIe underneath it
@@ -490,7 +491,14 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
       weight uploads per sample, and (once) the HBM the first large inverse will take."""
       from .algorithms.uniform_quantize import gptq
       from . import ops
-      rt.pump_prefetch()
+      if torch.cuda.is_available():
+        # ... but only while the GPU is behind the walk (the marker of two samples ago has not fired): until the first
+        # burst of Hessian products is queued -- 32 samples of 512 tokens fill a slab -- the GPU waits for the walk, and
+        # 7.5 ms of hipMalloc per sample there delayed that burst by 0.2 s
+        markers.append(torch.cuda.Event())
+        markers[-1].record()
+        if len(markers) > 2 and not markers.pop(0).query():
+          rt.pump_prefetch()
       if walked == 2 and torch.cuda.is_available():
         d = gptq.largest_hessian_order(mine_items)
         if d >= 4096:

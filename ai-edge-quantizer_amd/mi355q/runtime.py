@@ -340,8 +340,9 @@ def download_into_file(t: torch.Tensor, dst: np.ndarray, ready=None) -> bool:
   a registered output mapping (finish_downloads() before the file is handed back)."""
   addr = dst.ctypes.data
   hit = next(((base, fd) for base, length, fd in reversed(_OUT_MAPPINGS) if base <= addr and addr + dst.nbytes <= base + length), None)
-  if hit is None or not t.is_cuda or dst.nbytes < (1 << 20):
-    return False
+  if hit is None or not t.is_cuda or dst.nbytes == 0:
+    return False        # (every size goes through the download thread: a pageable copy of a 256 KB k_proj payload is ordered behind
+                        # everything queued on the compute stream and held the writer's loop in lock step with the GPU)
   base, fd = hit
   _submit_download(t.contiguous().reshape(-1).view(torch.uint8), fd, addr - base, ready)
   return True

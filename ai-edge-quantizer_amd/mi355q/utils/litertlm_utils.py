@@ -315,7 +315,9 @@ def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path, overw
       if result is not None:
         replaced[sid] = result
   finally:
+    runtime.mark("container: model sections done (host)")
     src.close_built_in_place()     # (the io ring's writes into the output file are done, its descriptor is closed)
+    runtime.mark("container: output file complete (host)")
   if built_in_place:
     # (no msync: a shared mapping is coherent with the page cache, readers see the bytes at once)
     return built_in_place["size"]

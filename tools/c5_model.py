@@ -212,6 +212,17 @@ class GpuPhases:
             "idle_ms_in_gaps_of_5ms_and_more": round(sum(g[1] for g in out), 1), "idle_ms_in_shorter_gaps": round(small, 1),
             "longest": sorted(out, key=lambda g: -g[1])[:8]}
 
+  def spans(self, lo_ms, hi_ms):
+    """(family, start ms, end ms) of the timed calls that overlap [lo_ms, hi_ms], measured from the first timed call."""
+    self.torch.cuda.synchronize()
+    t0 = self.events[0][1]
+    out = []
+    for f, e0, e1 in self.events:
+      a, b = t0.elapsed_time(e0), t0.elapsed_time(e1)
+      if b >= lo_ms and a <= hi_ms:
+        out.append((f, round(a, 1), round(b, 1)))
+    return sorted(out, key=lambda r: r[1])
+
   def calls(self, family):
     """Milliseconds of every call of one family, in call order."""
     self.torch.cuda.synchronize()
@@ -336,6 +347,7 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
       hbm=dict(device_allocations=torch.cuda.memory_stats().get("num_device_alloc"), peak_reserved_GiB=round(torch.cuda.max_memory_reserved() / 2**30, 1),
                peak_allocated_GiB=round(torch.cuda.max_memory_allocated() / 2**30, 1)),
       idle_gaps=(timer.gaps() if timer and os.environ.get("MI355Q_C5_GAPS") else None),
+      spans=(timer.spans(*[float(v) for v in os.environ["MI355Q_C5_SPANS"].split(",")]) if timer and os.environ.get("MI355Q_C5_SPANS") else None),
       plan=dict(modelled_s_per_rank=[round(v, 4) for v in loads],
                 makespan_over_mean=round(max(loads) / (sum(loads) / world), 3) if sum(loads) else None))
   from mi355q import runtime as rt
