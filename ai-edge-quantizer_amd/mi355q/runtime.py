@@ -36,6 +36,9 @@ def mark(label: str, sync: bool = False) -> None:
 
 
 def require_gpu() -> None:
+  # (called by every op wrapper: 17 000 times in an 18-layer GPTQ calibration -- the prepared device is the fast path)
+  if _PREPARED and torch.cuda.current_device() in _PREPARED:
+    return
   if not torch.cuda.is_available():
     raise RuntimeError(
         "mi355q needs an AMD GPU (torch.cuda.is_available() is False); the product"
