@@ -43,9 +43,11 @@ constexpr size_t kSlotBytes = 8u << 20;
 constexpr int kSlots = 3;
 constexpr size_t kPartBytes = 1u << 20;
 constexpr int kThreads = 4;            // readers (3 - 6 threads read 44 - 51 GB/s out of the page cache; 8 and more 32: tools/io_ring_bench.py)
-constexpr int kWriteThreads = 2;       // writers of their own: a 1 MiB pwrite() into a fresh file holds its thread ~5 x as long as a
+constexpr int kWriteThreads = 4;       // writers of their own: a 1 MiB pwrite() into a fresh file holds its thread ~5 x as long as a
                                        // pread() of a cached one (page allocation), and in one pool 186 MB of writes took a third of
-                                       // the thread time that 1.4 GB of reads needed (round 4: 46 -> 3x ms for a 1.4 GB file -> file run)
+                                       // the thread time that 1.4 GB of reads needed (round 4: 46 -> 41 ms for a 1.4 GB file -> file run;
+                                       // 2 / 4 / 6 writers: the same there within noise, a 1 GB container written after a short
+                                       // quantization phase 0.30 / 0.22 / 0.23 s)
 
 struct Latch {                       // the parts of one slot still in flight
   std::mutex m;

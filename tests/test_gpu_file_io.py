@@ -265,3 +265,49 @@ def test_container_written_through_the_ring_equals_the_pageable_copy(m, tmp_path
   assert took["down"] >= 3 and took["up"] >= 7, took
   assert n_ring == n_plain == os.path.getsize(ring) == os.path.getsize(plain)
   assert _sha(ring) == _sha(plain)
+
+
+def test_gptq_container_written_late_equals_the_values_first_no_prefetch_call(m, tmp_path, monkeypatch):
+  """BASELINE config 5's call on a small container (one decoder layer at d = 512 / ff = 4096, GPTQ int4 channelwise,
+  calibration samples resident in HBM), once as shipped -- weights announced to the upload thread and pumped during
+  calibration, placeholders kept until the writer, per-channel scales as late vectors, payloads behind their own events,
+  the large-inverse workspace from the helper thread -- and once with all of that off (MI355Q_NO_PREFETCH, scales and
+  constants read on the spot, no workspace): the two containers must be the same bytes."""
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  import c5_model
+  from mi355q import ops
+  from mi355q.utils import litertlm_utils
+  torch = m.torch
+  d, dkv, dff = 512, 128, 4096
+  src = str(tmp_path / "one_layer.litertlm")
+  c5_model.write_litertlm(c5_model.build_model(1, d, dkv, dff), src)
+  rcp = c5_model.recipe("gptq", 4)
+  data = {0: {"serving_default": c5_model.calibration_set(torch, 1, 24, 256, d, dkv, dff, 1, None)}}
+  monkeypatch.setattr(m.rt, "_UPLOAD_MIN_FILE_BYTES", 1)
+  monkeypatch.setattr(m.rt, "_UPLOAD_MIN_TENSOR_BYTES", 1)
+  late_vectors, workspaces = [], []
+  real_late, real_ws = m.rt.late_vector, ops.HinvWorkspace.__init__
+
+  def counted_late(values, dtype):
+    out = real_late(values, dtype)
+    late_vectors.append(isinstance(out, m.rt.LateVector))
+    return out
+
+  def counted_ws(self, dim):
+    workspaces.append(dim)
+    real_ws(self, dim)
+  monkeypatch.setattr(m.rt, "late_vector", counted_late)
+  monkeypatch.setattr(ops.HinvWorkspace, "__init__", counted_ws)
+  shipped = str(tmp_path / "shipped.litertlm")
+  n_shipped = litertlm_utils.quantize_litertlm(src, rcp, shipped, calibration_data=data)
+  assert any(late_vectors) and workspaces == [dff], (late_vectors, workspaces)     # the overlapped machinery was in use
+  plain = str(tmp_path / "plain.litertlm")
+  with monkeypatch.context() as mp:
+    mp.setenv("MI355Q_NO_PREFETCH", "1")
+    mp.setattr(m.rt, "late_vector", lambda values, dtype: np.ravel(values).astype(dtype, copy=False))
+    mp.setattr(m.rt, "late_constants_allowed", lambda: False)
+    mp.setattr(m.rt, "download_into_file", lambda t, dst, *gate: False)
+    mp.setattr(ops.HinvWorkspace, "pointer", lambda self, nbytes: None)
+    n_plain = litertlm_utils.quantize_litertlm(src, rcp, plain, calibration_data=data)
+  assert n_shipped == n_plain == os.path.getsize(shipped) == os.path.getsize(plain)
+  assert _sha(shipped) == _sha(plain)
