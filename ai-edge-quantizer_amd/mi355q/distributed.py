@@ -902,7 +902,7 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
       # float32 (0.5 GiB per d = 16384 Hessian); the receiving ranks keep it as a product (alpha = 2 / N)
       from .algorithms.uniform_quantize import gptq
       prod = None if h is None else h.product_form()[0]
-      if prod is None and mine:
+      if prod is None:             # this rank saw no sample of it: it still takes part (and may be the one that keeps the sum)
         prod = torch.zeros((d, d), dtype=torch.float32, device=rt.device())
       if comm is not None:
         L = _ffi.lib()
@@ -912,7 +912,7 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
           scratch = rt.empty((need,), torch.uint8)
         _ffi.check(L.mi355q_reduce_product_f32(comm, rt.ptr(prod), d, root, rt.ptr(scratch), scratch.numel(), rt.stream_ptr()))
       else:                                                     # test transport: ranks share a GPU
-        host = torch.zeros((d, d), dtype=torch.float32) if prod is None else torch.tril(prod).cpu()
+        host = torch.tril(prod).cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         if mine:
           prod.copy_(host)
