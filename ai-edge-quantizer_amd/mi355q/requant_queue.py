@@ -237,7 +237,9 @@ class RequantQueue:
       self.flush()
       return
     group = self._groups.get(slot.key)
-    if group is not None and len(group) >= GROUP_LAUNCH_TENSORS:
+    # (a group whose weights are still arriving from the model file does not leave at 16: its launch would hold the walk until
+    # those uploads are in, and the writer that follows the walk launches them as they arrive, payload by payload: resolve())
+    if group is not None and len(group) >= GROUP_LAUNCH_TENSORS and not isinstance(slot.x, np.ndarray):
       del self._groups[slot.key]
       rows, cols = slot.key[0], slot.key[1]
       self._pending -= len(group)
