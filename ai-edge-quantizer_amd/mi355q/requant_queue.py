@@ -136,11 +136,12 @@ class PendingArray(rt.HbmArray):
 
 
 class _Slot:
-  __slots__ = ("x", "scale", "out", "params", "key")
+  __slots__ = ("x", "scale", "out", "params", "key", "counted")
 
   def __init__(self, x, scale, out, key=None):
     self.x, self.scale, self.out, self.key = x, scale, out, key
     self.params = None
+    self.counted = not isinstance(x, np.ndarray)   # takes part in the wave budgets: its FP32 copy is in HBM on the queue's account
 
 
 class _Wave:
@@ -225,8 +226,9 @@ class RequantQueue:
     if group is None:
       group = self._groups[key] = []
     group.append(slot)
-    self._pending_bytes += rows * cols * 4
-    self._pending += 1
+    if slot.counted:      # (a weight still arriving from the model file is on the prefetch window's account, runtime.prefetch_uploads)
+      self._pending_bytes += rows * cols * 4
+      self._pending += 1
     return scale, q, slot
 
   def attach(self, slot: _Slot, params) -> None:
@@ -242,8 +244,9 @@ class RequantQueue:
     if group is not None and len(group) >= GROUP_LAUNCH_TENSORS and not isinstance(slot.x, np.ndarray):
       del self._groups[slot.key]
       rows, cols = slot.key[0], slot.key[1]
-      self._pending -= len(group)
-      self._pending_bytes -= len(group) * rows * cols * 4
+      counted = sum(1 for s in group if s.counted)
+      self._pending -= counted
+      self._pending_bytes -= counted * rows * cols * 4
       self._launch({slot.key: group})
 
   # ------------------------------------------------------------------------------ resolve
@@ -264,8 +267,9 @@ class RequantQueue:
     else:
       del self._groups[slot.key]
     rows, cols = slot.key[0], slot.key[1]
-    self._pending -= len(head)
-    self._pending_bytes -= len(head) * rows * cols * 4
+    counted = sum(1 for s in head if s.counted)
+    self._pending -= counted
+    self._pending_bytes -= counted * rows * cols * 4
     self._launch({slot.key: head})
 
   # -------------------------------------------------------------------------------- flush
