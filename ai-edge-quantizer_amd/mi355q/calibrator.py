@@ -188,6 +188,7 @@ class Calibrator:
     plan = None if self._plans is None else self._plans.get(key)
     if plan is None:
       from .algorithms.uniform_quantize import common_quantize, naive_min_max_quantize
+      from .algorithms.uniform_quantize import gptq as gptq_module
       names: dict[str, None] = {}
       ops_ = []
       readers: set[str] = set()
@@ -204,7 +205,9 @@ class Calibrator:
             mine.append(name)
         # the stock per-op function (min / max of every runtime tensor of the op) is a function of
         # these names alone: the walk takes them from here instead of deriving them per sample
-        stock = mine if calibrate is naive_min_max_quantize.min_max_calibrate else None
+        # (gptq.calibrate is the same walk plus a Hessian for the tensors its readers need: ("gptq", names))
+        stock = (mine if calibrate is naive_min_max_quantize.min_max_calibrate
+                 else ("gptq", mine) if calibrate is gptq_module.calibrate else None)
         ops_.append((sg, graph_info, op, op_key, alg, calibrate, stock))
       plan = {"ops": ops_, "runtime_tensors": list(names), "hessian_readers": readers}
       if self._plans is not None:
@@ -276,12 +279,18 @@ class Calibrator:
         # min_max_calibrate with its default valid_range, minus what a tensor seen earlier in this
         # sample (the previous op's output) would compute again only to be ignored below
         op_qsvs = {}
-        for name in stock:
+        with_hessian = isinstance(stock, tuple)
+        if with_hessian:
+          from .algorithms.uniform_quantize import gptq
+          readers = gptq._HESSIAN_READERS   # pylint: disable=protected-access
+        for name in (stock[1] if with_hessian else stock):
           if name in updated:
             continue
           content = self._tensor_content_map[name]
           qsv = common_quantize.get_activation_min_max(content, -3e38, 3e38)
           qsv["num_samples"] = np.array(content.shape[0] if content.ndim > 0 else 1)
+          if with_hessian and (readers is None or name in readers):
+            qsv["hessian"] = gptq.hessian_of(content, qsv["num_samples"])      # (ref gptq.py:55-108)
           op_qsvs[name] = qsv
       if self._recording is not None:
         # sample-sharded calibration: keep this sample's statistics as events; another process
