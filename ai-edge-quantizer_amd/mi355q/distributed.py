@@ -537,6 +537,7 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
   finally:
     if torch.cuda.is_available():
       torch.cuda.synchronize()
+      rt.release_upload_files()        # (weights announced before a calibration that failed are waited for and dropped)
     for ws in reserved:
       ws.release()
   if stats is not None:

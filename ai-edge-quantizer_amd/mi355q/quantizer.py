@@ -160,15 +160,17 @@ class Quantizer:
     # (model_modifier.serialize_model, utils/tflite_flatbuffer.serialize_with_external_buffers).
     from . import runtime as rt
     rt.mark("quantize: call")
-    with (requant_queue.batching() if serialize_to_path else contextlib.nullcontext()) as block:
-      params = generator.generate_quantization_parameters(self._recipe_manager, calibration_result)
-      rt.mark("quantize: parameters generated (host)")
-      serialized = modifier.modify_model(params, serialize_to_path=serialize_to_path)
+    try:
+      with (requant_queue.batching() if serialize_to_path else contextlib.nullcontext()) as block:
+        params = generator.generate_quantization_parameters(self._recipe_manager, calibration_result)
+        rt.mark("quantize: parameters generated (host)")
+        serialized = modifier.modify_model(params, serialize_to_path=serialize_to_path)
+    finally:
+      if serialize_to_path:
+        rt.release_upload_files()      # (also when the call failed: announced uploads are waited for and dropped)
     rt.mark("quantize: model modified and serialized (host)")
     # launches / tensors of the batched path (with a file written, some launches left from inside the writer)
     self.batch_stats = dict(block.stats) if block is not None else getattr(generator, "batch_stats", None)
-    if serialize_to_path:
-      rt.release_upload_files()
     self.quantized_model_object = modifier.quantized_model_object
     self._result = QuantizationResult(self.get_quantization_recipe(), serialized)
     return self._result
