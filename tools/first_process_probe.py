@@ -12,6 +12,14 @@ t0 = time.perf_counter()
 xs = [torch.randn((200 << 20,), device="cuda") for _ in range(128)]     # 128 x 0.8 GB
 torch.cuda.synchronize()
 print(f"allocated and filled {len(xs) * xs[0].numel() * 4 / 1e9:.0f} GB in {time.perf_counter() - t0:.2f} s", flush=True)
+stride = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # > 0: first read one float every `stride` bytes of every tensor (translations only)
+if stride:
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  acc = sum(x[::stride // 4].sum() for x in xs)
+  e1.record()
+  torch.cuda.synchronize()
+  print(f"touched one float per {stride} bytes of every tensor in {e0.elapsed_time(e1):.2f} ms", flush=True)
 rows = []
 t_start = time.perf_counter()
 k = 0
