@@ -883,6 +883,7 @@ struct ApplyArgs {
   float* err;           // [rows, kErrLd]: this block's 64 columns start at err_col
   int err_col;
   int8_t* q;            // [rows, d]
+  int32_t* q32;         // [rows, d] instead of q for targets wider than 8 bits (mi355q_gptq_apply_wide_f32), else null
 };
 
 // One 64-column block of the OBS sweep (ref gptq.py:180-212): columns are visited left to
@@ -1009,6 +1010,7 @@ __global__ __launch_bounds__(256, kRowLanes == 16 ? 4 : 1) void gptq_block_kerne
         qi = (v != v) ? 0 : static_cast<int>(q);
         int dd = qi - z;
         if (with_zp && a.diff_bits == 8) dd = static_cast<int8_t>(dd);  // (q itself fits int8)
+        if (with_zp && a.diff_bits == 16) dd = static_cast<int16_t>(dd);
         const double dq = static_cast<double>(dd) * s;
         e = static_cast<float>(static_cast<double>(wi) - dq);  // np.subtract(f32, f64, out=f32)
       } else {
@@ -1021,6 +1023,7 @@ __global__ __launch_bounds__(256, kRowLanes == 16 ? 4 : 1) void gptq_block_kerne
         qi = (v != v) ? 0 : static_cast<int>(q);
         int dd = qi - z;
         if (with_zp && a.diff_bits == 8) dd = static_cast<int8_t>(dd);
+        if (with_zp && a.diff_bits == 16) dd = static_cast<int16_t>(dd);
         const float dq = static_cast<float>(dd) * s;
         e = wi - dq;
       }
@@ -1041,7 +1044,15 @@ __global__ __launch_bounds__(256, kRowLanes == 16 ? 4 : 1) void gptq_block_kerne
   if (live) {
     int8_t* qrow = a.q + static_cast<long long>(r) * a.d + a.c0 + l * kColsPerLane;
     float* erow = a.err + static_cast<long long>(r) * kErrLd + a.err_col + l * kColsPerLane;
-    if (kPlain && (a.d % kColsPerLane) == 0) {  // one packed store each (c0 is a multiple of 64)
+    if (a.q32 != nullptr) {                     // wide targets: the integers as they are (uniform branch)
+      int32_t* q32row = a.q32 + static_cast<long long>(r) * a.d + a.c0 + l * kColsPerLane;
+#pragma unroll
+      for (int k = 0; k < kColsPerLane; ++k) {
+        const int c = l * kColsPerLane + k;
+        if (c < a.nb) q32row[k] = q_own[k];
+        erow[k] = c < a.nb ? e_own[k] : 0.f;
+      }
+    } else if (kPlain && (a.d % kColsPerLane) == 0) {  // one packed store each (c0 is a multiple of 64)
       unsigned packed = 0;
 #pragma unroll
       for (int k = 0; k < kColsPerLane; ++k) packed |= (static_cast<unsigned>(q_own[k]) & 0xFFu) << (8 * k);
@@ -1968,22 +1979,24 @@ extern "C" size_t mi355q_gptq_apply_workspace_bytes(int64_t rows, int64_t d) {
          (upd_bf16x3_usable(rows, d) ? upd_bf16x3_workspace_bytes(rows, d, kErrLd) : 0);
 }
 
-extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d, const float* hinv,
-                                         const void* scale, int32_t scale_is_f64, const int32_t* zero_point,
-                                         int32_t scale_mode, int32_t block_size, int32_t bits, int32_t narrow,
-                                         int32_t zp_via_f64, int32_t diff_bits, int8_t* q_out,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
-  clear_error();
+namespace {
+int32_t gptq_apply_impl(const float* w, int64_t rows, int64_t d, const float* hinv,
+                        const void* scale, int32_t scale_is_f64, const int32_t* zero_point,
+                        int32_t scale_mode, int32_t block_size, int32_t bits, int32_t narrow,
+                        int32_t zp_via_f64, int32_t diff_bits, int8_t* q_out, int32_t* q_out32,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  const bool wide = q_out32 != nullptr;
   if (rows < 0 || d < 0) return fail(MI355Q_BAD_ARG, "negative shape");
   if (rows == 0 || d == 0) return MI355Q_OK;
   if (rows > 0x7FFFFFFF || d > 0x7FFFFFFF) return fail(MI355Q_UNSUPPORTED, "dimension too large");
-  if (bits < 2 || bits > 8) return fail(MI355Q_UNSUPPORTED, "gptq apply supports 2..8 bits");
+  if (!wide && (bits < 2 || bits > 8)) return fail(MI355Q_UNSUPPORTED, "gptq apply supports 2..8 bits (wider targets: mi355q_gptq_apply_wide_f32)");
+  if (wide && (bits < 9 || bits > 16)) return fail(MI355Q_UNSUPPORTED, "gptq apply (wide) supports 9..16 bits");
   if (scale_mode < 0 || scale_mode > 2) return fail(MI355Q_BAD_ARG, "bad scale_mode");
   if (scale_mode == 2 && (block_size <= 0 || d % block_size != 0))
     return fail(MI355Q_BAD_SHAPE, "Quantized dimension %lld is not divisible by block size %d.",
                 static_cast<long long>(d), block_size);
 
-  if (!w || !hinv || !scale || !q_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  if (!w || !hinv || !scale || (!q_out && !q_out32)) return fail(MI355Q_BAD_ARG, "null pointer");
   const size_t need = mi355q_gptq_apply_workspace_bytes(rows, d);
   if (!workspace || workspace_bytes < need)
     return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
@@ -2004,7 +2017,7 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
   a.zp = zero_point; a.scale_mode = scale_mode; a.block_size = block_size > 0 ? block_size : 1;
   a.nblk = scale_mode == 2 ? static_cast<int>(d / block_size) : 1;
   a.lo = static_cast<float>(narrow ? qmin + 1 : qmin); a.hi = static_cast<float>(qmax);
-  a.zp_via_f64 = zp_via_f64; a.diff_bits = diff_bits; a.err = err; a.q = q_out;
+  a.zp_via_f64 = zp_via_f64; a.diff_bits = diff_bits; a.err = err; a.q = q_out; a.q32 = q_out32;
   // (Tried: look-ahead -- only the next group's 256 columns updated on this stream, the rest on the
   // library's side stream underneath the next chain, two alternating error buffers. The chain's
   // workgroups then wait for CUs the update holds: 0.77 -> 0.91 ms at 2048 x 2048, 11.0 -> 11.1 ms
@@ -2020,7 +2033,7 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
     // symmetric recipes with float scales: one launch takes every workgroup's rows through all of
     // the group's blocks (see gptq_rows_kernel)
     const bool plain_group = zero_point == nullptr && !(scale_mode == 2 && block_size % 32 != 0) && !scale_is_f64 &&
-                             d % NB == 0 && !getenv("MI355Q_GPTQ_SPREAD");
+                             d % NB == 0 && !wide && !getenv("MI355Q_GPTQ_SPREAD");   // (gptq_rows_kernel packs bytes)
     if (plain_group) {
       a.c0 = g0;
       a.nb = (g1 - g0) / NB;
@@ -2072,4 +2085,27 @@ extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d
   }
   MI355Q_CHECK_LAUNCH("gptq apply launch");
   return MI355Q_OK;
+}
+}  // namespace
+
+extern "C" int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d, const float* hinv,
+                                         const void* scale, int32_t scale_is_f64, const int32_t* zero_point,
+                                         int32_t scale_mode, int32_t block_size, int32_t bits, int32_t narrow,
+                                         int32_t zp_via_f64, int32_t diff_bits, int8_t* q_out,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (rows > 0 && d > 0 && !q_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  return gptq_apply_impl(w, rows, d, hinv, scale, scale_is_f64, zero_point, scale_mode, block_size, bits, narrow, zp_via_f64,
+                         diff_bits, q_out, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t mi355q_gptq_apply_wide_f32(const float* w, int64_t rows, int64_t d, const float* hinv,
+                                              const void* scale, int32_t scale_is_f64, const int32_t* zero_point,
+                                              int32_t scale_mode, int32_t block_size, int32_t bits, int32_t narrow,
+                                              int32_t zp_via_f64, int32_t diff_bits, int32_t* q_out,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (rows > 0 && d > 0 && !q_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  return gptq_apply_impl(w, rows, d, hinv, scale, scale_is_f64, zero_point, scale_mode, block_size, bits, narrow, zp_via_f64,
+                         diff_bits, nullptr, q_out, workspace, workspace_bytes, stream);
 }

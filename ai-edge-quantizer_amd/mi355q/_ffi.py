@@ -68,6 +68,8 @@ PROTOTYPES = {
     "mi355q_gptq_apply_workspace_bytes": (c_size, [c_i64, c_i64]),
     "mi355q_gptq_apply_f32": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32,
                                       c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_gptq_apply_wide_f32": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32,
+                                           c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_cast_f32_to_f16": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),
     "mi355q_oscar_col_sumsq_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_ptr]),
     "mi355q_oscar_group_terms_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_i32, c_ptr, c_ptr, c_ptr,

@@ -588,17 +588,18 @@ def hessian_product(mode: str = "exact"):
 def gptq_apply(w: torch.Tensor, hinv: torch.Tensor, scale: torch.Tensor,
                zero_point: torch.Tensor | None, scale_mode: int, block_size: int, bits: int,
                narrow: bool, zp_via_f64: bool, diff_bits: int) -> torch.Tensor:
-  """K10. int8 [rows, d]. ref: gptq.py:131-216."""
+  """K10. int8 [rows, d] (int32 for targets of 9..16 bits). ref: gptq.py:131-216."""
   rt.require_gpu()
   w = _f32(w)
   rows, d = w.shape
-  q = rt.empty((rows, d), torch.int8)
+  wide = bits > 8         # int32 [rows, d] from mi355q_gptq_apply_wide_f32 (9..16 bits; the caller narrows the container)
+  q = rt.empty((rows, d), torch.int32 if wide else torch.int8)
   if zero_point is not None:
     zero_point = zero_point.to(torch.int32).contiguous()
   L = _ffi.lib()
   nbytes = L.mi355q_gptq_apply_workspace_bytes(rows, d)
   ws = rt.empty((max(nbytes, 1),), torch.uint8)
-  _ffi.check(L.mi355q_gptq_apply_f32(
+  _ffi.check((L.mi355q_gptq_apply_wide_f32 if wide else L.mi355q_gptq_apply_f32)(
       rt.ptr(w), rows, d, rt.ptr(_f32(hinv)), rt.ptr(scale.contiguous()),
       1 if scale.dtype == torch.float64 else 0, rt.ptr(zero_point), scale_mode, block_size, bits,
       1 if narrow else 0, 1 if zp_via_f64 else 0, diff_bits, rt.ptr(q), rt.ptr(ws), nbytes,

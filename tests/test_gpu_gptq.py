@@ -758,3 +758,80 @@ def test_apply_specialised_and_general_block_kernels_agree(m, rows, d, mode, bs)
   b = m.ops.gptq_apply(w, hinv, scale, zeros, mode, bs, 4, False, True, 32)
   assert torch.equal(a, b)
   assert int(a.to(torch.int32).abs().max()) <= 8 and int((a != 0).sum()) > 0
+
+
+def _apply_with_the_block_product_in_two_halves(w, scale, zp, bits, symmetric, hinv, gran):
+  """oracle.gptq_apply (channel- / tensorwise) with `fw[:, b1:] -= eb @ hinv[b0:b1, b1:]` (ref gptq.py:213-214) formed as two
+  K = 32 products added in turn: what a BLAS with another K blocking returns -- the reference's own re-ordering floor."""
+  fw = np.array(w, copy=True)
+  qw = np.zeros(fw.shape, dtype=O.int_dtype(bits, True))
+  qd = 0 if str(gran).endswith("CHANNELWISE") else None
+  d = hinv.shape[0]
+  for b0 in range(0, d, 64):
+    b1 = min(b0 + 64, d)
+    wb = fw[:, b0:b1]
+    eb = np.zeros_like(wb)
+    for i in range(b1 - b0):
+      c = b0 + i
+      col = wb[:, i]
+      q = O.uniform_quantize(np.expand_dims(col, -1), scale, zp, bits, symmetric, quantized_dim=qd).reshape(-1, 1)
+      dq = O.uniform_dequantize(q, scale, zp, quantized_dim=qd).reshape(-1)
+      qw[:, c] = q.reshape(-1)
+      np.subtract(col, dq, out=eb[:, i])
+      eb[:, i] /= hinv[c, c]
+      if i < b1 - b0 - 1:
+        wb[:, i + 1:] -= np.outer(eb[:, i], hinv[c, c + 1:b1])
+    half = (b1 - b0) // 2
+    fw[:, b1:] -= np.matmul(eb[:, :half], hinv[b0:b0 + half, b1:]) + np.matmul(eb[:, half:], hinv[b0 + half:b1, b1:])
+  return qw
+
+
+@pytest.mark.parametrize("bits,symmetric,gran,shape", [(16, True, "CHANNELWISE", (24, 64)), (12, True, "CHANNELWISE", (40, 48)),
+                                                       (16, False, "TENSORWISE", (20, 64)), (9, True, "TENSORWISE", (16, 33)),
+                                                       (16, True, "CHANNELWISE", (24, 200)), (16, False, "CHANNELWISE", (16, 130))])
+def test_targets_wider_than_8_bits(m, bits, symmetric, gran, shape):
+  """ref gptq.py:141-151: 9..16-bit targets get an int16 container (mi355q_gptq_apply_wide_f32; the reference's policy
+  admits 2-, 4- and 8-bit weights only, so only a direct caller of get_tensor_quant_params gets here). Given the
+  oracle's inverse, one 64-column block is exact (the intra-block path, T1); with several blocks the order of the
+  float32 additions inside a block's product moves integers of a grid 256 x finer than int8's by one step -- the
+  reference itself does not reproduce its 16-bit integers across two implementations of strtri (17 % of them differ
+  by one step between the reference and the oracle on [24, 200]) -- so there the oracle's own re-ordering floor is
+  recorded beside the GPU's rate and steps are at most one. Scales and zero points are the oracle's bit for bit,
+  through the public entry point too."""
+  rng = np.random.default_rng(bits * 1000 + shape[1])
+  rows, d = shape
+  w = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+  x = rng.standard_normal((2, 256, d)).astype(np.float32)
+  h = O.gptq_hessian(x)
+  qsv = {"activation_tensor_qsv": {"hessian": h, "num_samples": 2}}
+  ref = O.gptq_quant_params(w, bits, symmetric, gran, qsv)
+  scale, zp = ref["scale"], ref["zero_point"]
+  hinv = O.gptq_hessian_inverse(h)
+  want = O.gptq_apply(w, scale, zp, bits, symmetric, h, gran, 0, hinv=hinv)
+  assert want.dtype == np.int16
+  mode = 0 if scale.size == 1 else 1
+  z = dev(m, np.broadcast_to(zp, scale.shape).reshape(-1).astype(np.int32)) if np.any(zp) else None
+  diff_bits = min(32, np.result_type(np.int16, zp.dtype).itemsize * 8)
+  q = host(m.ops.gptq_apply(dev(m, w), dev(m, hinv), dev(m, scale.reshape(-1).astype(np.float32)), z, mode, 0, bits,
+                            symmetric and bits >= 8, zp.dtype.itemsize >= 4, diff_bits))
+  assert q.dtype == np.int32 and np.abs(q).max() < (1 << (bits - 1)) + 1
+  if d <= 64:
+    assert np.array_equal(q, want)
+  else:
+    reordered = _apply_with_the_block_product_in_two_halves(w, scale, zp, bits, symmetric, hinv, gran)
+    parity_rates.check_with_floor(f"gptq apply {bits}-bit {gran} {'sym' if symmetric else 'asym'} [{rows},{d}] vs oracle (same Hinv)",
+                                  q, want, reordered, cap=1e-3, k=2.0, max_step=1)
+  # the public entry point: container, scales, zero points
+  q_ = m.qtyping
+  cfg = q_.TensorQuantizationConfig(num_bits=bits, symmetric=symmetric, granularity=q_.QuantGranularity[gran])
+  info = q_.OpInfo(op=q_.OperatorT(), op_name=q_.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
+                   op_quant_config=q_.OpQuantizationConfig(weight_tensor_config=cfg))
+  p = m.gptq.get_tensor_quant_params(info, cfg, w, {"activation_tensor_qsv": {"hessian": h, "num_samples": 2}})
+  got = np.asarray(p.quantized_data)
+  assert got.dtype == np.int16 and got.shape == w.shape
+  assert np.array_equal(p.scale, scale) and np.array_equal(p.zero_point, zp)
+  assert np.abs(got.astype(np.int64) - ref["quantized_data"].astype(np.int64)).max() <= (1 if d <= 64 else 2)
+  # 17 bits and more stay refused
+  cfg17 = q_.TensorQuantizationConfig(num_bits=17, symmetric=True, granularity=q_.QuantGranularity.CHANNELWISE)
+  with pytest.raises(NotImplementedError):
+    m.gptq.get_tensor_quant_params(info, cfg17, w, {"activation_tensor_qsv": {"hessian": h, "num_samples": 2}})
