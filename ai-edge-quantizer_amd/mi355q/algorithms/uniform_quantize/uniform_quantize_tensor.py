@@ -197,7 +197,10 @@ def uniform_quantize_on_device(tensor_data: np.ndarray, quantization_params: qty
     qd = p.quantized_dimension
     _get_tensor_shape_for_blockwise(tensor_data.shape, qd, p.block_size)  # divisibility check
     if any(d != 1 for d in tensor_data.shape[qd + 1:]):
-      raise NotImplementedError("blockwise quantization along a non-innermost dimension")
+      # blocks along an axis that is not the innermost one (ref :164-270 reshapes; no op of the reference's tables asks for it,
+      # a direct caller may): the kernel's blocks are contiguous, so the blocked axis is moved last on the device -- elementwise
+      # arithmetic, the same values in another place -- and the integers are moved back
+      return _blockwise_along_inner_axis(tensor_data, p, qd, resident)
     block_view = (1, int(p.scale.size), p.block_size)
     # validation the reference performs on the broadcast parameters
     if p.scale.ndim != tensor_data.ndim:
@@ -225,6 +228,37 @@ def uniform_quantize_on_device(tensor_data: np.ndarray, quantization_params: qty
                       p.num_bits, narrow, zp_via_f64=zp.dtype.itemsize >= 4)
 
 
+def _moved_last(p: qtyping.UniformQuantParams, qd: int, ndim: int) -> qtyping.UniformQuantParams:
+  """`p` for the tensor with axis `qd` moved last (scales and zero points follow their axis)."""
+  scale = np.ascontiguousarray(np.moveaxis(p.scale, qd, -1))
+  zp = p.zero_point
+  if zp is not None and np.size(zp) > 1:
+    zp = np.ascontiguousarray(np.moveaxis(zp.reshape(p.scale.shape), qd, -1))
+  return dataclasses.replace(p, scale=scale, zero_point=zp, quantized_dimension=ndim - 1)
+
+
+def _blockwise_along_inner_axis(tensor_data, p: qtyping.UniformQuantParams, qd: int, resident):
+  if tensor_data.size == 0:
+    return None
+  if p.scale.ndim != tensor_data.ndim:
+    raise ValueError(f"Ranks of scales ({p.scale.ndim}) and zps ({np.ndim(p.zero_point)}) must"
+                     f" be the same as the tensor rank ({tensor_data.ndim}).")
+  shape = tuple(tensor_data.shape)
+  x = resident if resident is not None else rt.to_device(_as_f32_exact(tensor_data))
+  moved = x.reshape(shape).movedim(qd, -1).contiguous()
+  q = uniform_quantize_on_device(_ShapeOnly(tuple(moved.shape), tensor_data.dtype),
+                                 _moved_last(p, qd, len(shape)), True, resident=moved.reshape(-1))
+  return q.reshape(tuple(moved.shape)).movedim(-1, qd).contiguous().reshape(-1)
+
+
+class _ShapeOnly:
+  """What uniform_quantize_on_device reads of `tensor_data` when the values are handed over as `resident`."""
+
+  def __init__(self, shape, dtype):
+    self.shape, self.dtype, self.ndim = shape, np.dtype(dtype), len(shape)
+    self.size = int(np.prod(shape, dtype=np.int64))
+
+
 def uniform_dequantize(tensor_data: np.ndarray,
                        quantization_params: qtyping.UniformQuantParams) -> np.ndarray:
   """(q - zp) * scale on the GPU (ref :365-409)."""
@@ -236,8 +270,10 @@ def uniform_dequantize(tensor_data: np.ndarray,
     sshape = list(tensor_data.shape)
     sshape[qd] //= p.block_size
     scale = p.scale.reshape(sshape)
-    if any(d != 1 for d in tensor_data.shape[qd + 1:]):
-      raise NotImplementedError("blockwise dequantization along a non-innermost dimension")
+    if any(d != 1 for d in tensor_data.shape[qd + 1:]):      # (see uniform_quantize_on_device: the blocked axis goes last and back)
+      moved = np.ascontiguousarray(np.moveaxis(tensor_data, qd, -1))
+      back = uniform_dequantize(moved, _moved_last(dataclasses.replace(p, scale=scale), qd, tensor_data.ndim))
+      return np.ascontiguousarray(np.moveaxis(back, -1, qd))
     zp = p.zero_point if np.size(p.zero_point) else np.zeros(scale.shape, np.int32)
     if zp.size != 1 and zp.shape != scale.shape:
       zp = zp.reshape(scale.shape)

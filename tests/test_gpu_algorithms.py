@@ -441,3 +441,30 @@ def test_octav_blockwise_groups_kernel_bit_exact(m, block):
     warnings.simplefilter("ignore")
     assert np.array_equal(m.octav._guess_clipping_with_octav(data, 4, 2, 10, 3.0), O.octav_clip(data, 4, 2, 10, 3.0),
                           equal_nan=True)
+
+
+@pytest.mark.parametrize("shape,qd,block,bits,symmetric", [((64, 10), 0, 32, 8, True), ((4, 96, 6), 1, 32, 4, True),
+                                                           ((3, 64, 5, 2), 1, 16, 8, False), ((128, 3), 0, 64, 4, True)])
+def test_blockwise_along_an_axis_that_is_not_the_innermost(m, shape, qd, block, bits, symmetric):
+  """uniform_quantize / uniform_dequantize with blocks along an inner axis (ref uniform_quantize_tensor.py:164-270 reshapes;
+  no op of the reference's tables asks for it -- TFL_OP_TO_BLOCKWISE_WEIGHT_QUANTIZED_DIM is 1 for the two 2-D ops -- a
+  direct caller may): the blocked axis is moved last on the device and the results moved back; bit-exact against the
+  oracle's broadcast form."""
+  q_ = m.qtyping
+  rng = np.random.default_rng(sum(shape) + block)
+  x = (rng.standard_normal(shape) * 0.3).astype(np.float32)
+  sshape = list(shape)
+  sshape[qd] //= block
+  split = list(shape[:qd]) + [shape[qd] // block, block] + list(shape[qd + 1:])
+  absmax = np.abs(x.reshape(split)).max(axis=qd + 1)
+  qmax = (1 << (bits - 1)) - 1
+  scale = (np.maximum(absmax, 1e-9) / qmax).astype(np.float32).reshape(sshape)
+  zp = (np.zeros(sshape, np.int32) if symmetric else rng.integers(-3, 4, sshape).astype(np.int32))
+  p = q_.UniformQuantParams(scale=scale, zero_point=zp, num_bits=bits, symmetric=symmetric, quantized_dimension=qd, block_size=block)
+  got = m.uqt.uniform_quantize(x, p, is_blockwise_quant=True)
+  want = O.uniform_quantize(x, scale, zp, bits, symmetric, quantized_dim=qd, block_size=block, is_blockwise_quant=True)
+  assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want)
+  if qd != 0:       # (quantized_dimension 0 means axis 1 to uniform_dequantize: ref :379-387, b/443830202)
+    back = m.uqt.uniform_dequantize(got, p)
+    ref = O.uniform_dequantize(want, scale, zp, quantized_dim=qd, block_size=block)
+    assert back.dtype == ref.dtype and np.array_equal(back, ref)
