@@ -727,3 +727,34 @@ extern "C" int32_t mi355q_act_minmax_f32(const float* const* x_ptrs, const int64
   MI355Q_CHECK_LAUNCH("act_minmax finalize launch");
   return MI355Q_OK;
 }
+
+// ---- shader clock seen from inside (measurement aid, not on the product path) -------------------------------------
+// One wave that watches the constant 100 MHz counter (wall_clock64) for `ticks_100mhz` ticks and reports how many shader
+// clocks (clock64) went by: launched on a stream of its own beside a kernel under test, it gives the clock the part
+// sustains WHILE that kernel runs -- the hwmon / SMI files on these boxes report a constant 2407 MHz.
+namespace mi355q {
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(long long ticks_100mhz, long long* out) {
+  if (threadIdx.x != 0) return;
+  const long long w0 = wall_clock64();
+  const long long c0 = clock64();
+  long long w = w0;
+  while (w - w0 < ticks_100mhz) {
+    __builtin_amdgcn_s_sleep(32);
+    w = wall_clock64();
+  }
+  out[0] = clock64() - c0;
+  out[1] = w - w0;
+}
+}  // namespace
+}  // namespace mi355q
+
+extern "C" int32_t mi355q_clock_probe(double seconds, int64_t* clocks_and_ticks_out, void* stream) {
+  mi355q::clear_error();
+  if (!clocks_and_ticks_out) return mi355q::fail(MI355Q_BAD_ARG, "null pointer");
+  if (!(seconds > 0.0 && seconds <= 1.0)) return mi355q::fail(MI355Q_BAD_ARG, "probe length must be in (0, 1] s");
+  hipLaunchKernelGGL(mi355q::clock_probe_kernel, dim3(1), dim3(64), 0, mi355q::as_stream(stream),
+                     static_cast<long long>(seconds * 1e8), reinterpret_cast<long long*>(clocks_and_ticks_out));
+  MI355Q_CHECK_LAUNCH("clock probe launch");
+  return MI355Q_OK;
+}

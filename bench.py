@@ -114,8 +114,10 @@ class ClockSampler:
   socket's power limit: their time moves with the clock a box sustains, and this is what makes a box-to-box spread
   attributable. All fields None when the files are not there."""
 
-  def __init__(self, index: int = 0):
+  def __init__(self, index: int = 0, expect_s: float = 0.0):
     import glob
+    self.expect_s = expect_s      # > 0: also count shader clocks from inside (mi355q_clock_probe) for about that long
+    self.probe = None
     self.freq = self.power = None
     for card in sorted(glob.glob("/sys/class/drm/card*/device")):
       mons = sorted(glob.glob(card + "/hwmon/hwmon*"))
@@ -137,6 +139,20 @@ class ClockSampler:
       return None
 
   def __enter__(self):
+    if self.expect_s > 0:
+      # the hwmon clock is a constant on these boxes: one wave on a stream of its own counts shader clocks against the
+      # constant 100 MHz counter while the timed kernels run (include/mi355q.h: mi355q_clock_probe)
+      import ctypes
+      import torch
+      from mi355q import _ffi
+      each = min(0.03, self.expect_s)
+      n = max(1, int(0.8 * self.expect_s / each))
+      side = torch.cuda.Stream()
+      out = torch.zeros((n, 2), dtype=torch.int64, device="cuda")
+      torch.cuda.synchronize()
+      for i in range(n):
+        _ffi.check(_ffi.lib().mi355q_clock_probe(each, ctypes.c_void_p(out[i].data_ptr()), ctypes.c_void_p(side.cuda_stream)))
+      self.probe = (side, out)
     if self.freq is not None:
       import threading
 
@@ -159,10 +175,17 @@ class ClockSampler:
       self._thread.join(1.0)
 
   def summary(self) -> dict:
+    inside = {}
+    if self.probe is not None:
+      side, out = self.probe
+      side.synchronize()
+      mhz = [100.0 * c / t for c, t in out.cpu().tolist() if t > 0]
+      inside = {"shader_MHz_counted_in_kernel_mean": round(sum(mhz) / len(mhz)) if mhz else None,
+                "shader_MHz_counted_in_kernel_min": round(min(mhz)) if mhz else None, "probes": len(mhz)}
     if not self.mhz:
-      return {"sclk_MHz_mean": None, "sclk_MHz_min": None, "socket_W_mean": None, "samples": 0}
+      return {"sclk_MHz_mean": None, "sclk_MHz_min": None, "socket_W_mean": None, "samples": 0, **inside}
     return {"sclk_MHz_mean": round(sum(self.mhz) / len(self.mhz)), "sclk_MHz_min": round(min(self.mhz)),
-            "socket_W_mean": round(sum(self.watts) / len(self.watts)) if self.watts else None, "samples": len(self.mhz)}
+            "socket_W_mean": round(sum(self.watts) / len(self.watts)) if self.watts else None, "samples": len(self.mhz), **inside}
 
 
 def hinv_roofline(d: int, ms: float) -> dict:
@@ -299,9 +322,10 @@ def more_extras(torch, ops, gen, xs) -> dict:
     reps = 10 if d == 2048 else 3
     # (the d = 16384 product is repeated for ~0.3 s so that the clock sampler sees the sustained state, not the ramp)
     reps_h = reps if d == 2048 else 12
-    with ClockSampler() as clk:
+    expect = (reps_h + 1) * (0.0023 if d == 2048 else 0.023)
+    with ClockSampler(expect_s=expect) as clk:
       ms_h = timed_ms(torch, lambda: ops.gptq_xtx(x, 2.0 / 128), reps_h, 1)
-    with ops.hessian_product("fast"), ClockSampler() as clk_fast:
+    with ops.hessian_product("fast"), ClockSampler(expect_s=0.6 * expect) as clk_fast:
       ms_h_fast = timed_ms(torch, lambda: ops.gptq_xtx(x, 2.0 / 128), reps_h, 1)
     h = ops.gptq_xtx(x, 2.0 / 128)
     del x

@@ -328,6 +328,10 @@ int32_t mi355q_prepare_device(void);
  * interpreter's) for that long; through these two a helper thread of the host side allocates while the thread that
  * feeds the GPU goes on (mi355q/ops.py: HinvWorkspace). mi355q_device_free(NULL) is a no-op; freeing waits for the
  * device like hipFree. */
+/* Measurement aid (bench.py `clock_while_timed`): one wave counts shader clocks (clock64) over `seconds` of the constant
+ * 100 MHz counter (wall_clock64) and writes {clocks, ticks} to the device int64[2] -- clocks / ticks * 100 = MHz sustained
+ * while whatever else is running runs. Launch it on a stream of its own beside the kernel under test. */
+int32_t mi355q_clock_probe(double seconds, int64_t* clocks_and_ticks_out, void* stream);
 int32_t mi355q_device_alloc(size_t nbytes, void** out);
 int32_t mi355q_device_free(void* p);
 int32_t mi355q_gptq_hinv_f64(const double* hessian, int64_t d, double damp_factor, float* hinv_out,
