@@ -262,12 +262,27 @@ class Calibrator:
     dev = [a.device_tensor.contiguous().reshape(-1) if isinstance(a, rt.HbmArray)
            else rt.to_device(np.ascontiguousarray(a).reshape(-1)) for a in arrays]
     mm = ops.act_minmax(dev, lo, hi)
-    pinned = torch.empty(tuple(mm.shape), dtype=mm.dtype, pin_memory=True)
+    pinned = self._pinned_results(tuple(mm.shape), mm.dtype)
     pinned.fill_(float("nan"))         # (a statistic read before its copy has landed must not look like one)
     pinned.copy_(mm, non_blocking=True)
     event = torch.cuda.Event()
     event.record()
     return arrays, dev, pinned, event, lo, hi
+
+  def _pinned_results(self, shape, dtype):
+    """A sample's [tensors, 2] results in page-locked memory, cut from an arena of 64 samples' worth: every sample's block
+    stays alive until the statistics are read (record_steps), and a page-locked allocation of its own per sample was a
+    hipHostMalloc each -- 512 of them for BASELINE config 4."""
+    import torch
+    n = 1
+    for d in shape:
+      n *= d
+    arena = getattr(self, "_pinned_arena", None)
+    if arena is None or arena[0].dtype != dtype or arena[1] + n > arena[0].numel():
+      arena = self._pinned_arena = [torch.empty((max(64 * n, n),), dtype=dtype, pin_memory=True), 0]
+    out = arena[0][arena[1]:arena[1] + n].view(shape)
+    arena[1] += n
+    return out
 
   def _walk(self, signature_key, model_recipe_manager) -> None:
     from .algorithms.uniform_quantize import common_quantize
