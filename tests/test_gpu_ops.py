@@ -392,3 +392,42 @@ def test_cast_f16_matches_numpy_astype():
     got = rt.to_numpy(ops.cast_f16(rt.to_device(arr)))
     want = arr.astype(np.float16)
     assert got.dtype == np.float16 and np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+def test_device_alloc_clock_probe_and_the_held_inverse_workspace(ops):
+  """The round-4 plumbing entry points: mi355q_device_alloc / _free hand out device memory the kernels can use (the
+  workspace ops.HinvWorkspace allocates on a helper thread: an inverse computed in it equals the one computed in the
+  framework's allocation, bit for bit, also when the batched call borrows it); mi355q_clock_probe counts a plausible
+  shader clock."""
+  import ctypes
+  import torch
+  from mi355q import _ffi
+  O_ = ops
+  L = _ffi.lib()
+  p = ctypes.c_void_p()
+  _ffi.check(L.mi355q_device_alloc(1 << 20, ctypes.byref(p)))
+  assert p.value
+  _ffi.check(L.mi355q_device_free(p))
+  assert L.mi355q_device_alloc(1 << 20, None) == -1 and L.mi355q_device_free(None) == 0
+  out = torch.zeros(2, dtype=torch.int64, device="cuda")
+  _ffi.check(L.mi355q_clock_probe(0.01, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+  clocks, ticks = out.cpu().tolist()
+  assert 0.9e6 <= ticks <= 1.5e6 and 300.0 <= 100.0 * clocks / ticks <= 3500.0, (clocks, ticks)
+  assert L.mi355q_clock_probe(2.0, ctypes.c_void_p(out.data_ptr()), None) == -1
+  d = 4096
+  x = torch.randn((6000, d), device="cuda")
+  prod = O_.gptq_xtx_accum(x, None)
+  plain, info = O_.gptq_hinv_from_product(prod, 2.0 / 6000)
+  small = [torch.randn((900, 320), device="cuda", dtype=torch.float64) for _ in range(3)]
+  hs = [s.T @ s / 900 for s in small]
+  plain_small = O_.gptq_hinv_batched(hs)
+  ws = O_.HinvWorkspace(d)
+  with ws:
+    assert O_.HinvWorkspace.current is ws and ws.pointer(ws.nbytes) is not None and ws.pointer(ws.nbytes + 1) is None
+    held, info2 = O_.gptq_hinv_from_product(prod, 2.0 / 6000)
+    held_small = O_.gptq_hinv_batched(hs)
+    torch.cuda.synchronize()
+  assert O_.HinvWorkspace.current is None
+  assert int(info.item()) == int(info2.item()) == 0 and torch.equal(plain, held)
+  for (a, _), (b, _) in zip(plain_small, held_small):
+    assert torch.equal(a, b)
