@@ -497,8 +497,8 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
         # 7.5 ms of hipMalloc per sample there delayed that burst by 0.2 s
         markers.append(torch.cuda.Event())
         markers[-1].record()
-        if len(markers) > 2 and not markers.pop(0).query():
-          rt.pump_prefetch()
+        behind = len(markers) > 2 and not markers.pop(0).query()
+        rt.pump_prefetch(256 << 20 if behind else 0)      # (uploads into the arena cost this thread nothing: always)
       if walked == 2 and torch.cuda.is_available():
         d = gptq.largest_hessian_order(mine_items)
         if d >= 4096:

@@ -208,14 +208,75 @@ PREFETCH_WINDOW_BYTES = int(os.environ.get("MI355Q_PREFETCH_BYTES", 32 << 30))  
 _PREFETCHED: dict = {}     # (fd, offset, nbytes) -> (uint8 tensor, ticket)
 _PREFETCH_WAITING: dict = {}   # (fd, offset, nbytes) -> None, in plan order: beyond the window, submitted as earlier ones are consumed
 _PREFETCH_OUTSTANDING = [0]
+_ARENA_MIN_BYTES = 64 << 20     # announced at once and at least this much: one allocation for all of it (_UploadArena)
+
+
+# The upload tensors of a model are fresh device memory: ~30 ms of hipMalloc per GiB on whoever asks, and the framework's
+# allocator holds its lock (and the interpreter's) meanwhile. A caller that announces a whole plan's weights at once gets ONE
+# allocation for all of them, made by a helper thread through mi355q_device_alloc while the caller goes on; the uploads land in
+# slices of it (torch tensors over foreign memory: __cuda_array_interface__), and the memory is given back when the last tensor
+# that aliases it is gone AND release_upload_files() comes by (hipFree waits for the device: never in the middle of a walk).
+_ARENA_OF: dict = {}        # announced key -> (_UploadArena, offset)
+_ARENA_FREES: list = []     # device pointers nobody aliases any more
+
+
+class _UploadArena:
+  def __init__(self, nbytes: int):
+    import threading
+    self.nbytes = nbytes
+    self._ptr = ctypes.c_void_p()
+    self._status = None
+    self._device = torch.cuda.current_device()
+
+    def work():
+      torch.cuda.set_device(self._device)
+      self._status = _ffi.lib().mi355q_device_alloc(nbytes, ctypes.byref(self._ptr))
+    self._thread = threading.Thread(target=work, name="mi355q-upload-arena", daemon=True)
+    self._thread.start()
+
+  def ready(self) -> bool:
+    return not self._thread.is_alive()
+
+  def slice(self, offset: int, n: int):
+    """uint8 tensor over [offset, offset + n) of the arena, or None when the allocation failed."""
+    self._thread.join()
+    if self._status != 0 or not self._ptr.value:
+      return None
+    return torch.as_tensor(_ArenaSlice(self, self._ptr.value + offset, n), device=torch.device("cuda", self._device))
+
+  def __del__(self):
+    try:
+      self._thread.join()
+      if self._status == 0 and self._ptr.value:
+        _ARENA_FREES.append(self._ptr.value)
+    except Exception:  # noqa: BLE001 - interpreter exit
+      pass
+
+
+class _ArenaSlice:
+  """What torch.as_tensor wraps (and keeps alive for as long as the tensor's storage lives)."""
+
+  def __init__(self, arena: _UploadArena, ptr: int, n: int):
+    self.arena = arena
+    self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _free_dead_arenas() -> None:
+  while _ARENA_FREES:
+    _ffi.lib().mi355q_device_free(ctypes.c_void_p(_ARENA_FREES.pop()))
 
 
 def _submit_upload(key) -> None:
   fd, offset, n = key
   dev = device()
   copy_stream = _copy_stream(dev)
-  with torch.cuda.stream(copy_stream):
-    out = torch.empty((n,), dtype=torch.uint8, device=dev)
+  out = None
+  held = _ARENA_OF.pop(key, None)
+  if held is not None:
+    out = held[0].slice(held[1], n)
+  if out is None:
+    with torch.cuda.stream(copy_stream):
+      out = torch.empty((n,), dtype=torch.uint8, device=dev)
   ticket = ctypes.c_int64(0)
   _ffi.check(_ffi.lib().mi355q_file_io_submit_upload(fd, offset, n, ctypes.c_void_p(out.data_ptr()),
                                                      ctypes.c_void_p(copy_stream.cuda_stream), ctypes.byref(ticket)))
@@ -223,10 +284,16 @@ def _submit_upload(key) -> None:
   _PREFETCH_OUTSTANDING[0] += n
 
 
-def _top_up_prefetch(at_most_bytes: Optional[int] = None) -> int:
+def _top_up_prefetch(at_most_bytes: Optional[int] = None, wait_for_arena: bool = True) -> int:
   done = 0
-  while _PREFETCH_WAITING and _PREFETCH_OUTSTANDING[0] < PREFETCH_WINDOW_BYTES and (at_most_bytes is None or done < at_most_bytes):
+  while _PREFETCH_WAITING and _PREFETCH_OUTSTANDING[0] < PREFETCH_WINDOW_BYTES:
     key = next(iter(_PREFETCH_WAITING))
+    held = _ARENA_OF.get(key)
+    if held is None:                      # a tensor of its own: fresh memory on this thread's time, so a bounded amount per call
+      if at_most_bytes is not None and done >= at_most_bytes:
+        break
+    elif not wait_for_arena and not held[0].ready():
+      break                               # (the helper thread is still allocating: next time)
     del _PREFETCH_WAITING[key]
     _submit_upload(key)
     done += key[2]
@@ -242,6 +309,7 @@ def prefetch_uploads(arrays, submit: bool = True) -> int:
   if os.environ.get("MI355Q_NO_PREFETCH") or not torch.cuda.is_available():
     return 0
   total = 0
+  fresh: list = []
   for a in arrays:
     if not isinstance(a, np.ndarray) or not a.flags.c_contiguous or a.nbytes < (1 << 20):
       continue
@@ -253,6 +321,12 @@ def prefetch_uploads(arrays, submit: bool = True) -> int:
       continue
     _PREFETCH_WAITING[key] = None
     total += a.nbytes
+    fresh.append(key)
+  if total >= _ARENA_MIN_BYTES and total <= PREFETCH_WINDOW_BYTES and not os.environ.get("MI355Q_NO_UPLOAD_ARENA"):
+    arena, at = _UploadArena(sum((k[2] + 255) & ~255 for k in fresh)), 0
+    for k in fresh:
+      _ARENA_OF[k] = (arena, at)
+      at += (k[2] + 255) & ~255
   if submit:
     _top_up_prefetch()
   return total
@@ -270,13 +344,15 @@ def announced(a) -> bool:
 
 
 def pump_prefetch(at_most_bytes: int = 256 << 20) -> int:
-  """Starts up to `at_most_bytes` more of the announced uploads (at least one, if any is waiting and the window has room)."""
-  return _top_up_prefetch(at_most_bytes) if _PREFETCH_WAITING else 0
+  """Starts more of the announced uploads without holding the caller: everything whose memory the arena's helper thread has
+  ready; of the uploads that need a tensor of their own, up to `at_most_bytes` (0: none of those)."""
+  return _top_up_prefetch(at_most_bytes, wait_for_arena=False) if _PREFETCH_WAITING else 0
 
 
 def cancel_prefetch() -> None:
   """Uploads nobody consumed: waited for (the upload thread writes into their tensors) and dropped."""
   _PREFETCH_WAITING.clear()
+  _ARENA_OF.clear()
   entries = list(_PREFETCHED.values())
   _PREFETCHED.clear()
   _PREFETCH_OUTSTANDING[0] = 0
@@ -454,6 +530,7 @@ def release_upload_files() -> None:
   cancel_prefetch()
   for st in _COPY_STREAMS.values():
     st.synchronize()
+  _free_dead_arenas()
   for rec in [m for m in _FILE_MAPPINGS if not m.alive()]:
     rec._gone()  # pylint: disable=protected-access
 
