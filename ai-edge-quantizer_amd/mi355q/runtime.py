@@ -217,7 +217,9 @@ _ARENA_MIN_BYTES = 64 << 20     # announced at once and at least this much: one 
 # slices of it (torch tensors over foreign memory: __cuda_array_interface__), and the memory is given back when the last tensor
 # that aliases it is gone AND release_upload_files() comes by (hipFree waits for the device: never in the middle of a walk).
 _ARENA_OF: dict = {}        # announced key -> (_UploadArena, offset)
-_ARENA_FREES: list = []     # device pointers nobody aliases any more
+_ARENA_FREES: list = []     # (device pointer, bytes) nobody aliases any more
+_ARENA_SPARE: list = []     # at most one of those, kept for the next call of the process (what a caching allocator would do:
+                            # a second model of the same size starts its uploads at once); release_upload_staging() frees it
 
 
 class _UploadArena:
@@ -227,10 +229,14 @@ class _UploadArena:
     self._ptr = ctypes.c_void_p()
     self._status = None
     self._device = torch.cuda.current_device()
+    if _ARENA_SPARE and _ARENA_SPARE[0][1] >= nbytes and _ARENA_SPARE[0][2] == self._device:
+      spare = _ARENA_SPARE.pop()
+      self._ptr.value, self.nbytes, self._status = spare[0], spare[1], 0
 
     def work():
-      torch.cuda.set_device(self._device)
-      self._status = _ffi.lib().mi355q_device_alloc(nbytes, ctypes.byref(self._ptr))
+      if self._status is None:
+        torch.cuda.set_device(self._device)
+        self._status = _ffi.lib().mi355q_device_alloc(nbytes, ctypes.byref(self._ptr))
     self._thread = threading.Thread(target=work, name="mi355q-upload-arena", daemon=True)
     self._thread.start()
 
@@ -248,7 +254,7 @@ class _UploadArena:
     try:
       self._thread.join()
       if self._status == 0 and self._ptr.value:
-        _ARENA_FREES.append(self._ptr.value)
+        _ARENA_FREES.append((self._ptr.value, self.nbytes, self._device))
     except Exception:  # noqa: BLE001 - interpreter exit
       pass
 
@@ -261,9 +267,20 @@ class _ArenaSlice:
     self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def _free_dead_arenas() -> None:
-  while _ARENA_FREES:
-    _ffi.lib().mi355q_device_free(ctypes.c_void_p(_ARENA_FREES.pop()))
+def _free_dead_arenas(keep_spare: bool = True) -> None:
+  """The arenas nobody aliases any more: the largest stays as the spare of the next call, the others go back (hipFree waits
+  for the device: callers come here when a whole-model call is over)."""
+  if not _ARENA_FREES and (keep_spare or not _ARENA_SPARE):
+    return
+  if torch.cuda.is_available():
+    torch.cuda.synchronize()        # (whatever still read an arena's slices has run: the spare may be written again at once)
+  dead = _ARENA_FREES[:] + _ARENA_SPARE[:]
+  del _ARENA_FREES[:], _ARENA_SPARE[:]
+  dead.sort(key=lambda e: e[1])
+  if keep_spare and dead:
+    _ARENA_SPARE.append(dead.pop())
+  for ptr, _, _ in dead:
+    _ffi.lib().mi355q_device_free(ctypes.c_void_p(ptr))
 
 
 def _submit_upload(key) -> None:
@@ -539,6 +556,7 @@ def release_upload_staging() -> None:
   """Closes the files; the pinned ring (24 MB of page-locked host memory per device) and the io
   threads go with mi355q_shutdown()."""
   release_upload_files()
+  _free_dead_arenas(keep_spare=False)
   _COPY_STREAMS.clear()
   _DOWNLOAD_STREAMS.clear()
 

@@ -144,6 +144,14 @@ def test_c3_model_32_layers_two_launches_and_identical_file(m, tmp_path):
   file_bench.build_model(src, 32, 4096, 11008)
   rcp = m.recipe.dynamic_wi4b128_afp32()
   outs = []
+  slices = []
+  arena_slice = m.rt._UploadArena.slice
+
+  def counted(self, offset, n):
+    out = arena_slice(self, offset, n)
+    slices.append(out is not None)
+    return out
+  m.rt._UploadArena.slice = counted
   for enabled in (True, False):
     m.rq.ENABLED = enabled
     try:
@@ -153,6 +161,9 @@ def test_c3_model_32_layers_two_launches_and_identical_file(m, tmp_path):
       outs.append((dst, qz.batch_stats))
     finally:
       m.rq.ENABLED = True
+  m.rt._UploadArena.slice = arena_slice
+  # the 32 announced weights of each run landed in ONE allocation made by a helper thread (runtime._UploadArena)
+  assert len(slices) == 64 and all(slices), slices
   (batched, stats), (single, stats_off) = outs
   assert stats["tensors"] == 32 and stats["launches"] <= 32, stats
   assert stats_off["tensors"] == 0
