@@ -153,15 +153,17 @@ def _sha(path):
   return h.hexdigest()
 
 
-def test_quantizer_through_the_ring_writes_the_same_file(m, tmp_path, monkeypatch):
+@pytest.mark.parametrize("recipe_name", ["dynamic_wi4b128_afp32", "dynamic_wi8_afp32", "dynamic_wi4_afp32"])
+def test_quantizer_through_the_ring_writes_the_same_file(m, tmp_path, monkeypatch, recipe_name):
   """The ring is for model files of a GiB and more; with the thresholds taken down a 4-layer model goes through
   it (uploads by pread, output by pwrite) and the file must equal the pageable path's byte for byte -- also when
-  it replaces an older, longer file of the same name (no O_TRUNC: the length is set explicitly)."""
+  it replaces an older, longer file of the same name (no O_TRUNC: the length is set explicitly). Blockwise int4
+  (scale tensors as late constants), per-channel int8 and int4 (scales as late vectors of the flatbuffer)."""
   sys.path.insert(0, os.path.join(ROOT, "tools"))
   import file_bench
   src = str(tmp_path / "small.tflite")
   file_bench.build_model(src, 4, 1024, 2048 + 128)
-  rcp = m.recipe.dynamic_wi4b128_afp32()
+  rcp = getattr(m.recipe, recipe_name)()
   plain = str(tmp_path / "plain.tflite")
   m.quantizer.Quantizer(src, rcp).quantize(serialize_to_path=plain)
   calls = {"up": 0, "down": 0}
