@@ -188,6 +188,13 @@ def test_quantizer_through_the_ring_writes_the_same_file(m, tmp_path, monkeypatc
   assert calls["up"] >= 4 and calls["down"] >= 3, calls   # (a buffer somebody already read on the host is copied from there)
   assert os.path.getsize(ring) == os.path.getsize(plain)
   assert _sha(ring) == _sha(plain)
+  # ... and the one written with every value read where the reference reads it (no late vectors, no late constants)
+  first = str(tmp_path / "values_first.tflite")
+  with monkeypatch.context() as mp:
+    mp.setattr(m.rt, "late_vector", lambda values, dtype: np.ravel(values).astype(dtype, copy=False))
+    mp.setattr(m.rt, "late_constants_allowed", lambda: False)
+    m.quantizer.Quantizer(src, rcp).quantize(serialize_to_path=first)
+  assert _sha(first) == _sha(plain)
 
 
 def test_equal_blockwise_scales_share_one_buffer_whether_read_early_or_late(m, tmp_path, monkeypatch):
