@@ -173,6 +173,51 @@ class HessianAccumulator(rt.HbmArray):
     self._fill += t
     self._n_pending += float(num_samples)
 
+  def add_block(self, xs, ns) -> None:
+    """add(xs[0], ns[0]); add(xs[1], ns[1]); ... with the same products of the same tokens in the same order (a product
+    covers the samples that fit SLAB_TOKENS; the next sample that does not fit closes it), hence the same float32
+    bits -- but a run of samples that fills a product exactly and lies back to back in the caller's memory is
+    multiplied where it lies, and the others reach the slab in one copy per run instead of one per sample."""
+    import torch
+    self.own()
+    self._touched()
+    cap = self.SLAB_TOKENS
+    i, n = 0, len(xs)
+    while i < n:
+      t = int(xs[i].shape[0])
+      if t >= cap:
+        self.add(xs[i], ns[i])
+        i += 1
+        continue
+      if self._fill and self._fill + t > cap:
+        self.flush()
+      j, total = i, self._fill
+      while j < n and int(xs[j].shape[0]) < cap and total + int(xs[j].shape[0]) <= cap:
+        total += int(xs[j].shape[0])
+        j += 1
+      run, count = xs[i:j], float(sum(float(v) for v in ns[i:j]))
+      tokens = total - self._fill
+      if not self._fill and (total == cap or j < n):   # this product is complete: the next sample does not fit in
+        joined = _back_to_back(run, tokens, self.d)
+        if joined is not None:
+          self._prod = ops.gptq_xtx_accum(joined, self._prod)
+          self._n_prod += count
+          i = j
+          continue
+      if self._slab is None or self._slab.shape[0] < cap:
+        grown = torch.empty((cap, self.d), dtype=torch.float32, device=run[0].device)
+        if self._fill:
+          grown[:self._fill].copy_(self._slab[:self._fill])
+        self._slab = grown
+      dst = self._slab[self._fill:total]
+      if len(run) == 1:
+        dst.copy_(run[0])
+      else:
+        torch.cat(run, out=dst)
+      self._fill = total
+      self._n_pending += count
+      i = j
+
   def _join(self, h, n: float) -> None:
     """float64 mean <- weighted mean with Hessian h of n samples (ref utils/qsv_utils.py:71-88)."""
     if self._mean is None:
@@ -262,6 +307,28 @@ class HessianAccumulator(rt.HbmArray):
   def __repr__(self):
     return (f"HessianAccumulator(d={self.d}, samples={self._n_done + self._n_prod + self._n_pending:g},"
             f" pending_tokens={self._fill})")
+
+
+def _back_to_back(run, tokens: int, d: int):
+  """One [tokens, d] view over samples that follow one another in the same allocation, or None."""
+  import torch
+  first = run[0]
+  if not all(x.is_contiguous() for x in run):
+    return None
+  at = first.data_ptr()
+  for x in run:
+    if x.data_ptr() != at:
+      return None
+    at += x.numel() * 4
+  if len(run) == 1:
+    return first
+  store = first.untyped_storage()
+  if any(x.untyped_storage().data_ptr() != store.data_ptr() for x in run):
+    return None
+  try:
+    return torch.as_strided(first, (tokens, d), (d, 1))
+  except RuntimeError:
+    return None
 
 
 def hessian_of(tensor_content: np.ndarray, num_samples):

@@ -479,6 +479,7 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
   qsvs = None
   reserved: list = []          # ops.HinvWorkspace of the large inverses, released when the call is over
   markers: list = []           # events behind the last samples' work (between_samples)
+  asked_for_workspace: list = []
   if qz._recipe_manager.need_calibration():  # pylint: disable=protected-access
     mine_items = [it for it, o in zip(plan, owner) if o == rank]
     # calibration reads activations only: the weights this rank will quantize afterwards cross PCIe underneath it
@@ -499,7 +500,8 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
         markers[-1].record()
         behind = len(markers) > 2 and not markers.pop(0).query()
         rt.pump_prefetch(256 << 20 if behind else 0)      # (uploads into the arena cost this thread nothing: always)
-      if walked == 2 and torch.cuda.is_available():
+      if walked >= 2 and not reserved and torch.cuda.is_available() and not asked_for_workspace:
+        asked_for_workspace.append(True)     # (once: blocks of samples count in steps of K)
         d = gptq.largest_hessian_order(mine_items)
         if d >= 4096:
           reserved.append(ops.HinvWorkspace(d).install())      # (allocated on a helper thread: ops.HinvWorkspace)
@@ -583,11 +585,15 @@ def _ema_and_count_update(qsv, new_qsv):
   return out
 
 
+_ema_and_count_update.block_mode = "count"      # (see utils/qsv_utils.py: Calibrator.replay advances it over whole blocks)
+
+
 def calibrate_sharded(float_model, recipe, calibration_data, previous_calibration_result=None,
                       tensor_provider=None, group=None, hessians: str = "consumed",
                       hessian_owners: Optional[dict[str, int]] = None,
                       after_hessians: Optional[Callable[[dict], None]] = None,
-                      between_samples: Optional[Callable[[int], None]] = None) -> dict:
+                      between_samples: Optional[Callable[[int], None]] = None,
+                      samples_per_launch: Optional[int] = None) -> dict:
   """`Quantizer(float_model, recipe).calibrate(calibration_data)` with every signature's samples
   sharded contiguously over the ranks of `group` (BASELINE config 4: 512 samples over 8 GPUs;
   config 5: GPTQ Hessians).
@@ -611,12 +617,43 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
     return {}
   from . import runtime as rt
   local = calibrator.Calibrator(qz.float_model, tensor_provider=tensor_provider, hessians=hessians)
-  mine = []                                    # (signature index, sample index, events)
+  mine = []                                    # (signature index, sample index, events | StepBlock of K samples from there)
   running: dict[str, list] = {}                # tensor name -> [Hessian mean over my samples, count]
+
+  def hessian_sink(name, xs, ns) -> None:
+    """The samples of one block for one Hessian: straight into this rank's running statistic (what
+    _set_hessians_aside does with the per-sample accumulators of the per-sample walk)."""
+    from .algorithms.uniform_quantize import gptq
+    cur = running.get(name)
+    if cur is None:
+      cur = running[name] = [gptq.HessianAccumulator(int(xs[0].shape[1])), 0]
+    if hasattr(cur[0], "add_block"):
+      cur[0].add_block(xs, ns)
+    else:          # (a float64 array from the per-sample walk of non-float32 samples: its own merge rule)
+      for x, n in zip(xs, ns):
+        cur[0], _ = qsv_utils._gptq_merge_hessian(   # pylint: disable=protected-access
+            {"hessian": cur[0], "num_samples": cur[1]}, {"hessian": gptq.HessianAccumulator.of(x, n), "num_samples": n})
+        cur[1] = cur[1] + n
+      return
+    cur[1] = cur[1] + sum(ns)
+
   with local.plan_once():
     for sig_idx, (signature_key, dataset) in enumerate(calibration_data.items()):
       samples = dataset if hasattr(dataset, "__len__") and hasattr(dataset, "__getitem__") else list(dataset)
       shard = sample_shard(len(samples), rank, world)
+      limit = local.samples_per_launch(signature_key, samples, rm, samples_per_launch)
+      if limit > 1:
+        # K samples per launch (calibrator.StepBlock): their statistics stay arrays until they are replayed
+        walked = 0
+        for k, item in local.record_blocks(signature_key, (samples[j] for j in shard), rm, limit, first=shard.start,
+                                           hessian_sink=hessian_sink, hessian_tag=_HESSIAN_ASIDE):
+          if not isinstance(item, calibrator.StepBlock):
+            item = _set_hessians_aside(item, running)
+          mine.append((sig_idx, k, item))
+          walked += len(item) if isinstance(item, calibrator.StepBlock) else 1
+          if between_samples is not None:
+            between_samples(walked)
+        continue
       steps = local.record_steps(signature_key, (samples[j] for j in shard), rm)
       for k, events in zip(shard, steps):
         mine.append((sig_idx, k, _set_hessians_aside(events, running)))
@@ -636,6 +673,11 @@ def calibrate_sharded(float_model, recipe, calibration_data, previous_calibratio
   # statistics below (25 000 small NumPy updates for an 18-layer model: 0.1 s during which the GPU used to idle).
   totals: dict[str, list] = {}
   for _, _, events in mine:
+    if isinstance(events, calibrator.StepBlock):
+      for t, d in events.hessian_dims.items():
+        entry = totals.setdefault(events.slots[t][0], [d, 0])
+        entry[1] += events.num_samples[:, t].sum()
+      continue
     for name, alg, _, qsv in events:
       if alg == _HESSIAN_ASIDE:
         entry = totals.setdefault(name, [qsv["hessian_dim"], 0])

@@ -285,6 +285,23 @@ def act_minmax(tensors, lo: float | None = -3e38, hi: float | None = 3e38) -> to
   return torch.cat([ActMinMaxBatch(ts[i:i + 65535], lo, hi).run() for i in range(0, len(ts), 65535)])
 
 
+def act_minmax_entries(pointers, lengths, lo: float = -3e38, hi: float = 3e38) -> torch.Tensor:
+  """K7 over (device pointer, float32 element count) pairs whose memory the caller keeps alive until the launch has
+  run -> float32 [count, 2]. The calibrator's K-samples-per-launch path: K x T activations, one table, one launch."""
+  rt.require_gpu()
+  n = len(pointers)
+  out = rt.empty((n, 2), torch.float32)
+  L = _ffi.lib()
+  for i in range(0, n, _TABLE_CAPACITY):
+    m = min(_TABLE_CAPACITY, n - i)
+    both = _table_to_device(pointers[i:i + m], lengths[i:i + m])
+    nbytes = L.mi355q_act_minmax_workspace_bytes(m)
+    ws = rt.empty((nbytes,), torch.uint8)
+    _ffi.check(L.mi355q_act_minmax_f32(rt.ptr(both[0]), rt.ptr(both[1]), m, np.float32(lo), np.float32(hi), 1,
+                                       rt.ptr(out[i:i + m]), rt.ptr(ws), nbytes, rt.stream_ptr()))
+  return out
+
+
 def octav_clip(x: torch.Tensor, units: int, unit_len: int, bits: int, max_iter: int = 10,
                exponent_divisor: float = 3.0, early_stop: bool = True, axis_given: bool = True):
   """K5. Returns (clip float32[units], iterations int). ref: octav.py:30-112.

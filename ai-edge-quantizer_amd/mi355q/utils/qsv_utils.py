@@ -103,3 +103,10 @@ def gptq_and_moving_average_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qt
     return out
   out["hessian"], out["num_samples"] = _gptq_merge_hessian(qsv, new_qsv)
   return out
+
+
+# Rules Calibrator.replay may advance for a whole block of samples at once (calibrator.StepBlock): "ema" = min / max
+# only, "count" = min / max plus the summed num_samples beside an untouched "hessian" entry. Anything without the
+# attribute -- a partial with another smoothing factor, a user's rule, OSCAR's -- is called sample by sample.
+moving_average_update.block_mode = "ema"
+gptq_and_moving_average_update.block_mode = "count"

@@ -156,7 +156,7 @@ class GpuPhases:
   FAMILIES = {"gptq_xtx": "hessian", "gptq_xtx_accum": "hessian", "gptq_xtx_finish": "hessian_finish",
               "gptq_hessian_merge": "hessian_merge", "gptq_hinv": "hinv", "gptq_hinv_batched": "hinv",
               "gptq_hinv_from_product": "hinv",
-              "gptq_apply": "apply", "act_minmax": "act_minmax", "requant_sym": "scales",
+              "gptq_apply": "apply", "act_minmax": "act_minmax", "act_minmax_entries": "act_minmax", "requant_sym": "scales",
               "hadamard_rotate": "hadamard", "octav_clip": "octav", "pack_bits": "pack", "minmax": "scales"}
 
   def __init__(self, torch, ops):
