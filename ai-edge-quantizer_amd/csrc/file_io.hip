@@ -532,7 +532,12 @@ extern "C" int32_t mi355q_file_io_finish(void) {
   }
   std::lock_guard<std::mutex> up(g_mutex[0]);
   std::lock_guard<std::mutex> down(g_mutex[1]);
-  if (!g_pool || g_pool_pid != getpid()) return MI355Q_OK;   // no transfer of this process is open
+  if (!g_pool || g_pool_pid != getpid()) {                   // no ring transfer of this process is open ...
+    // ... but a submitted one may have failed before it reached the pool (hipSetDevice on the driver thread): its status
+    // was taken (and cleared) above and must not be lost here
+    if (submitted_status != MI355Q_OK) return fail(static_cast<mi355q_status>(submitted_status), "%s", submitted_message.c_str());
+    return MI355Q_OK;
+  }
   for (auto& side : g_ring)
     for (Ring& r : side)
       if (r.ready)

@@ -263,16 +263,38 @@ def op_cost(item: tuple, model_qsvs: Optional[dict] = None) -> tuple[float, Opti
   return stream, None, 0.0
 
 
-def plan_op_shards(costs: Sequence[tuple[float, Optional[tuple], float]], world_size: int) -> list[int]:
+def plan_op_shards(costs: Sequence[tuple[float, Optional[tuple], float]], world_size: int,
+                   links: Optional[Sequence[Sequence]] = None) -> list[int]:
   """Owner rank of every op: ops with the same sharing key travel together (their shared part is
   paid once in the whole job), units are placed longest first on the least loaded rank
   (deterministic: ties -> lower op index / lower rank, so every rank derives the same plan
-  without communication)."""
-  units: dict[Any, list] = {}
+  without communication). `links[i]`: further keys op i shares with other ops without a cost of their own --
+  shared_constant_links: ops that read one constant buffer stay on one rank, where the (buffer, config) cache
+  gives both the same result object, as in one process (ref algorithms/utils/common_utils.py:48-77)."""
+  parent = list(range(len(costs)))
+
+  def find(i: int) -> int:
+    while parent[i] != i:
+      parent[i] = parent[parent[i]]
+      i = parent[i]
+    return i
+  first_with: dict[Any, int] = {}
+  for i, (_, key, _) in enumerate(costs):
+    for k in ([] if key is None else [key]) + list(links[i] if links is not None else ()):
+      j = first_with.setdefault(k, i)
+      if j != i:
+        a, b = find(i), find(j)
+        if a != b:
+          parent[max(a, b)] = min(a, b)        # (a unit is named by its first op: the tie-break below)
+  units: dict[int, list] = {}
+  paid: dict[int, set] = {}
   for i, (work, key, shared) in enumerate(costs):
-    u = units.setdefault(("solo", i) if key is None else key, [0.0, 0.0, []])
+    root = find(i)
+    u = units.setdefault(root, [0.0, 0.0, []])
     u[0] += float(work)
-    u[1] = max(u[1], float(shared))
+    if key is not None and key not in paid.setdefault(root, set()):      # each distinct shared part once per unit
+      paid[root].add(key)
+      u[1] += float(shared)
     u[2].append(i)
   order = sorted(units.values(), key=lambda u: (-(u[0] + u[1]), u[2][0]))
   load = [0.0] * world_size
@@ -283,6 +305,27 @@ def plan_op_shards(costs: Sequence[tuple[float, Optional[tuple], float]], world_
     for i in members:
       owner[i] = r
   return owner
+
+
+def shared_constant_links(plan: Sequence[tuple]) -> list[list]:
+  """Per planned op: ("buffer", index) of every constant buffer it reads that another quantized op reads too (tied
+  embedding / lm_head, weight-sharing FULLY_CONNECTED ops, tensors that share a buffer)."""
+  readers: dict[int, list[int]] = {}
+  for i, (graph_info, op, _, op_key, alg, _) in enumerate(plan):
+    if str(getattr(alg, "value", alg)) == "no_quantize" or op_key is None:
+      continue
+    for tid in getattr(op, "inputs", ()):
+      if tid == -1:
+        continue
+      b = graph_info.subgraph_tensors[tid].buffer
+      if b and graph_info.buffers[b].data is not None and (not readers.get(b) or readers[b][-1] != i):
+        readers.setdefault(b, []).append(i)
+  out: list[list] = [[] for _ in plan]
+  for b, ops_ in readers.items():
+    if len(ops_) > 1:
+      for i in ops_:
+        out[i].append(("buffer", b))
+  return out
 
 
 def plan_loads(costs: Sequence[tuple[float, Optional[tuple], float]], owner: Sequence[int],
@@ -307,7 +350,7 @@ def plan_model_shards(float_model, recipe, world_size: int, calibration_result: 
   gen = params_generator.ParamsGenerator(qz.float_model)
   plan = gen.plan_ops(qz._recipe_manager)  # pylint: disable=protected-access
   costs = [op_cost(it, calibration_result) for it in plan]
-  return qz, gen, plan, plan_op_shards(costs, world_size), costs
+  return qz, gen, plan, plan_op_shards(costs, world_size, shared_constant_links(plan)), costs
 
 
 def hessian_owners(plan: Sequence[tuple], owner: Sequence[int], costs) -> dict[str, int]:
@@ -379,44 +422,106 @@ def quantize_model_sharded(float_model, recipe, calibration_result: Optional[dic
   else:
     gathered = _gather_results(mine, group)
   out = None
-  writes = None
+  writes, slots, failure = None, [], None
   try:
     if gathered is not None:
       params = gen.finish(gathered[i] for i in range(len(plan)))
       out = model_modifier.ModelModifier(qz.float_model).modify_model(params, serialize_to_path=serialize_to_path, sink=sink)
-      writes = rt.take_remote_writes() if remote else None
-  finally:
-    if remote:           # (a failure on rank 0 must not leave the others waiting in the broadcast)
-      box = [writes]
-      dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
-      _write_remote_payloads(box[0] or [], rank)
-      dist.barrier(group=group)     # the file is complete when any rank returns
+  except BaseException as e:  # pylint: disable=broad-exception-caught
+    failure = e            # (surfaces below, after the other ranks have been told: none of them may be left waiting)
+  if remote:
+    if gathered is not None:
+      writes, slots = rt.take_remote_writes()
+    box = [(writes if failure is None else []), None if failure is None else f"{type(failure).__name__}: {failure}"]
+    src = 0 if group is None else dist.get_global_rank(group, 0)
+    dist.broadcast_object_list(box, src=src, group=group)
+    problem = _write_remote_payloads(box[0] or [], rank, group, slots)
+    if failure is None and box[1] is not None:
+      failure = RuntimeError(f"the rank that lays the output file out failed: {box[1]}")
+    if failure is None and problem is not None:
+      failure = RuntimeError(problem)
+  if failure is not None:
+    raise failure
   return out
 
 
-def _write_remote_payloads(writes: Sequence[tuple], rank: int) -> None:
-  """This rank's quantized payloads, still in HBM, into the shared output file at the offsets rank 0's layout
-  noted for them (runtime.RemoteBuffer.copy_into): pinned staging + pwrite() on this rank's own io ring."""
+def _write_remote_payloads(writes: Sequence[tuple], rank: int, group=None, host_slots: Sequence = ()) -> Optional[str]:
+  """This rank's quantized payloads, still in HBM, into the shared output file at the offsets the laying-out rank noted
+  for them (runtime.RemoteBuffer.copy_into): pinned staging + pwrite() on this rank's own io ring.
+
+  No rank is left behind: every rank reports how its writes went before anyone returns, and the first problem of any rank
+  comes back on ALL ranks (the caller raises it). A payload whose place this rank cannot reach -- the file cannot be opened
+  here (another node, a file system that is not shared), or the place is plain memory of the laying-out rank (a caller's
+  sink) -- travels to that rank as bytes and is written there: the route every payload took before round 4."""
   from . import runtime as rt
-  fds: dict[str, int] = {}
+  _, world = _world(group)
+  first = 0 if group is None else dist.get_global_rank(group, 0)
+  fds: dict[str, Optional[int]] = {}
+  by_host: dict[tuple, bytes] = {}        # (key, path, offset) -> the payload's bytes, for the laying-out rank to place
+  problem = None
   try:
     for owner, key, path, offset, nbytes in writes:
       if owner != rank:
         continue
-      arr = rt._REMOTE_LOCAL[key]   # pylint: disable=protected-access
+      arr = rt._REMOTE_LOCAL.get(key)   # pylint: disable=protected-access
+      if arr is None:
+        problem = problem or f"rank {rank}: payload {key} is not registered here"
+        continue
       t = arr.device_tensor
       if t.numel() * t.element_size() != nbytes:
-        raise RuntimeError(f"payload {key}: {t.numel() * t.element_size()} bytes here, {nbytes} in the layout")
-      fd = fds.get(path)
+        problem = problem or f"rank {rank}: payload {key} has {t.numel() * t.element_size()} bytes here, {nbytes} in the layout"
+        continue
+      fd = None
+      if path is not None and not os.environ.get("MI355Q_REMOTE_WRITES_BY_HOST"):
+        if path not in fds:
+          try:
+            fds[path] = os.open(path, os.O_RDWR)
+          except OSError:
+            fds[path] = None
+        fd = fds[path]
       if fd is None:
-        fd = fds[path] = os.open(path, os.O_RDWR)
-      rt.write_to_file(t, fd, offset)
-    if fds:
+        by_host[(key, path, offset)] = t.contiguous().reshape(-1).view(torch.uint8).cpu().numpy().tobytes()
+      else:
+        rt.write_to_file(t, fd, offset)
+    if any(fd is not None for fd in fds.values()):
       rt.finish_downloads()
+  except Exception as e:  # pylint: disable=broad-exception-caught
+    problem = problem or f"rank {rank}: {type(e).__name__}: {e}"
   finally:
     for fd in fds.values():
-      os.close(fd)
+      if fd is not None:
+        os.close(fd)
     rt._REMOTE_LOCAL.clear()   # pylint: disable=protected-access
+  # everybody's outcome, and the payloads that go through the laying-out rank's host
+  reports = [None] * world
+  dist.all_gather_object(reports, (problem, bool(by_host)), group=group)
+  if any(r[1] for r in reports):
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(by_host, parts, dst=first, group=group)
+    if parts is not None:
+      try:
+        opened: dict[str, int] = {}
+        try:
+          for part in parts:
+            for (key, path, offset), data in part.items():
+              if path is None:
+                host_slots[offset][:] = np.frombuffer(data, np.uint8)
+              else:
+                if path not in opened:
+                  opened[path] = os.open(path, os.O_RDWR)
+                done = 0
+                while done < len(data):
+                  done += os.pwrite(opened[path], data[done:], offset + done)
+        finally:
+          for fd in opened.values():
+            os.close(fd)
+      except Exception as e:  # pylint: disable=broad-exception-caught
+        problem = f"rank {rank} (placing payloads sent as bytes): {type(e).__name__}: {e}"
+    late = [problem if parts is not None else None]
+    dist.broadcast_object_list(late, src=first, group=group)
+    if late[0] is not None:
+      return late[0]
+  return next((r[0] for r in reports if r[0] is not None), None)
 
 
 def _require_hessians_where_read(items: Sequence[tuple], qsvs: dict, rank: int) -> None:

@@ -467,8 +467,11 @@ def output_file_range_of(dst: np.ndarray):
 # its io ring (distributed._write_remote_payloads).
 _REMOTE_RANK: list = [None]
 _REMOTE_LOCAL: dict = {}      # key -> HbmArray, on the rank that owns it
-_REMOTE_WRITES: list = []     # rank 0: (rank, key, path, offset, nbytes) noted by RemoteBuffer.copy_into
+_REMOTE_WRITES: list = []     # rank 0: (rank, key, path, offset, nbytes) noted by RemoteBuffer.copy_into; path None: offset
+                              # is an index into _REMOTE_HOST_SLOTS (a destination that is not inside a registered output file)
+_REMOTE_HOST_SLOTS: list = [] # rank 0: writable uint8 views such payloads are copied into once their bytes have arrived
 _REMOTE_SEQ = [0]
+_REMOTE_KEYS: dict = {}       # id(HbmArray) -> key, while remote_payloads() is open: one array pickled twice is ONE payload
 
 
 class remote_payloads:   # pylint: disable=invalid-name
@@ -479,17 +482,21 @@ class remote_payloads:   # pylint: disable=invalid-name
 
   def __enter__(self):
     _REMOTE_LOCAL.clear()
+    _REMOTE_KEYS.clear()
     _REMOTE_RANK[0] = self.rank
     return self
 
   def __exit__(self, *exc):
     _REMOTE_RANK[0] = None
+    _REMOTE_KEYS.clear()
 
 
-def take_remote_writes() -> list:
-  out = list(_REMOTE_WRITES)
+def take_remote_writes() -> tuple[list, list]:
+  """(the writes noted on this rank, the host destinations the path-less ones refer to by index)."""
+  out, slots = list(_REMOTE_WRITES), list(_REMOTE_HOST_SLOTS)
   _REMOTE_WRITES.clear()
-  return out
+  _REMOTE_HOST_SLOTS.clear()
+  return out, slots
 
 
 class RemoteBuffer:
@@ -513,11 +520,31 @@ class RemoteBuffer:
     return RemoteBuffer(self.rank, self.key + "/packed", (self._packed_nbytes,), "uint8", self._packed_nbytes, 0)
 
   def copy_into(self, dst: np.ndarray) -> None:
+    if dst.nbytes != self._nbytes:
+      raise RuntimeError(f"the quantized payload {self.key} of rank {self.rank} has {self._nbytes} bytes, its place {dst.nbytes}")
     where = output_file_range_of(dst)
-    if where is None or dst.nbytes != self._nbytes:
-      raise RuntimeError(f"the quantized payload {self.key} lives in the HBM of rank {self.rank}: it can only be written into"
-                         " a file that is being built through a registered output mapping")
+    if where is None:
+      # not a file this process laid out through a registered mapping (a caller's sink that hands out plain memory):
+      # the owner sends the bytes and they are copied in before the call returns (distributed._write_remote_payloads)
+      _REMOTE_HOST_SLOTS.append(dst)
+      _REMOTE_WRITES.append((self.rank, self.key, None, len(_REMOTE_HOST_SLOTS) - 1, self._nbytes))
+      return
     _REMOTE_WRITES.append((self.rank, self.key, where[0], int(where[1]), self._nbytes))
+
+  def same_payload(self, other) -> bool:
+    """Equality as qtyping's value comparisons need it (params_generator's sharing checks, ref params_generator.py:516-560),
+    without the bytes: the SAME payload of the same rank. Ops that read one constant buffer are planned onto one rank
+    (distributed.plan_op_shards), where the (buffer, config) cache hands both the same array -- pickled once, one key --
+    so two records that name different payloads are different results; they are reported unequal (the conservative
+    answer: the writer then keeps both)."""
+    return isinstance(other, RemoteBuffer) and (self.rank, self.key) == (other.rank, other.key)
+
+  def __eq__(self, other):
+    if isinstance(other, RemoteBuffer):
+      return self.same_payload(other)
+    return NotImplemented
+
+  __hash__ = object.__hash__
 
   def __array__(self, dtype=None, copy=None):
     raise RuntimeError(f"the quantized payload {self.key} lives in the HBM of rank {self.rank} (sharded run writing a file)")
@@ -731,8 +758,10 @@ class HbmArray:
     # From 256 KiB on: one such payload alone puts the model over the serializer's inline limit (model_modifier), so a
     # RemoteBuffer always meets the external-buffer layout, which copies payloads with copy_into().
     if _REMOTE_RANK[0] is not None and self.nbytes >= (1 << 18) and self.dtype in (np.int8, np.uint8):
-      _REMOTE_SEQ[0] += 1
-      key = f"r{_REMOTE_RANK[0]}/{_REMOTE_SEQ[0]}"
+      key = _REMOTE_KEYS.get(id(self))
+      if key is None:             # (an array two results share -- a weight two ops read -- is one payload under one key)
+        _REMOTE_SEQ[0] += 1
+        key = _REMOTE_KEYS[id(self)] = f"r{_REMOTE_RANK[0]}/{_REMOTE_SEQ[0]}"
       _REMOTE_LOCAL[key] = self
       packed_nbytes = 0
       if isinstance(self.packed, HbmArray):

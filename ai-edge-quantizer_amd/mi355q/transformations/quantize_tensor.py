@@ -92,8 +92,10 @@ def quantize_tensor(ti: transformation_utils.TransformationInput) -> qtyping.Tra
                         " data in buffer %s.", tensor.name, buffer_id)
       ti.buffer_origin[buffer_id] = p
       ready = getattr(p.quantized_data, "packed", None)    # packed by the quantizing launch
-      if ready is None and p.num_bits == 8 and hasattr(p.quantized_data, "copy_into"):
-        ready = p.quantized_data                           # int8 in HBM: its bytes are the buffer
+      if ready is None and p.num_bits not in (2, 4) and hasattr(p.quantized_data, "copy_into") \
+          and p.quantized_data.dtype in (np.int8, np.uint8):
+        ready = p.quantized_data                           # one byte per value in HBM: its bytes are the buffer (pack_data
+                                                           # returns every width but 2 and 4 unchanged, ref :293-353)
       ti.model.buffers[buffer_id].data = ready if ready is not None else transformation_utils.pack_data(
           p.num_bits, np.ravel(np.asarray(p.quantized_data)).view(np.uint8))
   if isinstance(p, qtyping.UniformQuantParams):

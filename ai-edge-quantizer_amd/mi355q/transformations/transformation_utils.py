@@ -106,9 +106,20 @@ def verify_late_constants(model: Any) -> None:
     added = list(entries)      # (also the device-resident buffers the model already had when the table was built)
     if len(added) < 2:
       continue
-    flat = torch.stack([d.device_tensor.contiguous().reshape(-1).view(torch.uint8) for d, _ in added]).to(torch.int64)
-    weights = (torch.arange(nbytes, device=flat.device, dtype=torch.int64) % 65521) + 1
-    marks = torch.stack([flat.sum(dim=1), (flat * weights).sum(dim=1)], dim=1).cpu().numpy()
+    # two checksums per constant, a piece at a time: the int64 widening of a whole size class (16 x its bytes: GiBs for the
+    # blockwise scales of a 32-layer model) never exists, and the class's marks come back in one copy
+    first = added[0][0].device_tensor
+    marks = torch.zeros((len(added), 2), dtype=torch.int64, device=first.device)
+    piece = 4 << 20
+    weights = (torch.arange(min(piece, nbytes), device=first.device, dtype=torch.int64) % 65521) + 1
+    for r, (d, _) in enumerate(added):
+      flat = d.device_tensor.contiguous().reshape(-1).view(torch.uint8)
+      for o in range(0, nbytes, piece):
+        part = flat[o:o + piece]
+        marks[r, 0] += part.sum(dtype=torch.int64)
+        # (the weight of a byte depends on its place within its piece and on the piece's index: same bytes, same marks)
+        marks[r, 1] += (part.to(torch.int64) * weights[:part.numel()]).sum() * (o // piece % 65521 + 1)
+    marks = marks.cpu().numpy()
     seen: dict = {}
     for row, (d, i) in zip(map(tuple, marks), added):
       for other, j in seen.get(row, ()):

@@ -174,9 +174,9 @@ def test_full_chain_d2048_against_the_oracles_own_chain(c5):
     zp = np.zeros((len(sel), 1), np.int8)
     ref = O.gptq_apply(w[sel], ref_scale[sel], zp, 4, True, None, "CHANNELWISE", hinv=hinv)
     ref_b = O.gptq_apply(w[sel], ref_scale[sel], zp, 4, True, None, "CHANNELWISE", hinv=hinv_b)
-    # (recorded: 0 with a floor of 0 at this size; the cap leaves room for one flipped integer in 5000)
-    parity_rates.check_with_floor(f"C5 model l0/{name} [{rows},2048] int4, 64 rows vs oracle FULL CHAIN (einsum)",
-                                  q[sel], ref, ref_b, cap=2e-4, k=4.0)
+    # (recorded: 0 with a floor of 0 at this size; the default path's own bound)
+    parity_rates.check_default_path(f"C5 model l0/{name} [{rows},2048] int4, 64 rows vs oracle FULL CHAIN (einsum)",
+                                    q[sel], ref, ref_b)
 
 
 def test_full_chain_d16384_against_the_oracles_own_chain(c5):
@@ -210,11 +210,10 @@ def test_full_chain_d16384_against_the_oracles_own_chain(c5):
   zp = np.zeros((len(sel), 1), np.int8)
   ref = O.gptq_apply(w[sel], ref_scale[sel], zp, 4, True, None, "CHANNELWISE", hinv=hinv)
   ref_b = O.gptq_apply(w[sel], ref_scale[sel], zp, 4, True, None, "CHANNELWISE", hinv=hinv_b)
-  # the model's Hessians come from the default product (the exact three-way bfloat16 split): recorded 0 of 1 048 576.
-  # The bound stays floor-based (another instance may meet a borderline integer), capped at 2 x the 1.22e-3 the two-way
-  # float16 split was recorded at (profiles/r03_parity_rates.txt).
-  parity_rates.check_with_floor("C5 model l1/down [2048,16384] int4, 64 rows vs oracle FULL CHAIN (sgemm product; Hessian by bf16x3)",
-                                q[sel], ref, ref_b, cap=2.5e-3, k=4.0)
+  # the model's Hessians come from the default product (the exact three-way bfloat16 split): recorded 0 of 1 048 576, held
+  # to the default path's own bound (5e-5), not to the re-ordering floor (1.5e-3 here)
+  parity_rates.check_default_path("C5 model l1/down [2048,16384] int4, 64 rows vs oracle FULL CHAIN (sgemm product; Hessian by bf16x3)",
+                                  q[sel], ref, ref_b)
   # the same rows through the GPU's own chain with the Hessian from the two-way float16 split (MI355Q_XTX_F16X2=1, the
   # opt-in fast product): a precision change in the Hessian product (a10) shows here as a change of the RATE
   import os
@@ -235,3 +234,8 @@ def test_full_chain_d16384_against_the_oracles_own_chain(c5):
   q3 = ops.gptq_apply(wd, hinv3, sd, None, 1, 0, 4, False, False, 8).cpu().numpy()
   parity_rates.check_with_floor("C5 model l1/down [2048,16384] int4, 64 rows vs oracle FULL CHAIN (sgemm product; Hessian by f16x2, opt-in)",
                                 q3, ref, ref_b, cap=2.5e-3, k=4.0)
+  # NEGATIVE CONTROL: the same f16x2 result fed to the DEFAULT path's gate must not pass -- if the default Hessian
+  # kernel ever regressed to this precision (as it silently did in round 3), the assert above the f16x2 leg would see it
+  with pytest.raises(AssertionError, match="default-path bound"):
+    parity_rates.check_default_path("NEGATIVE CONTROL (must fail): f16x2 Hessian through the default-path gate, C5 model l1/down",
+                                    q3, ref, ref_b, negative_control=True)

@@ -49,6 +49,95 @@ def _big_fc_model(path):
   open(path, "wb").write(fb.write_model(model))
 
 
+def _shared_weight_model(path):
+  """x -> FC(w) -> y0 -> FC(w) -> y1 -> FC(w2) -> y2: the first two ops read ONE weight tensor (tied weights) and w2 is
+  another tensor over the SAME buffer; 1 MiB of int8 each, so the payloads stay in their rank's HBM when a file is written."""
+  import numpy as np
+  from mi355q import qtyping as q
+  from mi355q.utils import tflite_flatbuffer as fb
+  w = np.random.default_rng(11).standard_normal((1024, 1024)).astype(np.float32)
+  model = q.ModelT(version=3, buffers=[q.BufferT(), q.BufferT(data=w.reshape(-1).view(np.uint8))],
+                   operatorCodes=[q.OperatorCodeT(builtinCode=9, deprecatedBuiltinCode=9)])
+  t = [q.TensorT(name=b"x", shape=[1, 1024], buffer=0), q.TensorT(name=b"w", shape=[1024, 1024], buffer=1),
+       q.TensorT(name=b"y0", shape=[1, 1024], buffer=0), q.TensorT(name=b"y1", shape=[1, 1024], buffer=0),
+       q.TensorT(name=b"w2", shape=[1024, 1024], buffer=1), q.TensorT(name=b"y2", shape=[1, 1024], buffer=0)]
+  fc = lambda i, w_, o: q.OperatorT(inputs=[i, w_, -1], outputs=[o], builtinOptionsType=8, builtinOptions=q.FullyConnectedOptionsT())
+  model.subgraphs = [q.SubGraphT(name=b"main", inputs=[0], outputs=[5], tensors=t, operators=[fc(0, 1, 2), fc(2, 1, 3), fc(3, 4, 5)])]
+  open(path, "wb").write(fb.write_model(model))
+
+
+def _worker_shared_weights(rank, world, port, out):
+  """A weight two ops read, written to a FILE by a sharded run: the ops land on one rank (distributed.shared_constant_links),
+  their results name one payload, and the sharing checks compare records instead of bytes -- through the ranks' own writes
+  and through the by-host route (MI355Q_REMOTE_WRITES_BY_HOST: what a rank does when it cannot open the output file)."""
+  dist = _setup(rank, world, port)
+  from mi355q import distributed as D, quantizer
+  path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mi355q_shared_w_{port}.tflite")
+  if rank == 0:
+    _shared_weight_model(path)
+  dist.barrier()
+  got = []
+  for key, bits, gran in (("min_max_uniform_quantize", 8, "CHANNELWISE"), ("min_max_uniform_quantize", 4, "BLOCKWISE_128")):
+    rcp = _recipe(key, bits, gran)
+    _, _, plan, owner, _ = D.plan_model_shards(path, rcp, world)
+    one_rank = len({o for it, o in zip(plan, owner) if str(getattr(it[4], "value", it[4])) != "no_quantize"}) == 1
+    single = bytes(quantizer.Quantizer(path, rcp).quantize().quantized_model) if rank == 0 else None
+    for by_host in (False, True):
+      if by_host:
+        os.environ["MI355Q_REMOTE_WRITES_BY_HOST"] = "1"
+      try:
+        dst = path + f".{bits}.{int(by_host)}.q"
+        D.quantize_model_sharded(path, rcp, serialize_to_path=dst)
+      finally:
+        os.environ.pop("MI355Q_REMOTE_WRITES_BY_HOST", None)
+      dist.barrier()
+      if rank == 0:
+        with open(dst, "rb") as fh:
+          got.append((fh.read() == single, one_rank))
+        os.remove(dst)
+  dist.barrier()
+  if rank == 0:
+    os.remove(path)
+  out.put((rank, got))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_ranks_write_a_model_whose_ops_share_a_weight():
+  results = dict(_run(_worker_shared_weights, timeout=600))
+  assert len(results[0]) == 4
+  for same_file, one_rank in results[0]:
+    assert same_file and one_rank
+
+
+def _worker_layout_failure(rank, world, port, out):
+  """The rank that lays the file out fails (an unwritable directory): every rank raises, none waits for the others."""
+  dist = _setup(rank, world, port)
+  from mi355q import distributed as D
+  big = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mi355q_big_fc_fail_{port}.tflite")
+  if rank == 0:
+    _big_fc_model(big)
+  dist.barrier()
+  try:
+    D.quantize_model_sharded(big, _recipe("min_max_uniform_quantize", 8, "CHANNELWISE"),
+                             serialize_to_path="/nonexistent-directory/out.tflite")
+    raised = None
+  except Exception as e:  # pylint: disable=broad-exception-caught
+    raised = type(e).__name__ + ": " + str(e)[:80]
+  dist.barrier()
+  if rank == 0:
+    os.remove(big)
+  out.put((rank, raised))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_a_failure_of_the_writing_rank_reaches_every_rank():
+  results = dict(_run(_worker_layout_failure, timeout=300))
+  assert results[0] is not None and results[1] is not None, results
+  assert "lays the output file out failed" in results[1], results
+
+
 def _worker(rank, world, port, out):
   dist = _setup(rank, world, port)
   from mi355q import distributed as D, quantizer

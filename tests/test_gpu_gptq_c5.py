@@ -198,9 +198,14 @@ def test_apply_down_proj_2048x16384_int8_rows_against_oracle(m, big, kernel):
   wr, sr = w[idx].cpu().numpy(), scale[idx].cpu().numpy()
   ref = _oracle_rows(wr, sr, hinv_host, 8)
   ref_b = _oracle_rows_split_matmul(wr, sr, hinv_host, 8)
-  # cap: 2 x the 1.66e-3 recorded in profiles/r03_parity_rates.txt
-  parity_rates.check_with_floor(f"gptq apply [2048,16384] int8 channelwise, 16 rows vs oracle (same Hinv; Hessian by {kernel})",
-                                q[idx].cpu().numpy(), ref, ref_b, cap=3.4e-3, k=2.0)
+  name = f"gptq apply [2048,16384] int8 channelwise, 16 rows vs oracle (same Hinv; Hessian by {kernel})"
+  if kernel == "bf16x3":      # the default product: its own bound (recorded 0), the floor only recorded beside it
+    parity_rates.check_default_path(name, q[idx].cpu().numpy(), ref, ref_b)
+  else:                       # the opt-in fast product: floor-based, cap = 2 x the 1.66e-3 of profiles/r03_parity_rates.txt
+    parity_rates.check_with_floor(name, q[idx].cpu().numpy(), ref, ref_b, cap=3.4e-3, k=2.0)
+    with pytest.raises(AssertionError, match="default-path bound"):       # NEGATIVE CONTROL: the default gate sees this precision
+      parity_rates.check_default_path("NEGATIVE CONTROL (must fail): f16x2 Hessian through the default-path gate, apply [2048,16384] int8",
+                                      q[idx].cpu().numpy(), ref, ref_b, negative_control=True)
 
 
 def test_apply_down_proj_2048x16384_rows_against_oracle(m, big):
@@ -255,9 +260,11 @@ def test_apply_gate_proj_16384x2048_rows_against_oracle(m, kernel):
       # block summed in two halves (what a BLAS with another K blocking does with gptq.py:213-214's
       # matmul): the rate at which THAT flips integers is the floor for any implementation
       ref_b = _oracle_rows_split_matmul(w[idx].cpu().numpy(), scale[idx].cpu().numpy(), hinv_host, bits)
-      # cap: 2 x the 2.4e-4 recorded in profiles/r03_parity_rates.txt
-      parity_rates.check_with_floor(f"gptq apply [16384,2048] int{bits} {gran}, 128 rows vs oracle (same Hinv; Hessian by {kernel})",
-                                    q[idx].cpu().numpy(), ref, ref_b, cap=5e-4, k=2.0)
+      name = f"gptq apply [16384,2048] int{bits} {gran}, 128 rows vs oracle (same Hinv; Hessian by {kernel})"
+      if kernel == "bf16x3":    # the default product: its own bound (recorded 0)
+        parity_rates.check_default_path(name, q[idx].cpu().numpy(), ref, ref_b)
+      else:                     # opt-in fast product; cap: 2 x the 2.4e-4 recorded in profiles/r03_parity_rates.txt
+        parity_rates.check_with_floor(name, q[idx].cpu().numpy(), ref, ref_b, cap=5e-4, k=2.0)
     else:
       parity_rates.check(f"gptq apply [16384,2048] int{bits} {gran}, 128 rows vs oracle (same Hinv; Hessian by {kernel})",
                          q[idx].cpu().numpy(), ref, parity_rates.T2)
@@ -307,8 +314,7 @@ def test_down_proj_through_get_tensor_quant_params(m, big):
 def test_full_chain_with_llm_like_activations_d4096(m):
   """Activations shaped like a decoder's, not like white noise: per-token scales spread over a decade
   (log-normal), eight massive channels 60 x the rest, a third of the entries gated to (almost) zero, a non-zero
-  mean per channel -- at d = 4096, where the Hessian runs on the two-way float16 split with 128 x 256 tiles
-  (xtx_f16x2.hip: a per-column power of two, 22 of 24 bits kept). The whole chain -- Hessian, damped inverse,
+  mean per channel -- at d = 4096, on the default Hessian product (the exact three-way bfloat16 split, 128 x 256 tiles). The whole chain -- Hessian, damped inverse,
   OBS apply through get_tensor_quant_params -- against the oracle's own chain (float32 x.T.dot(x), FP64
   Cholesky, single-precision triangular inverse and product: ref gptq.py:100-216), with the oracle's own
   reproducibility (its Hessian summed in two halves) measured beside it."""
@@ -347,5 +353,5 @@ def test_full_chain_with_llm_like_activations_d4096(m):
   floor = float((ref != ref_b).mean())
   parity_rates.note("reference noise floor: oracle FULL CHAIN [48,4096] int4, LLM-like activations, Hessian summed in another order",
                     "int_mismatch_fraction", floor, 1.0)
-  parity_rates.check("LLM-like activations: get_tensor_quant_params [48,4096] int4 vs oracle FULL CHAIN (sgemm product)",
-                     np.asarray(p.quantized_data), ref, max(parity_rates.T2, 4 * floor))
+  parity_rates.check_default_path("LLM-like activations: get_tensor_quant_params [48,4096] int4 vs oracle FULL CHAIN (sgemm product)",
+                                  np.asarray(p.quantized_data), ref, ref_b)

@@ -572,10 +572,13 @@ def test_remote_payload_records_instead_of_bytes(tmp_path):
   try:
     rt.take_remote_writes()
     got.packed.copy_into(np.frombuffer(mapping, dtype=np.uint8, count=1 << 18, offset=4096))
-    (rank, key, where, offset, nbytes), = rt.take_remote_writes()
+    ((rank, key, where, offset, nbytes),), _ = rt.take_remote_writes()
     assert (rank, key, offset, nbytes) == (3, got.packed.key, 4096, 1 << 18) and os.path.samefile(where, path)
-    with pytest.raises(RuntimeError, match="registered output mapping"):
-      got.packed.copy_into(np.zeros(1 << 18, np.uint8))
+    # a place that is not inside a registered output file: noted as a host slot, filled when the owner's bytes arrive
+    plain = np.zeros(1 << 18, np.uint8)
+    got.packed.copy_into(plain)
+    ((rank, key, where, slot, nbytes),), slots = rt.take_remote_writes()
+    assert (rank, key, where, slot, nbytes) == (3, got.packed.key, None, 0, 1 << 18) and slots[0] is plain
     with pytest.raises(RuntimeError):                          # a size that is not the payload's
       got.packed.copy_into(np.frombuffer(mapping, dtype=np.uint8, count=100, offset=0))
   finally:
@@ -583,6 +586,44 @@ def test_remote_payload_records_instead_of_bytes(tmp_path):
     rt._REMOTE_LOCAL.clear()
     mapping.close()
     os.close(fd)
+
+
+def test_one_array_pickled_twice_is_one_remote_payload_and_compares_equal():
+  """A constant two quantized ops read (tied embedding / lm_head): both results hold the SAME array (the (buffer, config)
+  cache, ref common_utils.py:48-77), so both records name one payload and qtyping's value comparison
+  (params_generator's sharing checks, ref params_generator.py:516-560) answers without the bytes; records of different
+  payloads are unequal, never an exception."""
+  import pickle
+  import torch
+  from mi355q import runtime as rt
+  shared = rt.HbmArray(torch.zeros((1024, 512), dtype=torch.int8))
+  other = rt.HbmArray(torch.zeros((1024, 512), dtype=torch.int8))
+
+  def params(data):
+    return q.UniformQuantParams(num_bits=8, quantized_dimension=0, scale=np.ones((1024, 1), np.float32),
+                                zero_point=np.zeros((1024, 1), np.int8), symmetric=True, quantized_data=data)
+  with rt.remote_payloads(1):
+    a, b, c = pickle.loads(pickle.dumps([params(shared), params(shared), params(other)]))
+    again = pickle.loads(pickle.dumps(params(shared)))           # a second pickle of the same gather
+  rt._REMOTE_LOCAL.clear()
+  assert isinstance(a.quantized_data, rt.RemoteBuffer) and a.quantized_data.key == b.quantized_data.key == again.quantized_data.key
+  assert a == b and a == again and not (a == c) and a != c
+  host = params(np.zeros((1024, 512), np.int8))
+  assert not (a == host) and not (host == a)                     # bytes here, a record there: not the same payload
+
+
+def test_ops_that_read_one_constant_are_planned_onto_one_rank():
+  from mi355q import distributed as D
+  costs = [(1.0, ("hessian", "a"), 5.0), (2.0, ("hessian", "a"), 5.0), (3.0, None, 0.0), (0.5, ("hessian", "b"), 1.0),
+           (0.1, None, 0.0)]
+  assert D.plan_op_shards(costs, 2) == [0, 0, 1, 1, 1]
+  linked = D.plan_op_shards(costs, 2, [[], [("buffer", 3)], [("buffer", 3)], [], []])
+  assert linked[0] == linked[1] == linked[2] and linked[3] != linked[0]
+  for world in (3, 8):
+    own = D.plan_op_shards(costs, world, [[("buffer", 9)], [], [], [("buffer", 9)], []])
+    assert own[0] == own[1] == own[3]                            # chained: Hessian a joins ops 0 and 1, buffer 9 ops 0 and 3
+    loads = D.plan_loads(costs, own, world)
+    assert abs(sum(loads) - (sum(c[0] for c in costs) + 5.0 + 1.0)) < 1e-9     # each shared part is paid once
 
 
 def test_late_vectors_are_laid_out_from_their_size_and_filled_last(tmp_path):
