@@ -35,8 +35,11 @@ template <int BITS> constexpr bool kGroupsFast = BITS < 8;
 template <int BITS> constexpr int kGroupsU = BITS == 8 ? 2 : 1;
 template <int BITS> constexpr int kGroupsCL = 2;
 
-template <int BITS, bool BATCHED>
-int32_t launch_bits(const RequantArgs& a, int count, bool aligned16, hipStream_t st) {
+inline bool wants_packed(const RequantArgs& a) { return a.packed != nullptr; }
+inline bool wants_packed(const RequantInlineArgs& a) { return a.packed.p[0] != nullptr; }
+
+template <int BITS, bool BATCHED, typename ARGS>
+int32_t launch_bits(const ARGS& a, int count, bool aligned16, hipStream_t st) {
   const int64_t rows = a.rows, cols = a.cols;
   const dim3 blk(256);
   const unsigned gy = static_cast<unsigned>(count);
@@ -48,22 +51,22 @@ int32_t launch_bits(const RequantArgs& a, int count, bool aligned16, hipStream_t
       constexpr int U = kGroupsU<BITS>, CL = kGroupsCL<BITS>;
       const dim3 grid(static_cast<unsigned>((n4 + 256 * U * CL - 1) / (256 * U * CL)), gy);
       switch (g4) {
-        case 8: hipLaunchKernelGGL((requant_groups_kernel<BITS, 8, U, CL, kGroupsFast<BITS>, BATCHED>), grid, blk, 0, st, a); break;
-        case 16: hipLaunchKernelGGL((requant_groups_kernel<BITS, 16, U, CL, kGroupsFast<BITS>, BATCHED>), grid, blk, 0, st, a); break;
-        case 32: hipLaunchKernelGGL((requant_groups_kernel<BITS, 32, U, CL, kGroupsFast<BITS>, BATCHED>), grid, blk, 0, st, a); break;
-        default: hipLaunchKernelGGL((requant_groups_kernel<BITS, 64, U, CL, kGroupsFast<BITS>, BATCHED>), grid, blk, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((requant_groups_kernel<BITS, 8, U, CL, kGroupsFast<BITS>, BATCHED, false, ARGS>), grid, blk, 0, st, a); break;
+        case 16: hipLaunchKernelGGL((requant_groups_kernel<BITS, 16, U, CL, kGroupsFast<BITS>, BATCHED, false, ARGS>), grid, blk, 0, st, a); break;
+        case 32: hipLaunchKernelGGL((requant_groups_kernel<BITS, 32, U, CL, kGroupsFast<BITS>, BATCHED, false, ARGS>), grid, blk, 0, st, a); break;
+        default: hipLaunchKernelGGL((requant_groups_kernel<BITS, 64, U, CL, kGroupsFast<BITS>, BATCHED, false, ARGS>), grid, blk, 0, st, a); break;
       }
     } else {
-      if (a.packed != nullptr && BITS != 8)
+      if (wants_packed(a) && BITS != 8)
         return fail(MI355Q_UNSUPPORTED, "packed output needs 16-byte aligned buffers and a block size in {32,64,128,256}");
       const dim3 grid(static_cast<unsigned>(rows * (cols / a.block)), gy);
-      hipLaunchKernelGGL((requant_generic_kernel<BITS, true, BATCHED>), grid, blk, 0, st, a);
+      hipLaunchKernelGGL((requant_generic_kernel<BITS, true, BATCHED, ARGS>), grid, blk, 0, st, a);
     }
   } else {
     const int64_t cols4 = cols / 4;
     if (vec_ok && cols4 <= 256 * 16) {
 #define MI355Q_ROWS(TPR, R)                                                            \
-  hipLaunchKernelGGL((requant_rows_kernel<BITS, TPR, R, false, BATCHED, kRowsNT>),                      \
+  hipLaunchKernelGGL((requant_rows_kernel<BITS, TPR, R, false, BATCHED, kRowsNT, ARGS>),                      \
                      dim3(static_cast<unsigned>((rows + (256 / TPR) - 1) / (256 / TPR)), gy), \
                      blk, 0, st, a)
       if (cols4 <= 64) MI355Q_ROWS(64, 1);
@@ -75,22 +78,22 @@ int32_t launch_bits(const RequantArgs& a, int count, bool aligned16, hipStream_t
       else MI355Q_ROWS(256, 16);
 #undef MI355Q_ROWS
     } else {
-      if (a.packed != nullptr && BITS != 8)
+      if (wants_packed(a) && BITS != 8)
         return fail(MI355Q_UNSUPPORTED, "packed output needs cols %% 4 == 0, 16-byte aligned buffers and cols <= 16384");
       const dim3 grid(static_cast<unsigned>(rows), gy);
-      hipLaunchKernelGGL((requant_generic_kernel<BITS, false, BATCHED>), grid, blk, 0, st, a);
+      hipLaunchKernelGGL((requant_generic_kernel<BITS, false, BATCHED, ARGS>), grid, blk, 0, st, a);
     }
   }
   MI355Q_CHECK_LAUNCH("requant_sym launch");
   return MI355Q_OK;
 }
 
-template <bool BATCHED>
-int32_t launch(const RequantArgs& a, int bits, int count, bool aligned16, hipStream_t st) {
+template <bool BATCHED, typename ARGS>
+int32_t launch(const ARGS& a, int bits, int count, bool aligned16, hipStream_t st) {
   switch (bits) {
-    case 8: return launch_bits<8, BATCHED>(a, count, aligned16, st);
-    case 4: return launch_bits<4, BATCHED>(a, count, aligned16, st);
-    case 2: return launch_bits<2, BATCHED>(a, count, aligned16, st);
+    case 8: return launch_bits<8, BATCHED, ARGS>(a, count, aligned16, st);
+    case 4: return launch_bits<4, BATCHED, ARGS>(a, count, aligned16, st);
+    case 2: return launch_bits<2, BATCHED, ARGS>(a, count, aligned16, st);
     default: return fail(MI355Q_UNSUPPORTED, "bits must be 8, 4 or 2 (got %d)", bits);
   }
 }
@@ -148,4 +151,38 @@ extern "C" int32_t mi355q_requant_sym_f32_batched(
   // The pointed-to buffers are required to be 16-byte aligned in the batched form
   // (hipMalloc / torch allocations are 256-byte aligned).
   return launch<true>(a, bits, count, true, as_stream(stream));
+}
+
+extern "C" int32_t mi355q_requant_sym_f32_batched_hostptrs(
+    const float* const* x_ptrs_host, int32_t count, int64_t rows, int64_t cols, int32_t block,
+    int32_t bits, int8_t* const* q_ptrs_host, uint8_t* const* packed_ptrs_host,
+    float* const* scale_ptrs_host, uint16_t* const* scale_f16_ptrs_host, void* stream) {
+  clear_error();
+  if (count < 0) return fail(MI355Q_BAD_ARG, "negative count");
+  if (int32_t st = check_shape(rows, cols, block, bits, packed_ptrs_host != nullptr)) return st;
+  if (count == 0 || rows == 0 || cols == 0) return MI355Q_OK;
+  if (x_ptrs_host == nullptr || scale_ptrs_host == nullptr)
+    return fail(MI355Q_BAD_ARG, "x_ptrs_host and scale_ptrs_host must not be null");
+  for (int32_t i = 0; i < count; ++i) {
+    if (!x_ptrs_host[i] || !scale_ptrs_host[i]) return fail(MI355Q_BAD_ARG, "null buffer pointer in a table (entry %d)", i);
+    // (inputs are read as float4; int8 values leave as dwords, packed sub-byte values as dwords: 4-byte aligned outputs,
+    // which equally shaped slices of one allocation are whenever cols % 4 == 0 -- the vector kernels' own condition)
+    if (!al16(x_ptrs_host[i]))
+      return fail(MI355Q_BAD_ARG, "the batched forms take 16-byte aligned inputs (entry %d)", i);
+  }
+  for (int32_t first = 0; first < count; first += kInlineTensors) {
+    const int n = count - first < kInlineTensors ? count - first : kInlineTensors;
+    RequantInlineArgs a{};
+    for (int i = 0; i < n; ++i) {
+      a.x.p[i] = x_ptrs_host[first + i];
+      a.q.p[i] = q_ptrs_host ? q_ptrs_host[first + i] : nullptr;
+      a.packed.p[i] = packed_ptrs_host ? packed_ptrs_host[first + i] : nullptr;
+      a.scale.p[i] = scale_ptrs_host[first + i];
+      a.scale_f16.p[i] = scale_f16_ptrs_host ? scale_f16_ptrs_host[first + i] : nullptr;
+    }
+    a.clip = nullptr;
+    a.rows = rows; a.cols = cols; a.block = block;
+    if (int32_t st = launch<true>(a, bits, n, true, as_stream(stream))) return st;
+  }
+  return MI355Q_OK;
 }

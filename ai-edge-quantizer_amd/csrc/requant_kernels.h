@@ -31,6 +31,28 @@ __device__ __forceinline__ T* pick(const void* p, int t) {
   }
 }
 
+// The batched form with its pointer tables IN the kernel arguments (up to kInlineTensors buffers per launch): the
+// tables of a group of equally shaped weights travel with the dispatch packet instead of through a host-to-device copy
+// that the launch has to wait for on its stream (the copy's completion signal, not its 512 bytes, is what costs:
+// ~10 us of stream time per launch against 14 us of kernel per tensor). blockIdx.y is uniform, so x[t] is one scalar
+// load from the kernarg segment.
+constexpr int kInlineTensors = 16;
+struct PtrTable {
+  const void* p[kInlineTensors];
+};
+struct RequantInlineArgs {
+  PtrTable x, q, packed, scale, scale_f16;
+  const float* clip;  // always null (the batched forms take no clip)
+  int64_t rows;
+  int64_t cols;
+  int32_t block;
+};
+
+template <bool BATCHED, typename T>
+__device__ __forceinline__ T* pick(const PtrTable& tab, int t) {
+  return reinterpret_cast<T*>(const_cast<void*>(tab.p[t]));
+}
+
 // Streaming access helpers: x is read exactly once and q is never re-read by this
 // kernel, so both can bypass cache retention (`nt`), see kbench for the effect.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -195,8 +217,8 @@ __device__ __forceinline__ uint32_t absmax4(float4 v) {
 // The tensor is a flat run of groups. Every lane owns CL consecutive float4
 // (G4/CL lanes share a group); a 256-thread block streams U tiles of 256*CL float4.
 // ------------------------------------------------------------------------
-template <int BITS, int G4, int U, int CL, bool FAST, bool BATCHED, bool NT = false>
-__global__ __launch_bounds__(256) void requant_groups_kernel(RequantArgs a) {
+template <int BITS, int G4, int U, int CL, bool FAST, bool BATCHED, bool NT = false, typename ARGS = RequantArgs>
+__global__ __launch_bounds__(256) void requant_groups_kernel(ARGS a) {
   static_assert(G4 % CL == 0 && G4 / CL >= 1, "group must be a multiple of the lane piece");
   constexpr int LPG = G4 / CL;  // lanes per group
   const int t = BATCHED ? blockIdx.y : 0;
@@ -243,8 +265,8 @@ __global__ __launch_bounds__(256) void requant_groups_kernel(RequantArgs a) {
 // row of cols4 <= TPR*R float4. TPR = 64 -> a wave owns the row (no LDS);
 // TPR = 256 -> the block owns the row (one LDS exchange).
 // ------------------------------------------------------------------------
-template <int BITS, int TPR, int R, bool FAST, bool BATCHED, bool NT = false>
-__global__ __launch_bounds__(256) void requant_rows_kernel(RequantArgs a) {
+template <int BITS, int TPR, int R, bool FAST, bool BATCHED, bool NT = false, typename ARGS = RequantArgs>
+__global__ __launch_bounds__(256) void requant_rows_kernel(ARGS a) {
   static_assert(TPR == 256 || (TPR <= kWave && (TPR & (TPR - 1)) == 0),
                 "a row is owned by part of a wave, one wave, or the whole 256-thread block");
   constexpr int RPB = 256 / TPR;  // rows per block
@@ -293,8 +315,8 @@ __global__ __launch_bounds__(256) void requant_rows_kernel(RequantArgs a) {
 // block per group, two sweeps (the second one hits L2). Packed output is not
 // produced here (the host entry refuses ragged packing; use mi355q_pack_bits).
 // ------------------------------------------------------------------------
-template <int BITS, bool BLOCKWISE, bool BATCHED>
-__global__ __launch_bounds__(256) void requant_generic_kernel(RequantArgs a) {
+template <int BITS, bool BLOCKWISE, bool BATCHED, typename ARGS = RequantArgs>
+__global__ __launch_bounds__(256) void requant_generic_kernel(ARGS a) {
   const int t = BATCHED ? blockIdx.y : 0;
   const float* __restrict__ x = pick<BATCHED, const float>(a.x, t);
   int8_t* q = pick<BATCHED, int8_t>(a.q, t);

@@ -31,6 +31,8 @@ PROTOTYPES = {
                                        c_ptr, c_ptr, c_ptr]),
     "mi355q_requant_sym_f32_batched": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i32, c_i32, c_ptr,
                                                c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mi355q_requant_sym_f32_batched_hostptrs": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i32, c_i32, c_ptr,
+                                                        c_ptr, c_ptr, c_ptr, c_ptr]),
     "mi355q_quantize_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i32, c_ptr, c_i32, c_i32,
                                     c_i32, c_i32, c_ptr, c_ptr]),
     "mi355q_dequantize_f32": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i32,

@@ -48,6 +48,15 @@ DEFAULT_BUDGET_TENSORS = int(os.environ.get("MI355Q_BATCH_TENSORS", 64))
 # roofline fraction with 16 buffers per launch): the GPU works on them while Python enqueues the next
 # ones, instead of idling until the whole model has been walked.
 GROUP_LAUNCH_TENSORS = int(os.environ.get("MI355Q_GROUP_LAUNCH_TENSORS", 16))
+# ... and the first groups of a walk leave smaller (4, then 8 tensors): until the first launch the GPU has nothing to do, and 16
+# submissions are 0.2 ms of Python -- a sixth of the wall time of a 64-tensor walk. (Tables in the kernel arguments and per-row
+# scales copied at the flush make a small launch cost its kernel time only; with a table upload in front of and a scale copy
+# behind every launch the ramp bought nothing: round 4.)
+GROUP_RAMP = tuple(int(v) for v in os.environ.get("MI355Q_GROUP_RAMP", "4,8").split(",") if v.strip())
+
+# Pointer tables of a launch: in the kernel arguments (mi355q_requant_sym_f32_batched_hostptrs), or -- MI355Q_REQUANT_TABLES=device,
+# for A / B timing -- copied to HBM in front of it (mi355q_requant_sym_f32_batched)
+_HOST_TABLES = os.environ.get("MI355Q_REQUANT_TABLES", "host") != "device"
 
 _I8, _U8, _F32, _F16 = np.dtype(np.int8), np.dtype(np.uint8), np.dtype(np.float32), np.dtype(np.float16)
 
@@ -124,6 +133,8 @@ class PendingArray(rt.HbmArray):
     if self._host is None:
       if self._unpack is None and self._source is None:
         self._queue.resolve(self._slot)
+      if self._wave is None and self._queue is not None:
+        self._queue._send_scales()               # (a per-row scale of a group that left early: its copy leaves now)  # pylint: disable=protected-access
       if self._wave is not None:                 # rode along in the wave's pinned scale copy
         self._host = self._wave.host_values(*self._host_at).reshape(self._shape)
       else:
@@ -182,6 +193,7 @@ class RequantQueue:
     self._pending_bytes = 0
     self._pending = 0
     self._waves: list[_Wave] = []
+    self._row_scales: list = []         # (slots, scale tensor) of launches whose per-row scales have not been sent to the host yet
     self._deferred: list = []           # other algorithms' own queues: completed with this one
     self.stats = {"tensors": 0, "launches": 0, "flushes": 0, "scale_copies": 0}
 
@@ -241,13 +253,15 @@ class RequantQueue:
     group = self._groups.get(slot.key)
     # (a group whose weights are still arriving from the model file does not leave at 16: its launch would hold the walk until
     # those uploads are in, and the writer that follows the walk launches them as they arrive, payload by payload: resolve())
-    if group is not None and len(group) >= GROUP_LAUNCH_TENSORS and not isinstance(slot.x, np.ndarray):
+    ramp = self.stats["launches"]
+    leave_at = GROUP_RAMP[ramp] if ramp < len(GROUP_RAMP) and _HOST_TABLES else GROUP_LAUNCH_TENSORS
+    if group is not None and len(group) >= min(leave_at, GROUP_LAUNCH_TENSORS) and not isinstance(slot.x, np.ndarray):
       del self._groups[slot.key]
       rows, cols = slot.key[0], slot.key[1]
       counted = sum(1 for s in group if s.counted)
       self._pending -= counted
       self._pending_bytes -= counted * rows * cols * 4
-      self._launch({slot.key: group})
+      self._launch({slot.key: group}, send_scales=False)
 
   # ------------------------------------------------------------------------------ resolve
   def resolve(self, slot) -> None:
@@ -277,17 +291,17 @@ class RequantQueue:
     """Issues everything pending: one launch per shape group, one asynchronous copy of the
     per-row scales. Does not wait for the GPU."""
     if not self._groups:
+      self._send_scales()
       return
     groups, self._groups = self._groups, {}
     self._pending_bytes = self._pending = 0
     self.stats["flushes"] += 1
     self._launch(groups)
 
-  def _launch(self, groups) -> None:
+  def _launch(self, groups, send_scales: bool = True) -> None:
     L = _ffi.lib()
     dev = rt.device()
     stream = rt.stream_ptr()
-    row_scales = []          # (slots, scale_all) of the groups whose scales go to the host
     for (rows, cols, block, bits, sub_byte), slots in groups.items():
       n = len(slots)
       for s in slots:
@@ -300,24 +314,36 @@ class RequantQueue:
       scale_all = torch.empty((n, nscale), dtype=torch.float32, device=dev)
       out_all = torch.empty((n, out_bytes), dtype=torch.uint8 if sub_byte else torch.int8, device=dev)
       f16_all = torch.empty((n, nscale), dtype=torch.float16, device=dev) if block else None
-      # one H2D for the pointer tables of the group
-      # (pinned staging: a pageable source would make the copy wait for the previous wave)
-      pinned = torch.empty((4, n), dtype=torch.int64, pin_memory=True)
-      table = pinned.numpy()
-      table[0] = [s.x.data_ptr() for s in slots]
       steps = np.arange(n, dtype=np.int64)
-      table[1] = out_all.data_ptr() + steps * out_bytes
-      table[2] = scale_all.data_ptr() + steps * (nscale * 4)
-      table[3] = f16_all.data_ptr() + steps * (nscale * 2) if block else 0
-      tab = pinned.to(dev, non_blocking=True)
-      base = tab.data_ptr()
-      for first in range(0, n, 65535):       # blockIdx.y limit of one launch
-        cnt = min(65535, n - first)
-        ptr = lambda row: ctypes.c_void_p(base + (row * n + first) * 8)   # noqa: E731
-        _ffi.check(L.mi355q_requant_sym_f32_batched(
-            ptr(0), cnt, rows, cols, block, bits, None if sub_byte else ptr(1),
-            ptr(1) if sub_byte else None, ptr(2), ptr(3) if block else None, stream))
-        self.stats["launches"] += 1
+      xs_at = [s.x.data_ptr() for s in slots]
+      if _HOST_TABLES:
+        # the tables travel in the kernel arguments (16 buffers per dispatch): no copy in front of the launch
+        arr = ctypes.c_void_p * n
+        outs = arr(*(out_all.data_ptr() + steps * out_bytes).tolist())
+        _ffi.check(L.mi355q_requant_sym_f32_batched_hostptrs(
+            arr(*xs_at), n, rows, cols, block, bits, None if sub_byte else outs, outs if sub_byte else None,
+            arr(*(scale_all.data_ptr() + steps * (nscale * 4)).tolist()),
+            arr(*(f16_all.data_ptr() + steps * (nscale * 2)).tolist()) if block else None, stream))
+        self.stats["launches"] += -(-n // 16)
+      else:
+        # one H2D for the pointer tables of the group
+        # (pinned staging: a pageable source would make the copy wait for the previous wave)
+        pinned = torch.empty((4, n), dtype=torch.int64, pin_memory=True)
+        table = pinned.numpy()
+        table[0] = xs_at
+        table[1] = out_all.data_ptr() + steps * out_bytes
+        table[2] = scale_all.data_ptr() + steps * (nscale * 4)
+        table[3] = f16_all.data_ptr() + steps * (nscale * 2) if block else 0
+        tab = pinned.to(dev, non_blocking=True)
+        base = tab.data_ptr()
+        for first in range(0, n, 65535):       # blockIdx.y limit of one launch
+          cnt = min(65535, n - first)
+          ptr = lambda row: ctypes.c_void_p(base + (row * n + first) * 8)   # noqa: E731
+          _ffi.check(L.mi355q_requant_sym_f32_batched(
+              ptr(0), cnt, rows, cols, block, bits, None if sub_byte else ptr(1),
+              ptr(1) if sub_byte else None, ptr(2), ptr(3) if block else None, stream))
+          self.stats["launches"] += 1
+        del tab                                # (stream-ordered allocator: freed after the launch)
       self.stats["tensors"] += n
       produced = torch.cuda.Event()            # behind this group's outputs (runtime.HbmArray.copy_into: the file writer's gate)
       produced.record()
@@ -330,21 +356,30 @@ class RequantQueue:
           s.scale.f16.ready = produced
         s.x = None                             # the FP32 copy in HBM is no longer needed
       if not block:
-        row_scales.append((slots, scale_all))
-      del tab                                  # (stream-ordered allocator: freed after the launch)
-    if row_scales:
-      flat = (torch.cat([g[1].reshape(-1) for g in row_scales]) if len(row_scales) > 1
-              else row_scales[0][1].reshape(-1))
-      wave = _Wave(flat)
-      self.stats["scale_copies"] += 1
-      pos = 0
-      for slots, scale_all in row_scales:
-        nscale = scale_all.shape[1]
-        for s in slots:
-          s.scale._wave, s.scale._host_at = wave, (pos, nscale)   # pylint: disable=protected-access
-          pos += nscale
-        wave.slots.extend(slots)
-      self._waves.append(wave)
+        self._row_scales.append((slots, scale_all))
+    if send_scales:
+      self._send_scales()
+
+  def _send_scales(self) -> None:
+    """ONE asynchronous copy of the per-row scales of every launch since the last one. A group that leaves early (16
+    tensors of a shape, attach()) does not send its own: a device-to-host copy between two launches holds the second
+    one back on the in-order stream until the copy's completion has been signalled (~10 us per launch); the scales
+    leave with the next flush, or when somebody reads one."""
+    row_scales, self._row_scales = self._row_scales, []
+    if not row_scales:
+      return
+    flat = (torch.cat([g[1].reshape(-1) for g in row_scales]) if len(row_scales) > 1
+            else row_scales[0][1].reshape(-1))
+    wave = _Wave(flat)
+    self.stats["scale_copies"] += 1
+    pos = 0
+    for slots, scale_all in row_scales:
+      nscale = scale_all.shape[1]
+      for s in slots:
+        s.scale._wave, s.scale._host_at = wave, (pos, nscale)   # pylint: disable=protected-access
+        pos += nscale
+      wave.slots.extend(slots)
+    self._waves.append(wave)
 
   def finish(self) -> None:
     """Flush + wait for the scale copies + swap the placeholders of per-row scales."""

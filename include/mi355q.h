@@ -112,6 +112,19 @@ int32_t mi355q_requant_sym_f32_batched(const float* const* x_ptrs, int32_t count
                                        float* const* scale_ptrs,
                                        uint16_t* const* scale_f16_ptrs, void* stream);
 
+/* The same launch with the pointer tables in HOST memory, read before the call returns: the device pointers travel
+ * inside the kernel arguments (16 buffers per dispatch; more than 16 leave as several dispatches), so a group of weights
+ * needs no host-to-device copy of its tables in front of its launch -- on an in-order stream that copy's completion
+ * signal, not its few hundred bytes, costs ~10 us per launch against 14 us of kernel per 4096 x 4096 buffer. What
+ * requant_queue issues for the resident weights of ParamsGenerator's per-op loop (ref: params_generator.py:162-183).
+ * Inputs must be 16-byte aligned (outputs as in the device-table form); entries of x / scale tables must not be NULL. */
+int32_t mi355q_requant_sym_f32_batched_hostptrs(const float* const* x_ptrs_host, int32_t count,
+                                                int64_t rows, int64_t cols, int32_t block,
+                                                int32_t bits, int8_t* const* q_ptrs_host,
+                                                uint8_t* const* packed_ptrs_host,
+                                                float* const* scale_ptrs_host,
+                                                uint16_t* const* scale_f16_ptrs_host, void* stream);
+
 /* ------------------------------------------------------------------------
  * K3 -- uniform quantize with given parameters ("T1" path; also asymmetric,
  * tensorwise and channel-last layouts).
