@@ -1591,6 +1591,215 @@ UnitPlan plan_units(int len) {
   return p;
 }
 
+
+// ---------------------------------------------------------------- OCTAV, one read (opt-in, tolerance class T2) ---
+// ref: algorithms/uniform_quantize/octav.py:30-112. The kernels above reproduce NumPy's float32 summation ORDER (pairwise
+// over runs of selected elements) so that the clipping constants are the reference's bit for bit; the price is 0.045 of
+// one read of the tensor. The reference pins neither NumPy nor its summation order (SURVEY 7 classes OCTAV as T2), so this
+// kernel offers the other trade: a unit (row / block) stays in REGISTERS as |x| for all iterations -- one pass over HBM --
+// and a masked sum is per-lane float32 partials (<= 64 elements each), a float32 tree over a wave's lanes and a float64
+// sum over a unit's waves: within 1e-6 of the reference's scale, not bit-identical to it.
+//   c <- sum_{|x| >= c} |x| / (f32(n_sel) (1 - s) + f64(s) N):  for c > 0 the reference's two masks (x >= c, x <= -c) are
+// disjoint and their sums' difference is the sum of |x| over their union; for c == 0 (every weight tensor's second iterate:
+// a first guess of 1 selects nothing) each zero sits in both masks, counted twice in n_sel as the reference counts it
+// (octav.py:87-100). NaNs fail both tests there and `|x| >= c` here.
+// The reference's early stop is global (octav.py:109): every unit runs all iterations, records its iterates and the
+// iterations in which it still moved, and octav_pick_kernel takes the first iterate at which no unit moved.
+struct OctavFastArgs {
+  const float* x;
+  long long units;
+  int len;          // elements per unit, a multiple of 4
+  int max_iter;
+  float s;
+  float* hist;      // [max_iter][units]
+  unsigned long long* moving;
+};
+
+// Sum over the LANES (<= 64) lanes that own a unit, result on every one of them, without LDS traffic: butterflies inside a
+// row of 16 lanes are DPP operands of the add itself (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror); rows
+// are combined through four v_readlane (the wave's four row totals in scalar registers). A ds_bpermute per step (what
+// __shfl_xor compiles to) made the twelve dependent exchanges of one iteration cost more than its 64 compare-select-adds.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+
+template <int LANES>
+__device__ __forceinline__ float unit_sum_f32(float v) {
+  if constexpr (LANES >= 2) v += dpp_f32<0xB1>(v);
+  if constexpr (LANES >= 4) v += dpp_f32<0x4E>(v);
+  if constexpr (LANES >= 8) v += dpp_f32<0x141>(v);
+  if constexpr (LANES >= 16) v += dpp_f32<0x140>(v);
+  if constexpr (LANES >= 32) {
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    if constexpr (LANES >= 64) v = (r0 + r1) + (r2 + r3);
+    else v = (threadIdx.x & 32) ? r2 + r3 : r0 + r1;
+  }
+  return v;
+}
+template <int LANES>
+__device__ __forceinline__ int unit_sum_i32(int v) {
+  if constexpr (LANES >= 2) v += dpp_i32<0xB1>(v);
+  if constexpr (LANES >= 4) v += dpp_i32<0x4E>(v);
+  if constexpr (LANES >= 8) v += dpp_i32<0x141>(v);
+  if constexpr (LANES >= 16) v += dpp_i32<0x140>(v);
+  if constexpr (LANES >= 32) {
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    if constexpr (LANES >= 64) v = (r0 + r1) + (r2 + r3);
+    else v = (threadIdx.x & 32) ? r2 + r3 : r0 + r1;
+  }
+  return v;
+}
+
+// LANES lanes own a unit (1 .. 64: part of a wave or a wave; 256 / 1024: the workgroup), V float4 per lane.
+template <int LANES, int V>
+__global__ __launch_bounds__(LANES > 256 ? LANES : 256) void octav_fast_kernel(OctavFastArgs a) {
+  constexpr int THREADS = LANES > 256 ? LANES : 256;
+  constexpr int UPB = THREADS / LANES;                     // units per workgroup
+  constexpr int WAVES = LANES / kWave;                    // waves per unit (0: several units per wave)
+  const int l = threadIdx.x % LANES;
+  const long long u = static_cast<long long>(blockIdx.x) * UPB + threadIdx.x / LANES;
+  const bool live = u < a.units;
+  const int len4 = a.len / 4;
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x) + (live ? u : 0) * len4;
+  const float qnan = __builtin_nanf("");
+  // every load is issued before the first value is looked at (V 16-byte loads in flight per lane): slots past the
+  // unit's end re-read its last piece and are blanked afterwards instead of branching around the load
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f raw[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c = j * LANES + l;
+    raw[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(&x4[c < len4 ? c : len4 - 1]));     // read once
+  }
+  float v[V][4];
+  int zeros = 0;                                          // per lane, or -- units that own whole waves -- per wave
+  float top = 0.f;                                        // this lane's largest |x| (fmaxf passes NaNs and blanks by)
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const bool mine = live && j * LANES + l < len4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[j][e] = mine ? fabsf(raw[j][e]) : qnan;           // a blank slot, like a NaN, is never selected and never a zero
+      top = fmaxf(top, v[j][e]);
+      if constexpr (LANES >= kWave) zeros += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v[j][e] == 0.f));
+      else zeros += v[j][e] == 0.f;
+    }
+  }
+  __shared__ double red_sum[2][WAVES > 0 ? WAVES : 1];
+  __shared__ int red_cnt[2][WAVES > 0 ? WAVES : 1];
+  float unit_top = 0.f;                                  // the unit's largest |x| (units that own whole waves)
+  if constexpr (LANES >= kWave) {
+    unit_top = top;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) unit_top = fmaxf(unit_top, __shfl_xor(unit_top, off, kWave));
+    if constexpr (WAVES > 1) {
+      __shared__ float red_top[WAVES > 0 ? WAVES : 1];
+      if ((threadIdx.x & (kWave - 1)) == 0) red_top[threadIdx.x / kWave] = unit_top;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < WAVES; ++k) unit_top = fmaxf(unit_top, red_top[k]);
+    }
+  }
+  float guess = 1.0f;
+  unsigned long long moved = 0;
+  int it = 0;
+  for (; it < a.max_iter; ++it) {
+    float part = 0.f;
+    int cnt = 0;
+    if constexpr (LANES >= kWave) {
+      // The guess is the same on every lane of the wave: a guess above the unit's largest |x| (the first guess, 1, of
+      // weights below 1) selects nothing, and the iteration costs nothing.
+      if (!(guess > unit_top)) {
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          // compare -> select -> lane count, element by element on VCC: left to the scheduler, the 64 compares are issued
+          // first and their lane masks (128 scalar registers) spill through v_writelane / v_readlane
+          // four elements per step, the four compares first: each lane mask (an SGPR pair of its own) is three
+          // instructions old when its select and its s_bcnt1 read it, so neither waits for the compare to retire
+          float t0, t1, t2, t3;
+          int n0, n1, n2, n3;
+          unsigned long long m0, m1, m2, m3;
+          asm volatile(
+              "v_cmp_ge_f32_e64 %[m0], %[x0], %[g]\n\tv_cmp_ge_f32_e64 %[m1], %[x1], %[g]\n\t"
+              "v_cmp_ge_f32_e64 %[m2], %[x2], %[g]\n\tv_cmp_ge_f32_e64 %[m3], %[x3], %[g]\n\t"
+              "v_cndmask_b32_e64 %[t0], 0, %[x0], %[m0]\n\tv_cndmask_b32_e64 %[t1], 0, %[x1], %[m1]\n\t"
+              "v_cndmask_b32_e64 %[t2], 0, %[x2], %[m2]\n\tv_cndmask_b32_e64 %[t3], 0, %[x3], %[m3]\n\t"
+              "s_bcnt1_i32_b64 %[n0], %[m0]\n\ts_bcnt1_i32_b64 %[n1], %[m1]\n\t"
+              "s_bcnt1_i32_b64 %[n2], %[m2]\n\ts_bcnt1_i32_b64 %[n3], %[m3]\n\t"
+              "v_add_f32 %[p0], %[p0], %[t0]\n\tv_add_f32 %[p1], %[p1], %[t1]\n\t"
+              "v_add_f32 %[p2], %[p2], %[t2]\n\tv_add_f32 %[p3], %[p3], %[t3]\n\t"
+              "s_add_i32 %[n0], %[n0], %[n1]\n\ts_add_i32 %[n2], %[n2], %[n3]\n\t"
+              "s_add_i32 %[c], %[c], %[n0]\n\ts_add_i32 %[c], %[c], %[n2]"
+              : [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [c] "+s"(cnt),
+                [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+                [n0] "=&s"(n0), [n1] "=&s"(n1), [n2] "=&s"(n2), [n3] "=&s"(n3),
+                [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
+              : [x0] "v"(v[j][0]), [x1] "v"(v[j][1]), [x2] "v"(v[j][2]), [x3] "v"(v[j][3]), [g] "v"(guess)
+              : "scc");
+        }
+        part = (p0 + p1) + (p2 + p3);
+        if (guess == 0.f) cnt += zeros;                  // every zero sits in both of the reference's masks
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool sel = v[j][e] >= guess;
+          part += sel ? v[j][e] : 0.f;
+          cnt += sel;
+        }
+      cnt = unit_sum_i32<LANES>(cnt + (guess == 0.f ? zeros : 0));
+    }
+    // per-lane float32 partials (<= 64 elements), float32 tree over the wave's lanes, float64 across the unit's waves
+    double sum = static_cast<double>(unit_sum_f32<(LANES < kWave ? LANES : kWave)>(part));
+    if constexpr (WAVES > 1) {
+      const int w = threadIdx.x / kWave, b = it & 1;
+      if ((threadIdx.x & (kWave - 1)) == 0) { red_sum[b][w] = sum; red_cnt[b][w] = cnt; }
+      __syncthreads();
+      sum = 0.0; cnt = 0;
+#pragma unroll
+      for (int k = 0; k < WAVES; ++k) { sum += red_sum[b][k]; cnt += red_cnt[b][k]; }
+    }
+    const OctavStep st = octav_step(guess, static_cast<float>(sum), 0.f, cnt, 0, a.len, a.s, 1);
+    if (live && l == 0) a.hist[static_cast<long long>(it) * a.units + u] = st.next;
+    if (!st.close) moved |= 1ull << it;
+    const bool fixed = reached_fixed_point(guess, st.next);
+    guess = st.next;
+    // every lane of a unit holds the same iterate: the unit leaves together; lanes of other units in the wave go on
+    if constexpr (LANES >= kWave) {
+      if (fixed) { ++it; break; }
+    }
+  }
+  if constexpr (LANES >= kWave) {
+    if (live && l == 0)
+      for (int k = it; k < a.max_iter; ++k) a.hist[static_cast<long long>(k) * a.units + u] = guess;
+  }
+  if (!live) moved = 0;
+  // one flag update per wave at most
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const unsigned lo = __shfl_xor(static_cast<unsigned>(moved), off, kWave);
+    const unsigned hi = __shfl_xor(static_cast<unsigned>(moved >> 32), off, kWave);
+    moved |= (static_cast<unsigned long long>(hi) << 32) | lo;
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) publish_moving(a.moving, moved);
+}
+
+template <int LANES, int V>
+void launch_octav_fast(const OctavFastArgs& a, hipStream_t st) {
+  constexpr int THREADS = LANES > 256 ? LANES : 256;
+  constexpr int UPB = THREADS / LANES;
+  hipLaunchKernelGGL((octav_fast_kernel<LANES, V>), dim3(static_cast<unsigned>((a.units + UPB - 1) / UPB)), dim3(THREADS), 0, st, a);
+}
+
 }  // namespace
 }  // namespace mi355q
 
@@ -1703,6 +1912,55 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
   MI355Q_CHECK_LAUNCH("octav launch");
   hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
                      hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
+  MI355Q_CHECK_LAUNCH("octav pick launch");
+  return MI355Q_OK;
+}
+
+extern "C" int32_t mi355q_octav_clip_fast_f32(const float* x, int64_t units, int64_t unit_len, int32_t bits,
+                                              int32_t max_iter, float exponent_divisor, int32_t early_stop,
+                                              float* clip_out, int32_t* iters_out, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+  clear_error();
+  if (units < 0 || unit_len < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (max_iter < 1 || max_iter > 64) return fail(MI355Q_BAD_ARG, "max_iter must be in [1, 64]");
+  if (bits < 1 || bits > 16) return fail(MI355Q_BAD_ARG, "bits must be in [1, 16]");
+  if (units == 0) return MI355Q_OK;
+  if (unit_len == 0) return fail(MI355Q_BAD_SHAPE, "empty reduction unit");
+  if (unit_len % 4 != 0 || unit_len > 65536)
+    return fail(MI355Q_UNSUPPORTED, "the one-read OCTAV kernel takes units of 4 .. 65536 elements, a multiple of 4 (got %lld):"
+                                    " use mi355q_octav_clip_f32", static_cast<long long>(unit_len));
+  if (units > 0x7FFFFFFFLL) return fail(MI355Q_UNSUPPORTED, "too many units");
+  if (!x || !clip_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  if (reinterpret_cast<uintptr_t>(x) & 15u) return fail(MI355Q_BAD_ARG, "x must be 16-byte aligned");
+  const size_t need = mi355q_octav_workspace_bytes(units, max_iter);
+  if (!workspace || workspace_bytes < need)
+    return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  hipStream_t st = as_stream(stream);
+  float* hist = static_cast<float*>(workspace);
+  unsigned long long* moving = reinterpret_cast<unsigned long long*>(hist + (units * max_iter + 1) / 2 * 2);
+  if (hipMemsetAsync(moving, 0, sizeof(unsigned long long), st) != hipSuccess)
+    return fail(MI355Q_HIP_ERROR, "hipMemsetAsync failed");
+  double p4 = 1.0;
+  for (int i = 0; i < bits; ++i) p4 *= 0.25;
+  const float s = static_cast<float>(p4 / static_cast<double>(exponent_divisor));
+  const OctavFastArgs a{x, units, static_cast<int>(unit_len), max_iter, s, hist, moving};
+  const int len4 = static_cast<int>(unit_len / 4);
+  if (len4 <= 4) launch_octav_fast<1, 4>(a, st);
+  else if (len4 <= 8) launch_octav_fast<2, 4>(a, st);
+  else if (len4 <= 16) launch_octav_fast<4, 4>(a, st);
+  else if (len4 <= 32) launch_octav_fast<8, 4>(a, st);
+  else if (len4 <= 64) launch_octav_fast<16, 4>(a, st);
+  else if (len4 <= 128) launch_octav_fast<32, 4>(a, st);
+  else if (len4 <= 256) launch_octav_fast<64, 4>(a, st);
+  else if (len4 <= 512) launch_octav_fast<64, 8>(a, st);
+  else if (len4 <= 1024) launch_octav_fast<64, 16>(a, st);
+  else if (len4 <= 2048) launch_octav_fast<256, 8>(a, st);
+  else if (len4 <= 4096) launch_octav_fast<256, 16>(a, st);
+  else if (len4 <= 8192) launch_octav_fast<1024, 8>(a, st);
+  else launch_octav_fast<1024, 16>(a, st);
+  MI355Q_CHECK_LAUNCH("octav one-read launch");
+  hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
+                     hist, moving, static_cast<long long>(units), max_iter, early_stop, clip_out, iters_out);
   MI355Q_CHECK_LAUNCH("octav pick launch");
   return MI355Q_OK;
 }

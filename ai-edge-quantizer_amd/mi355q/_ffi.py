@@ -46,6 +46,8 @@ PROTOTYPES = {
     "mi355q_octav_rows_workspace_bytes": (c_size, [c_i64, c_i64, c_i32]),
     "mi355q_octav_clip_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_f32, c_i32, c_i32,
                                       c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_octav_clip_fast_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_f32, c_i32, c_ptr, c_ptr, c_ptr,
+                                           c_size, c_ptr]),
     "mi355q_octav_clip_nd_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_i32, c_f32, c_i32,
                                          c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_mse_scale_f32": (c_i32, [c_ptr, c_i64, c_i64, c_f32, c_ptr, c_ptr]),

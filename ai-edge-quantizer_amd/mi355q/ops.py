@@ -7,6 +7,7 @@ include/mi355q.h.
 """
 from __future__ import annotations
 
+import contextlib as _contextlib
 import os
 import threading
 
@@ -302,6 +303,34 @@ def act_minmax_entries(pointers, lengths, lo: float = -3e38, hi: float = 3e38) -
   return out
 
 
+_OCTAV_MODE = [None]          # None: MI355Q_OCTAV_FAST decides; "exact" / "fast" inside octav_mode()
+
+
+def _octav_fast() -> bool:
+  if _OCTAV_MODE[0] is not None:
+    return _OCTAV_MODE[0] == "fast"
+  return os.environ.get("MI355Q_OCTAV_FAST", "") not in ("", "0")
+
+
+@_contextlib.contextmanager
+def octav_mode(mode: str = "exact"):
+  """The kernel OCTAV's clip search (ref octav.py:30-112) runs on inside this block.
+
+  "exact" (the default everywhere): the masked float32 sums in NumPy 2's summation order -- the clipping constants, and
+  with them scales and integers, are the reference's bit for bit; 0.045 of one read of the tensor.
+  "fast" (also MI355Q_OCTAV_FAST=1): one pass over HBM, a row / block stays in registers for all ten iterations, the
+  sums as float32 partials combined by a tree -- tolerance class T2 (scales within 1e-6 relative, integers
+  +-1 on <= 1e-5 of the elements; the reference pins neither NumPy nor its summation order). Units of 4 .. 65536
+  elements (a multiple of 4) with an axis given; anything else runs on the exact kernels in either mode."""
+  if mode not in ("exact", "fast"):
+    raise ValueError("octav_mode must be 'exact' or 'fast'")
+  before, _OCTAV_MODE[0] = _OCTAV_MODE[0], mode
+  try:
+    yield
+  finally:
+    _OCTAV_MODE[0] = before
+
+
 def octav_clip(x: torch.Tensor, units: int, unit_len: int, bits: int, max_iter: int = 10,
                exponent_divisor: float = 3.0, early_stop: bool = True, axis_given: bool = True):
   """K5. Returns (clip float32[units], iterations int). ref: octav.py:30-112.
@@ -315,6 +344,14 @@ def octav_clip(x: torch.Tensor, units: int, unit_len: int, bits: int, max_iter: 
   clip = rt.empty((units,), torch.float32)
   iters = rt.empty((1,), torch.int32)
   L = _ffi.lib()
+  if axis_given and _octav_fast() and unit_len % 4 == 0 and 4 <= unit_len <= 65536 and x.data_ptr() % 16 == 0:
+    # the opt-in one-read kernel (octav_mode("fast")): tolerance class T2 instead of NumPy's summation order
+    nbytes = L.mi355q_octav_workspace_bytes(units, max_iter)
+    ws = rt.empty((max(nbytes, 1),), torch.uint8)
+    _ffi.check(L.mi355q_octav_clip_fast_f32(
+        rt.ptr(x), units, unit_len, bits, max_iter, np.float32(exponent_divisor), 1 if early_stop else 0,
+        rt.ptr(clip), rt.ptr(iters), rt.ptr(ws), nbytes, rt.stream_ptr()))
+    return clip, iters
   nbytes = L.mi355q_octav_rows_workspace_bytes(units, unit_len, max_iter)
   ws = rt.empty((max(nbytes, 1),), torch.uint8)
   _ffi.check(L.mi355q_octav_clip_f32(
@@ -572,7 +609,6 @@ def gptq_hinv_batched(hessians, damp_factor: float = 0.01):
   return [(hinv[i], info[i:i + 1]) for i in range(n)]
 
 
-import contextlib as _contextlib
 
 
 @_contextlib.contextmanager

@@ -48,11 +48,11 @@ DEFAULT_BUDGET_TENSORS = int(os.environ.get("MI355Q_BATCH_TENSORS", 64))
 # roofline fraction with 16 buffers per launch): the GPU works on them while Python enqueues the next
 # ones, instead of idling until the whole model has been walked.
 GROUP_LAUNCH_TENSORS = int(os.environ.get("MI355Q_GROUP_LAUNCH_TENSORS", 16))
-# ... and the first groups of a walk leave smaller (4, then 8 tensors): until the first launch the GPU has nothing to do, and 16
-# submissions are 0.2 ms of Python -- a sixth of the wall time of a 64-tensor walk. (Tables in the kernel arguments and per-row
-# scales copied at the flush make a small launch cost its kernel time only; with a table upload in front of and a scale copy
-# behind every launch the ramp bought nothing: round 4.)
-GROUP_RAMP = tuple(int(v) for v in os.environ.get("MI355Q_GROUP_RAMP", "4,8").split(",") if v.strip())
+# The FIRST group of a walk leaves at 8 tensors (MI355Q_GROUP_RAMP, a comma-separated list of sizes for the first launches):
+# until the first launch the GPU has nothing to do. tools/api_resident_timeline.py, 64 resident 4096 x 4096 weights, total us:
+# no ramp 1126, "8" 1081, "4,8" 1119, "4,12" 1102, "2,6,8" 1142 -- smaller first launches run further below the roofline
+# fraction of 16-tensor ones than the earlier start buys. The walk is GPU-bound behind it (the host is done at 0.49 of 1.08 ms).
+GROUP_RAMP = tuple(int(v) for v in os.environ.get("MI355Q_GROUP_RAMP", "8").split(",") if v.strip())
 
 # Pointer tables of a launch: in the kernel arguments (mi355q_requant_sym_f32_batched_hostptrs), or -- MI355Q_REQUANT_TABLES=device,
 # for A / B timing -- copied to HBM in front of it (mi355q_requant_sym_f32_batched)
@@ -164,6 +164,7 @@ class _Wave:
     self._event = torch.cuda.Event()
     self._event.record()
     self._values = None
+    self._landing = None
     self.slots: list[_Slot] = []
 
   def host_values(self, offset: int, count: int) -> np.ndarray:
@@ -173,13 +174,38 @@ class _Wave:
       self._pinned = None
     return self._values[offset:offset + count]
 
-  def complete(self) -> None:
-    """Hands every per-row scale of the wave over as the ndarray the reference returns."""
+  def hand_over(self) -> None:
+    """Every per-row scale of the wave becomes the ndarray the reference returns -- a view of ONE block of ordinary
+    memory that land() fills. The 64 small host steps per wave (a view, a reshape, a field swap per tensor) happen HERE,
+    while the wave's last launch is still running; after the GPU has finished only one wait and one copy remain
+    (done the other way round, those steps were a quarter of the wall time of a 64-tensor walk: 2-3 us per tensor of
+    host work with the GPU idle)."""
+    if self._values is not None:                     # somebody read a scale earlier: the values are here already
+      for s in self.slots:
+        host = s.scale.numpy()
+        if s.params is not None and s.params.scale is s.scale:
+          object.__setattr__(s.params, "scale", host)
+      self.slots = []
+      return
+    self._landing = np.empty(tuple(self._pinned.shape), np.float32)
     for s in self.slots:
-      host = s.scale.numpy()
+      off, n = s.scale._host_at                      # pylint: disable=protected-access
+      host = self._landing[off:off + n].reshape(s.scale._shape)   # pylint: disable=protected-access
+      s.scale._host = host                           # pylint: disable=protected-access
       if s.params is not None and s.params.scale is s.scale:
         object.__setattr__(s.params, "scale", host)
     self.slots = []
+
+  def land(self) -> None:
+    """The wave's copy has arrived: its values fill the block the scales are views of."""
+    if self._landing is not None:
+      self._event.synchronize()
+      np.copyto(self._landing, self._pinned.numpy())
+      self._values, self._landing, self._pinned = self._landing, None, None
+
+  def complete(self) -> None:
+    self.hand_over()
+    self.land()
 
 
 class RequantQueue:
@@ -388,8 +414,10 @@ class RequantQueue:
       complete()
     self.flush()
     waves, self._waves = self._waves, []
+    for w in waves:          # (the host's share first, under the last launches; then the waits)
+      w.hand_over()
     for w in waves:
-      w.complete()
+      w.land()
 
 
 # the queue of the thread that opened `batching()`: another thread's calls neither join it nor

@@ -225,6 +225,19 @@ int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t unit_len, i
                               int32_t max_iter, float exponent_divisor, int32_t early_stop,
                               int32_t count_is_f64, float* clip_out, int32_t* iters_out,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* K5, one read (opt-in, tolerance class T2; mi355q.ops.octav_mode("fast") / MI355Q_OCTAV_FAST=1).
+ * ref: algorithms/uniform_quantize/octav.py:30-112, the same iteration and the same global early stop as
+ * mi355q_octav_clip_f32 with an axis given (count_is_f64 = 1). A unit stays in registers as |x| for all iterations:
+ * ONE pass over HBM instead of one per iteration. The masked sums are float32 partials per lane (<= 64 elements), a
+ * float32 tree over a wave's lanes and a float64 sum over a unit's waves -- not NumPy's order: clip_out agrees with the
+ * reference to ~1e-7 relative (scales within 1e-6, integers +-1 on <= 1e-5 of the elements: SURVEY 7's T2), not bit for
+ * bit. unit_len: a multiple of 4 in [4, 65536]; x 16-byte aligned; anything else is UNSUPPORTED (use the exact entry).
+ * workspace: mi355q_octav_workspace_bytes(units, max_iter). */
+int32_t mi355q_octav_clip_fast_f32(const float* x, int64_t units, int64_t unit_len, int32_t bits,
+                                   int32_t max_iter, float exponent_divisor, int32_t early_stop,
+                                   float* clip_out, int32_t* iters_out, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* General form: x is viewed as [outer, channels, inner] row-major and channel c's unit is the
  * `outer` segments x[o, c, :] (the reduction NumPy does when a middle or last axis is the
  * quantized dimension: DEPTHWISE_CONV_2D weights, BATCH_MATMUL right-hand sides; ref
