@@ -1381,17 +1381,21 @@ __global__ void side_delay_kernel(long long ticks) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
-SideStream g_side[64];
-// One call at a time enqueues look-ahead work per process: the side stream and its two events
-// are shared by every caller of a device, and hipStreamWaitEvent captures the event's state at
-// the time of the call, so record/wait pairs of two host threads must not interleave. The lock
-// is held only while a call enqueues (the entry point never synchronizes).
-std::mutex g_side_mutex;
+// Two slots per device: a large inverse owns one for the duration of its call, so two of them -- the pair
+// mi355q_gptq_hinv_*_batched keeps in flight at d >= 4096 -- each have a look-ahead stream of their own (sharing one,
+// the second matrix's rank-512 updates would queue behind ALL of the first's). Single calls use slot 0.
+constexpr int kSideSlots = 2;
+SideStream g_side[64][kSideSlots];
+// One call at a time enqueues look-ahead work per slot: a slot's stream and its two events are shared by every
+// caller of a device, and hipStreamWaitEvent captures the event's state at the time of the call, so record/wait
+// pairs of two host threads must not interleave. The lock is held only while a call enqueues (the entry point never
+// synchronizes).
+std::mutex g_side_mutex[kSideSlots];
 
-SideStream* side_stream() {
+SideStream* side_stream(int slot = 0) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SideStream& s = g_side[dev];
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || slot < 0 || slot >= kSideSlots) return nullptr;
+  SideStream& s = g_side[dev][slot];
   if (!s.tried) {
     s.tried = true;
     if (getenv("MI355Q_NO_LOOKAHEAD")) return nullptr;
@@ -1446,9 +1450,9 @@ extern "C" int32_t mi355q_device_free(void* p) {
 
 extern "C" int32_t mi355q_prepare_device(void) {
   clear_error();
-  {
-    std::lock_guard<std::mutex> lock(g_side_mutex);
-    (void)side_stream();        // (look-ahead switched off or no device: nothing to prepare)
+  for (int slot = 0; slot < kSideSlots; ++slot) {
+    std::lock_guard<std::mutex> lock(g_side_mutex[slot]);
+    (void)side_stream(slot);    // (look-ahead switched off or no device: nothing to prepare)
   }
   // ... and the lanes of the batched inverse: a hardware queue costs ~4 ms to create now and 3 - 4 times that
   // once the application has made its own streams (16 lanes made at the first batched call of an 18-layer
@@ -1461,15 +1465,18 @@ extern "C" int32_t mi355q_shutdown(void) {
   clear_error();
   release_hinv_pools();
   release_file_io();
-  std::lock_guard<std::mutex> lock(g_side_mutex);
-  for (SideStream& s : g_side) {
-    if (s.stream) {
-      (void)hipStreamSynchronize(s.stream);
-      (void)hipEventDestroy(s.panel_done);
-      (void)hipEventDestroy(s.update_done);
-      (void)hipStreamDestroy(s.stream);
+  for (int slot = 0; slot < kSideSlots; ++slot) {
+    std::lock_guard<std::mutex> lock(g_side_mutex[slot]);
+    for (auto& dev : g_side) {
+      SideStream& s = dev[slot];
+      if (s.stream) {
+        (void)hipStreamSynchronize(s.stream);
+        (void)hipEventDestroy(s.panel_done);
+        (void)hipEventDestroy(s.update_done);
+        (void)hipStreamDestroy(s.stream);
+      }
+      s = SideStream();
     }
-    s = SideStream();
   }
   return MI355Q_OK;
 }
@@ -1483,7 +1490,8 @@ extern "C" size_t mi355q_gptq_hinv_workspace_bytes(int64_t d) {
 namespace {
 // hessian (FLOAT64 [d, d]) or, when it is null, alpha * product (product FLOAT32 [d, d], lower triangle valid)
 int32_t hinv_impl(const double* hessian, const float* product, double alpha, int64_t d64, double damp_factor,
-                  float* hinv_out, int32_t* info_out, void* workspace, size_t workspace_bytes, void* stream) {
+                  float* hinv_out, int32_t* info_out, void* workspace, size_t workspace_bytes, void* stream,
+                  int side_slot = 0) {
   clear_error();
   if (d64 < 0) return fail(MI355Q_BAD_ARG, "negative shape");
   if (d64 == 0) return MI355Q_OK;
@@ -1513,9 +1521,9 @@ int32_t hinv_impl(const double* hessian, const float* product, double alpha, int
   // (d-k)^2/2 doubles for 64 flops each), so the 64-column steps only update the rest of their
   // own 512-column outer block; the matrix behind it gets one rank-512 update per outer block.
   static const int OB = [] { const char* e = getenv("MI355Q_CHOL_OB"); const int v = e ? atoi(e) : 0; return v >= 64 && v % 64 == 0 ? v : 8 * NB; }();
-  std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
+  std::unique_lock<std::mutex> side_lock(g_side_mutex[side_slot], std::defer_lock);
   if (d >= 4096) side_lock.lock();
-  SideStream* side = d >= 4096 ? side_stream() : nullptr;
+  SideStream* side = d >= 4096 ? side_stream(side_slot) : nullptr;
   bool side_busy = false;
   // Whatever way this call leaves the loop, the caller's stream waits for the side stream's last
   // update: the workspace it writes belongs to the caller, who may free it right after an error.
@@ -1766,8 +1774,20 @@ HinvPool* hinv_pool() {
 }
 
 size_t hinv_lane_bytes(int64_t d) { return (mi355q_gptq_hinv_workspace_bytes(d) + 255) & ~static_cast<size_t>(255); }
-int hinv_lanes_for(int32_t count, int64_t d) { return d >= 4096 || count < 2 ? 1 : (count < kHinvLanes ? count : kHinvLanes); }
-
+// d >= 4096: one matrix at a time by default. MI355Q_HINV_PAIRS=1 keeps TWO in flight (a lane each, each with the
+// look-ahead stream of its slot): built and measured in round 5 (tools/hinv_pairs_bench.py, profiles/r05_hinv_pairs.txt) --
+// bit-identical and SLOWER: 55.6 against 53.2 ms per d = 16384 inverse, 12.7 against 10.5 at 8192, 5.2 against 4.0 at 4608.
+// A lone call already keeps the machine busy (its own rank-512 update beside its own chain); what it loses, it loses to the
+// two interfering (the GEMM at 42-50 of its 64 TFLOP/s, the chain's kernels waiting for slots), and a second
+// matrix adds a second pair of the same to the same CUs instead of filling idle ones.
+int hinv_lanes_for(int32_t count, int64_t d) {
+  if (count < 2) return 1;
+  if (d >= 4096) {
+    static const bool pairs = [] { const char* e = getenv("MI355Q_HINV_PAIRS"); return e != nullptr && atoi(e) != 0; }();
+    return pairs ? kSideSlots : 1;
+  }
+  return count < kHinvLanes ? count : kHinvLanes;
+}
 // matrices that advance in lock step (hinv_lockstep): whole 64-column steps only, at most kHinvGroup, at most 4 GiB of workspace
 bool hinv_lockstep_ok(int32_t count, int64_t d) {
   static const bool on = getenv("MI355Q_HINV_LANES") == nullptr;
@@ -1895,24 +1915,39 @@ extern "C" size_t mi355q_gptq_hinv_batched_workspace_bytes(int32_t count, int64_
   if (hinv_lockstep_ok(count, d)) return hinv_lane_bytes(d) * static_cast<size_t>(hinv_group_for(count, d));
   return hinv_lane_bytes(d) * static_cast<size_t>(hinv_lanes_for(count, d));
 }
+// (Hessians handed over as float32 products are never taken in lock step: one slice per lane)
+extern "C" size_t mi355q_gptq_hinv_from_product_batched_workspace_bytes(int32_t count, int64_t d) {
+  if (count <= 0 || d <= 0) return 0;
+  return hinv_lane_bytes(d) * static_cast<size_t>(hinv_lanes_for(count, d));
+}
 
-extern "C" int32_t mi355q_gptq_hinv_f64_batched(const double* const* hessians_host, int32_t count, int64_t d,
-                                                double damp_factor, float* const* hinv_out_host, int32_t* info_out,
-                                                void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+// hessians_host[i] (FLOAT64) or, when that table is null, alphas_host[i] * products_host[i] (FLOAT32 products, lower triangle)
+int32_t hinv_batched_impl(const double* const* hessians_host, const float* const* products_host, const double* alphas_host,
+                          int32_t count, int64_t d, double damp_factor, float* const* hinv_out_host, int32_t* info_out,
+                          void* workspace, size_t workspace_bytes, void* stream) {
   clear_error();
   if (count < 0 || d < 0) return fail(MI355Q_BAD_ARG, "negative shape");
   if (count == 0 || d == 0) return MI355Q_OK;
-  if (!hessians_host || !hinv_out_host || !info_out) return fail(MI355Q_BAD_ARG, "null pointer");
-  const size_t need = mi355q_gptq_hinv_batched_workspace_bytes(count, d);
-  if (!workspace || workspace_bytes < need) return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  if ((!hessians_host && (!products_host || !alphas_host)) || !hinv_out_host || !info_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  for (int32_t i = 0; i < count; ++i)
+    if (!(hessians_host ? static_cast<const void*>(hessians_host[i]) : static_cast<const void*>(products_host[i])) || !hinv_out_host[i])
+      return fail(MI355Q_BAD_ARG, "null pointer");
+  const bool lockstep = hessians_host != nullptr && hinv_lockstep_ok(count, d);
   const size_t per = hinv_lane_bytes(d);
-  if (hinv_lockstep_ok(count, d)) {
+  const size_t need = per * static_cast<size_t>(lockstep ? hinv_group_for(count, d) : hinv_lanes_for(count, d));
+  if (!workspace || workspace_bytes < need) return fail(MI355Q_BAD_ARG, "workspace too small: need %zu bytes", need);
+  auto one = [&](int32_t i, void* ws, void* st, int slot) {
+    return hinv_impl(hessians_host ? hessians_host[i] : nullptr, hessians_host ? nullptr : products_host[i],
+                     hessians_host ? 1.0 : alphas_host[i], d, damp_factor, hinv_out_host[i], info_out + i, ws, per, st, slot);
+  };
+  if (lockstep) {
     // equally sized small Hessians advance through every step together: three launches per 64-column step for all of them
     const int group = hinv_group_for(count, d);
     for (int32_t i = 0; i < count; i += group) {
       const int g = count - i < group ? count - i : group;
       if (g == 1) {
-        if (int32_t e = mi355q_gptq_hinv_f64(hessians_host[i], d, damp_factor, hinv_out_host[i], info_out + i, workspace, per, stream)) return e;
+        if (int32_t e = one(i, workspace, stream, 0)) return e;
       } else if (int32_t e = hinv_lockstep(hessians_host + i, g, static_cast<int>(d), damp_factor, hinv_out_host + i, info_out + i,
                                            static_cast<unsigned char*>(workspace), per, as_stream(stream))) {
         return e;
@@ -1931,16 +1966,16 @@ extern "C" int32_t mi355q_gptq_hinv_f64_batched(const double* const* hessians_ho
   hipStream_t st = as_stream(stream);
   if (lanes == 1) {
     for (int32_t i = 0; i < count; ++i)
-      if (int32_t e = mi355q_gptq_hinv_f64(hessians_host[i], d, damp_factor, hinv_out_host[i], info_out + i, workspace, per, stream))
-        return e;
+      if (int32_t e = one(i, workspace, stream, 0)) return e;
     return MI355Q_OK;
   }
   if (hipEventRecord(pool->fork, st) != hipSuccess) return fail(MI355Q_HIP_ERROR, "hinv lanes: record failed");
   for (int l = 0; l < lanes; ++l)
     if (hipStreamWaitEvent(pool->lane[l], pool->fork, 0) != hipSuccess) return fail(MI355Q_HIP_ERROR, "hinv lanes: wait failed");
-  // One inverse is ~130 launches of a few microseconds of host time each: a single thread enqueuing 54
-  // chains is the bottleneck long before the chip is (39 ms of enqueue for 54 x 0.73 ms). Every lane
-  // therefore gets a thread of its own for the duration of the call.
+  // One inverse is ~130 launches (d = 2048; a thousand at d = 16384) of a few microseconds of host time each: a single
+  // thread enqueuing 54 chains is the bottleneck long before the chip is (39 ms of enqueue for 54 x 0.73 ms), and two
+  // large matrices enqueued one after the other would not run side by side. Every lane therefore gets a thread of its
+  // own for the duration of the call. A lane of large matrices also has the look-ahead stream of its slot.
   int32_t status = MI355Q_OK;
   {
     int dev = 0;
@@ -1952,8 +1987,8 @@ extern "C" int32_t mi355q_gptq_hinv_f64_batched(const double* const* hessians_ho
       workers.emplace_back([&, l] {
         (void)hipSetDevice(dev);
         for (int32_t i = l; i < count; i += lanes) {
-          const int32_t e = mi355q_gptq_hinv_f64(hessians_host[i], d, damp_factor, hinv_out_host[i], info_out + i,
-                                                static_cast<unsigned char*>(workspace) + static_cast<size_t>(l) * per, per, pool->lane[l]);
+          const int32_t e = one(i, static_cast<unsigned char*>(workspace) + static_cast<size_t>(l) * per, pool->lane[l],
+                                d >= 4096 ? l % kSideSlots : 0);
           if (e != MI355Q_OK) {
             lane_status[static_cast<size_t>(l)] = e;
             lane_error[static_cast<size_t>(l)] = mi355q_last_error();
@@ -1971,6 +2006,24 @@ extern "C" int32_t mi355q_gptq_hinv_f64_batched(const double* const* hessians_ho
     if (hipEventRecord(pool->done[l], pool->lane[l]) != hipSuccess || hipStreamWaitEvent(st, pool->done[l], 0) != hipSuccess)
       return fail(MI355Q_HIP_ERROR, "hinv lanes: join failed");
   return status;
+}
+}  // namespace
+
+extern "C" int32_t mi355q_gptq_hinv_f64_batched(const double* const* hessians_host, int32_t count, int64_t d,
+                                                double damp_factor, float* const* hinv_out_host, int32_t* info_out,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (count > 0 && d > 0 && !hessians_host) { clear_error(); return fail(MI355Q_BAD_ARG, "null pointer"); }
+  return hinv_batched_impl(hessians_host, nullptr, nullptr, count, d, damp_factor, hinv_out_host, info_out, workspace,
+                           workspace_bytes, stream);
+}
+
+extern "C" int32_t mi355q_gptq_hinv_from_product_f32_batched(const float* const* products_host, const double* alphas_host,
+                                                             int32_t count, int64_t d, double damp_factor,
+                                                             float* const* hinv_out_host, int32_t* info_out, void* workspace,
+                                                             size_t workspace_bytes, void* stream) {
+  if (count > 0 && d > 0 && (!products_host || !alphas_host)) { clear_error(); return fail(MI355Q_BAD_ARG, "null pointer"); }
+  return hinv_batched_impl(nullptr, products_host, alphas_host, count, d, damp_factor, hinv_out_host, info_out, workspace,
+                           workspace_bytes, stream);
 }
 
 extern "C" size_t mi355q_gptq_apply_workspace_bytes(int64_t rows, int64_t d) {

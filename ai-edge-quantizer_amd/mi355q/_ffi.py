@@ -69,6 +69,9 @@ PROTOTYPES = {
     "mi355q_gptq_hinv_from_product_f32": (c_i32, [c_ptr, c_i64, c_f64, c_f64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_gptq_hinv_batched_workspace_bytes": (c_size, [c_i32, c_i64]),
     "mi355q_gptq_hinv_f64_batched": (c_i32, [c_ptr, c_i32, c_i64, c_f64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "mi355q_gptq_hinv_from_product_batched_workspace_bytes": (c_size, [c_i32, c_i64]),
+    "mi355q_gptq_hinv_from_product_f32_batched": (c_i32, [c_ptr, c_ptr, c_i32, c_i64, c_f64, c_ptr, c_ptr, c_ptr, c_size,
+                                                          c_ptr]),
     "mi355q_gptq_apply_workspace_bytes": (c_size, [c_i64, c_i64]),
     "mi355q_gptq_apply_f32": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32,
                                       c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_size, c_ptr]),

@@ -543,11 +543,13 @@ class HinvWorkspace:
   follow each other, so one workspace serves them all."""
   current = None
 
-  def __init__(self, d: int):
+  def __init__(self, d: int, lanes: int = 1):
+    """lanes = 2: room for the pair of large matrices gptq_hinv_from_product_batched keeps in flight."""
     import ctypes
     import threading
     rt.require_gpu()
-    self.nbytes = int(_ffi.lib().mi355q_gptq_hinv_workspace_bytes(d))
+    self.nbytes = int(_ffi.lib().mi355q_gptq_hinv_from_product_batched_workspace_bytes(lanes, d)) if lanes > 1 \
+        else int(_ffi.lib().mi355q_gptq_hinv_workspace_bytes(d))
     self.d = d
     self._ptr = ctypes.c_void_p()
     self._status = 0
@@ -609,6 +611,33 @@ def gptq_hinv_batched(hessians, damp_factor: float = 0.01):
   return [(hinv[i], info[i:i + 1]) for i in range(n)]
 
 
+
+
+def gptq_hinv_from_product_batched(forms, damp_factor: float = 0.01):
+  """K9 for several Hessians of one order handed over as (product float32 [d, d], alpha) pairs (what calibration leaves
+  behind: gptq.HessianAccumulator.product_form): [(hinv float32 [d, d], info int32[1]), ...], the same bits as
+  gptq_hinv_from_product on each (mi355q_gptq_hinv_from_product_f32_batched; MI355Q_HINV_PAIRS=1: two d >= 4096 matrices in flight)."""
+  import ctypes
+  rt.require_gpu()
+  forms = [(_f32(p), float(a)) for p, a in forms]
+  if not forms:
+    return []
+  d = forms[0][0].shape[0]
+  if any(tuple(p.shape) != (d, d) for p, _ in forms):
+    raise ValueError("all Hessians of a batch must have one order")
+  n = len(forms)
+  hinvs = [rt.empty((d, d), torch.float32) for _ in range(n)]      # (separate allocations: each is given back with its last reader)
+  info = rt.empty((n,), torch.int32)
+  L = _ffi.lib()
+  nbytes = L.mi355q_gptq_hinv_from_product_batched_workspace_bytes(n, d)
+  held = HinvWorkspace.current.pointer(nbytes) if HinvWorkspace.current is not None else None
+  ws = None if held is not None else rt.empty((max(nbytes, 1),), torch.uint8)
+  src = (ctypes.c_void_p * n)(*[p.data_ptr() for p, _ in forms])
+  alphas = (ctypes.c_double * n)(*[a for _, a in forms])
+  dst = (ctypes.c_void_p * n)(*[h.data_ptr() for h in hinvs])
+  _ffi.check(L.mi355q_gptq_hinv_from_product_f32_batched(src, alphas, n, d, float(damp_factor), dst, rt.ptr(info),
+                                                         held if held is not None else rt.ptr(ws), nbytes, rt.stream_ptr()))
+  return [(hinvs[i], info[i:i + 1]) for i in range(n)]
 
 
 @_contextlib.contextmanager

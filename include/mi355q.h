@@ -374,15 +374,29 @@ int32_t mi355q_gptq_hinv_from_product_f32(const float* product, int64_t d, doubl
                                           size_t workspace_bytes, void* stream);
 
 /* `count` independent inverses of equally sized Hessians in one call (a model has one per distinct
- * FULLY_CONNECTED input: 54 of order 2048 in a Gemma-2B): for d < 4096, where one inverse is a chain
- * of small dependent kernels that leaves the chip idle, the chains interleave on a per-device pool
- * of streams; results are bit-identical to `count` calls of mi355q_gptq_hinv_f64. The two pointer
- * tables are HOST arrays of device pointers; info_out is device int32[count].
+ * FULLY_CONNECTED input: 54 of order 2048 and 18 of order 16384 in a Gemma-2B; ref gptq.py:111-128 is
+ * called once per weight, the calls share nothing). d < 4096, where one inverse is a chain of small
+ * dependent kernels that leaves the chip idle: the matrices advance through every step together.
+ * d >= 4096: one after the other on the caller's stream (a lone large inverse keeps the machine busy with its
+ * own look-ahead update; MI355Q_HINV_PAIRS=1 keeps two in flight, each with a look-ahead stream of its own --
+ * measured slower, profiles/r05_hinv_pairs.txt). Every matrix sees the launches of a single call in the
+ * same order: results are bit-identical to `count` calls of mi355q_gptq_hinv_f64. The two pointer tables
+ * are HOST arrays of device pointers; info_out is device int32[count].
  * workspace: mi355q_gptq_hinv_batched_workspace_bytes(count, d). */
 size_t mi355q_gptq_hinv_batched_workspace_bytes(int32_t count, int64_t d);
 int32_t mi355q_gptq_hinv_f64_batched(const double* const* hessians_host, int32_t count, int64_t d,
                                      double damp_factor, float* const* hinv_out_host, int32_t* info_out,
                                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same for Hessians handed over as hessian[i] = alphas_host[i] * products_host[i] (float32 X^T X, lower
+ * triangle valid: see mi355q_gptq_hinv_from_product_f32) -- what calibration leaves behind for the large
+ * layers. alphas_host is a HOST array of count doubles. Bit-identical to `count` single calls.
+ * workspace: mi355q_gptq_hinv_from_product_batched_workspace_bytes(count, d). */
+size_t mi355q_gptq_hinv_from_product_batched_workspace_bytes(int32_t count, int64_t d);
+int32_t mi355q_gptq_hinv_from_product_f32_batched(const float* const* products_host, const double* alphas_host,
+                                                  int32_t count, int64_t d, double damp_factor,
+                                                  float* const* hinv_out_host, int32_t* info_out, void* workspace,
+                                                  size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * K10 -- GPTQ weight update + quantization: for each 64-column block, quantize
