@@ -344,6 +344,132 @@ __global__ __launch_bounds__(512) void xtx_bf16x3_wide_kernel(XtxArgs a) {
   }
 }
 
+// The wide kernel with FOUR one-k-tile buffers instead of two two-k-tile stages (the same 144 KB of LDS): see the staging
+// comment inside. SQ counters of the kernel above (profiles/r05_xtx_bound.txt): its waves spend 32 % of their cycles in
+// s_waitcnt / s_barrier -- all eight at the same time -- and the MFMA pipe is 57 % busy. Same products, same accumulator
+// structure, same k order per output: the same bits (tests/test_gpu_gptq.py).
+__global__ __launch_bounds__(512) void xtx_bf16x3_deep_kernel(XtxArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
+  const int sup = (local / 32) * 8 + xcd, within = local % 32;
+  int si = static_cast<int>((__builtin_sqrtf(8.0f * static_cast<float>(sup) + 1.0f) - 1.0f) * 0.5f);
+  while ((si + 1) * (si + 2) / 2 <= sup) ++si;
+  while (si * (si + 1) / 2 > sup) --si;
+  const int sj = sup - si * (si + 1) / 2;
+  const int ti = si * kSuper + within / 4;          // 128-row tile
+  const int tj = sj * (kSuper / 2) + within % 4;    // 256-column tile
+  if (ti >= a.tiles || 2 * tj > ti) return;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 2, wc = wave & 3;           // this wave's 64 x 64 quadrant of the 128 x 256 tile
+  const int kt0 = 0, kt1 = a.kt_total;               // (no split-K: wide tiles are for d >= 4096)
+
+  f32x16 acc[2][2], lo[2][2], top[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = top[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fch = ((lane >> 5) ^ ((frow >> 3) & 1)) * 16;
+  const int offA = (wr * 64 + frow) * kRowB + fch, offB = kWideA + (wc * 64 + frow) * kRowB + fch;
+
+  const long long row_stride = static_cast<long long>(a.d) * kRowB;   // one plane of one k tile
+  const unsigned char* gA = a.planes + static_cast<long long>(ti) * kPlaneTileB + lane * 16;
+  const unsigned char* gB = a.planes + static_cast<long long>(tj) * (2 * kPlaneTileB) + lane * 16;
+
+  // 36 wave-wide 1 KB pieces per k tile: 12 of A (plane x 4 pieces of 32 rows) and 24 of B (plane x 8); wave w takes pieces
+  // w, w + 8, w + 16, w + 24 and -- waves 0..3 -- w + 32. FOUR buffers of one k tile: the pieces of k tile t + 3 go out
+  // behind the barrier that opens k tile t, so a piece has three k tiles of MFMAs (2300 cycles per SIMD at full rate) to land
+  // where the two-k-tile stages of the kernel above leave it one stage, and a wave waits for ITS OWN pieces of k tile t only
+  // (s_waitcnt vmcnt(n): those of t + 1 and t + 2 stay in flight).
+  const int mine = wave < 4 ? 5 : 4;
+  auto stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int r = q * 8 + wave;                     // 0 .. 35
+      if (q == 4 && wave >= 4) break;
+      const bool isB = r >= 12;
+      const int pl = isB ? (r - 12) >> 3 : r >> 2, seg = isB ? (r - 12) & 7 : r & 3;
+      const unsigned char* src = (isB ? gB : gA) + (static_cast<long long>(kt) * 3 + pl) * row_stride + seg * 1024;
+      unsigned char* dst = lds + buf * kWideKt + (isB ? kWideA + pl * (2 * kPlaneTileB) : pl * kPlaneTileB) + seg * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  (void)mine;
+#pragma unroll
+  for (int pre = 0; pre < 3; ++pre)
+    if (kt0 + pre < kt1) stage(kt0 + pre, pre);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 3;
+    // this wave's pieces of k tile kt have landed (the pieces of later k tiles it issued since may still be in flight)
+    const int later = (kt + 1 < kt1 ? 1 : 0) + (kt + 2 < kt1 ? 1 : 0);
+    if (wave < 4) {
+      if (later == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();          // every wave's pieces of this k tile have landed; every wave is done with k tile kt - 1's buffer
+    if (kt + 3 < kt1) stage(kt + 3, (buf + 3) & 3);
+    {
+      const unsigned char* img = lds + buf * kWideKt;
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          fa[i][pl] = *reinterpret_cast<const bf16x8*>(img + offA + pl * kPlaneTileB + i * 32 * kRowB);
+          fb[i][pl] = *reinterpret_cast<const bf16x8*>(img + offB + pl * (2 * kPlaneTileB) + i * 32 * kRowB);
+        }
+#define MI355Q_TERM(ACC, PA, PB)                                                                \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], ACC[i][j], 0, 0, 0)
+      MI355Q_TERM(lo, 0, 2);
+      MI355Q_TERM(lo, 1, 1);
+      MI355Q_TERM(lo, 2, 0);
+      MI355Q_TERM(lo, 0, 1);
+      MI355Q_TERM(lo, 1, 0);
+      MI355Q_TERM(acc, 0, 0);
+#undef MI355Q_TERM
+      if (((kt - kt0) & (kFold - 1)) == kFold - 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              top[i][j][r] = top[i][j][r] + acc[i][j][r];
+              acc[i][j][r] = 0.f;
+            }
+      }
+    }
+  }
+
+  float* base = a.c + static_cast<long long>(ti * kTile + wr * 64 + 4 * (lane >> 5)) * a.d + tj * (2 * kTile) + wc * 64 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        old[r] = a.accumulate ? base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float big = top[i][j][r] + acc[i][j][r];
+        const float v = __builtin_isinf(big) ? big : big + lo[i][j][r];
+        base[static_cast<long long>(i * 32 + (r & 3) + 8 * (r >> 2)) * a.d + j * 32] = a.accumulate ? old[r] + v : v;
+      }
+    }
+  }
+}
+
 // ---- the same exact split for GPTQ's update behind a group of columns (gptq.hip):
 //   W[:, g1:] -= E @ Hinv[g0:g1, g1:],  E = the group's errors [rows, kk] float32 (kk <= 256).
 // Hinv's planes are made once per call by xtx_split_kernel (x = Hinv: "token" = row k of Hinv,
@@ -808,9 +934,12 @@ int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspa
     static const bool wide_ok = [] { const char* e = getenv("MI355Q_XTX_NARROW"); return e == nullptr || *e == 0; }();
     if (wide_ok && a.patches && d % (2 * kTile) == 0 && splits == 1) {
       // 128 x 256 tiles: the same 8-XCD patch list, 32 workgroups per patch
-      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xtx_bf16x3_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWideStageB))
+      static const bool deep = [] { const char* e = getenv("MI355Q_XTX_DEEP"); return e == nullptr || atoi(e) != 0; }();
+      const void* fn = deep ? reinterpret_cast<const void*>(xtx_bf16x3_deep_kernel) : reinterpret_cast<const void*>(xtx_bf16x3_wide_kernel);
+      if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWideStageB))
         return fail(MI355Q_HIP_ERROR, "xtx bf16x3 LDS attribute: %s", hipGetErrorString(e));
-      hipLaunchKernelGGL(xtx_bf16x3_wide_kernel, dim3(gx / 2, 1), dim3(512), 2 * kWideStageB, st, a);
+      if (deep) hipLaunchKernelGGL(xtx_bf16x3_deep_kernel, dim3(gx / 2, 1), dim3(512), 2 * kWideStageB, st, a);
+      else hipLaunchKernelGGL(xtx_bf16x3_wide_kernel, dim3(gx / 2, 1), dim3(512), 2 * kWideStageB, st, a);
     } else {
       hipLaunchKernelGGL(xtx_bf16x3_kernel, dim3(gx, static_cast<unsigned>(splits)), dim3(256), 4 * kOperandB, st, a);
     }

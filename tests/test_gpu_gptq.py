@@ -523,6 +523,41 @@ def test_batched_inverses_equal_single_calls_bit_for_bit(m, d, count):
   assert int(got[-1][1].item()) != 0 and all(int(i.item()) == 0 for _, i in got[:-1])
 
 
+@pytest.mark.parametrize("d,count", [(4224, 3), (2048, 2), (448, 3)])
+def test_product_form_batches_equal_single_calls_bit_for_bit(m, d, count):
+  """mi355q_gptq_hinv_from_product_f32_batched: Hessians handed over as float32 products (what calibration leaves
+  behind) give the single product-form call's bits, which are those of the call on the finished float64 Hessian."""
+  torch = m.torch
+  forms = []
+  for i in range(count):
+    gen = torch.Generator(device="cuda").manual_seed(40 + 3 * i + d)
+    x = torch.randn((max(d, 1024) + 64 * i, d), generator=gen, device="cuda") * (1.0 + 0.5 * i)
+    forms.append((m.ops.gptq_xtx_accum(x, None), 2.0 / (3 + i)))
+  got = m.ops.gptq_hinv_from_product_batched(forms, 0.01)
+  for (p, alpha), (hinv, info) in zip(forms, got):
+    want, winfo = m.ops.gptq_hinv_from_product(p, alpha, 0.01)
+    assert int(info.item()) == int(winfo.item()) == 0 and torch.equal(hinv, want)
+    full, _ = m.ops.gptq_hinv(m.ops.gptq_xtx_finish(p, alpha), 0.01)
+    assert torch.equal(hinv, full)
+  assert m.ops.gptq_hinv_from_product_batched([], 0.01) == []
+
+
+def test_two_large_inverses_in_flight_return_the_single_calls_bits():
+  """MI355Q_HINV_PAIRS=1 (opt-in: measured slower, profiles/r05_hinv_pairs.txt): two d >= 4096 matrices on two lanes,
+  each with a look-ahead stream of its own. The switch is read once per process: a child process runs the bench tool."""
+  import json
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, MI355Q_HINV_PAIRS="1")
+  r = subprocess.run([sys.executable, os.path.join(root, "tools", "hinv_pairs_bench.py"), "4224", "3"], env=env, capture_output=True,
+                     text=True, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  rec = json.loads(r.stdout.strip().splitlines()[-1])
+  assert rec["bit_identical"] is True and rec["d"] == 4224
+
+
 def test_workspaces_and_outputs_are_written_before_they_are_read(m, monkeypatch):
   """The GPTQ entry points take caller-owned workspaces and outputs that they may not assume
   anything about: with every byte of them set to 0xFF beforehand (NaN as float32 / float64)
