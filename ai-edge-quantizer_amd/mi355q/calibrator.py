@@ -743,6 +743,14 @@ class Calibrator:
         fresh = self._new_hessians.pop(name, None)         # calibrate(): this block's samples went into it already
         if fresh is not None and "hessian" not in out:
           out["hessian"] = fresh
+        if cur is not None and "hessian" in out and t not in block.hessian_dims:
+          # the Hessian's own sample count, where it is not the QSV's (samples without a Hessian were merged into this
+          # QSV before: utils/qsv_utils.gptq_and_moving_average_update keeps the two apart)
+          mine = block.num_samples[:, t].sum()
+          if "hessian" not in cur:
+            out["hessian_num_samples"] = mine
+          elif "hessian_num_samples" in cur:
+            out["hessian_num_samples"] = cur["hessian_num_samples"] + mine
         self._model_qsvs[name] = out
     if slow:
       for k in range(k_samples):

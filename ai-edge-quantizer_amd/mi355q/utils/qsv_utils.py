@@ -30,13 +30,19 @@ def min_max_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qtyping.QSV:
           "max": np.maximum(qsv["max"], new_qsv["max"])}
 
 
+def _hessian_samples(qsv: qtyping.QSV):
+  """The number of samples a QSV's Hessian is the mean over: its num_samples, unless samples WITHOUT a Hessian have been
+  merged into the QSV since ("hessian_num_samples", see gptq_and_moving_average_update)."""
+  return qsv.get("hessian_num_samples", qsv["num_samples"])
+
+
 def _gptq_merge_hessian(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> tuple[Any, int]:
   """(H_cur*n_cur + H_new*n_new) / (n_cur + n_new), num_samples summed (ref :71-88).
 
   float64 Hessians (what calibrate() produces) are merged by
   mi355q_gptq_hessian_merge_f64 -- the same three IEEE operations per element.
   """
-  n0, n1 = qsv["num_samples"], new_qsv["num_samples"]
+  n0, n1 = _hessian_samples(qsv), _hessian_samples(new_qsv)
   total = n0 + n1
   if total == 0:
     return new_qsv["hessian"], 0
@@ -94,14 +100,20 @@ def gptq_and_moving_average_update(qsv: qtyping.QSV, new_qsv: qtyping.QSV) -> qt
     # count only. One side only (a resumed calibration whose earlier result came from hessians="all",
     # an earlier build or the reference, where every runtime tensor carries one; or a tensor read by a
     # GPTQ op under one signature's plan only): the samples of the side without a Hessian cannot
-    # weigh in, so the existing Hessian is kept as the mean over ITS samples and the counts add --
-    # the Hessian of a tensor nobody reads is never looked at, and a reader's always has both sides.
+    # weigh in, so the existing Hessian is kept as the mean over ITS samples, whose number travels with it
+    # ("hessian_num_samples"), and the counts add.
     out["num_samples"] = qsv.get("num_samples", 0) + new_qsv.get("num_samples", 0)
-    kept = qsv.get("hessian", new_qsv.get("hessian"))
-    if kept is not None:
-      out["hessian"] = kept
+    side = qsv if "hessian" in qsv else new_qsv if "hessian" in new_qsv else None
+    if side is not None:
+      # the Hessian stays the mean over ITS samples, and says so: a later merge weighs it by that count, not by the
+      # QSV's (which now includes samples that never contributed to it). The reference raises KeyError here.
+      out["hessian"] = side["hessian"]
+      out["hessian_num_samples"] = _hessian_samples(side) if "num_samples" in side else 0
     return out
-  out["hessian"], out["num_samples"] = _gptq_merge_hessian(qsv, new_qsv)
+  out["hessian"], with_hessian = _gptq_merge_hessian(qsv, new_qsv)
+  out["num_samples"] = qsv["num_samples"] + new_qsv["num_samples"]
+  if "hessian_num_samples" in qsv or "hessian_num_samples" in new_qsv:
+    out["hessian_num_samples"] = with_hessian
   return out
 
 

@@ -588,6 +588,29 @@ def test_remote_payload_records_instead_of_bytes(tmp_path):
     os.close(fd)
 
 
+def test_a_hessian_merged_into_a_qsv_without_one_keeps_its_own_sample_count():
+  """ref utils/qsv_utils.py:71-102 raises KeyError when only one side has a Hessian; here the Hessian is kept as the mean
+  over ITS samples, the QSV's count covers all of them, and a later merge weighs the Hessian by its own count."""
+  from mi355q.utils import qsv_utils
+
+  def qsv(n, h=None):
+    out = {"min": np.float32(-1), "max": np.float32(1), "num_samples": n}
+    if h is not None:
+      out["hessian"] = h
+    return out
+  h1, h2, h3 = (np.eye(2, dtype=np.float32) * v for v in (2.0, 8.0, 5.0))     # (float64 Hessians are merged on the GPU)
+  a = qsv_utils.gptq_and_moving_average_update(qsv(3), qsv(2, h1))
+  assert a["num_samples"] == 5 and a["hessian_num_samples"] == 2 and np.array_equal(a["hessian"], h1)
+  b = qsv_utils.gptq_and_moving_average_update(a, qsv(4, h2))
+  assert b["num_samples"] == 9 and b["hessian_num_samples"] == 6
+  np.testing.assert_allclose(b["hessian"], (2 * h1 + 4 * h2) / 6)         # not (5 h1 + 4 h2) / 9
+  c = qsv_utils.gptq_and_moving_average_update(b, qsv(1))                   # ... and the other way round
+  assert c["num_samples"] == 10 and c["hessian_num_samples"] == 6 and np.array_equal(c["hessian"], b["hessian"])
+  d = qsv_utils.gptq_and_moving_average_update(qsv(2, h1), qsv(4, h3))      # both sides from the start: nothing extra
+  assert d["num_samples"] == 6 and "hessian_num_samples" not in d
+  np.testing.assert_allclose(d["hessian"], (2 * h1 + 4 * h3) / 6)
+
+
 def test_one_array_pickled_twice_is_one_remote_payload_and_compares_equal():
   """A constant two quantized ops read (tied embedding / lm_head): both results hold the SAME array (the (buffer, config)
   cache, ref common_utils.py:48-77), so both records name one payload and qtyping's value comparison
