@@ -348,6 +348,7 @@ __global__ __launch_bounds__(512) void xtx_bf16x3_wide_kernel(XtxArgs a) {
 // comment inside. SQ counters of the kernel above (profiles/r05_xtx_bound.txt): its waves spend 32 % of their cycles in
 // s_waitcnt / s_barrier -- all eight at the same time -- and the MFMA pipe is 57 % busy. Same products, same accumulator
 // structure, same k order per output: the same bits (tests/test_gpu_gptq.py).
+template <int ALT>
 __global__ __launch_bounds__(512) void xtx_bf16x3_deep_kernel(XtxArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
@@ -384,39 +385,64 @@ __global__ __launch_bounds__(512) void xtx_bf16x3_deep_kernel(XtxArgs a) {
   // behind the barrier that opens k tile t, so a piece has three k tiles of MFMAs (2300 cycles per SIMD at full rate) to land
   // where the two-k-tile stages of the kernel above leave it one stage, and a wave waits for ITS OWN pieces of k tile t only
   // (s_waitcnt vmcnt(n): those of t + 1 and t + 2 stay in flight).
-  const int mine = wave < 4 ? 5 : 4;
+  // HALF of the waves stage a k tile, nine pieces each: waves 0-3 the even k tiles, waves 4-7 the odd ones (ALT == 2: even /
+  // odd waves). A piece costs its wave ~100 cycles of issue in which it issues no MFMA; when both waves of a SIMD stage behind
+  // the same barrier the SIMD's MFMA pipe idles for as long, when one does its partner's 24 MFMAs run underneath.
+  // (ALT == 0: every wave stages 4-5 pieces of every k tile. Same box, alternating runs: ALT 0 / 1 / 2 = 23.4 / 22.7 / 25.6 ms.)
+  const int team = ALT == 2 ? (wave & 1) : (wave >> 2);
+  const int slot = ALT == 2 ? (wave >> 1) : (wave & 3);          // 0 .. 3 within the team
   auto stage = [&](int kt, int buf) {
+    if constexpr (ALT != 0) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int r = q * 8 + wave;                     // 0 .. 35
-      if (q == 4 && wave >= 4) break;
-      const bool isB = r >= 12;
-      const int pl = isB ? (r - 12) >> 3 : r >> 2, seg = isB ? (r - 12) & 7 : r & 3;
-      const unsigned char* src = (isB ? gB : gA) + (static_cast<long long>(kt) * 3 + pl) * row_stride + seg * 1024;
-      unsigned char* dst = lds + buf * kWideKt + (isB ? kWideA + pl * (2 * kPlaneTileB) : pl * kPlaneTileB) + seg * 1024;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      for (int q = 0; q < 9; ++q) {
+        const int r = q * 4 + slot;                   // 0 .. 35
+        const bool isB = r >= 12;
+        const int pl = isB ? (r - 12) >> 3 : r >> 2, seg = isB ? (r - 12) & 7 : r & 3;
+        const unsigned char* src = (isB ? gB : gA) + (static_cast<long long>(kt) * 3 + pl) * row_stride + seg * 1024;
+        unsigned char* dst = lds + buf * kWideKt + (isB ? kWideA + pl * (2 * kPlaneTileB) : pl * kPlaneTileB) + seg * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int r = q * 8 + wave;                     // 0 .. 35
+        if (q == 4 && wave >= 4) break;
+        const bool isB = r >= 12;
+        const int pl = isB ? (r - 12) >> 3 : r >> 2, seg = isB ? (r - 12) & 7 : r & 3;
+        const unsigned char* src = (isB ? gB : gA) + (static_cast<long long>(kt) * 3 + pl) * row_stride + seg * 1024;
+        unsigned char* dst = lds + buf * kWideKt + (isB ? kWideA + pl * (2 * kPlaneTileB) : pl * kPlaneTileB) + seg * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
     }
   };
-  (void)mine;
+  auto stages = [&](int kt) { return ALT == 0 || ((kt - kt0) & 1) == team; };
 #pragma unroll
   for (int pre = 0; pre < 3; ++pre)
-    if (kt0 + pre < kt1) stage(kt0 + pre, pre);
+    if (kt0 + pre < kt1 && stages(kt0 + pre)) stage(kt0 + pre, pre);
   for (int kt = kt0; kt < kt1; ++kt) {
     const int buf = (kt - kt0) & 3;
     // this wave's pieces of k tile kt have landed (the pieces of later k tiles it issued since may still be in flight)
-    const int later = (kt + 1 < kt1 ? 1 : 0) + (kt + 2 < kt1 ? 1 : 0);
-    if (wave < 4) {
-      if (later == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else if (later == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (ALT != 0) {
+      if (stages(kt)) {                 // ... it also staged kt + 2, nothing in between
+        if (kt + 2 < kt1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     } else {
-      if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int later = (kt + 1 < kt1 ? 1 : 0) + (kt + 2 < kt1 ? 1 : 0);
+      if (wave < 4) {
+        if (later == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __syncthreads();          // every wave's pieces of this k tile have landed; every wave is done with k tile kt - 1's buffer
-    if (kt + 3 < kt1) stage(kt + 3, (buf + 3) & 3);
+    if (kt + 3 < kt1 && stages(kt + 3)) stage(kt + 3, (buf + 3) & 3);
     {
       const unsigned char* img = lds + buf * kWideKt;
       bf16x8 fa[2][3], fb[2][3];
@@ -935,10 +961,15 @@ int32_t xtx_bf16x3(const float* x, int64_t n, int64_t d, float* p, void* workspa
     if (wide_ok && a.patches && d % (2 * kTile) == 0 && splits == 1) {
       // 128 x 256 tiles: the same 8-XCD patch list, 32 workgroups per patch
       static const bool deep = [] { const char* e = getenv("MI355Q_XTX_DEEP"); return e == nullptr || atoi(e) != 0; }();
-      const void* fn = deep ? reinterpret_cast<const void*>(xtx_bf16x3_deep_kernel) : reinterpret_cast<const void*>(xtx_bf16x3_wide_kernel);
+      static const int alt = [] { const char* e = getenv("MI355Q_XTX_ALT"); return e == nullptr ? 1 : atoi(e); }();
+      const void* fn = !deep ? reinterpret_cast<const void*>(xtx_bf16x3_wide_kernel)
+                       : alt == 2 ? reinterpret_cast<const void*>(xtx_bf16x3_deep_kernel<2>)
+                       : alt == 1 ? reinterpret_cast<const void*>(xtx_bf16x3_deep_kernel<1>) : reinterpret_cast<const void*>(xtx_bf16x3_deep_kernel<0>);
       if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWideStageB))
         return fail(MI355Q_HIP_ERROR, "xtx bf16x3 LDS attribute: %s", hipGetErrorString(e));
-      if (deep) hipLaunchKernelGGL(xtx_bf16x3_deep_kernel, dim3(gx / 2, 1), dim3(512), 2 * kWideStageB, st, a);
+      if (deep && alt == 2) hipLaunchKernelGGL(xtx_bf16x3_deep_kernel<2>, dim3(gx / 2, 1), dim3(512), 2 * kWideStageB, st, a);
+      else if (deep && alt == 1) hipLaunchKernelGGL(xtx_bf16x3_deep_kernel<1>, dim3(gx / 2, 1), dim3(512), 2 * kWideStageB, st, a);
+      else if (deep) hipLaunchKernelGGL(xtx_bf16x3_deep_kernel<0>, dim3(gx / 2, 1), dim3(512), 2 * kWideStageB, st, a);
       else hipLaunchKernelGGL(xtx_bf16x3_wide_kernel, dim3(gx / 2, 1), dim3(512), 2 * kWideStageB, st, a);
     } else {
       hipLaunchKernelGGL(xtx_bf16x3_kernel, dim3(gx, static_cast<unsigned>(splits)), dim3(256), 4 * kOperandB, st, a);
