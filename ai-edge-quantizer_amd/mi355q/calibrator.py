@@ -98,18 +98,19 @@ class StepBlock:
     ndims        (T,)               rank of each content: min / max are shaped (1,) * ndim (ref :1380)
     hessian_dims {slot index: d}    slots whose GPTQ Hessian was set aside into a running accumulator in HBM
   `first` is the dataset index of the block's first sample (the replay order key)."""
-  __slots__ = ("slots", "stats", "num_samples", "ndims", "hessian_dims", "first")
+  __slots__ = ("slots", "stats", "num_samples", "ndims", "hessian_dims", "first", "with_hessian")
 
-  def __init__(self, slots, stats, num_samples, ndims, hessian_dims=None, first=0):
+  def __init__(self, slots, stats, num_samples, ndims, hessian_dims=None, first=0, with_hessian=()):
     self.slots, self.stats, self.num_samples, self.ndims = slots, stats, num_samples, ndims
     self.hessian_dims, self.first = dict(hessian_dims or {}), first
+    self.with_hessian = frozenset(with_hessian)      # slots whose samples went into a Hessian statistic (tagged or not)
 
   def __len__(self) -> int:
     return int(self.stats.shape[0])
 
   def __reduce__(self):
     return (StepBlock, (self.slots, np.array(self.stats, np.float32), np.array(self.num_samples), self.ndims,
-                        self.hessian_dims, self.first))
+                        self.hessian_dims, self.first, tuple(sorted(self.with_hessian))))
 
   def qsv(self, k: int, t: int) -> dict:
     """The event record of sample k, slot t, as the per-sample walk builds it."""
@@ -522,7 +523,7 @@ class Calibrator:
     block = StepBlock(tuple((s[0], hessian_tag if (t in hessian_dims and hessian_tag) else s[1], s[2])
                             for t, s in enumerate(slots)),
                       pinned.numpy(), np.array(leading, np.int64).reshape(taken, n_slots), ndims,
-                      hessian_dims if hessian_tag else None, first)
+                      hessian_dims if hessian_tag else None, first, tuple(hessian_dims))
     for key in uploaded_keys:          # the uploads of this block: their launch is queued, the allocator orders the reuse
       described.pop(key, None)
     return block, taken, unfit
@@ -744,10 +745,12 @@ class Calibrator:
         if fresh is not None and "hessian" not in out:
           out["hessian"] = fresh
         if cur is not None and "hessian" in out and t not in block.hessian_dims:
-          # the Hessian's own sample count, where it is not the QSV's (samples without a Hessian were merged into this
-          # QSV before: utils/qsv_utils.gptq_and_moving_average_update keeps the two apart)
+          # the Hessian's own sample count, where it is not the QSV's (one side of a merge had no Hessian:
+          # utils/qsv_utils.gptq_and_moving_average_update keeps the two counts apart)
           mine = block.num_samples[:, t].sum()
-          if "hessian" not in cur:
+          if t not in block.with_hessian:                      # these samples brought none: the Hessian stays what it was
+            out["hessian_num_samples"] = cur.get("hessian_num_samples", cur.get("num_samples", 0))
+          elif "hessian" not in cur:                           # the QSV had none so far
             out["hessian_num_samples"] = mine
           elif "hessian_num_samples" in cur:
             out["hessian_num_samples"] = cur["hessian_num_samples"] + mine
