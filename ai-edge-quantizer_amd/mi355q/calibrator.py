@@ -63,6 +63,13 @@ def _describe(v) -> Optional[list]:
   if isinstance(v, rt.HbmArray):
     shape, t = v.shape, v.device_tensor
   elif isinstance(v, torch.Tensor):
+    if v.is_cuda and v.dtype == torch.float32 and v.is_contiguous():
+      # the common entry -- an activation a float run left in HBM -- by the shortest way: three calls, no new tensor
+      n = v.numel()
+      if not n:
+        return None
+      shape = v.shape
+      return [v, v, v.data_ptr(), n, shape[0] if len(shape) else 1, len(shape), None, 0]
     shape, t = tuple(v.shape), v.detach()
     if t.dtype == torch.bfloat16:         # (as runtime.resident_sample: widening is exact)
       t = t.float()

@@ -311,6 +311,15 @@ def more_extras(torch, ops, gen, xs) -> dict:
   ms = timed_ms(torch, lambda: ops.octav_clip(w.view(-1), 4096 * 32, 128, 4, 10, 3.0, True, True), 20, 3)
   out["octav_clip_4096x4096_int4_blockwise128"] = {"ms": round(ms, 4),
                                                    "hbm_frac_of_one_read": round(ROWS * COLS * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+  # ... and the opt-in one-read kernel (ops.octav_mode("fast"), tolerance class T2): the row stays in registers
+  with ops.octav_mode("fast"):
+    ms = timed_ms(torch, lambda: ops.octav_clip(w.view(-1), 4096, 4096, 4, 10, 3.0, True, True), 20, 3)
+    out["octav_clip_4096x4096_int4_fast"] = {"ms": round(ms, 4), "hbm_frac_of_one_read": round(ROWS * COLS * 4 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                             "note": "opt-in (T2: scales within 1e-6, not bit-exact): one pass over HBM, float32 tree sums"}
+    w2 = (torch.randn((2048, 16384), generator=gen, device="cuda") * 0.02).contiguous()
+    ms = timed_ms(torch, lambda: ops.octav_clip(w2.view(-1), 2048, 16384, 4, 10, 3.0, True, True), 20, 3)
+    out["octav_clip_2048x16384_int4_fast"] = {"ms": round(ms, 4), "hbm_frac_of_one_read": round(w2.numel() * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    del w2
   ms = timed_ms(torch, lambda: ops.hadamard_rotate(w, 4096), 50, 5)
   out["hadamard_4096x4096"] = {"ms": round(ms, 5), "roofline": {"bound": "hbm", "achieved": round(2 * ROWS * COLS * 4 / ms / 1e6, 1),
                                                                "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -3,7 +3,7 @@
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'
 # Everything lands under gpurun_out/<round>/; copy what is to be judged into profiles/.
 set -u
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$ROUND
 mkdir -p "$OUT"
@@ -91,7 +91,23 @@ python tools/pmc_big_kernels.py /tmp/prof_fetch > "$OUT/hinv16384_fetch.txt" 2>&
   MI355Q_TIMELINE=1 timeout 300 python tools/file_bench.py --repeat 3 2>/dev/null | python tools/timeline_print.py
   MI355Q_TIMELINE=1 timeout 300 python tools/file_bench.py --repeat 3 --recipe wi8 2>/dev/null | python tools/timeline_print.py
 } > "$OUT/c5_timeline.txt" 2>&1
+{
+  echo "# tools/octav_fast_bench.py: OCTAV clip search, exact (NumPy-order) kernels against the opt-in one-read kernel"
+  timeout 400 python tools/octav_fast_bench.py 2>&1 | grep "^{"
+  echo "# tools/hinv_pairs_bench.py (MI355Q_HINV_PAIRS=1: two d >= 4096 inverses in flight; default: one after the other)"
+  MI355Q_HINV_PAIRS=1 timeout 300 python tools/hinv_pairs_bench.py 16384 4 2>&1 | tail -1
+  timeout 300 python tools/hinv_pairs_bench.py 16384 4 2>&1 | tail -1
+  echo "# tools/xtx_bound.py: the Hessian product with every clock / power reading (deep kernel, then round 4's wide kernel)"
+  timeout 200 python tools/xtx_bound.py 3 2>/dev/null
+  MI355Q_XTX_DEEP=0 timeout 200 python tools/xtx_bound.py 3 2>/dev/null
+  echo "# tools/api_resident_timeline.py: 64 resident 4096 x 4096 weights through get_tensor_quant_params inside batching()"
+  timeout 200 python tools/api_resident_timeline.py 2>&1 | tail -1
+  echo "# tools/c4_bench.py through distributed.calibrate_sharded is in bench.json (sharded.c4_*); tools/c5_second_call.py --variant mixed:"
+  MI355Q_TIMELINE=1 MI355Q_C5_GAPS=1 timeout 400 python tools/c5_second_call.py --variant mixed 2>/dev/null | cut -c1-1500
+} > "$OUT/round5_tools.txt" 2>&1
 bash tools/pmc_traffic_refresh.sh "$ROUND" > "$OUT/pmc_traffic.log" 2>&1
+bash tools/c2_pmc_refresh.sh "$ROUND" > "$OUT/c2_pmc.log" 2>&1
+cp gpurun_out/${ROUND}_c2_pmc_traffic.txt gpurun_out/${ROUND}_c2_rowwise_int8_kernel_trace.txt gpurun_out/pmc_latest.json "$OUT/" 2>/dev/null
 {
   echo "# tools/gptq_parity_instances.py: the d = 16384 full chain on several instances, GPU (exact / fast Hessian product) vs the oracle's own chain"
   timeout 1500 python tools/gptq_parity_instances.py 3 32 2>&1 | grep "^{"

@@ -52,6 +52,14 @@ def main():
   for _ in range(3):
     ops.octav_clip(w2.view(-1), 2048, 16384, 4, 10, 3.0, True, True)
   out.append(("octav_rows_kernel<1, 1024>", 2048 * 16384 * 4))
+  # ... and the opt-in one-read kernel (ops.octav_mode("fast")) on the same two shapes
+  with ops.octav_mode("fast"):
+    for _ in range(3):
+      ops.octav_clip(w.view(-1), 4096, 4096, 4, 10, 3.0, True, True)
+    out.append(("octav_fast_kernel<64, 16>", 4096 * 4096 * 4))
+    for _ in range(3):
+      ops.octav_clip(w2.view(-1), 2048, 16384, 4, 10, 3.0, True, True)
+    out.append(("octav_fast_kernel<1024, 16>", 2048 * 16384 * 4))
   del w, w2
   # GPTQ apply, 2048 x 2048 int4: the column-serial kernel reads W once and writes int8 once per group of 4 blocks
   d = 2048
