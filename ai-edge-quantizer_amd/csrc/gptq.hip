@@ -880,6 +880,8 @@ struct ApplyArgs {
   float lo, hi;
   int zp_via_f64;       // int32/int64 zero points are added in FP64
   int diff_bits;        // width of (q - zp) in dequantize (8: wraps like int8 - int8)
+  int container32;      // targets of 17..32 bits: an int32 container -- (q - zp) * float32 scale is a float64 product
+                        // (NumPy's int32 x float32), a NaN or a quotient of 2^31 and beyond casts to INT32_MIN (x86)
   float* err;           // [rows, kErrLd]: this block's 64 columns start at err_col
   int err_col;
   int8_t* q;            // [rows, d]
@@ -1007,8 +1009,8 @@ __global__ __launch_bounds__(256, kRowLanes == 16 ? 4 : 1) void gptq_block_kerne
         if (with_zp) v = v + static_cast<double>(z);  // uniform; a zero zero-point changes nothing
         double q = __builtin_rint(v);
         q = fmin(fmax(q, static_cast<double>(a.lo)), static_cast<double>(a.hi));
-        qi = (v != v) ? 0 : static_cast<int>(q);
-        int dd = qi - z;
+        qi = (v != v) ? (a.container32 ? INT32_MIN : 0) : (q >= 2147483648.0 ? INT32_MIN : static_cast<int>(q));
+        int dd = static_cast<int>(static_cast<unsigned>(qi) - static_cast<unsigned>(z));
         if (with_zp && a.diff_bits == 8) dd = static_cast<int8_t>(dd);  // (q itself fits int8)
         if (with_zp && a.diff_bits == 16) dd = static_cast<int16_t>(dd);
         const double dq = static_cast<double>(dd) * s;
@@ -1020,12 +1022,17 @@ __global__ __launch_bounds__(256, kRowLanes == 16 ? 4 : 1) void gptq_block_kerne
                            : v + static_cast<float>(z);
         float q = __builtin_rintf(v);
         q = fminf(fmaxf(q, a.lo), a.hi);
-        qi = (v != v) ? 0 : static_cast<int>(q);
-        int dd = qi - z;
+        const bool c32 = !kPlain && a.container32 != 0;   // uniform
+        qi = (v != v) ? (c32 ? INT32_MIN : 0) : (q >= 2147483648.f ? INT32_MIN : static_cast<int>(q));
+        int dd = static_cast<int>(static_cast<unsigned>(qi) - static_cast<unsigned>(z));
         if (with_zp && a.diff_bits == 8) dd = static_cast<int8_t>(dd);
         if (with_zp && a.diff_bits == 16) dd = static_cast<int16_t>(dd);
-        const float dq = static_cast<float>(dd) * s;
-        e = wi - dq;
+        if (c32) {   // int32 * float32 is a float64 product in NumPy, and np.subtract(f32, f64, out=f32) rounds once
+          e = static_cast<float>(static_cast<double>(wi) - static_cast<double>(dd) * static_cast<double>(s));
+        } else {
+          const float dq = static_cast<float>(dd) * s;
+          e = wi - dq;
+        }
       }
       e = e / hd[i];
       const bool mine_col = l == i / kColsPerLane;
@@ -2043,7 +2050,7 @@ int32_t gptq_apply_impl(const float* w, int64_t rows, int64_t d, const float* hi
   if (rows == 0 || d == 0) return MI355Q_OK;
   if (rows > 0x7FFFFFFF || d > 0x7FFFFFFF) return fail(MI355Q_UNSUPPORTED, "dimension too large");
   if (!wide && (bits < 2 || bits > 8)) return fail(MI355Q_UNSUPPORTED, "gptq apply supports 2..8 bits (wider targets: mi355q_gptq_apply_wide_f32)");
-  if (wide && (bits < 9 || bits > 16)) return fail(MI355Q_UNSUPPORTED, "gptq apply (wide) supports 9..16 bits");
+  if (wide && (bits < 9 || bits > 32)) return fail(MI355Q_UNSUPPORTED, "gptq apply (wide) supports 9..32 bits");
   if (scale_mode < 0 || scale_mode > 2) return fail(MI355Q_BAD_ARG, "bad scale_mode");
   if (scale_mode == 2 && (block_size <= 0 || d % block_size != 0))
     return fail(MI355Q_BAD_SHAPE, "Quantized dimension %lld is not divisible by block size %d.",
@@ -2064,13 +2071,15 @@ int32_t gptq_apply_impl(const float* w, int64_t rows, int64_t d, const float* hi
   void* upd_ws = err + rows * kErrLd;
   if (split_upd)
     if (int32_t s = upd_bf16x3_prepare(hinv, d, upd_ws, st)) return s;
-  const double qmax = static_cast<double>((1 << (bits - 1)) - 1), qmin = -static_cast<double>(1 << (bits - 1));
+  // (the bounds become float32 the way np.clip's Python floats do: 2^(bits-1) - 1 rounds up to 2^(bits-1) from 26 bits on)
+  const double qmax = static_cast<double>((1LL << (bits - 1)) - 1), qmin = -static_cast<double>(1LL << (bits - 1));
   ApplyArgs a{};
   a.w = wc; a.rows = static_cast<int>(rows); a.d = static_cast<int>(d); a.hinv = hinv; a.scale = scale;
   a.zp = zero_point; a.scale_mode = scale_mode; a.block_size = block_size > 0 ? block_size : 1;
   a.nblk = scale_mode == 2 ? static_cast<int>(d / block_size) : 1;
   a.lo = static_cast<float>(narrow ? qmin + 1 : qmin); a.hi = static_cast<float>(qmax);
   a.zp_via_f64 = zp_via_f64; a.diff_bits = diff_bits; a.err = err; a.q = q_out; a.q32 = q_out32;
+  a.container32 = bits > 16 ? 1 : 0;
   // (Tried: look-ahead -- only the next group's 256 columns updated on this stream, the rest on the
   // library's side stream underneath the next chain, two alternating error buffers. The chain's
   // workgroups then wait for CUs the update holds: 0.77 -> 0.91 ms at 2048 x 2048, 11.0 -> 11.1 ms
@@ -2099,7 +2108,7 @@ int32_t gptq_apply_impl(const float* w, int64_t rows, int64_t d, const float* hi
       a.err_col = c0 - g0;
       const int rl = row_lanes_for(rows);
       const dim3 grid(static_cast<unsigned>((rows + (256 / rl) - 1) / (256 / rl)));
-      const bool plain = a.nb == NB && zero_point == nullptr && !(scale_mode == 2 && block_size % 32 != 0);
+      const bool plain = a.nb == NB && zero_point == nullptr && !(scale_mode == 2 && block_size % 32 != 0) && !a.container32;
 #define MI355Q_BLOCK(ST, RL, PL) hipLaunchKernelGGL((gptq_block_kernel<ST, RL, PL>), grid, dim3(256), 0, st, a)
       if (scale_is_f64) {
         if (rl == 32) { if (plain) MI355Q_BLOCK(double, 32, true); else MI355Q_BLOCK(double, 32, false); }

@@ -469,12 +469,15 @@ def _apply_gptq(tensor_content: np.ndarray, quant_params: qtyping.UniformQuantPa
                 tensor_quant_config: qtyping.TensorQuantizationConfig,
                 blocksize: int = 64) -> qtyping.UniformQuantParams:
   """Blocked OBS update + column-serial quantization (ref :131-216)."""
-  if blocksize != 64:
-    raise NotImplementedError("the GPU kernel is built for the reference's blocksize of 64")
-  if tensor_quant_config.num_bits > 16:
-    # (ref :141-151 gives 17..32-bit targets an int32 container; float32 cannot hold their clip bounds, the reference's policy
-    # admits 2-, 4- and 8-bit weights only, and nothing asks for them: refused)
-    raise NotImplementedError("GPTQ kernel supports <= 16 bit targets")
+  if not isinstance(blocksize, (int, np.integer)) or blocksize < 1:
+    raise ValueError(f"blocksize must be a positive integer, got {blocksize!r}")
+  # `blocksize` is how many columns the reference sweeps before it pushes their errors into the columns behind them
+  # (ref :162-214): a schedule of the same updates -- in exact arithmetic every blocksize gives the same integers, in
+  # float32 it moves where the far columns are rounded. The kernels sweep 64 columns (and push up to four blocks at once
+  # where that never moved an integer, csrc/gptq.hip); another blocksize is answered by the same kernels, within the
+  # tolerance class (T2) every GPTQ result is in -- tests/test_gpu_gptq.py compares against the oracle at 1, 16, 100, 128, 256.
+  if tensor_quant_config.num_bits > 32:
+    raise ValueError(f"Unsupported num_bits for quantization: {tensor_quant_config.num_bits}")    # ref :141-151
   if tensor_content.ndim != 2 or tensor_content.dtype != np.float32:
     raise TypeError("GPTQ expects a 2-D float32 weight")
   rt.require_gpu()
@@ -493,12 +496,13 @@ def _apply_gptq(tensor_content: np.ndarray, quant_params: qtyping.UniformQuantPa
   z_dev = (rt.to_device(np.ascontiguousarray(np.broadcast_to(zp, scale.shape).reshape(-1)).astype(np.int32))
            if np.any(zp) else None)
   narrow = bool(quant_params.symmetric and quant_params.num_bits >= 8)
-  target = np.int8 if quant_params.num_bits <= 8 else np.int16      # ref :141-151 (_get_quantized_dtype)
+  target = (np.int8 if quant_params.num_bits <= 8 else np.int16 if quant_params.num_bits <= 16
+            else np.int32)                                            # ref :141-151 (_get_quantized_dtype)
   diff_bits = min(32, np.result_type(target, zp.dtype).itemsize * 8)
   q = ops.gptq_apply(rt.to_device(tensor_content), hinv, s_dev, z_dev, mode, bs,
                      quant_params.num_bits, narrow, zp.dtype.itemsize >= 4, diff_bits)
   _check_info(info)
-  if quant_params.num_bits > 8:      # (the wide entry point returns int32: narrowed to the reference's container)
+  if 8 < quant_params.num_bits <= 16:      # (the wide entry point returns int32: narrowed to the reference's container)
     import torch
     q = q.to(torch.int16)
   return dataclasses.replace(quant_params, quantized_data=rt.quantized_result(

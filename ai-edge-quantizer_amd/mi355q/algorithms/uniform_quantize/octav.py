@@ -54,13 +54,24 @@ def _guess_clipping_with_octav(x: np.ndarray, bits: int, axis, max_iterations: i
     # turns the guess into (1,)*ndim on the first iteration
     reduced = (1,) * x.ndim if max_iterations > 0 and x.ndim > 0 else (1,)
   view = _unit_view(x, axis)
-  if view is None:
-    raise NotImplementedError("OCTAV with two kept axes separated by a reduced one")
   if x.size == 0:
     return np.ones(reduced, dtype=np.float32)
   xf = uniform_quantize_tensor._as_f32_exact(x)  # pylint: disable=protected-access
   rt.require_gpu()
   xd = rt.to_device(xf.reshape(-1))
+  if view is None:
+    # Two kept axes with a reduced one in between (x [A, R, C] reduced over axis 1; the reference's np.sum takes any axis
+    # tuple, ref :55-61, no op of its tables makes one -- weights are reduced over whole trailing or leading axes). The
+    # kernels address [outer, channels, inner]; here the reduced axes are moved last on the device and each unit summed as
+    # one contiguous run. That is NumPy's pairwise order for a contiguous run, not the order NumPy walks the original
+    # layout in: the clipping constants are within the tolerance class SURVEY 7 gives OCTAV (T2, 1e-6 relative), not
+    # bit-exact like every layout above (tests/test_gpu_algorithms.py::test_octav_kept_axes_separated_by_a_reduced_one).
+    kept = [d for d in range(x.ndim) if d not in ax]
+    moved = xd.reshape(tuple(x.shape)).permute(kept + [d for d in range(x.ndim) if d in ax]).contiguous()
+    units = int(np.prod([x.shape[d] for d in kept], dtype=np.int64))
+    clip, _ = ops.octav_clip(moved.view(-1), units, int(x.size // units), bits, max_iterations, exponent_divisor,
+                             early_stop, axis_given=True)
+    return rt.to_numpy(clip).reshape(reduced)
   if view[0] == 1:
     clip, _ = ops.octav_clip(xd, view[1], view[2], bits, max_iterations, exponent_divisor,
                              early_stop, axis_given=axis is not None)

@@ -157,10 +157,29 @@ def _channel_view(shape: Sequence[int], pshape: Sequence[int]) -> tuple[int, int
     return 1, 1, int(np.prod(shape, dtype=np.int64))
   a, b = full[0], full[-1] + 1
   if any(shape[i] != 1 and pshape[i] == 1 for i in range(a, b)):
-    raise NotImplementedError("scale varies over non-adjacent dimensions; no kernel for this"
-                              f" layout (tensor {tuple(shape)}, scale {tuple(pshape)})")
+    raise ValueError(f"scale {tuple(pshape)} varies over dimensions of {tuple(shape)} that are not adjacent:"
+                     " _adjacent_params first")
   return (int(np.prod(shape[:a], dtype=np.int64)), int(np.prod(shape[a:b], dtype=np.int64)),
           int(np.prod(shape[b:], dtype=np.int64)))
+
+
+def _adjacent_params(shape: Sequence[int], scale: np.ndarray, zp: np.ndarray):
+  """Parameters that vary over dimensions with a broadcast one in between (scale [A, 1, C] over a tensor [A, B, C]: the
+  reference's arithmetic is NumPy broadcasting, ref :273-409, and takes any such shape; no op of its tables makes one) are
+  repeated over the dimensions in between, so that they vary over ONE run of adjacent dimensions -- which is what the
+  kernels' [outer, channels, inner] view addresses. The values every element meets are the same."""
+  pshape = tuple(scale.shape)
+  full = [i for i, p in enumerate(pshape) if p != 1]
+  if len(pshape) != len(shape) or len(full) < 2:
+    return scale, zp
+  a, b = full[0], full[-1] + 1
+  if not any(shape[i] != 1 and pshape[i] == 1 for i in range(a, b)):
+    return scale, zp
+  filled = tuple(shape[i] if a <= i < b else pshape[i] for i in range(len(shape)))
+  scale = np.ascontiguousarray(np.broadcast_to(scale, filled))
+  if zp is not None and np.size(zp) > 1:
+    zp = np.ascontiguousarray(np.broadcast_to(zp, filled))
+  return scale, zp
 
 
 def _flat_params(scale: np.ndarray, zp: np.ndarray, compute64: bool):
@@ -220,6 +239,8 @@ def uniform_quantize_on_device(tensor_data: np.ndarray, quantization_params: qty
   if tensor_data.size == 0:
     return None
   compute64 = np.result_type(tensor_data.dtype, scale.dtype) == np.float64
+  if block_view is None:
+    scale, zp = _adjacent_params(tensor_data.shape, scale, zp)
   outer, ch, inner = block_view or _channel_view(tensor_data.shape, scale.shape)
   s, z = _flat_params(scale, zp, compute64)
   rt.require_gpu()
@@ -290,6 +311,8 @@ def uniform_dequantize(tensor_data: np.ndarray,
       raise TypeError(f"uniform_dequantize expects int8/int16/int32 data, got {tensor_data.dtype}")
   diff = np.result_type(tensor_data.dtype, zp.dtype)
   diff_bits = min(32, diff.itemsize * 8)
+  if view is None:
+    scale, zp = _adjacent_params(tensor_data.shape, scale, zp)
   outer, ch, inner = view or _channel_view(tensor_data.shape, scale.shape)
   s, z = _flat_params(scale, zp, False)
   rt.require_gpu()

@@ -670,11 +670,11 @@ def hessian_product(mode: str = "exact"):
 def gptq_apply(w: torch.Tensor, hinv: torch.Tensor, scale: torch.Tensor,
                zero_point: torch.Tensor | None, scale_mode: int, block_size: int, bits: int,
                narrow: bool, zp_via_f64: bool, diff_bits: int) -> torch.Tensor:
-  """K10. int8 [rows, d] (int32 for targets of 9..16 bits). ref: gptq.py:131-216."""
+  """K10. int8 [rows, d] (int32 for targets of 9..32 bits). ref: gptq.py:131-216."""
   rt.require_gpu()
   w = _f32(w)
   rows, d = w.shape
-  wide = bits > 8         # int32 [rows, d] from mi355q_gptq_apply_wide_f32 (9..16 bits; the caller narrows the container)
+  wide = bits > 8         # int32 [rows, d] from mi355q_gptq_apply_wide_f32 (9..16 bits: the caller narrows the container; 17..32: int32 is the container)
   q = rt.empty((rows, d), torch.int32 if wide else torch.int8)
   if zero_point is not None:
     zero_point = zero_point.to(torch.int32).contiguous()

@@ -422,11 +422,14 @@ int32_t mi355q_gptq_apply_f32(const float* w, int64_t rows, int64_t d, const flo
                               int32_t scale_mode, int32_t block_size, int32_t bits, int32_t narrow,
                               int32_t zp_via_f64, int32_t diff_bits, int8_t* q_out, void* workspace,
                               size_t workspace_bytes, void* stream);
-/* The same sweep for targets of 9..16 bits (ref gptq.py:141-151: `_get_quantized_dtype` gives int16 / int32 containers;
+/* The same sweep for targets of 9..32 bits (ref gptq.py:141-151: `_get_quantized_dtype` gives int16 / int32 containers;
  * the reference's policy admits 2-, 4- and 8-bit weights only, so only a direct caller of get_tensor_quant_params gets
- * here): q_out int32 [rows, d] -- the host narrows to the container the reference returns --, the general 64-column
- * block kernel (one launch per block: the symmetric fast path packs bytes), the far update per block as for 8 bits;
- * diff_bits 16 wraps q - zp like int16 - int16. Same workspace. */
+ * here): q_out int32 [rows, d] -- for 9..16 bits the host narrows to the int16 the reference returns --, the general
+ * 64-column block kernel (one launch per block: the symmetric fast path packs bytes), the far update per block as for
+ * 8 bits; diff_bits 16 wraps q - zp like int16 - int16. From 17 bits on the container is int32 and the reference's
+ * float32 arithmetic is kept as it is: clip bounds are the float32 nearest to the integer bounds (2^(bits-1) from 26 bits
+ * on), a quotient of 2^31 or a NaN casts to INT32_MIN (x86), q - zp wraps in int32, (q - zp) * scale is a float64
+ * product rounded once with the subtraction (NumPy: int32 x float32). Same workspace. */
 int32_t mi355q_gptq_apply_wide_f32(const float* w, int64_t rows, int64_t d, const float* hinv,
                                    const void* scale, int32_t scale_is_f64, const int32_t* zero_point,
                                    int32_t scale_mode, int32_t block_size, int32_t bits, int32_t narrow,

@@ -468,3 +468,75 @@ def test_blockwise_along_an_axis_that_is_not_the_innermost(m, shape, qd, block, 
     back = m.uqt.uniform_dequantize(got, p)
     ref = O.uniform_dequantize(want, scale, zp, quantized_dim=qd, block_size=block)
     assert back.dtype == ref.dtype and np.array_equal(back, ref)
+
+
+@pytest.mark.parametrize("shape,axis,bits", [((6, 40, 24), (1,), 4), ((5, 300, 8), 1, 8), ((3, 16, 4, 64), (1, 3), 4),
+                                             ((4, 8, 5, 6, 32), (1, 3), 4), ((2, 1, 9, 128, 3), (3,), 2), ((7, 33, 1, 2), (1,), 4)])
+def test_octav_kept_axes_separated_by_a_reduced_one(m, shape, axis, bits):
+  """ref octav.py:55-61: np.sum takes any axis tuple. A reduced axis BETWEEN kept ones has no kernel of its own -- the
+  reduced axes are moved last on the device and each unit is summed as one contiguous run: NumPy's pairwise order for a
+  contiguous run, not the strided walk NumPy makes of the original layout, so the clipping constants are held to
+  SURVEY 7's tolerance for OCTAV (T2: 1e-6 relative) where every other layout is bit-exact. Shape, dtype, NaN / inf
+  placement and the (global) early stop are the reference's."""
+  rng = np.random.default_rng(sum(shape) + bits)
+  x = (rng.standard_normal(shape) * 0.02).astype(np.float32)
+  flat = x.reshape(-1)
+  flat[::97] *= 40.0                       # outliers the first guess selects
+  flat[5::211] = 0.0
+  flat[11] = np.nan
+  for early in (True, False):
+    with warnings.catch_warnings():
+      warnings.simplefilter("ignore")
+      ref = O.octav_clip(x, bits, axis, 10, 3.0, early_stop=early)
+      got = m.octav._guess_clipping_with_octav(x, bits, axis, 10, 3.0, early_stop=early)
+    assert got.shape == ref.shape and got.dtype == np.float32
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    rel = np.abs(got[fin].astype(np.float64) - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-30)
+    parity_rates.note(f"OCTAV clip, kept axes separated by a reduced one {shape} axis={axis} int{bits} early_stop={early}",
+                      "max_rel_error", float(rel.max()), 1e-6)
+
+
+@pytest.mark.parametrize("shape,block,bits", [((4, 64, 6), 32, 4), ((3, 128, 2, 5), 64, 8), ((2, 256, 3), 128, 4)])
+def test_blockwise_min_max_along_an_axis_that_is_not_the_innermost(m, shape, block, bits):
+  """ref common_quantize.py:1336-1352: blockwise min / max of a FULLY_CONNECTED weight of rank > 2 -- blocks run along
+  axis 1 (TFL_OP_TO_BLOCKWISE_WEIGHT_QUANTIZED_DIM), which is then not the innermost one. The blocked axis is moved last
+  on the device; a minimum does not depend on where its elements sit: bit-exact against the oracle, and so are the
+  parameters and the integers that follow from them (uniform_quantize moves the same axis, see above)."""
+  q_ = m.qtyping
+  from mi355q.algorithms.uniform_quantize import common_quantize
+  rng = np.random.default_rng(sum(shape))
+  w = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+  w[1, 3] = 0.0
+  gran = f"BLOCKWISE_{block}"
+  cfg = q_.TensorQuantizationConfig(num_bits=bits, symmetric=True, granularity=q_.QuantGranularity[gran])
+  got = common_quantize.init_tensor_min_max(w, op_info(m, "FULLY_CONNECTED", cfg))
+  ref = O.init_tensor_min_max(w, gran, 1)
+  for k in ("min", "max"):
+    assert got[k].shape == ref[k].shape and got[k].dtype == ref[k].dtype and np.array_equal(got[k], ref[k])
+  zp, scale = O.zp_scale_from_min_max(ref["min"], ref["max"], bits, True, gran, None)
+  zp2, scale2 = m.uqt.tensor_zp_scale_from_min_max(got["min"], got["max"], bits, True, q_.QuantGranularity[gran], None)
+  assert np.array_equal(scale, scale2) and np.array_equal(zp, zp2)
+  p = q_.UniformQuantParams(scale=scale2, zero_point=zp2, num_bits=bits, symmetric=True, quantized_dimension=1, block_size=block)
+  want = O.uniform_quantize(w, scale, zp, bits, True, quantized_dim=1, block_size=block, is_blockwise_quant=True)
+  assert np.array_equal(m.uqt.uniform_quantize(w, p, is_blockwise_quant=True), want)
+
+
+@pytest.mark.parametrize("shape,pshape,bits,symmetric", [((4, 5, 6), (4, 1, 6), 8, True), ((2, 4, 5, 6), (1, 4, 1, 6), 4, False),
+                                                         ((3, 7, 1, 5, 2), (3, 1, 1, 5, 1), 8, False), ((6, 9, 8), (6, 1, 8), 16, True)])
+def test_parameters_that_vary_over_non_adjacent_dimensions(m, shape, pshape, bits, symmetric):
+  """ref uniform_quantize_tensor.py:273-409 is NumPy broadcasting and takes scales of any broadcastable shape of the
+  tensor's rank; the kernels address one run of adjacent dimensions, so parameters with a broadcast dimension in between
+  ([4, 1, 6] over [4, 5, 6]) are repeated over it first. Elementwise arithmetic with the same operands: bit-exact."""
+  q_ = m.qtyping
+  rng = np.random.default_rng(sum(shape) + bits)
+  x = (rng.standard_normal(shape) * 0.5).astype(np.float32)
+  scale = (rng.random(pshape) * 0.01 + 0.002).astype(np.float32)
+  zp = np.zeros(pshape, np.int32) if symmetric else rng.integers(-5, 6, pshape).astype(np.int32)
+  p = q_.UniformQuantParams(scale=scale, zero_point=zp, num_bits=bits, symmetric=symmetric, quantized_dimension=None)
+  got = m.uqt.uniform_quantize(x, p)
+  want = O.uniform_quantize(x, scale, zp, bits, symmetric)
+  assert got.dtype == want.dtype and np.array_equal(got, want)
+  back = m.uqt.uniform_dequantize(got, p)
+  ref = O.uniform_dequantize(want, scale, zp)
+  assert back.dtype == ref.dtype and np.array_equal(back, ref)

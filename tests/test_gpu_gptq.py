@@ -866,7 +866,113 @@ def test_targets_wider_than_8_bits(m, bits, symmetric, gran, shape):
   assert got.dtype == np.int16 and got.shape == w.shape
   assert np.array_equal(p.scale, scale) and np.array_equal(p.zero_point, zp)
   assert np.abs(got.astype(np.int64) - ref["quantized_data"].astype(np.int64)).max() <= (1 if d <= 64 else 2)
-  # 17 bits and more stay refused
-  cfg17 = q_.TensorQuantizationConfig(num_bits=17, symmetric=True, granularity=q_.QuantGranularity.CHANNELWISE)
-  with pytest.raises(NotImplementedError):
-    m.gptq.get_tensor_quant_params(info, cfg17, w, {"activation_tensor_qsv": {"hessian": h, "num_samples": 2}})
+  # beyond 32 bits: the reference's own error (ref gptq.py:150-151)
+  cfg33 = q_.TensorQuantizationConfig(num_bits=33, symmetric=True, granularity=q_.QuantGranularity.CHANNELWISE)
+  with pytest.raises(ValueError, match="Unsupported num_bits"):
+    m.gptq.get_tensor_quant_params(info, cfg33, w, {"activation_tensor_qsv": {"hessian": h, "num_samples": 2}})
+
+
+@pytest.mark.parametrize("bits,symmetric,gran,shape", [(17, True, "CHANNELWISE", (24, 64)), (24, True, "CHANNELWISE", (40, 48)),
+                                                       (25, False, "TENSORWISE", (20, 64)), (26, True, "CHANNELWISE", (16, 33)),
+                                                       (31, True, "TENSORWISE", (16, 64)), (32, True, "CHANNELWISE", (24, 64)),
+                                                       (32, False, "CHANNELWISE", (16, 40)), (20, True, "CHANNELWISE", (24, 200)),
+                                                       (32, True, "CHANNELWISE", (16, 130))])
+def test_targets_of_17_to_32_bits(m, bits, symmetric, gran, shape):
+  """ref gptq.py:141-151, uniform_quantize_tensor.py:37-109: 17..32-bit targets get an int32 container. What the
+  reference's float32 arithmetic does there is kept as it is: np.clip's bounds become float32 (2^(bits-1) - 1 rounds UP to
+  2^(bits-1) from 26 bits on, so that integer is reachable), a quotient of 2^31 casts to INT32_MIN (x86 cvttps2dq; the
+  largest weight of a 32-bit symmetric tensor does that), q - zp wraps in int32, and (q - zp) * scale is a float64 product
+  (int32 x float32) whose difference with the weight is rounded once. Given the oracle's inverse one 64-column block is
+  bit-exact (T1) -- that pins all of the above; with several blocks the far columns differ by the order of float32
+  additions, which on a grid of 2^bits steps is 2^(bits-20) steps and more: there the dequantized weights are compared
+  (within 2^-18 of the tensor's range). The policy admits 2-, 4- and 8-bit weights only (ref default_policy.py), so only a
+  direct caller of get_tensor_quant_params gets here."""
+  rng = np.random.default_rng(bits * 1000 + shape[1])
+  rows, d = shape
+  w = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+  w[1, 0] = np.nan                      # NaN -> INT32_MIN in an int32 container (0 in the narrower ones)
+  x = rng.standard_normal((2, 256, d)).astype(np.float32)
+  h = O.gptq_hessian(x)
+  wf = np.where(np.isnan(w), np.float32(0), w)
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    mm = O.init_tensor_min_max(wf, gran, 0 if gran == "CHANNELWISE" else None)
+    zp, scale = O.zp_scale_from_min_max(mm["min"], mm["max"], bits, symmetric, gran, None)
+    hinv = O.gptq_hessian_inverse(h)
+    want = O.gptq_apply(w, scale, zp, bits, symmetric, h, gran, 0, hinv=hinv)
+  assert want.dtype == np.int32
+  mode = 0 if scale.size == 1 else 1
+  z = dev(m, np.broadcast_to(zp, scale.shape).reshape(-1).astype(np.int32)) if np.any(zp) else None
+  diff_bits = min(32, np.result_type(np.int32, zp.dtype).itemsize * 8)
+  q = host(m.ops.gptq_apply(dev(m, w), dev(m, hinv), dev(m, scale.reshape(-1).astype(np.float32)), z, mode, 0, bits,
+                            symmetric and bits >= 8, zp.dtype.itemsize >= 4, diff_bits))
+  assert q.dtype == np.int32
+  row_with_nan = np.zeros(rows, bool)
+  row_with_nan[1] = True                 # the NaN's error poisons the rest of its row (in the reference too)
+  assert q[1, 0] == want[1, 0] == np.iinfo(np.int32).min
+  if d <= 64:
+    assert np.array_equal(q[~row_with_nan], want[~row_with_nan])
+    if bits == 32 and symmetric:
+      assert (want[~row_with_nan] == np.iinfo(np.int32).min).any()      # the quotient 2^31 is in the case
+  else:
+    s_b = np.broadcast_to(scale.reshape(-1, 1) if mode else scale.reshape(1, 1), (rows, d)).astype(np.float64)
+    dq_got = (q.astype(np.float64) * s_b)[~row_with_nan]
+    dq_ref = (want.astype(np.float64) * s_b)[~row_with_nan]
+    wrapped = (q == np.iinfo(np.int32).min)[~row_with_nan] | (want == np.iinfo(np.int32).min)[~row_with_nan]
+    assert np.array_equal((q == np.iinfo(np.int32).min)[~row_with_nan], (want == np.iinfo(np.int32).min)[~row_with_nan])
+    parity_rates.check_rel(f"gptq apply {bits}-bit {gran} [{rows},{d}] dequantized vs oracle (same Hinv)",
+                           dq_got[~wrapped], dq_ref[~wrapped], 2.0 ** -18)
+  # the public entry point: container, scales, zero points
+  q_ = m.qtyping
+  cfg = q_.TensorQuantizationConfig(num_bits=bits, symmetric=symmetric, granularity=q_.QuantGranularity[gran])
+  info = q_.OpInfo(op=q_.OperatorT(), op_name=q_.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
+                   op_quant_config=q_.OpQuantizationConfig(weight_tensor_config=cfg))
+  with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    ref = O.gptq_quant_params(wf, bits, symmetric, gran, {"activation_tensor_qsv": {"hessian": h, "num_samples": 2}})
+    p = m.gptq.get_tensor_quant_params(info, cfg, wf, {"activation_tensor_qsv": {"hessian": h, "num_samples": 2}})
+  got = np.asarray(p.quantized_data)
+  assert got.dtype == np.int32 and got.shape == w.shape
+  assert np.array_equal(p.scale, ref["scale"]) and np.array_equal(p.zero_point, ref["zero_point"])
+  s_b = np.broadcast_to(np.asarray(ref["scale"], np.float64).reshape(-1, 1) if mode else np.asarray(ref["scale"], np.float64).reshape(1, 1), (rows, d))
+  same_wrap = (got == np.iinfo(np.int32).min) == (ref["quantized_data"] == np.iinfo(np.int32).min)
+  keep = (got != np.iinfo(np.int32).min) & same_wrap
+  # (end to end the inverse is the build's own: the wrap of a quotient that sits at 2^31 +- a rounding may fall on either side)
+  assert (~same_wrap).mean() <= 0.01
+  parity_rates.check_rel(f"gptq end to end {bits}-bit {gran} [{rows},{d}] dequantized vs oracle",
+                         (got.astype(np.float64) * s_b)[keep], (ref["quantized_data"].astype(np.float64) * s_b)[keep], 2.0 ** -16)
+
+
+@pytest.mark.parametrize("blocksize", [1, 16, 100, 128, 256, 1000])
+@pytest.mark.parametrize("bits,gran", [(4, "CHANNELWISE"), (8, "CHANNELWISE"), (4, "BLOCKWISE_32")])
+def test_any_blocksize(m, blocksize, bits, gran):
+  """ref gptq.py:131-216 `blocksize`: how many columns are swept before their errors are pushed into the columns behind
+  them. The same updates in another schedule -- the kernels keep their 64-column sweep and answer any blocksize. Two
+  comparisons: with the oracle at 64 (the default-path gate) and with the oracle run WITH that blocksize, where the
+  allowance is what the oracle's own two schedules differ by."""
+  rng = np.random.default_rng(blocksize * 10 + bits)
+  d, rows = 320, 96
+  w = (rng.standard_normal((rows, d)) * 0.05).astype(np.float32)
+  x = rng.standard_normal((4, 256, d)).astype(np.float32)
+  x[..., 7] *= 5
+  h = O.gptq_hessian(x)
+  bs = O.block_size_of(gran)
+  mm = O.init_tensor_min_max(w, gran, 1 if bs else 0)
+  zp, scale = O.zp_scale_from_min_max(mm["min"], mm["max"], bits, True, gran, None)
+  want = O.gptq_apply(w, scale, zp, bits, True, h.copy(), gran, bs, blocksize=blocksize)
+  at_64 = O.gptq_apply(w, scale, zp, bits, True, h.copy(), gran, bs)
+  q_ = m.qtyping
+  cfg = q_.TensorQuantizationConfig(num_bits=bits, symmetric=True, granularity=q_.QuantGranularity[gran])
+  params = q_.UniformQuantParams(scale=scale, zero_point=zp, num_bits=bits, symmetric=True,
+                                 quantized_dimension=1 if bs else 0, block_size=bs)
+  p = m.gptq._apply_gptq(w, params, {"hessian": h.copy(), "num_samples": 4}, cfg, blocksize=blocksize)
+  got = np.asarray(p.quantized_data)
+  # against the oracle at the kernels' own schedule (64): the default-path gate; against the oracle WITH the asked
+  # blocksize: no further than the oracle's two schedules are from each other (recorded: 0 ... 2 of 30 720 integers)
+  parity_rates.check_default_path(f"gptq apply blocksize={blocksize} int{bits} {gran} [96,320] vs oracle at blocksize 64",
+                                  got, at_64)
+  parity_rates.check_with_floor(f"gptq apply blocksize={blocksize} int{bits} {gran} [96,320] vs oracle with that blocksize",
+                                got, want, at_64, cap=2e-4, k=1.0, max_step=1)
+  for bad in (0, -64, 2.5):
+    with pytest.raises(ValueError, match="blocksize"):
+      m.gptq._apply_gptq(w, params, {"hessian": h.copy(), "num_samples": 4}, cfg, blocksize=bad)

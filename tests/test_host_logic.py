@@ -132,8 +132,18 @@ def test_host_helpers_and_validation_errors():
   assert uqt._channel_view((8, 3, 3, 16), (8, 1, 1, 1)) == (1, 8, 144)
   assert uqt._channel_view((1, 3, 3, 24), (1, 1, 1, 24)) == (9, 24, 1)
   assert uqt._channel_view((4, 5), (1, 1)) == (1, 1, 20)
-  with pytest.raises(NotImplementedError):
+  with pytest.raises(ValueError, match="not adjacent"):
     uqt._channel_view((4, 5, 6), (4, 1, 6))
+  # ... which is why such parameters are repeated over the dimensions in between first (NumPy broadcasting, ref :273-409)
+  sc = np.arange(24, dtype=np.float32).reshape(4, 1, 6) + 1
+  zpt = np.arange(24, dtype=np.int8).reshape(4, 1, 6)
+  s2, z2 = uqt._adjacent_params((4, 5, 6), sc, zpt)
+  assert s2.shape == z2.shape == (4, 5, 6) and np.array_equal(s2, np.broadcast_to(sc, (4, 5, 6)))
+  assert np.array_equal(z2, np.broadcast_to(zpt, (4, 5, 6))) and uqt._channel_view((4, 5, 6), s2.shape) == (1, 120, 1)
+  s3, z3 = uqt._adjacent_params((2, 4, 5, 6), sc.reshape(1, 4, 1, 6), np.zeros((1, 1, 1, 1), np.int8))
+  assert s3.shape == (1, 4, 5, 6) and z3.shape == (1, 1, 1, 1) and uqt._channel_view((2, 4, 5, 6), s3.shape) == (2, 120, 1)
+  for keep in (sc.reshape(4, 6, 1), sc.reshape(1, 4, 6)[:, :, :1]):
+    assert uqt._adjacent_params((4, 6, 7), keep, None)[0] is keep
   x = np.array([-3.0, 1.3, 2.4, 16.0])
   p = q.UniformQuantParams(4, 0, np.array([[[1.2666667]]]), np.array([[-6]]))
   with pytest.raises(ValueError, match=r"Ranks of scales \(3\) and zps \(2\)"):
