@@ -73,6 +73,7 @@ struct Job {
   size_t n;
   bool write;
   Latch* latch;
+  unsigned char* mapped = nullptr;   // a write whose destination is memory (the output file's own shared mapping): copied, not pwritten
 };
 
 struct Pool {
@@ -97,6 +98,10 @@ struct Pool {
       }
       size_t done = 0;
       int err = 0;
+      if (j.mapped != nullptr) {       // (pages that exist: no inode lock, the copies of several threads run side by side)
+        memcpy(j.mapped, j.p, j.n);
+        done = j.n;
+      }
       while (done < j.n) {
         const ssize_t k = j.write ? pwrite(j.fd, j.p + done, j.n - done, j.at + static_cast<long long>(done))
                                   : pread(j.fd, j.p + done, j.n - done, j.at + static_cast<long long>(done));
@@ -124,7 +129,7 @@ struct Pool {
     for (int i = 0; i < n; ++i) threads.emplace_back([this] { run(0); });
     for (int i = 0; i < nw; ++i) threads.emplace_back([this] { run(1); });
   }
-  void submit(int fd, long long at, unsigned char* p, size_t n, bool write, Latch* latch) {
+  void submit(int fd, long long at, unsigned char* p, size_t n, bool write, Latch* latch, unsigned char* mapped = nullptr) {
     const int parts = static_cast<int>((n + kPartBytes - 1) / kPartBytes);
     {
       std::lock_guard<std::mutex> l(latch->m);
@@ -133,7 +138,8 @@ struct Pool {
     {
       std::lock_guard<std::mutex> l(m);
       for (size_t o = 0; o < n; o += kPartBytes)
-        q[write ? 1 : 0].push_back(Job{fd, at + static_cast<long long>(o), p + o, n - o < kPartBytes ? n - o : kPartBytes, write, latch});
+        q[write ? 1 : 0].push_back(Job{fd, at + static_cast<long long>(o), p + o, n - o < kPartBytes ? n - o : kPartBytes, write, latch,
+                                       mapped ? mapped + o : nullptr});
     }
     cv.notify_all();
   }
@@ -296,8 +302,9 @@ int32_t upload_body(int32_t fd, int64_t file_offset, int64_t nbytes, void* dst, 
   return MI355Q_OK;
 }
 
-int32_t download_body(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset, void* copy_stream, hipEvent_t gate) {
-  if (nbytes < 0 || file_offset < 0 || fd < 0) return fail(MI355Q_BAD_ARG, "bad file range");
+int32_t download_body(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset, void* copy_stream, hipEvent_t gate,
+                      unsigned char* mapped = nullptr) {
+  if (nbytes < 0 || file_offset < 0 || (fd < 0 && !mapped)) return fail(MI355Q_BAD_ARG, "bad file range");
   if (nbytes == 0) return MI355Q_OK;
   if (!src) return fail(MI355Q_BAD_ARG, "null pointer");
   std::lock_guard<std::mutex> lock(g_mutex[1]);
@@ -314,7 +321,8 @@ int32_t download_body(const void* src, int64_t nbytes, int32_t fd, int64_t file_
   size_t pending_size = 0;
   auto drain = [&] {            // the pending slot's copy has arrived: hand it to the writers
     (void)hipEventSynchronize(r->left[pending_slot]);
-    p.submit(fd, file_offset + pending_off, r->pinned[pending_slot], pending_size, true, &r->io[pending_slot]);
+    p.submit(fd, file_offset + pending_off, r->pinned[pending_slot], pending_size, true, &r->io[pending_slot],
+             mapped ? mapped + pending_off : nullptr);
   };
   for (long long off = 0; off < nbytes; off += static_cast<long long>(kSlotBytes)) {
     const size_t size = static_cast<size_t>(nbytes - off < static_cast<long long>(kSlotBytes) ? nbytes - off : static_cast<long long>(kSlotBytes));
@@ -344,6 +352,7 @@ struct Transfer {
   void* device_ptr = nullptr;
   void* stream = nullptr;
   hipEvent_t gate = nullptr;      // download: the caller's event behind which the payload is final (may be null)
+  unsigned char* mapped = nullptr; // download: destination in memory instead of (fd, file_offset)
   int device = 0;
   bool enqueued = false;
   int32_t status = MI355Q_OK;
@@ -382,7 +391,7 @@ struct Driver {
         message = "hipSetDevice on the transfer thread failed";
       } else {
         status = t.upload ? upload_body(t.fd, t.file_offset, t.nbytes, t.device_ptr, t.stream)
-                          : download_body(t.device_ptr, t.nbytes, t.fd, t.file_offset, t.stream, t.gate);
+                          : download_body(t.device_ptr, t.nbytes, t.fd, t.file_offset, t.stream, t.gate, t.mapped);
         if (status != MI355Q_OK) message = mi355q_last_error();      // (this thread's)
       }
       {
@@ -491,6 +500,20 @@ extern "C" int32_t mi355q_file_io_submit_download(const void* src, int64_t nbyte
   Transfer t;
   t.upload = false; t.fd = fd; t.file_offset = file_offset; t.nbytes = nbytes; t.device_ptr = const_cast<void*>(src); t.stream = copy_stream;
   t.gate = reinterpret_cast<hipEvent_t>(ready_event);
+  int64_t ticket = 0;
+  return submit(t, &ticket);
+}
+
+extern "C" int32_t mi355q_file_io_submit_download_mapped(const void* src, int64_t nbytes, void* dst, void* copy_stream,
+                                                         void* ready_event) {
+  clear_error();
+  if (nbytes < 0) return fail(MI355Q_BAD_ARG, "negative size");
+  if (nbytes == 0) return MI355Q_OK;
+  if (!src || !dst) return fail(MI355Q_BAD_ARG, "null pointer");
+  Transfer t;
+  t.upload = false; t.fd = -1; t.file_offset = 0; t.nbytes = nbytes; t.device_ptr = const_cast<void*>(src); t.stream = copy_stream;
+  t.gate = reinterpret_cast<hipEvent_t>(ready_event);
+  t.mapped = static_cast<unsigned char*>(dst);
   int64_t ticket = 0;
   return submit(t, &ticket);
 }

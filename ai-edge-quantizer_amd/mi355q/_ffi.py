@@ -108,6 +108,7 @@ PROTOTYPES = {
     "mi355q_file_io_submit_upload": (c_i32, [c_i32, c_i64, c_i64, c_ptr, c_ptr, ctypes.POINTER(c_i64)]),
     "mi355q_file_io_wait": (c_i32, [c_i64]),
     "mi355q_file_io_submit_download": (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr]),
+    "mi355q_file_io_submit_download_mapped": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "mi355q_prepare_device": (c_i32, []),
     "mi355q_clock_probe": (c_i32, [c_f64, c_ptr, c_ptr]),
     "mi355q_device_alloc": (c_i32, [c_size, ctypes.POINTER(ctypes.c_void_p)]),

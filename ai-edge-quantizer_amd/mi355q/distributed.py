@@ -353,6 +353,48 @@ def plan_model_shards(float_model, recipe, world_size: int, calibration_result: 
   return qz, gen, plan, plan_op_shards(costs, world_size, shared_constant_links(plan)), costs
 
 
+def expected_model_bytes(float_model, plan: Sequence[tuple]) -> int:
+  """How long the serialized model is expected to be once `plan` has been carried out (0: no idea): the float model's
+  length minus what the planned weights lose -- a float32 weight of n elements quantized to b bits is n * b / 8 bytes
+  (sub-byte types are packed, ref uniform_quantize_tensor.pack_data) -- plus the scales a channel or a block gets. An
+  expectation, not a promise: it sizes the pages allocated ahead of time (LiteRTLMFile.prepare_output), the writer lays
+  the file out from the sizes it finds."""
+  try:
+    length = os.path.getsize(float_model) if isinstance(float_model, (str, os.PathLike)) else len(memoryview(float_model).cast("B"))
+  except (TypeError, ValueError, OSError):
+    return 0
+  seen: set = set()
+  saved = 0
+  for graph_info, op, _, op_key, _, cfg in plan:
+    w = getattr(cfg, "weight_tensor_config", None) if cfg is not None else None
+    if w is None or op_key is None or getattr(op, "inputs", None) is None:
+      continue
+    for index in list(op.inputs)[1:2]:          # the weight of FULLY_CONNECTED / CONV / EMBEDDING_LOOKUP-like ops
+      if index is None or index < 0:
+        continue
+      tensor = graph_info.subgraph_tensors[index]
+      shape = tensor.shape
+      if tensor.buffer in seen or shape is None or not len(shape) or tensor.type != 0:      # (0: FLOAT32)
+        continue
+      data = graph_info.buffers[tensor.buffer].data
+      have = len(data) if data is not None else 0
+      numel = int(np.prod(shape, dtype=np.int64))
+      if have < numel * 4:
+        continue                                # (not a constant: an activation feeds this input)
+      seen.add(tensor.buffer)
+      bits = int(w.num_bits)
+      kept = (numel * bits + 7) // 8 if bits in (2, 4) else numel * ((bits + 7) // 8)
+      # one float32 scale and one int64 zero point per channel / block / tensor in the tensor's quantization table
+      g = str(getattr(w.granularity, "name", w.granularity))
+      block = int(g.rsplit("_", 1)[1]) if g.startswith("BLOCKWISE_") and g.rsplit("_", 1)[1].isdigit() else 0
+      groups = numel // block if block else (int(shape[0]) if g == "CHANNELWISE" else 1)
+      saved += numel * 4 - kept - 12 * groups
+  expected = length - saved
+  # (+ 3 % and 1 MiB: the tables of a quantized model are longer, Hadamard ops carry their own constants; pages past
+  # the length the writer finds out are given back)
+  return int(expected + (expected >> 5) + (1 << 20)) if 0 < expected <= length else 0
+
+
 def hessian_owners(plan: Sequence[tuple], owner: Sequence[int], costs) -> dict[str, int]:
   """Activation tensor name -> the one rank whose ops read its GPTQ Hessian."""
   out: dict[str, int] = {}
@@ -580,6 +622,10 @@ def calibrate_and_quantize_sharded(float_model, recipe, calibration_data, serial
   planned = plan_model_shards(float_model, recipe, world)
   rt.mark("planned")
   qz, gen, plan, owner, costs = planned
+  if rank == 0 and sink is not None and hasattr(sink, "expect"):
+    expected = expected_model_bytes(float_model, plan)
+    if expected:
+      sink.expect(expected)       # (the output file's pages are allocated underneath the calibration)
   owners = hessian_owners(plan, owner, costs) if world > 1 else None
   qsvs = None
   reserved: list = []          # ops.HinvWorkspace of the large inverses, released when the call is over

@@ -94,6 +94,7 @@ _DOWNLOAD_STREAMS: dict = {}   # device index -> the download stream (the two di
 _DOWNLOADS_IN_FLIGHT: list = []    # (payload tensor, ready event) of submitted downloads, kept until finish_downloads()
 _FILE_MAPPINGS: list = []  # _FileMapping records of model files mapped by tfl_flatbuffer_utils
 _OUT_MAPPINGS: list = []   # (base address, length, file descriptor) of output files being built
+_OUT_PAGES_EXIST: dict = {}   # base address -> bytes from the start of the file whose pages are allocated and mapped in
 
 
 class _FileMapping:
@@ -142,13 +143,18 @@ def register_file_mapping(mapping, fd: int) -> None:
   _FILE_MAPPINGS.append(rec)
 
 
-def register_output_mapping(mapping, fd: int) -> None:
+def register_output_mapping(mapping, fd: int, pages_exist: int = 0) -> None:
   """The writable mapping of an output file and its descriptor: device-resident buffers then reach
   the file by pwrite() from pinned staging (HbmArray.copy_into) instead of a pageable copy that
-  faults every fresh page of the mapping in on one thread."""
+  faults every fresh page of the mapping in on one thread. `pages_exist`: the first so many bytes of the file have
+  their pages already (allocated ahead of time and mapped in, LiteRTLMFile.prepare_output): payloads that lie inside are
+  copied into the mapping by the io threads instead of pwritten (mi355q_file_io_submit_download_mapped)."""
   base = np.frombuffer(mapping, dtype=np.uint8).ctypes.data
   _OUT_MAPPINGS[:] = [m for m in _OUT_MAPPINGS if m[0] != base][-3:]
   _OUT_MAPPINGS.append((base, len(mapping), fd))
+  _OUT_PAGES_EXIST[base] = int(pages_exist)
+  for k in [k for k in _OUT_PAGES_EXIST if all(k != m[0] for m in _OUT_MAPPINGS)]:
+    del _OUT_PAGES_EXIST[k]
 
 
 def forget_output_mapping(mapping) -> None:
@@ -157,6 +163,7 @@ def forget_output_mapping(mapping) -> None:
   except (ValueError, TypeError):
     return
   _OUT_MAPPINGS[:] = [m for m in _OUT_MAPPINGS if m[0] != base]
+  _OUT_PAGES_EXIST.pop(base, None)
 
 
 def _backing_mapping(arr):
@@ -429,6 +436,18 @@ def _submit_download(src: torch.Tensor, fd: int, offset: int, ready=None) -> Non
   _DOWNLOADS_IN_FLIGHT.append((src, ready))
 
 
+def _submit_download_mapped(src: torch.Tensor, address: int, ready=None) -> None:
+  """`src` (flat uint8, device) -> host memory at `address` (inside an output file's mapping whose pages exist) through the
+  download ring: staged in pinned slots, copied from there by the io threads. Same ordering and lifetime as _submit_download."""
+  if ready is None:
+    ready = torch.cuda.Event()
+    ready.record()
+  st = _download_stream(src.device)
+  _ffi.check(_ffi.lib().mi355q_file_io_submit_download_mapped(ctypes.c_void_p(src.data_ptr()), src.numel(), ctypes.c_void_p(address),
+                                                              ctypes.c_void_p(st.cuda_stream), ctypes.c_void_p(ready.cuda_event)))
+  _DOWNLOADS_IN_FLIGHT.append((src, ready))
+
+
 def download_into_file(t: torch.Tensor, dst: np.ndarray, ready=None) -> bool:
   """Device bytes -> the output file whose mapping `dst` is a view of (register_output_mapping):
   asynchronous copies into the pinned download ring and pwrite() from there on the io threads, driven by the
@@ -440,7 +459,11 @@ def download_into_file(t: torch.Tensor, dst: np.ndarray, ready=None) -> bool:
     return False        # (every size goes through the download thread: a pageable copy of a 256 KB k_proj payload is ordered behind
                         # everything queued on the compute stream and held the writer's loop in lock step with the GPU)
   base, fd = hit
-  _submit_download(t.contiguous().reshape(-1).view(torch.uint8), fd, addr - base, ready)
+  flat = t.contiguous().reshape(-1).view(torch.uint8)
+  if addr - base + dst.nbytes <= _OUT_PAGES_EXIST.get(base, 0) and not os.environ.get("MI355Q_DOWNLOADS_BY_PWRITE"):
+    _submit_download_mapped(flat, addr, ready)
+  else:
+    _submit_download(flat, fd, addr - base, ready)
   return True
 
 

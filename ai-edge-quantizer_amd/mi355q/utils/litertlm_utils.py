@@ -70,6 +70,40 @@ def _scalar_of(value: Any) -> Any:
   return value
 
 
+_KEPT: list = []      # the mapping of the last output file built in place (see _set_aside)
+
+
+def _set_aside(holder: dict) -> None:
+  """The file is complete and closed; what is left of its mapping is address space -- and a gigabyte of populated
+  page-table entries, whose munmap() is 45-50 ms during which the process's other threads wait for the address-space lock
+  (measured: on a thread of its own the caller's return still took them). The mapping is kept instead and taken down
+  where that costs nothing: by the helper thread of the next output file (prepare_output), or by the process's exit."""
+  mapping = holder.pop("mapping", None)
+  if mapping is not None:
+    _KEPT.append(mapping)
+
+
+def _drop_kept() -> None:
+  while _KEPT:
+    try:
+      _KEPT.pop().close()
+    except (BufferError, ValueError):      # (a view of it is still alive somewhere: unmapped when that goes)
+      pass
+
+
+def _populate(mapping, length: int) -> None:
+  """Page-table entries for the first `length` bytes of a shared mapping whose pages exist (Linux 5.14+
+  MADV_POPULATE_WRITE; anything else: the first touch of each page maps it, as always)."""
+  import ctypes
+  import numpy as np
+  try:
+    libc = ctypes.CDLL(None, use_errno=True)
+    address = np.frombuffer(mapping, dtype=np.uint8).ctypes.data
+    libc.madvise(ctypes.c_void_p(address), ctypes.c_size_t(length), ctypes.c_int(23))     # MADV_POPULATE_WRITE
+  except (OSError, AttributeError, ValueError):
+    pass
+
+
 class LiteRTLMFile:
   """Sections of a `.litertlm` file (memory mapped, nothing is copied until serialize)."""
 
@@ -152,6 +186,54 @@ class LiteRTLMFile:
       struct.pack_into("<Q", header, HEADER_BEGIN_BYTE_OFFSET + end_at, offsets[sid] + lengths[sid])
     return header, offsets, lengths, offsets[-2] + lengths[-1]
 
+  def prepare_output(self, path: Path, section_id: int, expected_section_bytes: int) -> None:
+    """Creates the output file NOW -- before anything is quantized -- and has its pages allocated on a helper thread
+    (posix_fallocate of the container's expected size: header, the other sections, `expected_section_bytes` for the
+    one that will change). A gigabyte of fresh page-cache pages is 65 ms of allocation on a 256-core host and makes
+    pwrite() 8 instead of 14 GB/s (tools/tmpfs_write_probe.py); done here it sits underneath calibration instead of
+    behind the last kernel, where a C5 mixed call spent 0.15-0.33 of its 0.6 s waiting for the file
+    (profiles/r05_c5_mixed_tail.txt). The expectation may be wrong either way: open_with_section sets the length it
+    finds out, pages past it are given back, pages short of it are allocated by the writes as before."""
+    import threading
+    if not self._sections or expected_section_bytes <= 0:
+      return
+    self.discard_prepared()
+    _, _, _, total = self._layout({section_id: int(expected_section_bytes)})
+    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+    state = {"path": path, "fd": fd, "bytes": total, "error": None}
+
+    def allocate():
+      try:
+        _drop_kept()                 # (the previous output's mapping, if this process made one)
+        os.posix_fallocate(fd, 0, total)
+        # ... and mapped in: the page-table entries of 1 GB are 30 ms of minor faults for the threads that copy into the
+        # mapping otherwise (16 against 30 GB/s, tools/tmpfs_write_probe.py). madvise(MADV_POPULATE_WRITE) through ctypes,
+        # which lets go of the interpreter lock -- mmap.mmap(..., MAP_POPULATE) holds it for the 60 ms this takes, and the
+        # thread that feeds the GPU stood still for them
+        state["mapping"] = mmap.mmap(fd, total)
+        _populate(state["mapping"], total)
+      except (OSError, ValueError) as e:   # (a file system without room or without fallocate: the writes allocate, as before)
+        state["error"] = e
+    state["thread"] = threading.Thread(target=allocate, name="mi355q-output-pages", daemon=True)
+    state["thread"].start()
+    self._prepared = state
+
+  def discard_prepared(self, remove: bool = True) -> None:
+    """Drops a file prepare_output made and nobody built into (a call that failed before its writer ran)."""
+    state = getattr(self, "_prepared", None)
+    if state is None:
+      return
+    self._prepared = None
+    state["thread"].join()
+    if state.get("mapping") is not None:
+      state["mapping"].close()
+    os.close(state["fd"])
+    if remove:
+      try:
+        os.remove(state["path"])
+      except OSError:
+        pass
+
   def open_with_section(self, path: Path, section_id: int, section_bytes: int):
     """Creates the output file for a container whose section `section_id` will be `section_bytes`
     long, writes the header and every other section, and returns (mapping, writable view of the
@@ -161,12 +243,28 @@ class LiteRTLMFile:
       raise ValueError("LiteRT-LM file has no sections")
     self.close_built_in_place()      # (a writer that builds its model a second time asks again)
     header, offsets, lengths, total = self._layout({section_id: section_bytes})
-    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+    prepared = getattr(self, "_prepared", None)
+    out, pages_exist = None, 0
+    if prepared is not None and os.path.abspath(prepared["path"]) == os.path.abspath(path):
+      self._prepared = None
+      prepared["thread"].join()
+      fd = prepared["fd"]            # (its pages are there; the length becomes what the layout says)
+      early = prepared.get("mapping")
+      if early is not None and prepared["error"] is None:
+        pages_exist = min(prepared["bytes"], total)
+        if prepared["bytes"] >= total:
+          out = early                # longer than the file from here on: nothing past `total` is ever touched
+        else:
+          early.close()              # (expected too little: a mapping of the right length, its last pages fresh)
+    else:
+      self.discard_prepared()
+      fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
     os.ftruncate(fd, total)
-    out = mmap.mmap(fd, total)
-    # device-resident buffers of the model reach the file through the io ring (pinned staging + pwrite());
-    # the caller finishes the writes and closes `fd` (close_built_in_place)
-    runtime.register_output_mapping(out, fd)
+    if out is None:
+      out = mmap.mmap(fd, total)
+    # device-resident buffers of the model reach the file through the io ring (pinned staging, then pwrite() -- or a copy
+    # into this mapping where its pages exist); the caller finishes the writes and closes `fd` (close_built_in_place)
+    runtime.register_output_mapping(out, fd, pages_exist=pages_exist)
     self._built_in_place = (out, fd)
     out[:len(header)] = header
     for sid in range(len(self._sections)):
@@ -302,7 +400,15 @@ def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path, overw
           built_in_place.update(mapping=mapping, size=size)
           if stats is not None:
             stats["repack_s"] = stats.get("repack_s", 0.0) + (time.perf_counter() - t0)
+            stats["section_bytes"] = int(total)
           return place
+        # (whoever plans the model before it is quantized says how long it expects the section to get: the file is
+        # created and its pages are allocated underneath the calibration, LiteRTLMFile.prepare_output)
+        def expect(expected, sid=sid):
+          if stats is not None:
+            stats["expected_section_bytes"] = int(expected)
+          src.prepare_output(output_path, sid, expected)
+        sink.expect = expect
       data = _pick(calibration_data, sid, model_type)
       if data is not None:
         result = distributed.calibrate_and_quantize_sharded(
@@ -316,11 +422,14 @@ def quantize_litertlm(litertlm_path: Path, recipe: Any, output_path: Path, overw
         replaced[sid] = result
   finally:
     runtime.mark("container: model sections done (host)")
+    src.discard_prepared()         # (only a call that failed before its writer ran still has one: that file goes away)
     src.close_built_in_place()     # (the io ring's writes into the output file are done, its descriptor is closed)
     runtime.mark("container: output file complete (host)")
   if built_in_place:
     # (no msync: a shared mapping is coherent with the page cache, readers see the bytes at once)
-    return built_in_place["size"]
+    size = built_in_place["size"]
+    _set_aside(built_in_place)
+    return size
   if not replaced:          # a rank other than the group's first: nothing to write
     return None
   t0 = time.perf_counter()

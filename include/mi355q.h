@@ -598,6 +598,15 @@ int32_t mi355q_file_io_submit_upload(int32_t fd, int64_t file_offset, int64_t nb
 int32_t mi355q_file_io_wait(int64_t ticket);
 int32_t mi355q_file_io_submit_download(const void* src, int64_t nbytes, int32_t fd, int64_t file_offset,
                                        void* copy_stream, void* ready_event);
+/* The same download with memory as its destination (round 5): `dst` is the payload's place inside the OUTPUT FILE'S OWN
+ * shared mapping, whose pages exist already (the host allocates them ahead of time, LiteRTLMFile.prepare_output). The io
+ * threads then copy each staged piece into the mapping instead of pwrite()ing it: buffered writes of several threads to
+ * one file take turns on its inode lock (11 GB/s into allocated pages with 4 threads, 7 into fresh ones), copies into
+ * mapped pages do not (22 - 30 GB/s with 4 - 8 threads; tools/tmpfs_write_probe.py). Same queue, gate and completion
+ * (mi355q_file_io_finish) as mi355q_file_io_submit_download; `dst` .. `dst + nbytes` must stay mapped until then.
+ * ref: model_modifier.py:290-391 (the reference copies every quantized buffer into one host bytearray). */
+int32_t mi355q_file_io_submit_download_mapped(const void* src, int64_t nbytes, void* dst, void* copy_stream,
+                                              void* ready_event);
 
 #ifdef __cplusplus
 } /* extern "C" */

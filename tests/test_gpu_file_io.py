@@ -145,6 +145,76 @@ def test_submitted_transfers_do_not_hold_the_caller_and_arrive_whole(m, tmp_path
   del big
 
 
+def test_downloads_into_the_output_files_own_mapping(m, tmp_path):
+  """mi355q_file_io_submit_download_mapped (round 5): the destination is memory -- the output file's shared mapping, its
+  pages allocated ahead of time -- and the io threads copy instead of pwrite(). Ragged sizes and offsets, mixed with
+  pwritten downloads into the same file, gated on a late producer; what a reader of the FILE sees are the produced bytes;
+  null pointers are MI355Q_BAD_ARG. runtime.download_into_file takes this route exactly for payloads inside the part of
+  a registered mapping whose pages exist."""
+  import mmap
+  torch, L = m.torch, m.ffi.lib()
+  total = (40 << 20) + 4096
+  path = str(tmp_path / "mapped.bin")
+  fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
+  os.posix_fallocate(fd, 0, total)
+  mm = mmap.mmap(fd, total)
+  view = np.frombuffer(mm, dtype=np.uint8)
+  base = view.ctypes.data
+  down = torch.cuda.Stream()
+  big = torch.randn((8192, 8192), device="cuda")
+  for _ in range(10):
+    big = big @ big * 1e-4
+  pieces = [(5, (17 << 20) + 3), ((17 << 20) + 64, (9 << 20) + 1), ((27 << 20), 4097), ((28 << 20), 1), ((29 << 20) + 7, 8 << 20)]
+  made = []
+  try:
+    for k, (off, n) in enumerate(pieces):
+      t = ((torch.arange(n, device="cuda", dtype=torch.int32) * (k + 3)) % 253).to(torch.uint8)
+      ready = torch.cuda.Event()
+      ready.record()
+      made.append((off, t, ready))
+      if k == 2:      # one through the descriptor, between the mapped ones
+        m.ffi.check(L.mi355q_file_io_submit_download(ctypes.c_void_p(t.data_ptr()), n, fd, off, ctypes.c_void_p(down.cuda_stream),
+                                                     ctypes.c_void_p(ready.cuda_event)))
+      else:
+        m.ffi.check(L.mi355q_file_io_submit_download_mapped(ctypes.c_void_p(t.data_ptr()), n, ctypes.c_void_p(base + off),
+                                                            ctypes.c_void_p(down.cuda_stream), ctypes.c_void_p(ready.cuda_event)))
+    m.ffi.check(L.mi355q_file_io_finish())
+    back = np.fromfile(path, np.uint8)
+    covered = np.zeros(total, bool)
+    for off, t, _ in made:
+      assert np.array_equal(back[off:off + t.numel()], t.cpu().numpy()), off
+      covered[off:off + t.numel()] = True
+    assert not back[~covered].any()
+    assert L.mi355q_file_io_submit_download_mapped(None, 16, ctypes.c_void_p(base), None, None) == -1
+    assert L.mi355q_file_io_submit_download_mapped(ctypes.c_void_p(made[0][1].data_ptr()), 16, None, None, None) == -1
+    assert L.mi355q_file_io_submit_download_mapped(ctypes.c_void_p(made[0][1].data_ptr()), -1, ctypes.c_void_p(base), None, None) == -1
+    assert L.mi355q_file_io_submit_download_mapped(None, 0, None, None, None) == 0
+    # the host side: inside the part whose pages exist -> copied into the mapping; past it -> pwritten; both arrive
+    from mi355q import runtime as rt
+    calls = []
+    real_mapped, real_file = rt._submit_download_mapped, rt._submit_download      # pylint: disable=protected-access
+    rt._submit_download_mapped = lambda *a, **k: (calls.append("mapped"), real_mapped(*a, **k))[1]
+    rt._submit_download = lambda *a, **k: (calls.append("pwrite"), real_file(*a, **k))[1]
+    try:
+      rt.register_output_mapping(mm, fd, pages_exist=20 << 20)
+      a = (torch.arange(1 << 20, device="cuda", dtype=torch.int32) % 199).to(torch.uint8)
+      assert rt.download_into_file(a, view[(1 << 20):(2 << 20)]) and rt.download_into_file(a, view[(30 << 20):(31 << 20)])
+      assert rt.download_into_file(a, view[(19 << 20) + 1:(20 << 20) + 1])          # straddles the boundary: pwritten
+      rt.finish_downloads()
+    finally:
+      rt._submit_download_mapped, rt._submit_download = real_mapped, real_file      # pylint: disable=protected-access
+      rt.forget_output_mapping(mm)
+    assert calls == ["mapped", "pwrite", "pwrite"]
+    back = np.fromfile(path, np.uint8)
+    for lo in ((1 << 20), (30 << 20), (19 << 20) + 1):
+      assert np.array_equal(back[lo:lo + (1 << 20)], a.cpu().numpy())
+  finally:
+    del view
+    mm.close()
+    os.close(fd)
+  del big
+
+
 def _sha(path):
   h = hashlib.sha256()
   with open(path, "rb") as f:

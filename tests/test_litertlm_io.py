@@ -91,3 +91,49 @@ def test_rejects_bad_files(tmp_path):
   p.write_bytes(data)
   with pytest.raises(ValueError, match="out of range"):
     L.LiteRTLMFile(p)
+
+
+@pytest.mark.parametrize("expected_is", ["more", "less", "exact"])
+def test_output_file_prepared_ahead_of_time(tmp_path, expected_is):
+  """LiteRTLMFile.prepare_output creates the output file and allocates (and maps) its pages on a helper thread before
+  anything is quantized; open_with_section then sets the length the layout asks for -- whether more, less or exactly as
+  much was expected -- and the container built in place is the one serialize() writes."""
+  from mi355q import runtime
+  f = L.LiteRTLMFile(FIXTURE)
+  sid = next(i for i, s in enumerate(f.sections) if f.read_model(i) is not None)
+  section = bytes(f.get_section_buffer(sid))
+  new = section + b"\x5a" * 12345
+  want = tmp_path / "want.litertlm"
+  n_want = f.serialize(want, {sid: new})
+  out = tmp_path / "out.litertlm"
+  expected = {"more": len(new) + 300000, "less": len(new) - 20000, "exact": len(new)}[expected_is]
+  f.prepare_output(out, sid, expected)
+  assert os.path.exists(out)
+  mapping, place, size = f.open_with_section(out, sid, len(new))
+  assert size == n_want and len(place) == len(new) and os.path.getsize(out) == n_want
+  base = np.frombuffer(mapping, dtype=np.uint8).ctypes.data
+  exist = runtime._OUT_PAGES_EXIST.get(base)                   # pylint: disable=protected-access
+  assert exist == (n_want if expected_is != "less" else exist) and 0 < exist <= n_want
+  place[:] = new
+  del place
+  f.close_built_in_place()
+  assert base not in runtime._OUT_PAGES_EXIST                 # pylint: disable=protected-access
+  assert open(out, "rb").read() == open(want, "rb").read()
+
+
+def test_prepared_output_of_a_call_that_failed_goes_away(tmp_path):
+  f = L.LiteRTLMFile(FIXTURE)
+  out = tmp_path / "never.litertlm"
+  f.prepare_output(out, 0, 1 << 20)
+  assert os.path.exists(out)
+  f.discard_prepared()
+  assert not os.path.exists(out)
+  f.discard_prepared()                                          # (nothing left: a no-op)
+  # a second preparation replaces the first; a writer that asks for another path gets a file of its own
+  f.prepare_output(out, 0, 1 << 20)
+  f.prepare_output(out, 0, 2 << 20)
+  other = tmp_path / "other.litertlm"
+  mapping, place, size = f.open_with_section(other, 0, 4096)
+  assert not os.path.exists(out) and os.path.getsize(other) == size
+  del place
+  f.close_built_in_place()

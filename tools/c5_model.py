@@ -265,7 +265,7 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
   torchrun: samples and ops are sharded over the ranks, Hessians reduced to their owners."""
   import torch
   import torch.distributed as dist
-  from mi355q import distributed as Dm, ops
+  from mi355q import distributed as Dm, ops, runtime as rt
   from mi355q.utils import litertlm_utils
   rank, world = Dm._world()   # pylint: disable=protected-access
   d, dkv, dff = shapes
@@ -305,7 +305,9 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
   t0 = time.perf_counter()
   with ops.hessian_product(hessian):      # "exact": the default three-way bfloat16 split; "fast": the opt-in two-way float16 one
     n_out = litertlm_utils.quantize_litertlm(src, rcp, dst, overwrite=True, calibration_data=data, stats=stats)
+  rt.mark("returned (host)")
   torch.cuda.synchronize()
+  rt.mark("device drained (host)")
   if prof is not None:
     import pstats
     prof.disable()
@@ -341,6 +343,7 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
       quantize_and_write_s=round(stats.get("quantize_and_write_s", 0.0), 3), repack_s=round(stats.get("repack_s", 0.0), 3),
       s_per_layer=round((t2 - t0) / layers, 4), weight_bytes=weight_bytes,
       weight_GBps=round(weight_bytes / (t2 - t0) / 1e9, 2), out_bytes=n_out, build_s=round(t_build, 2),
+      section_bytes=stats.get("section_bytes"), expected_section_bytes=stats.get("expected_section_bytes"),
       gpu_busy_s_rank0=busy, gpu_busy_total_s=None if busy is None else round(sum(busy.values()), 3),
       gpu_busy_frac=None if busy is None else round(sum(busy.values()) / (t2 - t0), 3),
       trace=trace or None, per_rank=per_rank,
