@@ -1233,7 +1233,11 @@ size_t octav_groups_smem() {
 }
 
 // candidates per mask a row may hand to its tail (an eighth of the row, a multiple of 64)
-int octav_tail_cap(int len) { const int c = ((len / 8) + 63) & ~63; return c < 64 ? 64 : c; }
+int octav_tail_cap(int len) {
+  static const int div = [] { const char* e = getenv("MI355Q_OCTAV_TAIL_DIV"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 256 ? v : 8; }();
+  const int c = ((len / div) + 63) & ~63;
+  return c < 64 ? 64 : c;
+}
 
 int octav_rows_threads(int len) {
   const int npieces = (len + kPiece - 1) / kPiece;
