@@ -339,6 +339,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<typename TL::Elem> g
     }
   }
   // ---- epilogue
+  if (partial == nullptr && g.c32 == nullptr && g.beta != T(0)) {
+    // read-modify-write: a row of MFMA tiles asks for its old values before it needs the first (see gemm_fast_body)
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      T old[TM][NREG];
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          const long long i = i0 + wi + a * MF + acc_row(T(0), r, lane);
+          const long long j = j0 + wj + b * MF + fi;
+          old[b][r] = (i < g.M && j < g.N && (!g.lower_only || j <= i)) ? g.C[i * g.c_i + j * g.c_j] : T(0);
+        }
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          const long long i = i0 + wi + a * MF + acc_row(T(0), r, lane);
+          const long long j = j0 + wj + b * MF + fi;
+          const T p = g.alpha * acc[a][b][r];  // P is rounded first, as sgemm-then-update does
+          if (i < g.M && j < g.N && (!g.lower_only || j <= i)) g.C[i * g.c_i + j * g.c_j] = g.beta * old[b][r] + p;
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -536,6 +561,33 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs<typename TL::Elem>
     }
   }
   const bool diag = g.lower_only && bi == bj;
+#if !defined(MI355Q_GEMM_SERIAL_EPILOGUE)   // (tuning hook, tools/gemm_bench.py: defined = the epilogue of rounds 1-4 alone)
+  // A read-modify-write tile asks for its old values a row of MFMA tiles at a time, before it needs the first of them:
+  // written as `*c = beta * *c + p` per element (below), the stores and loads may alias as far as the compiler knows, so
+  // every element waits for its own round trip to HBM -- TM * TM * NREG = 64 of them in a row for the 128 x 128 FP64 tile.
+  // Whole tiles only here: elements above a diagonal tile's diagonal are inside C, read and not written.
+  if (partial == nullptr && g.c32 == nullptr && g.beta != T(0)) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      T old[TM][NREG];
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r)
+          old[b][r] = g.C[(i0 + wi + a * MF + acc_row(T(0), r, lane)) * g.c_i + (j0 + wj + b * MF + fi) * g.c_j];
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          const long long i = i0 + wi + a * MF + acc_row(T(0), r, lane);
+          const long long j = j0 + wj + b * MF + fi;
+          const T p = g.alpha * acc[a][b][r];
+          if (!diag || j <= i) g.C[i * g.c_i + j * g.c_j] = g.beta * old[b][r] + p;
+        }
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll

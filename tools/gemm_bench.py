@@ -1,6 +1,7 @@
 """FP64 / FP32 GEMM kernel timing for tuning gemm.hip variants on the GPU box.
 
   python tools/gemm_bench.py [--defs "-DFOO=1;-DBAR"]      # ';'-separated variant flag sets
+  python tools/gemm_bench.py --libs "a.so;b.so"              # libraries built beforehand (tools/build_variant.sh)
 Each variant compiles csrc/*.{hip,cpp} into /tmp/libmi355q_<n>.so with the extra flags and is
 timed (HIP events, interleaved rounds, medians) on three FP64 shapes of the Hessian inverse:
 full 8192^3, the rank-64 lower trailing update at n = 16384 and the L^-T L^-1 product.
@@ -20,11 +21,12 @@ import __graft_entry__ as g  # noqa: E402
 CSRC = os.path.join(ROOT, "ai-edge-quantizer_amd", "csrc")
 
 
-def build(idx, flags):
-  out = f"/tmp/libmi355q_{idx}.so"
-  srcs = [os.path.join(CSRC, s) for s in g.SOURCES]
-  cmd = ["/opt/rocm/bin/hipcc", *g.HIPCC_FLAGS, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *flags, *srcs, "-o", out]
-  subprocess.run(cmd, check=True)
+def build(idx, flags, prebuilt=None):
+  out = prebuilt or f"/tmp/libmi355q_{idx}.so"
+  if prebuilt is None:
+    srcs = [os.path.join(CSRC, s) for s in g.SOURCES]
+    cmd = ["/opt/rocm/bin/hipcc", *g.HIPCC_FLAGS, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *flags, *srcs, "-o", out]
+    subprocess.run(cmd, check=True)
   lib = ctypes.CDLL(out)
   lib.mi355q_gemm_f64.restype = ctypes.c_int32
   lib.mi355q_gemm_f64.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
@@ -37,10 +39,16 @@ def build(idx, flags):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--defs", default="")
+  ap.add_argument("--libs", default="")
   ap.add_argument("--rounds", type=int, default=5)
   a = ap.parse_args()
-  variants = [v.split() for v in a.defs.split(";")] if a.defs else [[]]
-  libs = [build(i, v) for i, v in enumerate(variants)]
+  if a.libs:
+    paths = [os.path.abspath(v) for v in a.libs.split(";") if v]
+    variants = [[os.path.basename(v)] for v in paths]
+    libs = [build(i, [], v) for i, v in enumerate(paths)]
+  else:
+    variants = [v.split() for v in a.defs.split(";")] if a.defs else [[]]
+    libs = [build(i, v) for i, v in enumerate(variants)]
   n = 16384
   A = torch.randn((n, n), dtype=torch.float64, device="cuda")
   B = torch.randn((n, n), dtype=torch.float64, device="cuda")

@@ -53,6 +53,12 @@ def phases(path):
   sym = max(i for i, r in enumerate(rows) if "mirror_lower_f32" in r[0])
   gemms = [i for i, r in enumerate(rows) if "gemm" in r[0]]
   prod = max(i for i in gemms if i < sym)
+  prod_end = prod + 1
+  # d >= 4096: L^-T L^-1 runs on the bf16 split (ltl_bf16x3: split kernels + xtx_bf16x3_kernel with the triangular k range),
+  # not as a kernel with "gemm" in its name -- everything between the last merge product and the mirror is the product
+  split_ltl = [i for i, r in enumerate(rows) if put < i < sym and "xtx_bf16x3" in r[0]]
+  if split_ltl and split_ltl[-1] > prod:
+    prod, prod_end = prod + 1, sym
   def span(a, b):
     sel = rows[a:b]
     return sum(r[3] for r in sel), (sel[-1][2] - sel[0][1]) if sel else 0
@@ -60,7 +66,7 @@ def phases(path):
   for label, a, b in (("cholesky (two-level blocked, potf2 + GEMMs)", 0, put),
                       ("  of which chol_step / potf2 + trsm_panel (the serial chain)", None, None),
                       ("triangular inverse (pairwise merge GEMMs)", put, prod),
-                      ("L^-T L^-1 product", prod, prod + 1), ("mirror of the float32 lower triangle", sym, sym + 1)):
+                      ("L^-T L^-1 product", prod, prod_end), ("mirror of the float32 lower triangle", sym, sym + 1)):
     if a is None:
       t = sum(r[3] for r in rows[:last_potf2 + 1] if "potf2_" in r[0] or "trsm_panel" in r[0] or "chol_step" in r[0])
       print(f"{t / 1e3:12.1f} {'':>12}  {label}")
