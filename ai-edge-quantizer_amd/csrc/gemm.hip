@@ -31,6 +31,11 @@
 namespace mi355q {
 namespace {
 
+// 16-byte operand pieces as NATIVE vectors: with HIP's float4 / double2 structs a staged piece was a memcpy into a stack
+// object the compiler did not promote (global -> scratch -> LDS in every K step of the m-contiguous operand modes).
+typedef float F32x4 __attribute__((ext_vector_type(4)));
+typedef double F64x2 __attribute__((ext_vector_type(2)));
+
 template <typename T>
 struct Tile;
 template <>
@@ -44,7 +49,7 @@ struct Tile<float> {
   static constexpr bool DBUF = true;  // two LDS buffers (one barrier per K step)
   using Elem = float;
   using Acc = __attribute__((ext_vector_type(16))) float;
-  using Vec = float4;
+  using Vec = F32x4;
 };
 template <>
 struct Tile<double> {
@@ -63,7 +68,7 @@ struct Tile<double> {
   static constexpr bool DBUF = MI355Q_F64_DBUF != 0;
   using Elem = double;
   using Acc = __attribute__((ext_vector_type(4))) double;
-  using Vec = double2;
+  using Vec = F64x2;
 };
 // The merge products of a small triangular inverse (d = 2048: two batched launches per level, at
 // most one 64 x 64 tile per CU) are chains of K / BK steps that each wait ~1.2 us for their
@@ -84,7 +89,7 @@ struct TileF32K64 {
   static constexpr bool DBUF = false;   // 2 x 33 KB of LDS
   using Elem = float;
   using Acc = __attribute__((ext_vector_type(16))) float;
-  using Vec = float4;
+  using Vec = F32x4;
 };
 // ... and when even those 128 x 128 tiles are fewer than the CUs (every group but the first few of a
 // d = 2048 layer), a quarter of the tile: its 512 MFMAs per wave (13.7 us at K = 256) become 128.
@@ -98,7 +103,7 @@ struct TileF32Small {
   static constexpr bool DBUF = false;
   using Elem = float;
   using Acc = __attribute__((ext_vector_type(16))) float;
-  using Vec = float4;
+  using Vec = F32x4;
 };
 struct TileF64K32 {
   static constexpr int MF = 16;
@@ -110,7 +115,7 @@ struct TileF64K32 {
   static constexpr bool DBUF = false;
   using Elem = double;
   using Acc = __attribute__((ext_vector_type(4))) double;
-  using Vec = double2;
+  using Vec = F64x2;
 };
 // Large FP64 shapes: at 64x64 the kernel needs 16 B / cycle / CU from L2 (9.8 TB/s chip-wide)
 // and saturates near 40 TFLOP/s; a 128x128 block halves that. Each wave owns 4x4 MFMA tiles
@@ -139,7 +144,7 @@ struct TileF64Big {
   static constexpr bool DBUF = MI355Q_BIG_DBUF != 0;
   using Elem = double;
   using Acc = __attribute__((ext_vector_type(4))) double;
-  using Vec = double2;
+  using Vec = F64x2;
 };
 
 __device__ __forceinline__ Tile<float>::Acc mfma(float a, float b, Tile<float>::Acc c) {
@@ -155,8 +160,8 @@ __device__ __forceinline__ int acc_row(float, int reg, int lane) {
 }
 __device__ __forceinline__ int acc_row(double, int reg, int lane) { return (lane >> 4) + 4 * reg; }
 
-__device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
-__device__ __forceinline__ double comp(const double2& v, int c) { return c == 0 ? v.x : v.y; }
+__device__ __forceinline__ float comp(const F32x4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+__device__ __forceinline__ double comp(const F64x2& v, int c) { return c == 0 ? v.x : v.y; }
 
 // How one operand tile (BM x BK, "m" = the non-k index) is fetched.
 enum LoadMode { kGeneric = 0, kMFast = 1, kKFast = 2 };
