@@ -79,6 +79,21 @@ __device__ __forceinline__ float round_scale_blockwise(float s, uint16_t* half_b
   return static_cast<float>(h);
 }
 
+// A workgroup barrier for loops whose LDS buffers are filled by global_load ... lds SEVERAL tiles ahead. __syncthreads() is a
+// release fence + s_barrier, and for the fence the compiler drains the vector-memory counter (s_waitcnt vmcnt(0)) -- it waits
+// for the pieces of LATER tiles as well, so a ring of N buffers never had more than one tile in flight across a barrier
+// whatever the s_waitcnt vmcnt(n) in front of it said (found in the ISA in round 5; every xtx kernel had it). Here the
+// caller has waited for what it needs (its own pieces of the tile about to be read: s_waitcnt vmcnt(n)); LDS reads of the
+// buffer about to be refilled have been consumed by the MFMAs that used them. The "memory" clobber keeps the compiler from
+// moving LDS accesses across it. MI355Q_FENCED_BARRIER=1 at compile time restores __syncthreads() (A / B timing).
+__device__ __forceinline__ void barrier_loads_in_flight() {
+#if defined(MI355Q_FENCED_BARRIER)
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 template <int BITS>
 struct QRange {
   static constexpr float qmax = static_cast<float>((1 << (BITS - 1)) - 1);

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512) void xtx_bf16x3_wide_kernel(XtxArgs a) {
   for (int s = 0; s < nst; ++s) {
     const int buf = s & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // this stage has landed; every wave is done with the other buffer
+    barrier_loads_in_flight();   // this stage has landed; every wave is done with the other buffer
     if (s + 1 < nst) stage(kt0 + 2 * (s + 1), buf ^ 1, kt1 - (kt0 + 2 * (s + 1)) >= 2 ? 2 : 1);
     const int here = kt1 - (kt0 + 2 * s) >= 2 ? 2 : 1;
 #pragma unroll
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(512) void xtx_bf16x3_deep_kernel(XtxArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
-    __syncthreads();          // every wave's pieces of this k tile have landed; every wave is done with k tile kt - 1's buffer
+    barrier_loads_in_flight();   // every wave's pieces of this k tile have landed; every wave is done with k tile kt - 1's buffer
     if (kt + 3 < kt1 && stages(kt + 3)) stage(kt + 3, (buf + 3) & 3);
     {
       const unsigned char* img = lds + buf * kWideKt;

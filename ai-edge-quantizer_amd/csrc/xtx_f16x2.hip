@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 
     if (DEPTH >= 4 && behind >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (DEPTH >= 3 && behind >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // this stage has landed; every wave is done with the buffer refilled next
+    barrier_loads_in_flight();   // this stage has landed; every wave is done with the buffer refilled next
     if (s + DEPTH - 1 < nst && !(a.probe & 2)) stage(kt0 + 2 * (s + DEPTH - 1), fill);
     fill = fill + 1 == DEPTH ? 0 : fill + 1;
     if (!(a.probe & 1))
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(512) void xtx_f16x2_wide_kernel(Xtx2Args a) {
     const int behind = nst - 1 - s;          // stages issued after this one (six loads per stage and wave)
     if (DEPTH >= 3 && behind >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // this stage has landed; every wave is done with the buffer refilled next
+    barrier_loads_in_flight();   // this stage has landed; every wave is done with the buffer refilled next
     if (s + DEPTH - 1 < nst && !(a.probe & 2)) stage(kt0 + 2 * (s + DEPTH - 1), fill);
     fill = fill + 1 == DEPTH ? 0 : fill + 1;
     if (!(a.probe & 1))
