@@ -610,7 +610,11 @@ __device__ __forceinline__ void gemm_fast_body(const GemmArgs<typename TL::Elem>
               g.c32[i * g.c_i + j * g.c_j] = static_cast<float>(p);
             } else {
               T* c = g.C + i * g.c_i + j * g.c_j;
+#if defined(MI355Q_GEMM_SERIAL_EPILOGUE)
               *c = (g.beta == T(0)) ? p : g.beta * (*c) + p;
+#else
+              *c = p;                    // (beta == 0 here: a read-modify-write tile has left above)
+#endif
             }
           }
         }

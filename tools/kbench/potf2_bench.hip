@@ -1,7 +1,8 @@
 // Timing of the links of the Cholesky step chain: potf2_kernel (one workgroup; phases from
 // cycle-counter stamps) and trsm_panel_kernel, on one 64 x 64 block with m rows below it.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -DMI355Q_POTF2_PROF -I include -I ai-edge-quantizer_amd/csrc \
-//         tools/kbench/potf2_bench.hip ai-edge-quantizer_amd/csrc/{api.cpp,gemm.hip} -o /tmp/potf2_bench && /tmp/potf2_bench
+//         tools/kbench/potf2_bench.hip ai-edge-quantizer_amd/csrc/{api.cpp,gemm.hip,xtx_bf16x3.hip,xtx_f16x2.hip,file_io.hip} -lpthread -ldl \
+//         -o tools/kbench/potf2_bench && tools/kbench/potf2_bench      (tools/refresh_profiles.sh runs the binary; it is git-ignored and travels with gpurun)
 #include <cmath>
 #include <cstdio>
 #include <vector>
