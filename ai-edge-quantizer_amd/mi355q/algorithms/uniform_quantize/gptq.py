@@ -139,6 +139,15 @@ class HessianAccumulator(rt.HbmArray):
       acc.add(x2d, num_samples)
     return acc
 
+  @classmethod
+  def resumed(cls, hessian, num_samples: float) -> "HessianAccumulator":
+    """An accumulator whose float64 share is a finished Hessian (the mean over `num_samples` samples: an ndarray or an
+    array resident in HBM); samples added from here on are weighed against it by the reference's rule."""
+    h = rt.on_device(hessian)
+    acc = cls(int(h.shape[0]))
+    acc._join(h, float(num_samples))
+    return acc
+
   def own(self) -> None:
     """A borrowed sample is taken over (copied into this statistic's own slab, or multiplied)."""
     if self._borrowed is not None:

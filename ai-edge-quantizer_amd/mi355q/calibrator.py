@@ -88,6 +88,10 @@ def _describe(v) -> Optional[list]:
   if t.dtype != torch.float32 or not t.numel():
     return None
   t = t.contiguous()
+  if not uploaded and isinstance(v, torch.Tensor) and (v.dtype != torch.float32 or t.data_ptr() != v.data_ptr()):
+    # a float32 copy made in HBM (bfloat16 widened, strides gathered): given back with its block, like an upload --
+    # kept until the dataset is through it would be a second copy of every such sample
+    uploaded = t.numel() * 4
   flat = t.reshape(-1)
   return [v, t.reshape(shape) if uploaded else t, flat.data_ptr(), flat.numel(), shape[0] if len(shape) else 1,
           len(shape), None, uploaded]
@@ -156,6 +160,7 @@ class Calibrator:
     self._raw_carry: dict[str, Any] = {}       # record_blocks(): the samples' entries as the caller handed them over
     self._described: dict[int, list] = {}      # id(entry) -> [entry, device tensor, pointer, numel, leading dim, ndim, tokens]
     self._new_hessians: dict[str, Any] = {}    # calibrate() over blocks: accumulators of tensors not merged yet
+    self._blocks_off = False                   # calibrate() over blocks: the rest of the dataset takes the per-sample walk
 
   # ---- signatures ---------------------------------------------------------------------------
   def get_signature_list(self) -> list[str]:
@@ -449,11 +454,36 @@ class Calibrator:
         return 1
     return max(1, min(asked or self.BLOCK_SAMPLES, self.BLOCK_ENTRIES // len(slots)))
 
+  def _blocks_keep_hessians(self, signature_key, model_recipe_manager) -> bool:
+    """Whether calibrate()'s own block merge (_replay_block with no overrides) hands every Hessian slot's accumulator
+    to the QSV. It does so on the array path only: the slot's update rule must be one that advances over whole blocks
+    (`block_mode`: the stock rules of utils/qsv_utils.py) and the stored QSV must be calibration's own float32 pair.
+    Any other rule -- a custom qsv_update_func, a wrapper or functools.partial around the stock one -- is fed the
+    block's samples as events WITHOUT a 'hessian' (the tokens went into the accumulator), so such signatures take the
+    per-sample walk, whose events carry the Hessian (ref calibrator.py:567-582, utils/qsv_utils.py:90-122)."""
+    for name, _, _, with_hessian, alg, op_key in self._plan(signature_key, model_recipe_manager)["slots"] or ():
+      if not with_hessian:
+        continue
+      update = (self._qsv_update_func if self._is_custom_qsv_update_func
+                else algorithm_manager.get_update_qsv_func(alg, op_key))
+      if getattr(update, "block_mode", None) is None:
+        return False
+      cur = self._model_qsvs.get(name)
+      if cur is not None and not _plain_min_max(cur):
+        return False
+    return True
+
   def _sync_carry(self) -> None:
     """What record_blocks saw last of every tensor joins the content map of the per-sample walk."""
     if self._raw_carry:
       self._tensor_content_map.update({k: rt.resident_sample(v) for k, v in self._raw_carry.items()})
       self._raw_carry.clear()
+
+  def _seed_carry(self) -> None:
+    """The block path's view of "the last content of every tensor" starts from the per-sample walk's: the two are ONE
+    store in the reference (ref calibrator.py:529: a sample that omits a tensor reuses what an earlier sample left)."""
+    self._raw_carry.clear()
+    self._raw_carry.update(self._tensor_content_map)
 
   def _gather_block(self, slots, samples, limit: int, first: int, hessian_sink, hessian_tag):
     """(StepBlock, samples taken, whether the sample after them does not qualify) from the head of `samples` (a list).
@@ -464,7 +494,9 @@ class Calibrator:
     n_slots = len(slots)
     names = [s[0] for s in slots]
     hslots = [t for t, s in enumerate(slots) if s[3]]
-    if hslots and hessian_sink is None:       # nowhere to put the Hessians' samples: the per-sample walk returns them
+    if (hslots and hessian_sink is None) or self._blocks_off:
+      # nowhere to put the Hessians' samples (the per-sample walk returns them), or calibrate() has seen the walk leave
+      # a QSV its block merge would not take
       return None, 0, True
     described, carry = self._described, self._raw_carry
     pointers, lengths, leading = [], [], []
@@ -554,6 +586,7 @@ class Calibrator:
     buf: collections.deque = collections.deque()
     failed = None
     index = first
+    self._seed_carry()
     try:
       while True:
         while failed is None and len(buf) < limit:
@@ -582,9 +615,11 @@ class Calibrator:
             taken_up(1)
           yield index, fallback(data)
           index += 1
+          self._seed_carry()
       if failed is not None and failed is not StopIteration:
         raise failed
     finally:
+      self._sync_carry()       # (a later per-sample step, or the next call, starts from what these samples left)
       self._described.clear()
 
   def _walk(self, signature_key, model_recipe_manager) -> None:
@@ -778,6 +813,8 @@ class Calibrator:
     with self.plan_once():
       for signature_key, dataset in calibration_dataset.items():
         limit = self.samples_per_launch(signature_key, dataset, model_recipe_manager, samples_per_launch)
+        if limit > 1 and not self._blocks_keep_hessians(signature_key, model_recipe_manager):
+          limit = 1
         if limit > 1:
           self._calibrate_in_blocks(signature_key, dataset, model_recipe_manager, limit)
           continue
@@ -809,6 +846,12 @@ class Calibrator:
       if acc is None:
         cur = self._model_qsvs.get(name)
         acc = cur.get("hessian") if isinstance(cur, dict) else None
+        if acc is not None and not hasattr(acc, "add_block"):
+          # a finished float64 Hessian: a sample the blocks do not cover (float64 tokens, say) went through the
+          # per-sample walk, whose merge left a plain array. Nothing waits to be merged at this point (per_sample
+          # merges first), so the QSV's count is the Hessian's: it becomes the float64 share of an accumulator
+          # (the reference's weighted mean, utils/qsv_utils.py:71-88) and the blocks carry on.
+          acc = cur["hessian"] = gptq.HessianAccumulator.resumed(acc, float(qsv_utils._hessian_samples(cur)))  # pylint: disable=protected-access
         if acc is None:
           acc = self._new_hessians[name] = gptq.HessianAccumulator(int(xs[0].shape[1]))
       acc.add_block(xs, ns)
@@ -816,6 +859,9 @@ class Calibrator:
     def per_sample(data) -> None:
       merge_waiting()
       self._calibrate_step(signature_key, data, model_recipe_manager)
+      # what the walk left may be a QSV the array path of _replay_block does not take (see _blocks_keep_hessians):
+      # the rest of the dataset then goes sample by sample too
+      self._blocks_off = not self._blocks_keep_hessians(signature_key, model_recipe_manager)
 
     try:
       for _, item in self.record_blocks(signature_key, dataset, model_recipe_manager, limit, hessian_sink=hessian_sink,
@@ -823,6 +869,7 @@ class Calibrator:
         if isinstance(item, StepBlock):
           waiting.append(item)
     finally:
+      self._blocks_off = False
       merge_waiting()
       self._new_hessians.clear()
 

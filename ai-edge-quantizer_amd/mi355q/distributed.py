@@ -365,7 +365,8 @@ def expected_model_bytes(float_model, plan: Sequence[tuple]) -> int:
     return 0
   seen: set = set()
   saved = 0
-  for graph_info, op, _, op_key, _, cfg in plan:
+  hadamard_sizes: set = set()
+  for graph_info, op, _, op_key, alg, cfg in plan:
     w = getattr(cfg, "weight_tensor_config", None) if cfg is not None else None
     if w is None or op_key is None or getattr(op, "inputs", None) is None:
       continue
@@ -389,10 +390,16 @@ def expected_model_bytes(float_model, plan: Sequence[tuple]) -> int:
       block = int(g.rsplit("_", 1)[1]) if g.startswith("BLOCKWISE_") and g.rsplit("_", 1)[1].isdigit() else 0
       groups = numel // block if block else (int(shape[0]) if g == "CHANNELWISE" else 1)
       saved += numel * 4 - kept - 12 * groups
+      if str(getattr(alg, "value", alg)) == "DECOMPOSED_HADAMARD_ROTATION":
+        # the rotation's FULLY_CONNECTED multiplies by H_h / sqrt(h): ONE float32 constant of h x h per distinct size
+        # (transformations/graph_edits.py shares it), 16 MiB at h = 2048 -- more than the 3 % below on a small model
+        from .algorithms.uniform_quantize import hadamard_rotation
+        hadamard_sizes.add(hadamard_rotation.hadamard_size_for(int(shape[-1]), (w.algorithm_params or {}).get("max_hadamard_size")))
+  saved -= sum(4 * h * h for h in hadamard_sizes)
   expected = length - saved
   # (+ 3 % and 1 MiB: the tables of a quantized model are longer, Hadamard ops carry their own constants; pages past
   # the length the writer finds out are given back)
-  return int(expected + (expected >> 5) + (1 << 20)) if 0 < expected <= length else 0
+  return int(expected + (expected >> 5) + (1 << 20)) if 0 < expected <= length + sum(4 * h * h for h in hadamard_sizes) else 0
 
 
 def hessian_owners(plan: Sequence[tuple], owner: Sequence[int], costs) -> dict[str, int]:

@@ -187,7 +187,8 @@ class _Wave:
           object.__setattr__(s.params, "scale", host)
       self.slots = []
       return
-    self._landing = np.empty(tuple(self._pinned.shape), np.float32)
+    # (NaN until land() has filled it: a scale read after a failed wait must not look like one)
+    self._landing = np.full(tuple(self._pinned.shape), np.nan, np.float32)
     for s in self.slots:
       off, n = s.scale._host_at                      # pylint: disable=protected-access
       host = self._landing[off:off + n].reshape(s.scale._shape)   # pylint: disable=protected-access
@@ -199,8 +200,11 @@ class _Wave:
   def land(self) -> None:
     """The wave's copy has arrived: its values fill the block the scales are views of."""
     if self._landing is not None:
-      self._event.synchronize()
-      np.copyto(self._landing, self._pinned.numpy())
+      if self._values is not None:      # host_values() was asked between hand_over() and here: the values are its copy
+        np.copyto(self._landing, self._values)
+      else:
+        self._event.synchronize()
+        np.copyto(self._landing, self._pinned.numpy())
       self._values, self._landing, self._pinned = self._landing, None, None
 
   def complete(self) -> None:

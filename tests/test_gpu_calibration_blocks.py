@@ -277,3 +277,98 @@ def test_step_blocks_pickle_as_plain_arrays(m):
   b.replay(e for blk in blocks for e in (blk.events(k) for k in range(len(blk))))
   _same_qsvs(a.get_model_qsvs(), b.get_model_qsvs())
   assert a._metadata == b._metadata == {"num_samples_calibrated": 6}
+
+
+# ---- what the block path must not lose ---------------------------------------------------------------------
+def test_a_custom_update_rule_keeps_every_gptq_hessian(m, monkeypatch):
+  """A rule without `block_mode` (a wrapper around the stock one, a partial, a user's own) is handed events by the block
+  replay that carry no 'hessian' (the tokens went into an accumulator): such signatures take the per-sample walk, whose
+  events do (ref calibrator.py:567-582, utils/qsv_utils.py:90-122)."""
+  import functools
+  from mi355q.utils import qsv_utils
+  monkeypatch.setattr(m.gptq.HessianAccumulator, "SLAB_TOKENS", 4096)
+  model, samples = _gptq_setup(m, layers=1, sequences=9, tokens=256)
+  rm = _rm(m, m.c5.recipe("gptq"))
+  want = _walk(m, model, rm, samples, 1).get_model_qsvs()
+  assert sum("hessian" in q for q in want.values()) == 4
+  rules = (lambda a, b: qsv_utils.gptq_and_moving_average_update(a, b),
+           functools.partial(qsv_utils.gptq_and_moving_average_update))
+  gathered = []
+  real = m.cal.Calibrator._gather_block
+  monkeypatch.setattr(m.cal.Calibrator, "_gather_block", lambda self, *a, **kw: gathered.append(1) or real(self, *a, **kw))
+  for rule in rules:
+    for k in (None, 4):
+      got = _walk(m, model, rm, samples, k, qsv_update_func=rule)
+      assert not gathered, "a rule that cannot advance over blocks was given blocks"
+      _same_qsvs(got.get_model_qsvs(), want)
+      assert got._metadata == {"num_samples_calibrated": 9}
+  _same_qsvs(_walk(m, model, rm, samples, 4).get_model_qsvs(), want)      # the stock rule: blocks, same result
+  assert gathered
+
+
+def test_a_float64_sample_mid_dataset_under_gptq_joins_the_accumulator(m, monkeypatch):
+  """Sample 5 brings float64 tokens for one GPTQ input: the per-sample walk takes it (FP64 GEMM, a plain float64 Hessian
+  comes out of the merge) and the blocks after it must carry on -- the finished Hessian becomes the float64 share of an
+  accumulator (ref utils/qsv_utils.py:71-88: the sample-weighted mean)."""
+  monkeypatch.setattr(m.gptq.HessianAccumulator, "SLAB_TOKENS", 4096)
+  model, samples = _gptq_setup(m, layers=1, sequences=12, tokens=256)
+  samples = [dict(s) for s in samples]
+  samples[5]["l0/attn_in"] = samples[5]["l0/attn_in"].cpu().numpy().astype(np.float64)
+  rm = _rm(m, m.c5.recipe("gptq"))
+  want = _walk(m, model, rm, samples, 1).get_model_qsvs()
+  for k in (4, None):
+    got = _walk(m, model, rm, samples, k).get_model_qsvs()
+    _same_qsvs(got, want, hessians=False)
+    for name in want:
+      assert ("hessian" in got[name]) == ("hessian" in want[name]), name
+      if "hessian" in want[name]:
+        a, b = np.asarray(got[name]["hessian"]), np.asarray(want[name]["hessian"])
+        assert a.dtype == b.dtype == np.float64
+        # same samples, same weights; the float32 products are grouped differently around the float64 sample
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), name
+    assert int(got["l0/attn_in"]["num_samples"]) == 12
+
+
+def test_blocks_and_single_steps_share_one_content_map(m):
+  """A per-sample step after a block-mode calibrate() may omit a tensor (it reuses what the blocks saw last), and a
+  block-mode call after per-sample steps starts from what those left (ref calibrator.py:529: ONE map)."""
+  model = m.c4.build_model(4, 256, 8)
+  rm = _rm(m, m.recipe.static_wi8_ai8())
+  samples = _c4_samples(9, 4, 8, 256, seed=10)
+  partial_a = {k: v for k, v in samples[6].items() if k != "act1"}
+  partial_b = {k: v for k, v in samples[8].items() if k != "act2"}
+
+  def run(k):
+    cal = m.cal.Calibrator(model)
+    cal.calibrate({"serving_default": samples[:6]}, rm, samples_per_launch=k)
+    cal.calibrate({"serving_default": [partial_a]}, rm, samples_per_launch=1)       # reads act1 of sample 5
+    cal.calibrate({"serving_default": [samples[7], partial_b]}, rm, samples_per_launch=k)   # reads act2 of sample 7
+    return cal
+  want, got = run(1), run(4)
+  _same_qsvs(got.get_model_qsvs(), want.get_model_qsvs())
+  assert got._metadata == want._metadata == {"num_samples_calibrated": 9}
+  assert not got._raw_carry
+
+
+def test_float32_copies_made_for_a_block_leave_with_it(m):
+  """bfloat16 and strided device samples are widened / gathered into float32 copies: the block that launched them gives
+  them back (kept to the end they would be a second copy of the whole dataset in HBM)."""
+  torch = m.torch
+  x = torch.randn((1, 8, 256), device="cuda")
+  rec = m.cal._describe(x.to(torch.bfloat16))
+  assert rec is not None and rec[7] == x.numel() * 4
+  rec = m.cal._describe(torch.randn((1, 256, 8), device="cuda").transpose(1, 2))
+  assert rec is not None and rec[7] == x.numel() * 4
+  assert m.cal._describe(x)[7] == 0
+  model = m.c4.build_model(4, 256, 8)
+  rm = _rm(m, m.recipe.static_wi8_ai8())
+  host = _c4_samples(8, 4, 8, 256, seed=11)
+  samples = [{k: torch.from_numpy(v).cuda().to(torch.bfloat16) for k, v in s.items()} for s in host]
+  cal = m.cal.Calibrator(model)
+  left = []
+  with cal.plan_once():
+    for _, block in cal.record_blocks("serving_default", samples, rm, 4):
+      left.append(len(cal._described))
+  assert left == [0, 0], left
+  cal.wait_for_statistics()
+  _same_qsvs(_walk(m, model, rm, samples, 4).get_model_qsvs(), _walk(m, model, rm, samples, 1).get_model_qsvs())

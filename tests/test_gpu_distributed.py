@@ -6,9 +6,60 @@ import sys
 import pytest
 
 import parity_rates
-from test_distributed_gloo import ROOT, _run, _setup
+from test_distributed_gloo import ROOT, _run
+from test_distributed_gloo import _setup as _setup_gloo
 
 pytestmark = pytest.mark.gpu
+
+# Every worker below runs twice where the box allows it: as two gloo ranks sharing cuda:0 (any box), and -- the moment two
+# GPUs are visible -- as one rank per GPU over RCCL ("nccl" backend), where the data collectives are libmi355q's own RCCL
+# entry points over xGMI (mi355q_allgather_minmax, mi355q_reduce_product_f32, ...) and every rank's payloads leave from
+# its own HBM. The builder's lease has one GPU: the RCCL variants are collected and skipped there.
+_BACKEND_ENV = "MI355Q_TEST_DIST_BACKEND"
+
+
+def _gpus() -> int:
+  try:
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+  except Exception:  # pylint: disable=broad-exception-caught
+    return 0
+
+
+needs_two_gpus = pytest.mark.skipif(_gpus() < 2, reason="RCCL with N > 1 needs one GPU per rank (this box shows fewer than 2)")
+
+
+def _setup(rank, world, port):
+  """The workers' rendezvous: gloo (ranks share cuda:0) unless the test asked for RCCL (one rank per device)."""
+  if os.environ.get(_BACKEND_ENV) != "nccl":
+    return _setup_gloo(rank, world, port)
+  for p in (os.path.join(ROOT, "ai-edge-quantizer_amd"), ROOT):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                    LOCAL_RANK=str(rank))
+  os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  import torch
+  import torch.distributed as dist
+  torch.cuda.set_device(rank)
+  dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+  return dist
+
+
+def _rccl_ranks():
+  """(ranks, my rank) as libmi355q's communicator reports them (mi355q_comm_info), or None on a host transport."""
+  import ctypes
+  from mi355q import _ffi, distributed as D
+  comm = D.rccl_comm()
+  if comm is None:
+    return None
+  nr, rk = ctypes.c_int32(-1), ctypes.c_int32(-1)
+  _ffi.check(_ffi.lib().mi355q_comm_info(comm, ctypes.byref(nr), ctypes.byref(rk)))
+  return (nr.value, rk.value)
+
+
+def _over_rccl(monkeypatch):
+  monkeypatch.setenv(_BACKEND_ENV, "nccl")      # (spawned workers inherit the environment)
 
 _CASES = [
     ("conv_fc_mnist.tflite", "min_max_uniform_quantize", 8, "CHANNELWISE"),
@@ -98,16 +149,30 @@ def _worker_shared_weights(rank, world, port, out):
   dist.barrier()
   if rank == 0:
     os.remove(path)
-  out.put((rank, got))
+  out.put((rank, (got, _rccl_ranks())))
   dist.barrier()
   dist.destroy_process_group()
 
 
-def test_two_ranks_write_a_model_whose_ops_share_a_weight():
-  results = dict(_run(_worker_shared_weights, timeout=600))
-  assert len(results[0]) == 4
-  for same_file, one_rank in results[0]:
+def _check_shared_weights(results, rccl: bool):
+  results = dict(results)
+  got, _ = results[0]
+  assert len(got) == 4
+  for same_file, one_rank in got:
     assert same_file and one_rank
+  for rank, (_, comm) in results.items():
+    assert comm == ((2, rank) if rccl else None), (rank, comm)
+
+
+def test_two_ranks_write_a_model_whose_ops_share_a_weight():
+  _check_shared_weights(_run(_worker_shared_weights, timeout=600), rccl=False)
+
+
+@needs_two_gpus
+def test_two_ranks_write_a_model_whose_ops_share_a_weight_over_rccl(monkeypatch):
+  """One rank per GPU: the payload of the rank that is not the writer crosses from ITS device into the file."""
+  _over_rccl(monkeypatch)
+  _check_shared_weights(_run(_worker_shared_weights, timeout=600), rccl=True)
 
 
 def _worker_layout_failure(rank, world, port, out):
@@ -177,12 +242,22 @@ def _worker(rank, world, port, out):
   dist.destroy_process_group()
 
 
-def test_two_ranks_quantize_model_files_like_one():
-  (r0, got0), (r1, got1) = _run(_worker, timeout=600)
+def _check_model_files(results):
+  (r0, got0), (r1, got1) = results
   assert len(got0) == len(_CASES) + 4
   for case, (sharded, single), (other, _) in zip([("big", 4), ("big file", 4), ("big", 8), ("big file", 8)] + _CASES, got0, got1):
     assert other is None and sharded is not None, case
     assert sharded == single, case
+
+
+def test_two_ranks_quantize_model_files_like_one():
+  _check_model_files(_run(_worker, timeout=600))
+
+
+@needs_two_gpus
+def test_two_ranks_quantize_model_files_like_one_over_rccl(monkeypatch):
+  _over_rccl(monkeypatch)
+  _check_model_files(_run(_worker, timeout=600))
 
 
 def _worker_rccl_single(rank, world, port, out):
@@ -349,14 +424,26 @@ def _worker_calibrate_gptq(rank, world, port, out):
   ok &= all(np.array_equal(np.asarray(got[n][k]), np.asarray(want[n][k])) for n in want for k in ("min", "max"))
   ok &= int(got["x"]["num_samples"]) == int(want["x"]["num_samples"]) == sum(s["x"].shape[0] for s in data["serving_default"])
   ok &= "hessian_dim" not in got["x"]
-  out.put((rank, bool(ok), rel, max(sizes), hw.nbytes, rel_forms, kept_as_product))
+  out.put((rank, bool(ok), rel, max(sizes), hw.nbytes, rel_forms, kept_as_product, _rccl_ranks()))
   dist.barrier()
   dist.destroy_process_group()
 
 
 def test_two_ranks_reduce_gptq_hessians_in_hbm():
-  results = _run(_worker_calibrate_gptq, timeout=600)
-  for rank, ok, rel, gathered_bytes, hessian_bytes, rel_forms, kept_as_product in results:
+  _check_reduced_hessians(_run(_worker_calibrate_gptq, timeout=600), rccl=False)
+
+
+@needs_two_gpus
+def test_two_ranks_reduce_gptq_hessians_in_hbm_over_rccl(monkeypatch):
+  """X2 over xGMI: mi355q_reduce_product_f32 (packed float32 triangles, ncclAllReduce / ncclReduce) between two devices
+  -- what replaces the reference's sample-ordered merge chain (ref utils/qsv_utils.py:71-102, calibrator.py:395-421)."""
+  _over_rccl(monkeypatch)
+  _check_reduced_hessians(_run(_worker_calibrate_gptq, timeout=600), rccl=True)
+
+
+def _check_reduced_hessians(results, rccl: bool):
+  for rank, ok, rel, gathered_bytes, hessian_bytes, rel_forms, kept_as_product, comm in results:
+    assert comm == ((2, rank) if rccl else None), (rank, comm)
     assert ok, rank
     # X2 as packed float32 product triangles against X2 as float64 Hessians: the same mean within float32 summation
     assert rel_forms <= 1e-7, rel_forms
@@ -409,7 +496,7 @@ def _worker_c5_fused(rank, world, port, out):
   dist.barrier()
   if rank == 0:
     os.remove(path)
-  out.put((rank, mine, None if sharded is None else bytes(sharded), single))
+  out.put((rank, mine, None if sharded is None else bytes(sharded), single, _rccl_ranks()))
   dist.barrier()
   dist.destroy_process_group()
 
@@ -419,13 +506,26 @@ def test_two_ranks_calibrate_and_quantize_in_one_call_one_inverse_per_hessian():
   exactly once in the whole job, on the rank that owns the ops reading it, and the file rank 0
   writes is the single-process file but for T2 (the Hessian of two ranks' token products; observed
   identical bytes)."""
+  _check_c5_fused(sorted(_run(_worker_c5_fused, timeout=600)), "two ranks", rccl=False)
+
+
+@needs_two_gpus
+def test_two_ranks_calibrate_and_quantize_in_one_call_over_rccl(monkeypatch):
+  """The same call with one rank per GPU: statistics all-gathered, every Hessian reduced over xGMI to the rank that owns
+  its readers (ncclReduce on the packed float32 triangle), results gathered to rank 0."""
+  _over_rccl(monkeypatch)
+  _check_c5_fused(sorted(_run(_worker_c5_fused, timeout=600)), "two GPUs over RCCL", rccl=True)
+
+
+def _check_c5_fused(results, label: str, rccl: bool):
   import numpy as np
-  (r0, n0, sharded, single), (r1, n1, other, _) = sorted(_run(_worker_c5_fused, timeout=600))
+  (r0, n0, sharded, single, comm0), (r1, n1, other, _, comm1) = results
+  assert (comm0, comm1) == (((2, 0), (2, 1)) if rccl else (None, None))
   assert other is None and sharded is not None
   assert n0 + n1 == 8 and n0 > 0 and n1 > 0, (n0, n1)
   assert len(sharded) == len(single)
   diff = np.frombuffer(sharded, np.uint8) != np.frombuffer(single, np.uint8)
-  parity_rates.note("C5 small model, two ranks vs one: differing bytes of the written file", "byte_mismatch_fraction",
+  parity_rates.note(f"C5 small model, {label} vs one: differing bytes of the written file", "byte_mismatch_fraction",
                     float(diff.mean()), 1e-4)
 
 
@@ -503,5 +603,14 @@ def _worker_calibrate(rank, world, port, out):
 def test_two_ranks_calibrate_like_one():
   """Samples sharded over two ranks, events gathered and replayed: the QSVs (moving-average
   min/max; OSCAR's sample-weighted mu2) equal the single-process ones bit for bit."""
+  (r0, ok0), (r1, ok1) = _run(_worker_calibrate, timeout=600)
+  assert ok0 and ok1
+
+
+@needs_two_gpus
+def test_two_ranks_calibrate_like_one_over_rccl(monkeypatch):
+  """BASELINE config 4's exchange between two devices: the per-sample (min, max) travel through
+  mi355q_allgather_minmax and are replayed in dataset order (ref utils/qsv_utils.py:43-68)."""
+  _over_rccl(monkeypatch)
   (r0, ok0), (r1, ok1) = _run(_worker_calibrate, timeout=600)
   assert ok0 and ok1
