@@ -7,8 +7,9 @@ serializes with this build's own flatbuffer writer: inline when the large buffer
 behind the flatbuffer at 16-byte aligned offsets (`Buffer.offset/size`), written straight into
 an mmap of the output file when a path is given.
 
-QUANTIZE_TENSOR, ADD_QUANTIZE, ADD_DEQUANTIZE and constant duplication are applied; Hadamard /
-multiply op insertion is outside this build's scope and raises NotImplementedError.
+Every transformation of the reference is applied: QUANTIZE_TENSOR, ADD_QUANTIZE, ADD_DEQUANTIZE, constant
+duplication, and the op insertions -- Hadamard rotation (custom op and decomposed RESHAPE / FULLY_CONNECTED / RESHAPE),
+OSCAR's multiply (transformations/graph_edits.py, ref transformations/insert_*.py).
 """
 from __future__ import annotations
 

@@ -3,13 +3,14 @@
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'
 # Everything lands under gpurun_out/<round>/; copy what is to be judged into profiles/.
 set -u
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$ROUND
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$R"
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > "$OUT/gpu_tests_tail.txt"
+timeout 600 bash tools/build_kbench.sh > "$OUT/build_kbench.log" 2>&1    # (r05: the probes below were run without having been built)
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > "$OUT/gpu_tests_tail.txt"
 cp gpurun_out/parity_rates.jsonl "$OUT/" 2>/dev/null
 timeout 600 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 timeout 400 python tools/path_bench.py --big > "$OUT/path_bench.txt" 2>&1
