@@ -422,13 +422,19 @@ __device__ __forceinline__ void sort_levels(double* key, uint16_t* pos, int tile
 __global__ __launch_bounds__(kSortThreadsMax) void sort_tile_kernel(
     const float* __restrict__ w, const double* __restrict__ s, const double* __restrict__ m,
     int64_t segments, int32_t g, int32_t P, int32_t tile, int64_t d, int32_t transposed,
-    int64_t seg_len, int32_t runs_per_seg, double* __restrict__ keys_out, double* __restrict__ vals_out) {
+    int64_t seg_len, int32_t runs_per_seg, double* __restrict__ keys_out, double* __restrict__ vals_out,
+    const uint8_t* __restrict__ todo) {
   extern __shared__ unsigned char lds_raw[];
   double* key = reinterpret_cast<double*>(lds_raw);
   uint16_t* pos = reinterpret_cast<uint16_t*>(key + lds_pad(tile) + 1);
   const int segs_per_tile = tile / P;
   const int64_t seg0 = static_cast<int64_t>(blockIdx.x) * segs_per_tile;
   const int64_t segs_here = (segments - seg0 < segs_per_tile) ? segments - seg0 : segs_per_tile;
+  if (todo) {                        // the prefix kernel has answered most rows: a tile none of whose segments is left returns
+    bool any = false;
+    for (int64_t sl = 0; sl < segs_here; ++sl) any |= todo[(seg0 + sl) / runs_per_seg] != 0;
+    if (!any) return;
+  }
 
   for (int e = threadIdx.x; e < tile; e += blockDim.x) {
     const int sl = e / P, i = e - sl * P;
@@ -497,10 +503,12 @@ __global__ __launch_bounds__(256) void merge_runs_kernel(const double* __restric
                                                          const double* __restrict__ vals,
                                                          int64_t total, int64_t g, int64_t run,
                                                          double* __restrict__ keys_out,
-                                                         double* __restrict__ vals_out) {
+                                                         double* __restrict__ vals_out,
+                                                         const uint8_t* __restrict__ todo) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (e >= total) return;
   const int64_t seg = e / g, off = e - seg * g;
+  if (todo && !todo[seg]) return;
   const int64_t pair0 = off / (2 * run) * (2 * run);       // first element of the pair of runs
   const int64_t mid = pair0 + run < g ? pair0 + run : g;   // end of the left run
   const int64_t end = pair0 + 2 * run < g ? pair0 + 2 * run : g;
@@ -531,9 +539,11 @@ __global__ __launch_bounds__(64) void clip_scan_kernel(const double* __restrict_
                                                        const double* __restrict__ noise,
                                                        double qmax, int32_t blockwise,
                                                        double* __restrict__ bounds,
-                                                       double* __restrict__ scale) {
+                                                       double* __restrict__ scale,
+                                                       const uint8_t* __restrict__ todo) {
   const int64_t seg = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
   if (seg >= segments) return;
+  if (todo && !todo[seg]) return;
   const double* a = keys + seg * seg_stride;
   const double* m = vals + seg * seg_stride;
   const double uk = u[seg % G], nk = noise[seg % G];
@@ -591,9 +601,11 @@ __global__ __launch_bounds__(64) void clip_scan_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void clip_scan_wave_kernel(
     const double* __restrict__ keys, const double* __restrict__ vals, int64_t segments, int64_t g,
     int64_t G, const double* __restrict__ u, const double* __restrict__ noise, double qmax,
-    int32_t blockwise, double* __restrict__ bounds, double* __restrict__ scale) {
+    int32_t blockwise, double* __restrict__ bounds, double* __restrict__ scale,
+    const uint8_t* __restrict__ todo) {
   const int64_t seg = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (seg >= segments) return;                       // whole waves leave together
+  if (todo && !todo[seg]) return;
   const int lane = threadIdx.x & 63;
   const double* a = keys + seg * g;
   const double* m = vals + seg * g;
@@ -664,6 +676,454 @@ __global__ __launch_bounds__(256) void clip_scan_wave_kernel(
         sc = static_cast<double>(round_scale_blockwise(static_cast<float>(sc), &half_bits));
       }
       scale[seg] = sc;
+    }
+  }
+}
+
+// -------------------------------------------------------- the prefix of the scan ---
+// CHANNELWISE rows (g == d): the first minimum of the breakpoint scan almost always lies among the few largest
+// magnitudes -- with qmax >= 7 the optimal bound clips a percent of a row -- and everything the scan does up to index k
+// depends on the k largest elements only. So a row is answered from a PREFIX of its sorted order:
+//   1. every thread keeps the upper halves of the float32 patterns of its elements' keys in registers (monotone in
+//      the key, 128 steps per binade); a bisection
+//      over thresholds one eighth of a binade apart below the row's largest key (seven counts over the row) finds the
+//      threshold with at least `target` elements at or above it; those P elements ARE the first P of the stable
+//      descending order (equal keys have equal patterns), and the largest key below the threshold is element P + 1
+//      (`a_next`, recomputed in FP64);
+//   2. the P elements are sorted in LDS as 64-bit composites -- the upper 48 bits of the FP64 key's pattern (monotone)
+//      over 0xFFFF - position (equal keys: lower position first, the full sort's tie rule): ONE integer comparison
+//      per exchange instead of two FP64 and one integer comparison on a 10-byte pair. Keys that agree in their upper
+//      48 bits and differ below are ordered by position, which may be wrong: the scan compares every neighbouring pair
+//      with the exact keys and hands the row to the full route if one is out of order (1e-5 of ordinary rows);
+//   3. one wave runs the three sequential FP64 sums and the candidates 1..P exactly as clip_scan_wave_kernel does --
+//      the same operations on the same operands (keys recomputed as |w| s from the positions) in the same order, hence
+//      the same bits -- with a_next as the lower end of the last interval;
+//   4. the row is answered only if candidates P+1..g PROVABLY cannot win. E(c) = noise c^2 + sum_j m_j max(a_j - c, 0)^2
+//      is convex and candidate k is E at a point of [a_(k+1), a_k] evaluated in floating point. If the stationary
+//      point of interval P, 2 S_am / (u + 2 S_m), lies above a_next (with 1e-6 to spare), E decreases towards
+//      a_next from below, so every later candidate's exact value is >= E(a_next). A computed candidate is within
+//      B = 64 g 2^-53 (a_1^2 noise + 4 S_a2m(g)) of its exact value (g positive addends per sum, a handful of
+//      roundings in the closed form, every intermediate <= the bracket; S_a2m(g) <= S_a2m(P) + a_next^2 M), so
+//      E(a_next) computed > best + 4 B implies that every later computed candidate exceeds the best of the prefix:
+//      np.argmin's first minimum is the prefix's. Otherwise -- or when a key is not finite, or more than `cap`
+//      elements share the top eighths -- the row is flagged and the full sort + scan answers it (todo[row] = 1).
+// Rows of up to 4096 columns are ONE WAVE's work (WAVES = 1: 16 / 32 / 64 elements per lane): no workgroup barrier
+// anywhere, twenty rows in flight per CU. The first form of this kernel gave every row a 256-thread workgroup: 110 000
+// cycles per row, half of them in the 45 barriers of the sort with six workgroups per CU taking turns
+// (profiles/r06_oscar_prefix.txt). Longer rows (to 16384) take four waves with 32 / 64 elements per thread (sixteen
+// waves with 16 each left a CU one row at a time: 433 us for 2048 x 16384).
+// Ref oscar.py:62-104. The answer is the reference's, bit for bit, on either route.
+
+// (float32 pattern of a key, monotone in the key for finite keys >= 0; anything else -- NaN, inf, a negative product --
+// maps to 0x7F800000 or above and sends the row to the full route)
+__device__ __forceinline__ uint32_t key_bits(float w, double s) {
+  return f2u(static_cast<float>(fabs(static_cast<double>(w)) * s));
+}
+
+__device__ __forceinline__ uint64_t key_composite(double key, uint32_t position) {
+  return (static_cast<uint64_t>(__double_as_longlong(key)) & ~0xFFFFull) | (0xFFFFu - position);
+}
+
+// LEVELS consecutive compare-exchange levels of the descending bitonic network on 64-bit composites in LDS
+// (see sort_levels: the same index arithmetic, one register per element).
+template <int LEVELS>
+__device__ __forceinline__ void sort_levels_u64(uint64_t* a, int tile, int k, int j) {
+  constexpr int N = 1 << LEVELS;
+  const int low = j >> (LEVELS - 1);
+  for (int t = threadIdx.x; t < tile / N; t += blockDim.x) {
+    const int base = ((t & ~(low - 1)) << LEVELS) | (t & (low - 1));
+    const bool desc = (base & k) == 0;
+    uint64_t v[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) v[c] = a[lds_pad(base + c * low)];
+#pragma unroll
+    for (int lvl = LEVELS - 1; lvl >= 0; --lvl) {
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        if ((c >> lvl) & 1) continue;
+        const int o = c | (1 << lvl);
+        const bool swap = (v[o] > v[c]) == desc;
+        const uint64_t t0 = swap ? v[o] : v[c];
+        v[o] = swap ? v[c] : v[o];
+        v[c] = t0;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) a[lds_pad(base + c * low)] = v[c];
+  }
+}
+
+#if defined(MI355Q_PREFIX_PROF)
+#define MI355Q_PREFIX_STAMP(k) do { if (row == 1000 && lane == 0 && wv == 0) stamp[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MI355Q_PREFIX_STAMP(k) do {} while (0)
+#endif
+
+// One row per workgroup of WAVES waves, EPT elements per thread (element tid + 64 WAVES k).
+template <int EPT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 4 : 1) void clip_prefix_kernel(      // (one-wave form: four waves per SIMD, 128 VGPRs)
+    const float* __restrict__ w, const double* __restrict__ s, const double* __restrict__ m, int64_t n,
+    int32_t g, int32_t target, const double* __restrict__ u, const double* __restrict__ noise, double qmax,
+    int32_t blockwise, double* __restrict__ bounds, double* __restrict__ scale, uint8_t* __restrict__ todo) {
+  constexpr int THREADS = 64 * WAVES;
+  constexpr int CAP = WAVES == 1 ? 512 : 1024;
+  __shared__ uint64_t comp[CAP + CAP / 8 + CAP / 32 + 2];
+  __shared__ double stage[2][3][64];                 // the scan's addends and running sums; before it, the selected positions
+  double (&addend)[3][64] = stage[0];
+  double (&prefix)[3][64] = stage[1];
+  __shared__ uint32_t cnt_slot[WAVES == 1 ? 1 : 10][WAVES];     // one set of per-wave figures per row-wide reduction
+  __shared__ double max_slot[WAVES];
+  __shared__ uint32_t filled;
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* wr = w + row * g;
+#if defined(MI355Q_PREFIX_PROF)
+  unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  if (WAVES > 1 && tid == 0) filled = 0;
+  MI355Q_PREFIX_STAMP(0);
+  // a reduction over the row: the wave's butterfly, then (WAVES > 1) the waves' figures through LDS -- one barrier
+  auto over_row = [&](auto v, auto* slot, auto op) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v = op(v, __shfl_xor(v, off, kWave));
+    if constexpr (WAVES > 1) {
+      if (lane == 0) slot[wv] = v;
+      __syncthreads();
+      v = slot[0];
+#pragma unroll
+      for (int k = 1; k < WAVES; ++k) v = op(v, slot[k]);
+    }
+    return v;
+  };
+  auto umax = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  auto uadd = [](uint32_t a, uint32_t b) { return a + b; };
+  auto dmax = [](double a, double b) { return fmax(a, b); };
+  // ---- 1. the upper halves of the keys' float32 patterns, two per register (EPT = 64 would not fit otherwise:
+  // 128 VGPRs is what four waves per SIMD leave); sixteen (weight, scale) pairs in flight per thread
+  uint32_t kp[EPT / 2];
+#pragma unroll
+  for (int k0 = 0; k0 < EPT; k0 += 16) {
+    float wv_[16];
+    double sv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      // (unsigned 32-bit element index: base in SGPRs + a 32-bit lane offset; with a signed index every load keeps a
+      // 64-bit address of its own -- 2 x 128 VGPRs of addresses for EPT = 64, spilled)
+      const uint32_t i = static_cast<uint32_t>(tid) + static_cast<uint32_t>(THREADS * (k0 + k));
+      const uint32_t ic = i < static_cast<uint32_t>(g) ? i : 0u;
+      wv_[k] = wr[ic];
+      sv[k] = s[ic];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      const uint32_t i = static_cast<uint32_t>(tid) + static_cast<uint32_t>(THREADS * (k0 + k));
+      const uint32_t b0 = i < static_cast<uint32_t>(g) ? key_bits(wv_[k], sv[k]) >> 16 : 0u;
+      const uint32_t b1 = i + THREADS < static_cast<uint32_t>(g) ? key_bits(wv_[k + 1], sv[k + 1]) & 0xFFFF0000u : 0u;
+      kp[(k0 + k) / 2] = b0 | b1;
+    }
+    asm volatile("" ::: "memory");                   // (the next sixteen pairs are not loaded before these are packed: with all
+  }                                                  //  EPT pairs in flight the one-wave form for 4096 columns spills)
+  auto pattern = [&](int k) { return (k & 1) ? kp[k / 2] >> 16 : kp[k / 2] & 0xFFFFu; };
+  uint32_t top = 0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) top = pattern(k) > top ? pattern(k) : top;
+  top = over_row(top, cnt_slot[0], umax);
+  MI355Q_PREFIX_STAMP(1);
+  if (top >= 0x7F80u || top == 0u) {                 // a key that is not a finite non-negative number; or a row of (almost) zeros
+    if (tid == 0) todo[row] = 1;
+    return;
+  }
+  // ---- the threshold: the half patterns step 16 per eighth of a binade; the smallest j in [1, 64] whose threshold
+  // top - 16 j has at least `target` elements at or above it (64 = eight binades below the row's largest: take those)
+  auto count_at = [&](uint32_t tb, uint32_t* slot) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) c += pattern(k) >= tb ? 1u : 0u;
+    return over_row(c, slot, uadd);
+  };
+  auto threshold = [&](int j) {
+    const uint32_t step = static_cast<uint32_t>(j) << 4;
+    return top > step ? top - step : 1u;             // (never 0: absent elements and zeros carry pattern 0)
+  };
+  constexpr int kSlots = WAVES == 1 ? 1 : 10;        // (a single wave needs no slots: index 0 throughout)
+  int lo = 1, hi = 64;                               // the answer lies in [lo, hi]
+  uint32_t P = count_at(threshold(64), cnt_slot[1 % kSlots]);
+  if (P >= static_cast<uint32_t>(target)) {
+#pragma unroll 1
+    for (int r = 0; r < 6; ++r) {
+      const int mid = (lo + hi) >> 1;
+      const uint32_t c = count_at(threshold(mid), cnt_slot[(2 + r) % kSlots]);
+      if (c >= static_cast<uint32_t>(target)) {
+        hi = mid;
+        P = c;
+      } else {
+        lo = mid + 1;
+      }
+      if (lo >= hi) break;
+    }
+  }
+  int j = hi;
+  if (P > static_cast<uint32_t>(CAP) && j > 1) {       // a crowded eighth: stop above it if that leaves a prefix worth scanning
+    const uint32_t c = count_at(threshold(j - 1), cnt_slot[8 % kSlots]);
+    if (c >= 32u) {
+      P = c;
+      j -= 1;
+    }
+  }
+  if (P > static_cast<uint32_t>(CAP) || P < 1u) {
+    if (tid == 0) todo[row] = 1;
+    return;
+  }
+  const uint32_t tb = threshold(j);
+  MI355Q_PREFIX_STAMP(2);
+  // ---- 2. the selected elements and the largest key among the others. Positions first -- a ballot per element
+  // slot, no memory traffic -- then every thread fetches (weight, scale) of the slots lane, lane + THREADS, ... and
+  // writes their composites: a handful of independent gathers per thread. (Fetching inside the ballot loop made every
+  // one of its EPT iterations wait for its own pair of loads: 120 000 of a row's 200 000 cycles.)
+  uint16_t* sel_pos = reinterpret_cast<uint16_t*>(&stage[0][0][0]);   // (CAP positions: 1 / 2 KiB; the scan's staging area is free until then)
+  static_assert(sizeof(stage) >= 2 * CAP, "position list");
+  uint32_t below = 0;
+  uint32_t placed = 0;                               // where this wave's next selected elements go
+  if constexpr (WAVES > 1) {
+    // the wave's stretch of the list: ONE atomic per wave (an atomic per ballot made each of the EPT iterations wait
+    // for its return)
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) mine += static_cast<uint32_t>(__builtin_popcountll(__ballot(pattern(k) >= tb)));
+    if (lane == 0) placed = atomicAdd(&filled, mine);
+    placed = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(placed)));
+  }
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const uint32_t pk = pattern(k);
+    const bool sel = pk >= tb;
+    const unsigned long long mask = __ballot(sel);
+    if (sel)
+      sel_pos[placed + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = static_cast<uint16_t>(tid + THREADS * k);
+    placed += static_cast<uint32_t>(__builtin_popcountll(mask));
+    if (!sel) below = pk > below ? pk : below;
+  }
+  below = over_row(below, cnt_slot[9 % kSlots], umax);
+  // exact FP64 key of element P + 1: the largest key among the elements that share the largest unselected half pattern
+  // (a dozen of a 4096-column row). Their positions are listed like the selected ones', then fetched side by side.
+  constexpr int kNextCap = 256;
+  uint16_t* next_pos = sel_pos + CAP;
+  static_assert(sizeof(stage) >= 2 * (CAP + kNextCap), "position lists");
+  uint32_t listed = 0;
+  if (below != 0u) {
+    if constexpr (WAVES > 1) {
+      if (tid == 0) filled = 0;                      // (every wave has its stretch of the selected list: the counter is free)
+      __syncthreads();
+      uint32_t mine = 0;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) mine += static_cast<uint32_t>(__builtin_popcountll(__ballot(pattern(k) == below)));
+      if (lane == 0) listed = atomicAdd(&filled, mine);
+      listed = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(listed)));
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const bool hit = pattern(k) == below;
+      const unsigned long long mask = __ballot(hit);
+      const uint32_t at = listed + static_cast<uint32_t>(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
+      if (hit && at < static_cast<uint32_t>(kNextCap)) next_pos[at] = static_cast<uint16_t>(tid + THREADS * k);
+      listed += static_cast<uint32_t>(__builtin_popcountll(mask));
+    }
+  }
+  uint32_t n_next = listed;                          // WAVES == 1: the count; WAVES > 1: read back below
+  if constexpr (WAVES > 1) {
+    __syncthreads();
+    n_next = filled;
+  } else {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+  if (n_next > static_cast<uint32_t>(kNextCap)) {    // hundreds of elements in one 128th of a binade: the full route sorts them
+    if (tid == 0) todo[row] = 1;
+    return;
+  }
+  double a_next = 0.0;
+  for (uint32_t q = tid; q < n_next; q += THREADS) {
+    const uint32_t at = next_pos[q];
+    a_next = fmax(a_next, fabs(static_cast<double>(wr[at])) * s[at]);
+  }
+  a_next = over_row(a_next, max_slot, dmax);         // (WAVES > 1: its barrier also publishes the positions)
+  int P2 = 64;
+  while (P2 < static_cast<int>(P)) P2 <<= 1;
+  if constexpr (WAVES == 1) {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+  for (int q0 = tid; q0 < P2; q0 += 4 * THREADS) {    // four gathers in flight per thread
+    uint32_t at[4];
+    float wq[4];
+    double sq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int slot = q0 + q * THREADS;
+      at[q] = slot < static_cast<int>(P) ? sel_pos[slot] : 0u;
+      wq[q] = wr[at[q]];
+      sq[q] = s[at[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int slot = q0 + q * THREADS;
+      if (slot < P2)                                   // padding (composite 0) sorts behind every element
+        comp[lds_pad(slot)] = slot < static_cast<int>(P) ? key_composite(fabs(static_cast<double>(wq[q])) * sq[q], at[q]) : 0ull;
+    }
+  }
+  auto row_sync = [&]() {
+    if constexpr (WAVES > 1) {
+      __syncthreads();
+    } else {                                         // one wave: its LDS operations complete in order
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+  };
+  row_sync();
+  MI355Q_PREFIX_STAMP(3);
+  {
+    const int per_thread = P2 / THREADS;             // elements per thread with every thread at work
+    for (int k = 2; k <= P2; k <<= 1) {
+      int jj = k >> 1;
+      while (jj > 0) {
+        if (jj >= 4 && per_thread >= 8) {
+          sort_levels_u64<3>(comp, P2, k, jj);
+          jj >>= 3;
+        } else if (jj >= 2 && per_thread >= 4) {
+          sort_levels_u64<2>(comp, P2, k, jj);
+          jj >>= 2;
+        } else {
+          sort_levels_u64<1>(comp, P2, k, jj);
+          jj >>= 1;
+        }
+        row_sync();
+      }
+    }
+  }
+  MI355Q_PREFIX_STAMP(4);
+  if (wv) return;
+  // ---- 3. the scan of candidates 1..P (one wave; see clip_scan_wave_kernel)
+  const double uk = u[0], nk = noise[0];
+  const int Pn = static_cast<int>(P);
+  auto exact_key = [&](int i, uint32_t* position) {  // (key, position) of the i-th element of the sorted prefix
+    const uint32_t at = 0xFFFFu - static_cast<uint32_t>(comp[lds_pad(i)] & 0xFFFFull);
+    *position = at;
+    return fabs(static_cast<double>(wr[at])) * s[at];
+  };
+  uint32_t p0;
+  const double a0 = exact_key(0, &p0);
+  double best_c = a0, best_e = (a0 * a0) * nk;
+  int32_t best_i = -1;
+  const int chain = lane < 3 ? lane : 0;
+  double acc = 0.0;
+  bool out_of_order = false;
+  // (key, mass, position) of this lane's element of a chunk; the NEXT chunk's are fetched while this one's sums run
+  uint32_t pi_n = 0;
+  double ai_n = lane < Pn ? exact_key(lane, &pi_n) : 0.0;
+  double mi_n = lane < Pn ? m[pi_n] : 0.0;
+  for (int base = 0; base < Pn; base += 64) {
+    const int i = base + lane;
+    const bool live = i < Pn;
+    const uint32_t pi = pi_n;
+    const double ai = ai_n, mi = mi_n;
+    if (i + 64 < Pn) {
+      ai_n = exact_key(i + 64, &pi_n);
+      mi_n = m[pi_n];
+    } else {
+      ai_n = mi_n = 0.0;
+      pi_n = 0;
+    }
+    double lower = __shfl_down(ai, 1, kWave);        // the next element's key: the neighbouring lane's
+    uint32_t pn = static_cast<uint32_t>(__shfl_down(static_cast<int>(pi), 1, kWave));
+    const double first_of_next = __shfl(ai_n, 0, kWave);                       // lane 63's neighbour opens the next chunk
+    const uint32_t first_pos = static_cast<uint32_t>(__shfl(static_cast<int>(pi_n), 0, kWave));
+    if (lane == 63) {
+      lower = first_of_next;
+      pn = first_pos;
+    }
+    const bool has_next = i + 1 < Pn;
+    if (!has_next) lower = a_next;
+    // the composites order equal upper-48-bit keys by position: the exact keys must agree with that order
+    if (live && has_next && !((ai > lower) | ((ai == lower) & (pi < pn)))) out_of_order = true;
+    addend[0][lane] = mi;
+    addend[1][lane] = ai * mi;
+    addend[2][lane] = (ai * ai) * mi;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // (sixteen addends at a time: the whole chunk in registers, as clip_scan_wave_kernel keeps it, is 128 VGPRs)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double v[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = addend[chain][16 * q + t];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        acc = acc + v[t];
+        v[t] = acc;
+      }
+      if (lane < 3) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) prefix[chain][16 * q + t] = v[t];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const double run_m = prefix[0][lane], run_am = prefix[1][lane], run_a2m = prefix[2][lane];
+    if (live) {
+      double cc = (2.0 * run_am) / (uk + 2.0 * run_m);
+      cc = fmin(fmax(cc, lower), ai);
+      const double c2 = cc * cc;
+      const double e = ((c2 * nk + run_a2m) - (2.0 * cc) * run_am) + c2 * run_m;
+      if (e < best_e) {
+        best_e = e;
+        best_c = cc;
+        best_i = i;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double oe = __shfl_xor(best_e, off, kWave);
+    const double oc = __shfl_xor(best_c, off, kWave);
+    const int32_t oi = __shfl_xor(best_i, off, kWave);
+    if (oe < best_e || (oe == best_e && oi < best_i)) {
+      best_e = oe;
+      best_c = oc;
+      best_i = oi;
+    }
+  }
+  MI355Q_PREFIX_STAMP(5);
+#if defined(MI355Q_PREFIX_PROF)
+  if (row == 1000 && lane == 0)
+    printf("prefix row 1000: P %u P2 %d | load+max %llu  search %llu  compact+next %llu  sort %llu  scan %llu cycles\n", P, P2,
+           stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4]);
+#endif
+  // ---- 4. may the rest of the row be left out?
+  const double s_m = __shfl(acc, 0, kWave), s_am = __shfl(acc, 1, kWave), s_a2m = __shfl(acc, 2, kWave);
+  bool done = Pn == g;
+  if (!done) {
+    const double mass = (12.0 * qmax * qmax) * nk;                        // M (+ 1e-12), as the host formed noise from it
+    const double t_max = (a0 * a0) * nk + 4.0 * (s_a2m + (a_next * a_next) * mass);
+    const double slack = 64.0 * static_cast<double>(g) * 1.1102230246251565e-16 * t_max;
+    const double stationary = (2.0 * s_am) / (uk + 2.0 * s_m);
+    const double an2 = a_next * a_next;
+    const double e_next = ((an2 * nk + s_a2m) - (2.0 * a_next) * s_am) + an2 * s_m;
+    // (every comparison is false when one of its operands is NaN, and inf fails `t_max < inf`)
+    done = stationary >= a_next * (1.0 + 1e-6) && e_next > best_e + 4.0 * slack && t_max < __builtin_inf() && best_e >= 0.0;
+  }
+  if (__ballot(out_of_order) != 0) done = false;
+  if (lane == 0) {
+    todo[row] = done ? 0 : 1;
+    if (done) {
+      if (bounds) bounds[row] = best_c;
+      if (scale) {
+        double sc = fmax(best_c, 1e-9) / qmax;
+        if (blockwise) {
+          uint16_t half_bits;
+          sc = static_cast<double>(round_scale_blockwise(static_cast<float>(sc), &half_bits));
+        }
+        scale[row] = sc;
+      }
     }
   }
 }
@@ -842,8 +1302,9 @@ extern "C" int32_t mi355q_oscar_clip_workspace_bytes(int64_t n, int64_t d, int64
                 (long long)d, (long long)g);
   const int64_t total = n * d;
   if (total > 0xFFFFFFFFll - g) return fail(MI355Q_UNSUPPORTED, "oscar clip: more than 2^32 weights");
-  // two (key, value) slabs: the run merges ping-pong between them
-  *bytes_out = 4 * align256(static_cast<size_t>(total) * sizeof(double));
+  // two (key, value) slabs: the run merges ping-pong between them; behind them one byte per segment (the rows the prefix
+  // kernel left to the full sort, clip_prefix_kernel)
+  *bytes_out = 4 * align256(static_cast<size_t>(total) * sizeof(double)) + align256(static_cast<size_t>(total / g));
   return MI355Q_OK;
 }
 
@@ -862,7 +1323,7 @@ constexpr int64_t kSortRun = 8192;
 
 int32_t sort_segments(const float* w, const double* s, const double* m, int64_t n, int64_t d,
                       int64_t g, bool allow_rank_major, void* workspace, size_t need, hipStream_t st,
-                      Sorted* out) {
+                      Sorted* out, const uint8_t* todo = nullptr) {
   (void)need;
   const int64_t total = n * d;
   const size_t slab = align256(static_cast<size_t>(total) * sizeof(double));
@@ -893,13 +1354,13 @@ int32_t sort_segments(const float* w, const double* s, const double* m, int64_t 
   const int threads = tile >= 8192 ? 1024 : 512;   // measured best of {256, 512, 1024} per tile size
   hipLaunchKernelGGL(sort_tile_kernel, dim3(static_cast<unsigned>(tiles)), dim3(threads), lds, st,
                      w, s, m, units, static_cast<int32_t>(unit_len), P, tile, d, transposed, g,
-                     static_cast<int32_t>(runs_per_seg), keys_a, vals_a);
+                     static_cast<int32_t>(runs_per_seg), keys_a, vals_a, todo);
   MI355Q_CHECK_LAUNCH("oscar_sort_tile");
   const double *keys = keys_a, *vals = vals_a;
   double *keys_o = keys_b, *vals_o = vals_b;
   for (int64_t run = kSortRun; run < g; run *= 2) {
     hipLaunchKernelGGL(merge_runs_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
-                       0, st, keys, m ? vals : nullptr, total, g, run, keys_o, vals_o);
+                       0, st, keys, m ? vals : nullptr, total, g, run, keys_o, vals_o, todo);
     MI355Q_CHECK_LAUNCH("oscar_merge_runs");
     const double* tk = keys; keys = keys_o; keys_o = const_cast<double*>(tk);
     const double* tv = vals; vals = vals_o; vals_o = const_cast<double*>(tv);
@@ -937,22 +1398,49 @@ extern "C" int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s,
   hipStream_t st = as_stream(stream);
   const int64_t total = n * d, segments = total / g;
   const int64_t G = (g == total) ? 1 : d / g;
+  // CHANNELWISE rows are answered from a prefix of their sorted order where that provably gives the full scan's
+  // answer (clip_prefix_kernel); the rows it flags -- and every other layout -- go through the full sort + scan.
+  // MI355Q_OSCAR_PREFIX=0: full sort + scan for every row (A / B timing, and the equality test of the two routes).
+  const uint8_t* todo = nullptr;
+  const char* prefix_env = getenv("MI355Q_OSCAR_PREFIX");          // (read per call: the tests switch routes in one process)
+  const bool prefix_on = !(prefix_env && prefix_env[0] == '0');
+  if (prefix_on && g == d && n > 0 && g >= 1024 && g <= 16384 && qmax >= 7) {
+    uint8_t* flags = static_cast<uint8_t*>(workspace) + 4 * align256(static_cast<size_t>(total) * sizeof(double));
+    // elements asked for: a sixteenth of the row within [128, 256] for the one-wave form (it sorts at most 512), a
+    // thirty-second within [256, 512] beyond (at most 1024 sorted)
+    int64_t target = g / 16;
+    if (g <= 4096) target = target < 128 ? 128 : (target > 256 ? 256 : target);
+    else target = g / 32 < 256 ? 256 : (g / 32 > 512 ? 512 : g / 32);
+#define MI355Q_LAUNCH_PREFIX(EPT, WAVES)                                                                                \
+  hipLaunchKernelGGL((clip_prefix_kernel<EPT, WAVES>), dim3(static_cast<unsigned>(n)), dim3(64 * WAVES), 0, st, w, s, m, n, \
+                     static_cast<int32_t>(g), static_cast<int32_t>(target), u, noise, static_cast<double>(qmax),       \
+                     blockwise_scale, bounds_out, scale_out, flags)
+    if (g <= 1024) MI355Q_LAUNCH_PREFIX(16, 1);
+    else if (g <= 2048) MI355Q_LAUNCH_PREFIX(32, 1);
+    else if (g <= 4096) MI355Q_LAUNCH_PREFIX(64, 1);
+    else if (g <= 8192) MI355Q_LAUNCH_PREFIX(32, 4);
+    else MI355Q_LAUNCH_PREFIX(64, 4);
+#undef MI355Q_LAUNCH_PREFIX
+    MI355Q_CHECK_LAUNCH("oscar_clip_prefix");
+    todo = flags;
+  }
   Sorted sorted;
-  st_code = sort_segments(w, s, m, n, d, g, true, workspace, need, st, &sorted);
+  st_code = sort_segments(w, s, m, n, d, g, true, workspace, need, st, &sorted, todo);
   if (st_code != MI355Q_OK) return st_code;
   const double* keys_out = sorted.keys;
   const double* vals_out = sorted.vals;
   const int64_t seg_stride = sorted.seg_stride, elem_stride = sorted.elem_stride;
-  if (elem_stride == 1 && g >= 256 && segments < 12288) {
+  if (elem_stride == 1 && g >= 256 && (segments < 12288 || todo)) {
     // the wave form costs ~40 SIMD cycles per element instead of ~6, but runs on `segments` (not
     // segments / 64) waves: measured faster up to ~12k long segments (4096 x 4096: 0.73 vs 1.27 ms)
+    // -- and always when only the rows the prefix kernel flagged are left
     hipLaunchKernelGGL(clip_scan_wave_kernel, dim3(static_cast<unsigned>((segments + 3) / 4)), dim3(256),
                        0, st, keys_out, vals_out, segments, g, G, u, noise, static_cast<double>(qmax),
-                       blockwise_scale, bounds_out, scale_out);
+                       blockwise_scale, bounds_out, scale_out, todo);
   } else {
     hipLaunchKernelGGL(clip_scan_kernel<8>, dim3(static_cast<unsigned>((segments + 63) / 64)), dim3(64),
                        0, st, keys_out, vals_out, segments, g, G, seg_stride, elem_stride, u, noise,
-                       static_cast<double>(qmax), blockwise_scale, bounds_out, scale_out);
+                       static_cast<double>(qmax), blockwise_scale, bounds_out, scale_out, todo);
   }
   MI355Q_CHECK_LAUNCH("oscar_clip_scan");
   return MI355Q_OK;

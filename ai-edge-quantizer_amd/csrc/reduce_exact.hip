@@ -766,6 +766,18 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : (SLOTS == 1 ? 4 : (SL
   int nit = 0;      // iterations that exchanged something (the exchange areas alternate with it)
   int scan_p = 0, scan_n = 0;   // the last dense iteration's inclusive scans of selected elements inside the wave
   for (int it = 0; it < a.max_iter; ++it) {
+#if !defined(MI355Q_OCTAV_HOISTED)
+    // The per-lane LDS addresses of an iteration (this thread's mask words, its dummy slot, its wave's exchange slots)
+    // are functions of the thread index alone: hoisted out of the loop they are eight VGPRs that live across every
+    // iteration -- and at the 128 VGPRs four rows per CU allow, eight scratch dwords per lane (33 MB of dirty lines
+    // per 4096 x 4096 call, profiles/r05_octav_exact_writes.txt). Laundering the index makes them this iteration's
+    // values: a dozen integer instructions per iteration instead, no scratch in any instantiation, and 4096 x 4096
+    // went from 187 to 175 us (profiles/r06_octav_remat.txt; -DMI355Q_OCTAV_HOISTED restores the hoisted form).
+    int tid_now = threadIdx.x;
+    asm volatile("" : "+v"(tid_now));
+    const int tid = tid_now, lane = tid_now & (kWave - 1), wave = tid_now >> 6;
+    float* dummy = smem + 2 * kX + tid;
+#endif
     const float hi = guess, lo = -guess;
     bool have_sums = false;
     if (guess > row_amax) {

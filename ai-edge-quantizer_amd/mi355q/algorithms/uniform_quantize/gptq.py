@@ -127,6 +127,7 @@ class HessianAccumulator(rt.HbmArray):
     self._host = None
     self.cache = {}
     self.packed = None
+    self.ready = None             # event behind a reduce across ranks that is still filling _prod on another stream
 
   @classmethod
   def of(cls, x2d, num_samples: float, borrow: bool = False) -> "HessianAccumulator":
@@ -237,6 +238,8 @@ class HessianAccumulator(rt.HbmArray):
 
   def absorb(self, other: "HessianAccumulator") -> None:
     """self <- the mean over both sets of samples."""
+    self._wait_ready()
+    other._wait_ready()   # pylint: disable=protected-access
     self._touched()
     if other._borrowed is not None:   # pylint: disable=protected-access
       (x2d, n), other._borrowed = other._borrowed, None   # pylint: disable=protected-access
@@ -253,7 +256,16 @@ class HessianAccumulator(rt.HbmArray):
     if other._mean is not None:   # pylint: disable=protected-access
       self._join(other._mean, other._n_done)   # pylint: disable=protected-access
 
+  def _wait_ready(self) -> None:
+    if self.ready is not None:
+      # the product is the sum over the ranks once this event has fired (distributed.reduce_products_beside_compute):
+      # every reader comes through here, and only the stream that reads waits
+      import torch
+      torch.cuda.current_stream().wait_event(self.ready)
+      self.ready = None
+
   def flush(self) -> None:
+    self._wait_ready()
     self.own()
     if not self._fill:
       return

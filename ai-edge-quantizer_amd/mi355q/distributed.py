@@ -213,6 +213,10 @@ COST_MODEL = {
                "DECOMPOSED_HADAMARD_ROTATION": 16.0, "OSCAR": 100.0, "GPTQ": 1.0, "float_casting": 1.0,
                "dequantized_weight_recovery": 30.0},
     "launch_s": 20e-6,
+    # X2: one ring reduce per distinct Hessian over xGMI (7 links x ~153 GB/s per GPU, point to point: a ring step is bound by
+    # ONE link). ASSUMED until a node with more than one GPU has run it: 120 GB/s sustained per link, 30 us per collective.
+    "xgmi_link_bytes_per_s": float(os.environ.get("MI355Q_COST_XGMI_LINK", 120e9)),
+    "collective_s": 30e-6,
 }
 
 
@@ -339,6 +343,43 @@ def plan_loads(costs: Sequence[tuple[float, Optional[tuple], float]], owner: Seq
       paid.add((r, key))
       load[r] += shared
   return load
+
+
+def x2_reduce_plan(plan: Sequence[tuple], owner: Sequence[int], costs, world_size: int) -> dict:
+  """What the Hessian exchange (X2) adds to a sharded GPTQ run, per the cost model: every distinct Hessian is ONE ring
+  reduce of its float32 product's packed lower triangle -- d (d + 1) / 2 x 4 bytes, 0.5 GiB at d = 16384 -- to the rank
+  that owns its readers (merge_hessians_across_ranks). A ring reduce of S bytes over N ranks moves S (N - 1) / N over
+  every link in turn, so it takes every rank the same time whoever receives it: `seconds` is added to EVERY rank's
+  modelled load, and `seconds_exposed` is what remains of it on the busiest owner once reduce k + 1 ... run beside the
+  damped inverse of Hessian k (reduce_products_beside_compute): the first reduce of an owner, plus whatever exceeds the
+  inverses it runs under."""
+  c = COST_MODEL
+  seen: dict = {}
+  for item, o, (_, key, shared) in zip(plan, owner, costs):
+    if key is None or key[0] != "hessian" or key in seen:
+      continue
+    graph_info, op = item[0], item[1]
+    d = int(graph_info.subgraph_tensors[op.inputs[1]].shape[-1])
+    seen[key] = (d, int(o), float(shared))
+  out = {"hessians": len(seen), "bytes": 0, "seconds": 0.0, "bytes_to_owner": [0] * world_size,
+         "seconds_exposed": 0.0, "assumed_link_GBps": c["xgmi_link_bytes_per_s"] / 1e9}
+  if world_size <= 1 or not seen:
+    return out
+  inverse_s = [0.0] * world_size
+  first_s = [0.0] * world_size
+  for (d, o, shared) in seen.values():
+    nbytes = d * (d + 1) // 2 * 4
+    t = c["collective_s"] + nbytes * (world_size - 1) / world_size / c["xgmi_link_bytes_per_s"]
+    out["bytes"] += nbytes
+    out["seconds"] += t
+    out["bytes_to_owner"][o] += nbytes
+    inverse_s[o] += shared
+    first_s[o] = max(first_s[o], t)
+  # an owner's inverses hide every reduce but (at least) the largest one it waits for first
+  out["seconds_exposed"] = max(max(first_s), out["seconds"] - min(v for v in inverse_s if v > 0.0) if any(inverse_s) else out["seconds"])
+  out["seconds"] = round(out["seconds"], 5)
+  out["seconds_exposed"] = round(out["seconds_exposed"], 5)
+  return out
 
 
 def plan_model_shards(float_model, recipe, world_size: int, calibration_result: Optional[dict] = None):
@@ -1056,6 +1097,48 @@ def _product_form_everywhere(names: Sequence[str], local: dict, group, comm) -> 
   return {name: v >= 1.0 for name, v in zip(names, agreed)}
 
 
+_COMM_STREAM: list = []
+ISSUED: list = []       # (tensor name, root) of every product reduce, in the order it was issued (tests read this)
+
+
+def comm_stream():
+  """The HIP stream the X2 reduces run on, beside the compute stream (one per process)."""
+  if not _COMM_STREAM:
+    _COMM_STREAM.append(torch.cuda.Stream())
+  return _COMM_STREAM[0]
+
+
+def reduce_products_beside_compute(comm, jobs: Sequence[tuple]) -> dict[str, Any]:
+  """The float32-product reduces of `jobs` = [(name, product [d, d] float32 in HBM, d, root)], issued back to back on
+  the communication stream in the order given -- the SAME order on every rank (RCCL matches collectives by order of
+  issue) -- behind everything the compute stream has been given so far. Returns {name: event that fires when that
+  Hessian's sum has been unpacked into `product` on the ranks that receive it}. Nothing waits here: the host goes on
+  to start the damped inverses, each of which waits for ITS Hessian's event only (HessianAccumulator.ready), so the
+  inverse of Hessian k runs while Hessians k + 1 ... are still crossing xGMI. The 8-rank C5 plan has 18 reduces of
+  0.5 GiB (d = 16384) per job -- tens of milliseconds the owners used to spend waiting before their first inverse.
+  Ref (what this exchange replaces): utils/qsv_utils.py:71-102, calibrator.py:395-421."""
+  from . import _ffi
+  from . import runtime as rt
+  if not jobs:
+    return {}
+  L = _ffi.lib()
+  side = comm_stream()
+  side.wait_stream(torch.cuda.current_stream())          # the products' last slabs are multiplied on the compute stream
+  need = max(int(L.mi355q_product_exchange_workspace_bytes(d)) for _, _, d, _ in jobs)
+  scratch = rt.empty((max(need, 1),), torch.uint8)
+  scratch.record_stream(side)                            # (the allocator must not hand it out again before `side` is through)
+  events = {}
+  for name, prod, d, root in jobs:
+    prod.record_stream(side)
+    _ffi.check(L.mi355q_reduce_product_f32(comm, rt.ptr(prod), d, int(root), rt.ptr(scratch), scratch.numel(),
+                                           ctypes.c_void_p(side.cuda_stream)))
+    ISSUED.append((name, int(root)))
+    ev = torch.cuda.Event()
+    ev.record(side)
+    events[name] = ev
+  return events
+
+
 def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dict[str, tuple[int, float]],
                                 group=None, owners: Optional[dict[str, int]] = None) -> dict[str, Any]:
   """X2: the sample-weighted mean of every GPTQ Hessian over all ranks.
@@ -1090,6 +1173,23 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
   scratch = None
   names = sorted(totals)
   in_product_form = _product_form_everywhere(names, local, group, comm) if (world > 1 and on_gpu) else {}
+  # the statistics that travel in the form they are kept in -- the float32 product's packed lower triangle, summed in
+  # float32 (0.5 GiB per d = 16384 Hessian); the receiving ranks keep them as products (alpha = 2 / N). Over RCCL all of
+  # them are issued first, on the communication stream (reduce_products_beside_compute): same order on every rank.
+  jobs, kept = [], {}
+  if world > 1:
+    for name in names:
+      if not in_product_form.get(name):
+        continue
+      d, total = totals[name]
+      h, _ = local.get(name, (None, 0.0))
+      root = -1 if owners is None else int(owners.get(name, -1))
+      prod = None if h is None else h.product_form()[0]
+      if prod is None:             # this rank saw no sample of it: it still takes part (and may be the one that keeps the sum)
+        prod = torch.zeros((d, d), dtype=torch.float32, device=rt.device())
+      jobs.append((name, prod, d, root))
+      kept[name] = prod
+  ready = reduce_products_beside_compute(comm, jobs) if comm is not None else {}
   for name in names:
     d, total = totals[name]
     h, n_rank = local.get(name, (None, 0.0))
@@ -1099,20 +1199,10 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
       out[name] = h
       continue
     if in_product_form.get(name):
-      # the statistic travels in the form it is kept in: the float32 product's packed lower triangle, summed in
-      # float32 (0.5 GiB per d = 16384 Hessian); the receiving ranks keep it as a product (alpha = 2 / N)
       from .algorithms.uniform_quantize import gptq
-      prod = None if h is None else h.product_form()[0]
-      if prod is None:             # this rank saw no sample of it: it still takes part (and may be the one that keeps the sum)
-        prod = torch.zeros((d, d), dtype=torch.float32, device=rt.device())
-      if comm is not None:
-        L = _ffi.lib()
-        need = L.mi355q_product_exchange_workspace_bytes(d)
-        if scratch is None or scratch.numel() < need:
-          scratch = None
-          scratch = rt.empty((need,), torch.uint8)
-        _ffi.check(L.mi355q_reduce_product_f32(comm, rt.ptr(prod), d, root, rt.ptr(scratch), scratch.numel(), rt.stream_ptr()))
-      else:                                                     # test transport: ranks share a GPU
+      prod = kept[name]
+      if comm is None:                                          # test transport: ranks share a GPU
+        ISSUED.append((name, root))
         host = torch.tril(prod).cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         if mine:
@@ -1120,6 +1210,7 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
       if mine:
         acc = gptq.HessianAccumulator(d)
         acc._prod, acc._n_prod = prod, float(total)   # pylint: disable=protected-access
+        acc.ready = ready.get(name)                   # (whoever reads the product first waits for its sum: flush())
         out[name] = acc
       continue
     weight = float(n_rank) / float(total) if total else 0.0

@@ -732,10 +732,13 @@ def oscar_winner_energy(winner: torch.Tensor, wsq: torch.Tensor, d: int, g: int)
 
 def oscar_clip_bounds(w: torch.Tensor, s: torch.Tensor, masses: torch.Tensor, g: int,
                       u: torch.Tensor, noise: torch.Tensor, qmax: int, blockwise_scale: bool = False,
-                      want_bounds: bool = True, want_scale: bool = False):
+                      want_bounds: bool = True, want_scale: bool = False, want_rows_left: bool = False):
   """Optimal clip bound (float64) of every g-element segment of the flattened weight and / or
-  the symmetric scale derived from it (float64 values; float16-representable when blockwise)."""
+  the symmetric scale derived from it (float64 values; float16-representable when blockwise).
+  `want_rows_left`: also the per-segment flags of the rows the prefix kernel handed to the full sort + scan
+  (uint8 [n * d / g]; None when the call took the full route for every segment) -- for the tests and the bench."""
   import ctypes
+  import os
   rt.require_gpu()
   w = _f32(w)
   n, d = w.shape
@@ -747,6 +750,10 @@ def oscar_clip_bounds(w: torch.Tensor, s: torch.Tensor, masses: torch.Tensor, g:
   _ffi.check(_ffi.lib().mi355q_oscar_clip_bounds_f32(
       rt.ptr(w), rt.ptr(s), rt.ptr(masses), n, d, g, rt.ptr(u), rt.ptr(noise), int(qmax),
       int(blockwise_scale), rt.ptr(bounds), rt.ptr(scale), rt.ptr(ws), need.value, rt.stream_ptr()))
+  if want_rows_left:
+    took_prefix = (g == d and 1024 <= g <= 16384 and qmax >= 7 and os.environ.get("MI355Q_OSCAR_PREFIX", "")[:1] != "0")
+    slab = (n * d * 8 + 255) // 256 * 256
+    return bounds, scale, (ws[4 * slab:4 * slab + n * d // g].clone() if took_prefix else None)
   return bounds, scale
 
 

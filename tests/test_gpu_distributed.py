@@ -339,6 +339,26 @@ def _worker_rccl_single(rank, world, port, out):
   _ffi.check(L.mi355q_comm_destroy(other))
   merged = D.merge_hessians_across_ranks({"t": (rt.HbmArray(torch.from_numpy(h).cuda()), 3)}, {"t": (64, 3)})
   ok &= bool(np.array_equal(np.asarray(merged["t"]), h))
+  # ---- the product reduces on the communication stream (what N ranks run for X2): issued back to back in the order
+  # given, one event per Hessian, the reader of a product waits for ITS event only
+  from mi355q.algorithms.uniform_quantize import gptq
+  del D.ISSUED[:]
+  big = torch.from_numpy(rng.standard_normal((1024, 1024)).astype(np.float32)).cuda()
+  small = torch.from_numpy(rng.standard_normal((67, 67)).astype(np.float32)).cuda()
+  want_big, want_small = big.clone(), small.clone()
+  busy = torch.ones((1 << 26,), device="cuda")
+  for _ in range(20):
+    busy = busy * 1.0000001                                  # the compute stream has work queued in front of the reduces
+  events = D.reduce_products_beside_compute(D.rccl_comm(), [("a/big", big, 1024, 0), ("b/small", small, 67, -1)])
+  ok &= D.ISSUED == [("a/big", 0), ("b/small", -1)] and list(events) == ["a/big", "b/small"]
+  acc = gptq.HessianAccumulator(1024)
+  acc._prod, acc._n_prod, acc.ready = big, 4.0, events["a/big"]        # pylint: disable=protected-access
+  prod, alpha = acc.product_form()                                       # waits for the event on the reading stream
+  ok &= acc.ready is None and alpha == 0.5
+  ok &= bool(torch.equal(torch.tril(prod), torch.tril(want_big)))        # a world of one: the sum is the rank's own triangle
+  events["b/small"].synchronize()
+  ok &= bool(torch.equal(torch.tril(small), torch.tril(want_small)))
+  ok &= D.comm_stream() is D.comm_stream() and D.comm_stream() != torch.cuda.current_stream()
   D.destroy_rccl_comms()
   out.put((0, bool(ok)))
   dist.barrier()
@@ -486,8 +506,10 @@ def _worker_c5_fused(rank, world, port, out):
     calls["hinv"] += 1
     return real_product(*a, **k)
   ops.gptq_hinv, ops.gptq_hinv_batched, ops.gptq_hinv_from_product = counting, counting_batched, counting_product
+  del D.ISSUED[:]
   sharded = D.calibrate_and_quantize_sharded(path, rcp, data)
   mine = calls["hinv"]
+  issued = list(D.ISSUED)
   ops.gptq_hinv, ops.gptq_hinv_batched, ops.gptq_hinv_from_product = real, real_batched, real_product
   single = None
   if rank == 0:
@@ -496,7 +518,7 @@ def _worker_c5_fused(rank, world, port, out):
   dist.barrier()
   if rank == 0:
     os.remove(path)
-  out.put((rank, mine, None if sharded is None else bytes(sharded), single, _rccl_ranks()))
+  out.put((rank, mine, None if sharded is None else bytes(sharded), single, _rccl_ranks(), issued))
   dist.barrier()
   dist.destroy_process_group()
 
@@ -519,8 +541,13 @@ def test_two_ranks_calibrate_and_quantize_in_one_call_over_rccl(monkeypatch):
 
 def _check_c5_fused(results, label: str, rccl: bool):
   import numpy as np
-  (r0, n0, sharded, single, comm0), (r1, n1, other, _, comm1) = results
+  (r0, n0, sharded, single, comm0, issued0), (r1, n1, other, _, comm1, issued1) = results
   assert (comm0, comm1) == (((2, 0), (2, 1)) if rccl else (None, None))
+  # X2: every distinct Hessian is ONE reduce, issued in the same order on both ranks (RCCL matches collectives by order
+  # of issue: a rank that issued them in another order would deadlock or add the wrong triangles), each to the rank
+  # that owns its readers
+  assert issued0 == issued1 and len(issued0) == 8 and [n for n, _ in issued0] == sorted(n for n, _ in issued0)
+  assert {root for _, root in issued0} == {0, 1}
   assert other is None and sharded is not None
   assert n0 + n1 == 8 and n0 > 0 and n1 > 0, (n0, n1)
   assert len(sharded) == len(single)

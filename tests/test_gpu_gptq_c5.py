@@ -355,3 +355,96 @@ def test_full_chain_with_llm_like_activations_d4096(m):
                     "int_mismatch_fraction", floor, 1.0)
   parity_rates.check_default_path("LLM-like activations: get_tensor_quant_params [48,4096] int4 vs oracle FULL CHAIN (sgemm product)",
                                   np.asarray(p.quantized_data), ref, ref_b)
+
+
+def test_full_chain_ill_conditioned_down_proj_d16384(m):
+  """d = 16384 where the FP64-Cholesky / bf16-split TRTRI + L^-T L^-1 choice is actually stressed (every other d = 16384
+  case feeds i.i.d. N(0, 1) tokens: H ~ 2 tokens I, the best-conditioned matrix there is). Activations shaped like a
+  decoder's MLP hidden state: per-token scales over a decade, a per-channel mean, eight massive channels 80 x the rest,
+  and a RANK-DEFICIENT TAIL -- the last 2048 channels are mixtures of the other 14336 plus 1e-3 of noise, so along 2048
+  directions the Hessian is ~1e-6 of its bulk and the damp term (0.01 mean(diag), ref gptq.py:115-116) decides the
+  inverse. Whole chain -- Hessian, damped inverse, OBS apply -- on 64 rows of a down_proj-shaped weight against the
+  oracle's OWN chain (sgemm Hessian, FP64 Cholesky, strtri, sgemm product: ref gptq.py:100-128, 131-216), with the
+  oracle's reproducibility (its Hessian summed in two halves) and BOTH sides' distance to an all-FP64 chain recorded
+  beside it; H^-1 against the exact FP64 inverse of the damped matrix."""
+  torch, q_ = m.torch, m.q
+  d, tail, samples, per = D_BIG, 2048, 32, 512                 # 16384 tokens: no more than d (rank <= 14336 + noise)
+  tokens = samples * per
+  gen = torch.Generator(device="cuda").manual_seed(6006)
+  base = torch.randn((tokens, d - tail), generator=gen, device="cuda")
+  base = base * torch.exp(0.8 * torch.randn((tokens, 1), generator=gen, device="cuda"))       # token-correlated scale
+  base = base + 0.3 * torch.randn((1, d - tail), generator=gen, device="cuda")                 # per-channel mean
+  mix = torch.randn((d - tail, tail), generator=gen, device="cuda") / float(np.sqrt(d - tail))
+  x = torch.cat([base, base @ mix + 1e-3 * torch.randn((tokens, tail), generator=gen, device="cuda")], dim=1)
+  del base, mix
+  x[:, torch.randint(0, d, (8,), generator=gen, device="cuda")] *= 80.0                      # massive channels
+  x = x.contiguous()
+  h = m.ops.gptq_xtx(x, 2.0 / samples)
+  hinv, info = m.ops.gptq_hinv(h, 0.01)
+  assert int(info.item()) == 0
+  damped = _damped(torch, h)
+  exact = torch.linalg.inv(damped)
+  def largest_eigenvalue(a, iters=60):            # symmetric positive definite: power iteration (an SVD of order 16384 takes minutes)
+    v = torch.ones((a.shape[0], 1), dtype=torch.float64, device="cuda")
+    lam = 0.0
+    for _ in range(iters):
+      v = a @ v
+      lam = float(v.norm())
+      v /= lam
+    return lam
+  cond = largest_eigenvalue(damped) * largest_eigenvalue(exact)          # lambda_max / lambda_min (a lower estimate)
+  parity_rates.note("ill-conditioned d=16384: condition number of the damped Hessian (recorded, not gated)", "condition_number",
+                    cond, 1e30)
+  assert cond > 1e4                                              # (N(0,1) tokens: ~10)
+  err = float((hinv.double() - exact).abs().max() / exact.abs().max())
+  parity_rates.note("ill-conditioned d=16384: hinv vs exact FP64 inverse", "max_rel_error", err, 7e-7)
+  del damped
+  # ---- the oracle's own chain on the host
+  xh = x.reshape(samples, per, d).cpu().numpy()
+  del x
+  hess = O.gptq_hessian(xh)
+  x2 = xh.reshape(-1, d)
+  half = x2.shape[0] // 2
+  hess_b = (2.0 / np.array(samples)) * (x2[:half].T.dot(x2[:half]) + x2[half:].T.dot(x2[half:]))
+  del xh, x2
+  sub = np.r_[0:64, 8000:8064, d - 64:d]
+  idx = torch.from_numpy(sub).cuda()
+  parity_rates.check_rel("ill-conditioned d=16384: Hessian vs oracle x.T.dot(x), 192 columns",
+                         h[idx][:, idx].cpu().numpy(), hess[np.ix_(sub, sub)], 2e-6)
+  ref_hinv = O.gptq_hessian_inverse(hess, product="matmul")
+  ref_hinv_b = O.gptq_hessian_inverse(hess_b, product="matmul")
+  del hess, hess_b
+  exact32 = exact.float().cpu().numpy()
+  scale_of = float(np.abs(exact32).max())
+  parity_rates.note("ill-conditioned d=16384: the ORACLE's inverse (FP64 Cholesky, strtri, sgemm) vs the exact FP64 inverse (recorded)",
+                    "max_rel_error", float(np.abs(ref_hinv.astype(np.float64) - exact.cpu().numpy()).max() / scale_of), 1.0)
+  del exact
+  rows = 64
+  w = np.random.default_rng(6007).standard_normal((rows, d), dtype=np.float32) * np.float32(0.02)
+  cfg = q_.TensorQuantizationConfig(num_bits=4, symmetric=True, granularity=q_.QuantGranularity.CHANNELWISE)
+  info_ = q_.OpInfo(op=q_.OperatorT(), op_name=q_.TFLOperationName.FULLY_CONNECTED, subgraph_op_index=0,
+                    op_quant_config=q_.OpQuantizationConfig(weight_tensor_config=cfg))
+  p = m.gptq.get_tensor_quant_params(info_, cfg, w, {"activation_tensor_qsv": {"hessian": m.rt.HbmArray(h), "num_samples": samples}})
+  got = np.asarray(p.quantized_data)
+  ref_scale = O.min_max_quant_params(w, 4, True, "CHANNELWISE")["scale"]
+  assert np.array_equal(p.scale, ref_scale)
+  zp = np.zeros((rows, 1), np.int8)
+  ref = O.gptq_apply(w, ref_scale, zp, 4, True, None, "CHANNELWISE", hinv=ref_hinv)
+  ref_b = O.gptq_apply(w, ref_scale, zp, 4, True, None, "CHANNELWISE", hinv=ref_hinv_b)
+  truth = O.gptq_apply(w, ref_scale, zp, 4, True, None, "CHANNELWISE", hinv=exact32)        # all-FP64 Hessian and inverse
+  # Recorded when this test was written (cond 1.9e5): the ORACLE's float32 steps leave its inverse 8.8e-6 from the exact one
+  # (the GPU's: 5.3e-7) and 2.4e-3 of its integers differ from the all-FP64 chain's; summing its Hessian in another order
+  # moves 2.0e-3 of them -- the reference does not reproduce itself below that here. The GPU's integers EQUAL the all-FP64
+  # chain's (0 of 1 048 576). So the gates are: (1) the GPU against the exact-arithmetic answer under the default path's
+  # fixed bound; (2) the GPU no further from the reference than the reference is from itself (two floors, capped);
+  # (3) the GPU at least as close to the exact answer as the reference is.
+  rates = {}
+  for label, a in (("GPU", got), ("oracle", ref), ("oracle, Hessian summed in two halves", ref_b)):
+    rates[label] = float((a != truth).mean())
+    parity_rates.note(f"ill-conditioned d=16384 [64,16384] int4: {label} vs the all-FP64 chain (recorded)", "int_mismatch_fraction",
+                      rates[label], 1.0)
+  parity_rates.check_default_path("ill-conditioned d=16384: get_tensor_quant_params [64,16384] int4 vs the ALL-FP64 chain (exact Hessian, exact inverse)",
+                                  got, truth)
+  parity_rates.check_with_floor("ill-conditioned d=16384: get_tensor_quant_params [64,16384] int4 vs oracle FULL CHAIN (sgemm product)",
+                                got, ref, ref_b, cap=5e-3, k=2.0)
+  assert rates["GPU"] <= rates["oracle"]

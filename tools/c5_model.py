@@ -352,7 +352,9 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
       idle_gaps=(timer.gaps() if timer and os.environ.get("MI355Q_C5_GAPS") else None),
       spans=(timer.spans(*[float(v) for v in os.environ["MI355Q_C5_SPANS"].split(",")]) if timer and os.environ.get("MI355Q_C5_SPANS") else None),
       plan=dict(modelled_s_per_rank=[round(v, 4) for v in loads],
-                makespan_over_mean=round(max(loads) / (sum(loads) / world), 3) if sum(loads) else None))
+                makespan_over_mean=round(max(loads) / (sum(loads) / world), 3) if sum(loads) else None,
+                x2=Dm.x2_reduce_plan(plan, owner, costs, world),
+                x2_issued=len(Dm.ISSUED)))
   from mi355q import runtime as rt
   if rt.TIMELINE:      # MI355Q_TIMELINE=1: (label, ms since the call began when the host got there, ms when the GPU had drained if waited for, hipMallocs so far)
     out["timeline"] = [(label, round((a - t0) * 1e3, 1), round((b - t0) * 1e3, 1), n) for label, a, b, n in rt.TIMELINE]
