@@ -91,6 +91,35 @@ def table(rnd):
          ratio("octav_fast_kernel<64, 16>"), bench + " `extras.octav_clip_4096x4096_int4_fast`"))
     add(("`octav_fast_kernel<1024,16>` the same, 2048 x 16384", "`mi355q_octav_clip_fast_f32`", "HBM (one read)", "4 B/elem", f"{of2['ms'] * 1e3:.1f} us", f"{of2['hbm_frac_of_one_read']:.3f}",
          ratio("octav_fast_kernel<1024, 16>"), bench + " `extras.octav_clip_2048x16384_int4_fast`"))
+  # ---- round 6: MSE, OSCAR and the non-fused kernels (bench.py round6_extras)
+  if "mse_4096x4096_int4" in e:
+    ms_ = e["mse_4096x4096_int4"]
+    add(("`mse_scale_balanced_kernel` MSE scale 4096², NumPy pairwise order (bit-exact)", "`mi355q_mse_scale_f32`", "HBM (one read)", "4 B/elem", f"{ms_['scale_kernel_ms'] * 1e3:.1f} us",
+         f"{ms_['hbm_frac_of_one_read']:.3f}", ratio("mse_scale_balanced_kernel"), bench + " `extras.mse_4096x4096_int4`"))
+    add(("MSE `get_tensor_quant_params` on a resident 4096² weight (scale + quantize, wall clock)", "public call", "HBM", "9 B/elem (two reads, int8 out)", f"{ms_['public_call_ms'] * 1e3:.1f} us",
+         f"{ms_['public_call_hbm_frac']:.3f}", "-", bench + " `extras.mse_4096x4096_int4`"))
+  for label, key in (("channelwise", "oscar_4096x4096_int4_channelwise"), ("blocks of 128", "oscar_4096x4096_int4_b128")):
+    if key in e:
+      o = e[key]
+      cb = o["clip_bounds"]
+      kern = "`clip_prefix_kernel<64,1>` (rows answered from a sorted prefix; full sort + scan for the rest)" if label == "channelwise" else "`sort_tile_kernel` + `clip_scan_kernel<8>`"
+      add((f"{kern} OSCAR clip search 4096², {label}, bit-exact", "`mi355q_oscar_clip_bounds_f32`", "HBM (one read)", "4 B/elem", f"{cb['ms'] * 1e3:.1f} us", f"{cb['hbm_frac_of_one_read']:.3f}",
+           ratio("clip_prefix_kernel<64, 1>") if label == "channelwise" else "-", bench + f" `extras.{key}.clip_bounds`"))
+      add((f"OSCAR `get_tensor_quant_params` 4096², {label}: column energies {e['oscar_col_sumsq_4096x4096']['ms'] * 1e3:.0f} us, 4 x group terms {o['group_terms']['ms'] * 1e3:.0f} us,"
+           f" 3 x winner energy {o['winner_energy']['ms'] * 1e3:.0f} us, clip search, quantize {o['quantize']['ms'] * 1e3:.0f} us + the host's O(columns) NumPy between them (wall clock)",
+           "public call", "host", "-", f"{o['public_call_ms']:.2f} ms", f"{o['public_call_hbm_frac_of_one_read']:.4f} of one read", "-", bench + f" `extras.{key}`"))
+  if "oscar_clip_bounds_2048x16384_channelwise" in e:
+    o2 = e["oscar_clip_bounds_2048x16384_channelwise"]
+    add(("`clip_prefix_kernel<64,4>` OSCAR clip search 2048 x 16384, channelwise, bit-exact", "`mi355q_oscar_clip_bounds_f32`", "HBM (one read)", "4 B/elem", f"{o2['ms'] * 1e3:.1f} us",
+         f"{o2['hbm_frac_of_one_read']:.3f}", "-", bench + " `extras.oscar_clip_bounds_2048x16384_channelwise`"))
+  for key, name, entry, alg, tkey in (
+      ("minmax_f32_4096x4096_channelwise", "`minmax_runs_kernel` per-channel min / max 4096² (the non-fused route)", "`mi355q_minmax_f32`", "4 B/elem", "minmax_runs_kernel"),
+      ("minmax_f32_4096x4096_tensorwise", "the same, TENSORWISE (one channel: 4096 partials, one wave combines them)", "`mi355q_minmax_f32`", "4 B/elem", None),
+      ("quantize_f32_4096x4096_int8_asymmetric", "`quantize_rows_vec4_kernel` quantize with given scale / zero point, int8 asymmetric", "`mi355q_quantize_f32`", "5 B/elem", "quantize_rows_vec4_kernel"),
+      ("dequantize_f32_4096x4096_int8", "`dequantize_rows_vec4_kernel` int8 -> float32", "`mi355q_dequantize_f32`", "5 B/elem", "dequantize_rows_vec4_kernel")):
+    if key in e:
+      v = e[key]
+      add((name, entry, "HBM", alg, f"{v['ms'] * 1e3:.1f} us", f"{v.get('hbm_frac', v.get('hbm_frac_of_one_read')):.3f}", ratio(tkey) if tkey else "-", bench + f" `extras.{key}`"))
   for d in (2048, 16384):
     g = e["c5_gptq"][f"d{d}"]
     h = g["hessian"]
@@ -133,7 +162,7 @@ def table(rnd):
 
 def main():
   args = [a for a in sys.argv[1:] if not a.startswith("--")]
-  rnd = args[0] if args else "r05"
+  rnd = args[0] if args else "r06"
   text = table(rnd)
   path = os.path.join(ROOT, "DESIGN.md")
   old = open(path).read()

@@ -105,7 +105,11 @@ python tools/pmc_big_kernels.py /tmp/prof_fetch > "$OUT/hinv16384_fetch.txt" 2>&
   timeout 200 python tools/api_resident_timeline.py 2>&1 | tail -1
   echo "# tools/c4_bench.py through distributed.calibrate_sharded is in bench.json (sharded.c4_*); tools/c5_second_call.py --variant mixed:"
   MI355Q_TIMELINE=1 MI355Q_C5_GAPS=1 timeout 400 python tools/c5_second_call.py --variant mixed 2>/dev/null | cut -c1-1500
-} > "$OUT/round5_tools.txt" 2>&1
+  echo "# tools/oscar_bench.py --api: OSCAR stage by stage (clip_bounds: the prefix route, round 6) and the whole public call"
+  timeout 400 python tools/oscar_bench.py --api 2>&1 | grep "^{"
+  echo "# the same clip search with the prefix route off (MI355Q_OSCAR_PREFIX=0: full sort + scan of every row, round 5's kernels)"
+  MI355Q_OSCAR_PREFIX=0 timeout 400 python tools/oscar_bench.py 2>&1 | grep clip_bounds
+} > "$OUT/round6_tools.txt" 2>&1
 bash tools/pmc_traffic_refresh.sh "$ROUND" > "$OUT/pmc_traffic.log" 2>&1
 bash tools/c2_pmc_refresh.sh "$ROUND" > "$OUT/c2_pmc.log" 2>&1
 cp gpurun_out/${ROUND}_c2_pmc_traffic.txt gpurun_out/${ROUND}_c2_rowwise_int8_kernel_trace.txt gpurun_out/pmc_latest.json "$OUT/" 2>/dev/null

@@ -70,6 +70,31 @@ def main():
   for _ in range(3):
     ops.gptq_apply(w, hinv, sc, None, 1, 0, 4, False, False, 8)
   out.append(("gptq_rows_kernel", (2048 * 256 * 4 * 2 + 2048 * 256) * 1))     # per launch: one group of 256 columns read + written back (float32) + int8
+  # ---- round 6: MSE scale (one read), OSCAR clip search by prefix (one read of w + s), the non-fused kernels
+  import numpy as np
+  w = rand(4096, 4096)
+  for _ in range(3):
+    ops.mse_scale(w.view(-1), 4096, 4096, 0.37755)
+  out.append(("mse_scale_balanced_kernel", 4096 * 4096 * 4))
+  rng = np.random.default_rng(1)
+  s_ = ops._f64_dev(np.exp(rng.normal(size=4096) * 0.2))   # pylint: disable=protected-access
+  m_ = ops._f64_dev(np.exp(rng.normal(size=4096) * 1.5))   # pylint: disable=protected-access
+  u_, n_ = ops._f64_dev(np.full(1, 0.01)), ops._f64_dev(np.full(1, 0.005))   # pylint: disable=protected-access
+  for _ in range(3):
+    ops.oscar_clip_bounds(w, s_, m_, 4096, u_, n_, 7, False, True, True)
+  out.append(("clip_prefix_kernel<64, 1>", 4096 * 4096 * 4))
+  for _ in range(3):
+    ops.minmax(w, 1, 4096, 4096)
+  out.append(("minmax_runs_kernel", 4096 * 4096 * 4))
+  mn, mx = ops.minmax(w, 1, 4096, 4096)
+  scale = ((mx - mn) / 255.0).contiguous()
+  zp = torch.round(-128 - mn / scale).to(torch.int32)
+  for _ in range(3):
+    q8 = ops.quantize(w, 1, 4096, 4096, scale, zp, 8, False)
+  out.append(("quantize_rows_vec4_kernel", 4096 * 4096 * 5))
+  for _ in range(3):
+    ops.dequantize(q8, 1, 4096, 4096, scale, zp, 8)
+  out.append(("dequantize_rows_vec4_kernel", 4096 * 4096 * 5))
   torch.cuda.synchronize()
   for k, v in out:
     print(f"ALG {k}\t{v}")
