@@ -138,20 +138,43 @@ __global__ __launch_bounds__(256) void minmax_finalize_kernel(
 }
 
 // The same for FEW channels with MANY partials (TENSORWISE: one channel, thousands of splits -- a lane per channel walked
-// them one after the other, 0.46 ms for a 4096 x 4096 tensor whose reduction itself takes 15 us): one wave per channel,
-// lanes stride over the splits, butterfly at the end. min / max are order-free, so the result is the same.
-__global__ __launch_bounds__(kWave) void minmax_finalize_wave_kernel(
+// them one after the other, 0.46 ms for a 4096 x 4096 tensor whose reduction itself takes 15 us): a workgroup per
+// channel, threads stride over the splits four pairs at a time, butterfly + one LDS exchange at the end. min / max are
+// order-free, so the result is the same.
+__global__ __launch_bounds__(256) void minmax_finalize_wave_kernel(
     const float* __restrict__ pmn, const float* __restrict__ pmx, int64_t channels,
     int64_t splits, float* mn_out, float* mx_out) {
+  __shared__ float smn[4], smx[4];
+  __shared__ int snan[4];
   const int64_t c = blockIdx.x;
   if (c >= channels) return;
   MinMax a = mm_identity();
-  for (int64_t s = threadIdx.x; s < splits; s += kWave) {
+  int64_t s = threadIdx.x;
+  for (; s + 3 * 256 < splits; s += 4 * 256) {       // four pairs of partials in flight per thread
+    float mn[4], mx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mn[k] = pmn[(s + 256 * k) * channels + c];
+      mx[k] = pmx[(s + 256 * k) * channels + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mm_merge(a, mn[k], mx[k], mn[k] != mn[k]);
+  }
+  for (; s < splits; s += 256) {
     const float mn = pmn[s * channels + c], mx = pmx[s * channels + c];
     mm_merge(a, mn, mx, mn != mn);
   }
   a = wave_reduce(a);
-  if (threadIdx.x == 0) mm_store(a, mn_out, mx_out, c);
+  const int wave = threadIdx.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    smn[wave] = a.mn; smx[wave] = a.mx; snan[wave] = a.nan;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) mm_merge(a, smn[k], smx[k], snan[k] != 0);
+    mm_store(a, mn_out, mx_out, c);
+  }
 }
 
 struct MinMaxPlan {
@@ -651,7 +674,7 @@ extern "C" int32_t mi355q_minmax_f32(const float* x, int64_t outer, int64_t chan
   }
   MI355Q_CHECK_LAUNCH("minmax launch");
   if (p.splits >= 16 && channels <= 4096) {
-    hipLaunchKernelGGL(minmax_finalize_wave_kernel, dim3(static_cast<unsigned>(channels)), dim3(kWave), 0, st, pmn,
+    hipLaunchKernelGGL(minmax_finalize_wave_kernel, dim3(static_cast<unsigned>(channels)), dim3(256), 0, st, pmn,
                        pmx, channels, p.splits, min_out, max_out);
     MI355Q_CHECK_LAUNCH("minmax finalize launch");
   } else if (p.splits > 1) {
