@@ -503,6 +503,30 @@ def test_c5_plan_is_deterministic_and_mixed_recipe_has_no_heavy_units():
   assert max(loads) <= 1.15 * (sum(loads) / 8)
 
 
+def test_c5_plan_prices_the_hessian_exchange():
+  """X2 in the plan: one ring reduce of a packed float32 triangle per distinct Hessian, to its owner;
+  the time is the same for every rank, and what stays exposed once the reduces run beside the inverses is about one reduce."""
+  tri = lambda d: d * (d + 1) // 2 * 4
+  D, plan, owner, costs = _c5_plan(1)
+  x = D.x2_reduce_plan(plan, owner, costs, 1)
+  assert x["hessians"] == 72 and x["bytes"] == 0 and x["seconds"] == 0.0           # one rank: nothing travels
+  for world in (2, 8):
+    D, plan, owner, costs = _c5_plan(world)
+    x = D.x2_reduce_plan(plan, owner, costs, world)
+    assert x["hessians"] == 72 and x["bytes"] == 18 * tri(16384) + 54 * tri(2048)
+    assert sum(x["bytes_to_owner"]) == x["bytes"] and len(x["bytes_to_owner"]) == world
+    owners = D.hessian_owners(plan, owner, costs)
+    assert all(b > 0 for b in x["bytes_to_owner"]) and len(set(owners.values())) == world
+    link = D.COST_MODEL["xgmi_link_bytes_per_s"]
+    want = 72 * D.COST_MODEL["collective_s"] + x["bytes"] * (world - 1) / world / link
+    assert abs(x["seconds"] - want) < 1e-4
+    one_big = D.COST_MODEL["collective_s"] + tri(16384) * (world - 1) / world / link
+    assert one_big - 1e-5 <= x["seconds_exposed"] < 0.1 * x["seconds"] + one_big          # the first reduce of an owner
+  D, plan, owner, costs = _c5_plan(8, "mixed")
+  x = D.x2_reduce_plan(plan, owner, costs, 8)
+  assert x["hessians"] == 54 and x["bytes"] == 54 * tri(2048)                             # no d = 16384 Hessian in the mixed recipe
+
+
 def test_sample_sharded_gptq_calibration_reduces_hessians_instead_of_gathering_them():
   """calibrate_sharded with a GPTQ recipe: min / max / num_samples equal the single-process result
   exactly, the Hessian within FP64 rounding, and no d x d array enters the object gather."""
