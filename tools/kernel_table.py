@@ -114,7 +114,7 @@ def table(rnd):
          f"{o2['hbm_frac_of_one_read']:.3f}", "-", bench + " `extras.oscar_clip_bounds_2048x16384_channelwise`"))
   for key, name, entry, alg, tkey in (
       ("minmax_f32_4096x4096_channelwise", "`minmax_runs_kernel` per-channel min / max 4096² (the non-fused route)", "`mi355q_minmax_f32`", "4 B/elem", "minmax_runs_kernel"),
-      ("minmax_f32_4096x4096_tensorwise", "the same, TENSORWISE (one channel: 4096 partials, one wave combines them)", "`mi355q_minmax_f32`", "4 B/elem", None),
+      ("minmax_f32_4096x4096_tensorwise", "the same, TENSORWISE (one channel: 4096 partials, one workgroup combines them)", "`mi355q_minmax_f32`", "4 B/elem", None),
       ("quantize_f32_4096x4096_int8_asymmetric", "`quantize_rows_vec4_kernel` quantize with given scale / zero point, int8 asymmetric", "`mi355q_quantize_f32`", "5 B/elem", "quantize_rows_vec4_kernel"),
       ("dequantize_f32_4096x4096_int8", "`dequantize_rows_vec4_kernel` int8 -> float32", "`mi355q_dequantize_f32`", "5 B/elem", "dequantize_rows_vec4_kernel")):
     if key in e:
