@@ -1411,6 +1411,10 @@ extern "C" int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s,
     int64_t target = g / 16;
     if (g <= 4096) target = target < 128 ? 128 : (target > 256 ? 256 : target);
     else target = g / 32 < 256 ? 256 : (g / 32 > 512 ? 512 : g / 32);
+    if (const char* e = getenv("MI355Q_OSCAR_PREFIX_TARGET")) {           // A / B: how long a prefix is worth sorting
+      const long v = atol(e);
+      if (v >= 32 && v <= (g <= 4096 ? 512 : 1024)) target = v;
+    }
 #define MI355Q_LAUNCH_PREFIX(EPT, WAVES)                                                                                \
   hipLaunchKernelGGL((clip_prefix_kernel<EPT, WAVES>), dim3(static_cast<unsigned>(n)), dim3(64 * WAVES), 0, st, w, s, m, n, \
                      static_cast<int32_t>(g), static_cast<int32_t>(target), u, noise, static_cast<double>(qmax),       \

@@ -470,7 +470,12 @@ int32_t mi355q_oscar_winner_energy_f64(const int32_t* winner, const double* wsq,
  * target: max(bound, 1e-9) / qmax, and with blockwise_scale != 0 rounded FP64 -> float32 ->
  * bfloat16 -> float16 (ref uniform_quantize_tensor.py:553-581), stored as double.
  *   bounds_out / scale_out double [n*d/g], either may be NULL;
- *   workspace: mi355q_oscar_clip_workspace_bytes(n, d, g) */
+ *   workspace: mi355q_oscar_clip_workspace_bytes(n, d, g) (two (key, mass) slabs for the sort's merge passes + one byte per
+ *   segment).
+ * CHANNELWISE rows (g == d, 1024 <= g <= 16384, qmax >= 7) are answered from a sorted prefix of their largest magnitudes
+ * where a convexity argument with an explicit rounding bound shows that no later breakpoint can hold the first minimum;
+ * rows where it cannot take the full sort + scan. Same bits either way (csrc/oscar.hip: clip_prefix_kernel).
+ * Environment: MI355Q_OSCAR_PREFIX=0 full sort + scan for every row; MI355Q_OSCAR_PREFIX_TARGET=<n> elements asked for. */
 int32_t mi355q_oscar_clip_workspace_bytes(int64_t n, int64_t d, int64_t g, size_t* bytes_out);
 int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s, const double* m, int64_t n,
                                      int64_t d, int64_t g, const double* u, const double* noise,
