@@ -1172,6 +1172,11 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
     ops.release_scratch()
   scratch = None
   names = sorted(totals)
+  if comm is not None and _COMM_STREAM:
+    # collectives of one communicator are kept in ONE order on the device as well: whatever an earlier call still has on
+    # the communication stream is in front of everything this call issues on the compute stream (the agreement below,
+    # the float64 form further down)
+    torch.cuda.current_stream().wait_stream(_COMM_STREAM[0])
   in_product_form = _product_form_everywhere(names, local, group, comm) if (world > 1 and on_gpu) else {}
   # the statistics that travel in the form they are kept in -- the float32 product's packed lower triangle, summed in
   # float32 (0.5 GiB per d = 16384 Hessian); the receiving ranks keep them as products (alpha = 2 / N). Over RCCL all of
@@ -1221,6 +1226,8 @@ def merge_hessians_across_ranks(local: dict[str, tuple[Any, float]], totals: dic
         t = rt.on_device(h, torch.float64)
         t = t.clone() if mine else t
       if comm is not None:
+        if ready:        # (this call's product reduces first: same communicator, one order on the device)
+          torch.cuda.current_stream().wait_stream(comm_stream())
         L = _ffi.lib()
         need = L.mi355q_hessian_exchange_workspace_bytes(d)
         if scratch is None or scratch.numel() < need:
