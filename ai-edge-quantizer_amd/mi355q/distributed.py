@@ -22,6 +22,12 @@ communicator created from a ncclUniqueId broadcast over the existing rendezvous;
 is the rendezvous, the barrier and the object gather of results. With the "gloo" backend (CPU
 tests, or several test ranks sharing one GPU -- RCCL refuses duplicate devices) the same
 functions move host tensors through torch.distributed instead.
+
+N > 1 over RCCL on a box that shows ONE GPU (`one_gpu_ranks_env`): RCCL's refusal compares host hash and bus id, and the host
+hash can be set per process (NCCL_HOSTID). Ranks that claim different hosts are peers over RCCL's NET transport (sockets on
+the loopback interface, staged through host memory) and may all sit on cuda:0: not xGMI, but every "nccl" branch of this
+module and every RCCL entry point of libmi355q then runs with real peers (tests/test_gpu_distributed.py, bench.py
+MI355Q_BENCH_ONE_GPU_HOSTS=1).
 """
 from __future__ import annotations
 
@@ -37,6 +43,14 @@ from .utils import qsv_utils
 
 
 # ------------------------------------------------------------------ setup ---
+def one_gpu_ranks_env(rank: int) -> dict[str, str]:
+  """Environment under which rank `rank` of an N > 1 "nccl" process group may share cuda:0 with its peers: every rank names
+  a host of its own (RCCL then sees no duplicate device), the peers meet over sockets on the loopback interface. Set it
+  before the first RCCL call of the process (LOCAL_RANK = 0: the device index is not the rank)."""
+  return dict(NCCL_HOSTID=f"mi355q-one-gpu-rank-{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket",
+              NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", LOCAL_RANK="0")
+
+
 def init(backend: Optional[str] = None) -> tuple[int, int]:
   """Initialises the default process group from torchrun's environment.
 

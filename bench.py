@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ai-edge-quantizer_amd"))
 sys.path.insert(0, ROOT)
 
+ONE_GPU_HOSTS = os.environ.get("MI355Q_BENCH_ONE_GPU_HOSTS", "") == "1"
 ROWS = COLS = 4096
 POOL = 16
 PCT_LAUNCHES = 200     # launches the per-launch percentiles are taken over (>= SURVEY 8d's 100)
@@ -673,12 +674,13 @@ def spawn_ranks(args) -> int:
   their exit status. Rank 0's JSON line goes to this process's stdout (inherited)."""
   import subprocess
   backend = os.environ.get("MI355Q_BENCH_BACKEND", "nccl")
-  if backend == "nccl":
+  if backend == "nccl" and not ONE_GPU_HOSTS:
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if have < args.gpus:
       raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (one rank per GPU over RCCL;"
-                       " MI355Q_BENCH_BACKEND=gloo shares cuda:0 for a control-path check)")
+                       " MI355Q_BENCH_ONE_GPU_HOSTS=1 runs the ranks as separate hosts on cuda:0 over RCCL's socket"
+                       " transport, MI355Q_BENCH_BACKEND=gloo shares cuda:0 for a control-path check)")
   env = dict(os.environ)
   env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
   env.setdefault("OMP_NUM_THREADS", "8")
@@ -706,6 +708,13 @@ def main():
   backend = os.environ.get("MI355Q_BENCH_BACKEND", "nccl")
   if backend != "nccl":
     local = local % torch.cuda.device_count()
+  if ONE_GPU_HOSTS and backend == "nccl" and world > 1:
+    # RCCL with N > 1 on a one-GPU box: every rank names a host of its own (no "duplicate GPU"), the peers meet over RCCL's
+    # socket transport on the loopback interface, all of them on cuda:0. Not xGMI and not a scaling figure (N ranks share
+    # one GPU's HBM and CUs): it is the N > 1 code path -- collective probe, C3 / C4 / C5 sharded -- with real RCCL peers.
+    from mi355q import distributed as D_
+    os.environ.update(D_.one_gpu_ranks_env(rank))
+    local = 0
   torch.cuda.set_device(local)
   # MI355Q_BENCH_FORCE_PROBE=1: run the N > 1 collective probe on a world of one as well (the only
   # way to exercise it on a one-GPU box)
@@ -891,7 +900,10 @@ def main():
         "config": {"workload": "per-channel int8 symmetric requant of 4096x4096 FP32 weight"
                                " buffers (BASELINE config 2)",
                    "buffers_per_step": POOL, "bytes_in_per_step": POOL * ROWS * COLS * 4,
-                   "sharding": f"tensor-buffers x{world} (no collective)"},
+                   "sharding": f"tensor-buffers x{world} (no collective)",
+                   **({"ranks_share_one_gpu": "MI355Q_BENCH_ONE_GPU_HOSTS=1: N ranks as separate hosts on cuda:0 over RCCL's"
+                                              " socket transport -- the N > 1 code path, not a scaling figure"}
+                      if ONE_GPU_HOSTS and world > 1 else {})},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      # HBM bytes per launch from the rocprofv3 PMC passes recorded under profiles/

@@ -261,3 +261,67 @@ def test_samples_per_launch_does_not_change_the_bytes(c5m, k, monkeypatch):
   assert n == c5m["out_bytes"]
   assert _sha(out) == c5m["sha"]
   os.remove(out)
+
+
+def _worker_c5_mixed_two_ranks(rank, world, port, out, src="", dst=""):
+  """One rank of the bench's C5 call over RCCL: samples sharded, every Hessian's float32 product reduced to the rank that
+  owns the ops reading it (mi355q_reduce_product_f32 on the communication stream), ops sharded, rank 0 writes."""
+  os.environ["MI355Q_TEST_DIST_BACKEND"] = "nccl"
+  import test_gpu_distributed as T
+  dist = T._setup(rank, world, port)   # pylint: disable=protected-access
+  import torch
+  import c5_model as C
+  from mi355q import distributed as D
+  from mi355q.utils import litertlm_utils
+  samples = C.calibration_set(torch, LAYERS, SEQUENCES, TOKENS)          # the fixture's samples: every rank walks ITS shard of them
+  del D.ISSUED[:]
+  n = litertlm_utils.quantize_litertlm(src, C.recipe("mixed"), dst, calibration_data={0: {"serving_default": samples}})
+  torch.cuda.synchronize()
+  out.put((rank, n, T._rccl_ranks(), list(D.ISSUED), len(D.sample_shard(SEQUENCES, rank, world))))   # pylint: disable=protected-access
+  dist.barrier()
+  D.destroy_rccl_comms()
+  dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl_write_the_container_of_one(c5m):
+  """SURVEY 8e at the headline's shapes: the SAME call on two ranks over RCCL (one rank per GPU where two are visible, else two
+  "hosts" on cuda:0). Everything that does not depend on a Hessian -- scales, zero points, the rotated down rows, the graph -- is
+  byte for byte the single-process container's; a GPTQ projection's integers may differ only where the float32 product summed as
+  two partial products instead of one tips a rounding: under the default path's fixed bound, one step."""
+  import functools
+  from test_distributed_gloo import _run
+  dst = os.path.join(c5m["tmp"], "two_ranks.litertlm")
+  worker = functools.partial(_worker_c5_mixed_two_ranks, src=c5m["src"], dst=dst)
+  results = _run(worker, world=2, timeout=900)
+  (_, n0, comm0, issued0, share0), (_, n1, comm1, issued1, share1) = results
+  assert comm0 == (2, 0) and comm1 == (2, 1)
+  assert n0 == c5m["out_bytes"] == os.path.getsize(dst) and n1 is None
+  assert share0 + share1 == SEQUENCES and share0 > 0 and share1 > 0
+  # every rank issued the same product reduces in the same order (RCCL matches collectives by order of issue): one per Hessian
+  # (attn_in, o_in, mlp_in of every layer), each to ONE owner
+  assert issued0 == issued1 and len(issued0) == 3 * LAYERS
+  assert sorted(name for name, _ in issued0) == sorted(f"l{l}/{s}" for l in range(LAYERS) for s in ("attn_in", "o_in", "mlp_in"))
+  assert all(root in (0, 1) for _, root in issued0)
+  one, two = c5m["qmodel"], c5m["lm"].LiteRTLMFile(dst).read_model(0)
+  sg1, sg2 = one.subgraphs[0], two.subgraphs[0]
+  assert len(sg1.tensors) == len(sg2.tensors) and len(sg1.operators) == len(sg2.operators)
+  ints_one, ints_two = [], []
+  for t1, t2 in zip(sg1.tensors, sg2.tensors):
+    assert t1.name == t2.name and list(t1.shape) == list(t2.shape) and t1.type == t2.type
+    q1, q2 = t1.quantization, t2.quantization
+    assert (q1 is None) == (q2 is None)
+    if q1 is not None:
+      assert np.array_equal(np.asarray(q1.scale), np.asarray(q2.scale)) and np.array_equal(np.asarray(q1.zeroPoint), np.asarray(q2.zeroPoint))
+    b1, b2 = np.asarray(one.buffers[t1.buffer].data), np.asarray(two.buffers[t2.buffer].data)
+    name = t1.name.decode()
+    gptq_weight = name.endswith("/w") and "/down/" not in name
+    if not gptq_weight:
+      assert np.array_equal(b1, b2), name
+      continue
+    count = int(np.prod(t1.shape))
+    ints_one.append(_unpack_int4(b1, count))
+    ints_two.append(_unpack_int4(b2, count))
+  assert len(ints_one) == 6 * LAYERS
+  parity_rates.check("C5 MIXED one call, two ranks over RCCL vs one process: GPTQ int4 of q / k / v / o / gate / up, every row",
+                     np.concatenate(ints_two), np.concatenate(ints_one), 5e-5)
+  os.remove(dst)

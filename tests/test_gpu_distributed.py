@@ -11,10 +11,11 @@ from test_distributed_gloo import _setup as _setup_gloo
 
 pytestmark = pytest.mark.gpu
 
-# Every worker below runs twice where the box allows it: as two gloo ranks sharing cuda:0 (any box), and -- the moment two
-# GPUs are visible -- as one rank per GPU over RCCL ("nccl" backend), where the data collectives are libmi355q's own RCCL
-# entry points over xGMI (mi355q_allgather_minmax, mi355q_reduce_product_f32, ...) and every rank's payloads leave from
-# its own HBM. The builder's lease has one GPU: the RCCL variants are collected and skipped there.
+# Every worker below runs twice: as two gloo ranks sharing cuda:0, and as two ranks over RCCL ("nccl" backend), where the data
+# collectives are libmi355q's own RCCL entry points (mi355q_allgather_minmax, mi355q_reduce_product_f32, ...) and every rank's
+# payloads leave from HBM. With two GPUs visible that is one rank per GPU over xGMI; on a one-GPU box (the builder's lease) the
+# two ranks name different hosts (distributed.one_gpu_ranks_env: NCCL_HOSTID) and meet over RCCL's socket transport, both on
+# cuda:0 -- RCCL with a real peer either way.
 _BACKEND_ENV = "MI355Q_TEST_DIST_BACKEND"
 
 
@@ -26,7 +27,7 @@ def _gpus() -> int:
     return 0
 
 
-needs_two_gpus = pytest.mark.skipif(_gpus() < 2, reason="RCCL with N > 1 needs one GPU per rank (this box shows fewer than 2)")
+two_ranks_over_rccl = pytest.mark.skipif(_gpus() < 1, reason="RCCL with N > 1: one rank per GPU, or ranks as separate hosts on one GPU")
 
 
 def _setup(rank, world, port):
@@ -41,8 +42,13 @@ def _setup(rank, world, port):
   os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
   import torch
   import torch.distributed as dist
-  torch.cuda.set_device(rank)
-  dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+  device = rank
+  if torch.cuda.device_count() < world:      # fewer GPUs than ranks: the ranks are separate "hosts" sharing cuda:0
+    from mi355q import distributed as D
+    os.environ.update(D.one_gpu_ranks_env(rank))
+    device = 0
+  torch.cuda.set_device(device)
+  dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
   return dist
 
 
@@ -168,7 +174,7 @@ def test_two_ranks_write_a_model_whose_ops_share_a_weight():
   _check_shared_weights(_run(_worker_shared_weights, timeout=600), rccl=False)
 
 
-@needs_two_gpus
+@two_ranks_over_rccl
 def test_two_ranks_write_a_model_whose_ops_share_a_weight_over_rccl(monkeypatch):
   """One rank per GPU: the payload of the rank that is not the writer crosses from ITS device into the file."""
   _over_rccl(monkeypatch)
@@ -254,7 +260,7 @@ def test_two_ranks_quantize_model_files_like_one():
   _check_model_files(_run(_worker, timeout=600))
 
 
-@needs_two_gpus
+@two_ranks_over_rccl
 def test_two_ranks_quantize_model_files_like_one_over_rccl(monkeypatch):
   _over_rccl(monkeypatch)
   _check_model_files(_run(_worker, timeout=600))
@@ -372,6 +378,124 @@ def test_collectives_over_rccl_world_of_one():
   assert ok
 
 
+def _worker_rccl_pair(rank, world, port, out):
+  """Two ranks over RCCL: every collective entry point of include/mi355q.h with a real peer and rank-dependent data
+  (sums, extrema, gathers and root-directed reduces that a world of one cannot tell from a copy)."""
+  import ctypes
+  import numpy as np
+  os.environ[_BACKEND_ENV] = "nccl"
+  dist = _setup(rank, world, port)
+  import torch
+  from mi355q import _ffi, distributed as D, runtime as rt
+  L = _ffi.lib()
+  comm = D.rccl_comm()
+  ok = comm is not None and D._comm_device().type == "cuda"     # pylint: disable=protected-access
+  nr, rk = ctypes.c_int32(-1), ctypes.c_int32(-1)
+  _ffi.check(L.mi355q_comm_info(comm, ctypes.byref(nr), ctypes.byref(rk)))
+  ok &= (nr.value, rk.value) == (world, rank)
+  st = rt.stream_ptr()
+  rngs = [np.random.default_rng(100 + r) for r in range(world)]      # every rank can rebuild every rank's data
+  stats = [g.standard_normal((7, 3, 2)).astype(np.float32) for g in rngs]
+  hs = [g.standard_normal((67, 67)) for g in rngs]
+  hs = [h + h.T for h in hs]
+  prods = [g.standard_normal((67, 67)).astype(np.float32) for g in rngs]
+  weights = [0.25, 0.75] if world == 2 else [1.0 / world] * world
+  # X1: all-gather of the per-sample pairs, and the min / max all-reduce pair (one RCCL group)
+  a = torch.from_numpy(stats[rank].reshape(-1).copy()).cuda()
+  g_out = torch.empty((world * a.numel(),), device="cuda")
+  _ffi.check(L.mi355q_allgather_minmax(comm, rt.ptr(a), a.numel(), rt.ptr(g_out), st))
+  ok &= bool(np.array_equal(g_out.cpu().numpy(), np.concatenate([s.reshape(-1) for s in stats])))
+  mn, mx = a.clone(), a.clone()
+  _ffi.check(L.mi355q_allreduce_minmax_f32(comm, rt.ptr(mn), rt.ptr(mx), a.numel(), st))
+  flat = np.stack([s.reshape(-1) for s in stats])
+  ok &= bool(np.array_equal(mn.cpu().numpy(), flat.min(0)) and np.array_equal(mx.cpu().numpy(), flat.max(0)))
+  # the same through the host layer (what calibrate_sharded calls)
+  ok &= bool(np.array_equal(D.gather_sample_stats(stats[rank]), np.concatenate(stats)))
+  both = D.allreduce_min_max(stats[rank])
+  allst = np.concatenate(stats)
+  ok &= bool(np.array_equal(both[:, 0], allst[..., 0].min(0)) and np.array_equal(both[:, 1], allst[..., 1].max(0)))
+  # sums (two ranks: one addition per element, the same in any order)
+  f32 = a.clone()
+  _ffi.check(L.mi355q_allreduce_sum_f32(comm, rt.ptr(f32), f32.numel(), st))
+  f64 = torch.from_numpy(hs[rank]).cuda()
+  _ffi.check(L.mi355q_allreduce_sum_f64(comm, rt.ptr(f64), f64.numel(), st))
+  if world == 2:
+    ok &= bool(np.array_equal(f32.cpu().numpy(), flat[0] + flat[1]) and np.array_equal(f64.cpu().numpy(), hs[0] + hs[1]))
+  # X2, float64: the weighted all-reduce, then the packed triangle to every rank / to each root in turn
+  hh = torch.from_numpy(hs[rank]).cuda()
+  _ffi.check(L.mi355q_allreduce_hessian_f64(comm, rt.ptr(hh), 67, weights[rank], st))
+  want = sum(w * h for w, h in zip(weights, hs)) if world != 2 else weights[0] * hs[0] + weights[1] * hs[1]
+  ok &= bool(np.array_equal(hh.cpu().numpy(), want))
+  need = L.mi355q_hessian_exchange_workspace_bytes(67)
+  ws = torch.empty((need,), dtype=torch.uint8, device="cuda")
+  for root in [-1] + list(range(world)):
+    h1 = torch.from_numpy(hs[rank]).cuda()
+    _ffi.check(L.mi355q_reduce_hessian_f64(comm, rt.ptr(h1), 67, weights[rank], root, rt.ptr(ws), need, st))
+    got = h1.cpu().numpy()
+    ok &= bool(np.array_equal(got, want if root in (-1, rank) else hs[rank]))      # the other ranks keep what they had
+  ok &= L.mi355q_reduce_hessian_f64(comm, rt.ptr(h1), 67, 0.5, world, rt.ptr(ws), need, st) == -1     # no such rank (no peer is waited for)
+  # X2, the float32 product form: lower triangles summed, one rank may have seen no sample (NULL product)
+  need32 = L.mi355q_product_exchange_workspace_bytes(67)
+  ws32 = torch.empty((need32,), dtype=torch.uint8, device="cuda")
+  tril = np.tril(np.ones((67, 67), bool))
+  for root in [-1] + list(range(world)):
+    pp = torch.from_numpy(prods[rank]).cuda()
+    _ffi.check(L.mi355q_reduce_product_f32(comm, rt.ptr(pp), 67, root, rt.ptr(ws32), need32, st))
+    got = pp.cpu().numpy()
+    if root in (-1, rank):
+      wsum = prods[0] + prods[1] if world == 2 else sum(prods)
+      ok &= bool(np.array_equal(got[tril], wsum[tril]))
+    else:
+      ok &= bool(np.array_equal(got, prods[rank]))
+  if world == 2:       # rank 1 saw no sample: it contributes zeros, rank 0 ends with its own triangle
+    pp = torch.from_numpy(prods[rank]).cuda()
+    _ffi.check(L.mi355q_reduce_product_f32(comm, rt.ptr(pp) if rank == 0 else None, 67, 0, rt.ptr(ws32), need32, st))
+    if rank == 0:
+      ok &= bool(np.array_equal(pp.cpu().numpy()[tril], prods[0][tril]))
+  # the host layer over the same communicator: the weighted Hessian mean and the merge of per-rank Hessians
+  got_h, total = D.allreduce_hessian(rt.HbmArray(torch.from_numpy(hs[rank] * (rank + 2)).cuda()), rank + 2)
+  mean = sum(hs[r] * (r + 2) for r in range(world)) / sum(r + 2 for r in range(world))
+  ok &= total == sum(r + 2 for r in range(world))
+  ok &= bool(np.allclose(got_h.cpu().numpy(), mean, rtol=1e-13, atol=1e-13))
+  # the product reduces on the communication stream, owner-directed, behind queued compute: each reader waits for ITS event
+  from mi355q.algorithms.uniform_quantize import gptq
+  del D.ISSUED[:]
+  big = [torch.from_numpy(np.random.default_rng(300 + r).standard_normal((1024, 1024)).astype(np.float32)) for r in range(world)]
+  mine_big, mine_small = big[rank].cuda(), torch.from_numpy(prods[rank]).cuda()
+  busy = torch.ones((1 << 26,), device="cuda")
+  for _ in range(20):
+    busy = busy * 1.0000001
+  owner_big = world - 1
+  events = D.reduce_products_beside_compute(comm, [("a/big", mine_big, 1024, owner_big), ("b/small", mine_small, 67, -1)])
+  ok &= D.ISSUED == [("a/big", owner_big), ("b/small", -1)]
+  acc = gptq.HessianAccumulator(1024)
+  acc._prod, acc._n_prod, acc.ready = mine_big, 4.0, events["a/big"]      # pylint: disable=protected-access
+  prod, _ = acc.product_form()
+  t1024 = np.tril(np.ones((1024, 1024), bool))
+  if rank == owner_big:
+    wsum = (big[0] + big[1]).numpy() if world == 2 else sum(b.numpy() for b in big)
+    ok &= bool(np.array_equal(prod.cpu().numpy()[t1024], wsum[t1024]))
+  else:
+    ok &= bool(np.array_equal(prod.cpu().numpy(), big[rank].numpy()))
+  events["b/small"].synchronize()
+  wsmall = prods[0] + prods[1] if world == 2 else sum(prods)
+  ok &= bool(np.array_equal(mine_small.cpu().numpy()[tril], wsmall[tril]))
+  torch.cuda.synchronize()
+  dist.barrier()
+  D.destroy_rccl_comms()
+  out.put((rank, bool(ok)))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@two_ranks_over_rccl
+def test_collectives_over_rccl_two_ranks():
+  """Every RCCL entry point of the C ABI and the host layer's "nccl" branches with a real peer (one rank per GPU where two are
+  visible, else two "hosts" on cuda:0: distributed.one_gpu_ranks_env)."""
+  results = dict(_run(_worker_rccl_pair, world=2, timeout=600))
+  assert results == {0: True, 1: True}
+
+
 def _gptq_recipe(bits=4):
   return [dict(regex=".*", operation="FULLY_CONNECTED", algorithm_key="GPTQ", op_config=dict(
       weight_tensor_config=dict(num_bits=bits, symmetric=True, granularity="CHANNELWISE", dtype="INT"),
@@ -453,7 +577,7 @@ def test_two_ranks_reduce_gptq_hessians_in_hbm():
   _check_reduced_hessians(_run(_worker_calibrate_gptq, timeout=600), rccl=False)
 
 
-@needs_two_gpus
+@two_ranks_over_rccl
 def test_two_ranks_reduce_gptq_hessians_in_hbm_over_rccl(monkeypatch):
   """X2 over xGMI: mi355q_reduce_product_f32 (packed float32 triangles, ncclAllReduce / ncclReduce) between two devices
   -- what replaces the reference's sample-ordered merge chain (ref utils/qsv_utils.py:71-102, calibrator.py:395-421)."""
@@ -531,7 +655,7 @@ def test_two_ranks_calibrate_and_quantize_in_one_call_one_inverse_per_hessian():
   _check_c5_fused(sorted(_run(_worker_c5_fused, timeout=600)), "two ranks", rccl=False)
 
 
-@needs_two_gpus
+@two_ranks_over_rccl
 def test_two_ranks_calibrate_and_quantize_in_one_call_over_rccl(monkeypatch):
   """The same call with one rank per GPU: statistics all-gathered, every Hessian reduced over xGMI to the rank that owns
   its readers (ncclReduce on the packed float32 triangle), results gathered to rank 0."""
@@ -634,7 +758,7 @@ def test_two_ranks_calibrate_like_one():
   assert ok0 and ok1
 
 
-@needs_two_gpus
+@two_ranks_over_rccl
 def test_two_ranks_calibrate_like_one_over_rccl(monkeypatch):
   """BASELINE config 4's exchange between two devices: the per-sample (min, max) travel through
   mi355q_allgather_minmax and are replayed in dataset order (ref utils/qsv_utils.py:43-68)."""

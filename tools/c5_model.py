@@ -297,6 +297,7 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
   if timer:
     timer.__enter__()
   stats = {}
+  issued_before = len(Dm.ISSUED)      # (the list is a process-wide log: count this call's product reduces only)
   prof = None
   if os.environ.get("MI355Q_C5_PROFILE") and rank == 0:      # where the host's time goes (slows the run down)
     import cProfile
@@ -354,7 +355,7 @@ def run(layers=18, sequences=128, tokens=512, variant="gptq", batch=1, workdir="
       plan=dict(modelled_s_per_rank=[round(v, 4) for v in loads],
                 makespan_over_mean=round(max(loads) / (sum(loads) / world), 3) if sum(loads) else None,
                 x2=Dm.x2_reduce_plan(plan, owner, costs, world),
-                x2_issued=len(Dm.ISSUED)))
+                x2_issued=len(Dm.ISSUED) - issued_before))
   from mi355q import runtime as rt
   if rt.TIMELINE:      # MI355Q_TIMELINE=1: (label, ms since the call began when the host got there, ms when the GPU had drained if waited for, hipMallocs so far)
     out["timeline"] = [(label, round((a - t0) * 1e3, 1), round((b - t0) * 1e3, 1), n) for label, a, b, n in rt.TIMELINE]
