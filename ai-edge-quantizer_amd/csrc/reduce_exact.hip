@@ -1237,11 +1237,153 @@ __global__ __launch_bounds__(kGroupThreads, 2) void octav_groups_kernel(OctavArg
   if (tid < upg) publish_moving(a.moving, moved);
 }
 
+// ---- short units on LANES (blockwise granularity: 32 / 64 / 128 elements per unit) ----
+//
+// octav_groups_kernel above treats a stretch of 4096 elements like a row: pieces of 16 on threads, run sums listed in
+// LDS through a workgroup prefix sum, chains on a few lanes, two barriers per iteration (~15 vector instructions per
+// element and mask, 0.039 of one read at 4096 x 4096 in blocks of 128). A unit this short needs none of that: LANE l of
+// a wave owns unit 64 b + l, keeps its elements in REGISTERS for all iterations and simply walks them left to right
+// as NumPy's masked reduction does -- nothing is exchanged between lanes, nothing is listed, there is no barrier.
+//   fast walk (fully unrolled over the unit: registers are not indexable), valid while every run is shorter than 8:
+//       seq = 0 + a0 + a1 + ...  is NumPy's n < 8 loop, and acc = acc + seq where the run ends. Branch-free: every step
+//       adds (selected ? +0.0 : seq) to acc -- adding +0.0 is exact, a total that started at +0.0 is never -0.0 -- and
+//       sets seq = selected ? seq + x : +0.0. Six vector instructions per element and mask (compare, two additions, two
+//       selects, the count). Whether some run reached 8 is decided on the SCALAR unit from the compare masks themselves
+//       (m_j & m_j-1 & ... & m_j-7 as three running ANDs), at no cost to the vector pipe;
+//   exact walk for the lanes so flagged (the second iterate of a weight tensor, guess 0, is where runs of 8+ same-signed
+//       elements occur: half of every mask selected): a rolled loop over the unit in memory (read a moment ago), the
+//       same steps plus NumPy's eight-accumulator leaf where a run of 8 .. 128 ends (a unit is at most one leaf long).
+// A lane that reached its fixed point is masked off; the wave leaves when all have. Bit-identical to octav_kernel.
+__device__ __forceinline__ float unit_long_run(const float* a, int n) {   // NumPy's leaf, 8 <= n <= 128
+  float r[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = a[k];
+  const int full = n & ~7;
+  for (int i = 8; i < full; i += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = r[k] + a[i + k];
+  }
+  float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (int i = full; i < n; ++i) res = res + a[i];
+  return res;
+}
+
+struct LaneMask {
+  float acc, seq;
+  int cnt;
+};
+
+// one element, one mask, runs shorter than 8 only; returns the wave's compare mask
+template <bool NEG>
+__device__ __forceinline__ unsigned long long lane_step(LaneMask& m, float v, float thr) {
+  const bool sel = NEG ? v <= thr : v >= thr;
+  m.acc = m.acc + (sel ? 0.f : m.seq);
+  m.seq = sel ? m.seq + v : 0.f;
+  m.cnt += sel ? 1 : 0;
+  return __ballot(sel);
+}
+
+// the same with the run length kept, any run (the exact walk; `here` = the element's address)
+template <bool NEG>
+__device__ __forceinline__ void lane_step_exact(LaneMask& m, int& len, float v, float thr, const float* here) {
+  const bool sel = NEG ? v <= thr : v >= thr;
+  float add = sel ? 0.f : m.seq;
+  if (!sel && len >= 8) add = unit_long_run(here - len, len);
+  m.acc = m.acc + add;
+  m.seq = sel ? m.seq + v : 0.f;
+  len = sel ? len + 1 : 0;
+  m.cnt += sel ? 1 : 0;
+}
+
+template <int LEN>
+__global__ __launch_bounds__(kWave) void octav_unit_lanes_kernel(OctavArgs a) {
+  const int lane = threadIdx.x;
+  const long long unit = static_cast<long long>(blockIdx.x) * kWave + lane;
+  const bool live = unit < a.units;
+  const float* u = a.x + (live ? unit : 0) * LEN;
+  float x[LEN];
+  {
+    const float4* u4 = reinterpret_cast<const float4*>(u);
+#pragma unroll
+    for (int q = 0; q < LEN / 4; ++q) {
+      const float4 v = u4[q];
+      x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+  }
+  float amax = 0.f;     // NaN is never selected and never the maximum
+#pragma unroll
+  for (int j = 0; j < LEN; ++j) amax = fmaxf(amax, fabsf(x[j]));
+  float guess = 1.0f;
+  bool done = !live;
+  unsigned long long moved = 0;     // wave-uniform: iterations in which some unit of this wave still moved
+  for (int it = 0; it < a.max_iter; ++it) {
+    bool still_moving = false;
+    if (!done) {
+      LaneMask p{0.f, 0.f, 0}, n{0.f, 0.f, 0};
+      const float hi = guess, lo = -guess;
+      if (guess <= amax) {      // (a guess above the unit's largest |x| selects nothing: the reference's first guess 1.0)
+        // running ANDs of the compare masks: a1 = m_j & m_j-1, a2 = a1_j & a1_j-2, a4 = a2_j & a2_j-4 = eight in a row
+        unsigned long long mp[2] = {0, 0}, mn[2] = {0, 0};           // m_j-1 (index j & 1)
+        unsigned long long p1[2] = {0, 0}, n1[2] = {0, 0};           // a1_j-1, a1_j-2
+        unsigned long long p2[4] = {0, 0, 0, 0}, n2[4] = {0, 0, 0, 0};
+        unsigned long long long_p = 0, long_n = 0;
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) {
+          const unsigned long long cp = lane_step<false>(p, x[j], hi);
+          const unsigned long long cn = lane_step<true>(n, x[j], lo);
+          const unsigned long long ap1 = cp & mp[(j + 1) & 1], an1 = cn & mn[(j + 1) & 1];
+          const unsigned long long ap2 = ap1 & p1[j & 1], an2 = an1 & n1[j & 1];
+          long_p |= ap2 & p2[j & 3];
+          long_n |= an2 & n2[j & 3];
+          mp[j & 1] = cp; mn[j & 1] = cn;
+          p1[j & 1] = ap1; n1[j & 1] = an1;
+          p2[j & 3] = ap2; n2[j & 3] = an2;
+        }
+        // a run that touches the unit's end ends there
+        p.acc = p.acc + p.seq;
+        n.acc = n.acc + n.seq;
+        if (((long_p | long_n) >> lane) & 1ull) {
+          // a run of 8+ somewhere in this unit: walk it again, exactly (both masks: one pass over the unit)
+          p = LaneMask{0.f, 0.f, 0};
+          n = LaneMask{0.f, 0.f, 0};
+          int lp = 0, ln = 0;
+          for (int j = 0; j < LEN; j += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(u + j);
+            lane_step_exact<false>(p, lp, v.x, hi, u + j);     lane_step_exact<true>(n, ln, v.x, lo, u + j);
+            lane_step_exact<false>(p, lp, v.y, hi, u + j + 1); lane_step_exact<true>(n, ln, v.y, lo, u + j + 1);
+            lane_step_exact<false>(p, lp, v.z, hi, u + j + 2); lane_step_exact<true>(n, ln, v.z, lo, u + j + 2);
+            lane_step_exact<false>(p, lp, v.w, hi, u + j + 3); lane_step_exact<true>(n, ln, v.w, lo, u + j + 3);
+          }
+          p.acc = p.acc + (lp >= 8 ? unit_long_run(u + LEN - lp, lp) : p.seq);
+          n.acc = n.acc + (ln >= 8 ? unit_long_run(u + LEN - ln, ln) : n.seq);
+        }
+      }
+      const OctavStep st = octav_step(guess, p.acc, n.acc, p.cnt, n.cnt, LEN, a.s, a.count_is_f64);
+      a.hist[static_cast<long long>(it) * a.units + unit] = st.next;
+      still_moving = !st.close;
+      if (reached_fixed_point(guess, st.next)) {
+        repeat_iterate(a, it, unit, st.next);
+        done = true;
+      }
+      guess = st.next;
+    }
+    if (__ballot(still_moving) != 0) moved |= 1ull << it;      // (outside the divergent part: every lane keeps the wave's mask)
+    if (__ballot(!done) == 0) break;
+  }
+  if (lane == 0) publish_moving(a.moving, moved);
+}
+
 size_t octav_groups_smem() {
   const size_t row_floats = static_cast<size_t>((kGroupLen + (kGroupLen >> 4) + 4) & ~3);
   const size_t cap = static_cast<size_t>(((kGroupLen / 2 + 2 + 63) & ~63) + 64);
   return 512 + kGroupThreads * sizeof(float) + row_floats * sizeof(float) + cap * 2 * sizeof(float) +
          2 * kGroupThreads * sizeof(unsigned short) + 4 * kGroupThreads * sizeof(int) + kGroupThreads * sizeof(float) + 16;
+}
+
+// MI355Q_OCTAV_UNIT_LANES=0: blockwise units take octav_groups_kernel again (A / B, tests compare the two)
+bool octav_unit_lanes_on() {
+  const char* e = getenv("MI355Q_OCTAV_UNIT_LANES");
+  return e == nullptr || atoi(e) != 0;
 }
 
 // candidates per mask a row may hand to its tail (an eighth of the row, a multiple of 64)
@@ -1898,6 +2040,20 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
       hipLaunchKernelGGL(octav_tail_kernel, dim3(static_cast<unsigned>(units)), dim3(kWave), static_cast<size_t>(a.tail_cap) * 12, st, a);
       MI355Q_CHECK_LAUNCH("octav tail launch");
     }
+    hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
+                       hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
+    MI355Q_CHECK_LAUNCH("octav pick launch");
+    return MI355Q_OK;
+  }
+  if ((unit_len == 32 || unit_len == 64 || unit_len == 128) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (units + kWave - 1) / kWave <= 0x7FFFFFFFLL && octav_unit_lanes_on()) {
+    // blockwise units: a lane per unit, the unit in registers (octav_unit_lanes_kernel)
+    OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close};
+    const dim3 grid(static_cast<unsigned>((units + kWave - 1) / kWave));
+    if (unit_len == 32) hipLaunchKernelGGL(octav_unit_lanes_kernel<32>, grid, dim3(kWave), 0, st, a);
+    else if (unit_len == 64) hipLaunchKernelGGL(octav_unit_lanes_kernel<64>, grid, dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL(octav_unit_lanes_kernel<128>, grid, dim3(kWave), 0, st, a);
+    MI355Q_CHECK_LAUNCH("octav unit lanes launch");
     hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
                        hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
     MI355Q_CHECK_LAUNCH("octav pick launch");

@@ -62,3 +62,19 @@ def test_plain_python_gpus_2_prints_n_gpus_2_on_one_gpu():
   line = json.loads(r.stdout.strip().splitlines()[-1])
   assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "weak"
   assert line["collectives"]["transport"] == "gloo"
+
+
+@pytest.mark.gpu
+def test_plain_python_gpus_2_over_rccl():
+  """`python bench.py --gpus 2` over RCCL: one rank per GPU where two are visible, else (MI355Q_BENCH_ONE_GPU_HOSTS=1) the two
+  ranks as separate hosts on cuda:0 over RCCL's socket transport. The line must come from an RCCL communicator of two ranks
+  whose all-gather check passed -- anything else is exit status 3 with an `error` key."""
+  import torch
+  extra = {} if torch.cuda.device_count() >= 2 else {"MI355Q_BENCH_ONE_GPU_HOSTS": "1"}
+  r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0", "--extras", "0"],
+                     env=_env(**extra), capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stderr[-3000:]
+  line = json.loads(r.stdout.strip().splitlines()[-1])
+  assert line["n_gpus"] == 2 and "error" not in line
+  assert line["collectives"]["transport"] == "rccl via libmi355q"
+  assert line["collectives"]["rccl_ranks"] == 2 and line["collectives"]["allgather_correct"] is True
