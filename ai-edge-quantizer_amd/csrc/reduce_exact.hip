@@ -1247,12 +1247,11 @@ __global__ __launch_bounds__(kGroupThreads, 2) void octav_groups_kernel(OctavArg
 //   fast walk (fully unrolled over the unit: registers are not indexable), valid while every run is shorter than 8:
 //       seq = 0 + a0 + a1 + ...  is NumPy's n < 8 loop, and acc = acc + seq where the run ends. Branch-free: every step
 //       adds (selected ? +0.0 : seq) to acc -- adding +0.0 is exact, a total that started at +0.0 is never -0.0 -- and
-//       sets seq = selected ? seq + x : +0.0. Six vector instructions per element and mask (compare, two additions, two
-//       selects, the count). Whether some run reached 8 is decided on the SCALAR unit from the compare masks themselves
-//       (m_j & m_j-1 & ... & m_j-7 as three running ANDs), at no cost to the vector pipe;
-//   exact walk for the lanes so flagged (the second iterate of a weight tensor, guess 0, is where runs of 8+ same-signed
-//       elements occur: half of every mask selected): a rolled loop over the unit in memory (read a moment ago), the
-//       same steps plus NumPy's eight-accumulator leaf where a run of 8 .. 128 ends (a unit is at most one leaf long).
+//       sets seq = selected ? seq + x : +0.0, both masks side by side, selections as sign bits (lane_step_pair);
+//   exact walk for the lanes whose fast walk saw a run reach 8, and for guess 0 / special values (the second iterate of
+//       a weight tensor, guess 0, is where runs of 8+ same-signed elements occur: half of every mask selected): a
+//       rolled loop over the unit in memory (read a moment ago), compares, the same steps plus NumPy's eight-accumulator
+//       leaf where a run of 8 .. 128 ends (a unit is at most one leaf long).
 // A lane that reached its fixed point is masked off; the wave leaves when all have. Bit-identical to octav_kernel.
 __device__ __forceinline__ float unit_long_run(const float* a, int n) {   // NumPy's leaf, 8 <= n <= 128
   float r[8];
@@ -1273,17 +1272,8 @@ struct LaneMask {
   int cnt;
 };
 
-// one element, one mask, runs shorter than 8 only; returns the wave's compare mask
-template <bool NEG>
-__device__ __forceinline__ unsigned long long lane_step(LaneMask& m, float v, float thr) {
-  const bool sel = NEG ? v <= thr : v >= thr;
-  m.acc = m.acc + (sel ? 0.f : m.seq);
-  m.seq = sel ? m.seq + v : 0.f;
-  m.cnt += sel ? 1 : 0;
-  return __ballot(sel);
-}
-
-// the same with the run length kept, any run (the exact walk; `here` = the element's address)
+// One element, one mask, any run: compares, the run length kept, NumPy's leaf where a run of 8+ ends (the exact walk;
+// `here` = the element's address).
 template <bool NEG>
 __device__ __forceinline__ void lane_step_exact(LaneMask& m, int& len, float v, float thr, const float* here) {
   const bool sel = NEG ? v <= thr : v >= thr;
@@ -1295,24 +1285,232 @@ __device__ __forceinline__ void lane_step_exact(LaneMask& m, int& len, float v, 
   m.cnt += sel ? 1 : 0;
 }
 
+// The fast walk's state: both masks, no compare and no scalar register anywhere (a v_cmp result crosses to the scalar
+// file and back before a v_cndmask can use it: with the running totals depending on every select, that round trip was
+// most of a step's time). For a guess g > 0 and a finite x:   x >= g  <=>  x - g is not negative,   x <= -g  <=>
+// (-x) - g is not negative, and neither difference can be -0.0 (x - x = +0.0), so "not selected" is the difference's
+// sign bit smeared over the word (one subtraction, one shift) and the selects are bit operations.
+// The run lengths of both masks share a register (16 bits each) and so do the counts of unselected elements.
+struct LanePair {
+  float acc_p, seq_p, acc_n, seq_n;
+  unsigned len2, unsel2, long2;     // [15:0] positive mask, [31:16] negative mask; long2 = OR of every len2 seen
+};
+
+// (as an instruction the compiler cannot look into: it rewrites (d >> 31) & y as d < 0 ? y : 0 -- the compare and select
+// through the scalar file this walk exists to avoid)
+__device__ __forceinline__ unsigned sign_smear(float d) {
+  unsigned m;
+  asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m) : "v"(d));
+  return m;
+}
+
+// (the additions as single instructions too: seen as C++, the two masks' additions are paired into v_pk_add_f32, whose
+// second operand must be a register PAIR holding x twice -- a copy of the whole unit, spilled)
+__device__ __forceinline__ float add_f32(float a_, float b_) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a_), "v"(b_));
+  return r;
+}
+
+__device__ __forceinline__ void lane_step_pair(LanePair& s, float v, float g) {
+  const unsigned np_ = sign_smear(v - g);       // all ones: NOT selected
+  const unsigned nn_ = sign_smear((-v) - g);
+  s.acc_p = add_f32(s.acc_p, __uint_as_float(__float_as_uint(s.seq_p) & np_));   // + (selected ? +0.0 : seq)
+  s.acc_n = add_f32(s.acc_n, __uint_as_float(__float_as_uint(s.seq_n) & nn_));
+  s.seq_p = __uint_as_float(__float_as_uint(add_f32(s.seq_p, v)) & ~np_);        // selected ? seq + x : +0.0
+  s.seq_n = __uint_as_float(__float_as_uint(add_f32(s.seq_n, v)) & ~nn_);
+  const unsigned both = (np_ & 0xFFFFu) | (nn_ & 0xFFFF0000u);
+  s.len2 = (s.len2 + 0x00010001u) & ~both;
+  asm("v_or_b32 %0, %1, %2" : "=v"(s.long2) : "v"(s.long2), "v"(s.len2));   // (s.long2 |= s.len2 as C++ is turned into a
+  s.unsel2 += both & 0x00010001u;                                           //  tree over all the unit's run lengths, kept live and spilled)
+}
+
+// (the second bound is waves per SIMD: 2 / 3 / 4 = 256 / 168 / 128 registers)
+//
+// The unit lives in 32-float register TUPLES read with a wave-uniform index (s_set_gpr_idx_on): the walks are loops of
+// four steps, not LEN unrolled steps. Unrolled, the fast walk was 18 KB of straight-line code that every wave of the
+// chip entered at the same moment: its first execution cost 20-25 us of instruction-cache misses, more than the walk.
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// (eight named 16-register tuples, not an array of them and not four of 32: the array went through scratch on its way
+// into registers, and 32-register tuples were spilled whole when a second one had to be placed)
+struct UnitRegs {
+  v16f t0, t1, t2, t3, t4, t5, t6, t7;
+};
+
+// (tuples are handed around BY VALUE: a reference to a member plus a run-time element index is an address computation, and the
+// struct then lives in scratch)
+template <int T>
+__device__ __forceinline__ v16f unit_tuple(const UnitRegs& r) {
+  if constexpr (T == 0) return r.t0;
+  else if constexpr (T == 1) return r.t1;
+  else if constexpr (T == 2) return r.t2;
+  else if constexpr (T == 3) return r.t3;
+  else if constexpr (T == 4) return r.t4;
+  else if constexpr (T == 5) return r.t5;
+  else if constexpr (T == 6) return r.t6;
+  else return r.t7;
+}
+
+template <int T>
+__device__ __forceinline__ void set_unit_tuple(UnitRegs& r, v16f t) {
+  if constexpr (T == 0) r.t0 = t;
+  else if constexpr (T == 1) r.t1 = t;
+  else if constexpr (T == 2) r.t2 = t;
+  else if constexpr (T == 3) r.t3 = t;
+  else if constexpr (T == 4) r.t4 = t;
+  else if constexpr (T == 5) r.t5 = t;
+  else if constexpr (T == 6) r.t6 = t;
+  else r.t7 = t;
+}
+
+__device__ __forceinline__ float tuple_element(v16f t, int jj) { return t[jj]; }
+
+template <int J0, int N, typename F>
+__device__ __forceinline__ void each_slot(const UnitRegs& r, F&& f) {   // f(value) for positions J0 .. J0 + N - 1
+  if constexpr (N > 0) {
+    f(tuple_element(unit_tuple<J0 / 16>(r), J0 % 16));
+    each_slot<J0 + 1, N - 1>(r, f);
+  }
+}
+
+__device__ __forceinline__ void walk16(LanePair& s, v16f t, float guess) {
+#pragma unroll 1
+  for (int j = 0; j < 16; j += 4) {
+    lane_step_pair(s, t[j], guess);
+    lane_step_pair(s, t[j + 1], guess);
+    lane_step_pair(s, t[j + 2], guess);
+    lane_step_pair(s, t[j + 3], guess);
+  }
+}
+
+template <int TUPLES, int T = 0>
+__device__ __forceinline__ void walk_unit(LanePair& s, const UnitRegs& r, float guess) {
+  if constexpr (T < TUPLES) {
+    walk16(s, unit_tuple<T>(r), guess);
+    walk_unit<TUPLES, T + 1>(s, r, guess);
+  }
+}
+
+// The same step for ANY run length and for guess 0 as well (finite data, finite guess >= 0): the differences get + 0.0 --
+// nothing for a guess above zero, and at guess +0.0 it turns the one wrong sign, (-0.0) - (+0.0) = -0.0, into +0.0 (x >= +0.0
+// holds for -0.0) -- and where a run of 8 or more ends, NumPy's leaf over that run (from memory, only the lanes concerned)
+// takes the place of the left-to-right sum. Costs a compare and a branch per step more than lane_step_pair: this walk runs
+// where the fast one reported a long run, and at guess 0, where nearly every unit has one.
+__device__ __forceinline__ void lane_step_pair_long(LanePair& s, float v, float g, const float* at) {
+  const unsigned np_ = sign_smear((v - g) + 0.f);
+  const unsigned nn_ = sign_smear(((-v) - g) + 0.f);
+  const unsigned both = (np_ & 0xFFFFu) | (nn_ & 0xFFFF0000u);
+  float add_p = __uint_as_float(__float_as_uint(s.seq_p) & np_);
+  float add_n = __uint_as_float(__float_as_uint(s.seq_n) & nn_);
+  const unsigned ends_long = s.len2 & 0xFFF8FFF8u & both;       // a half that holds a length >= 8 and is not selected here
+  if (ends_long != 0) {
+    const int lp = static_cast<int>(s.len2 & 0xFFFFu), ln = static_cast<int>(s.len2 >> 16);
+    if (ends_long & 0xFFFFu) add_p = unit_long_run(at - lp, lp);
+    if (ends_long >> 16) add_n = unit_long_run(at - ln, ln);
+  }
+  s.acc_p = add_f32(s.acc_p, add_p);
+  s.acc_n = add_f32(s.acc_n, add_n);
+  s.seq_p = __uint_as_float(__float_as_uint(add_f32(s.seq_p, v)) & ~np_);
+  s.seq_n = __uint_as_float(__float_as_uint(add_f32(s.seq_n, v)) & ~nn_);
+  s.len2 = (s.len2 + 0x00010001u) & ~both;
+  s.unsel2 += both & 0x00010001u;
+}
+
+__device__ __forceinline__ void walk16_long(LanePair& s, v16f t, float guess, const float* at) {
+#pragma unroll 1
+  for (int j = 0; j < 16; ++j) lane_step_pair_long(s, t[j], guess, at + j);
+}
+
+template <int TUPLES, int T = 0>
+__device__ __forceinline__ void walk_unit_long(LanePair& s, const UnitRegs& r, float guess, const float* u) {
+  if constexpr (T < TUPLES) {
+    walk16_long(s, unit_tuple<T>(r), guess, u + 16 * T);
+    walk_unit_long<TUPLES, T + 1>(s, r, guess, u);
+  }
+}
+
+// the exact walk, tuple by tuple like the fast one (ONE loop over the unit with the tuple chosen by the position made
+// the compiler keep a second copy of the unit in scratch and read it from there, a dependent load per step)
+struct ExactWalk {
+  LaneMask p, n;
+  int lp, ln;
+};
+
+__device__ __forceinline__ void exact16(ExactWalk& w, v16f t, float hi, float lo, const float* at) {
+#pragma unroll 1
+  for (int j = 0; j < 16; ++j) {
+    const float v = t[j];
+    lane_step_exact<false>(w.p, w.lp, v, hi, at + j);
+    lane_step_exact<true>(w.n, w.ln, v, lo, at + j);
+  }
+}
+
+template <int TUPLES, int T = 0>
+__device__ __forceinline__ void exact_unit(ExactWalk& w, const UnitRegs& r, float hi, float lo, const float* u) {
+  if constexpr (T < TUPLES) {
+    exact16(w, unit_tuple<T>(r), hi, lo, u + 16 * T);
+    exact_unit<TUPLES, T + 1>(w, r, hi, lo, u);
+  }
+}
+
+// tuples T0 .. T0 + N - 1 from this lane's LDS row (16 floats each)
+template <int T0, int N>
+__device__ __forceinline__ void tuples_from_lds(UnitRegs& r, const float* row) {
+  if constexpr (N > 0) {
+    v16f t;
+#pragma unroll
+    for (int p_ = 0; p_ < 16; ++p_) t[p_] = row[p_];
+    set_unit_tuple<T0>(r, t);
+    tuples_from_lds<T0 + 1, N - 1>(r, row + 16);
+  }
+}
+
 template <int LEN>
-__global__ __launch_bounds__(kWave) void octav_unit_lanes_kernel(OctavArgs a) {
+__global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void octav_unit_lanes_kernel(OctavArgs a) {
+  constexpr int kStage = LEN < 64 ? LEN : 64;       // positions per trip through LDS
+  constexpr int kStride = kStage + 1;               // floats per unit in LDS: lane l reads bank (l + p) % 32
+  constexpr int kTuples = LEN / 16;
+  __shared__ float lds[kWave * kStride];
   const int lane = threadIdx.x;
-  const long long unit = static_cast<long long>(blockIdx.x) * kWave + lane;
+  const long long unit0 = static_cast<long long>(blockIdx.x) * kWave;
+  const long long unit = unit0 + lane;
   const bool live = unit < a.units;
   const float* u = a.x + (live ? unit : 0) * LEN;
-  float x[LEN];
+  UnitRegs xr;
+  // ---- the wave's 64 units: whole lines from HBM (16 lanes per 256-byte stretch of a unit), turned through LDS so
+  // that lane l ends up with unit l (a lane reading its own 16-byte pieces cost 25 us at 4096 x 4096: 64 lines per load)
   {
-    const float4* u4 = reinterpret_cast<const float4*>(u);
+    const float* base = a.x + unit0 * LEN;
+    const long long wave_floats = (a.units - unit0 < kWave ? a.units - unit0 : kWave) * LEN;
 #pragma unroll
-    for (int q = 0; q < LEN / 4; ++q) {
-      const float4 v = u4[q];
-      x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    for (int h = 0; h < LEN / kStage; ++h) {
+      constexpr int kPer = kStage / 4;              // float4 per unit and stage
+#pragma unroll
+      for (int q = 0; q < kStage / 4; ++q) {        // 64 units x kPer float4 = kPer instructions of 64 lanes
+        const int f = q * kWave + lane;
+        const int uu = f / kPer, p4 = f % kPer;
+        const long long e = static_cast<long long>(uu) * LEN + h * kStage + p4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < wave_floats) v = *reinterpret_cast<const float4*>(base + e);
+        float* d = lds + uu * kStride + p4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+      __syncthreads();
+      if (h == 0) tuples_from_lds<0, kStage / 16>(xr, lds + lane * kStride);
+      if constexpr (LEN > kStage) {
+        if (h == 1) tuples_from_lds<kStage / 16, kStage / 16>(xr, lds + lane * kStride);
+      }
+      __syncthreads();
     }
   }
   float amax = 0.f;     // NaN is never selected and never the maximum
-#pragma unroll
-  for (int j = 0; j < LEN; ++j) amax = fmaxf(amax, fabsf(x[j]));
+  float poison = 0.f;   // x * 0 summed: NaN as soon as the unit holds a NaN or an infinity (those units: the exact walk only)
+  each_slot<0, LEN>(xr, [&](float v) {
+    amax = fmaxf(amax, fabsf(v));
+    poison = __builtin_fmaf(v, 0.f, poison);
+  });
+  const bool special = poison != poison;
   float guess = 1.0f;
   bool done = !live;
   unsigned long long moved = 0;     // wave-uniform: iterations in which some unit of this wave still moved
@@ -1320,42 +1518,39 @@ __global__ __launch_bounds__(kWave) void octav_unit_lanes_kernel(OctavArgs a) {
     bool still_moving = false;
     if (!done) {
       LaneMask p{0.f, 0.f, 0}, n{0.f, 0.f, 0};
-      const float hi = guess, lo = -guess;
       if (guess <= amax) {      // (a guess above the unit's largest |x| selects nothing: the reference's first guess 1.0)
-        // running ANDs of the compare masks: a1 = m_j & m_j-1, a2 = a1_j & a1_j-2, a4 = a2_j & a2_j-4 = eight in a row
-        unsigned long long mp[2] = {0, 0}, mn[2] = {0, 0};           // m_j-1 (index j & 1)
-        unsigned long long p1[2] = {0, 0}, n1[2] = {0, 0};           // a1_j-1, a1_j-2
-        unsigned long long p2[4] = {0, 0, 0, 0}, n2[4] = {0, 0, 0, 0};
-        unsigned long long long_p = 0, long_n = 0;
-#pragma unroll
-        for (int j = 0; j < LEN; ++j) {
-          const unsigned long long cp = lane_step<false>(p, x[j], hi);
-          const unsigned long long cn = lane_step<true>(n, x[j], lo);
-          const unsigned long long ap1 = cp & mp[(j + 1) & 1], an1 = cn & mn[(j + 1) & 1];
-          const unsigned long long ap2 = ap1 & p1[j & 1], an2 = an1 & n1[j & 1];
-          long_p |= ap2 & p2[j & 3];
-          long_n |= an2 & n2[j & 3];
-          mp[j & 1] = cp; mn[j & 1] = cn;
-          p1[j & 1] = ap1; n1[j & 1] = an1;
-          p2[j & 3] = ap2; n2[j & 3] = an2;
+        // three walks. Units with special values and guesses that are not finite: compares (exact_unit). Guess 0 (a weight
+        // tensor's second iterate: x >= 0 / x <= -0, a run of 8+ in nearly every unit) and the units whose fast walk met a
+        // run of 8+: the sign-bit walk with the leaf where such a run ends (walk_unit_long). Everything else: the fast walk.
+        const bool by_compares = special || !(guess >= 0.f) || !(guess < __builtin_inff());
+        bool long_runs = !by_compares && !(guess > 0.f);
+        if (__ballot(!by_compares && !long_runs) != 0) {
+          LanePair s{0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
+          walk_unit<kTuples>(s, xr, guess);
+          // a run that touches the unit's end ends there
+          p.acc = s.acc_p + s.seq_p;
+          n.acc = s.acc_n + s.seq_n;
+          p.cnt = LEN - static_cast<int>(s.unsel2 & 0xFFFFu);
+          n.cnt = LEN - static_cast<int>(s.unsel2 >> 16);
+          long_runs |= !by_compares && (s.long2 & 0x00F800F8u) != 0;      // some run reached 8
         }
-        // a run that touches the unit's end ends there
-        p.acc = p.acc + p.seq;
-        n.acc = n.acc + n.seq;
-        if (((long_p | long_n) >> lane) & 1ull) {
-          // a run of 8+ somewhere in this unit: walk it again, exactly (both masks: one pass over the unit)
-          p = LaneMask{0.f, 0.f, 0};
-          n = LaneMask{0.f, 0.f, 0};
-          int lp = 0, ln = 0;
-          for (int j = 0; j < LEN; j += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(u + j);
-            lane_step_exact<false>(p, lp, v.x, hi, u + j);     lane_step_exact<true>(n, ln, v.x, lo, u + j);
-            lane_step_exact<false>(p, lp, v.y, hi, u + j + 1); lane_step_exact<true>(n, ln, v.y, lo, u + j + 1);
-            lane_step_exact<false>(p, lp, v.z, hi, u + j + 2); lane_step_exact<true>(n, ln, v.z, lo, u + j + 2);
-            lane_step_exact<false>(p, lp, v.w, hi, u + j + 3); lane_step_exact<true>(n, ln, v.w, lo, u + j + 3);
-          }
-          p.acc = p.acc + (lp >= 8 ? unit_long_run(u + LEN - lp, lp) : p.seq);
-          n.acc = n.acc + (ln >= 8 ? unit_long_run(u + LEN - ln, ln) : n.seq);
+        if (long_runs) {
+          LanePair s{0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
+          walk_unit_long<kTuples>(s, xr, guess, u);
+          const int lp = static_cast<int>(s.len2 & 0xFFFFu), ln = static_cast<int>(s.len2 >> 16);
+          p.acc = s.acc_p + (lp >= 8 ? unit_long_run(u + LEN - lp, lp) : s.seq_p);
+          n.acc = s.acc_n + (ln >= 8 ? unit_long_run(u + LEN - ln, ln) : s.seq_n);
+          p.cnt = LEN - static_cast<int>(s.unsel2 & 0xFFFFu);
+          n.cnt = LEN - static_cast<int>(s.unsel2 >> 16);
+        }
+        if (by_compares) {
+          const float hi = guess, lo = -guess;
+          ExactWalk w{LaneMask{0.f, 0.f, 0}, LaneMask{0.f, 0.f, 0}, 0, 0};
+          exact_unit<kTuples>(w, xr, hi, lo, u);
+          p = w.p;
+          n = w.n;
+          p.acc = p.acc + (w.lp >= 8 ? unit_long_run(u + LEN - w.lp, w.lp) : p.seq);
+          n.acc = n.acc + (w.ln >= 8 ? unit_long_run(u + LEN - w.ln, w.ln) : n.seq);
         }
       }
       const OctavStep st = octav_step(guess, p.acc, n.acc, p.cnt, n.cnt, LEN, a.s, a.count_is_f64);
