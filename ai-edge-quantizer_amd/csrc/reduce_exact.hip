@@ -1430,6 +1430,80 @@ __device__ __forceinline__ void walk_unit_long(LanePair& s, const UnitRegs& r, f
   }
 }
 
+// ---- late iterations on a few candidates. Once an iterate grows, what it selects is a subset of what the previous one
+// selected; the last iterations of a unit select a handful of elements and would still walk all of it. So when every live
+// unit of the wave selected at most kCand elements and its iterate grew, the next fast walk also LISTS what it selects
+// (value and position per lane, in LDS: slot k of lane l at k * 64 + l), and the iterations after that walk the lists:
+// the same step with one addition -- a gap between two candidates' positions ends the runs in front of it, exactly what
+// walking over the unselected elements in between does (acc + seq, then seq = +0.0). An iterate below the one the list was
+// made for (never seen on weights; the iteration does not forbid it) sends the wave back to full walks.
+constexpr int kCand = 16;          // (+ one slot that takes the unconditional store of a step that lists nothing)
+constexpr int kCandNoPos = -4;     // position of an empty slot: never adjacent to anything
+
+struct CandList {
+  float* v;      // [kCand + 1][64]
+  int* pos;      // [kCand + 1][64]
+};
+
+__device__ __forceinline__ void lane_step_pair_collect(LanePair& s, float v, float g, const CandList& c, int lane,
+                                                       int position, int& count) {
+  const unsigned np_ = sign_smear(v - g);
+  const unsigned nn_ = sign_smear((-v) - g);
+  c.v[count * kWave + lane] = v;                       // (overwritten by the next step unless this one is selected)
+  c.pos[count * kWave + lane] = position;
+  count += static_cast<int>(~(np_ & nn_) & 1u);        // selected by either mask
+  s.acc_p = add_f32(s.acc_p, __uint_as_float(__float_as_uint(s.seq_p) & np_));
+  s.acc_n = add_f32(s.acc_n, __uint_as_float(__float_as_uint(s.seq_n) & nn_));
+  s.seq_p = __uint_as_float(__float_as_uint(add_f32(s.seq_p, v)) & ~np_);
+  s.seq_n = __uint_as_float(__float_as_uint(add_f32(s.seq_n, v)) & ~nn_);
+  const unsigned both = (np_ & 0xFFFFu) | (nn_ & 0xFFFF0000u);
+  s.len2 = (s.len2 + 0x00010001u) & ~both;
+  asm("v_or_b32 %0, %1, %2" : "=v"(s.long2) : "v"(s.long2), "v"(s.len2));
+  s.unsel2 += both & 0x00010001u;
+}
+
+__device__ __forceinline__ void walk16_collect(LanePair& s, v16f t, float guess, const CandList& c, int lane, int base,
+                                               int& count) {
+#pragma unroll 1
+  for (int j = 0; j < 16; j += 2) {
+    lane_step_pair_collect(s, t[j], guess, c, lane, base + j, count);
+    lane_step_pair_collect(s, t[j + 1], guess, c, lane, base + j + 1, count);
+  }
+}
+
+template <int TUPLES, int T = 0>
+__device__ __forceinline__ void walk_unit_collect(LanePair& s, const UnitRegs& r, float guess, const CandList& c, int lane,
+                                                  int& count) {
+  if constexpr (T < TUPLES) {
+    walk16_collect(s, unit_tuple<T>(r), guess, c, lane, 16 * T, count);
+    walk_unit_collect<TUPLES, T + 1>(s, r, guess, c, lane, count);
+  }
+}
+
+// One pass over the first `slots` candidates (wave-uniform; a lane with fewer has empty slots: value 0, never selected
+// by a guess above 0, position never adjacent). s.unsel2 counts the candidates NOT selected.
+__device__ __forceinline__ void walk_candidates(LanePair& s, const CandList& c, int lane, int slots, float g) {
+  int prev = kCandNoPos;
+#pragma unroll 1
+  for (int k = 0; k < slots; ++k) {
+    const float v = c.v[k * kWave + lane];
+    const int position = c.pos[k * kWave + lane];
+    const unsigned gap = static_cast<unsigned>((prev + 1 - position) >> 31);     // positions ascend: all ones unless adjacent
+    prev = position;
+    const unsigned np_ = sign_smear(v - g);
+    const unsigned nn_ = sign_smear((-v) - g);
+    const unsigned ep = gap | np_, en = gap | nn_;      // the run in front of this element ends (or there is none)
+    s.acc_p = add_f32(s.acc_p, __uint_as_float(__float_as_uint(s.seq_p) & ep));
+    s.acc_n = add_f32(s.acc_n, __uint_as_float(__float_as_uint(s.seq_n) & en));
+    s.seq_p = __uint_as_float(__float_as_uint(add_f32(__uint_as_float(__float_as_uint(s.seq_p) & ~ep), v)) & ~np_);
+    s.seq_n = __uint_as_float(__float_as_uint(add_f32(__uint_as_float(__float_as_uint(s.seq_n) & ~en), v)) & ~nn_);
+    const unsigned both = (np_ & 0xFFFFu) | (nn_ & 0xFFFF0000u);
+    s.len2 = ((s.len2 & ~gap) + 0x00010001u) & ~both;
+    asm("v_or_b32 %0, %1, %2" : "=v"(s.long2) : "v"(s.long2), "v"(s.len2));
+    s.unsel2 += both & 0x00010001u;
+  }
+}
+
 // the exact walk, tuple by tuple like the fast one (ONE loop over the unit with the tuple chosen by the position made
 // the compiler keep a second copy of the unit in scratch and read it from there, a dependent load per step)
 struct ExactWalk {
@@ -1471,7 +1545,8 @@ __global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void o
   constexpr int kStage = LEN < 64 ? LEN : 64;       // positions per trip through LDS
   constexpr int kStride = kStage + 1;               // floats per unit in LDS: lane l reads bank (l + p) % 32
   constexpr int kTuples = LEN / 16;
-  __shared__ float lds[kWave * kStride];
+  constexpr int kLdsFloats = kWave * kStride > 2 * (kCand + 1) * kWave ? kWave * kStride : 2 * (kCand + 1) * kWave;
+  __shared__ float lds[kLdsFloats];    // the transposition's staging area, then the candidate lists
   const int lane = threadIdx.x;
   const long long unit0 = static_cast<long long>(blockIdx.x) * kWave;
   const long long unit = unit0 + lane;
@@ -1514,8 +1589,19 @@ __global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void o
   float guess = 1.0f;
   bool done = !live;
   unsigned long long moved = 0;     // wave-uniform: iterations in which some unit of this wave still moved
+  const CandList cand{lds, reinterpret_cast<int*>(lds + (kCand + 1) * kWave)};
+  int mode = 0;                     // wave-uniform: 0 full walks, 1 the next walk lists what it selects, 2 the lists are walked
+  int cand_slots = 0;               // wave-uniform: the longest list
+  int cand_count = 0;               // this lane's list
+  float cand_guess = 0.f;           // the iterate this lane's list was made for
   for (int it = 0; it < a.max_iter; ++it) {
     bool still_moving = false;
+    bool may_list = false;          // after this iteration: few elements selected and the iterate grew
+    if (mode == 2 && __ballot(!done && !(guess >= cand_guess)) != 0) mode = 0;      // (an iterate fell below its list)
+    if (mode == 1) {                // (also for a unit this iterate selects nothing of: it walks nothing)
+      cand_count = 0;
+      cand_guess = guess;
+    }
     if (!done) {
       LaneMask p{0.f, 0.f, 0}, n{0.f, 0.f, 0};
       if (guess <= amax) {      // (a guess above the unit's largest |x| selects nothing: the reference's first guess 1.0)
@@ -1526,12 +1612,20 @@ __global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void o
         bool long_runs = !by_compares && !(guess > 0.f);
         if (__ballot(!by_compares && !long_runs) != 0) {
           LanePair s{0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
-          walk_unit<kTuples>(s, xr, guess);
+          int walked = LEN;
+          if (mode == 2) {
+            walk_candidates(s, cand, lane, cand_slots, guess);
+            walked = cand_slots;
+          } else if (mode == 1) {
+            walk_unit_collect<kTuples>(s, xr, guess, cand, lane, cand_count);
+          } else {
+            walk_unit<kTuples>(s, xr, guess);
+          }
           // a run that touches the unit's end ends there
           p.acc = s.acc_p + s.seq_p;
           n.acc = s.acc_n + s.seq_n;
-          p.cnt = LEN - static_cast<int>(s.unsel2 & 0xFFFFu);
-          n.cnt = LEN - static_cast<int>(s.unsel2 >> 16);
+          p.cnt = walked - static_cast<int>(s.unsel2 & 0xFFFFu);
+          n.cnt = walked - static_cast<int>(s.unsel2 >> 16);
           long_runs |= !by_compares && (s.long2 & 0x00F800F8u) != 0;      // some run reached 8
         }
         if (long_runs) {
@@ -1556,6 +1650,7 @@ __global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void o
       const OctavStep st = octav_step(guess, p.acc, n.acc, p.cnt, n.cnt, LEN, a.s, a.count_is_f64);
       a.hist[static_cast<long long>(it) * a.units + unit] = st.next;
       still_moving = !st.close;
+      may_list = !special && guess > 0.f && st.next >= guess && st.next < __builtin_inff() && p.cnt + n.cnt <= kCand;
       if (reached_fixed_point(guess, st.next)) {
         repeat_iterate(a, it, unit, st.next);
         done = true;
@@ -1564,6 +1659,20 @@ __global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void o
     }
     if (__ballot(still_moving) != 0) moved |= 1ull << it;      // (outside the divergent part: every lane keeps the wave's mask)
     if (__ballot(!done) == 0) break;
+    if (mode == 1) {
+      // the lists are complete: empty slots behind every lane's own, the longest list bounds the walks
+      int longest = cand_count;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off));
+      cand_slots = __builtin_amdgcn_readfirstlane(longest);
+      for (int k = cand_count; k < cand_slots; ++k) {
+        cand.v[k * kWave + lane] = 0.f;
+        cand.pos[k * kWave + lane] = kCandNoPos;
+      }
+      mode = 2;
+    } else if (mode == 0 && __ballot(!done && !may_list) == 0) {
+      mode = 1;
+    }
   }
   if (lane == 0) publish_moving(a.moving, moved);
 }

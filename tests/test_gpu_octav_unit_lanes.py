@@ -130,3 +130,36 @@ def test_public_call_takes_the_new_kernel_and_matches_the_oracle(g):
   ref = O.octav_quant_params(w, 4, "BLOCKWISE_64")
   assert np.array_equal(np.asarray(p.scale), ref["scale"])
   assert np.array_equal(np.asarray(p.quantized_data), ref["quantized_data"])
+
+
+@pytest.mark.parametrize("unit_len", [32, 64, 128])
+def test_a_million_mixed_units_against_the_groups_kernel(g, unit_len):
+  """Both kernels on 2^24 elements of units drawn from very different laws -- Gaussian at several scales, heavy tails, a few
+  huge outliers on a tiny background (iterates that overshoot and come back down), sparse units, two-valued units, long
+  same-signed stretches: every clipping constant and the iteration count, bit for bit. What this sweeps that the designed
+  cases cannot: the switch to the candidate lists (and back) at whatever iteration each wave takes it."""
+  rng = np.random.default_rng(7 + unit_len)
+  units = (1 << 24) // unit_len
+  w = rng.standard_normal((units, unit_len)).astype(np.float32)
+  kind = rng.integers(0, 8, size=units)
+  scale = np.float32(10.0) ** rng.integers(-3, 2, size=units).astype(np.float32)
+  w *= scale[:, None]
+  heavy = kind == 1
+  w[heavy] = (w[heavy] * np.exp(rng.standard_normal(w[heavy].shape) * 1.5)).astype(np.float32)
+  outl = kind == 2
+  w[outl] *= np.float32(1e-3)
+  pick = rng.random(w.shape) < 0.03
+  w[outl[:, None] & pick] *= np.float32(3e3)
+  sparse = kind == 3
+  w[sparse[:, None] & (rng.random(w.shape) < 0.9)] = 0.0
+  two = kind == 4
+  w[two] = np.where(rng.random(w[two].shape) < 0.1, np.float32(1.7), np.float32(-0.02))
+  runs = kind == 5
+  w[runs] = np.abs(w[runs])
+  flip = rng.random(w.shape) < 0.08
+  w[runs[:, None] & flip] *= -1
+  got, iters = _clip(g, w, unit_len, 4)
+  old, old_iters = _clip(g, w, unit_len, 4, lanes=False)
+  assert iters == old_iters
+  same = got.view(np.uint32) == old.view(np.uint32)
+  assert same.all(), (int((~same).sum()), np.flatnonzero(~same)[:8], kind[np.flatnonzero(~same)[:8]])
