@@ -1384,14 +1384,6 @@ __device__ __forceinline__ void walk16(LanePair& s, v16f t, float guess) {
   }
 }
 
-template <int TUPLES, int T = 0>
-__device__ __forceinline__ void walk_unit(LanePair& s, const UnitRegs& r, float guess) {
-  if constexpr (T < TUPLES) {
-    walk16(s, unit_tuple<T>(r), guess);
-    walk_unit<TUPLES, T + 1>(s, r, guess);
-  }
-}
-
 // The same step for ANY run length and for guess 0 as well (finite data, finite guess >= 0): the differences get + 0.0 --
 // nothing for a guess above zero, and at guess +0.0 it turns the one wrong sign, (-0.0) - (+0.0) = -0.0, into +0.0 (x >= +0.0
 // holds for -0.0) -- and where a run of 8 or more ends, NumPy's leaf over that run (from memory, only the lanes concerned)
@@ -1420,6 +1412,28 @@ __device__ __forceinline__ void lane_step_pair_long(LanePair& s, float v, float 
 __device__ __forceinline__ void walk16_long(LanePair& s, v16f t, float guess, const float* at) {
 #pragma unroll 1
   for (int j = 0; j < 16; ++j) lane_step_pair_long(s, t[j], guess, at + j);
+}
+
+// The full walk of the ordinary iterations, a tuple at a time: the fast steps, unless a run of 8+ is open where the tuple
+// begins (then the long-aware steps at once) or reaches 8 inside it (then the tuple is walked AGAIN, from the state it
+// began with, by the long-aware steps). A rare long run costs its wave sixteen slower steps -- walking the whole unit
+// again cost that wave another iteration, and the kernel ends with its slowest wave.
+template <int TUPLES, int T = 0>
+__device__ __forceinline__ void walk_unit(LanePair& s, const UnitRegs& r, float guess, const float* u) {
+  if constexpr (T < TUPLES) {
+    bool long_steps = __ballot((s.len2 & 0xFFF8FFF8u) != 0) != 0;      // (wave-uniform)
+    if (!long_steps) {
+      const LanePair began = s;
+      s.long2 = 0;
+      walk16(s, unit_tuple<T>(r), guess);
+      if (__ballot((s.long2 & 0x00F800F8u) != 0) != 0) {
+        s = began;
+        long_steps = true;
+      }
+    }
+    if (long_steps) walk16_long(s, unit_tuple<T>(r), guess, u + 16 * T);
+    walk_unit<TUPLES, T + 1>(s, r, guess, u);
+  }
 }
 
 template <int TUPLES, int T = 0>
@@ -1619,14 +1633,16 @@ __global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void o
           } else if (mode == 1) {
             walk_unit_collect<kTuples>(s, xr, guess, cand, lane, cand_count);
           } else {
-            walk_unit<kTuples>(s, xr, guess);
+            walk_unit<kTuples>(s, xr, guess, u);
+            s.long2 = 0;         // (long runs were dealt with where they ended; one that touches the unit's end: below)
           }
           // a run that touches the unit's end ends there
-          p.acc = s.acc_p + s.seq_p;
-          n.acc = s.acc_n + s.seq_n;
+          const int lp = static_cast<int>(s.len2 & 0xFFFFu), ln = static_cast<int>(s.len2 >> 16);
+          p.acc = s.acc_p + (mode == 0 && lp >= 8 ? unit_long_run(u + LEN - lp, lp) : s.seq_p);
+          n.acc = s.acc_n + (mode == 0 && ln >= 8 ? unit_long_run(u + LEN - ln, ln) : s.seq_n);
           p.cnt = walked - static_cast<int>(s.unsel2 & 0xFFFFu);
           n.cnt = walked - static_cast<int>(s.unsel2 >> 16);
-          long_runs |= !by_compares && (s.long2 & 0x00F800F8u) != 0;      // some run reached 8
+          long_runs |= !by_compares && (s.long2 & 0x00F800F8u) != 0;      // (listing / list walks: some run reached 8)
         }
         if (long_runs) {
           LanePair s{0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
