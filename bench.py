@@ -312,7 +312,11 @@ def more_extras(torch, ops, gen, xs) -> dict:
                                       "note": "bit-exact NumPy-order masked sums, 10 Newton iterations, sigma = 0.02"}
   ms = timed_ms(torch, lambda: ops.octav_clip(w.view(-1), 4096 * 32, 128, 4, 10, 3.0, True, True), 20, 3)
   out["octav_clip_4096x4096_int4_blockwise128"] = {"ms": round(ms, 4),
-                                                   "hbm_frac_of_one_read": round(ROWS * COLS * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                                                   "hbm_frac_of_one_read": round(ROWS * COLS * 4 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                                   "note": "bit-exact, a lane per block (octav_unit_lanes_kernel; round 5: octav_groups_kernel 0.217 ms)"}
+  ms = timed_ms(torch, lambda: ops.octav_clip(w.view(-1), 4096 * 128, 32, 4, 10, 3.0, True, True), 20, 3)
+  out["octav_clip_4096x4096_int4_blockwise32"] = {"ms": round(ms, 4),
+                                                  "hbm_frac_of_one_read": round(ROWS * COLS * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)}
   # ... and the opt-in one-read kernel (ops.octav_mode("fast"), tolerance class T2): the row stays in registers
   with ops.octav_mode("fast"):
     ms = timed_ms(torch, lambda: ops.octav_clip(w.view(-1), 4096, 4096, 4, 10, 3.0, True, True), 20, 3)
@@ -415,6 +419,8 @@ def roofline_summary(extras: dict) -> dict:
       "c5_apply_d2048": get("c5_gptq", "d2048", "apply_2048_rows_int4", "roofline", "frac"),
       "c5_apply_d16384": get("c5_gptq", "d16384", "apply_2048_rows_int4", "roofline", "frac"),
       "octav_exact_one_read": get("octav_clip_4096x4096_int4", "hbm_frac_of_one_read"),
+      "octav_exact_b128_one_read": get("octav_clip_4096x4096_int4_blockwise128", "hbm_frac_of_one_read"),
+      "octav_exact_b32_one_read": get("octav_clip_4096x4096_int4_blockwise32", "hbm_frac_of_one_read"),
       "octav_fast_one_read": get("octav_clip_4096x4096_int4_fast", "hbm_frac_of_one_read"),
       "mse_scale_one_read": get("mse_4096x4096_int4", "hbm_frac_of_one_read"),
       "oscar_clip_channelwise_one_read": get("oscar_4096x4096_int4_channelwise", "clip_bounds", "hbm_frac_of_one_read"),

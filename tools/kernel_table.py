@@ -83,8 +83,12 @@ def table(rnd):
   add(("`octav_rows_kernel<1,256>` + `octav_tail_kernel` OCTAV clip search 4096², bit-exact (default)", "`mi355q_octav_clip_f32`", "HBM (one read)", "4 B/elem", f"{oc['ms'] * 1e3:.1f} us",
        f"{oc['hbm_frac_of_one_read']:.3f}", ratio("octav_rows_kernel<1, 256>"), bench + " `extras.octav_clip_4096x4096_int4`"))
   ob = e["octav_clip_4096x4096_int4_blockwise128"]
-  add(("`octav_groups_kernel` the same for blocks of 128, bit-exact", "`mi355q_octav_clip_f32`", "HBM (one read)", "4 B/elem", f"{ob['ms'] * 1e3:.1f} us", f"{ob['hbm_frac_of_one_read']:.3f}",
-       ratio("octav_groups_kernel"), bench + " `extras.octav_clip_4096x4096_int4_blockwise128`"))
+  add(("`octav_unit_lanes_kernel<128>` the same for blocks of 128 (a lane per block), bit-exact", "`mi355q_octav_clip_f32`", "HBM (one read)", "4 B/elem", f"{ob['ms'] * 1e3:.1f} us", f"{ob['hbm_frac_of_one_read']:.3f}",
+       ratio("octav_unit_lanes_kernel"), bench + " `extras.octav_clip_4096x4096_int4_blockwise128`"))
+  if "octav_clip_4096x4096_int4_blockwise32" in e:
+    o32 = e["octav_clip_4096x4096_int4_blockwise32"]
+    add(("`octav_unit_lanes_kernel<32>` blocks of 32, bit-exact", "`mi355q_octav_clip_f32`", "HBM (one read)", "4 B/elem", f"{o32['ms'] * 1e3:.1f} us",
+         f"{o32['hbm_frac_of_one_read']:.3f}", "-", bench + " `extras.octav_clip_4096x4096_int4_blockwise32`"))
   if "octav_clip_4096x4096_int4_fast" in e:
     of, of2 = e["octav_clip_4096x4096_int4_fast"], e["octav_clip_2048x16384_int4_fast"]
     add(("`octav_fast_kernel<64,16>` one-read OCTAV 4096² (opt-in, T2)", "`mi355q_octav_clip_fast_f32`", "HBM (one read)", "4 B/elem", f"{of['ms'] * 1e3:.1f} us", f"{of['hbm_frac_of_one_read']:.3f}",

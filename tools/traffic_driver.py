@@ -47,7 +47,7 @@ def main():
   out.append(("octav_rows_kernel<1, 256>", 4096 * 4096 * 4))
   for _ in range(3):
     ops.octav_clip(w.view(-1), 4096 * 32, 128, 4, 10, 3.0, True, True)
-  out.append(("octav_groups_kernel", 4096 * 4096 * 4))
+  out.append(("octav_unit_lanes_kernel", 4096 * 4096 * 4))
   w2 = rand(2048, 16384)
   for _ in range(3):
     ops.octav_clip(w2.view(-1), 2048, 16384, 4, 10, 3.0, True, True)
