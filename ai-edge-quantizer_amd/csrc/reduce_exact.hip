@@ -1887,6 +1887,10 @@ struct MseArgs {
   int lds_stride;
   float multiplier;
   float* scale;
+  // mi355q_mse_requant_f32: the wave that made a unit's scale also quantizes the unit (it has just read it: the second
+  // pass comes out of the L2), four int8 per lane and store; null: scales only
+  unsigned* q = nullptr;     // [units][len / 4]
+  float lo = 0.f, hi = 0.f;
 };
 
 // Leaves of NumPy's pairwise recursion over [lo, lo + n), in order (n <= 8192: at most 128).
@@ -2033,9 +2037,23 @@ __global__ __launch_bounds__(256) void mse_scale_balanced_kernel(MseArgs a, int 
     }
     acc = c0 == 0 ? x : acc + x;
   }
-  if (lane == 0) {
-    const float mean = acc / static_cast<float>(a.len);
-    a.scale[unit] = a.multiplier * __builtin_sqrtf(mean);
+  acc = lane_bcast(acc, 0);      // (lane 0's total is the unit's: short last chunks leave other slots with copies of leaf 0)
+  const float mean = acc / static_cast<float>(a.len);
+  const float scale = a.multiplier * __builtin_sqrtf(mean);
+  if (lane == 0) a.scale[unit] = scale;
+  if (a.q != nullptr) {
+    // uniform_quantize with a zero zero point: rint(x / scale) clipped (ref uniform_quantize_tensor.py:357-360; the reference's
+    // `+ zero_point` in float64 changes no value here: it only turns -0.0 into +0.0, and both round to the integer 0)
+    const float4* u4 = reinterpret_cast<const float4*>(u);
+    unsigned* q = a.q + unit * (a.len / 4);
+    for (int i = lane; i < a.len / 4; i += kWave) {
+      const float4 v = u4[i];
+      const unsigned w = (static_cast<unsigned>(round_clip(v.x / scale, a.lo, a.hi)) & 0xFFu) |
+                         ((static_cast<unsigned>(round_clip(v.y / scale, a.lo, a.hi)) & 0xFFu) << 8) |
+                         ((static_cast<unsigned>(round_clip(v.z / scale, a.lo, a.hi)) & 0xFFu) << 16) |
+                         ((static_cast<unsigned>(round_clip(v.w / scale, a.lo, a.hi)) & 0xFFu) << 24);
+      __builtin_nontemporal_store(w, q + i);
+    }
   }
 }
 
@@ -2543,5 +2561,33 @@ extern "C" int32_t mi355q_mse_scale_f32(const float* x, int64_t units, int64_t u
   else
     hipLaunchKernelGGL(mse_scale_leaves_kernel, grid, blk, 0, st, a);
   MI355Q_CHECK_LAUNCH("mse_scale launch");
+  return MI355Q_OK;
+}
+
+extern "C" int32_t mi355q_mse_requant_f32(const float* x, int64_t units, int64_t unit_len, float multiplier, int32_t bits,
+                                          int32_t narrow, float* scale_out, int8_t* q_out, void* stream) {
+  clear_error();
+  if (units < 0 || unit_len < 0) return fail(MI355Q_BAD_ARG, "negative shape");
+  if (bits < 2 || bits > 8) return fail(MI355Q_BAD_ARG, "bits must be in [2, 8]");
+  if (units == 0) return MI355Q_OK;
+  if (unit_len == 0) return fail(MI355Q_BAD_SHAPE, "empty reduction unit");
+  if (unit_len > 0x7FFFFFFFLL - 64) return fail(MI355Q_UNSUPPORTED, "unit_len too large");
+  if (!x || !scale_out || !q_out) return fail(MI355Q_BAD_ARG, "null pointer");
+  int leaf = 0, depth = 0;
+  const int len = static_cast<int>(unit_len);
+  const bool one_kernel = unit_len % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(q_out) & 3) == 0 &&
+                          balanced_chunk(len - (len - 1) / kChunk * kChunk, &leaf, &depth) && !getenv("MI355Q_MSE_TWO_KERNELS");
+  if (!one_kernel) {      // the scale kernel of any length, then the quantizer every other algorithm uses
+    const int32_t st = mi355q_mse_scale_f32(x, units, unit_len, multiplier, scale_out, stream);
+    if (st != MI355Q_OK) return st;
+    return mi355q_quantize_f32(x, 1, units, unit_len, scale_out, 0, nullptr, 1, bits, narrow, 8, q_out, stream);
+  }
+  MseArgs a{x, units, len, 0, multiplier, scale_out};
+  a.q = reinterpret_cast<unsigned*>(q_out);
+  a.hi = static_cast<float>((1 << (bits - 1)) - 1);
+  a.lo = -static_cast<float>(1 << (bits - 1)) + (narrow ? 1.f : 0.f);
+  hipLaunchKernelGGL(mse_scale_balanced_kernel, dim3(static_cast<unsigned>((units + 3) / 4)), dim3(4 * kWave), 0, as_stream(stream), a,
+                     leaf, depth);
+  MI355Q_CHECK_LAUNCH("mse requant launch");
   return MI355Q_OK;
 }

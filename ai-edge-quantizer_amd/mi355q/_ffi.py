@@ -52,6 +52,7 @@ PROTOTYPES = {
                                          c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "mi355q_mse_scale_f32": (c_i32, [c_ptr, c_i64, c_i64, c_f32, c_ptr, c_ptr]),
     "mi355q_mse_scale_nd_f32": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_f32, c_ptr, c_ptr]),
+    "mi355q_mse_requant_f32": (c_i32, [c_ptr, c_i64, c_i64, c_f32, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
     "mi355q_hadamard_rotate_f32": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr]),
     "mi355q_gemm_f32": (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64,
                                 c_i64, c_i64, c_i64, c_f32, c_f32, c_i32, c_ptr]),

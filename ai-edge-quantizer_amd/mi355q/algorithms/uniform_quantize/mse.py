@@ -62,9 +62,12 @@ def get_tensor_quant_params(
   inner = x.size // (outer * units)
   rt.require_gpu()
   xd = rt.to_device(x.reshape(-1))
-  scale_d = ops.mse_scale_nd(xd, outer, units, inner, _MSE_QUANT_MULS[cfg.num_bits])
-  q = ops.quantize(xd, outer, units, inner, scale_d, None, cfg.num_bits, cfg.num_bits >= 8,
-                   zp_via_f64=True)
+  if outer == 1:     # rows of a weight: scale and integers in one launch (the unit is still in the L2 when it is quantized)
+    scale_d, q = ops.mse_requant(xd, units, inner, _MSE_QUANT_MULS[cfg.num_bits], cfg.num_bits, cfg.num_bits >= 8)
+  else:
+    scale_d = ops.mse_scale_nd(xd, outer, units, inner, _MSE_QUANT_MULS[cfg.num_bits])
+    q = ops.quantize(xd, outer, units, inner, scale_d, None, cfg.num_bits, cfg.num_bits >= 8,
+                     zp_via_f64=True)
   # a large weight's results stay in HBM (the integers for the model writer, the scales so that
   # the call does not wait for its own kernels); NumPy consumers get host copies on demand
   scale = (rt.HbmArray(scale_d.reshape(out_shape)) if tensor_content.nbytes >= rt.KEEP_IN_HBM_BYTES

@@ -392,6 +392,21 @@ def mse_scale_nd(x: torch.Tensor, outer: int, channels: int, inner: int,
   return scale
 
 
+def mse_requant(x: torch.Tensor, units: int, unit_len: int, multiplier: float, bits: int,
+                narrow: bool) -> tuple[torch.Tensor, torch.Tensor]:
+  """a14 whole, contiguous units: (scale float32 [units], q int8 [units * unit_len]) -- the MSE scale in NumPy's order
+  and clip(rint(x / scale)) with a zero zero point, one kernel where the unit length allows. ref: mse.py:100-128."""
+  rt.require_gpu()
+  x = _f32(x)
+  if x.numel() != units * unit_len:
+    raise ValueError("shape view does not match numel")
+  scale = rt.empty((units,), torch.float32)
+  q = rt.empty(tuple(x.shape), torch.int8)
+  _ffi.check(_ffi.lib().mi355q_mse_requant_f32(rt.ptr(x), units, unit_len, np.float32(multiplier), bits,
+                                               1 if narrow else 0, rt.ptr(scale), rt.ptr(q), rt.stream_ptr()))
+  return scale, q
+
+
 def mse_scale(x: torch.Tensor, units: int, unit_len: int, multiplier: float) -> torch.Tensor:
   """a14. scale[u] = multiplier * sqrt(mean(x_u**2)). ref: mse.py:100-109."""
   rt.require_gpu()

@@ -423,6 +423,8 @@ def roofline_summary(extras: dict) -> dict:
       "octav_exact_b32_one_read": get("octav_clip_4096x4096_int4_blockwise32", "hbm_frac_of_one_read"),
       "octav_fast_one_read": get("octav_clip_4096x4096_int4_fast", "hbm_frac_of_one_read"),
       "mse_scale_one_read": get("mse_4096x4096_int4", "hbm_frac_of_one_read"),
+      "mse_scale_and_quantize": get("mse_4096x4096_int4", "scale_and_quantize_hbm_frac"),
+      "mse_public_call": get("mse_4096x4096_int4", "public_call_hbm_frac"),
       "oscar_clip_channelwise_one_read": get("oscar_4096x4096_int4_channelwise", "clip_bounds", "hbm_frac_of_one_read"),
       "oscar_clip_b128_one_read": get("oscar_4096x4096_int4_b128", "clip_bounds", "hbm_frac_of_one_read"),
       "oscar_clip_2048x16384_one_read": get("oscar_clip_bounds_2048x16384_channelwise", "hbm_frac_of_one_read"),
@@ -488,11 +490,15 @@ def round6_extras(torch, ops, gen, xs) -> dict:
   res = rt.HbmArray(w)
   mse.get_tensor_quant_params(info, cfg, res, None)
   sec = wall(lambda: mse.get_tensor_quant_params(info, cfg, res, None))
+  ms_fused = timed_ms(torch, lambda: ops.mse_requant(w.view(-1), n, d, 0.37755, 4, False), 50, 5)
   out["mse_4096x4096_int4"] = {"scale_kernel_ms": round(ms, 5), "hbm_frac_of_one_read": frac(one_read, ms),
+                               "scale_and_quantize_kernel_ms": round(ms_fused, 5),
+                               "scale_and_quantize_hbm_frac": frac(one_read + n * d + n * 4, ms_fused),
                                "public_call_ms": round(sec * 1e3, 4),
-                               "public_call_hbm_frac": frac(2 * one_read + n * d, sec * 1e3),
-                               "note": "scale = 0.37755 * sqrt(mean(x^2)) in NumPy's pairwise order (bit-exact), then quantize:"
-                                       " two reads + one int8 write per element end to end"}
+                               "public_call_hbm_frac": frac(one_read + n * d + n * 4, sec * 1e3),
+                               "note": "scale = 0.37755 * sqrt(mean(x^2)) in NumPy's pairwise order (bit-exact) and clip(rint(x / scale)):"
+                                       " ONE launch (mi355q_mse_requant_f32: the wave that summed a row quantizes it out of the L2),"
+                                       " one read + one int8 write per element (round 5: two kernels, two reads)"}
   # ---- f4 OSCAR: stage by stage, then the whole public call (3 fixed-point iterations, clip search, quantize)
   rng = np.random.default_rng(1)
   mu2 = np.exp(rng.normal(size=d) * 1.5)

@@ -259,6 +259,13 @@ int32_t mi355q_mse_scale_f32(const float* x, int64_t units, int64_t unit_len, fl
 /* [outer, channels, inner] view, one scale per channel (see mi355q_octav_clip_nd_f32). */
 int32_t mi355q_mse_scale_nd_f32(const float* x, int64_t outer, int64_t channels, int64_t inner,
                                 float multiplier, float* scale_out, void* stream);
+/* a14 whole: the scale of every contiguous unit AND its integers, q = clip(rint(x / scale[u])) with a zero zero point
+ * (ref: mse.py:100-128 -> uniform_quantize_tensor.py:273-362), int8 containers, lo = -2^(bits-1) + (narrow ? 1 : 0).
+ * One kernel when a unit's pairwise tree is complete (every length 128 * 2^k, and 8192-multiples of those) and x is
+ * 16-byte aligned: the wave that summed a unit quantizes it out of the L2; otherwise mi355q_mse_scale_f32 followed by
+ * mi355q_quantize_f32. Same bits either way. */
+int32_t mi355q_mse_requant_f32(const float* x, int64_t units, int64_t unit_len, float multiplier, int32_t bits,
+                               int32_t narrow, float* scale_out, int8_t* q_out, void* stream);
 
 /* ------------------------------------------------------------------------
  * K6 -- block-diagonal Hadamard rotation: out = reshape(x, (n_vec, h)) @ (H_h / sqrt(h)),

@@ -100,7 +100,10 @@ def table(rnd):
     ms_ = e["mse_4096x4096_int4"]
     add(("`mse_scale_balanced_kernel` MSE scale 4096², NumPy pairwise order (bit-exact)", "`mi355q_mse_scale_f32`", "HBM (one read)", "4 B/elem", f"{ms_['scale_kernel_ms'] * 1e3:.1f} us",
          f"{ms_['hbm_frac_of_one_read']:.3f}", ratio("mse_scale_balanced_kernel"), bench + " `extras.mse_4096x4096_int4`"))
-    add(("MSE `get_tensor_quant_params` on a resident 4096² weight (scale + quantize, wall clock)", "public call", "HBM", "9 B/elem (two reads, int8 out)", f"{ms_['public_call_ms'] * 1e3:.1f} us",
+    if "scale_and_quantize_kernel_ms" in ms_:
+      add(("the same kernel with the quantize behind the sum (one launch: scale + int8)", "`mi355q_mse_requant_f32`", "HBM", "5 B/elem", f"{ms_['scale_and_quantize_kernel_ms'] * 1e3:.1f} us",
+           f"{ms_['scale_and_quantize_hbm_frac']:.3f}", "-", bench + " `extras.mse_4096x4096_int4`"))
+    add(("MSE `get_tensor_quant_params` on a resident 4096² weight (wall clock)", "public call", "HBM", "5 B/elem (one read, int8 out)" if "scale_and_quantize_kernel_ms" in ms_ else "9 B/elem (two reads, int8 out)", f"{ms_['public_call_ms'] * 1e3:.1f} us",
          f"{ms_['public_call_hbm_frac']:.3f}", "-", bench + " `extras.mse_4096x4096_int4`"))
   for label, key in (("channelwise", "oscar_4096x4096_int4_channelwise"), ("blocks of 128", "oscar_4096x4096_int4_b128")):
     if key in e:
