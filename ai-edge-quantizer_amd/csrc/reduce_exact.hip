@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(kGroupThreads, 2) void octav_groups_kernel(OctavArg
 //       rolled loop over the unit in memory (read a moment ago), compares, the same steps plus NumPy's eight-accumulator
 //       leaf where a run of 8 .. 128 ends (a unit is at most one leaf long).
 // A lane that reached its fixed point is masked off; the wave leaves when all have. Bit-identical to octav_kernel.
-__device__ __forceinline__ float unit_long_run(const float* a, int n) {   // NumPy's leaf, 8 <= n <= 128
+__device__ __forceinline__ float unit_leaf(const float* a, int n) {   // NumPy's leaf, 8 <= n <= 128
   float r[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) r[k] = a[k];
@@ -1267,6 +1267,17 @@ __device__ __forceinline__ float unit_long_run(const float* a, int n) {   // Num
   return res;
 }
 
+// NumPy's pairwise sum of a run of 8 .. 256 elements: a leaf up to 128, beyond that the two halves (the first rounded
+// down to a multiple of 8), each a leaf -- a unit of 256 needs one level of the recursion, no more.
+template <bool WIDE>      // WIDE: units of 256 (shorter units never see the second case: one branch less at every site)
+__device__ __forceinline__ float unit_long_run(const float* a, int n) {
+  if (!WIDE || n <= 128) return unit_leaf(a, n);
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  const float left = unit_leaf(a, n2);
+  return left + unit_leaf(a + n2, n - n2);
+}
+
 struct LaneMask {
   float acc, seq;
   int cnt;
@@ -1274,11 +1285,11 @@ struct LaneMask {
 
 // One element, one mask, any run: compares, the run length kept, NumPy's leaf where a run of 8+ ends (the exact walk;
 // `here` = the element's address).
-template <bool NEG>
+template <bool NEG, bool WIDE>
 __device__ __forceinline__ void lane_step_exact(LaneMask& m, int& len, float v, float thr, const float* here) {
   const bool sel = NEG ? v <= thr : v >= thr;
   float add = sel ? 0.f : m.seq;
-  if (!sel && len >= 8) add = unit_long_run(here - len, len);
+  if (!sel && len >= 8) add = unit_long_run<WIDE>(here - len, len);
   m.acc = m.acc + add;
   m.seq = sel ? m.seq + v : 0.f;
   len = sel ? len + 1 : 0;
@@ -1325,7 +1336,7 @@ __device__ __forceinline__ void lane_step_pair(LanePair& s, float v, float g) {
   s.unsel2 += both & 0x00010001u;                                           //  tree over all the unit's run lengths, kept live and spilled)
 }
 
-// (the second bound is waves per SIMD: 2 / 3 / 4 = 256 / 168 / 128 registers)
+// (the second bound is waves per SIMD: 1 / 2 / 3 / 4 = 512 / 256 / 168 / 128 registers)
 //
 // The unit lives in 32-float register TUPLES read with a wave-uniform index (s_set_gpr_idx_on): the walks are loops of
 // four steps, not LEN unrolled steps. Unrolled, the fast walk was 18 KB of straight-line code that every wave of the
@@ -1335,7 +1346,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // (eight named 16-register tuples, not an array of them and not four of 32: the array went through scratch on its way
 // into registers, and 32-register tuples were spilled whole when a second one had to be placed)
 struct UnitRegs {
-  v16f t0, t1, t2, t3, t4, t5, t6, t7;
+  v16f t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;      // (units of 256: all sixteen)
 };
 
 // (tuples are handed around BY VALUE: a reference to a member plus a run-time element index is an address computation, and the
@@ -1349,7 +1360,15 @@ __device__ __forceinline__ v16f unit_tuple(const UnitRegs& r) {
   else if constexpr (T == 4) return r.t4;
   else if constexpr (T == 5) return r.t5;
   else if constexpr (T == 6) return r.t6;
-  else return r.t7;
+  else if constexpr (T == 7) return r.t7;
+  else if constexpr (T == 8) return r.t8;
+  else if constexpr (T == 9) return r.t9;
+  else if constexpr (T == 10) return r.t10;
+  else if constexpr (T == 11) return r.t11;
+  else if constexpr (T == 12) return r.t12;
+  else if constexpr (T == 13) return r.t13;
+  else if constexpr (T == 14) return r.t14;
+  else return r.t15;
 }
 
 template <int T>
@@ -1361,7 +1380,15 @@ __device__ __forceinline__ void set_unit_tuple(UnitRegs& r, v16f t) {
   else if constexpr (T == 4) r.t4 = t;
   else if constexpr (T == 5) r.t5 = t;
   else if constexpr (T == 6) r.t6 = t;
-  else r.t7 = t;
+  else if constexpr (T == 7) r.t7 = t;
+  else if constexpr (T == 8) r.t8 = t;
+  else if constexpr (T == 9) r.t9 = t;
+  else if constexpr (T == 10) r.t10 = t;
+  else if constexpr (T == 11) r.t11 = t;
+  else if constexpr (T == 12) r.t12 = t;
+  else if constexpr (T == 13) r.t13 = t;
+  else if constexpr (T == 14) r.t14 = t;
+  else r.t15 = t;
 }
 
 __device__ __forceinline__ float tuple_element(v16f t, int jj) { return t[jj]; }
@@ -1389,6 +1416,7 @@ __device__ __forceinline__ void walk16(LanePair& s, v16f t, float guess) {
 // holds for -0.0) -- and where a run of 8 or more ends, NumPy's leaf over that run (from memory, only the lanes concerned)
 // takes the place of the left-to-right sum. Costs a compare and a branch per step more than lane_step_pair: this walk runs
 // where the fast one reported a long run, and at guess 0, where nearly every unit has one.
+template <bool WIDE>
 __device__ __forceinline__ void lane_step_pair_long(LanePair& s, float v, float g, const float* at) {
   const unsigned np_ = sign_smear((v - g) + 0.f);
   const unsigned nn_ = sign_smear(((-v) - g) + 0.f);
@@ -1398,8 +1426,8 @@ __device__ __forceinline__ void lane_step_pair_long(LanePair& s, float v, float 
   const unsigned ends_long = s.len2 & 0xFFF8FFF8u & both;       // a half that holds a length >= 8 and is not selected here
   if (ends_long != 0) {
     const int lp = static_cast<int>(s.len2 & 0xFFFFu), ln = static_cast<int>(s.len2 >> 16);
-    if (ends_long & 0xFFFFu) add_p = unit_long_run(at - lp, lp);
-    if (ends_long >> 16) add_n = unit_long_run(at - ln, ln);
+    if (ends_long & 0xFFFFu) add_p = unit_long_run<WIDE>(at - lp, lp);
+    if (ends_long >> 16) add_n = unit_long_run<WIDE>(at - ln, ln);
   }
   s.acc_p = add_f32(s.acc_p, add_p);
   s.acc_n = add_f32(s.acc_n, add_n);
@@ -1409,9 +1437,10 @@ __device__ __forceinline__ void lane_step_pair_long(LanePair& s, float v, float 
   s.unsel2 += both & 0x00010001u;
 }
 
+template <bool WIDE>
 __device__ __forceinline__ void walk16_long(LanePair& s, v16f t, float guess, const float* at) {
 #pragma unroll 1
-  for (int j = 0; j < 16; ++j) lane_step_pair_long(s, t[j], guess, at + j);
+  for (int j = 0; j < 16; ++j) lane_step_pair_long<WIDE>(s, t[j], guess, at + j);
 }
 
 // The full walk of the ordinary iterations, a tuple at a time: the fast steps, unless a run of 8+ is open where the tuple
@@ -1431,7 +1460,7 @@ __device__ __forceinline__ void walk_unit(LanePair& s, const UnitRegs& r, float 
         long_steps = true;
       }
     }
-    if (long_steps) walk16_long(s, unit_tuple<T>(r), guess, u + 16 * T);
+    if (long_steps) walk16_long<(TUPLES > 8)>(s, unit_tuple<T>(r), guess, u + 16 * T);
     walk_unit<TUPLES, T + 1>(s, r, guess, u);
   }
 }
@@ -1439,7 +1468,7 @@ __device__ __forceinline__ void walk_unit(LanePair& s, const UnitRegs& r, float 
 template <int TUPLES, int T = 0>
 __device__ __forceinline__ void walk_unit_long(LanePair& s, const UnitRegs& r, float guess, const float* u) {
   if constexpr (T < TUPLES) {
-    walk16_long(s, unit_tuple<T>(r), guess, u + 16 * T);
+    walk16_long<(TUPLES > 8)>(s, unit_tuple<T>(r), guess, u + 16 * T);
     walk_unit_long<TUPLES, T + 1>(s, r, guess, u);
   }
 }
@@ -1525,19 +1554,20 @@ struct ExactWalk {
   int lp, ln;
 };
 
+template <bool WIDE>
 __device__ __forceinline__ void exact16(ExactWalk& w, v16f t, float hi, float lo, const float* at) {
 #pragma unroll 1
   for (int j = 0; j < 16; ++j) {
     const float v = t[j];
-    lane_step_exact<false>(w.p, w.lp, v, hi, at + j);
-    lane_step_exact<true>(w.n, w.ln, v, lo, at + j);
+    lane_step_exact<false, WIDE>(w.p, w.lp, v, hi, at + j);
+    lane_step_exact<true, WIDE>(w.n, w.ln, v, lo, at + j);
   }
 }
 
 template <int TUPLES, int T = 0>
 __device__ __forceinline__ void exact_unit(ExactWalk& w, const UnitRegs& r, float hi, float lo, const float* u) {
   if constexpr (T < TUPLES) {
-    exact16(w, unit_tuple<T>(r), hi, lo, u + 16 * T);
+    exact16<(TUPLES > 8)>(w, unit_tuple<T>(r), hi, lo, u + 16 * T);
     exact_unit<TUPLES, T + 1>(w, r, hi, lo, u);
   }
 }
@@ -1554,8 +1584,31 @@ __device__ __forceinline__ void tuples_from_lds(UnitRegs& r, const float* row) {
   }
 }
 
+// Stage H of the load: positions H * STAGE .. (H + 1) * STAGE - 1 of the wave's 64 units, whole lines from HBM (16 lanes
+// per 256-byte stretch of a unit) turned through LDS so that lane l ends up with unit l.
+template <int LEN, int STAGE, int STRIDE, int H>
+__device__ __forceinline__ void load_unit_stages(UnitRegs& xr, const float* base, long long wave_floats, float* lds, int lane) {
+  if constexpr (H < LEN / STAGE) {
+    constexpr int kPer = STAGE / 4;              // float4 per unit and stage
+#pragma unroll
+    for (int q = 0; q < STAGE / 4; ++q) {        // 64 units x kPer float4 = kPer instructions of 64 lanes
+      const int f = q * kWave + lane;
+      const int uu = f / kPer, p4 = f % kPer;
+      const long long e = static_cast<long long>(uu) * LEN + H * STAGE + p4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < wave_floats) v = *reinterpret_cast<const float4*>(base + e);
+      float* d = lds + uu * STRIDE + p4 * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    tuples_from_lds<H * STAGE / 16, STAGE / 16>(xr, lds + lane * STRIDE);
+    __syncthreads();
+    load_unit_stages<LEN, STAGE, STRIDE, H + 1>(xr, base, wave_floats, lds, lane);
+  }
+}
+
 template <int LEN>
-__global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void octav_unit_lanes_kernel(OctavArgs a) {
+__global__ __launch_bounds__(kWave, LEN >= 256 ? 1 : (LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4))) void octav_unit_lanes_kernel(OctavArgs a) {
   constexpr int kStage = LEN < 64 ? LEN : 64;       // positions per trip through LDS
   constexpr int kStride = kStage + 1;               // floats per unit in LDS: lane l reads bank (l + p) % 32
   constexpr int kTuples = LEN / 16;
@@ -1567,32 +1620,8 @@ __global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void o
   const bool live = unit < a.units;
   const float* u = a.x + (live ? unit : 0) * LEN;
   UnitRegs xr;
-  // ---- the wave's 64 units: whole lines from HBM (16 lanes per 256-byte stretch of a unit), turned through LDS so
-  // that lane l ends up with unit l (a lane reading its own 16-byte pieces cost 25 us at 4096 x 4096: 64 lines per load)
-  {
-    const float* base = a.x + unit0 * LEN;
-    const long long wave_floats = (a.units - unit0 < kWave ? a.units - unit0 : kWave) * LEN;
-#pragma unroll
-    for (int h = 0; h < LEN / kStage; ++h) {
-      constexpr int kPer = kStage / 4;              // float4 per unit and stage
-#pragma unroll
-      for (int q = 0; q < kStage / 4; ++q) {        // 64 units x kPer float4 = kPer instructions of 64 lanes
-        const int f = q * kWave + lane;
-        const int uu = f / kPer, p4 = f % kPer;
-        const long long e = static_cast<long long>(uu) * LEN + h * kStage + p4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < wave_floats) v = *reinterpret_cast<const float4*>(base + e);
-        float* d = lds + uu * kStride + p4 * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
-      __syncthreads();
-      if (h == 0) tuples_from_lds<0, kStage / 16>(xr, lds + lane * kStride);
-      if constexpr (LEN > kStage) {
-        if (h == 1) tuples_from_lds<kStage / 16, kStage / 16>(xr, lds + lane * kStride);
-      }
-      __syncthreads();
-    }
-  }
+  // (a lane reading its own 16-byte pieces instead cost 25 us at 4096 x 4096: 64 lines per load instruction)
+  load_unit_stages<LEN, kStage, kStride, 0>(xr, a.x + unit0 * LEN, (a.units - unit0 < kWave ? a.units - unit0 : kWave) * LEN, lds, lane);
   float amax = 0.f;     // NaN is never selected and never the maximum
   float poison = 0.f;   // x * 0 summed: NaN as soon as the unit holds a NaN or an infinity (those units: the exact walk only)
   each_slot<0, LEN>(xr, [&](float v) {
@@ -1638,8 +1667,8 @@ __global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void o
           }
           // a run that touches the unit's end ends there
           const int lp = static_cast<int>(s.len2 & 0xFFFFu), ln = static_cast<int>(s.len2 >> 16);
-          p.acc = s.acc_p + (mode == 0 && lp >= 8 ? unit_long_run(u + LEN - lp, lp) : s.seq_p);
-          n.acc = s.acc_n + (mode == 0 && ln >= 8 ? unit_long_run(u + LEN - ln, ln) : s.seq_n);
+          p.acc = s.acc_p + (mode == 0 && lp >= 8 ? unit_long_run<(LEN > 128)>(u + LEN - lp, lp) : s.seq_p);
+          n.acc = s.acc_n + (mode == 0 && ln >= 8 ? unit_long_run<(LEN > 128)>(u + LEN - ln, ln) : s.seq_n);
           p.cnt = walked - static_cast<int>(s.unsel2 & 0xFFFFu);
           n.cnt = walked - static_cast<int>(s.unsel2 >> 16);
           long_runs |= !by_compares && (s.long2 & 0x00F800F8u) != 0;      // (listing / list walks: some run reached 8)
@@ -1648,8 +1677,8 @@ __global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void o
           LanePair s{0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
           walk_unit_long<kTuples>(s, xr, guess, u);
           const int lp = static_cast<int>(s.len2 & 0xFFFFu), ln = static_cast<int>(s.len2 >> 16);
-          p.acc = s.acc_p + (lp >= 8 ? unit_long_run(u + LEN - lp, lp) : s.seq_p);
-          n.acc = s.acc_n + (ln >= 8 ? unit_long_run(u + LEN - ln, ln) : s.seq_n);
+          p.acc = s.acc_p + (lp >= 8 ? unit_long_run<(LEN > 128)>(u + LEN - lp, lp) : s.seq_p);
+          n.acc = s.acc_n + (ln >= 8 ? unit_long_run<(LEN > 128)>(u + LEN - ln, ln) : s.seq_n);
           p.cnt = LEN - static_cast<int>(s.unsel2 & 0xFFFFu);
           n.cnt = LEN - static_cast<int>(s.unsel2 >> 16);
         }
@@ -1659,8 +1688,8 @@ __global__ __launch_bounds__(kWave, LEN >= 128 ? 2 : (LEN >= 64 ? 3 : 4)) void o
           exact_unit<kTuples>(w, xr, hi, lo, u);
           p = w.p;
           n = w.n;
-          p.acc = p.acc + (w.lp >= 8 ? unit_long_run(u + LEN - w.lp, w.lp) : p.seq);
-          n.acc = n.acc + (w.ln >= 8 ? unit_long_run(u + LEN - w.ln, w.ln) : n.seq);
+          p.acc = p.acc + (w.lp >= 8 ? unit_long_run<(LEN > 128)>(u + LEN - w.lp, w.lp) : p.seq);
+          n.acc = n.acc + (w.ln >= 8 ? unit_long_run<(LEN > 128)>(u + LEN - w.ln, w.ln) : n.seq);
         }
       }
       const OctavStep st = octav_step(guess, p.acc, n.acc, p.cnt, n.cnt, LEN, a.s, a.count_is_f64);
@@ -2383,14 +2412,15 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
     MI355Q_CHECK_LAUNCH("octav pick launch");
     return MI355Q_OK;
   }
-  if ((unit_len == 32 || unit_len == 64 || unit_len == 128) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+  if ((unit_len == 32 || unit_len == 64 || unit_len == 128 || unit_len == 256) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
       (units + kWave - 1) / kWave <= 0x7FFFFFFFLL && octav_unit_lanes_on()) {
     // blockwise units: a lane per unit, the unit in registers (octav_unit_lanes_kernel)
     OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close};
     const dim3 grid(static_cast<unsigned>((units + kWave - 1) / kWave));
     if (unit_len == 32) hipLaunchKernelGGL(octav_unit_lanes_kernel<32>, grid, dim3(kWave), 0, st, a);
     else if (unit_len == 64) hipLaunchKernelGGL(octav_unit_lanes_kernel<64>, grid, dim3(kWave), 0, st, a);
-    else hipLaunchKernelGGL(octav_unit_lanes_kernel<128>, grid, dim3(kWave), 0, st, a);
+    else if (unit_len == 128) hipLaunchKernelGGL(octav_unit_lanes_kernel<128>, grid, dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL(octav_unit_lanes_kernel<256>, grid, dim3(kWave), 0, st, a);
     MI355Q_CHECK_LAUNCH("octav unit lanes launch");
     hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
                        hist, not_close, units, max_iter, early_stop, clip_out, iters_out);

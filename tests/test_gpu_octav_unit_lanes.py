@@ -1,4 +1,4 @@
-"""OCTAV on blockwise units of 32 / 64 / 128 elements: the lane-per-unit kernel (csrc/reduce_exact.hip,
+"""OCTAV on blockwise units of 32 / 64 / 128 / 256 elements: the lane-per-unit kernel (csrc/reduce_exact.hip,
 octav_unit_lanes_kernel) against the oracle's NumPy iteration (ref octav.py:30-112) and against the kernel it replaced
 (MI355Q_OCTAV_UNIT_LANES=0: octav_groups_kernel / octav_kernel), bit for bit: clipping constants AND iteration counts.
 
@@ -62,7 +62,7 @@ def _designed(rng, units, unit_len):
   return w
 
 
-@pytest.mark.parametrize("unit_len", [32, 64, 128])
+@pytest.mark.parametrize("unit_len", [32, 64, 128, 256])
 @pytest.mark.parametrize("bits", [4, 8, 2])
 def test_designed_runs_against_the_oracle(g, unit_len, bits):
   rng = np.random.default_rng(unit_len * 10 + bits)
@@ -74,7 +74,7 @@ def test_designed_runs_against_the_oracle(g, unit_len, bits):
     assert iters == ref_iters
 
 
-@pytest.mark.parametrize("unit_len", [32, 64, 128])
+@pytest.mark.parametrize("unit_len", [32, 64, 128, 256])
 @pytest.mark.parametrize("kind", ["weights", "unit_normal", "same_sign", "zeros_and_specials", "constant"])
 def test_random_layouts_against_the_oracle_and_the_groups_kernel(g, unit_len, kind):
   rng = np.random.default_rng(hash((unit_len, kind)) % (1 << 31))
@@ -111,7 +111,7 @@ def test_layer_sized_blockwise_weight_against_the_groups_kernel(g):
   gen = torch.Generator(device="cuda").manual_seed(99)
   for sigma in (0.02, 1.0):
     w = (torch.randn((4096, 4096), generator=gen, device="cuda") * sigma).cpu().numpy()
-    for unit_len in (128, 32):
+    for unit_len in (256, 128, 32):
       got, iters = _clip(g, w, unit_len, 4)
       old, old_iters = _clip(g, w, unit_len, 4, lanes=False)
       assert _same(got, old) and iters == old_iters, (sigma, unit_len)
@@ -132,7 +132,7 @@ def test_public_call_takes_the_new_kernel_and_matches_the_oracle(g):
   assert np.array_equal(np.asarray(p.quantized_data), ref["quantized_data"])
 
 
-@pytest.mark.parametrize("unit_len", [32, 64, 128])
+@pytest.mark.parametrize("unit_len", [32, 64, 128, 256])
 def test_a_million_mixed_units_against_the_groups_kernel(g, unit_len):
   """Both kernels on 2^24 elements of units drawn from very different laws -- Gaussian at several scales, heavy tails, a few
   huge outliers on a tiny background (iterates that overshoot and come back down), sparse units, two-valued units, long
