@@ -60,7 +60,10 @@ python tools/pmc_big_kernels.py /tmp/prof_fetch > "$OUT/hinv16384_fetch.txt" 2>&
   for s in "2048 2048" "16384 2048" "2048 8192" "4096 8192" "4096 11008" "2048 16384"; do
     echo "# rows cols = $s"; timeout 200 python tools/octav_iter_bench.py $s 0.02 2>&1 | grep "max_iter=10"
   done
-  echo "# tools/octav_block_bench.py (blockwise units, octav_groups_kernel)"
+  echo "# tools/octav_block_bench.py (blockwise units: 32 .. 256 octav_unit_lanes_kernel, 512 octav_groups_kernel, 1024+ the rows kernel)"
+  timeout 200 python tools/octav_unit_iter_bench.py 128 0.02 2>&1 | grep max_iter
+  echo "# ... and with MI355Q_OCTAV_UNIT_LANES=0 (octav_groups_kernel for every blockwise unit length: round 5)"
+  MI355Q_OCTAV_UNIT_LANES=0 timeout 200 python tools/octav_block_bench.py 2>&1 | grep -v amdgpu.ids | head -4
   timeout 200 python tools/octav_block_bench.py 2>&1 | grep -v amdgpu.ids
   echo "# tools/api_resident_bench.py (get_tensor_quant_params on HBM-resident weights; batched = inside requant_queue.batching())"
   timeout 300 python tools/api_resident_bench.py 2>&1 | grep workload
