@@ -9,6 +9,10 @@ profiles/r05_xtx_barrier_ab.txt):
   * a read-modify-write epilogue that waits for every element's own round trip: no load -> s_waitcnt vmcnt(0) -> store chain
     in the fast kernels;
   * __syncthreads() in front of a ring of LDS-DMA buffers: the ring kernels' s_barrier is not preceded by s_waitcnt vmcnt(0).
+Round 6, the lane-per-unit OCTAV kernel (profiles/r06_octav_unit_lanes.txt):
+  * the unit in register tuples read with a uniform index: no scratch in any instantiation, s_set_gpr_idx_on present;
+  * the fast step without the scalar file: its loop holds no v_cmp / v_cndmask and no v_pk_add_f32 (the two masks' additions
+    paired needed the unit twice, as register pairs).
 """
 import concurrent.futures
 import os
@@ -41,7 +45,7 @@ def _assembly(name: str, out_dir: str) -> str:
 @pytest.fixture(scope="module")
 def asm(tmp_path_factory):
   out_dir = str(tmp_path_factory.mktemp("isa"))
-  names = ("gemm", "xtx_bf16x3", "xtx_f16x2")
+  names = ("gemm", "xtx_bf16x3", "xtx_f16x2", "reduce_exact")
   with concurrent.futures.ThreadPoolExecutor(len(names)) as pool:
     return dict(zip(names, pool.map(lambda n: _assembly(n, out_dir), names)))
 
@@ -129,3 +133,30 @@ def test_ring_kernels_keep_their_pieces_in_flight_across_the_barrier(asm):
   assert len(rings) == 2
   for name, body in rings.items():
     assert all("vmcnt(0)" not in w for w in _waits_in_front_of_barriers(body)), name
+
+
+def test_octav_unit_lanes_kernel_keeps_its_unit_in_registers_and_its_fast_step_off_the_scalar_file(asm):
+  kernels = {n: b for n, b in _kernels(asm["reduce_exact"]).items() if "octav_unit_lanes_kernel" in n}
+  assert len(kernels) == 4                       # units of 32 / 64 / 128 / 256
+  for name, body in kernels.items():
+    wide = "ILi256E" in name      # (sixteen tuples + the walks' state: a few values of the set-up code go to scratch; never the walks)
+    assert _resource(body, "ScratchSize") <= (256 if wide else 0), name
+    assert wide or ("scratch_store" not in body and "scratch_load" not in body), name
+    assert "s_set_gpr_idx_on" in body, name
+    # the fast walk: the loops whose bodies smear four pairs of sign bits (eight v_ashrrev_i32 by 31 between a label and its
+    # backward branch) and nothing else of the long-aware or listing steps (no ds_write, no exec masking)
+    lines = body.split("\n")
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB[\w]+):", l)] if m}
+    fast_loops = 0
+    for i, l in enumerate(lines):
+      m = re.search(r"s_cbranch_scc[01] (\.LBB[\w]+)", l)
+      if not m or labels.get(m.group(1), i) >= i:
+        continue
+      loop = lines[labels[m.group(1)]:i]
+      text = "\n".join(loop)
+      if text.count("v_ashrrev_i32") == 8 and "ds_write" not in text and "s_and_saveexec" not in text:
+        fast_loops += 1
+        assert "v_cmp_" not in text and "v_cndmask" not in text, (name, "a compare / select in the fast step")
+        assert "v_pk_add_f32" not in text, (name, "paired additions in the fast step")
+        assert "scratch_" not in text, (name, "scratch traffic in the fast step")
+    assert fast_loops >= int(re.search(r"kernelILi(\d+)E", name).group(1)) // 16, (name, fast_loops)
