@@ -163,3 +163,19 @@ def test_a_million_mixed_units_against_the_groups_kernel(g, unit_len):
   assert iters == old_iters
   same = got.view(np.uint32) == old.view(np.uint32)
   assert same.all(), (int((~same).sum()), np.flatnonzero(~same)[:8], kind[np.flatnonzero(~same)[:8]])
+
+
+@pytest.mark.parametrize("size", [32, 64, 128, 256])
+@pytest.mark.parametrize("max_iter", [1, 3, 10, 25])
+def test_one_unit_tensorwise_and_other_iteration_counts(g, size, max_iter):
+  """A whole tensor of 32 .. 256 elements as ONE unit (TENSORWISE: the reference's count is a Python int there, s * N stays
+  float32 -- ref octav.py:55-61) and iteration limits other than the recipe's ten."""
+  torch, ops = g["torch"], g["ops"]
+  rng = np.random.default_rng(size + max_iter)
+  w = (rng.standard_normal(size) * 0.7).astype(np.float32)
+  for early in (True, False):
+    ref, ref_iters = O.octav_clip(w, 4, None, max_iter, 3.0, early_stop=early, return_iters=True)
+    clip, iters = ops.octav_clip(torch.from_numpy(w).cuda(), 1, size, 4, max_iter, 3.0, early, False)
+    torch.cuda.synchronize()
+    assert np.array_equal(clip.cpu().numpy().view(np.uint32), np.asarray(ref, np.float32).reshape(-1).view(np.uint32))
+    assert int(iters.cpu().item()) == ref_iters
