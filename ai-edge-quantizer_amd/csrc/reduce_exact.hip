@@ -374,7 +374,14 @@ __global__ void octav_kernel(OctavArgs a) {
 //           addition per four cycles however the operands arrive); the lists are read with
 //           broadcast 16-byte LDS loads, 32 entries ahead of the additions.
 // The row is stored with one float of padding per 16 (thread-owned pieces start on distinct banks).
-constexpr int kRowsMinLen = 1024, kRowsMaxLen = 2 * kChunk;   // up to 4 pieces per thread
+// (round 6: from 129 elements on -- 1024 until then. Units of 384 / 640 / 768 / 896 elements, the rows of small transformers'
+// projections, took the one-wave-per-unit kernel: 0.63 ms per 2^24 elements against 0.37 / 0.26 / 0.23 / 0.21 ms here; 512
+// took the groups kernel: 0.32 against 0.29 ms; 144 / 200 / 250: 0.78 / 0.72 / 0.66 against 0.75 / 0.58 / 0.48 ms. Below 128
+// the one-wave kernel is the faster of the two; 32 / 64 / 128 / 256 elements are a lane's: octav_unit_lanes_kernel.)
+#ifndef MI355Q_ROWS_MIN_LEN
+#define MI355Q_ROWS_MIN_LEN 129
+#endif
+constexpr int kRowsMinLen = MI355Q_ROWS_MIN_LEN, kRowsMaxLen = 2 * kChunk;   // up to 4 pieces per thread
 constexpr int kPiece = 16;
 
 __device__ __forceinline__ int pidx(int e) { return e + (e >> 4); }
