@@ -1404,7 +1404,12 @@ extern "C" int32_t mi355q_oscar_clip_bounds_f32(const float* w, const double* s,
   const uint8_t* todo = nullptr;
   const char* prefix_env = getenv("MI355Q_OSCAR_PREFIX");          // (read per call: the tests switch routes in one process)
   const bool prefix_on = !(prefix_env && prefix_env[0] == '0');
-  if (prefix_on && g == d && n > 0 && g >= 1024 && g <= 16384 && qmax >= 7) {
+  // (rows of 384 .. 1023 columns since late round 6: 2^24 elements in rows of 768: 0.68 -> 0.20 ms, of 384: 0.53 -> 0.37 ms;
+  // at 256 columns the prefix -- 128 elements, half the row -- costs more than the full sort)
+#ifndef MI355Q_OSCAR_PREFIX_MIN
+#define MI355Q_OSCAR_PREFIX_MIN 384
+#endif
+  if (prefix_on && g == d && n > 0 && g >= MI355Q_OSCAR_PREFIX_MIN && g <= 16384 && qmax >= 7) {
     uint8_t* flags = static_cast<uint8_t*>(workspace) + 4 * align256(static_cast<size_t>(total) * sizeof(double));
     // elements asked for: a sixteenth of the row within [128, 256] for the one-wave form (it sorts at most 512), a
     // thirty-second within [256, 512] beyond (at most 1024 sorted)

@@ -766,7 +766,7 @@ def oscar_clip_bounds(w: torch.Tensor, s: torch.Tensor, masses: torch.Tensor, g:
       rt.ptr(w), rt.ptr(s), rt.ptr(masses), n, d, g, rt.ptr(u), rt.ptr(noise), int(qmax),
       int(blockwise_scale), rt.ptr(bounds), rt.ptr(scale), rt.ptr(ws), need.value, rt.stream_ptr()))
   if want_rows_left:
-    took_prefix = (g == d and 1024 <= g <= 16384 and qmax >= 7 and os.environ.get("MI355Q_OSCAR_PREFIX", "")[:1] != "0")
+    took_prefix = (g == d and 384 <= g <= 16384 and qmax >= 7 and os.environ.get("MI355Q_OSCAR_PREFIX", "")[:1] != "0")
     slab = (n * d * 8 + 255) // 256 * 256
     return bounds, scale, (ws[4 * slab:4 * slab + n * d // g].clone() if took_prefix else None)
   return bounds, scale
