@@ -907,7 +907,10 @@ __global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict
 
 int xtx_splits(int64_t d, int64_t kt) {
   const int64_t tiles = (d / kTile) * (d / kTile + 1) / 2;
-  if (tiles >= 512) return 1;
+#ifndef MI355Q_XTX_SPLIT_BELOW
+#define MI355Q_XTX_SPLIT_BELOW 512
+#endif
+  if (tiles >= MI355Q_XTX_SPLIT_BELOW) return 1;
   int64_t s = (768 + tiles - 1) / tiles;
   if (s > 16) s = 16;
   if (s > kt / 64) s = kt / 64;        // >= 1024 tokens per split
