@@ -1482,17 +1482,21 @@ __device__ __forceinline__ void walk_unit_long(LanePair& s, const UnitRegs& r, f
 
 // ---- late iterations on a few candidates. Once an iterate grows, what it selects is a subset of what the previous one
 // selected; the last iterations of a unit select a handful of elements and would still walk all of it. So when every live
-// unit of the wave selected at most kCand elements and its iterate grew, the next fast walk also LISTS what it selects
+// unit of the wave selected at most cand_capacity<LEN>() elements and its iterate grew, the next fast walk also LISTS what it selects
 // (value and position per lane, in LDS: slot k of lane l at k * 64 + l), and the iterations after that walk the lists:
 // the same step with one addition -- a gap between two candidates' positions ends the runs in front of it, exactly what
 // walking over the unselected elements in between does (acc + seq, then seq = +0.0). An iterate below the one the list was
 // made for (never seen on weights; the iteration does not forbid it) sends the wave back to full walks.
-constexpr int kCand = 16;          // (+ one slot that takes the unconditional store of a step that lists nothing)
+// capacity: 16 / 24 / 32 / 32 entries per lane for units of 32 / 64 / 128 / 256 (+ one slot that takes the unconditional store of a
+// step that lists nothing). Measured at 4096 x 4096 (us per call): units of 128: 16 -> 107.7, 24 -> 93.4, 32 -> 91.1; of 64: 99.6 / 97.2 / 98.2;
+// of 32: 81.5 / 95.2 / 111.5 (longer lists are walked in full by every later iteration).
+template <int LEN>
+constexpr int cand_capacity() { return LEN <= 32 ? 16 : (LEN <= 64 ? 24 : 32); }
 constexpr int kCandNoPos = -4;     // position of an empty slot: never adjacent to anything
 
 struct CandList {
-  float* v;      // [kCand + 1][64]
-  int* pos;      // [kCand + 1][64]
+  float* v;      // [capacity + 1][64]
+  int* pos;      // [capacity + 1][64]
 };
 
 __device__ __forceinline__ void lane_step_pair_collect(LanePair& s, float v, float g, const CandList& c, int lane,
@@ -1619,6 +1623,7 @@ __global__ __launch_bounds__(kWave, LEN >= 256 ? 1 : (LEN >= 128 ? 2 : (LEN >= 6
   constexpr int kStage = LEN < 64 ? LEN : 64;       // positions per trip through LDS
   constexpr int kStride = kStage + 1;               // floats per unit in LDS: lane l reads bank (l + p) % 32
   constexpr int kTuples = LEN / 16;
+  constexpr int kCand = cand_capacity<LEN>();
   constexpr int kLdsFloats = kWave * kStride > 2 * (kCand + 1) * kWave ? kWave * kStride : 2 * (kCand + 1) * kWave;
   __shared__ float lds[kLdsFloats];    // the transposition's staging area, then the candidate lists
   const int lane = threadIdx.x;
@@ -2374,6 +2379,21 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
   double p4 = 1.0;
   for (int i = 0; i < bits; ++i) p4 *= 0.25;
   const float s = static_cast<float>(p4 / static_cast<double>(exponent_divisor));
+  if ((unit_len == 32 || unit_len == 64 || unit_len == 128 || unit_len == 256) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (units + kWave - 1) / kWave <= 0x7FFFFFFFLL && octav_unit_lanes_on() && !getenv("MI355Q_OCTAV_WAVE_KERNEL")) {
+    // blockwise units: a lane per unit, the unit in registers (octav_unit_lanes_kernel)
+    OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close};
+    const dim3 grid(static_cast<unsigned>((units + kWave - 1) / kWave));
+    if (unit_len == 32) hipLaunchKernelGGL(octav_unit_lanes_kernel<32>, grid, dim3(kWave), 0, st, a);
+    else if (unit_len == 64) hipLaunchKernelGGL(octav_unit_lanes_kernel<64>, grid, dim3(kWave), 0, st, a);
+    else if (unit_len == 128) hipLaunchKernelGGL(octav_unit_lanes_kernel<128>, grid, dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL(octav_unit_lanes_kernel<256>, grid, dim3(kWave), 0, st, a);
+    MI355Q_CHECK_LAUNCH("octav unit lanes launch");
+    hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
+                       hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
+    MI355Q_CHECK_LAUNCH("octav pick launch");
+    return MI355Q_OK;
+  }
   if (unit_len >= kRowsMinLen && unit_len <= kRowsMaxLen && !getenv("MI355Q_OCTAV_WAVE_KERNEL")) {
     // rows of a weight matrix: lanes own 64-element batches of the LDS-resident row
     // late iterations on a one-wave tail kernel (octav_tail_kernel) when the caller's workspace has room for
@@ -2414,21 +2434,6 @@ extern "C" int32_t mi355q_octav_clip_f32(const float* x, int64_t units, int64_t 
       hipLaunchKernelGGL(octav_tail_kernel, dim3(static_cast<unsigned>(units)), dim3(kWave), static_cast<size_t>(a.tail_cap) * 12, st, a);
       MI355Q_CHECK_LAUNCH("octav tail launch");
     }
-    hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
-                       hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
-    MI355Q_CHECK_LAUNCH("octav pick launch");
-    return MI355Q_OK;
-  }
-  if ((unit_len == 32 || unit_len == 64 || unit_len == 128 || unit_len == 256) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-      (units + kWave - 1) / kWave <= 0x7FFFFFFFLL && octav_unit_lanes_on()) {
-    // blockwise units: a lane per unit, the unit in registers (octav_unit_lanes_kernel)
-    OctavArgs a{x, units, static_cast<int>(unit_len), 0, max_iter, count_is_f64, s, hist, not_close};
-    const dim3 grid(static_cast<unsigned>((units + kWave - 1) / kWave));
-    if (unit_len == 32) hipLaunchKernelGGL(octav_unit_lanes_kernel<32>, grid, dim3(kWave), 0, st, a);
-    else if (unit_len == 64) hipLaunchKernelGGL(octav_unit_lanes_kernel<64>, grid, dim3(kWave), 0, st, a);
-    else if (unit_len == 128) hipLaunchKernelGGL(octav_unit_lanes_kernel<128>, grid, dim3(kWave), 0, st, a);
-    else hipLaunchKernelGGL(octav_unit_lanes_kernel<256>, grid, dim3(kWave), 0, st, a);
-    MI355Q_CHECK_LAUNCH("octav unit lanes launch");
     hipLaunchKernelGGL(octav_pick_kernel, dim3(static_cast<unsigned>((units + 255) / 256)), dim3(256), 0, st,
                        hist, not_close, units, max_iter, early_stop, clip_out, iters_out);
     MI355Q_CHECK_LAUNCH("octav pick launch");

@@ -1,6 +1,6 @@
 """OCTAV on blockwise units of 32 / 64 / 128 / 256 elements: the lane-per-unit kernel (csrc/reduce_exact.hip,
 octav_unit_lanes_kernel) against the oracle's NumPy iteration (ref octav.py:30-112) and against the kernel it replaced
-(MI355Q_OCTAV_UNIT_LANES=0: octav_groups_kernel / octav_kernel), bit for bit: clipping constants AND iteration counts.
+(MI355Q_OCTAV_UNIT_LANES=0: octav_groups_kernel; the rows kernel for units of 256), bit for bit: clipping constants AND iteration counts.
 
 The inputs aim at what distinguishes the two walks of the new kernel: runs of selected elements of exactly 7 / 8 / 9 / 15 /
 16 / 17 / whole-unit length (NumPy's left-to-right loop below 8 elements, eight strided accumulators + tail from 8 on),
