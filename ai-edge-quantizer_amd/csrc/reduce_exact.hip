@@ -1265,6 +1265,17 @@ __device__ __forceinline__ float unit_leaf(const float* a, int n) {   // NumPy's
 #pragma unroll
   for (int k = 0; k < 8; ++k) r[k] = a[k];
   const int full = n & ~7;
+  if (full == 8) {
+    // runs of 8 .. 15 (nearly all there are): the up to seven elements behind the accumulators are asked for together with
+    // them -- one round trip to memory, not one per element of the tail
+    float t[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) t[k] = 8 + k < n ? a[8 + k] : 0.f;
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int k = 0; k < 7; ++k) res = 8 + k < n ? res + t[k] : res;
+    return res;
+  }
   for (int i = 8; i < full; i += 8) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) r[k] = r[k] + a[i + k];
@@ -1432,9 +1443,13 @@ __device__ __forceinline__ void lane_step_pair_long(LanePair& s, float v, float 
   float add_n = __uint_as_float(__float_as_uint(s.seq_n) & nn_);
   const unsigned ends_long = s.len2 & 0xFFF8FFF8u & both;       // a half that holds a length >= 8 and is not selected here
   if (ends_long != 0) {
-    const int lp = static_cast<int>(s.len2 & 0xFFFFu), ln = static_cast<int>(s.len2 >> 16);
-    if (ends_long & 0xFFFFu) add_p = unit_long_run<WIDE>(at - lp, lp);
-    if (ends_long >> 16) add_n = unit_long_run<WIDE>(at - ln, ln);
+    // (at most one of the two masks ends a long run at a given element: both would need the element before it in both
+    // masks, which only a zero at guess 0 is -- and then this element, being finite, is in one of them. One site of the leaf.)
+    const bool pos = (ends_long & 0xFFFFu) != 0;
+    const int len = static_cast<int>(pos ? s.len2 & 0xFFFFu : s.len2 >> 16);
+    const float sum = unit_long_run<WIDE>(at - len, len);
+    add_p = pos ? sum : add_p;
+    add_n = pos ? add_n : sum;
   }
   s.acc_p = add_f32(s.acc_p, add_p);
   s.acc_n = add_f32(s.acc_n, add_n);
