@@ -1610,27 +1610,46 @@ __device__ __forceinline__ void tuples_from_lds(UnitRegs& r, const float* row) {
   }
 }
 
-// Stage H of the load: positions H * STAGE .. (H + 1) * STAGE - 1 of the wave's 64 units, whole lines from HBM (16 lanes
-// per 256-byte stretch of a unit) turned through LDS so that lane l ends up with unit l.
-template <int LEN, int STAGE, int STRIDE, int H>
-__device__ __forceinline__ void load_unit_stages(UnitRegs& xr, const float* base, long long wave_floats, float* lds, int lane) {
-  if constexpr (H < LEN / STAGE) {
-    constexpr int kPer = STAGE / 4;              // float4 per unit and stage
+// The load: positions H * STAGE .. (H + 1) * STAGE - 1 of the wave's 64 units per stage, whole lines from HBM (16 lanes per
+// 256-byte stretch of a unit) turned through LDS so that lane l ends up with unit l. A stage's lines are asked for BEFORE the stage
+// in front of it is turned (its trip through LDS then hides under their round trip to memory).
+template <int LEN, int STAGE>
+struct StageLines {
+  float4 v[STAGE / 4];
+};
+
+template <int LEN, int STAGE, int H>
+__device__ __forceinline__ StageLines<LEN, STAGE> ask_unit_stage(const float* base, long long wave_floats, int lane) {
+  constexpr int kPer = STAGE / 4;              // float4 per unit and stage
+  StageLines<LEN, STAGE> out;
 #pragma unroll
-    for (int q = 0; q < STAGE / 4; ++q) {        // 64 units x kPer float4 = kPer instructions of 64 lanes
-      const int f = q * kWave + lane;
-      const int uu = f / kPer, p4 = f % kPer;
-      const long long e = static_cast<long long>(uu) * LEN + H * STAGE + p4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < wave_floats) v = *reinterpret_cast<const float4*>(base + e);
-      float* d = lds + uu * STRIDE + p4 * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    __syncthreads();
-    tuples_from_lds<H * STAGE / 16, STAGE / 16>(xr, lds + lane * STRIDE);
-    __syncthreads();
-    load_unit_stages<LEN, STAGE, STRIDE, H + 1>(xr, base, wave_floats, lds, lane);
+  for (int q = 0; q < STAGE / 4; ++q) {        // 64 units x kPer float4 = kPer instructions of 64 lanes
+    const int f = q * kWave + lane;
+    const int uu = f / kPer, p4 = f % kPer;
+    const long long e = static_cast<long long>(uu) * LEN + H * STAGE + p4 * 4;
+    out.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < wave_floats) out.v[q] = *reinterpret_cast<const float4*>(base + e);
   }
+  return out;
+}
+
+template <int LEN, int STAGE, int STRIDE, int H>
+__device__ __forceinline__ void load_unit_stages(UnitRegs& xr, const float* base, long long wave_floats, float* lds, int lane,
+                                                 const StageLines<LEN, STAGE>& mine) {
+  constexpr int kPer = STAGE / 4;
+  StageLines<LEN, STAGE> next;
+  if constexpr (H + 1 < LEN / STAGE) next = ask_unit_stage<LEN, STAGE, H + 1>(base, wave_floats, lane);
+#pragma unroll
+  for (int q = 0; q < STAGE / 4; ++q) {
+    const int f = q * kWave + lane;
+    const int uu = f / kPer, p4 = f % kPer;
+    float* d = lds + uu * STRIDE + p4 * 4;
+    d[0] = mine.v[q].x; d[1] = mine.v[q].y; d[2] = mine.v[q].z; d[3] = mine.v[q].w;
+  }
+  __syncthreads();
+  tuples_from_lds<H * STAGE / 16, STAGE / 16>(xr, lds + lane * STRIDE);
+  __syncthreads();
+  if constexpr (H + 1 < LEN / STAGE) load_unit_stages<LEN, STAGE, STRIDE, H + 1>(xr, base, wave_floats, lds, lane, next);
 }
 
 template <int LEN>
@@ -1648,7 +1667,11 @@ __global__ __launch_bounds__(kWave, LEN >= 256 ? 1 : (LEN >= 128 ? 2 : (LEN >= 6
   const float* u = a.x + (live ? unit : 0) * LEN;
   UnitRegs xr;
   // (a lane reading its own 16-byte pieces instead cost 25 us at 4096 x 4096: 64 lines per load instruction)
-  load_unit_stages<LEN, kStage, kStride, 0>(xr, a.x + unit0 * LEN, (a.units - unit0 < kWave ? a.units - unit0 : kWave) * LEN, lds, lane);
+  {
+    const float* base = a.x + unit0 * LEN;
+    const long long wave_floats = (a.units - unit0 < kWave ? a.units - unit0 : kWave) * LEN;
+    load_unit_stages<LEN, kStage, kStride, 0>(xr, base, wave_floats, lds, lane, ask_unit_stage<LEN, kStage, 0>(base, wave_floats, lane));
+  }
   float amax = 0.f;     // NaN is never selected and never the maximum
   float poison = 0.f;   // x * 0 summed: NaN as soon as the unit holds a NaN or an infinity (those units: the exact walk only)
   each_slot<0, LEN>(xr, [&](float v) {
