@@ -1244,22 +1244,27 @@ __global__ __launch_bounds__(kGroupThreads, 2) void octav_groups_kernel(OctavArg
   if (tid < upg) publish_moving(a.moving, moved);
 }
 
-// ---- short units on LANES (blockwise granularity: 32 / 64 / 128 elements per unit) ----
+// ---- short units on LANES (the four blockwise granularities: 32 / 64 / 128 / 256 elements per unit) ----
 //
 // octav_groups_kernel above treats a stretch of 4096 elements like a row: pieces of 16 on threads, run sums listed in
 // LDS through a workgroup prefix sum, chains on a few lanes, two barriers per iteration (~15 vector instructions per
 // element and mask, 0.039 of one read at 4096 x 4096 in blocks of 128). A unit this short needs none of that: LANE l of
-// a wave owns unit 64 b + l, keeps its elements in REGISTERS for all iterations and simply walks them left to right
-// as NumPy's masked reduction does -- nothing is exchanged between lanes, nothing is listed, there is no barrier.
-//   fast walk (fully unrolled over the unit: registers are not indexable), valid while every run is shorter than 8:
-//       seq = 0 + a0 + a1 + ...  is NumPy's n < 8 loop, and acc = acc + seq where the run ends. Branch-free: every step
-//       adds (selected ? +0.0 : seq) to acc -- adding +0.0 is exact, a total that started at +0.0 is never -0.0 -- and
-//       sets seq = selected ? seq + x : +0.0, both masks side by side, selections as sign bits (lane_step_pair);
-//   exact walk for the lanes whose fast walk saw a run reach 8, and for guess 0 / special values (the second iterate of
-//       a weight tensor, guess 0, is where runs of 8+ same-signed elements occur: half of every mask selected): a
-//       rolled loop over the unit in memory (read a moment ago), compares, the same steps plus NumPy's eight-accumulator
-//       leaf where a run of 8 .. 128 ends (a unit is at most one leaf long).
-// A lane that reached its fixed point is masked off; the wave leaves when all have. Bit-identical to octav_kernel.
+// a wave owns unit 64 b + l, keeps its elements in REGISTERS for all iterations (16-register tuples read with a
+// wave-uniform index, so the walks are loops) and walks them left to right as NumPy's masked reduction does -- nothing is
+// exchanged between lanes, no run sum is listed, there is no barrier. An iteration is one of
+//   the fast step (lane_step_pair), valid while every run is shorter than 8: seq = 0 + a0 + a1 + ... is NumPy's n < 8
+//       loop, and acc = acc + seq where the run ends. Branch-free: every step adds (selected ? +0.0 : seq) to acc --
+//       adding +0.0 is exact, a total that started at +0.0 is never -0.0 -- and sets seq = selected ? seq + x : +0.0, both
+//       masks side by side, selections as sign bits of x - g and (-x) - g (no compare, no scalar register);
+//   the long-aware step (lane_step_pair_long) wherever a run of 8+ is met -- the tuple in which a run reaches 8 is walked
+//       again from the state it began with (walk_unit) -- and throughout at guess 0, the second iterate of a weight
+//       tensor, where half of every mask is selected: the same step, and where a run of 8+ ENDS, NumPy's eight-accumulator
+//       leaf over that run (from memory; only the lanes concerned) takes the place of seq;
+//   the step by compares (lane_step_exact) for units that hold a NaN or an infinity and for iterates that are not finite;
+//   and, once every live unit of the wave selects a handful of elements with growing iterates, a walk over per-lane
+//       candidate lists in LDS (walk_candidates) instead of the unit.
+// A lane that reached its fixed point is masked off; the wave leaves when all have. Bit-identical to octav_kernel /
+// octav_groups_kernel (tests/test_gpu_octav_unit_lanes.py); how it got here, measured: profiles/r06_octav_unit_lanes.txt.
 __device__ __forceinline__ float unit_leaf(const float* a, int n) {   // NumPy's leaf, 8 <= n <= 128
   float r[8];
 #pragma unroll
