@@ -837,7 +837,11 @@ def main():
     del b4
 
   if args.extras and rank == 0 and world == 1:
-    extras.update(more_extras(torch, ops, gen, xs))
+    try:
+      extras.update(more_extras(torch, ops, gen, xs))
+    except Exception as e:  # noqa: BLE001 - an extra must never cost the headline
+      import traceback
+      extras["more_extras_error"] = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:]}
     try:
       extras.update(round6_extras(torch, ops, gen, xs))
     except Exception as e:  # noqa: BLE001 - an extra must never cost the headline
